@@ -1,0 +1,199 @@
+"""ctypes bindings for the TEST-ONLY CPU oracle (and, when built, the reference kernel).
+
+TEST INFRASTRUCTURE: importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (sedef_amd) never imports this module.
+
+  Oracle()      -> oracle/liboracle_extz2.so   (our scalar restatement, extz2_oracle.c)
+  Reference()   -> oracle/_ref/libksw2_ref.so  (reference extern/ksw2_extz2_sse.cc compiled as is;
+                                                present only where `make -C oracle ref` was run)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NEG_INF = -0x40000000
+
+# SEDEF's scoring (reference: src/align.cc:41-44, src/globals.cc:25-28)
+def sedef_mat(match=5, mismatch=-4):
+    a, b = match, mismatch if mismatch < 0 else -mismatch
+    return np.array([a, b, b, b, 0, b, a, b, b, 0, b, b, a, b, 0, b, b, b, a, 0, 0, 0, 0, 0, 0],
+                    dtype=np.int8)
+
+
+class _OracleResult(C.Structure):
+    _fields_ = [("max", C.c_uint32), ("zdropped", C.c_int32), ("max_q", C.c_int32),
+                ("max_t", C.c_int32), ("mqe", C.c_int32), ("mqe_t", C.c_int32),
+                ("mte", C.c_int32), ("mte_q", C.c_int32), ("score", C.c_int32),
+                ("n_cigar", C.c_int64), ("cigar", C.POINTER(C.c_uint32))]
+
+
+class _KswExtz(C.Structure):  # ksw_extz_t, reference extern/ksw2.h:22-30
+    _fields_ = [("max_zd", C.c_uint32), ("max_q", C.c_int), ("max_t", C.c_int),
+                ("mqe", C.c_int), ("mqe_t", C.c_int), ("mte", C.c_int), ("mte_q", C.c_int),
+                ("score", C.c_int), ("cigar", C.POINTER(C.c_uint32)),
+                ("m_cigar", C.c_int64), ("n_cigar", C.c_int64)]
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def build_oracle(force=False):
+    so = os.path.join(_HERE, "liboracle_extz2.so")
+    src = os.path.join(_HERE, "extz2_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle_extz2.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def build_reference():
+    """Compile the reference kernel from /root/reference if that checkout exists. Returns path or None."""
+    so = os.path.join(_HERE, "_ref", "libksw2_ref.so")
+    if os.path.exists(so):
+        return so
+    if os.path.exists("/root/reference/extern/ksw2_extz2_sse.cc"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+        return so
+    return None
+
+
+def _as_dict(max_, zd, r, n_cigar, cigar_ptr):
+    cig = np.ctypeslib.as_array(cigar_ptr, shape=(n_cigar,)).copy() if n_cigar else \
+        np.zeros(0, np.uint32)
+    return dict(max=int(max_), zdropped=int(zd), max_q=r.max_q, max_t=r.max_t, mqe=r.mqe,
+                mqe_t=r.mqe_t, mte=r.mte, mte_q=r.mte_q, score=r.score, cigar=cig)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        L.sdfo_extz2.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8),
+                                 C.c_int, C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.POINTER(_OracleResult)]
+        L.sdfo_extz2.restype = None
+        L.sdfo_band_cells.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.sdfo_band_cells.restype = C.c_int64
+        L.sdfo_extz2_batch.restype = C.c_int64
+        L.sdfo_extz2_batch.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.POINTER(C.c_int8), C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.sdfo_cigar_counts.restype = None
+        L.sdfo_cigar_counts.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+
+    def extz2(self, query, target, mat=None, m=5, gapo=40, gape=1, w=-1, zdrop=-1, flag=0):
+        mat = sedef_mat() if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+        q, qp = _u8(query)
+        t, tp = _u8(target)
+        r = _OracleResult()
+        self.lib.sdfo_extz2(len(q), qp, len(t), tp, m, mat.ctypes.data_as(C.POINTER(C.c_int8)),
+                            gapo, gape, w, zdrop, flag, C.byref(r))
+        d = _as_dict(r.max, r.zdropped, r, r.n_cigar, r.cigar)
+        if r.n_cigar or r.cigar:
+            _libc.free(C.cast(r.cigar, C.c_void_p))
+        return d
+
+    def band_cells(self, qlen, tlen, w):
+        return int(self.lib.sdfo_band_cells(qlen, tlen, w))
+
+    def counts(self, cigar, query, target):
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        q, _ = _u8(query)
+        t, _ = _u8(target)
+        o = [C.c_int32() for _ in range(4)]
+        self.lib.sdfo_cigar_counts(cigar.ctypes.data, len(cigar), q.ctypes.data, t.ctypes.data,
+                                   *[C.byref(x) for x in o])
+        return dict(matches=o[0].value, mismatches=o[1].value, gaps=o[2].value,
+                    gap_bases=o[3].value)
+
+    def batch(self, pool, q_off, qlen, t_off, tlen, mat=None, m=5, gapo=40, gape=1, w=-1,
+              zdrop=-1, flag=0):
+        mat = sedef_mat() if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.int64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.int64)
+        qlen = np.ascontiguousarray(qlen, dtype=np.int32)
+        tlen = np.ascontiguousarray(tlen, dtype=np.int32)
+        n = len(qlen)
+        score = np.zeros(n, np.int32)
+        h = np.zeros(n, np.uint64)
+        cells = self.lib.sdfo_extz2_batch(n, pool.ctypes.data, q_off.ctypes.data, qlen.ctypes.data,
+                                          t_off.ctypes.data, tlen.ctypes.data, m,
+                                          mat.ctypes.data_as(C.POINTER(C.c_int8)), gapo, gape, w,
+                                          zdrop, flag, score.ctypes.data, h.ctypes.data)
+        return int(cells), score, h
+
+
+class Reference:
+    """The reference's own ksw_extz2_sse (extern/ksw2.h:50), compiled unmodified."""
+
+    def __init__(self):
+        so = build_reference()
+        if so is None:
+            raise FileNotFoundError("oracle/_ref/libksw2_ref.so not built and /root/reference absent")
+        self.lib = C.CDLL(so)
+        f = self.lib.ksw_extz2_sse
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8),
+                      C.c_int8, C.POINTER(C.c_int8), C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int,
+                      C.POINTER(_KswExtz)]
+
+    @staticmethod
+    def available():
+        return build_reference() is not None
+
+    def extz2(self, query, target, mat=None, m=5, gapo=40, gape=1, w=-1, zdrop=-1, flag=0):
+        mat = sedef_mat() if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+        q, qp = _u8(query)
+        t, tp = _u8(target)
+        r = _KswExtz()
+        self.lib.ksw_extz2_sse(None, len(q), qp, len(t), tp, m,
+                               mat.ctypes.data_as(C.POINTER(C.c_int8)), gapo, gape, w, zdrop, flag,
+                               C.byref(r))
+        d = _as_dict(r.max_zd & 0x7fffffff, r.max_zd >> 31, r, r.n_cigar, r.cigar)
+        if r.cigar:
+            _libc.free(C.cast(r.cigar, C.c_void_p))
+        return d
+
+
+def cigar_to_str(cigar):
+    return "".join("%d%s" % (c >> 4, "MID"[c & 0xf]) for c in np.asarray(cigar).tolist())
+
+
+# ---- deterministic synthetic inputs (BASELINE config 2 mutation model: 6 % substitution draws,
+#      2 % deletions, 2 % insertions; mirrors the reference's simulation idea, python/simulations.py:53-75)
+def random_codes(rng, n, n_frac=0.0):
+    s = rng.integers(0, 4, size=n, dtype=np.uint8)
+    if n_frac > 0:
+        s[rng.random(n) < n_frac] = 4
+    return s
+
+
+def mutate(rng, s, sub=0.06, dele=0.02, ins=0.02):
+    out = []
+    r = rng.random(len(s))
+    for k, c in enumerate(s.tolist()):
+        x = r[k]
+        if x < sub:
+            out.append(int(rng.integers(0, 4)))
+        elif x < sub + dele:
+            continue
+        elif x < sub + dele + ins:
+            out.append(c)
+            out.append(int(rng.integers(0, 4)))
+        else:
+            out.append(c)
+    if not out:
+        out = [0]
+    return np.array(out, dtype=np.uint8)
