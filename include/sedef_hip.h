@@ -1,0 +1,164 @@
+/*
+ * sedef_hip.h -- C ABI of the MI355X-native `sedef align` DP hot path.
+ *
+ * This is the drop-in boundary.  The reference has exactly one native interface on this path:
+ *
+ *     void ksw_extz2_sse(void *km, int qlen, const uint8_t *query, int tlen,
+ *                        const uint8_t *target, int8_t m, const int8_t *mat, int8_t q, int8_t e,
+ *                        int w, int zdrop, int flag, ksw_extz_t *ez);
+ *                                              (reference: extern/ksw2.h:50, result ksw2.h:22-30)
+ *
+ * called once per DP task from align_helper (reference: src/align.cc:39-68).  A GPU needs the
+ * tasks in batches, so the boundary is exported twice:
+ *
+ *   sdf_ksw_extz2()         same signature and result struct as ksw_extz2_sse -> 1-task drop-in;
+ *   sdf_extz2_batch()       n tasks over a shared code pool; host buffers in, host buffers out;
+ *   sdf_extz2_batch_device()  the same with inputs/outputs resident in HBM (no PCIe in the call).
+ *
+ * All entry points are plain C: pointers and sizes only.  Buffers are owned by the caller.
+ * Every function that can fail returns 0 on success or a negative SDF_ERR_* code; the message
+ * is available from sdf_last_error().  There is no CPU fallback: without a usable HIP device
+ * sdf_create() fails.
+ */
+#ifndef SEDEF_HIP_H
+#define SEDEF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDF_NEG_INF (-0x40000000) /* KSW_NEG_INF, reference extern/ksw2.h:6 */
+
+/* task flag bits: numerically the reference's KSW_EZ_* (extern/ksw2.h:8-16) */
+#define SDF_FLAG_SCORE_ONLY 0x01 /* no direction matrix, no CIGAR */
+#define SDF_FLAG_RIGHT 0x02      /* right-align gaps */
+#define SDF_FLAG_GENERIC_SC 0x04 /* NOT supported on the GPU path (SEDEF never sets it) */
+#define SDF_FLAG_APPROX_MAX 0x08 /* NOT supported */
+#define SDF_FLAG_APPROX_DROP 0x10 /* NOT supported */
+#define SDF_FLAG_EXTZ_ONLY 0x40  /* traceback from the best extension cell */
+#define SDF_FLAG_REV_CIGAR 0x80  /* leave the CIGAR reversed */
+
+/* error codes */
+#define SDF_OK 0
+#define SDF_ERR_NO_DEVICE (-1)
+#define SDF_ERR_HIP (-2)
+#define SDF_ERR_UNSUPPORTED (-3) /* flag / alphabet the GPU path does not implement */
+#define SDF_ERR_INVALID (-4)
+#define SDF_ERR_CIGAR_OVERFLOW (-5) /* cigar_cap too small; *cigar_used holds the need */
+#define SDF_ERR_NOMEM (-6)
+
+/* what to compute for a batch (bit mask) */
+#define SDF_WANT_CIGAR 0x1  /* CIGAR + n_cigar + column counts */
+#define SDF_WANT_SCORE 0x2  /* score, mte, mte_q, zdropped (always produced) */
+#define SDF_WANT_EXT 0x4    /* also max, max_q, max_t, mqe, mqe_t: every ksw_extz_t field.  Needed
+                               for zdrop >= 0 and SDF_FLAG_EXTZ_ONLY; SEDEF reads none of them
+                               (reference: src/align.cc:49-66 uses ez.cigar / ez.n_cigar only). */
+#define SDF_WANT_ALL 0x7
+
+typedef struct sdf_ctx sdf_ctx;
+
+/* Scoring, as passed to ksw_extz2_sse: alphabet size m (must be 5: ACGT + wildcard), the m*m
+ * matrix of which the non-generic kernel uses mat[0] (match), mat[1] (mismatch) and the
+ * min over all entries (reference: extern/ksw2_extz2_sse.cc:66-67,77-81), gap open q, extend e. */
+typedef struct {
+  int32_t m;
+  int8_t mat[25];
+  int8_t gapo, gape;
+  int8_t pad_;
+} sdf_scoring;
+
+/* One DP task.  q_off/t_off index the sequence pool: bytes for sdf_extz2_batch (one code 0..4
+ * per byte, exactly what ksw_extz2_sse takes), 32-bit words of the packed pool for
+ * sdf_extz2_batch_device (see sdf_pack_codes). */
+typedef struct {
+  int64_t q_off, t_off;
+  int32_t qlen, tlen;
+  int32_t w;     /* band width, <0 = full (reference default, src/align.cc:86) */
+  int32_t zdrop; /* <0 = off */
+  int32_t flag;
+  int32_t pad_;
+} sdf_task;
+
+/* Per-task result record (64 B).  First nine fields mirror ksw_extz_t (extern/ksw2.h:22-30). */
+typedef struct {
+  int32_t score;
+  int32_t max, max_q, max_t;
+  int32_t mqe, mqe_t;
+  int32_t mte, mte_q;
+  int32_t zdropped;
+  int32_t n_cigar;    /* number of CIGAR words */
+  int64_t cigar_off;  /* first word in the CIGAR pool; words are len<<4|op, op 0=M 1=I 2=D */
+  /* alignment column statistics over the CIGAR (the counters of populate_nice_alignment,
+   * reference: src/align.cc:274-315, for ACGTN input): */
+  int32_t matches, mismatches, gaps, gap_bases;
+} sdf_result;
+
+/* ksw_extz_t, field-for-field (reference: extern/ksw2.h:22-30) */
+typedef struct {
+  uint32_t max : 31, zdropped : 1;
+  int max_q, max_t;
+  int mqe, mqe_t;
+  int mte, mte_q;
+  int score;
+  uint32_t *cigar; /* malloc'd by the callee, caller free()s (reference: src/align.cc:65) */
+  int64_t m_cigar, n_cigar;
+} sdf_ksw_extz_t;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int sdf_device_count(void);
+/* device: HIP ordinal.  workspace_bytes: HBM budget for direction matrices per internal
+ * sub-batch (0 = default 24 GiB, clamped to free memory).  Returns NULL on failure
+ * (sdf_last_error(NULL) has the reason). */
+sdf_ctx *sdf_create(int device, size_t workspace_bytes);
+void sdf_destroy(sdf_ctx *ctx);
+const char *sdf_last_error(const sdf_ctx *ctx);
+
+/* ---- packed sequence format --------------------------------------------------------------
+ * A sequence of len codes occupies sdf_packed_words(len) 32-bit words:
+ *   ceil(len/16) words of 2-bit codes (base b in bits 2*(b%16) of word b/16; N stored as 0)
+ *   ceil(len/32) words of N mask      (bit b%32 of word b/32 set <=> code >= 4). */
+size_t sdf_packed_words(int32_t len);
+void sdf_pack_codes(const uint8_t *codes, int32_t len, uint32_t *out);
+
+/* ---- batched DP ---------------------------------------------------------------------------
+ * Host-buffer form.  seq_pool holds byte codes; out[n]; cigar_pool[cigar_cap] words receives
+ * all CIGARs back to back in task order (out[i].cigar_off, out[i].n_cigar); *cigar_used gets
+ * the number of words written (or needed, with SDF_ERR_CIGAR_OVERFLOW). */
+int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                    const uint8_t *seq_pool, size_t pool_bytes, uint32_t want, sdf_result *out,
+                    uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+
+/* Device-resident form: d_packed_pool, d_out and d_cigar_pool are HBM pointers on ctx's device;
+ * tasks (host) carry word offsets into d_packed_pool.  Work is enqueued on `stream`
+ * (a hipStream_t, NULL = the context's own stream) and the call returns after the stream has
+ * drained (it needs *cigar_used).  */
+int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                           const uint32_t *d_packed_pool, uint32_t want, sdf_result *d_out,
+                           uint32_t *d_cigar_pool, size_t cigar_cap, size_t *cigar_used,
+                           void *stream);
+
+/* In-band DP cells of a task: the unit of the Gcell/s metric
+ * (sum over anti-diagonals of en0-st0+1, reference: extern/ksw2_extz2_sse.cc:101-114). */
+int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w);
+
+/* Timing of the last batch call, from HIP events recorded on the launch stream:
+ * which = 0 DP kernels, 1 traceback, 2 CIGAR compaction, 3 whole call (stream time). */
+float sdf_last_ms(const sdf_ctx *ctx, int which);
+/* Number of DP kernel launches in the last batch call and algorithmic bytes they moved. */
+int sdf_last_launches(const sdf_ctx *ctx);
+
+/* ---- one-task drop-in: same contract as ksw_extz2_sse (extern/ksw2.h:50).  `km` is ignored
+ * like in the reference build (no HAVE_KALLOC).  Uses a process-wide context on device 0 (or
+ * the device named by SDF_DEVICE).  On a fatal error prints to stderr and exits with 120, the
+ * reference's own failure mode (extern/ksw2.h:106). */
+void sdf_ksw_extz2(void *km, int qlen, const uint8_t *query, int tlen, const uint8_t *target,
+                   int8_t m, const int8_t *mat, int8_t q, int8_t e, int w, int zdrop, int flag,
+                   sdf_ksw_extz_t *ez);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

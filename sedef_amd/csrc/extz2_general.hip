@@ -1,0 +1,344 @@
+// General extz2 DP kernel for gfx950: any band, any length that fits LDS, every ksw_extz_t field.
+//
+// What it computes: the anti-diagonal difference-form affine-gap DP of the reference kernel
+// (reference: extern/ksw2_extz2_sse.cc:23-298) with bit-identical results, including the
+// cells the reference computes outside the logical band because it works in 16-cell blocks
+// (:115) and the scores it leaves stale there (:124-138).  To make that exact by construction
+// the per-target-position state lives in LDS in the same order the reference keeps it
+// (u|v|x|y|s|target|reversed query, zero-initialised), so every read "past the end" of one
+// array lands where it lands in the reference.
+//
+// Mapping: one workgroup (64 or 256 threads) per DP task.  An anti-diagonal's widened band is
+// cut into chunks of 4*BS cells; a thread owns 4 consecutive cells (one dword per state array).
+// Chunks are visited from high t to low t so that the (r-1, t-1) neighbour of a chunk's first
+// cell is still the previous anti-diagonal's value.  Direction bytes (1 B/cell, row stride
+// n_col*16 as in the reference) stream to HBM as one coalesced dword per thread.
+//
+// This is the correctness-first kernel and the fallback for shapes the register-resident
+// kernel (extz2_wave.hip) does not take.
+#include <hip/hip_runtime.h>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+
+struct BestCell {
+  int32_t H, r, key, t;
+};
+
+// a beats b: larger H; then earlier anti-diagonal; then the reference's in-row scan order
+__device__ __forceinline__ bool beats(const BestCell &a, const BestCell &b) {
+  if (a.H != b.H) return a.H > b.H;
+  if (a.r != b.r) return a.r < b.r;
+  return a.key < b.key;
+}
+
+__device__ __forceinline__ BestCell wave_best(BestCell c) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    BestCell o;
+    o.H = __shfl_xor(c.H, off);
+    o.r = __shfl_xor(c.r, off);
+    o.key = __shfl_xor(c.key, off);
+    o.t = __shfl_xor(c.t, off);
+    if (beats(o, c)) c = o;
+  }
+  return c;
+}
+
+template <int BS>
+__device__ __forceinline__ BestCell block_best(BestCell c, BestCell *red) {
+  c = wave_best(c);
+  if (BS > 64) {
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wv] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 1; k < BS / 64; ++k)
+        if (beats(red[k], c)) c = red[k];
+    }
+    __syncthreads();
+  }
+  return c;  // valid in thread 0
+}
+
+__device__ __forceinline__ uint32_t packed_code(const uint32_t *codes, const uint32_t *nmask, int k,
+                                                uint32_t wild) {
+  uint32_t c = (codes[k >> 4] >> ((k & 15) * 2)) & 3u;
+  uint32_t n = (nmask[k >> 5] >> (k & 31)) & 1u;
+  return n ? wild : c;
+}
+
+template <int BS>
+__global__ __launch_bounds__(BS) void extz2_general_kernel(
+    const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
+    const uint32_t *__restrict__ pool, ScoreK sc, uint8_t *__restrict__ dirbase,
+    sdf_result *__restrict__ res) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const PlanTask tk = plan[order[blockIdx.x]];
+  const int tid = threadIdx.x;
+  const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
+  const int T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
+  uint8_t *U = lds, *V = U + T16, *X = V + T16, *Y = X + T16, *S = Y + T16;
+  uint8_t *SF = S + T16, *QR = SF + T16;
+  const int arena = 6 * T16 + Q16 + 16;
+  int32_t *H = reinterpret_cast<int32_t *>(lds + arena);
+  BestCell *red = reinterpret_cast<BestCell *>(H + T16);
+  int *stop_flag = reinterpret_cast<int *>(red + 4);
+
+  for (int k = tid * 4; k < arena; k += BS * 4) *reinterpret_cast<uint32_t *>(lds + k) = 0u;
+  for (int k = tid; k < T16; k += BS) H[k] = SDF_NEG_INF;
+  if (tid == 0) *stop_flag = 0;
+  __syncthreads();
+  {
+    const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen + 15) / 16;
+    const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
+    for (int k = tid; k < tlen; k += BS) SF[k] = (uint8_t)packed_code(tw, tn, k, sc.wild);
+    for (int k = tid; k < qlen; k += BS) QR[k] = (uint8_t)packed_code(qw, qn, qlen - 1 - k, sc.wild);
+  }
+  __syncthreads();
+
+  const int flag = tk.flag;
+  const bool with_dir = !(flag & SDF_FLAG_SCORE_ONLY);
+  const bool right = (flag & SDF_FLAG_RIGHT) != 0;
+  const bool zd_mode = tk.zdrop >= 0;
+  const int64_t stride = tk.ncol16;
+  uint8_t *dir = dirbase + tk.dir_off;
+  const int nrow = qlen + tlen - 1;
+
+  // ksw_extz_t state, meaningful in thread 0
+  int32_t ez_max = 0, ez_max_t = -1, ez_max_q = -1;
+  int32_t ez_mqe = SDF_NEG_INF, ez_mqe_t = -1, ez_mte = SDF_NEG_INF, ez_mte_q = -1;
+  int32_t ez_score = SDF_NEG_INF, ez_zdropped = 0;
+  BestCell best = {0, -1, 0, -1};  // running arg-max over all cells (zdrop < 0 mode)
+  int prev_lo = -1, prev_hi = -1;
+
+  for (int r = 0; r < nrow; ++r) {
+    Band b;
+    if (!band_of(r, qlen, tlen, w, b)) {
+      ez_zdropped = 1;
+      break;
+    }
+    // ---- carry-in of cell `lo`, boundary writes, score refresh ----
+    int cx, cv;
+    if (b.lo > 0) {
+      if (b.lo - 1 >= prev_lo && b.lo - 1 <= prev_hi) {
+        cx = (int8_t)X[b.lo - 1];
+        cv = (int8_t)V[b.lo - 1];
+      } else {
+        cx = cv = 0;
+      }
+    } else {
+      cx = 0;
+      cv = r ? sc.q : 0;
+    }
+    int32_t h_diag_prev = 0;
+    if (tid == 0) {
+      h_diag_prev = b.hi0 > 0 ? H[b.hi0 - 1] : H[b.hi0];
+      if (b.hi >= r) {
+        Y[r] = 0;
+        U[r] = r ? sc.q_b : 0;
+      }
+    }
+    {
+      const int top = b.lo0 + ((b.hi0 - b.lo0) / 16 + 1) * 16;
+      const uint8_t *qrow = QR + (qlen - 1 - r);
+      for (int t = b.lo0 + tid; t < top; t += BS) {
+        const uint8_t a = SF[t], c = qrow[t];
+        uint8_t s = a == c ? sc.sc_match : sc.sc_mis;
+        if (a == sc.wild || c == sc.wild) s = 0;
+        S[t] = s;  // t >= T16 spills into SF[0..14]; those cells are below lo0 by then
+      }
+    }
+    __syncthreads();
+
+    // ---- recurrence over the widened band, 4 cells per thread, chunks from high t down ----
+    const int ncell = b.hi - b.lo + 1;
+    const int nchunk = (ncell + 4 * BS - 1) / (4 * BS);
+    for (int c = nchunk - 1; c >= 0; --c) {
+      const int t = b.lo + c * 4 * BS + tid * 4;
+      const bool act = t <= b.hi;
+      uint32_t u4 = 0, v4 = 0, x4 = 0, y4 = 0, s4 = 0;
+      uint32_t xl = 0, vl = 0;
+      if (act) {
+        u4 = *reinterpret_cast<const uint32_t *>(U + t);
+        v4 = *reinterpret_cast<const uint32_t *>(V + t);
+        x4 = *reinterpret_cast<const uint32_t *>(X + t);
+        y4 = *reinterpret_cast<const uint32_t *>(Y + t);
+        s4 = *reinterpret_cast<const uint32_t *>(S + t);
+        if (t == b.lo) {
+          xl = (uint32_t)cx & 0xffu;
+          vl = (uint32_t)cv & 0xffu;
+        } else {
+          xl = X[t - 1];
+          vl = V[t - 1];
+        }
+      }
+      __syncthreads();
+      if (act) {
+        // a negative carry byte is sign-extended over lanes 1..3 of the first block
+        const uint32_t smx = (t == b.lo && cx < 0) ? 0xffu : 0u;
+        const uint32_t smv = (t == b.lo && cv < 0) ? 0xffu : 0u;
+        uint32_t un = 0, vn = 0, xn = 0, yn = 0, d4 = 0;
+        uint32_t xprev = xl, vprev = vl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t xo = (x4 >> (8 * k)) & 0xffu, vo = (v4 >> (8 * k)) & 0xffu;
+          const uint32_t uo = (u4 >> (8 * k)) & 0xffu, yo = (y4 >> (8 * k)) & 0xffu;
+          const uint32_t so = (s4 >> (8 * k)) & 0xffu;
+          uint32_t xt1 = xprev, vt1 = vprev;
+          if (k >= 1) {
+            xt1 |= smx;
+            vt1 |= smv;
+          }
+          xprev = xo;
+          vprev = vo;
+          uint32_t z = (so + sc.qe2_b) & 0xffu;
+          uint32_t a = (xt1 + vt1) & 0xffu;
+          uint32_t bb = (yo + uo) & 0xffu;
+          uint32_t d;
+          if (!right) {
+            d = (int8_t)a > (int8_t)z ? 1u : 0u;
+            if ((int8_t)a > (int8_t)z) z = a;
+            if ((int8_t)bb > (int8_t)z) d = 2u;
+          } else {
+            d = (int8_t)z > (int8_t)a ? 0u : 1u;
+            if ((int8_t)a > (int8_t)z) z = a;
+            if (!((int8_t)z > (int8_t)bb)) d = 2u;
+          }
+          if (bb > z) z = bb;
+          if (z > sc.cap_b) z = sc.cap_b;
+          const uint32_t unew = (z - vt1) & 0xffu;
+          const uint32_t vnew = (z - uo) & 0xffu;
+          z = (z - sc.q_b) & 0xffu;
+          a = (a - z) & 0xffu;
+          bb = (bb - z) & 0xffu;
+          uint32_t xnew, ynew;
+          if (!right) {
+            xnew = (int8_t)a > 0 ? a : 0u;
+            ynew = (int8_t)bb > 0 ? bb : 0u;
+            if ((int8_t)a > 0) d |= 0x08u;
+            if ((int8_t)bb > 0) d |= 0x10u;
+          } else {
+            xnew = (int8_t)a < 0 ? 0u : a;
+            ynew = (int8_t)bb < 0 ? 0u : bb;
+            if (!((int8_t)a < 0)) d |= 0x08u;
+            if (!((int8_t)bb < 0)) d |= 0x10u;
+          }
+          un |= unew << (8 * k);
+          vn |= vnew << (8 * k);
+          xn |= xnew << (8 * k);
+          yn |= ynew << (8 * k);
+          d4 |= d << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(U + t) = un;
+        *reinterpret_cast<uint32_t *>(V + t) = vn;
+        *reinterpret_cast<uint32_t *>(X + t) = xn;
+        *reinterpret_cast<uint32_t *>(Y + t) = yn;
+        if (with_dir) *reinterpret_cast<uint32_t *>(dir + (int64_t)r * stride + (t - b.lo)) = d4;
+      }
+    }
+    __syncthreads();
+
+    // ---- exact H[] and the row arg-max (reference :222-258) ----
+    BestCell rowbest = {SDF_NEG_INF, r, 0x7fffffff, -1};
+    if (r > 0) {
+      const int vec_end = b.lo0 + (b.hi0 - b.lo0) / 4 * 4;
+      for (int t = b.lo0 + tid; t < b.hi0; t += BS) {
+        const int32_t h = H[t] + (int32_t)V[t] - sc.qe;
+        H[t] = h;
+        BestCell cnd = {h, r, t < vec_end ? 1 + (((t - b.lo0) & 3) << 20) + t : 1 + (4 << 20) + t, t};
+        if (beats(cnd, rowbest)) rowbest = cnd;
+      }
+      if (tid == 0) {
+        const int32_t h = h_diag_prev + (b.hi0 > 0 ? (int32_t)U[b.hi0] : (int32_t)V[b.hi0]) - sc.qe;
+        H[b.hi0] = h;
+        BestCell cnd = {h, r, 0, b.hi0};
+        if (beats(cnd, rowbest)) rowbest = cnd;
+      }
+    } else if (tid == 0) {
+      const int32_t h = (int32_t)V[0] - 2 * sc.qe;
+      H[0] = h;
+      rowbest = BestCell{h, 0, 0, 0};
+    }
+    if (!zd_mode) {
+      if (rowbest.t >= 0 && beats(rowbest, best)) best = rowbest;
+    }
+    __syncthreads();
+
+    // ---- ksw_extz_t bookkeeping (reference :259-267) ----
+    if (zd_mode) rowbest = block_best<BS>(rowbest, red);
+    if (tid == 0) {
+      if (b.hi0 == tlen - 1 && H[b.hi0] > ez_mte) {
+        ez_mte = H[b.hi0];
+        ez_mte_q = r - b.hi;
+      }
+      if (r - b.lo0 == qlen - 1 && H[b.lo0] > ez_mqe) {
+        ez_mqe = H[b.lo0];
+        ez_mqe_t = b.lo0;
+      }
+      bool stop = false;
+      if (zd_mode) {  // ksw_apply_zdrop (reference: extern/ksw2.h:161-177)
+        const int32_t hh = rowbest.H, tt = rowbest.t;
+        if (hh > ez_max) {
+          ez_max = hh;
+          ez_max_t = tt;
+          ez_max_q = r - tt;
+        } else if (tt >= ez_max_t && r - tt >= ez_max_q) {
+          const int tl = tt - ez_max_t, ql = (r - tt) - ez_max_q;
+          const int l = tl > ql ? tl - ql : ql - tl;
+          if (ez_max - hh > tk.zdrop + l * sc.e) {
+            ez_zdropped = 1;
+            stop = true;
+          }
+        }
+        if (stop) *stop_flag = 1;
+      }
+      if (!stop && r == nrow - 1 && b.hi0 == tlen - 1) ez_score = H[tlen - 1];
+    }
+    if (zd_mode) {
+      __syncthreads();
+      if (*stop_flag) break;
+    }
+    prev_lo = b.lo;
+    prev_hi = b.hi;
+  }
+
+  if (!zd_mode) {
+    best = block_best<BS>(best, red);
+    if (tid == 0 && best.r >= 0) {
+      ez_max = best.H;
+      ez_max_t = best.t;
+      ez_max_q = best.r - best.t;
+    }
+  }
+  if (tid == 0) {
+    sdf_result o;
+    o.score = ez_score;
+    o.max = ez_max;
+    o.max_q = ez_max_q;
+    o.max_t = ez_max_t;
+    o.mqe = ez_mqe;
+    o.mqe_t = ez_mqe_t;
+    o.mte = ez_mte;
+    o.mte_q = ez_mte_q;
+    o.zdropped = ez_zdropped;
+    o.n_cigar = 0;
+    o.cigar_off = 0;
+    o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
+    res[tk.out_idx] = o;
+  }
+}
+
+template __global__ void extz2_general_kernel<64>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                  ScoreK, uint8_t *, sdf_result *);
+template __global__ void extz2_general_kernel<256>(const PlanTask *, const int32_t *,
+                                                   const uint32_t *, ScoreK, uint8_t *,
+                                                   sdf_result *);
+
+size_t general_lds_bytes(int qlen, int tlen) {
+  const size_t T16 = (size_t)(tlen + 15) / 16 * 16, Q16 = (size_t)(qlen + 15) / 16 * 16;
+  return 6 * T16 + Q16 + 16 + 4 * T16 + 4 * sizeof(BestCell) + 16;
+}
+
+}  // namespace sdf

@@ -1,0 +1,555 @@
+// Host side of the C ABI (include/sedef_hip.h): planning, workspace, launches, timing.
+// Replaces the call site of ksw_extz2_sse in align_helper (reference: src/align.cc:39-68) with a
+// batched device path.  No CPU fallback exists here: every DP cell is computed by a gfx950 kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+template <int BS>
+__global__ void extz2_general_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                     uint8_t *, sdf_result *);
+size_t general_lds_bytes(int qlen, int tlen);
+__global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *,
+                                 sdf_result *, uint32_t *);
+__global__ void cigar_scan_kernel(sdf_result *, int, unsigned long long *);
+__global__ void cigar_compact_kernel(const PlanTask *, int, const sdf_result *, const uint32_t *,
+                                     uint32_t *, unsigned long long);
+
+__global__ __launch_bounds__(256) void reset_results_kernel(sdf_result *res, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  sdf_result o;  // ksw_reset_extz (reference: extern/ksw2.h:153-159)
+  o.score = o.mqe = o.mte = SDF_NEG_INF;
+  o.max = 0;
+  o.max_q = o.max_t = o.mqe_t = o.mte_q = -1;
+  o.zdropped = 0;
+  o.n_cigar = 0;
+  o.cigar_off = 0;
+  o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
+  res[k] = o;
+}
+}  // namespace sdf
+
+using namespace sdf;
+
+namespace {
+
+std::string g_err;  // error of the last failed sdf_create
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipMalloc(&p, want);
+    }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct sdf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t ws_budget = 0;
+  DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf;
+  DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
+  std::vector<hipEvent_t> events;
+  float ms[4] = {0, 0, 0, 0};
+  int launches = 0;
+  std::string err;
+  int max_dyn_lds = 64 * 1024;
+};
+
+#define SDF_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      return SDF_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+extern "C" int sdf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char *sdf_last_error(const sdf_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_err.c_str();
+}
+
+extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_err = "no HIP device available (this library has no CPU fallback)";
+    return nullptr;
+  }
+  if (device < 0 || device >= n) {
+    g_err = "device ordinal out of range";
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_err = "hipSetDevice failed";
+    return nullptr;
+  }
+  sdf_ctx *ctx = new sdf_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_err = "hipStreamCreate failed";
+    delete ctx;
+    return nullptr;
+  }
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  size_t budget = workspace_bytes ? workspace_bytes : (size_t)24 << 30;
+  if (free_b && budget > free_b / 2) budget = free_b / 2;
+  ctx->ws_budget = budget;
+  // allow the general kernel its full 160 KiB of LDS
+  const int want_lds = 160 * 1024;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<64>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess)
+    ctx->max_dyn_lds = want_lds;
+  (void)hipGetLastError();
+  return ctx;
+}
+
+extern "C" void sdf_destroy(sdf_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto ev : ctx->events) (void)hipEventDestroy(ev);
+  for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf,
+                    &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
+    b->release();
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" size_t sdf_packed_words(int32_t len) {
+  if (len <= 0) return 0;
+  return (size_t)(len + 15) / 16 + (size_t)(len + 31) / 32;
+}
+
+extern "C" void sdf_pack_codes(const uint8_t *codes, int32_t len, uint32_t *out) {
+  const size_t nw = sdf_packed_words(len);
+  std::memset(out, 0, nw * sizeof(uint32_t));
+  uint32_t *cw = out, *nm = out + (len + 15) / 16;
+  for (int32_t k = 0; k < len; ++k) {
+    const uint8_t c = codes[k];
+    if (c >= 4) nm[k >> 5] |= 1u << (k & 31);
+    else cw[k >> 4] |= (uint32_t)c << ((k & 15) * 2);
+  }
+}
+
+extern "C" int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w) {
+  if (qlen <= 0 || tlen <= 0) return 0;
+  if (w < 0) w = tlen > qlen ? tlen : qlen;
+  int64_t cells = 0;
+  for (int r = 0; r < qlen + tlen - 1; ++r) {
+    Band b;
+    if (!band_of(r, qlen, tlen, w, b)) break;
+    cells += b.hi0 - b.lo0 + 1;
+  }
+  return cells;
+}
+
+extern "C" float sdf_last_ms(const sdf_ctx *ctx, int which) {
+  if (!ctx || which < 0 || which > 3) return 0.f;
+  return ctx->ms[which];
+}
+
+extern "C" int sdf_last_launches(const sdf_ctx *ctx) { return ctx ? ctx->launches : 0; }
+
+namespace {
+
+int make_scorek(sdf_ctx *ctx, const sdf_scoring *sc, ScoreK &k, bool &degenerate) {
+  if (!sc || sc->m != 5) {
+    ctx->err = "scoring: the GPU path implements the 5-letter alphabet (ACGT + wildcard) only";
+    return SDF_ERR_UNSUPPORTED;
+  }
+  const int q = sc->gapo, e = sc->gape;
+  k.q = q;
+  k.e = e;
+  k.qe = q + e;
+  k.q_b = (uint8_t)q;
+  k.qe2_b = (uint8_t)((q + e) * 2);
+  k.cap_b = (uint8_t)(int8_t)(sc->mat[0] + (q + e) * 2);
+  k.sc_match = (uint8_t)sc->mat[0];
+  k.sc_mis = (uint8_t)sc->mat[1];
+  k.wild = (uint8_t)(sc->m - 1);
+  int min_sc = sc->mat[1];
+  for (int t = 1; t < sc->m * sc->m; ++t) min_sc = std::min<int>(min_sc, sc->mat[t]);
+  degenerate = -min_sc > 2 * (q + e);  // reference returns before any work (:81)
+  return SDF_OK;
+}
+
+hipEvent_t next_event(sdf_ctx *ctx, size_t &cursor) {
+  if (cursor == ctx->events.size()) {
+    hipEvent_t ev;
+    (void)hipEventCreate(&ev);
+    ctx->events.push_back(ev);
+  }
+  return ctx->events[cursor++];
+}
+
+}  // namespace
+
+extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks,
+                                      size_t n, const uint32_t *d_pool, uint32_t want,
+                                      sdf_result *d_out, uint32_t *d_cig, size_t cigar_cap,
+                                      size_t *cigar_used, void *stream_) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  ctx->ms[0] = ctx->ms[1] = ctx->ms[2] = ctx->ms[3] = 0.f;
+  ctx->launches = 0;
+  if (cigar_used) *cigar_used = 0;
+  if (n == 0) return SDF_OK;
+  if (!tasks || !d_out || n > 0x7fffffffu) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  SDF_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
+  ScoreK sk;
+  bool degenerate = false;
+  if (int rc = make_scorek(ctx, sc, sk, degenerate)) return rc;
+  const bool want_cigar = (want & SDF_WANT_CIGAR) != 0;
+
+  // ---- plan ----
+  std::vector<PlanTask> plan;
+  plan.reserve(n);
+  int64_t stage_words = 0;
+  for (size_t k = 0; k < n; ++k) {
+    const sdf_task &t = tasks[k];
+    if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
+      ctx->err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
+      return SDF_ERR_UNSUPPORTED;
+    }
+    if (t.qlen <= 0 || t.tlen <= 0 || degenerate) continue;  // reference early return (:57,:81)
+    PlanTask p;
+    p.q_word = t.q_off;
+    p.t_word = t.t_off;
+    p.qlen = t.qlen;
+    p.tlen = t.tlen;
+    p.w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+    p.zdrop = t.zdrop;
+    p.flag = t.flag | (want_cigar ? 0 : SDF_FLAG_SCORE_ONLY);
+    int nc = std::min(t.qlen, t.tlen);
+    nc = (std::min(nc, p.w + 1) + 15) / 16 + 1;
+    p.ncol16 = nc * 16;
+    p.out_idx = (int32_t)k;
+    p.dir_off = 0;
+    p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
+    p.cig_slot = stage_words;
+    stage_words += p.cig_cap;
+    if (general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds) {
+      ctx->err = "task too long for the LDS-resident kernel (qlen/tlen above ~14k)";
+      return SDF_ERR_UNSUPPORTED;
+    }
+    plan.push_back(p);
+  }
+  const size_t np = plan.size();
+
+  // sub-batches bounded by the direction-matrix workspace
+  struct Sub {
+    size_t s, e;
+    size_t dir_bytes;
+  };
+  std::vector<Sub> subs;
+  {
+    size_t s = 0, acc = 0;
+    for (size_t k = 0; k < np; ++k) {
+      PlanTask &p = plan[k];
+      size_t need = 0;
+      if (!(p.flag & SDF_FLAG_SCORE_ONLY))
+        need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+      if (acc + need > ctx->ws_budget && k > s) {
+        subs.push_back({s, k, acc});
+        s = k;
+        acc = 0;
+      }
+      p.dir_off = (int64_t)acc;
+      acc += need;
+    }
+    if (np > s) subs.push_back({s, np, acc});
+  }
+  size_t max_dir = 16;
+  for (auto &sb : subs) max_dir = std::max(max_dir, sb.dir_bytes);
+  if (ctx->dir_ws.reserve(max_dir) != hipSuccess) {
+    ctx->err = "cannot allocate the direction-matrix workspace";
+    (void)hipGetLastError();
+    return SDF_ERR_NOMEM;
+  }
+  SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(stage_words, 4) * 4));
+  SDF_HIP(ctx->plan_buf.reserve(std::max<size_t>(np, 1) * sizeof(PlanTask)));
+  SDF_HIP(ctx->order_buf.reserve(std::max<size_t>(np, 1) * sizeof(int32_t)));
+  SDF_HIP(ctx->misc_buf.reserve(256));
+
+  // launch classes: (threads per task, LDS bytes rounded to a power of two)
+  struct Cls {
+    int bs;
+    size_t lds;
+    std::vector<int32_t> idx;
+  };
+  std::vector<int32_t> order(np);
+  struct Launch {
+    int bs;
+    size_t lds;
+    size_t off, cnt;
+  };
+  std::vector<std::vector<Launch>> sub_launches(subs.size());
+  {
+    size_t cursor = 0;
+    for (size_t si = 0; si < subs.size(); ++si) {
+      std::vector<Cls> cls;
+      for (size_t k = subs[si].s; k < subs[si].e; ++k) {
+        const PlanTask &p = plan[k];
+        const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
+        const int bs = width > 256 ? 256 : 64;
+        size_t lds = 2048;
+        const size_t need = general_lds_bytes(p.qlen, p.tlen);
+        while (lds < need) lds *= 2;
+        if (lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
+        Cls *c = nullptr;
+        for (auto &x : cls)
+          if (x.bs == bs && x.lds == lds) c = &x;
+        if (!c) {
+          cls.push_back({bs, lds, {}});
+          c = &cls.back();
+        }
+        c->idx.push_back((int32_t)(k - subs[si].s));
+      }
+      // big classes first so the long tasks start early
+      std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.lds > b.lds; });
+      for (auto &c : cls) {
+        sub_launches[si].push_back({c.bs, c.lds, cursor, c.idx.size()});
+        std::copy(c.idx.begin(), c.idx.end(), order.begin() + cursor);
+        cursor += c.idx.size();
+      }
+    }
+  }
+
+  PlanTask *d_plan = (PlanTask *)ctx->plan_buf.p;
+  int32_t *d_order = (int32_t *)ctx->order_buf.p;
+  unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
+  uint8_t *d_dir = (uint8_t *)ctx->dir_ws.p;
+  uint32_t *d_stage = (uint32_t *)ctx->stage_ws.p;
+
+  size_t evc = 0;
+  hipEvent_t ev_begin = next_event(ctx, evc);
+  SDF_HIP(hipEventRecord(ev_begin, st));
+  if (np) {
+    SDF_HIP(hipMemcpyAsync(d_plan, plan.data(), np * sizeof(PlanTask), hipMemcpyHostToDevice, st));
+    SDF_HIP(hipMemcpyAsync(d_order, order.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out,
+                     (int)n);
+
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_ev, tb_ev;
+  for (size_t si = 0; si < subs.size(); ++si) {
+    const Sub &sb = subs[si];
+    hipEvent_t e0 = next_event(ctx, evc), e1 = next_event(ctx, evc), e2 = next_event(ctx, evc);
+    SDF_HIP(hipEventRecord(e0, st));
+    for (const Launch &L : sub_launches[si]) {
+      if (L.bs == 64)
+        hipLaunchKernelGGL(extz2_general_kernel<64>, dim3((unsigned)L.cnt), dim3(64), L.lds, st,
+                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out);
+      else
+        hipLaunchKernelGGL(extz2_general_kernel<256>, dim3((unsigned)L.cnt), dim3(256), L.lds, st,
+                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out);
+      ++ctx->launches;
+    }
+    SDF_HIP(hipEventRecord(e1, st));
+    if (want_cigar) {
+      const int cnt = (int)(sb.e - sb.s);
+      hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st,
+                         d_plan + sb.s, cnt, d_pool, d_dir, d_out, d_stage);
+    }
+    SDF_HIP(hipEventRecord(e2, st));
+    dp_ev.push_back({e0, e1});
+    tb_ev.push_back({e1, e2});
+  }
+  hipEvent_t ev_c0 = next_event(ctx, evc), ev_c1 = next_event(ctx, evc), ev_end = next_event(ctx, evc);
+  SDF_HIP(hipEventRecord(ev_c0, st));
+  unsigned long long total = 0;
+  if (want_cigar) {
+    hipLaunchKernelGGL(cigar_scan_kernel, dim3(1), dim3(1024), 0, st, d_out, (int)n, d_total);
+    SDF_HIP(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, st));
+    SDF_HIP(hipStreamSynchronize(st));
+    if (cigar_used) *cigar_used = (size_t)total;
+    if (total > cigar_cap || (total && !d_cig)) {
+      ctx->err = "CIGAR pool too small";
+      return SDF_ERR_CIGAR_OVERFLOW;
+    }
+    if (np)
+      hipLaunchKernelGGL(cigar_compact_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, st, d_plan,
+                         (int)np, d_out, d_stage, d_cig, (unsigned long long)cigar_cap);
+  }
+  SDF_HIP(hipEventRecord(ev_c1, st));
+  SDF_HIP(hipEventRecord(ev_end, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  SDF_HIP(hipGetLastError());
+  for (auto &p : dp_ev) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, p.first, p.second);
+    ctx->ms[0] += ms;
+  }
+  for (auto &p : tb_ev) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, p.first, p.second);
+    ctx->ms[1] += ms;
+  }
+  (void)hipEventElapsedTime(&ctx->ms[2], ev_c0, ev_c1);
+  (void)hipEventElapsedTime(&ctx->ms[3], ev_begin, ev_end);
+  return SDF_OK;
+}
+
+extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                               const uint8_t *seq_pool, size_t pool_bytes, uint32_t want,
+                               sdf_result *out, uint32_t *cigar_pool, size_t cigar_cap,
+                               size_t *cigar_used) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  if (cigar_used) *cigar_used = 0;
+  if (n == 0) return SDF_OK;
+  if (!tasks || !out || (!seq_pool && pool_bytes)) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  SDF_HIP(hipSetDevice(ctx->device));
+  // pack every referenced sequence once (2-bit codes + N mask) and rewrite offsets to words
+  std::vector<sdf_task> t2(tasks, tasks + n);
+  size_t words = 0;
+  for (size_t k = 0; k < n; ++k) {
+    const sdf_task &t = tasks[k];
+    if (t.qlen < 0 || t.tlen < 0 || t.q_off < 0 || t.t_off < 0 ||
+        (size_t)t.q_off + (size_t)t.qlen > pool_bytes || (size_t)t.t_off + (size_t)t.tlen > pool_bytes) {
+      ctx->err = "task sequence range outside the pool";
+      return SDF_ERR_INVALID;
+    }
+    t2[k].q_off = (int64_t)words;
+    words += sdf_packed_words(t.qlen);
+    t2[k].t_off = (int64_t)words;
+    words += sdf_packed_words(t.tlen);
+  }
+  std::vector<uint32_t> packed(std::max<size_t>(words, 1));
+  for (size_t k = 0; k < n; ++k) {
+    if (tasks[k].qlen > 0) sdf_pack_codes(seq_pool + tasks[k].q_off, tasks[k].qlen, packed.data() + t2[k].q_off);
+    if (tasks[k].tlen > 0) sdf_pack_codes(seq_pool + tasks[k].t_off, tasks[k].tlen, packed.data() + t2[k].t_off);
+  }
+  SDF_HIP(ctx->h_pool.reserve(packed.size() * 4));
+  SDF_HIP(ctx->h_out.reserve(n * sizeof(sdf_result)));
+  SDF_HIP(ctx->h_cig.reserve(std::max<size_t>(cigar_cap, 1) * 4));
+  SDF_HIP(hipMemcpyAsync(ctx->h_pool.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  size_t used = 0;
+  int rc = sdf_extz2_batch_device(ctx, sc, t2.data(), n, (const uint32_t *)ctx->h_pool.p, want,
+                                  (sdf_result *)ctx->h_out.p, (uint32_t *)ctx->h_cig.p, cigar_cap, &used,
+                                  ctx->stream);
+  if (cigar_used) *cigar_used = used;
+  if (rc != SDF_OK) return rc;
+  SDF_HIP(hipMemcpy(out, ctx->h_out.p, n * sizeof(sdf_result), hipMemcpyDeviceToHost));
+  if (used && cigar_pool) SDF_HIP(hipMemcpy(cigar_pool, ctx->h_cig.p, used * 4, hipMemcpyDeviceToHost));
+  return SDF_OK;
+}
+
+// ---- one-task drop-in with the reference's exact signature (extern/ksw2.h:50) -----------------
+namespace {
+std::mutex g_mu;
+sdf_ctx *g_ctx = nullptr;
+}  // namespace
+
+extern "C" void sdf_ksw_extz2(void * /*km*/, int qlen, const uint8_t *query, int tlen,
+                              const uint8_t *target, int8_t m, const int8_t *mat, int8_t q, int8_t e,
+                              int w, int zdrop, int flag, sdf_ksw_extz_t *ez) {
+  ez->max_q = ez->max_t = ez->mqe_t = ez->mte_q = -1;
+  ez->max = 0;
+  ez->score = ez->mqe = ez->mte = SDF_NEG_INF;
+  ez->n_cigar = 0;
+  ez->m_cigar = 0;
+  ez->zdropped = 0;
+  ez->cigar = 0;
+  if (m <= 0 || qlen <= 0 || tlen <= 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ctx) {
+    const char *dv = getenv("SDF_DEVICE");
+    g_ctx = sdf_create(dv ? atoi(dv) : 0, (size_t)1 << 30);
+    if (!g_ctx) {
+      fprintf(stderr, "sdf_ksw_extz2: %s\n", sdf_last_error(nullptr));
+      exit(120);
+    }
+  }
+  sdf_scoring sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.m = m;
+  if (m == 5) memcpy(sc.mat, mat, 25);
+  sc.gapo = q;
+  sc.gape = e;
+  std::vector<uint8_t> pool((size_t)qlen + tlen);
+  memcpy(pool.data(), query, qlen);
+  memcpy(pool.data() + qlen, target, tlen);
+  sdf_task t;
+  memset(&t, 0, sizeof(t));
+  t.q_off = 0;
+  t.t_off = qlen;
+  t.qlen = qlen;
+  t.tlen = tlen;
+  t.w = w;
+  t.zdrop = zdrop;
+  t.flag = flag;
+  sdf_result r;
+  const size_t cap = (size_t)qlen + tlen + 2;
+  uint32_t *cig = (uint32_t *)malloc(cap * 4);
+  size_t used = 0;
+  uint32_t want = SDF_WANT_ALL;
+  if (flag & SDF_FLAG_SCORE_ONLY) want &= ~SDF_WANT_CIGAR;
+  int rc = sdf_extz2_batch(g_ctx, &sc, &t, 1, pool.data(), pool.size(), want, &r, cig, cap, &used);
+  if (rc != SDF_OK) {
+    fprintf(stderr, "sdf_ksw_extz2: %s (rc=%d)\n", sdf_last_error(g_ctx), rc);
+    exit(120);
+  }
+  ez->max = (uint32_t)r.max;
+  ez->zdropped = (uint32_t)r.zdropped;
+  ez->max_q = r.max_q;
+  ez->max_t = r.max_t;
+  ez->mqe = r.mqe;
+  ez->mqe_t = r.mqe_t;
+  ez->mte = r.mte;
+  ez->mte_q = r.mte_q;
+  ez->score = r.score;
+  ez->n_cigar = r.n_cigar;
+  if (r.n_cigar > 0) {
+    ez->cigar = cig;
+    ez->m_cigar = (int64_t)cap;
+    if (r.cigar_off) memmove(cig, cig + r.cigar_off, (size_t)r.n_cigar * 4);
+  } else {
+    free(cig);
+  }
+}

@@ -1,0 +1,159 @@
+// Traceback (direction matrix -> CIGAR + column counts) and CIGAR compaction for gfx950.
+//
+// Restates ksw_backtrack / ksw_push_cigar (reference: extern/ksw2.h:98-151, rotated layout)
+// and the counters of populate_nice_alignment (reference: src/align.cc:274-315).
+//
+// The walk is inherently serial per task (each step's address depends on the previous
+// direction byte), so it is parallelised across tasks: one lane per task, every lane chasing
+// its own path.  Runs are emitted from the END of the task's staging slot towards its start,
+// which leaves them in forward order without a reversal pass.
+#include <hip/hip_runtime.h>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+
+__device__ __forceinline__ uint32_t code_at(const uint32_t *codes, const uint32_t *nmask, int k) {
+  const uint32_t c = (codes[k >> 4] >> ((k & 15) * 2)) & 3u;
+  const uint32_t n = (nmask[k >> 5] >> (k & 31)) & 1u;
+  return n ? 4u : c;
+}
+
+__global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restrict__ plan, int n,
+                                                       const uint32_t *__restrict__ pool,
+                                                       const uint8_t *__restrict__ dirbase,
+                                                       sdf_result *__restrict__ res,
+                                                       uint32_t *__restrict__ stage) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const PlanTask tk = plan[k];
+  sdf_result rr = res[tk.out_idx];
+  if (tk.flag & SDF_FLAG_SCORE_ONLY) return;
+
+  int64_t i, j;
+  if (!rr.zdropped && !(tk.flag & SDF_FLAG_EXTZ_ONLY)) {
+    i = tk.tlen - 1;
+    j = tk.qlen - 1;
+  } else if (rr.max_t >= 0 && rr.max_q >= 0) {
+    i = rr.max_t;
+    j = rr.max_q;
+  } else {
+    return;  // n_cigar stays 0
+  }
+
+  const uint8_t *dir = dirbase + tk.dir_off;
+  const int64_t stride = tk.ncol16;
+  const uint32_t *tw = pool + tk.t_word, *tn = tw + (tk.tlen + 15) / 16;
+  const uint32_t *qw = pool + tk.q_word, *qn = qw + (tk.qlen + 15) / 16;
+  uint32_t *slot = stage + tk.cig_slot;
+  int pos = tk.cig_cap;
+  int cur_op = -1, cur_len = 0;
+  int32_t matches = 0, mismatches = 0, gaps = 0, gap_bases = 0;
+
+  auto push = [&](int op, int len) {
+    if (op == cur_op) {
+      cur_len += len;
+    } else {
+      if (cur_op >= 0) slot[--pos] = ((uint32_t)cur_len << 4) | (uint32_t)cur_op;
+      cur_op = op;
+      cur_len = len;
+    }
+  };
+
+  int state = 0;
+  while (i >= 0 && j >= 0) {
+    const int r = (int)(i + j);
+    Band b;
+    band_of(r, tk.qlen, tk.tlen, tk.w, b);
+    int forced = -1;
+    uint32_t d = 0;
+    if (i < b.lo) forced = 2;
+    if (i > b.hi) forced = 1;
+    if (forced < 0) d = dir[(int64_t)r * stride + (i - b.lo)];
+    if (state == 0) state = (int)(d & 7u);
+    else if (!((d >> (state + 2)) & 1u)) state = 0;
+    if (state == 0) state = (int)(d & 7u);
+    if (forced >= 0) state = forced;
+    if (state == 0) {
+      const uint32_t a = code_at(qw, qn, (int)j), c = code_at(tw, tn, (int)i);
+      if (a < 4u && a == c) ++matches; else ++mismatches;
+      push(0, 1);
+      --i;
+      --j;
+    } else if (state == 1 || state == 3) {
+      push(2, 1);
+      --i;
+    } else {
+      push(1, 1);
+      --j;
+    }
+  }
+  if (i >= 0) push(2, (int)i + 1);
+  if (j >= 0) push(1, (int)j + 1);
+  if (cur_op >= 0) slot[--pos] = ((uint32_t)cur_len << 4) | (uint32_t)cur_op;
+
+  const int ncig = tk.cig_cap - pos;
+  for (int c = pos; c < tk.cig_cap; ++c) {
+    const uint32_t wd = slot[c];
+    if (wd & 0xfu) {
+      ++gaps;
+      gap_bases += (int32_t)(wd >> 4);
+    }
+  }
+  rr.n_cigar = ncig;
+  rr.matches = matches;
+  rr.mismatches = mismatches;
+  rr.gaps = gaps;
+  rr.gap_bases = gap_bases;
+  res[tk.out_idx] = rr;
+}
+
+// Exclusive scan of n_cigar over result records in record order (single workgroup; the batch is
+// at most a few million records) -> cigar_off; total goes to *total.
+__global__ __launch_bounds__(1024) void cigar_scan_kernel(sdf_result *__restrict__ res, int n,
+                                                          unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per, hi = min(n, lo + per);
+  unsigned long long s = 0;
+  for (int k = lo; k < hi; ++k) s += (unsigned long long)res[k].n_cigar;
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    unsigned long long v = tid >= off ? part[tid - off] : 0ull;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  unsigned long long base = tid ? part[tid - 1] : 0ull;
+  for (int k = lo; k < hi; ++k) {
+    res[k].cigar_off = (int64_t)base;
+    base += (unsigned long long)res[k].n_cigar;
+  }
+  if (tid == 1023) *total = part[1023];
+}
+
+// Copy every task's CIGAR from its staging slot to its compact position.  One wave per task.
+__global__ __launch_bounds__(256) void cigar_compact_kernel(const PlanTask *__restrict__ plan, int n,
+                                                            const sdf_result *__restrict__ res,
+                                                            const uint32_t *__restrict__ stage,
+                                                            uint32_t *__restrict__ out,
+                                                            unsigned long long cap) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const int lane = threadIdx.x & 63;
+  const PlanTask tk = plan[k];
+  const sdf_result rr = res[tk.out_idx];
+  const int nc = rr.n_cigar;
+  if ((unsigned long long)rr.cigar_off + (unsigned long long)nc > cap) return;
+  const uint32_t *src = stage + tk.cig_slot + (tk.cig_cap - nc);
+  uint32_t *dst = out + rr.cigar_off;
+  if (tk.flag & SDF_FLAG_REV_CIGAR) {
+    for (int c = lane; c < nc; c += 64) dst[c] = src[nc - 1 - c];
+  } else {
+    for (int c = lane; c < nc; c += 64) dst[c] = src[c];
+  }
+}
+
+}  // namespace sdf

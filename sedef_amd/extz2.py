@@ -1,0 +1,211 @@
+"""ctypes mirror of include/sedef_hip.h.
+
+`ksw_extz2()` keeps the argument order and meaning of the reference's ksw_extz2_sse
+(reference: extern/ksw2.h:50) so parity tests read like calls to the reference;
+`Extz2Engine` exposes the batched entry points.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+NEG_INF = -0x40000000
+WANT_CIGAR, WANT_SCORE, WANT_EXT, WANT_ALL = 1, 2, 4, 7
+
+TASK_DTYPE = np.dtype([("q_off", "<i8"), ("t_off", "<i8"), ("qlen", "<i4"), ("tlen", "<i4"),
+                       ("w", "<i4"), ("zdrop", "<i4"), ("flag", "<i4"), ("pad_", "<i4")])
+RESULT_DTYPE = np.dtype([("score", "<i4"), ("max", "<i4"), ("max_q", "<i4"), ("max_t", "<i4"),
+                         ("mqe", "<i4"), ("mqe_t", "<i4"), ("mte", "<i4"), ("mte_q", "<i4"),
+                         ("zdropped", "<i4"), ("n_cigar", "<i4"), ("cigar_off", "<i8"),
+                         ("matches", "<i4"), ("mismatches", "<i4"), ("gaps", "<i4"),
+                         ("gap_bases", "<i4")])
+assert TASK_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 64
+
+
+class SdfError(RuntimeError):
+    pass
+
+
+class _Scoring(C.Structure):
+    _fields_ = [("m", C.c_int32), ("mat", C.c_int8 * 25), ("gapo", C.c_int8), ("gape", C.c_int8),
+                ("pad_", C.c_int8)]
+
+
+_lib = None
+
+
+def library_path():
+    return LIB_PATH
+
+
+def load_library():
+    """Loads the HIP library; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SdfError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                       % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.sdf_device_count.restype = C.c_int
+    L.sdf_create.restype = C.c_void_p
+    L.sdf_create.argtypes = [C.c_int, C.c_size_t]
+    L.sdf_destroy.argtypes = [C.c_void_p]
+    L.sdf_last_error.restype = C.c_char_p
+    L.sdf_last_error.argtypes = [C.c_void_p]
+    L.sdf_packed_words.restype = C.c_size_t
+    L.sdf_packed_words.argtypes = [C.c_int32]
+    L.sdf_pack_codes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.sdf_band_cells.restype = C.c_int64
+    L.sdf_band_cells.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.sdf_extz2_batch.restype = C.c_int
+    L.sdf_extz2_batch.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t,
+                                  C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdf_extz2_batch_device.restype = C.c_int
+    L.sdf_extz2_batch_device.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    L.sdf_last_ms.restype = C.c_float
+    L.sdf_last_ms.argtypes = [C.c_void_p, C.c_int]
+    L.sdf_last_launches.restype = C.c_int
+    L.sdf_last_launches.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def packed_words(n):
+    return int(load_library().sdf_packed_words(int(n)))
+
+
+def pack_codes(codes):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.zeros(packed_words(len(codes)), np.uint32)
+    if len(codes):
+        load_library().sdf_pack_codes(codes.ctypes.data, len(codes), out.ctypes.data)
+    return out
+
+
+def band_cells(qlen, tlen, w):
+    return int(load_library().sdf_band_cells(qlen, tlen, w))
+
+
+def _scoring(mat, gapo, gape, m=5):
+    s = _Scoring()
+    s.m = m
+    mat = np.asarray(mat, dtype=np.int8)
+    for i in range(min(25, len(mat))):
+        s.mat[i] = int(mat[i])
+    s.gapo, s.gape = gapo, gape
+    return s
+
+
+def sedef_mat(match=5, mismatch=-4):
+    """The 5x5 matrix align_helper builds (reference: src/align.cc:41-44)."""
+    a, b = match, mismatch if mismatch < 0 else -mismatch
+    return np.array([a, b, b, b, 0, b, a, b, b, 0, b, b, a, b, 0, b, b, b, a, 0, 0, 0, 0, 0, 0],
+                    dtype=np.int8)
+
+
+class Extz2Engine:
+    """One context = one GPU (include/sedef_hip.h: sdf_create)."""
+
+    def __init__(self, device=0, workspace_bytes=0):
+        self.lib = load_library()
+        self.ctx = self.lib.sdf_create(device, workspace_bytes)
+        if not self.ctx:
+            raise SdfError("sdf_create failed: %s" % self.lib.sdf_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.sdf_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SdfError("rc=%d: %s" % (rc, self.lib.sdf_last_error(self.ctx).decode()))
+
+    def align_pairs(self, pairs, w=-1, zdrop=-1, flag=0, mat=None, gapo=40, gape=1,
+                    want=WANT_ALL):
+        """pairs: list of (query_codes, target_codes).  w/zdrop/flag: scalar or per-pair list.
+        Returns (results structured array, cigar pool)."""
+        n = len(pairs)
+        tasks = np.zeros(n, TASK_DTYPE)
+        chunks, off = [], 0
+        for k, (q, t) in enumerate(pairs):
+            q = np.ascontiguousarray(q, dtype=np.uint8)
+            t = np.ascontiguousarray(t, dtype=np.uint8)
+            tasks["q_off"][k], tasks["qlen"][k] = off, len(q)
+            off += len(q)
+            tasks["t_off"][k], tasks["tlen"][k] = off, len(t)
+            off += len(t)
+            chunks += [q, t]
+        pool = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+        tasks["w"], tasks["zdrop"], tasks["flag"] = w, zdrop, flag
+        return self.align_batch(tasks, pool, mat=mat, gapo=gapo, gape=gape, want=want)
+
+    def align_batch(self, tasks, pool, mat=None, gapo=40, gape=1, want=WANT_ALL, cigar_cap=None):
+        tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        n = len(tasks)
+        sc = _scoring(sedef_mat() if mat is None else mat, gapo, gape)
+        out = np.zeros(n, RESULT_DTYPE)
+        if cigar_cap is None:
+            cigar_cap = int((tasks["qlen"].astype(np.int64) + tasks["tlen"] + 2).sum()) + 1
+        cig = np.zeros(cigar_cap, np.uint32)
+        used = C.c_size_t(0)
+        rc = self.lib.sdf_extz2_batch(self.ctx, C.byref(sc), tasks.ctypes.data, n, pool.ctypes.data,
+                                      pool.nbytes, want, out.ctypes.data, cig.ctypes.data,
+                                      cigar_cap, C.byref(used))
+        self._check(rc)
+        return out, cig[:used.value]
+
+    def align_batch_device(self, tasks, d_pool, d_out, d_cig, cigar_cap, mat=None, gapo=40, gape=1,
+                           want=WANT_ALL, stream=None):
+        """Device-resident form: d_pool/d_out/d_cig are raw HBM addresses (ints)."""
+        tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
+        sc = _scoring(sedef_mat() if mat is None else mat, gapo, gape)
+        used = C.c_size_t(0)
+        rc = self.lib.sdf_extz2_batch_device(self.ctx, C.byref(sc), tasks.ctypes.data, len(tasks),
+                                             d_pool, want, d_out, d_cig, cigar_cap, C.byref(used),
+                                             stream)
+        self._check(rc)
+        return used.value
+
+    def last_ms(self, which):
+        return float(self.lib.sdf_last_ms(self.ctx, which))
+
+    def last_launches(self):
+        return int(self.lib.sdf_last_launches(self.ctx))
+
+
+_default_engine = None
+
+
+def ksw_extz2(query, target, m=5, mat=None, q=40, e=1, w=-1, zdrop=-1, flag=0, engine=None):
+    """Mirror of ksw_extz2_sse(km, qlen, query, tlen, target, m, mat, q, e, w, zdrop, flag, &ez)
+    (reference: extern/ksw2.h:50).  Returns the ksw_extz_t fields as a dict + 'cigar' words."""
+    global _default_engine
+    if engine is None:
+        if _default_engine is None:
+            _default_engine = Extz2Engine()
+        engine = _default_engine
+    if m != 5:
+        raise SdfError("GPU path implements m=5 only")
+    want = WANT_ALL & ~WANT_CIGAR if flag & 1 else WANT_ALL
+    res, cig = engine.align_pairs([(query, target)], w=w, zdrop=zdrop, flag=flag, mat=mat, gapo=q,
+                                  gape=e, want=want)
+    r = res[0]
+    d = {k: int(r[k]) for k in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q",
+                                "score")}
+    d["cigar"] = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])].copy()
+    d["counts"] = {k: int(r[k]) for k in ("matches", "mismatches", "gaps", "gap_bases")}
+    return d

@@ -1,0 +1,124 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle.binding import mutate, random_codes
+from util import FIELDS, check_case, cigar_to_str, codes, sedef_mat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import sedef_amd
+    return sedef_amd.Extz2Engine(0)
+
+
+def _rec_to_dict(r, cig):
+    d = {k: int(r[k]) for k in FIELDS}
+    d["cigar"] = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+    return d
+
+
+GPU_FLAGS_OK = lambda f: not (f & (0x04 | 0x08 | 0x10))  # noqa: E731
+
+
+def test_golden_vectors_single_calls(engine, golden_cases):
+    import sedef_amd
+    n = 0
+    for c in golden_cases:
+        if not GPU_FLAGS_OK(c["flag"]):
+            continue
+        got = sedef_amd.ksw_extz2(codes(c["q"]), codes(c["t"]), 5, sedef_mat(c["match"], c["mismatch"]),
+                                  c["gapo"], c["gape"], c["w"], c["zdrop"], c["flag"], engine=engine)
+        check_case(got, c)
+        n += 1
+    assert n > 200
+
+
+def test_golden_vectors_one_batch(engine, golden_cases):
+    sel = [c for c in golden_cases if GPU_FLAGS_OK(c["flag"]) and (c["match"], c["mismatch"], c["gapo"], c["gape"]) == (5, -4, 40, 1)]
+    pairs = [(codes(c["q"]), codes(c["t"])) for c in sel]
+    res, cig = engine.align_pairs(pairs, w=[c["w"] for c in sel], zdrop=[c["zdrop"] for c in sel],
+                                  flag=[c["flag"] for c in sel])
+    for c, r in zip(sel, res):
+        check_case(_rec_to_dict(r, cig), c)
+
+
+def test_unsupported_flags_are_rejected(engine):
+    import sedef_amd
+    q = np.zeros(10, np.uint8)
+    for f in (0x04, 0x08):
+        with pytest.raises(sedef_amd.SdfError):
+            engine.align_pairs([(q, q)], flag=f)
+
+
+def test_fuzz_vs_oracle(engine, oracle):
+    rng = np.random.default_rng(2024)
+    pairs, kws = [], []
+    for _ in range(1500):
+        q = random_codes(rng, int(rng.integers(1, 600)), 0.02 if rng.random() < 0.3 else 0.0)
+        d = rng.random() * 0.15
+        t = mutate(rng, q, d, d / 3, d / 3)
+        if rng.random() < 0.3:
+            k, L = int(rng.integers(0, len(t))), int(rng.integers(1, 90))
+            t = np.concatenate([t[:k], random_codes(rng, L), t[k:]])
+        if rng.random() < 0.1:
+            t = random_codes(rng, int(rng.integers(1, 600)))
+        pairs.append((q, t))
+        kws.append(dict(w=int(rng.choice([-1, -1, 0, 1, 2, 7, 15, 16, 17, 31, 32, 33, 64, 128])),
+                        flag=int(rng.choice([0, 0, 0, 0x02, 0x40, 0x80, 0x01, 0xC2])),
+                        zdrop=int(rng.choice([-1, -1, 30, 200]))))
+    res, cig = engine.align_pairs(pairs, w=[k["w"] for k in kws], zdrop=[k["zdrop"] for k in kws],
+                                  flag=[k["flag"] for k in kws])
+    for (q, t), kw, r in zip(pairs, kws, res):
+        exp = oracle.extz2(q, t, **kw)
+        got = _rec_to_dict(r, cig)
+        for f in FIELDS:
+            assert got[f] == exp[f], (f, kw, len(q), len(t))
+        assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"]), (kw, len(q), len(t))
+        full_path = not (kw["flag"] & (0x80 | 0x40 | 0x01)) and not exp["zdropped"]
+        if full_path:  # column counters (populate_nice_alignment restated) over a whole forward CIGAR
+            assert {k: int(r[k]) for k in ("matches", "mismatches", "gaps", "gap_bases")} == \
+                oracle.counts(exp["cigar"], q, t)
+
+
+def test_fuzz_other_scorings(engine, oracle):
+    rng = np.random.default_rng(77)
+    for _ in range(60):
+        ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
+        go, ge = int(rng.integers(0, 70)), int(rng.integers(0, 6))
+        pairs = []
+        for _ in range(12):
+            q = random_codes(rng, int(rng.integers(1, 300)), 0.03)
+            d = rng.random() * 0.2
+            pairs.append((q, mutate(rng, q, d, d / 3, d / 3)))
+        w = int(rng.choice([-1, 3, 16, 40, 100]))
+        res, cig = engine.align_pairs(pairs, w=w, mat=sedef_mat(ma, mi), gapo=go, gape=ge)
+        for (q, t), r in zip(pairs, res):
+            exp = oracle.extz2(q, t, mat=sedef_mat(ma, mi), gapo=go, gape=ge, w=w)
+            got = _rec_to_dict(r, cig)
+            for f in FIELDS:
+                assert got[f] == exp[f], (f, ma, mi, go, ge, w)
+            assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"])
+
+
+def test_sedef_shapes_full_band(engine, oracle):
+    """SEDEF's real call shapes: w=-1, gap fills <=210x209, 500x500 sides, <=1000^2 (src/align.cc:129,159,235)."""
+    rng = np.random.default_rng(5)
+    pairs = []
+    for ql, tl in [(210, 209), (37, 3), (3, 180), (500, 500), (500, 431), (1000, 1000), (1000, 640),
+                   (977, 1000), (1, 1), (1, 300), (2000, 1800), (16, 16), (17, 15)]:
+        q = random_codes(rng, ql)
+        t = mutate(rng, q)
+        t = t[:tl] if len(t) >= tl else np.concatenate([t, random_codes(rng, tl - len(t))])
+        pairs.append((q, t))
+    res, cig = engine.align_pairs(pairs)
+    for (q, t), r in zip(pairs, res):
+        exp = oracle.extz2(q, t)
+        got = _rec_to_dict(r, cig)
+        for f in FIELDS:
+            assert got[f] == exp[f], (f, len(q), len(t))
+        assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"])
+        assert {k: int(r[k]) for k in ("matches", "mismatches", "gaps", "gap_bases")} == \
+            oracle.counts(exp["cigar"], q, t)
