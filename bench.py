@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned DP cells/s of the `sedef align` DP hot path on MI355X.
+
+One "step" = one pass of the hot path (extz2 DP -> traceback -> CIGAR compaction -> result
+gather) over one batch of synthetic DP tasks whose packed sequences are already resident in HBM.
+Workload at every N: BASELINE.json configs[1] per GPU -- 100,000 tasks, query = 1000 uniform
+ACGT, target = query with 6 % substitution draws / 2 % deletions / 2 % insertions, band w=128,
+scoring 5/-4/40/1, zdrop=-1, flag=0.  N GPUs = N independent shards
+(weak scaling); after the DP every rank all-gathers the per-task result records and CIGARs
+(RCCL over xGMI), as the north star asks.
+
+Prints ONE JSON line (rank 0).  `value` = in-band cells of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def synth_batch(n, qlen, seed, sub=0.06, dele=0.02, ins=0.02):
+    """Vectorised version of the survey's mutation model. Returns (pool_codes, q_off, qlen[], t_off, tlen[])."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    q = rng.integers(0, 4, size=(n, qlen), dtype=np.uint8)
+    r = rng.random((n, qlen))
+    base = q.copy()
+    m_sub = r < sub
+    base[m_sub] = rng.integers(0, 4, size=int(m_sub.sum()), dtype=np.uint8)
+    cnt = np.ones((n, qlen), np.int64)
+    cnt[(r >= sub) & (r < sub + dele)] = 0
+    m_ins = (r >= sub + dele) & (r < sub + dele + ins)
+    cnt[m_ins] = 2
+    empty = cnt.sum(1) == 0
+    cnt[empty, 0] = 1
+    flat_cnt = cnt.reshape(-1)
+    t_flat = np.repeat(base.reshape(-1), flat_cnt)
+    ends = np.cumsum(flat_cnt)
+    ins_pos = ends[m_ins.reshape(-1)] - 1
+    t_flat[ins_pos] = rng.integers(0, 4, size=len(ins_pos), dtype=np.uint8)
+    tlen = cnt.sum(1).astype(np.int32)
+    t_off = np.concatenate([[0], np.cumsum(tlen)[:-1]]).astype(np.int64)
+    qlen_a = np.full(n, qlen, np.int32)
+    q_off = (np.arange(n, dtype=np.int64) * qlen)
+    pool = np.concatenate([q.reshape(-1), t_flat])
+    return pool, q_off, qlen_a, t_off + n * qlen, tlen
+
+
+def pack_batch(pool, q_off, qlen, t_off, tlen):
+    """Packs every sequence (2-bit codes + N mask) into one uint32 pool; returns (words, q_word, t_word)."""
+    import sedef_amd
+    lib = sedef_amd.load_library()
+    n = len(qlen)
+    qw = np.array([sedef_amd.packed_words(int(x)) for x in np.unique(qlen)])
+    qmap = dict(zip(np.unique(qlen).tolist(), qw.tolist()))
+    tuniq = np.unique(tlen)
+    tmap = dict(zip(tuniq.tolist(), [sedef_amd.packed_words(int(x)) for x in tuniq]))
+    q_words = np.array([qmap[int(x)] for x in qlen], np.int64)
+    t_words = np.array([tmap[int(x)] for x in tlen], np.int64)
+    offs = np.zeros(2 * n + 1, np.int64)
+    inter = np.empty(2 * n, np.int64)
+    inter[0::2], inter[1::2] = q_words, t_words
+    offs[1:] = np.cumsum(inter)
+    words = np.zeros(int(offs[-1]), np.uint32)
+    base = words.ctypes.data
+    pbase = pool.ctypes.data
+    for k in range(n):
+        lib.sdf_pack_codes(pbase + int(q_off[k]), int(qlen[k]), base + 4 * int(offs[2 * k]))
+        lib.sdf_pack_codes(pbase + int(t_off[k]), int(tlen[k]), base + 4 * int(offs[2 * k + 1]))
+    return words, offs[0:2 * n:2].copy(), offs[1:2 * n:2].copy()
+
+
+def algorithmic_bytes(qlen, tlen, cells, n_cigar):
+    """2-bit inputs + N mask + 1 B/cell direction write + traceback read bound +
+    result record, per task."""
+    s = qlen.astype(np.int64) + tlen
+    return int(((s + 3) // 4 + (s + 7) // 8 + cells + s + 4 * n_cigar.astype(np.int64) + 64).sum())
+
+
+def cpu_baseline(pool, q_off, qlen, t_off, tlen, w, budget_s=15.0):
+    """Times the CPU path on a bounded sample of the same workload on this box's host cores.
+    kind = "reference": the reference kernel itself (oracle/_ref, built from /root/reference in the
+    build container); else "port": our scalar oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle.binding import Oracle, Reference
+    orc = Oracle()
+    try:
+        impl, kind = Reference(), "reference"
+    except Exception:
+        impl, kind = orc, "port"
+    cores = os.cpu_count() or 1
+
+    def run(idx):
+        c = 0
+        for k in idx:
+            q = pool[q_off[k]:q_off[k] + qlen[k]]
+            t = pool[t_off[k]:t_off[k] + tlen[k]]
+            impl.extz2(q, t, w=w)
+            c += orc.band_cells(int(qlen[k]), int(tlen[k]), w)
+        return c
+
+    t0 = time.perf_counter()
+    c0 = run(range(4))
+    per_task = (time.perf_counter() - t0) / 4
+    per_core = max(4, int(budget_s / per_task))
+    per_core = min(per_core, len(qlen) // cores)
+    sample = [range(i * per_core, (i + 1) * per_core) for i in range(cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        cells = sum(ex.map(run, sample))
+    dt = time.perf_counter() - t0
+    return {"value": round(cells / dt / 1e9, 4), "unit": "Gcell/s", "cores": cores, "kind": kind,
+            "sample": "%d tasks of the same batch (first %d per core), %d threads, %.1f s"
+                      % (per_core * cores, per_core, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tasks", type=int, default=100000, help="DP tasks per GPU per step")
+    ap.add_argument("--qlen", type=int, default=1000)
+    ap.add_argument("--band", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workspace-gib", type=float, default=48.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import sedef_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, w = args.tasks, args.band
+    pool, q_off, qlen, t_off, tlen = synth_batch(n, args.qlen, seed=42 + rank)
+    words, q_word, t_word = pack_batch(pool, q_off, qlen, t_off, tlen)
+    tasks = np.zeros(n, sedef_amd.TASK_DTYPE)
+    tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"] = q_word, t_word, qlen, tlen
+    tasks["w"], tasks["zdrop"], tasks["flag"] = w, -1, 0
+    cells = np.array([sedef_amd.band_cells(int(a), int(b), w) for a, b in
+                      zip(*np.unique(np.stack([qlen, tlen]), axis=1))])
+    keys = {(int(a), int(b)): int(c) for (a, b), c in
+            zip(np.unique(np.stack([qlen, tlen]), axis=1).T, cells)}
+    cells_task = np.array([keys[(int(a), int(b))] for a, b in zip(qlen, tlen)], np.int64)
+    cells_rank = int(cells_task.sum())
+
+    eng = sedef_amd.Extz2Engine(local, int(args.workspace_gib * (1 << 30)))
+    d_pool = torch.from_numpy(words.view(np.int32)).to(dev)
+    d_out = torch.empty(n * 16, dtype=torch.int32, device=dev)
+    cig_cap = int((qlen.astype(np.int64) + tlen + 2).sum())
+    cig_cap = min(cig_cap, 256 * n)  # ~50 runs per task at 10 % divergence; overflow is an error
+    d_cig = torch.empty(cig_cap, dtype=torch.int32, device=dev)
+    want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
+    stream = torch.cuda.current_stream().cuda_stream
+
+    gathered = {}
+
+    def step():
+        used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_out.data_ptr(), d_cig.data_ptr(),
+                                      cig_cap, want=want, stream=stream)
+        if world > 1:  # all-gatherv of result records + CIGAR words: counts, then padded payloads
+            cnt = torch.tensor([used], dtype=torch.int64, device=dev)
+            cnts = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(cnts, cnt)
+            mx = int(cnts.max().item())
+            recs = torch.empty(world * n * 16, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(recs, d_out)
+            cg = torch.empty(world * mx, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(cg, d_cig[:mx] if mx <= cig_cap else d_cig)
+            gathered["recs"], gathered["cig"], gathered["cnts"] = recs, cg, cnts
+        return used
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    dp_ms, tb_ms, cp_ms, launches = 0.0, 0.0, 0.0, 0
+    t0 = time.perf_counter()
+    used = 0
+    for _ in range(args.steps):
+        used = step()
+        dp_ms += eng.last_ms(0)
+        tb_ms += eng.last_ms(1)
+        cp_ms += eng.last_ms(2)
+        launches += eng.last_launches()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([cells_rank], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        cells_all = int(tot.item())
+    else:
+        cells_all = cells_rank
+
+    if rank == 0:
+        res = d_out.cpu().numpy().view(sedef_amd.RESULT_DTYPE)
+        assert int(res["n_cigar"].astype(np.int64).sum()) == used
+        alg = algorithmic_bytes(qlen, tlen, cells_task, res["n_cigar"])
+        avg_launch_s = dp_ms / 1e3 / max(launches, 1)
+        bytes_per_launch = alg * args.steps / max(launches, 1)
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get("bytes_per_launch")
+        value = cells_all * args.steps / dt / 1e9
+        line = {
+            "metric": "aligned DP cells/sec (Gcell/s) on `sedef align` batch",
+            "value": round(value, 3), "unit": "Gcell/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic %dx~%d DP tasks per GPU, band=%d, "
+                                   "affine gap 5/-4/40/1, CIGAR+score+counts" % (n, args.qlen, args.qlen, w),
+                       "tasks_per_gpu": n, "band": w, "cells_per_step_per_gpu": cells_rank,
+                       "parallelism": "task-sharded x%d + all-gatherv of result records" % world},
+            "kernel_ms_per_step": {"dp": round(dp_ms / args.steps, 3), "traceback": round(tb_ms / args.steps, 3),
+                                   "compact": round(cp_ms / args.steps, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "extz2 DP", "launches_per_step": launches / args.steps,
+                         "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pool, q_off, qlen, t_off, tlen, w)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
