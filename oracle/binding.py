@@ -128,11 +128,11 @@ class Oracle:
         n = len(qlen)
         score = np.zeros(n, np.int32)
         h = np.zeros(n, np.uint64)
-        cells = self.lib.sdfo_extz2_batch(n, pool.ctypes.data, q_off.ctypes.data, qlen.ctypes.data,
-                                          t_off.ctypes.data, tlen.ctypes.data, m,
-                                          mat.ctypes.data_as(C.POINTER(C.c_int8)), gapo, gape, w,
-                                          zdrop, flag, score.ctypes.data, h.ctypes.data)
-        return int(cells), score, h
+        self.lib.sdfo_extz2_batch(n, pool.ctypes.data, q_off.ctypes.data, qlen.ctypes.data,
+                                  t_off.ctypes.data, tlen.ctypes.data, m,
+                                  mat.ctypes.data_as(C.POINTER(C.c_int8)), gapo, gape, w, zdrop, flag,
+                                  score.ctypes.data, h.ctypes.data)
+        return score, h
 
 
 class Reference:
@@ -149,9 +149,33 @@ class Reference:
                       C.c_int8, C.POINTER(C.c_int8), C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int,
                       C.POINTER(_KswExtz)]
 
+        b = self.lib.ref_extz2_batch
+        b.restype = C.c_int64
+        b.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                      C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                      C.c_void_p]
+
     @staticmethod
     def available():
         return build_reference() is not None
+
+    def batch(self, pool, q_off, qlen, t_off, tlen, mat=None, m=5, gapo=40, gape=1, w=-1,
+              zdrop=-1, flag=0):
+        """Loops ksw_extz2_sse over the tasks in C (GIL released); returns (scores, cigar hashes)."""
+        mat = sedef_mat() if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.int64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.int64)
+        qlen = np.ascontiguousarray(qlen, dtype=np.int32)
+        tlen = np.ascontiguousarray(tlen, dtype=np.int32)
+        n = len(qlen)
+        score = np.zeros(n, np.int32)
+        h = np.zeros(n, np.uint64)
+        self.lib.ref_extz2_batch(n, pool.ctypes.data, q_off.ctypes.data, qlen.ctypes.data,
+                                 t_off.ctypes.data, tlen.ctypes.data, m,
+                                 mat.ctypes.data_as(C.POINTER(C.c_int8)), gapo, gape, w, zdrop, flag,
+                                 score.ctypes.data, h.ctypes.data)
+        return score, h
 
     def extz2(self, query, target, mat=None, m=5, gapo=40, gape=1, w=-1, zdrop=-1, flag=0):
         mat = sedef_mat() if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
