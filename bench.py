@@ -83,7 +83,7 @@ def algorithmic_bytes(qlen, tlen, cells, n_cigar):
     return int(((s + 3) // 4 + (s + 7) // 8 + cells + s + 4 * n_cigar.astype(np.int64) + 64).sum())
 
 
-def cpu_baseline(pool, q_off, qlen, t_off, tlen, cells_task, w, budget_s=12.0):
+def cpu_baseline(pool, q_off, qlen, t_off, tlen, cells_task, w, budget_s=10.0):
     """Times the CPU path on a bounded sample of the same workload on this box's host cores: one
     task stream per hardware thread, each a C loop over ksw_extz2_sse calls (the reference runs
     one single-threaded process per bucket file, reference: sedef.sh:187-190).
@@ -96,25 +96,45 @@ def cpu_baseline(pool, q_off, qlen, t_off, tlen, cells_task, w, budget_s=12.0):
         impl, kind = Reference(), "reference"
     except Exception:
         impl, kind = Oracle(), "port"
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     n = len(qlen)
+    chunk = 32
+    deadline = [0.0]
 
-    def run(idx):
-        impl.batch(pool, q_off[idx], qlen[idx], t_off[idx], tlen[idx], w=w)
-        return int(cells_task[idx].sum())
+    def stream(i):  # one task stream: C loops over `chunk` tasks until the wall-clock budget is spent
+        cells, k = 0, (i * 7919 * chunk) % n
+        while time.perf_counter() < deadline[0]:
+            idx = np.arange(k, k + chunk) % n
+            impl.batch(pool, q_off[idx], qlen[idx], t_off[idx], tlen[idx], w=w)
+            cells += int(cells_task[idx].sum())
+            k = (k + chunk) % n
+        return cells
 
     t0 = time.perf_counter()
-    run(np.arange(0, 16))
-    per_task = (time.perf_counter() - t0) / 16
-    per_core = max(16, int(budget_s / per_task))
-    sample = [np.arange(i * per_core, (i + 1) * per_core) % n for i in range(cores)]
-    t0 = time.perf_counter()
+    deadline[0] = t0 + budget_s
     with ThreadPoolExecutor(cores) as ex:
-        cells = sum(ex.map(run, sample))
+        per = list(ex.map(stream, range(cores)))
     dt = time.perf_counter() - t0
+    cells = sum(per)
     return {"value": round(cells / dt / 1e9, 4), "unit": "Gcell/s", "cores": cores, "kind": kind,
-            "sample": "%d task executions drawn from the same batch (%d per thread, wrapping), "
-                      "%d threads, %.1f s" % (per_core * cores, per_core, cores, dt)}
+            "sample": "%d tasks drawn from the same batch, %d concurrent single-threaded streams "
+                      "(host exposes %d logical CPUs), %.1f s wall" % (cells // max(int(cells_task.mean()), 1),
+                                                                        cores, os.cpu_count() or 1, dt)}
+
+
+def effective_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def main():

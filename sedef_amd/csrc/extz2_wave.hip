@@ -1,0 +1,467 @@
+// Register-resident extz2 DP kernel for gfx950: one wavefront per DP task.
+//
+// Same results as extz2_general.hip (and therefore as the reference kernel,
+// extern/ksw2_extz2_sse.cc:23-298) for the fields SEDEF consumes -- CIGAR, score, mte -- but the
+// anti-diagonal state never leaves the register file:
+//
+//   * a lane owns two adjacent cells (slots 2l, 2l+1) of every 128-slot register; each state
+//     byte of the reference (u, v, x, y, and the possibly stale score s) is kept as value<<8 in a
+//     16-bit half, so v_pk_{add,sub,max,min}_{u,i}16 reproduce the reference's wrap-around int8
+//     arithmetic (signed and unsigned) exactly, two cells per instruction;
+//   * slot k of the window is target position base+k, where base = the reference's block-rounded
+//     band start at the first row of each 16-row block, so the window only re-bases (by 16 slots
+//     = 8 lanes, via ds_bpermute) at block boundaries;
+//   * the (r-1, t-1) neighbour comes from a wavefront DPP shift (wave_shr:1) + v_alignbit;
+//   * the reversed query and the target sit in LDS as 16-bit codes (unpacked once from the
+//     2-bit/N-mask pool with coalesced dword loads); one aligned ds_read_b32 per register per row
+//     yields the two query codes of a lane;
+//   * the four direction flags of a cell are shifted into four 32-bit accumulators (16 rows x
+//     2 cells each) and leave for HBM as one 16-byte store per lane per 16 rows: 0.5 B/cell,
+//     1 KiB per wave-instruction, fully coalesced.
+//
+// Exactness in banded mode: the reference computes whole 16-cell blocks, i.e. also cells outside
+// the logical band, from persistent per-position state and from scores refreshed only in
+// [st0, st0+16*n) (:115,:124-138).  Those cells feed real cells at the band edges and the
+// traceback may walk through them, so they are computed here too: lanes are enabled for exactly
+// the reference's widened range and the score register keeps its old value outside the refreshed
+// range.  The exact H values the reference derives for score / mte are followed along the one
+// path of cells they depend on (the cell under the band's upper edge), O(1) per row.
+//
+// Not produced here (general kernel instead): max/max_q/max_t, mqe/mqe_t, z-drop, right-aligned
+// gaps, extension-only traceback.
+#include <hip/hip_runtime.h>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+#define SDF_OPQ(x) asm("" : "+v"(x))  // make a value opaque to instcombine (keeps the packed forms)
+
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ unsigned pk_maxi(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a),
+                                                                __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_maxu(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
+                                                                __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a),
+                                                                __builtin_bit_cast(u16x2, b)));
+}
+// min(x, 1) per half = "x != 0" as 0/1.  Written as the instruction itself: the optimiser would
+// otherwise turn it into per-half compares + selects.
+__device__ __forceinline__ unsigned pk_nonzero(unsigned a) {
+  unsigned d;
+  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+  return d;
+}
+__device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) +
+                                          __builtin_bit_cast(u16x2, c));
+}
+__device__ __forceinline__ unsigned pk_ashr15(unsigned a) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(i16x2, a) >> (i16x2){15, 15});
+}
+__device__ __forceinline__ unsigned pk_shl(unsigned a, unsigned n) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a)
+                                          << (u16x2){(unsigned short)n, (unsigned short)n});
+}
+
+// lane mask with bits [lo, hi) set (0 <= lo, hi; clamped to 64)
+__device__ __forceinline__ unsigned long long lane_range(int lo, int hi) {
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > 64 ? 64 : hi;
+  if (hi <= lo) return 0ull;
+  const unsigned long long top = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+  return top & ~((1ull << lo) - 1ull);
+}
+
+// dst half <- src half where the lane's bit in `mask` is set (SDWA keeps the other half)
+__device__ __forceinline__ void sel_lo16(unsigned &dst, unsigned src, unsigned long long mask) {
+  asm volatile(
+      "s_mov_b64 vcc, %2\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\ts_nop 0"
+      : "+v"(dst)
+      : "v"(src), "s"(mask)
+      : "vcc");
+}
+__device__ __forceinline__ void sel_hi16(unsigned &dst, unsigned src, unsigned long long mask) {
+  asm volatile(
+      "s_mov_b64 vcc, %2\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1\n\ts_nop 0"
+      : "+v"(dst)
+      : "v"(src), "s"(mask)
+      : "vcc");
+}
+
+// value of slot `s` (0..127) of a packed register, as its 16-bit half
+__device__ __forceinline__ unsigned slot_half(unsigned reg, int s) {
+  const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)reg, s >> 1);
+  return (s & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+template <int NREG>
+__global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
+                                                        const int32_t *__restrict__ order,
+                                                        const uint32_t *__restrict__ pool, ScoreK sc,
+                                                        uint8_t *__restrict__ dirbase,
+                                                        sdf_result *__restrict__ res) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NSLOT = 128 * NREG;
+  const PlanTask tk = plan[order[blockIdx.x]];
+  const int lane = threadIdx.x;
+  const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
+  const int T16 = (tlen + 15) / 16 * 16;
+  const int tcap = T16 + NSLOT + 32;                 // target codes, zero padded
+  const int qcap = (qlen + NSLOT + 36 + 1) & ~1;     // reversed query, 32 pad elements in front
+  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);
+  uint16_t *QA = Tb + tcap;
+  uint16_t *QB = QA + qcap;  // QB[j] = QA[j-1]
+
+  // ---- unpack sequences into LDS (coalesced dword loads of the 2-bit / N-mask pool) ----
+  for (int k = lane; k < (tcap + 2 * qcap) / 2; k += 64) reinterpret_cast<uint32_t *>(lds)[k] = 0u;
+  __syncthreads();
+  uint32_t n_seen = 0;
+  {
+    const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen + 15) / 16;
+    const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
+    for (int wd = lane; wd < (tlen + 15) / 16; wd += 64) {
+      const uint32_t cw = tw[wd];
+      const uint32_t nm = tn[wd >> 1] >> ((wd & 1) * 16);
+      n_seen |= nm & 0xffffu;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int t = wd * 16 + j;
+        if (t < tlen) Tb[t] = (uint16_t)(((nm >> j) & 1u) ? (0xff00u | sc.wild) : ((cw >> (2 * j)) & 3u));
+      }
+    }
+    for (int wd = lane; wd < (qlen + 15) / 16; wd += 64) {
+      const uint32_t cw = qw[wd];
+      const uint32_t nm = qn[wd >> 1] >> ((wd & 1) * 16);
+      n_seen |= nm & 0xffffu;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int q = wd * 16 + j;
+        if (q < qlen) {
+          const uint16_t v = (uint16_t)(((nm >> j) & 1u) ? (0xff00u | sc.wild) : ((cw >> (2 * j)) & 3u));
+          const int e = qlen - 1 - q + 32;  // element index of QR[qlen-1-q] with the 32-element pad
+          QA[e] = v;
+          QB[e + 1] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const bool has_n = __any(n_seen != 0);  // wave-uniform: wildcard handling only where needed
+
+  // ---- constants of the <<8 difference domain ----
+  const unsigned qv = ((unsigned)sc.q_b << 8) * 0x00010001u;
+  const unsigned capv = ((unsigned)sc.cap_b << 8) * 0x00010001u;
+  const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
+  const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
+  const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
+  const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
+
+  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], Tc[NREG];
+  unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
+#pragma unroll
+  for (int k = 0; k < NREG; ++k) {
+    U[k] = V[k] = X[k] = Y[k] = 0u;
+    S[k] = z_wild;
+    Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
+    Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + 128 * k + 2 * lane);
+  }
+
+  const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
+  uint4 *dir = reinterpret_cast<uint4 *>(dirbase + tk.dir_off);
+  const int nrow = qlen + tlen - 1;
+  const int bperm_idx = ((lane + 8) & 63) * 4;
+
+  int base = 0;
+  int prev_lo = -1;
+  unsigned carry_x = 0u, carry_v = 0u;  // halves shifted into slot 0 on the first row of a block
+  bool zero_low = false;  // slots below the reference window still hold x,v that must read as 0
+  int32_t h_top = 0, h_under = 0;  // H of the top cell / of the cell the next top cell will read
+  int32_t ez_score = SDF_NEG_INF, ez_mte = SDF_NEG_INF, ez_mte_q = -1, ez_zdropped = 0;
+
+  for (int r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
+    // ---- block start: re-base the window to the reference's band start of this row ----
+    {
+      Band b0;
+      if (!band_of(r0, qlen, tlen, w, b0)) {
+        ez_zdropped = 1;
+        break;
+      }
+      carry_x = carry_v = 0u;
+      if (b0.lo != base) {  // always +16: shift everything down by 8 lanes
+        if (prev_lo == base) {  // the reference re-bases at this very row: its carry-in is the
+          carry_x = slot_half(X[0], 15);  // (r-1) value of the cell just below the new window
+          carry_v = slot_half(V[0], 15);
+        }
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          const bool from_next = lane >= 56;
+          unsigned a0, a1;
+#define SDF_SHIFT8(A, INIT)                                                              \
+  a0 = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_idx, (int)A[k]);                     \
+  a1 = (k + 1 < NREG) ? (unsigned)__builtin_amdgcn_ds_bpermute(bperm_idx, (int)A[k + 1 < NREG ? k + 1 : k]) : (INIT); \
+  A[k] = from_next ? a1 : a0;
+          SDF_SHIFT8(U, 0u)
+          SDF_SHIFT8(V, 0u)
+          SDF_SHIFT8(X, 0u)
+          SDF_SHIFT8(Y, 0u)
+          SDF_SHIFT8(S, z_wild)
+#undef SDF_SHIFT8
+        }
+        base = b0.lo;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k)
+          Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + base + 128 * k + 2 * lane);
+        zero_low = false;
+      }
+    }
+    const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
+    int drop_row = -1;  // row of this block at which the reference window left slots 0..15
+    int r = r0;
+    for (; r < rend; ++r) {
+      Band b;
+      if (!band_of(r, qlen, tlen, w, b)) {
+        ez_zdropped = 1;
+        break;
+      }
+      const int off_lo = b.lo - base;  // 0 or 16
+      const int off_hi = b.hi - base;  // last enabled slot
+      // the reference rebased at this row: slot off_lo's (r-1,t-1) neighbour is slot 15 (natural);
+      // on later rows that neighbour reads as 0
+      const bool ref_rebased = b.lo != prev_lo && prev_lo >= 0;
+      if (ref_rebased && off_lo == 16) drop_row = r;
+      if (off_lo == 16 && !ref_rebased && !zero_low) {
+        if (lane < 8) {
+          X[0] = 0u;
+          V[0] = 0u;
+        }
+        zero_low = true;
+      }
+      // ---- boundary cell t = r: y = 0, u = gap open (reference :122) ----
+      if (b.hi >= r) {
+        const int sr = r - base;
+        const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
+        const unsigned uval = r ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k)
+          if ((sr >> 7) == k && lane == ((sr & 127) >> 1)) {
+            U[k] = (U[k] & keep) | uval;
+            Y[k] &= keep;
+          }
+      }
+      // ---- (r-1, t-1) neighbours: shift x and v up by one slot ----
+      unsigned xt1[NREG], vt1[NREG];
+      {
+        // carry into slot 0: only when the window starts at t = 0 (x = 0, v = gap open for r > 0)
+        const unsigned vcarry = (base == 0 && r > 0) ? ((unsigned)sc.q_b << 24)
+                                : (r == r0 ? carry_v << 16 : 0u);
+        const unsigned xcarry = (base != 0 && r == r0) ? carry_x << 16 : 0u;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          unsigned xs, vs;
+          if (k == 0) {
+            xs = (unsigned)__builtin_amdgcn_update_dpp((int)xcarry, (int)X[0], 0x138, 0xf, 0xf, false);
+            vs = (unsigned)__builtin_amdgcn_update_dpp((int)vcarry, (int)V[0], 0x138, 0xf, 0xf, false);
+          } else {
+            const int x0 = __builtin_amdgcn_update_dpp(0, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+            xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+            const int v0 = __builtin_amdgcn_update_dpp(0, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+            vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+          }
+          xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
+          vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
+        }
+        // sign-extension artefact of the reference's carry-in (:145-146): a negative v carry also
+        // sets lanes 1..3 of the first block.  Only possible on the reference's rebase rows.
+        if (ref_rebased && off_lo == 16) {
+          const unsigned cvh = slot_half(V[0], 15);
+          if (cvh & 0x8000u) {
+            if (lane == 8) vt1[0] |= 0xff000000u;
+            if (lane == 9) vt1[0] |= 0xff00ff00u;
+          }
+        } else if (ref_rebased && r == r0 && (carry_v & 0x8000u)) {
+          if (lane == 0) vt1[0] |= 0xff000000u;
+          if (lane == 1) vt1[0] |= 0xff00ff00u;
+        }
+      }
+      // ---- scores: refresh [lo0, lo0 + 16*n), keep the old value elsewhere ----
+      {
+        const int ra = b.lo0 - base;
+        const int rb = ra + ((b.hi0 - b.lo0) / 16 + 1) * 16;
+        const int cq = qlen - 1 - r + base + 32;
+        const uint16_t *qp = (cq & 1) ? QB + cq + 1 : QA + cq;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          const int a_ = ra - 128 * k, b_ = rb - 128 * k;
+          if (b_ > 0 && a_ < 128) {
+            const unsigned qc = *reinterpret_cast<const uint32_t *>(qp + 128 * k + 2 * lane);
+            unsigned d = pk_sub(Tc[k], qc);
+            SDF_OPQ(d);
+            const unsigned m = pk_nonzero(d);
+            unsigned z = pk_mad(m, z_delta, z_match);
+            if (has_n) {
+              unsigned nn = pk_ashr15(Tc[k] | qc);
+              SDF_OPQ(nn);
+              z = (z_wild & nn) | (z & ~nn);
+            }
+            if (a_ <= 0 && b_ >= 128) {
+              S[k] = z;
+            } else {
+              sel_lo16(S[k], z, lane_range((a_ + 1) >> 1, (b_ + 1) >> 1));
+              sel_hi16(S[k], z, lane_range(a_ >> 1, b_ >> 1));
+            }
+          }
+        }
+      }
+      // ---- the recurrence on the reference's widened range [lo, hi] ----
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        const int l0 = off_lo - 128 * k <= 0 ? 0 : (off_lo - 128 * k) >> 1;
+        const int l1 = (off_hi - 128 * k) >> 1;  // off_hi is odd
+        if (l1 >= l0 && l0 < 64) {
+          if ((unsigned)(lane - l0) <= (unsigned)(l1 - l0)) {
+            const unsigned a = pk_add(xt1[k], vt1[k]);
+            const unsigned bb = pk_add(Y[k], U[k]);
+            const unsigned z0 = S[k];
+            const unsigned z1 = pk_maxi(z0, a);
+            unsigned fa = pk_sub(z1, z0);  // != 0 <=> a > z (signed)
+            SDF_OPQ(fa);
+            const unsigned zb = pk_maxi(z1, bb);
+            unsigned fb = pk_sub(zb, z1);  // != 0 <=> b > max(z, a) (signed)
+            SDF_OPQ(fb);
+            const unsigned z2 = pk_maxu(z1, bb);
+            const unsigned z3 = pk_minu(z2, capv);
+            const unsigned un = pk_sub(z3, vt1[k]);
+            const unsigned vn = pk_sub(z3, U[k]);
+            const unsigned zq = pk_sub(z3, qv);
+            const unsigned a2 = pk_sub(a, zq);
+            const unsigned b2 = pk_sub(bb, zq);
+            unsigned xn = pk_maxi(a2, 0u);
+            unsigned yn = pk_maxi(b2, 0u);
+            U[k] = un;
+            V[k] = vn;
+            X[k] = xn;
+            Y[k] = yn;
+            SDF_OPQ(xn);
+            SDF_OPQ(yn);
+            Fa[k] = (Fa[k] << 1) | pk_nonzero(fa);
+            Fb[k] = (Fb[k] << 1) | pk_nonzero(fb);
+            Fx[k] = (Fx[k] << 1) | pk_nonzero(xn);
+            Fy[k] = (Fy[k] << 1) | pk_nonzero(yn);
+          }
+        }
+      }
+      // ---- exact H of the top cell and of the cell under the band edge (score, mte) ----
+      {
+        const int st = b.hi0 - base;  // slot of the top cell
+        unsigned uh = 0, vh = 0, vu = 0;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          if ((st >> 7) == k) {
+            uh = slot_half(U[k], st & 127);
+            vh = slot_half(V[k], st & 127);
+          }
+          if (st > 0 && ((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
+        }
+        const int32_t u8v = (int32_t)(uh >> 8), v8v = (int32_t)(vh >> 8), vu8 = (int32_t)(vu >> 8);
+        if (r == 0) {
+          h_top = v8v - 2 * sc.qe;
+        } else {
+          h_top = (b.hi0 > 0 ? h_under + u8v : h_top + v8v) - sc.qe;
+        }
+        // cell that row r+1's top cell will read: hi0(r+1) - 1
+        Band bn;
+        const bool nv = r + 1 < nrow && band_of(r + 1, qlen, tlen, w, bn);
+        const int hin = nv ? bn.hi0 : b.hi0;
+        if (hin == 0 || hin == b.hi0 + 1) {
+          h_under = h_top;
+        } else if (b.hi0 - 1 >= b.lo0 && r > 0) {
+          h_under += vu8 - sc.qe;
+        } else if (r == 0) {
+          h_under = h_top;
+        }
+        if (b.hi0 == tlen - 1 && h_top > ez_mte) {
+          ez_mte = h_top;
+          ez_mte_q = r - b.hi;
+        }
+        if (r == nrow - 1 && b.hi0 == tlen - 1) ez_score = h_top;
+      }
+      prev_lo = b.lo;
+    }
+    // ---- block end: direction flags of these (<=16) rows leave for HBM ----
+    if (with_dir) {
+      const int done = r - r0;
+      const int rbk = r0 >> 4;
+      if (drop_row >= 0 && lane < 8) {  // lanes that stopped shifting when their slots were dropped
+        const unsigned sh = (unsigned)(r - drop_row);
+        Fa[0] = pk_shl(Fa[0], sh);
+        Fb[0] = pk_shl(Fb[0], sh);
+        Fx[0] = pk_shl(Fx[0], sh);
+        Fy[0] = pk_shl(Fy[0], sh);
+      }
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        unsigned fa = Fa[k], fb = Fb[k], fx = Fx[k], fy = Fy[k];
+        if (done < 16) {
+          const unsigned sh = 16 - done;
+          fa = pk_shl(fa, sh);
+          fb = pk_shl(fb, sh);
+          fx = pk_shl(fx, sh);
+          fy = pk_shl(fy, sh);
+        }
+        dir[((int64_t)rbk * NREG + k) * 64 + lane] = make_uint4(fa, fb, fx, fy);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
+  }
+
+  if (lane == 0) {
+    sdf_result o;
+    o.score = ez_score;
+    o.max = 0;
+    o.max_q = o.max_t = -1;
+    o.mqe = SDF_NEG_INF;
+    o.mqe_t = -1;
+    o.mte = ez_mte;
+    o.mte_q = ez_mte_q;
+    o.zdropped = ez_zdropped;
+    o.n_cigar = 0;
+    o.cigar_off = 0;
+    o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
+    res[tk.out_idx] = o;
+  }
+}
+
+template __global__ void extz2_wave_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                              uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                              uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                              uint8_t *, sdf_result *);
+
+size_t wave_lds_bytes(int qlen, int tlen, int nreg) {
+  const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
+  const size_t tcap = T16 + 128 * nreg + 32;
+  const size_t qcap = ((size_t)qlen + 128 * nreg + 36 + 1) & ~(size_t)1;
+  return 2 * (tcap + 2 * qcap);
+}
+
+}  // namespace sdf

@@ -18,6 +18,10 @@ template <int BS>
 __global__ void extz2_general_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
                                      uint8_t *, sdf_result *);
 size_t general_lds_bytes(int qlen, int tlen);
+template <int NREG>
+__global__ void extz2_wave_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                  sdf_result *);
+size_t wave_lds_bytes(int qlen, int tlen, int nreg);
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *,
                                  sdf_result *, uint32_t *);
 __global__ void cigar_scan_kernel(sdf_result *, int, unsigned long long *);
@@ -82,6 +86,7 @@ struct sdf_ctx {
   int launches = 0;
   std::string err;
   int max_dyn_lds = 64 * 1024;
+  bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
 };
 
 #define SDF_HIP(call)                                                                          \
@@ -137,7 +142,15 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess)
     ctx->max_dyn_lds = want_lds;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipGetLastError();
+  const char *fg = getenv("SDF_FORCE_GENERAL");
+  ctx->force_general = fg && fg[0] == '1';
   return ctx;
 }
 
@@ -266,11 +279,26 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     nc = (std::min(nc, p.w + 1) + 15) / 16 + 1;
     p.ncol16 = nc * 16;
     p.out_idx = (int32_t)k;
+    p.pad_ = 0;
+    // register-resident wave kernel when only CIGAR/score/mte are wanted and the shape fits
+    p.nreg = 0;
+    {
+      const int nrow = t.qlen + t.tlen - 1;
+      Band bl;
+      const bool band_whole = (p.w >= 1 || nrow == 1) && band_of(nrow - 1, t.qlen, t.tlen, p.w, bl);
+      const bool plain = !(want & SDF_WANT_EXT) && t.zdrop < 0 &&
+                         !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY)) && sc->gapo >= 0 && band_whole;
+      if (plain && !ctx->force_general) {
+        const int need = p.ncol16 + 32;
+        const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : 0;
+        if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)ctx->max_dyn_lds) p.nreg = nreg;
+      }
+    }
     p.dir_off = 0;
     p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
     p.cig_slot = stage_words;
     stage_words += p.cig_cap;
-    if (general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds) {
+    if (!p.nreg && general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds) {
       ctx->err = "task too long for the LDS-resident kernel (qlen/tlen above ~14k)";
       return SDF_ERR_UNSUPPORTED;
     }
@@ -289,8 +317,12 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     for (size_t k = 0; k < np; ++k) {
       PlanTask &p = plan[k];
       size_t need = 0;
-      if (!(p.flag & SDF_FLAG_SCORE_ONLY))
-        need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+      if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
+        if (p.nreg)
+          need = (size_t)((p.qlen + p.tlen - 1 + 15) / 16) * (size_t)p.nreg * 1024;
+        else
+          need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+      }
       if (acc + need > ctx->ws_budget && k > s) {
         subs.push_back({s, k, acc});
         s = k;
@@ -315,7 +347,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
 
   // launch classes: (threads per task, LDS bytes rounded to a power of two)
   struct Cls {
-    int bs;
+    int bs;  // 64 / 256: general kernel with that many threads; 1, 2, 4: wave kernel with NREG
     size_t lds;
     std::vector<int32_t> idx;
   };
@@ -333,10 +365,15 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       for (size_t k = subs[si].s; k < subs[si].e; ++k) {
         const PlanTask &p = plan[k];
         const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
-        const int bs = width > 256 ? 256 : 64;
+        int bs = width > 256 ? 256 : 64;
         size_t lds = 2048;
-        const size_t need = general_lds_bytes(p.qlen, p.tlen);
-        while (lds < need) lds *= 2;
+        if (p.nreg) {
+          bs = p.nreg;
+          lds = (wave_lds_bytes(p.qlen, p.tlen, p.nreg) + 2047) & ~(size_t)2047;
+        } else {
+          const size_t need = general_lds_bytes(p.qlen, p.tlen);
+          while (lds < need) lds *= 2;
+        }
         if (lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
         Cls *c = nullptr;
         for (auto &x : cls)
@@ -379,7 +416,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     hipEvent_t e0 = next_event(ctx, evc), e1 = next_event(ctx, evc), e2 = next_event(ctx, evc);
     SDF_HIP(hipEventRecord(e0, st));
     for (const Launch &L : sub_launches[si]) {
-      if (L.bs == 64)
+      if (L.bs == 1)
+        hipLaunchKernelGGL(extz2_wave_kernel<1>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
+                           d_order + L.off, d_pool, sk, d_dir, d_out);
+      else if (L.bs == 2)
+        hipLaunchKernelGGL(extz2_wave_kernel<2>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
+                           d_order + L.off, d_pool, sk, d_dir, d_out);
+      else if (L.bs == 4)
+        hipLaunchKernelGGL(extz2_wave_kernel<4>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
+                           d_order + L.off, d_pool, sk, d_dir, d_out);
+      else if (L.bs == 64)
         hipLaunchKernelGGL(extz2_general_kernel<64>, dim3((unsigned)L.cnt), dim3(64), L.lds, st,
                            d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out);
       else
@@ -552,4 +598,11 @@ extern "C" void sdf_ksw_extz2(void * /*km*/, int qlen, const uint8_t *query, int
   } else {
     free(cig);
   }
+}
+
+// ---- debugging aid (not part of the public header): copy the head of the direction workspace ----
+extern "C" int sdf_debug_copy_dir(sdf_ctx *ctx, void *host, size_t bytes) {
+  if (!ctx || !ctx->dir_ws.p) return SDF_ERR_INVALID;
+  if (bytes > ctx->dir_ws.cap) bytes = ctx->dir_ws.cap;
+  return hipMemcpy(host, ctx->dir_ws.p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SDF_OK : SDF_ERR_HIP;
 }

@@ -32,6 +32,9 @@ struct PlanTask {
   int32_t ncol16;    // direction-matrix row stride in cells (n_col_*16 of the reference)
   int32_t out_idx;   // index of the result record
   int32_t cig_cap;   // words in the staging slot
+  int32_t nreg;      // 0: general kernel, byte-per-cell direction rows; >0: wave kernel with nreg
+                     // packed registers, direction flags in 16-row x 128-slot bit blocks
+  int32_t pad_;
 };
 
 // Per-anti-diagonal band geometry (reference: extern/ksw2_extz2_sse.cc:101-115).

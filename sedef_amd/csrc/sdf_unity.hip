@@ -1,4 +1,5 @@
 // Unity translation unit: one code object for gfx950 (kernels are launched from sdf_api.hip).
 #include "extz2_general.hip"
+#include "extz2_wave.hip"
 #include "traceback.hip"
 #include "sdf_api.hip"

@@ -61,6 +61,14 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   };
 
   int state = 0;
+  // wave-kernel layout: block rb = r/16 holds, per packed register k and lane, one uint4 of four
+  // 32-bit flag words (a>z, b>z', x>0, y>0); bit 15-(r%16) (+16 for the odd slot) is row r;
+  // slot = t - (band start of row 16*rb).  The last fetched uint4 is kept: a path stays inside
+  // one 16-row x 2-slot tile for several steps.
+  const uint4 *dirw = reinterpret_cast<const uint4 *>(dir);
+  int64_t cached_idx = -1;
+  uint4 cached = make_uint4(0, 0, 0, 0);
+  int blk_rb = -1, blk_base = 0;
   while (i >= 0 && j >= 0) {
     const int r = (int)(i + j);
     Band b;
@@ -69,7 +77,29 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     uint32_t d = 0;
     if (i < b.lo) forced = 2;
     if (i > b.hi) forced = 1;
-    if (forced < 0) d = dir[(int64_t)r * stride + (i - b.lo)];
+    if (forced < 0) {
+      if (tk.nreg == 0) {
+        d = dir[(int64_t)r * stride + (i - b.lo)];
+      } else {
+        const int rb = r >> 4;
+        if (rb != blk_rb) {
+          Band b0;
+          band_of(rb << 4, tk.qlen, tk.tlen, tk.w, b0);
+          blk_rb = rb;
+          blk_base = b0.lo;
+        }
+        const int slot = (int)i - blk_base;
+        const int64_t idx = ((int64_t)rb * tk.nreg + (slot >> 7)) * 64 + ((slot & 127) >> 1);
+        if (idx != cached_idx) {
+          cached = dirw[idx];
+          cached_idx = idx;
+        }
+        const int bit = 15 - (r & 15) + ((slot & 1) << 4);
+        const uint32_t fa = (cached.x >> bit) & 1u, fb = (cached.y >> bit) & 1u;
+        const uint32_t fx = (cached.z >> bit) & 1u, fy = (cached.w >> bit) & 1u;
+        d = (fb ? 2u : fa) | (fx << 3) | (fy << 4);
+      }
+    }
     if (state == 0) state = (int)(d & 7u);
     else if (!((d >> (state + 2)) & 1u)) state = 0;
     if (state == 0) state = (int)(d & 7u);

@@ -122,3 +122,81 @@ def test_sedef_shapes_full_band(engine, oracle):
         assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"])
         assert {k: int(r[k]) for k in ("matches", "mismatches", "gaps", "gap_bases")} == \
             oracle.counts(exp["cigar"], q, t)
+
+
+# ---- register-resident wave kernel (taken when only CIGAR / score / mte are requested) ----
+FAST_FIELDS = ("score", "mte", "mte_q", "zdropped")
+
+
+def _check_fast(engine, oracle, pairs, ws, flags=None, **sc):
+    import sedef_amd
+    flags = flags or [0] * len(pairs)
+    res, cig = engine.align_pairs(pairs, w=ws, flag=flags, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE,
+                                  **sc)
+    for (q, t), w, f, r in zip(pairs, ws, flags, res):
+        exp = oracle.extz2(q, t, w=w, flag=f, **sc)
+        got = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+        for fld in FAST_FIELDS:
+            assert int(r[fld]) == exp[fld], (fld, w, len(q), len(t), int(r[fld]), exp[fld])
+        assert cigar_to_str(got) == cigar_to_str(exp["cigar"]), (w, len(q), len(t))
+        if not exp["zdropped"] and not (f & 0x81):
+            assert {k: int(r[k]) for k in ("matches", "mismatches", "gaps", "gap_bases")} == \
+                oracle.counts(exp["cigar"], q, t)
+
+
+def test_wave_kernel_golden(engine, golden_cases):
+    import sedef_amd
+    sel = [c for c in golden_cases if (c["flag"] & ~0x81) == 0 and c["zdrop"] < 0
+           and (c["match"], c["mismatch"], c["gapo"], c["gape"]) == (5, -4, 40, 1)]
+    assert len(sel) > 150
+    pairs = [(codes(c["q"]), codes(c["t"])) for c in sel]
+    res, cig = engine.align_pairs(pairs, w=[c["w"] for c in sel], flag=[c["flag"] for c in sel],
+                                  want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    for c, r in zip(sel, res):
+        exp = c["expect"]
+        got = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+        for fld in FAST_FIELDS:
+            assert int(r[fld]) == exp[fld], (c["tag"], fld, c["w"], len(c["q"]), len(c["t"]))
+        assert cigar_to_str(got) == exp["cigar"], (c["tag"], c["w"], len(c["q"]), len(c["t"]))
+
+
+def test_wave_kernel_fuzz_banded(engine, oracle):
+    rng = np.random.default_rng(99)
+    pairs, ws = [], []
+    for _ in range(1200):
+        q = random_codes(rng, int(rng.integers(1, 900)), 0.02 if rng.random() < 0.3 else 0.0)
+        d = rng.random() * 0.15
+        t = mutate(rng, q, d, d / 3, d / 3)
+        if rng.random() < 0.4:
+            k, L = int(rng.integers(0, len(t))), int(rng.integers(1, 120))
+            t = np.concatenate([t[:k], random_codes(rng, L), t[k:]]) if rng.random() < 0.5 else \
+                (np.concatenate([t[:k], t[k + L:]]) if len(t) - L > 1 else t)
+        pairs.append((q, t))
+        ws.append(int(rng.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 64, 100, 128, 200, 300])))
+    _check_fast(engine, oracle, pairs, ws)
+
+
+def test_wave_kernel_config2_shape(engine, oracle):
+    """BASELINE config 2 shape (1000 x ~1000, w=128, 10 % divergence) + the other headline bands."""
+    rng = np.random.default_rng(123)
+    pairs, ws = [], []
+    for w in (64, 128, 128, 128, 256):
+        for _ in range(6):
+            q = random_codes(rng, 1000)
+            pairs.append((q, mutate(rng, q)))
+            ws.append(w)
+    _check_fast(engine, oracle, pairs, ws)
+
+
+def test_wave_kernel_other_scorings(engine, oracle):
+    rng = np.random.default_rng(321)
+    for _ in range(40):
+        ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
+        go, ge = int(rng.integers(0, 70)), int(rng.integers(0, 6))
+        pairs = []
+        for _ in range(10):
+            q = random_codes(rng, int(rng.integers(1, 400)), 0.03)
+            d = rng.random() * 0.2
+            pairs.append((q, mutate(rng, q, d, d / 3, d / 3)))
+        w = int(rng.choice([3, 16, 40, 100]))
+        _check_fast(engine, oracle, pairs, [w] * len(pairs), mat=sedef_mat(ma, mi), gapo=go, gape=ge)
