@@ -112,6 +112,92 @@ __device__ __forceinline__ unsigned slot_half(unsigned reg, int s) {
   return (s & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
+// S half <- z half in the lanes where `thr <= lane` (GE) or `lane < thr` (LT); the compare writes
+// VCC and the SDWA select consumes it (no wait state needed between them on gfx9).
+__device__ __forceinline__ void sel_lo_ge(unsigned &dst, unsigned src, int thr, int lane) {
+  asm volatile(
+      "v_cmp_le_i32 vcc, %2, %3\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\ts_nop 0"
+      : "+v"(dst) : "v"(src), "s"(thr), "v"(lane) : "vcc");
+}
+__device__ __forceinline__ void sel_hi_ge(unsigned &dst, unsigned src, int thr, int lane) {
+  asm volatile(
+      "v_cmp_le_i32 vcc, %2, %3\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1\n\ts_nop 0"
+      : "+v"(dst) : "v"(src), "s"(thr), "v"(lane) : "vcc");
+}
+__device__ __forceinline__ void sel_lo_lt(unsigned &dst, unsigned src, int thr, int lane) {
+  asm volatile(
+      "v_cmp_gt_i32 vcc, %2, %3\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\ts_nop 0"
+      : "+v"(dst) : "v"(src), "s"(thr), "v"(lane) : "vcc");
+}
+__device__ __forceinline__ void sel_hi_lt(unsigned &dst, unsigned src, int thr, int lane) {
+  asm volatile(
+      "v_cmp_gt_i32 vcc, %2, %3\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1\n\ts_nop 0"
+      : "+v"(dst) : "v"(src), "s"(thr), "v"(lane) : "vcc");
+}
+
+__device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uint32_t *nmask, int k,
+                                                uint32_t wild) {
+  const uint32_t c = (codes[k >> 4] >> ((k & 15) * 2)) & 3u;
+  const uint32_t n = (nmask[k >> 5] >> (k & 31)) & 1u;
+  return n ? (0xff00u | wild) : c;
+}
+
+// One anti-diagonal step of the recurrence for packed register k (two cells per lane), in the
+// <<8 int16 domain; appends the four direction flags to the accumulators.
+#define SDF_CORE(k)                                                     \
+  {                                                                     \
+    const unsigned a_ = pk_add(xt1[k], vt1[k]);                         \
+    const unsigned bb_ = pk_add(Y[k], U[k]);                            \
+    const unsigned z0_ = S[k];                                          \
+    const unsigned z1_ = pk_maxi(z0_, a_);                              \
+    unsigned fa_ = pk_sub(z1_, z0_); /* != 0 <=> a > z (signed) */      \
+    SDF_OPQ(fa_);                                                       \
+    const unsigned zb_ = pk_maxi(z1_, bb_);                             \
+    unsigned fb_ = pk_sub(zb_, z1_); /* != 0 <=> b > max(z,a) */        \
+    SDF_OPQ(fb_);                                                       \
+    const unsigned z2_ = pk_maxu(z1_, bb_);                             \
+    const unsigned z3_ = pk_minu(z2_, capv);                            \
+    const unsigned un_ = pk_sub(z3_, vt1[k]);                           \
+    const unsigned vn_ = pk_sub(z3_, U[k]);                             \
+    const unsigned zq_ = pk_sub(z3_, qv);                               \
+    const unsigned a2_ = pk_sub(a_, zq_);                               \
+    const unsigned b2_ = pk_sub(bb_, zq_);                              \
+    unsigned xn_ = pk_maxi(a2_, 0u);                                    \
+    unsigned yn_ = pk_maxi(b2_, 0u);                                    \
+    U[k] = un_;                                                         \
+    V[k] = vn_;                                                         \
+    X[k] = xn_;                                                         \
+    Y[k] = yn_;                                                         \
+    SDF_OPQ(xn_);                                                       \
+    SDF_OPQ(yn_);                                                       \
+    Fa[k] = (Fa[k] << 1) | pk_nonzero(fa_);                             \
+    Fb[k] = (Fb[k] << 1) | pk_nonzero(fb_);                             \
+    Fx[k] = (Fx[k] << 1) | pk_nonzero(xn_);                             \
+    Fy[k] = (Fy[k] << 1) | pk_nonzero(yn_);                             \
+  }
+
+// fresh (score + 2(q+e)) << 8 of the two cells of a lane from their target / query codes
+#define SDF_FRESH(z, tc, qc)                                            \
+  {                                                                     \
+    unsigned d_ = pk_sub(tc, qc);                                       \
+    SDF_OPQ(d_);                                                        \
+    const unsigned m_ = pk_nonzero(d_);                                 \
+    z = pk_mad(m_, z_delta, z_match);                                   \
+    if (has_n) {                                                        \
+      unsigned nn_ = pk_ashr15((tc) | (qc));                            \
+      SDF_OPQ(nn_);                                                     \
+      z = (z_wild & nn_) | (z & ~nn_);                                  \
+    }                                                                   \
+  }
+
 template <int NREG>
 __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
                                                         const int32_t *__restrict__ order,
@@ -124,47 +210,29 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   const int lane = threadIdx.x;
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
   const int T16 = (tlen + 15) / 16 * 16;
-  const int tcap = T16 + NSLOT + 32;                 // target codes, zero padded
-  const int qcap = (qlen + NSLOT + 36 + 1) & ~1;     // reversed query, 32 pad elements in front
-  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);
-  uint16_t *QA = Tb + tcap;
-  uint16_t *QB = QA + qcap;  // QB[j] = QA[j-1]
+  const int tcap = T16 + NSLOT + 32;      // target codes (u16), zero padded
+  const int qcap = qlen + NSLOT + 36;     // reversed query with a 32-element front pad, as PAIRS:
+  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);            // W[j] = QR[j-32] | QR[j-31] << 16
+  uint32_t *W = reinterpret_cast<uint32_t *>(lds + 2 * tcap);  // (any j is one aligned dword)
 
-  // ---- unpack sequences into LDS (coalesced dword loads of the 2-bit / N-mask pool) ----
-  for (int k = lane; k < (tcap + 2 * qcap) / 2; k += 64) reinterpret_cast<uint32_t *>(lds)[k] = 0u;
-  __syncthreads();
-  uint32_t n_seen = 0;
+  // ---- unpack the 2-bit / N-mask sequences into LDS ----
+  bool has_n;
   {
     const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen + 15) / 16;
     const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
-    for (int wd = lane; wd < (tlen + 15) / 16; wd += 64) {
-      const uint32_t cw = tw[wd];
-      const uint32_t nm = tn[wd >> 1] >> ((wd & 1) * 16);
-      n_seen |= nm & 0xffffu;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int t = wd * 16 + j;
-        if (t < tlen) Tb[t] = (uint16_t)(((nm >> j) & 1u) ? (0xff00u | sc.wild) : ((cw >> (2 * j)) & 3u));
-      }
-    }
-    for (int wd = lane; wd < (qlen + 15) / 16; wd += 64) {
-      const uint32_t cw = qw[wd];
-      const uint32_t nm = qn[wd >> 1] >> ((wd & 1) * 16);
-      n_seen |= nm & 0xffffu;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int q = wd * 16 + j;
-        if (q < qlen) {
-          const uint16_t v = (uint16_t)(((nm >> j) & 1u) ? (0xff00u | sc.wild) : ((cw >> (2 * j)) & 3u));
-          const int e = qlen - 1 - q + 32;  // element index of QR[qlen-1-q] with the 32-element pad
-          QA[e] = v;
-          QB[e + 1] = v;
-        }
-      }
+    uint32_t n_seen = 0;
+    for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tn[k];
+    for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qn[k];
+    has_n = __any(n_seen != 0);  // wave-uniform: wildcard handling only where needed
+    for (int t = lane; t < tcap; t += 64) Tb[t] = t < tlen ? (uint16_t)pool_code16(tw, tn, t, sc.wild) : 0;
+    for (int j = lane; j < qcap; j += 64) {
+      const int e0 = j - 32, e1 = j - 31;  // QR indices; QR[e] = query[qlen-1-e], 0 outside
+      const uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
+      const uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
+      W[j] = v0 | (v1 << 16);
     }
   }
   __syncthreads();
-  const bool has_n = __any(n_seen != 0);  // wave-uniform: wildcard handling only where needed
 
   // ---- constants of the <<8 difference domain ----
   const unsigned qv = ((unsigned)sc.q_b << 8) * 0x00010001u;
@@ -195,8 +263,237 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   bool zero_low = false;  // slots below the reference window still hold x,v that must read as 0
   int32_t h_top = 0, h_under = 0;  // H of the top cell / of the cell the next top cell will read
   int32_t ez_score = SDF_NEG_INF, ez_mte = SDF_NEG_INF, ez_mte_q = -1, ez_zdropped = 0;
+  int drop_row = -1;  // row of the current block at which the reference window left slots 0..15
+  int r0 = 0;
 
-  for (int r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
+  // ------------------------------------------------------------------------------------------
+  // General row: every special case of the reference (first/last rows, boundary cell t = r,
+  // clipping by the sequence ends, carry-in artefacts).  Returns false when the band is exhausted.
+  // ------------------------------------------------------------------------------------------
+  auto slow_row = [&](const int r) -> bool {
+    Band b;
+    if (!band_of(r, qlen, tlen, w, b)) return false;
+    const int off_lo = b.lo - base;  // 0 or 16
+    const int off_hi = b.hi - base;  // last enabled slot
+    // the reference rebased at this row: slot off_lo's (r-1,t-1) neighbour is slot 15 (natural);
+    // on later rows that neighbour reads as 0
+    const bool ref_rebased = b.lo != prev_lo && prev_lo >= 0;
+    if (ref_rebased && off_lo == 16) drop_row = r;
+    if (off_lo == 16 && !ref_rebased && !zero_low) {
+      if (lane < 8) {
+        X[0] = 0u;
+        V[0] = 0u;
+      }
+      zero_low = true;
+    }
+    // ---- boundary cell t = r: y = 0, u = gap open (reference :122) ----
+    if (b.hi >= r) {
+      const int sr = r - base;
+      const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
+      const unsigned uval = r ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k)
+        if ((sr >> 7) == k && lane == ((sr & 127) >> 1)) {
+          U[k] = (U[k] & keep) | uval;
+          Y[k] &= keep;
+        }
+    }
+    // ---- (r-1, t-1) neighbours: shift x and v up by one slot ----
+    unsigned xt1[NREG], vt1[NREG];
+    {
+      // carry into slot 0: x = 0, v = gap open when the window starts at t = 0 (r > 0); the
+      // captured (r-1) values when the reference re-bases exactly at a block start
+      const unsigned vcarry = (base == 0 && r > 0) ? ((unsigned)sc.q_b << 24)
+                                                   : (r == r0 ? carry_v << 16 : 0u);
+      const unsigned xcarry = (base != 0 && r == r0) ? carry_x << 16 : 0u;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        unsigned xs, vs;
+        if (k == 0) {
+          xs = (unsigned)__builtin_amdgcn_update_dpp((int)xcarry, (int)X[0], 0x138, 0xf, 0xf, false);
+          vs = (unsigned)__builtin_amdgcn_update_dpp((int)vcarry, (int)V[0], 0x138, 0xf, 0xf, false);
+        } else {
+          const int x0 = __builtin_amdgcn_update_dpp(0, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+          const int v0 = __builtin_amdgcn_update_dpp(0, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+        }
+        xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
+        vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
+      }
+      // sign-extension artefact of the reference's carry-in (:145-146): a negative v carry also
+      // sets lanes 1..3 of the first block.  Only possible on the reference's rebase rows.
+      if (ref_rebased && off_lo == 16) {
+        const unsigned cvh = slot_half(V[0], 15);
+        if (cvh & 0x8000u) {
+          if (lane == 8) vt1[0] |= 0xff000000u;
+          if (lane == 9) vt1[0] |= 0xff00ff00u;
+        }
+      } else if (ref_rebased && r == r0 && (carry_v & 0x8000u)) {
+        if (lane == 0) vt1[0] |= 0xff000000u;
+        if (lane == 1) vt1[0] |= 0xff00ff00u;
+      }
+    }
+    // ---- scores: refresh [lo0, lo0 + 16*n), keep the old value elsewhere ----
+    {
+      const int ra = b.lo0 - base;
+      const int rb = ra + ((b.hi0 - b.lo0) / 16 + 1) * 16;
+      const int cq = qlen - 1 - r + base + 32;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        const int a_ = ra - 128 * k, b_ = rb - 128 * k;
+        if (b_ > 0 && a_ < 128) {
+          const unsigned qc = W[cq + 128 * k + 2 * lane];
+          unsigned z;
+          SDF_FRESH(z, Tc[k], qc)
+          if (a_ <= 0 && b_ >= 128) {
+            S[k] = z;
+          } else {
+            sel_lo16(S[k], z, lane_range((a_ + 1) >> 1, (b_ + 1) >> 1));
+            sel_hi16(S[k], z, lane_range(a_ >> 1, b_ >> 1));
+          }
+        }
+      }
+    }
+    // ---- the recurrence on the reference's widened range [lo, hi] ----
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int l0 = off_lo - 128 * k <= 0 ? 0 : (off_lo - 128 * k) >> 1;
+      const int l1 = (off_hi - 128 * k) >> 1;  // off_hi is odd
+      if (l1 >= l0 && l0 < 64) {
+        if ((unsigned)(lane - l0) <= (unsigned)(l1 - l0)) SDF_CORE(k)
+      }
+    }
+    // ---- exact H of the top cell and of the cell under the band edge (score, mte) ----
+    {
+      const int st = b.hi0 - base;  // slot of the top cell
+      unsigned uh = 0, vh = 0, vu = 0;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        if ((st >> 7) == k) {
+          uh = slot_half(U[k], st & 127);
+          vh = slot_half(V[k], st & 127);
+        }
+        if (st > 0 && ((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
+      }
+      const int32_t u8v = (int32_t)(uh >> 8), v8v = (int32_t)(vh >> 8), vu8 = (int32_t)(vu >> 8);
+      if (r == 0) {
+        h_top = v8v - 2 * sc.qe;
+      } else {
+        h_top = (b.hi0 > 0 ? h_under + u8v : h_top + v8v) - sc.qe;
+      }
+      // cell that row r+1's top cell will read: hi0(r+1) - 1
+      Band bn;
+      const bool nv = r + 1 < nrow && band_of(r + 1, qlen, tlen, w, bn);
+      const int hin = nv ? bn.hi0 : b.hi0;
+      if (hin == 0 || hin == b.hi0 + 1) {
+        h_under = h_top;
+      } else if (b.hi0 - 1 >= b.lo0 && r > 0) {
+        h_under += vu8 - sc.qe;
+      } else if (r == 0) {
+        h_under = h_top;
+      }
+      if (b.hi0 == tlen - 1 && h_top > ez_mte) {
+        ez_mte = h_top;
+        ez_mte_q = r - b.hi;
+      }
+      if (r == nrow - 1 && b.hi0 == tlen - 1) ez_score = h_top;
+    }
+    prev_lo = b.lo;
+    return true;
+  };
+
+  // ------------------------------------------------------------------------------------------
+  // Steady rows [rb, re): pure band regime (lo0 = (r-w+1)>>1, hi0 = (r+w)>>1 < tlen-1), window
+  // away from t = 0 and from the boundary cell t = r, constant reference band start (LOW16: it is
+  // base+16, slots 0..15 are out of the window).  Nothing but the recurrence remains; the few
+  // uniform quantities are recomputed per row with a handful of scalar instructions and all
+  // lane predicates are VALU compares (the scalar unit is shared by the CU's four SIMDs).
+  // ------------------------------------------------------------------------------------------
+  auto fast_rows = [&](const int rb, const int re, const bool low16) {
+    unsigned hacc = 0u;                                  // per-lane share of the H path sum
+    unsigned qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + 2 * lane));
+#pragma unroll 1
+    for (int r = rb; r < re; ++r) {
+      const int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
+      unsigned xt1[NREG], vt1[NREG];
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        unsigned xs, vs;
+        if (k == 0) {
+          xs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X[0], 0x138, 0xf, 0xf, true);
+          vs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)V[0], 0x138, 0xf, 0xf, true);
+        } else {
+          const int x0 = __builtin_amdgcn_update_dpp(0, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+          const int v0 = __builtin_amdgcn_update_dpp(0, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+        }
+        xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
+        vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
+      }
+      // scores
+      const int ra = lo0 - base;
+      const int rbb = ra + ((hi0 - lo0) & ~15) + 16;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        const int a_ = ra - 128 * k, b_ = rbb - 128 * k;
+        if (b_ > 0 && a_ < 128) {
+          const unsigned qc = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
+          unsigned z;
+          SDF_FRESH(z, Tc[k], qc)
+          if (a_ <= 0 && b_ >= 128) {
+            S[k] = z;
+          } else if (b_ >= 128) {  // lower edge of the refreshed range inside this register
+            sel_lo_ge(S[k], z, (a_ + 1) >> 1, lane);
+            sel_hi_ge(S[k], z, a_ >> 1, lane);
+          } else if (a_ <= 0) {    // upper edge
+            sel_lo_lt(S[k], z, (b_ + 1) >> 1, lane);
+            sel_hi_lt(S[k], z, b_ >> 1, lane);
+          } else {
+            sel_lo16(S[k], z, lane_range((a_ + 1) >> 1, (b_ + 1) >> 1));
+            sel_hi16(S[k], z, lane_range(a_ >> 1, b_ >> 1));
+          }
+        }
+      }
+      qaddr -= 4;
+      // recurrence: lanes of the reference window [lo, hi]
+      const int off_hi = (hi0 | 15) - base;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        const int l0 = (k == 0 && low16) ? 8 : 0;
+        const int l1 = (off_hi - 128 * k) >> 1;
+        if (l1 >= 63) {
+          if (l0 == 0) SDF_CORE(k)
+          else if (lane >= l0) SDF_CORE(k)
+        } else if (l1 >= l0) {
+          if (l0 == 0) {
+            if (lane <= l1) SDF_CORE(k)
+          } else if ((unsigned)(lane - l0) <= (unsigned)(l1 - l0)) SDF_CORE(k)
+        }
+      }
+      // H path: rows whose successor moves the top cell up read u of the top cell, the others
+      // read v of the cell under it.  Added up inside the owning lane, reduced once at the end.
+      {
+        const int odd = (r + w) & 1;
+        const int sl = hi0 - base - 1 + odd;  // slot to read
+        const int sh = ((sl & 1) << 4) + 8;
+        unsigned val = 0u;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k)
+          if ((sl >> 7) == k) val = odd ? U[k] : V[k];
+        if (lane == ((sl & 127) >> 1)) hacc += (val >> sh) & 0xffu;
+      }
+    }
+    // fold the lane-distributed sum back into the scalar path value
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
+    h_under += (int32_t)hacc - (re - rb) * sc.qe;
+    h_top = h_under;
+    prev_lo = base + (low16 ? 16 : 0);
+  };
+
+  for (r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
     // ---- block start: re-base the window to the reference's band start of this row ----
     {
       Band b0;
@@ -233,177 +530,47 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
       }
     }
     const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
-    int drop_row = -1;  // row of this block at which the reference window left slots 0..15
+    drop_row = -1;
     int r = r0;
-    for (; r < rend; ++r) {
-      Band b;
-      if (!band_of(r, qlen, tlen, w, b)) {
-        ez_zdropped = 1;
-        break;
+    // steady block?  (pure band regime on all 16 rows, no boundary cell, window away from t = 0)
+    const int rl = r0 + 15;
+    const bool steady = w >= 2 && r0 + 16 <= nrow && base >= 16 && ((r0 - w + 1) >> 1) >= 0 &&
+                        ((rl - w + 1) >> 1) >= rl - qlen + 1 && ((rl + w) >> 1) < tlen - 1 &&
+                        ((r0 + w) >> 1) + 15 < r0;
+    if (steady) {
+      // first row of this block at which the reference's band start moves to base + 16
+      int rr = 2 * (base + 16) + w - 1;
+      if (rr <= r0 || rr >= rend) rr = -1;
+      if ((carry_x | carry_v) != 0u) {
+        slow_row(r);
+        ++r;
       }
-      const int off_lo = b.lo - base;  // 0 or 16
-      const int off_hi = b.hi - base;  // last enabled slot
-      // the reference rebased at this row: slot off_lo's (r-1,t-1) neighbour is slot 15 (natural);
-      // on later rows that neighbour reads as 0
-      const bool ref_rebased = b.lo != prev_lo && prev_lo >= 0;
-      if (ref_rebased && off_lo == 16) drop_row = r;
-      if (off_lo == 16 && !ref_rebased && !zero_low) {
+      const int end1 = rr >= 0 ? rr : rend;
+      if (r < end1) fast_rows(r, end1, false);
+      r = end1;
+      if (rr >= 0) {
+        // the re-base row itself: natural neighbour, but mind the sign-extension artefact
+        if (slot_half(V[0], 15) & 0x8000u) {
+          slow_row(rr);
+        } else {
+          drop_row = rr;
+          fast_rows(rr, rr + 1, true);
+        }
         if (lane < 8) {
           X[0] = 0u;
           V[0] = 0u;
         }
         zero_low = true;
+        if (rr + 1 < rend) fast_rows(rr + 1, rend, true);
+        r = rend;
       }
-      // ---- boundary cell t = r: y = 0, u = gap open (reference :122) ----
-      if (b.hi >= r) {
-        const int sr = r - base;
-        const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
-        const unsigned uval = r ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
-#pragma unroll
-        for (int k = 0; k < NREG; ++k)
-          if ((sr >> 7) == k && lane == ((sr & 127) >> 1)) {
-            U[k] = (U[k] & keep) | uval;
-            Y[k] &= keep;
-          }
-      }
-      // ---- (r-1, t-1) neighbours: shift x and v up by one slot ----
-      unsigned xt1[NREG], vt1[NREG];
-      {
-        // carry into slot 0: only when the window starts at t = 0 (x = 0, v = gap open for r > 0)
-        const unsigned vcarry = (base == 0 && r > 0) ? ((unsigned)sc.q_b << 24)
-                                : (r == r0 ? carry_v << 16 : 0u);
-        const unsigned xcarry = (base != 0 && r == r0) ? carry_x << 16 : 0u;
-#pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          unsigned xs, vs;
-          if (k == 0) {
-            xs = (unsigned)__builtin_amdgcn_update_dpp((int)xcarry, (int)X[0], 0x138, 0xf, 0xf, false);
-            vs = (unsigned)__builtin_amdgcn_update_dpp((int)vcarry, (int)V[0], 0x138, 0xf, 0xf, false);
-          } else {
-            const int x0 = __builtin_amdgcn_update_dpp(0, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
-            xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-            const int v0 = __builtin_amdgcn_update_dpp(0, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
-            vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
-          }
-          xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
-          vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
-        }
-        // sign-extension artefact of the reference's carry-in (:145-146): a negative v carry also
-        // sets lanes 1..3 of the first block.  Only possible on the reference's rebase rows.
-        if (ref_rebased && off_lo == 16) {
-          const unsigned cvh = slot_half(V[0], 15);
-          if (cvh & 0x8000u) {
-            if (lane == 8) vt1[0] |= 0xff000000u;
-            if (lane == 9) vt1[0] |= 0xff00ff00u;
-          }
-        } else if (ref_rebased && r == r0 && (carry_v & 0x8000u)) {
-          if (lane == 0) vt1[0] |= 0xff000000u;
-          if (lane == 1) vt1[0] |= 0xff00ff00u;
+    } else {
+      for (; r < rend; ++r) {
+        if (!slow_row(r)) {
+          ez_zdropped = 1;
+          break;
         }
       }
-      // ---- scores: refresh [lo0, lo0 + 16*n), keep the old value elsewhere ----
-      {
-        const int ra = b.lo0 - base;
-        const int rb = ra + ((b.hi0 - b.lo0) / 16 + 1) * 16;
-        const int cq = qlen - 1 - r + base + 32;
-        const uint16_t *qp = (cq & 1) ? QB + cq + 1 : QA + cq;
-#pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          const int a_ = ra - 128 * k, b_ = rb - 128 * k;
-          if (b_ > 0 && a_ < 128) {
-            const unsigned qc = *reinterpret_cast<const uint32_t *>(qp + 128 * k + 2 * lane);
-            unsigned d = pk_sub(Tc[k], qc);
-            SDF_OPQ(d);
-            const unsigned m = pk_nonzero(d);
-            unsigned z = pk_mad(m, z_delta, z_match);
-            if (has_n) {
-              unsigned nn = pk_ashr15(Tc[k] | qc);
-              SDF_OPQ(nn);
-              z = (z_wild & nn) | (z & ~nn);
-            }
-            if (a_ <= 0 && b_ >= 128) {
-              S[k] = z;
-            } else {
-              sel_lo16(S[k], z, lane_range((a_ + 1) >> 1, (b_ + 1) >> 1));
-              sel_hi16(S[k], z, lane_range(a_ >> 1, b_ >> 1));
-            }
-          }
-        }
-      }
-      // ---- the recurrence on the reference's widened range [lo, hi] ----
-#pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        const int l0 = off_lo - 128 * k <= 0 ? 0 : (off_lo - 128 * k) >> 1;
-        const int l1 = (off_hi - 128 * k) >> 1;  // off_hi is odd
-        if (l1 >= l0 && l0 < 64) {
-          if ((unsigned)(lane - l0) <= (unsigned)(l1 - l0)) {
-            const unsigned a = pk_add(xt1[k], vt1[k]);
-            const unsigned bb = pk_add(Y[k], U[k]);
-            const unsigned z0 = S[k];
-            const unsigned z1 = pk_maxi(z0, a);
-            unsigned fa = pk_sub(z1, z0);  // != 0 <=> a > z (signed)
-            SDF_OPQ(fa);
-            const unsigned zb = pk_maxi(z1, bb);
-            unsigned fb = pk_sub(zb, z1);  // != 0 <=> b > max(z, a) (signed)
-            SDF_OPQ(fb);
-            const unsigned z2 = pk_maxu(z1, bb);
-            const unsigned z3 = pk_minu(z2, capv);
-            const unsigned un = pk_sub(z3, vt1[k]);
-            const unsigned vn = pk_sub(z3, U[k]);
-            const unsigned zq = pk_sub(z3, qv);
-            const unsigned a2 = pk_sub(a, zq);
-            const unsigned b2 = pk_sub(bb, zq);
-            unsigned xn = pk_maxi(a2, 0u);
-            unsigned yn = pk_maxi(b2, 0u);
-            U[k] = un;
-            V[k] = vn;
-            X[k] = xn;
-            Y[k] = yn;
-            SDF_OPQ(xn);
-            SDF_OPQ(yn);
-            Fa[k] = (Fa[k] << 1) | pk_nonzero(fa);
-            Fb[k] = (Fb[k] << 1) | pk_nonzero(fb);
-            Fx[k] = (Fx[k] << 1) | pk_nonzero(xn);
-            Fy[k] = (Fy[k] << 1) | pk_nonzero(yn);
-          }
-        }
-      }
-      // ---- exact H of the top cell and of the cell under the band edge (score, mte) ----
-      {
-        const int st = b.hi0 - base;  // slot of the top cell
-        unsigned uh = 0, vh = 0, vu = 0;
-#pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          if ((st >> 7) == k) {
-            uh = slot_half(U[k], st & 127);
-            vh = slot_half(V[k], st & 127);
-          }
-          if (st > 0 && ((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
-        }
-        const int32_t u8v = (int32_t)(uh >> 8), v8v = (int32_t)(vh >> 8), vu8 = (int32_t)(vu >> 8);
-        if (r == 0) {
-          h_top = v8v - 2 * sc.qe;
-        } else {
-          h_top = (b.hi0 > 0 ? h_under + u8v : h_top + v8v) - sc.qe;
-        }
-        // cell that row r+1's top cell will read: hi0(r+1) - 1
-        Band bn;
-        const bool nv = r + 1 < nrow && band_of(r + 1, qlen, tlen, w, bn);
-        const int hin = nv ? bn.hi0 : b.hi0;
-        if (hin == 0 || hin == b.hi0 + 1) {
-          h_under = h_top;
-        } else if (b.hi0 - 1 >= b.lo0 && r > 0) {
-          h_under += vu8 - sc.qe;
-        } else if (r == 0) {
-          h_under = h_top;
-        }
-        if (b.hi0 == tlen - 1 && h_top > ez_mte) {
-          ez_mte = h_top;
-          ez_mte_q = r - b.hi;
-        }
-        if (r == nrow - 1 && b.hi0 == tlen - 1) ez_score = h_top;
-      }
-      prev_lo = b.lo;
     }
     // ---- block end: direction flags of these (<=16) rows leave for HBM ----
     if (with_dir) {
@@ -416,17 +583,19 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
         Fx[0] = pk_shl(Fx[0], sh);
         Fy[0] = pk_shl(Fy[0], sh);
       }
+      if (done > 0) {
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        unsigned fa = Fa[k], fb = Fb[k], fx = Fx[k], fy = Fy[k];
-        if (done < 16) {
-          const unsigned sh = 16 - done;
-          fa = pk_shl(fa, sh);
-          fb = pk_shl(fb, sh);
-          fx = pk_shl(fx, sh);
-          fy = pk_shl(fy, sh);
+        for (int k = 0; k < NREG; ++k) {
+          unsigned fa = Fa[k], fb = Fb[k], fx = Fx[k], fy = Fy[k];
+          if (done < 16) {
+            const unsigned sh = 16 - done;
+            fa = pk_shl(fa, sh);
+            fb = pk_shl(fb, sh);
+            fx = pk_shl(fx, sh);
+            fy = pk_shl(fy, sh);
+          }
+          dir[((int64_t)rbk * NREG + k) * 64 + lane] = make_uint4(fa, fb, fx, fy);
         }
-        dir[((int64_t)rbk * NREG + k) * 64 + lane] = make_uint4(fa, fb, fx, fy);
       }
     }
 #pragma unroll
@@ -460,8 +629,8 @@ template __global__ void extz2_wave_kernel<4>(const PlanTask *, const int32_t *,
 size_t wave_lds_bytes(int qlen, int tlen, int nreg) {
   const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
   const size_t tcap = T16 + 128 * nreg + 32;
-  const size_t qcap = ((size_t)qlen + 128 * nreg + 36 + 1) & ~(size_t)1;
-  return 2 * (tcap + 2 * qcap);
+  const size_t qcap = (size_t)qlen + 128 * nreg + 36;
+  return 2 * tcap + 4 * qcap;
 }
 
 }  // namespace sdf
