@@ -31,6 +31,8 @@
 // gaps, extension-only traceback.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "sdf_internal.h"
 
 namespace sdf {
@@ -141,6 +143,26 @@ __device__ __forceinline__ void sel_hi_lt(unsigned &dst, unsigned src, int thr, 
       "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
       "src1_sel:WORD_1\n\ts_nop 0"
       : "+v"(dst) : "v"(src), "s"(thr), "v"(lane) : "vcc");
+}
+
+// two-sided: lanes in [lo, hi)
+__device__ __forceinline__ void sel_lo_rng(unsigned &dst, unsigned src, int lo, int hi, int lane) {
+  unsigned t;
+  asm volatile(
+      "v_subrev_u32 %1, %3, %5\n\t"
+      "v_cmp_gt_u32 vcc, %4, %1\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %2, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\ts_nop 0"
+      : "+v"(dst), "=&v"(t) : "v"(src), "s"(lo), "s"(hi > lo ? hi - lo : 0), "v"(lane) : "vcc");
+}
+__device__ __forceinline__ void sel_hi_rng(unsigned &dst, unsigned src, int lo, int hi, int lane) {
+  unsigned t;
+  asm volatile(
+      "v_subrev_u32 %1, %3, %5\n\t"
+      "v_cmp_gt_u32 vcc, %4, %1\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %2, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1\n\ts_nop 0"
+      : "+v"(dst), "=&v"(t) : "v"(src), "s"(lo), "s"(hi > lo ? hi - lo : 0), "v"(lane) : "vcc");
 }
 
 __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uint32_t *nmask, int k,
@@ -405,14 +427,21 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
 
   // ------------------------------------------------------------------------------------------
   // Steady rows [rb, re): pure band regime (lo0 = (r-w+1)>>1, hi0 = (r+w)>>1 < tlen-1), window
-  // away from t = 0 and from the boundary cell t = r, constant reference band start (LOW16: it is
-  // base+16, slots 0..15 are out of the window).  Nothing but the recurrence remains; the few
-  // uniform quantities are recomputed per row with a handful of scalar instructions and all
-  // lane predicates are VALU compares (the scalar unit is shared by the CU's four SIMDs).
+  // away from t = 0 and from the boundary cell t = r, and -- within one call -- a constant
+  // reference window [base + (LOW16 ? 16 : 0), hi].  Register 0 holds the lower edge of the
+  // refreshed score range, register NREG-1 its upper edge and the window top.  Lanes above the
+  // window top are NOT masked: they compute values nobody reads (the neighbour dependency only
+  // runs upwards) and are zeroed when the window grows over them.  Nothing but the recurrence
+  // remains; the few uniform quantities are recomputed per row with a handful of scalar
+  // instructions and every lane predicate is a VALU compare (the scalar unit is shared by the
+  // CU's four SIMDs and was the bottleneck of the general row).
   // ------------------------------------------------------------------------------------------
-  auto fast_rows = [&](const int rb, const int re, const bool low16) {
-    unsigned hacc = 0u;                                  // per-lane share of the H path sum
+  auto fast_rows = [&](auto low16_c, const int rb, const int re) {
+    constexpr bool LOW16 = decltype(low16_c)::value;
+    constexpr int KT = NREG - 1;
+    unsigned hacc = 0u;  // per-lane share of the H path sum
     unsigned qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + 2 * lane));
+    const int base_top = base + 128 * KT;
 #pragma unroll 1
     for (int r = rb; r < re; ++r) {
       const int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
@@ -432,56 +461,44 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
         xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
         vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
       }
-      // scores
+      // scores: refreshed slots are [ra, rbt + 128*KT)
       const int ra = lo0 - base;
-      const int rbb = ra + ((hi0 - lo0) & ~15) + 16;
+      const int rbt = lo0 + ((hi0 - lo0) & ~15) + 16 - base_top;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
-        const int a_ = ra - 128 * k, b_ = rbb - 128 * k;
-        if (b_ > 0 && a_ < 128) {
-          const unsigned qc = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
-          unsigned z;
-          SDF_FRESH(z, Tc[k], qc)
-          if (a_ <= 0 && b_ >= 128) {
-            S[k] = z;
-          } else if (b_ >= 128) {  // lower edge of the refreshed range inside this register
-            sel_lo_ge(S[k], z, (a_ + 1) >> 1, lane);
-            sel_hi_ge(S[k], z, a_ >> 1, lane);
-          } else if (a_ <= 0) {    // upper edge
-            sel_lo_lt(S[k], z, (b_ + 1) >> 1, lane);
-            sel_hi_lt(S[k], z, b_ >> 1, lane);
-          } else {
-            sel_lo16(S[k], z, lane_range((a_ + 1) >> 1, (b_ + 1) >> 1));
-            sel_hi16(S[k], z, lane_range(a_ >> 1, b_ >> 1));
-          }
+        const unsigned qc = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
+        unsigned z;
+        SDF_FRESH(z, Tc[k], qc)
+        if (NREG == 1) {
+          sel_lo_rng(S[0], z, (ra + 1) >> 1, (rbt + 1) >> 1, lane);
+          sel_hi_rng(S[0], z, ra >> 1, rbt >> 1, lane);
+        } else if (k == 0) {
+          sel_lo_ge(S[0], z, (ra + 1) >> 1, lane);
+          sel_hi_ge(S[0], z, ra >> 1, lane);
+        } else if (k == KT) {
+          sel_lo_lt(S[k], z, (rbt + 1) >> 1, lane);
+          sel_hi_lt(S[k], z, rbt >> 1, lane);
+        } else {
+          S[k] = z;
         }
       }
       qaddr -= 4;
-      // recurrence: lanes of the reference window [lo, hi]
-      const int off_hi = (hi0 | 15) - base;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
-        const int l0 = (k == 0 && low16) ? 8 : 0;
-        const int l1 = (off_hi - 128 * k) >> 1;
-        if (l1 >= 63) {
-          if (l0 == 0) SDF_CORE(k)
-          else if (lane >= l0) SDF_CORE(k)
-        } else if (l1 >= l0) {
-          if (l0 == 0) {
-            if (lane <= l1) SDF_CORE(k)
-          } else if ((unsigned)(lane - l0) <= (unsigned)(l1 - l0)) SDF_CORE(k)
+        if (k == 0 && LOW16) {
+          if (lane >= 8) SDF_CORE(0)
+        } else {
+          SDF_CORE(k)
         }
       }
       // H path: rows whose successor moves the top cell up read u of the top cell, the others
       // read v of the cell under it.  Added up inside the owning lane, reduced once at the end.
       {
         const int odd = (r + w) & 1;
-        const int sl = hi0 - base - 1 + odd;  // slot to read
+        const int sl = hi0 - base_top - 1 + odd;  // slot to read, relative to register KT
         const int sh = ((sl & 1) << 4) + 8;
-        unsigned val = 0u;
-#pragma unroll
-        for (int k = 0; k < NREG; ++k)
-          if ((sl >> 7) == k) val = odd ? U[k] : V[k];
+        unsigned val = odd ? U[KT] : V[KT];
+        if (NREG > 1 && sl < 0) val = odd ? U[KT > 0 ? KT - 1 : 0] : V[KT > 0 ? KT - 1 : 0];
         if (lane == ((sl & 127) >> 1)) hacc += (val >> sh) & 0xffu;
       }
     }
@@ -490,7 +507,17 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
     h_under += (int32_t)hacc - (re - rb) * sc.qe;
     h_top = h_under;
-    prev_lo = base + (low16 ? 16 : 0);
+    prev_lo = base + (LOW16 ? 16 : 0);
+  };
+  // lanes of register KT above `l1` hold scratch values after fast rows: make them "never computed"
+  auto zero_above = [&](const int l1_from, const int l1_to) {  // lanes (l1_from, l1_to]
+    constexpr int KT = NREG - 1;
+    if (lane > l1_from && lane <= l1_to) {
+      U[KT] = 0u;
+      V[KT] = 0u;
+      X[KT] = 0u;
+      Y[KT] = 0u;
+    }
   };
 
   for (r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
@@ -532,38 +559,69 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
     drop_row = -1;
     int r = r0;
-    // steady block?  (pure band regime on all 16 rows, no boundary cell, window away from t = 0)
+    // steady block?  pure band regime on all 16 rows, no boundary cell, window away from t = 0,
+    // lower edge of the refreshed range in register 0, upper edge and window top in register KT
     const int rl = r0 + 15;
-    const bool steady = w >= 2 && r0 + 16 <= nrow && base >= 16 && ((r0 - w + 1) >> 1) >= 0 &&
-                        ((rl - w + 1) >> 1) >= rl - qlen + 1 && ((rl + w) >> 1) < tlen - 1 &&
-                        ((r0 + w) >> 1) + 15 < r0;
+    constexpr int KT = NREG - 1;
+    bool steady = w >= 2 && r0 + 16 <= nrow && base >= 16 && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
+                  ((rl + w) >> 1) < tlen - 1 && ((r0 + w) >> 1) + 15 < r0;
     if (steady) {
-      // first row of this block at which the reference's band start moves to base + 16
+      const int lo0a = (r0 - w + 1) >> 1, lo0b = (rl - w + 1) >> 1;
+      const int hi0a = (r0 + w) >> 1;
+      steady = lo0b - base < 128 &&                         // refresh start stays in register 0
+               lo0a + ((w - 1) & ~15) + 16 - base >= 128 * KT &&  // refresh end reaches register KT
+               (hi0a | 15) - base >= 128 * KT &&            // so does the window top
+               hi0a - 1 - base >= 128 * KT - 128;           // H path cell in register KT or KT-1
+      if (NREG > 2) steady = steady && lo0a + ((w - 1) & ~15) + 16 - base >= 128 * KT + 0;
+    }
+    if (steady) {
+      // rows of this block at which the reference window changes: its start moves to base + 16 ...
       int rr = 2 * (base + 16) + w - 1;
       if (rr <= r0 || rr >= rend) rr = -1;
+      // ... and its end grows by one 16-cell block (hi0 reaches the next multiple of 16)
+      const int hi_first = ((r0 + w) >> 1) | 15;
+      int rh = 2 * (hi_first + 1) - w;
+      if (rh <= r0 || rh >= rend) rh = -1;
+      int l1 = (hi_first - base - 128 * KT) >> 1;  // last window lane of register KT
       if ((carry_x | carry_v) != 0u) {
         slow_row(r);
         ++r;
       }
-      const int end1 = rr >= 0 ? rr : rend;
-      if (r < end1) fast_rows(r, end1, false);
-      r = end1;
-      if (rr >= 0) {
-        // the re-base row itself: natural neighbour, but mind the sign-extension artefact
-        if (slot_half(V[0], 15) & 0x8000u) {
-          slow_row(rr);
-        } else {
-          drop_row = rr;
-          fast_rows(rr, rr + 1, true);
+      bool low16 = false;
+      while (r < rend) {
+        int stop = rend;
+        if (rr > r && rr < stop) stop = rr;
+        if (rh > r && rh < stop) stop = rh;
+        if (r == rh) {  // window grows: lanes l1+1 .. l1+8 enter as "never computed"
+          zero_above(l1, l1 + 8);
+          l1 += 8;
+          if (rr == r) stop = r;  // both events on one row: fall through to the rr handling
         }
-        if (lane < 8) {
-          X[0] = 0u;
-          V[0] = 0u;
+        if (r == rr) {
+          // the re-base row itself: natural neighbour, but mind the sign-extension artefact
+          if (slot_half(V[0], 15) & 0x8000u) {
+            zero_above(l1, 63);
+            slow_row(rr);
+          } else {
+            drop_row = rr;
+            fast_rows(std::true_type{}, rr, rr + 1);
+          }
+          if (lane < 8) {
+            X[0] = 0u;
+            V[0] = 0u;
+          }
+          zero_low = true;
+          low16 = true;
+          r = rr + 1;
+          continue;
         }
-        zero_low = true;
-        if (rr + 1 < rend) fast_rows(rr + 1, rend, true);
-        r = rend;
+        if (stop > r) {
+          if (low16) fast_rows(std::true_type{}, r, stop);
+          else fast_rows(std::false_type{}, r, stop);
+          r = stop;
+        }
       }
+      zero_above(l1, 63);  // hand clean "never computed" lanes back to the general rows
     } else {
       for (; r < rend; ++r) {
         if (!slow_row(r)) {
