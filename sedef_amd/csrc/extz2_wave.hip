@@ -62,9 +62,14 @@ __device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) {
 }
 // min(x, 1) per half = "x != 0" as 0/1.  Written as the instruction itself: the optimiser would
 // otherwise turn it into per-half compares + selects.
-__device__ __forceinline__ unsigned pk_nonzero(unsigned a) {
+__device__ __forceinline__ unsigned pk_nonzero_(unsigned a, unsigned one_opaque) {
+  return pk_minu(a, one_opaque);
+}
+#define pk_nonzero(a) pk_nonzero_((a), one2)
+// F <- (F << 1) | bit, as the single instruction it is
+__device__ __forceinline__ unsigned shl1_or(unsigned f, unsigned bit) {
   unsigned d;
-  asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+  asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(d) : "v"(f), "v"(bit));
   return d;
 }
 __device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
@@ -180,11 +185,9 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
     const unsigned bb_ = pk_add(Y[k], U[k]);                            \
     const unsigned z0_ = S[k];                                          \
     const unsigned z1_ = pk_maxi(z0_, a_);                              \
-    unsigned fa_ = pk_sub(z1_, z0_); /* != 0 <=> a > z (signed) */      \
-    SDF_OPQ(fa_);                                                       \
+    const unsigned fa_ = pk_sub(z1_, z0_); /* != 0 <=> a > z (signed) */ \
     const unsigned zb_ = pk_maxi(z1_, bb_);                             \
-    unsigned fb_ = pk_sub(zb_, z1_); /* != 0 <=> b > max(z,a) */        \
-    SDF_OPQ(fb_);                                                       \
+    const unsigned fb_ = pk_sub(zb_, z1_); /* != 0 <=> b > max(z,a) */  \
     const unsigned z2_ = pk_maxu(z1_, bb_);                             \
     const unsigned z3_ = pk_minu(z2_, capv);                            \
     const unsigned un_ = pk_sub(z3_, vt1[k]);                           \
@@ -192,25 +195,22 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
     const unsigned zq_ = pk_sub(z3_, qv);                               \
     const unsigned a2_ = pk_sub(a_, zq_);                               \
     const unsigned b2_ = pk_sub(bb_, zq_);                              \
-    unsigned xn_ = pk_maxi(a2_, 0u);                                    \
-    unsigned yn_ = pk_maxi(b2_, 0u);                                    \
+    const unsigned xn_ = pk_maxi(a2_, 0u);                              \
+    const unsigned yn_ = pk_maxi(b2_, 0u);                              \
     U[k] = un_;                                                         \
     V[k] = vn_;                                                         \
     X[k] = xn_;                                                         \
     Y[k] = yn_;                                                         \
-    SDF_OPQ(xn_);                                                       \
-    SDF_OPQ(yn_);                                                       \
-    Fa[k] = (Fa[k] << 1) | pk_nonzero(fa_);                             \
-    Fb[k] = (Fb[k] << 1) | pk_nonzero(fb_);                             \
-    Fx[k] = (Fx[k] << 1) | pk_nonzero(xn_);                             \
-    Fy[k] = (Fy[k] << 1) | pk_nonzero(yn_);                             \
+    Fa[k] = shl1_or(Fa[k], pk_nonzero(fa_));                            \
+    Fb[k] = shl1_or(Fb[k], pk_nonzero(fb_));                            \
+    Fx[k] = shl1_or(Fx[k], pk_nonzero(xn_));                            \
+    Fy[k] = shl1_or(Fy[k], pk_nonzero(yn_));                            \
   }
 
 // fresh (score + 2(q+e)) << 8 of the two cells of a lane from their target / query codes
 #define SDF_FRESH(z, tc, qc)                                            \
   {                                                                     \
-    unsigned d_ = pk_sub(tc, qc);                                       \
-    SDF_OPQ(d_);                                                        \
+    const unsigned d_ = pk_sub(tc, qc);                                 \
     const unsigned m_ = pk_nonzero(d_);                                 \
     z = pk_mad(m_, z_delta, z_match);                                   \
     if (has_n) {                                                        \
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     uint32_t n_seen = 0;
     for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tn[k];
     for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qn[k];
-    has_n = __any(n_seen != 0);  // wave-uniform: wildcard handling only where needed
+    has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0)) != 0;  // wave-uniform
     for (int t = lane; t < tcap; t += 64) Tb[t] = t < tlen ? (uint16_t)pool_code16(tw, tn, t, sc.wild) : 0;
     for (int j = lane; j < qcap; j += 64) {
       const int e0 = j - 32, e1 = j - 31;  // QR indices; QR[e] = query[qlen-1-e], 0 outside
@@ -263,6 +263,8 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
   const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
   const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
+  unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16
+  SDF_OPQ(one2);
 
   unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], Tc[NREG];
   unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
@@ -442,9 +444,19 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     unsigned hacc = 0u;  // per-lane share of the H path sum
     unsigned qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + 2 * lane));
     const int base_top = base + 128 * KT;
+    unsigned qnext[NREG];  // query codes of the row about to be computed (loaded one row ahead)
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
 #pragma unroll 1
     for (int r = rb; r < re; ++r) {
       const int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
+      unsigned qcur[NREG];
+      qaddr -= 4;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        qcur[k] = qnext[k];
+        qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
+      }
       unsigned xt1[NREG], vt1[NREG];
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
@@ -453,9 +465,12 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
           xs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X[0], 0x138, 0xf, 0xf, true);
           vs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)V[0], 0x138, 0xf, 0xf, true);
         } else {
-          const int x0 = __builtin_amdgcn_update_dpp(0, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          int ux, uv;  // lanes 1..63 are overwritten by the second move: no initial value needed
+          asm("" : "=v"(ux));
+          asm("" : "=v"(uv));
+          const int x0 = __builtin_amdgcn_update_dpp(ux, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
           xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-          const int v0 = __builtin_amdgcn_update_dpp(0, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          const int v0 = __builtin_amdgcn_update_dpp(uv, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
           vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
         }
         xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
       const int rbt = lo0 + ((hi0 - lo0) & ~15) + 16 - base_top;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
-        const unsigned qc = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
+        const unsigned qc = qcur[k];
         unsigned z;
         SDF_FRESH(z, Tc[k], qc)
         if (NREG == 1) {
@@ -482,7 +497,6 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
           S[k] = z;
         }
       }
-      qaddr -= 4;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
         if (k == 0 && LOW16) {
@@ -497,8 +511,12 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
         const int odd = (r + w) & 1;
         const int sl = hi0 - base_top - 1 + odd;  // slot to read, relative to register KT
         const int sh = ((sl & 1) << 4) + 8;
-        unsigned val = odd ? U[KT] : V[KT];
-        if (NREG > 1 && sl < 0) val = odd ? U[KT > 0 ? KT - 1 : 0] : V[KT > 0 ? KT - 1 : 0];
+        unsigned val;
+        if (NREG > 1 && sl < 0) {
+          if (odd) val = U[KT > 0 ? KT - 1 : 0]; else val = V[KT > 0 ? KT - 1 : 0];
+        } else {
+          if (odd) val = U[KT]; else val = V[KT];
+        }
         if (lane == ((sl & 127) >> 1)) hacc += (val >> sh) & 0xffu;
       }
     }
