@@ -295,13 +295,19 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   // clipping by the sequence ends, carry-in artefacts).  Returns false when the band is exhausted.
   // ------------------------------------------------------------------------------------------
   auto slow_row = [&](const int r) -> bool {
-    Band b;
-    if (!band_of(r, qlen, tlen, w, b)) return false;
-    const int off_lo = b.lo - base;  // 0 or 16
-    const int off_hi = b.hi - base;  // last enabled slot
+    // band of this row (reference :101-115); eligibility guarantees it is never empty
+    int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
+    lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
+    lo0 = lo0 < 0 ? 0 : lo0;
+    hi0 = hi0 > r ? r : hi0;
+    hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
+    if (lo0 > hi0) return false;
+    const int lo = lo0 & ~15, hi = hi0 | 15;
+    const int off_lo = lo - base;  // 0 or 16
+    const int off_hi = hi - base;  // last enabled slot
     // the reference rebased at this row: slot off_lo's (r-1,t-1) neighbour is slot 15 (natural);
     // on later rows that neighbour reads as 0
-    const bool ref_rebased = b.lo != prev_lo && prev_lo >= 0;
+    const bool ref_rebased = lo != prev_lo && prev_lo >= 0;
     if (ref_rebased && off_lo == 16) drop_row = r;
     if (off_lo == 16 && !ref_rebased && !zero_low) {
       if (lane < 8) {
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
       zero_low = true;
     }
     // ---- boundary cell t = r: y = 0, u = gap open (reference :122) ----
-    if (b.hi >= r) {
+    if (hi >= r) {
       const int sr = r - base;
       const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
       const unsigned uval = r ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
@@ -337,9 +343,12 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
           xs = (unsigned)__builtin_amdgcn_update_dpp((int)xcarry, (int)X[0], 0x138, 0xf, 0xf, false);
           vs = (unsigned)__builtin_amdgcn_update_dpp((int)vcarry, (int)V[0], 0x138, 0xf, 0xf, false);
         } else {
-          const int x0 = __builtin_amdgcn_update_dpp(0, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          int ux, uv;
+          asm("" : "=v"(ux));
+          asm("" : "=v"(uv));
+          const int x0 = __builtin_amdgcn_update_dpp(ux, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
           xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-          const int v0 = __builtin_amdgcn_update_dpp(0, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          const int v0 = __builtin_amdgcn_update_dpp(uv, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
           vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
         }
         xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
@@ -347,21 +356,23 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
       }
       // sign-extension artefact of the reference's carry-in (:145-146): a negative v carry also
       // sets lanes 1..3 of the first block.  Only possible on the reference's rebase rows.
-      if (ref_rebased && off_lo == 16) {
-        const unsigned cvh = slot_half(V[0], 15);
-        if (cvh & 0x8000u) {
-          if (lane == 8) vt1[0] |= 0xff000000u;
-          if (lane == 9) vt1[0] |= 0xff00ff00u;
+      if (ref_rebased) {
+        if (off_lo == 16) {
+          const unsigned cvh = slot_half(V[0], 15);
+          if (cvh & 0x8000u) {
+            if (lane == 8) vt1[0] |= 0xff000000u;
+            if (lane == 9) vt1[0] |= 0xff00ff00u;
+          }
+        } else if (r == r0 && (carry_v & 0x8000u)) {
+          if (lane == 0) vt1[0] |= 0xff000000u;
+          if (lane == 1) vt1[0] |= 0xff00ff00u;
         }
-      } else if (ref_rebased && r == r0 && (carry_v & 0x8000u)) {
-        if (lane == 0) vt1[0] |= 0xff000000u;
-        if (lane == 1) vt1[0] |= 0xff00ff00u;
       }
     }
     // ---- scores: refresh [lo0, lo0 + 16*n), keep the old value elsewhere ----
     {
-      const int ra = b.lo0 - base;
-      const int rb = ra + ((b.hi0 - b.lo0) / 16 + 1) * 16;
+      const int ra = lo0 - base;
+      const int rb = ra + ((hi0 - lo0) & ~15) + 16;
       const int cq = qlen - 1 - r + base + 32;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
@@ -373,8 +384,8 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
           if (a_ <= 0 && b_ >= 128) {
             S[k] = z;
           } else {
-            sel_lo16(S[k], z, lane_range((a_ + 1) >> 1, (b_ + 1) >> 1));
-            sel_hi16(S[k], z, lane_range(a_ >> 1, b_ >> 1));
+            sel_lo_rng(S[k], z, (a_ + 1) >> 1, (b_ + 1) >> 1, lane);
+            sel_hi_rng(S[k], z, a_ >> 1, b_ >> 1, lane);
           }
         }
       }
@@ -390,40 +401,37 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     }
     // ---- exact H of the top cell and of the cell under the band edge (score, mte) ----
     {
-      const int st = b.hi0 - base;  // slot of the top cell
-      unsigned uh = 0, vh = 0, vu = 0;
+      const int st = hi0 - base;  // slot of the top cell
+      unsigned uh = 0, vu = 0;
+      // next row's top cell: does it move up?
+      int hin = (r + 1 + w) >> 1;
+      hin = hin > r + 1 ? r + 1 : hin;
+      hin = hin > tlen - 1 ? tlen - 1 : hin;
+      const bool up = hin == hi0 + 1 || hin == 0;
+      const bool want_top = up || hi0 == tlen - 1 || hi0 == 0;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
-        if ((st >> 7) == k) {
-          uh = slot_half(U[k], st & 127);
-          vh = slot_half(V[k], st & 127);
+        if (want_top && (st >> 7) == k) uh = hi0 > 0 ? slot_half(U[k], st & 127) : slot_half(V[k], st & 127);
+        if (!up && st > 0 && ((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
+      }
+      if (want_top) {
+        if (r == 0) h_top = (int32_t)(uh >> 8) - 2 * sc.qe;
+        else h_top = (hi0 > 0 ? h_under : h_top) + (int32_t)(uh >> 8) - sc.qe;
+      }
+      if (up || r == 0) {
+        h_under = h_top;
+      } else if (hi0 - 1 >= lo0) {
+        h_under += (int32_t)(vu >> 8) - sc.qe;
+      }
+      if (hi0 == tlen - 1) {
+        if (h_top > ez_mte) {
+          ez_mte = h_top;
+          ez_mte_q = r - hi;
         }
-        if (st > 0 && ((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
+        if (r == nrow - 1) ez_score = h_top;
       }
-      const int32_t u8v = (int32_t)(uh >> 8), v8v = (int32_t)(vh >> 8), vu8 = (int32_t)(vu >> 8);
-      if (r == 0) {
-        h_top = v8v - 2 * sc.qe;
-      } else {
-        h_top = (b.hi0 > 0 ? h_under + u8v : h_top + v8v) - sc.qe;
-      }
-      // cell that row r+1's top cell will read: hi0(r+1) - 1
-      Band bn;
-      const bool nv = r + 1 < nrow && band_of(r + 1, qlen, tlen, w, bn);
-      const int hin = nv ? bn.hi0 : b.hi0;
-      if (hin == 0 || hin == b.hi0 + 1) {
-        h_under = h_top;
-      } else if (b.hi0 - 1 >= b.lo0 && r > 0) {
-        h_under += vu8 - sc.qe;
-      } else if (r == 0) {
-        h_under = h_top;
-      }
-      if (b.hi0 == tlen - 1 && h_top > ez_mte) {
-        ez_mte = h_top;
-        ez_mte_q = r - b.hi;
-      }
-      if (r == nrow - 1 && b.hi0 == tlen - 1) ez_score = h_top;
     }
-    prev_lo = b.lo;
+    prev_lo = lo;
     return true;
   };
 
