@@ -170,6 +170,28 @@ __device__ __forceinline__ void sel_hi_rng(unsigned &dst, unsigned src, int lo, 
       : "+v"(dst), "=&v"(t) : "v"(src), "s"(lo), "s"(hi > lo ? hi - lo : 0), "v"(lane) : "vcc");
 }
 
+// both halves of one register: lo half where thr_lo <= lane, hi half where thr_hi <= lane
+__device__ __forceinline__ void sel2_ge(unsigned &dst, unsigned src, int thr_lo, int thr_hi, int lane) {
+  asm volatile(
+      "v_cmp_le_i32 vcc, %2, %4\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\t"
+      "v_cmp_le_i32 vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1"
+      : "+v"(dst) : "v"(src), "s"(thr_lo), "s"(thr_hi), "v"(lane) : "vcc");
+}
+__device__ __forceinline__ void sel2_lt(unsigned &dst, unsigned src, int thr_lo, int thr_hi, int lane) {
+  asm volatile(
+      "v_cmp_gt_i32 vcc, %2, %4\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\t"
+      "v_cmp_gt_i32 vcc, %3, %4\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1"
+      : "+v"(dst) : "v"(src), "s"(thr_lo), "s"(thr_hi), "v"(lane) : "vcc");
+}
+
 __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uint32_t *nmask, int k,
                                                 uint32_t wild) {
   const uint32_t c = (codes[k >> 4] >> ((k & 15) * 2)) & 3u;
@@ -212,7 +234,7 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
   {                                                                     \
     const unsigned d_ = pk_sub(tc, qc);                                 \
     const unsigned m_ = pk_nonzero(d_);                                 \
-    z = pk_mad(m_, z_delta, z_match);                                   \
+    z = pk_mad(m_, z_delta, z_match_v);                                 \
     if (has_n) {                                                        \
       unsigned nn_ = pk_ashr15((tc) | (qc));                            \
       SDF_OPQ(nn_);                                                     \
@@ -265,6 +287,8 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
   unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16
   SDF_OPQ(one2);
+  unsigned z_match_v = z_match;  // kept in a VGPR: v_pk_mad_u16 takes one scalar operand only
+  SDF_OPQ(z_match_v);
 
   unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], Tc[NREG];
   unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
@@ -446,8 +470,9 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   // instructions and every lane predicate is a VALU compare (the scalar unit is shared by the
   // CU's four SIMDs and was the bottleneck of the general row).
   // ------------------------------------------------------------------------------------------
-  auto fast_rows = [&](auto low16_c, const int rb, const int re) {
+  auto fast_rows_n = [&](auto low16_c, auto hasn_c, const int rb, const int re) {
     constexpr bool LOW16 = decltype(low16_c)::value;
+    constexpr bool has_n = decltype(hasn_c)::value;  // shadows the runtime flag: no per-row branch
     constexpr int KT = NREG - 1;
     unsigned hacc = 0u;  // per-lane share of the H path sum
     unsigned qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + 2 * lane));
@@ -496,11 +521,9 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
           sel_lo_rng(S[0], z, (ra + 1) >> 1, (rbt + 1) >> 1, lane);
           sel_hi_rng(S[0], z, ra >> 1, rbt >> 1, lane);
         } else if (k == 0) {
-          sel_lo_ge(S[0], z, (ra + 1) >> 1, lane);
-          sel_hi_ge(S[0], z, ra >> 1, lane);
+          sel2_ge(S[0], z, (ra + 1) >> 1, ra >> 1, lane);
         } else if (k == KT) {
-          sel_lo_lt(S[k], z, (rbt + 1) >> 1, lane);
-          sel_hi_lt(S[k], z, rbt >> 1, lane);
+          sel2_lt(S[k], z, (rbt + 1) >> 1, rbt >> 1, lane);
         } else {
           S[k] = z;
         }
@@ -534,6 +557,10 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     h_under += (int32_t)hacc - (re - rb) * sc.qe;
     h_top = h_under;
     prev_lo = base + (LOW16 ? 16 : 0);
+  };
+  auto fast_rows = [&](auto low16_c, const int rb, const int re) {
+    if (has_n) fast_rows_n(low16_c, std::true_type{}, rb, re);
+    else fast_rows_n(low16_c, std::false_type{}, rb, re);
   };
   // lanes of register KT above `l1` hold scratch values after fast rows: make them "never computed"
   auto zero_above = [&](const int l1_from, const int l1_to) {  // lanes (l1_from, l1_to]

@@ -60,14 +60,28 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     }
   };
 
+  // the two sequences are read backwards one base per M step: keep the current 16-base code word
+  // and 32-base N-mask word of each in registers
+  int qci = -1, tci = -1, qni = -1, tni = -1;
+  uint32_t qcw = 0, tcw = 0, qnw = 0, tnw = 0;
+  auto qcode = [&](int k) -> uint32_t {
+    if ((k >> 4) != qci) { qci = k >> 4; qcw = qw[qci]; }
+    if ((k >> 5) != qni) { qni = k >> 5; qnw = qn[qni]; }
+    return ((qnw >> (k & 31)) & 1u) ? 4u : ((qcw >> ((k & 15) * 2)) & 3u);
+  };
+  auto tcode = [&](int k) -> uint32_t {
+    if ((k >> 4) != tci) { tci = k >> 4; tcw = tw[tci]; }
+    if ((k >> 5) != tni) { tni = k >> 5; tnw = tn[tni]; }
+    return ((tnw >> (k & 31)) & 1u) ? 4u : ((tcw >> ((k & 15) * 2)) & 3u);
+  };
   int state = 0;
   // wave-kernel layout: block rb = r/16 holds, per packed register k and lane, one uint4 of four
   // 32-bit flag words (a>z, b>z', x>0, y>0); bit 15-(r%16) (+16 for the odd slot) is row r;
   // slot = t - (band start of row 16*rb).  The last fetched uint4 is kept: a path stays inside
   // one 16-row x 2-slot tile for several steps.
   const uint4 *dirw = reinterpret_cast<const uint4 *>(dir);
-  int64_t cached_idx = -1;
-  uint4 cached = make_uint4(0, 0, 0, 0);
+  int64_t cached_line = -1;  // index/4 of the 64-byte line (4 lanes = 8 slots x 16 rows) held below
+  uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
   int blk_rb = -1, blk_base = 0;
   while (i >= 0 && j >= 0) {
     const int r = (int)(i + j);
@@ -90,10 +104,16 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
         }
         const int slot = (int)i - blk_base;
         const int64_t idx = ((int64_t)rb * tk.nreg + (slot >> 7)) * 64 + ((slot & 127) >> 1);
-        if (idx != cached_idx) {
-          cached = dirw[idx];
-          cached_idx = idx;
+        if ((idx >> 2) != cached_line) {  // a diagonal run stays inside one line for ~8 steps
+          cached_line = idx >> 2;
+          const uint4 *ln = dirw + (cached_line << 2);
+          c0 = ln[0];
+          c1 = ln[1];
+          c2 = ln[2];
+          c3 = ln[3];
         }
+        const int sel = (int)(idx & 3);
+        const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
         const int bit = 15 - (r & 15) + ((slot & 1) << 4);
         const uint32_t fa = (cached.x >> bit) & 1u, fb = (cached.y >> bit) & 1u;
         const uint32_t fx = (cached.z >> bit) & 1u, fy = (cached.w >> bit) & 1u;
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     if (state == 0) state = (int)(d & 7u);
     if (forced >= 0) state = forced;
     if (state == 0) {
-      const uint32_t a = code_at(qw, qn, (int)j), c = code_at(tw, tn, (int)i);
+      const uint32_t a = qcode((int)j), c = tcode((int)i);
       if (a < 4u && a == c) ++matches; else ++mismatches;
       push(0, 1);
       --i;
