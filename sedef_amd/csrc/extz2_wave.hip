@@ -460,29 +460,42 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   };
 
   // ------------------------------------------------------------------------------------------
-  // Steady rows [rb, re): pure band regime (lo0 = (r-w+1)>>1, hi0 = (r+w)>>1 < tlen-1), window
-  // away from t = 0 and from the boundary cell t = r, and -- within one call -- a constant
-  // reference window [base + (LOW16 ? 16 : 0), hi].  Register 0 holds the lower edge of the
-  // refreshed score range, register NREG-1 its upper edge and the window top.  Lanes above the
-  // window top are NOT masked: they compute values nobody reads (the neighbour dependency only
-  // runs upwards) and are zeroed when the window grows over them.  Nothing but the recurrence
-  // remains; the few uniform quantities are recomputed per row with a handful of scalar
-  // instructions and every lane predicate is a VALU compare (the scalar unit is shared by the
-  // CU's four SIMDs and was the bottleneck of the general row).
+  // Lean rows [rb, re) of one block (rb >= 1): the same recurrence as the general row with the
+  // rare cases taken out (row 0, captured carries, the sign-extension artefact -- the caller
+  // routes those rows to slow_row) and everything that is constant over the segment hoisted:
+  //   LOW16   the reference window starts at base+16 (lanes 0..7 of register 0 are out of it);
+  //   SCALARH hi0 == tlen-1: the top cell's H is needed every row (mte / score) -> scalar path;
+  //           otherwise the H path sum is accumulated inside the owning lane, reduced at the end;
+  //   STEADY  pure band regime lo0 = (r-w+1)>>1, hi0 = (r+w)>>1, no boundary cell t = r, refresh
+  //           range from register 0 to register KT: no per-register case analysis at all.
+  // Lanes above the window top are NOT masked: they compute values nobody reads (the neighbour
+  // dependency only runs upwards); the caller zeroes them when the window grows over them.
+  // Lane predicates are VALU compares: the scalar unit is shared by the CU's four SIMDs and was
+  // the bottleneck of the general row.
   // ------------------------------------------------------------------------------------------
-  auto fast_rows_n = [&](auto low16_c, auto hasn_c, const int rb, const int re) {
+  auto lean_rows = [&](auto low16_c, auto scalarh_c, auto steady_c, const int rb, const int re) {
     constexpr bool LOW16 = decltype(low16_c)::value;
-    constexpr bool has_n = decltype(hasn_c)::value;  // shadows the runtime flag: no per-row branch
+    constexpr bool SCALARH = decltype(scalarh_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
     constexpr int KT = NREG - 1;
     unsigned hacc = 0u;  // per-lane share of the H path sum
+    int hcnt = 0;        // number of path steps taken (each subtracts q+e)
     unsigned qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + 2 * lane));
     const int base_top = base + 128 * KT;
+    const unsigned vcar = base == 0 ? ((unsigned)sc.q_b << 24) : 0u;  // v carry into slot 0 (r > 0)
     unsigned qnext[NREG];  // query codes of the row about to be computed (loaded one row ahead)
 #pragma unroll
     for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
 #pragma unroll 1
     for (int r = rb; r < re; ++r) {
-      const int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
+      int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
+      if (!STEADY) {
+        lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
+        lo0 = lo0 < 0 ? 0 : lo0;
+        hi0 = hi0 > r ? r : hi0;
+        hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
+      }
+      const int off_hi = (hi0 | 15) - base;
       unsigned qcur[NREG];
       qaddr -= 4;
 #pragma unroll
@@ -490,13 +503,27 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
         qcur[k] = qnext[k];
         qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
       }
+      // boundary cell t = r: y = 0, u = gap open (reference :122)
+      if (!STEADY && off_hi + base >= r) {
+        const int sr = r - base;
+        const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
+        const unsigned uval = ((unsigned)sc.q_b << 8) << ((sr & 1) * 16);
+        const bool mine = lane == ((sr & 127) >> 1);
+#pragma unroll
+        for (int k = 0; k < NREG; ++k)
+          if ((sr >> 7) == k) {
+            U[k] = mine ? ((U[k] & keep) | uval) : U[k];
+            Y[k] = mine ? (Y[k] & keep) : Y[k];
+          }
+      }
       unsigned xt1[NREG], vt1[NREG];
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
         unsigned xs, vs;
         if (k == 0) {
           xs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X[0], 0x138, 0xf, 0xf, true);
-          vs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)V[0], 0x138, 0xf, 0xf, true);
+          if (STEADY) vs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)V[0], 0x138, 0xf, 0xf, true);
+          else vs = (unsigned)__builtin_amdgcn_update_dpp((int)vcar, (int)V[0], 0x138, 0xf, 0xf, false);
         } else {
           int ux, uv;  // lanes 1..63 are overwritten by the second move: no initial value needed
           asm("" : "=v"(ux));
@@ -509,69 +536,128 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
         xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
         vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
       }
-      // scores: refreshed slots are [ra, rbt + 128*KT)
+      // scores: refreshed slots are [ra, rbe)
       const int ra = lo0 - base;
-      const int rbt = lo0 + ((hi0 - lo0) & ~15) + 16 - base_top;
+      const int rbe = ra + ((hi0 - lo0) & ~15) + 16;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
-        const unsigned qc = qcur[k];
-        unsigned z;
-        SDF_FRESH(z, Tc[k], qc)
-        if (NREG == 1) {
-          sel_lo_rng(S[0], z, (ra + 1) >> 1, (rbt + 1) >> 1, lane);
-          sel_hi_rng(S[0], z, ra >> 1, rbt >> 1, lane);
-        } else if (k == 0) {
-          sel2_ge(S[0], z, (ra + 1) >> 1, ra >> 1, lane);
-        } else if (k == KT) {
-          sel2_lt(S[k], z, (rbt + 1) >> 1, rbt >> 1, lane);
-        } else {
-          S[k] = z;
+        const int b_ = rbe - 128 * k;
+        if (STEADY) {
+          unsigned z;
+          SDF_FRESH(z, Tc[k], qcur[k])
+          if (NREG == 1) {
+            sel_lo_rng(S[0], z, (ra + 1) >> 1, (b_ + 1) >> 1, lane);
+            sel_hi_rng(S[0], z, ra >> 1, b_ >> 1, lane);
+          } else if (k == 0) {
+            sel2_ge(S[0], z, (ra + 1) >> 1, ra >> 1, lane);
+          } else if (k == KT) {
+            sel2_lt(S[k], z, (b_ + 1) >> 1, b_ >> 1, lane);
+          } else {
+            S[k] = z;
+          }
+        } else if (b_ > 0) {
+          unsigned z;
+          SDF_FRESH(z, Tc[k], qcur[k])
+          if (k == 0) {
+            if (b_ >= 128) {
+              sel2_ge(S[0], z, (ra + 1) >> 1, ra >> 1, lane);
+            } else {
+              sel_lo_rng(S[0], z, (ra + 1) >> 1, (b_ + 1) >> 1, lane);
+              sel_hi_rng(S[0], z, ra >> 1, b_ >> 1, lane);
+            }
+          } else if (b_ >= 128) {
+            S[k] = z;
+          } else {
+            sel2_lt(S[k], z, (b_ + 1) >> 1, b_ >> 1, lane);
+          }
         }
       }
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
-        if (k == 0 && LOW16) {
-          if (lane >= 8) SDF_CORE(0)
-        } else {
-          SDF_CORE(k)
+        if (STEADY || off_hi >= 128 * k) {
+          if (k == 0 && LOW16) {
+            if (lane >= 8) SDF_CORE(0)
+          } else {
+            SDF_CORE(k)
+          }
         }
       }
-      // H path: rows whose successor moves the top cell up read u of the top cell, the others
-      // read v of the cell under it.  Added up inside the owning lane, reduced once at the end.
-      {
-        const int odd = (r + w) & 1;
-        const int sl = hi0 - base_top - 1 + odd;  // slot to read, relative to register KT
-        const int sh = ((sl & 1) << 4) + 8;
-        unsigned val;
-        if (NREG > 1 && sl < 0) {
-          if (odd) val = U[KT > 0 ? KT - 1 : 0]; else val = V[KT > 0 ? KT - 1 : 0];
-        } else {
-          if (odd) val = U[KT]; else val = V[KT];
-        }
-        if (lane == ((sl & 127) >> 1)) hacc += (val >> sh) & 0xffu;
-      }
-    }
-    // fold the lane-distributed sum back into the scalar path value
+      if (SCALARH) {
+        // top cell H every row: h_top = H(cell under the edge, previous row) + u(top) - (q+e)
+        const int st = hi0 - base;
+        unsigned uh = 0u, vu = 0u;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
-    h_under += (int32_t)hacc - (re - rb) * sc.qe;
-    h_top = h_under;
-    prev_lo = base + (LOW16 ? 16 : 0);
-  };
-  auto fast_rows = [&](auto low16_c, const int rb, const int re) {
-    if (has_n) fast_rows_n(low16_c, std::true_type{}, rb, re);
-    else fast_rows_n(low16_c, std::false_type{}, rb, re);
-  };
-  // lanes of register KT above `l1` hold scratch values after fast rows: make them "never computed"
-  auto zero_above = [&](const int l1_from, const int l1_to) {  // lanes (l1_from, l1_to]
-    constexpr int KT = NREG - 1;
-    if (lane > l1_from && lane <= l1_to) {
-      U[KT] = 0u;
-      V[KT] = 0u;
-      X[KT] = 0u;
-      Y[KT] = 0u;
+        for (int k = 0; k < NREG; ++k) {
+          if ((st >> 7) == k) uh = slot_half(U[k], st & 127);
+          if (((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
+        }
+        h_top = h_under + (int32_t)(uh >> 8) - sc.qe;
+        if (hi0 - 1 >= lo0) h_under += (int32_t)(vu >> 8) - sc.qe;
+        if (h_top > ez_mte) {
+          ez_mte = h_top;
+          ez_mte_q = r - (hi0 | 15);
+        }
+        if (r == nrow - 1) ez_score = h_top;
+      } else {
+        // H path: rows whose successor moves the top cell up read u of the top cell, the others
+        // read v of the cell under it.  Added up inside the owning lane, reduced once at the end.
+        int up;
+        if (STEADY) {
+          up = (r + w) & 1;
+        } else {
+          int hin = (r + 1 + w) >> 1;
+          hin = hin > r + 1 ? r + 1 : hin;
+          hin = hin > tlen - 1 ? tlen - 1 : hin;
+          up = hin == hi0 + 1;
+        }
+        if (STEADY || up || hi0 - 1 >= lo0) {
+          const int sl = hi0 - base - 1 + up;
+          const int sh = ((sl & 1) << 4) + 8;
+          unsigned val = 0u;
+          if (STEADY) {
+            const int slt = sl - 128 * KT;
+            if (NREG > 1 && slt < 0) {
+              if (up) val = U[KT > 0 ? KT - 1 : 0]; else val = V[KT > 0 ? KT - 1 : 0];
+            } else {
+              if (up) val = U[KT]; else val = V[KT];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < NREG; ++k)
+              if ((sl >> 7) == k) {
+                if (up) val = U[k]; else val = V[k];
+              }
+          }
+          if (lane == ((sl & 127) >> 1)) hacc += (val >> sh) & 0xffu;
+          ++hcnt;
+        }
+      }
+    }
+    if (!SCALARH) {  // fold the lane-distributed sum back into the scalar path value
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
+      h_under += (int32_t)hacc - hcnt * sc.qe;
+      h_top = h_under;
     }
   };
+  // U,V,X,Y of the cells t in [t_from, t_to] back to "never computed" (both bounds block aligned)
+  auto zero_cells = [&](const int t_from, const int t_to) {
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int a_ = t_from - base - 128 * k, b_ = t_to - base - 128 * k;
+      if (b_ >= 0 && a_ < 128) {
+        const int la = a_ <= 0 ? 0 : a_ >> 1, lb = b_ >> 1;
+        if ((unsigned)(lane - la) <= (unsigned)(lb - la)) {
+          U[k] = 0u;
+          V[k] = 0u;
+          X[k] = 0u;
+          Y[k] = 0u;
+        }
+      }
+    }
+  };
+  int win_hi = -1;    // last cell of the reference window so far (cells above it were never computed)
+  int dirty_hi = -1;  // cells in (win_hi, dirty_hi] may hold scratch values left by lean rows
 
   for (r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
     // ---- block start: re-base the window to the reference's band start of this row ----
@@ -612,76 +698,105 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
     drop_row = -1;
     int r = r0;
-    // steady block?  pure band regime on all 16 rows, no boundary cell, window away from t = 0,
-    // lower edge of the refreshed range in register 0, upper edge and window top in register KT
-    const int rl = r0 + 15;
-    constexpr int KT = NREG - 1;
-    bool steady = w >= 2 && r0 + 16 <= nrow && base >= 16 && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
-                  ((rl + w) >> 1) < tlen - 1 && ((r0 + w) >> 1) + 15 < r0;
-    if (steady) {
-      const int lo0a = (r0 - w + 1) >> 1, lo0b = (rl - w + 1) >> 1;
-      const int hi0a = (r0 + w) >> 1;
-      steady = lo0b - base < 128 &&                         // refresh start stays in register 0
-               lo0a + ((w - 1) & ~15) + 16 - base >= 128 * KT &&  // refresh end reaches register KT
-               (hi0a | 15) - base >= 128 * KT &&            // so does the window top
-               hi0a - 1 - base >= 128 * KT - 128;           // H path cell in register KT or KT-1
-      if (NREG > 2) steady = steady && lo0a + ((w - 1) & ~15) + 16 - base >= 128 * KT + 0;
-    }
-    if (steady) {
-      // rows of this block at which the reference window changes: its start moves to base + 16 ...
-      int rr = 2 * (base + 16) + w - 1;
-      if (rr <= r0 || rr >= rend) rr = -1;
-      // ... and its end grows by one 16-cell block (hi0 reaches the next multiple of 16)
-      const int hi_first = ((r0 + w) >> 1) | 15;
-      int rh = 2 * (hi_first + 1) - w;
-      if (rh <= r0 || rh >= rend) rh = -1;
-      int l1 = (hi_first - base - 128 * KT) >> 1;  // last window lane of register KT
-      if ((carry_x | carry_v) != 0u) {
-        slow_row(r);
-        ++r;
+    // rows of this block: lean segments between the rows at which the reference window changes
+    {
+      constexpr int KT = NREG - 1;
+      const int rl = r0 + 15;
+      // pure band regime on all 16 rows, no boundary cell, refresh range spanning registers 0..KT
+      bool steady = w >= 2 && r0 + 16 <= nrow && base >= 16 && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
+                    ((rl + w) >> 1) < tlen - 1 && ((r0 + w) >> 1) + 15 < r0;
+      if (steady) {
+        const int lo0a = (r0 - w + 1) >> 1, hi0a = (r0 + w) >> 1;
+        steady = lo0a + ((w - 1) & ~15) + 16 - base >= 128 * KT && (hi0a | 15) - base >= 128 * KT &&
+                 hi0a - 1 - base >= 128 * KT - 128;
       }
+      const bool lean_ok = tlen >= 2 && w >= 1;
       bool low16 = false;
       while (r < rend) {
-        int stop = rend;
-        if (rr > r && rr < stop) stop = rr;
-        if (rh > r && rh < stop) stop = rh;
-        if (r == rh) {  // window grows: lanes l1+1 .. l1+8 enter as "never computed"
-          zero_above(l1, l1 + 8);
-          l1 += 8;
-          if (rr == r) stop = r;  // both events on one row: fall through to the rr handling
+        int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
+        lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
+        lo0 = lo0 < 0 ? 0 : lo0;
+        hi0 = hi0 > r ? r : hi0;
+        hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
+        if (lo0 > hi0) {
+          ez_zdropped = 1;
+          break;
         }
-        if (r == rr) {
-          // the re-base row itself: natural neighbour, but mind the sign-extension artefact
-          if (slot_half(V[0], 15) & 0x8000u) {
-            zero_above(l1, 63);
-            slow_row(rr);
-          } else {
-            drop_row = rr;
-            fast_rows(std::true_type{}, rr, rr + 1);
+        const int lo = lo0 & ~15, hi = hi0 | 15;
+        if (hi > win_hi) {  // the window grows over cells that must read as "never computed"
+          if (dirty_hi > win_hi) zero_cells(win_hi + 1, hi < dirty_hi ? hi : dirty_hi);
+          win_hi = hi;
+          if (dirty_hi < win_hi) dirty_hi = win_hi;
+        }
+        const bool rebase_row = lo != prev_lo && prev_lo >= 0;
+        bool special = !lean_ok || r == 0 || (r == r0 && (carry_x | carry_v) != 0u);
+        if (rebase_row && !special) {
+          // natural neighbour, but mind the sign-extension artefact of a negative carry
+          const unsigned cvh = lo - base == 16 ? slot_half(V[0], 15) : carry_v;
+          special = (cvh & 0x8000u) != 0u;
+        }
+        if (special) {
+          if (dirty_hi > win_hi) zero_cells(win_hi + 1, dirty_hi);
+          dirty_hi = win_hi;
+          if (!slow_row(r)) {
+            ez_zdropped = 1;
+            break;
           }
+          low16 = prev_lo - base == 16;
+          ++r;
+          continue;
+        }
+        if (rebase_row) {
+          if (lo - base == 16) {
+            drop_row = r;
+            low16 = true;
+          }
+        } else if (low16 && !zero_low) {
           if (lane < 8) {
             X[0] = 0u;
             V[0] = 0u;
           }
           zero_low = true;
-          low16 = true;
-          r = rr + 1;
-          continue;
         }
-        if (stop > r) {
-          if (low16) fast_rows(std::true_type{}, r, stop);
-          else fast_rows(std::false_type{}, r, stop);
-          r = stop;
+        // rows until the reference window changes again (closed forms of the band geometry)
+        int stop = rend;
+        if (rebase_row) {
+          stop = r + 1;  // the re-base row runs alone: slots 0..15 are zeroed right after it
+        } else {
+          int rr = lo + 15 + qlen;
+          const int rr2 = 2 * (lo + 16) + w - 1;
+          rr = rr2 < rr ? rr2 : rr;
+          if (rr > r && rr < stop) stop = rr;
+          const int h1 = hi + 1;
+          if (h1 <= tlen - 1) {
+            int rh = 2 * h1 - w;
+            rh = rh < h1 ? h1 : rh;
+            if (rh > r && rh < stop) stop = rh;
+          }
+          int rt = 2 * (tlen - 1) - w;
+          rt = rt < tlen - 1 ? tlen - 1 : rt;
+          if (rt > r && rt < stop) stop = rt;
         }
+        const bool scalarh = hi0 == tlen - 1;
+        if (scalarh) {
+          if (low16) lean_rows(std::true_type{}, std::true_type{}, std::false_type{}, r, stop);
+          else lean_rows(std::false_type{}, std::true_type{}, std::false_type{}, r, stop);
+        } else if (steady) {
+          if (low16) lean_rows(std::true_type{}, std::false_type{}, std::true_type{}, r, stop);
+          else lean_rows(std::false_type{}, std::false_type{}, std::true_type{}, r, stop);
+        } else {
+          if (low16) lean_rows(std::true_type{}, std::false_type{}, std::false_type{}, r, stop);
+          else lean_rows(std::false_type{}, std::false_type{}, std::false_type{}, r, stop);
+        }
+        {  // the top register of the window now holds scratch values above the window
+          const int top = base + 128 * (((win_hi - base) >> 7) + 1) - 1;
+          if (top > dirty_hi) dirty_hi = top;
+        }
+        prev_lo = lo;
+        r = stop;
       }
-      zero_above(l1, 63);  // hand clean "never computed" lanes back to the general rows
-    } else {
-      for (; r < rend; ++r) {
-        if (!slow_row(r)) {
-          ez_zdropped = 1;
-          break;
-        }
-      }
+      if (dirty_hi > win_hi) zero_cells(win_hi + 1, dirty_hi);  // clean lanes for the re-base shift
+      dirty_hi = win_hi;
     }
     // ---- block end: direction flags of these (<=16) rows leave for HBM ----
     if (with_dir) {
