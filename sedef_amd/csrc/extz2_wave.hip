@@ -230,20 +230,21 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
   }
 
 // fresh (score + 2(q+e)) << 8 of the two cells of a lane from their target / query codes
-#define SDF_FRESH(z, tc, qc)                                            \
+#define SDF_FRESH(z, tc, qraw)                                          \
   {                                                                     \
-    const unsigned d_ = pk_sub(tc, qc);                                 \
+    const unsigned qc_ = __builtin_amdgcn_perm(0u, (qraw), 0x0c010c00u); /* bytes -> halves */ \
+    const unsigned d_ = pk_sub(tc, qc_);                                \
     const unsigned m_ = pk_nonzero(d_);                                 \
     z = pk_mad(m_, z_delta, z_match_v);                                 \
     if (has_n) {                                                        \
-      unsigned nn_ = pk_ashr15((tc) | (qc));                            \
+      unsigned nn_ = pk_ashr15((tc) | pk_shl(qc_, 8));                  \
       SDF_OPQ(nn_);                                                     \
       z = (z_wild & nn_) | (z & ~nn_);                                  \
     }                                                                   \
   }
 
 template <int NREG>
-__global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
+__global__ __launch_bounds__(64, NREG <= 2 ? 7 : 4) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
                                                         const int32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ pool, ScoreK sc,
                                                         uint8_t *__restrict__ dirbase,
@@ -255,9 +256,10 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
   const int T16 = (tlen + 15) / 16 * 16;
   const int tcap = T16 + NSLOT + 32;      // target codes (u16), zero padded
-  const int qcap = qlen + NSLOT + 36;     // reversed query with a 32-element front pad, as PAIRS:
-  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);            // W[j] = QR[j-32] | QR[j-31] << 16
-  uint32_t *W = reinterpret_cast<uint32_t *>(lds + 2 * tcap);  // (any j is one aligned dword)
+  const int qcap = qlen + NSLOT + 36;     // reversed query with a 32-element front pad, as byte
+  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);            // PAIRS: W[j] = QR[j-32] | QR[j-31] << 8
+  uint16_t *W = reinterpret_cast<uint16_t *>(lds + 2 * tcap);  // (any j is one aligned 16-bit load;
+                                                               //  N is 0x80|wild in a byte)
 
   // ---- unpack the 2-bit / N-mask sequences into LDS ----
   bool has_n;
@@ -271,9 +273,11 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     for (int t = lane; t < tcap; t += 64) Tb[t] = t < tlen ? (uint16_t)pool_code16(tw, tn, t, sc.wild) : 0;
     for (int j = lane; j < qcap; j += 64) {
       const int e0 = j - 32, e1 = j - 31;  // QR indices; QR[e] = query[qlen-1-e], 0 outside
-      const uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
-      const uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
-      W[j] = v0 | (v1 << 16);
+      uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
+      uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
+      v0 = (v0 & 0x7fu) | ((v0 >> 8) & 0x80u);
+      v1 = (v1 & 0x7fu) | ((v1 >> 8) & 0x80u);
+      W[j] = (uint16_t)(v0 | (v1 << 8));
     }
   }
   __syncthreads();
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
       for (int k = 0; k < NREG; ++k) {
         const int a_ = ra - 128 * k, b_ = rb - 128 * k;
         if (b_ > 0 && a_ < 128) {
-          const unsigned qc = W[cq + 128 * k + 2 * lane];
+          const unsigned qc = W[cq + 128 * k + 2 * lane];  // zero-extended byte pair
           unsigned z;
           SDF_FRESH(z, Tc[k], qc)
           if (a_ <= 0 && b_ >= 128) {
@@ -480,12 +484,11 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
     constexpr int KT = NREG - 1;
     unsigned hacc = 0u;  // per-lane share of the H path sum
     int hcnt = 0;        // number of path steps taken (each subtracts q+e)
-    unsigned qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + 2 * lane));
-    const int base_top = base + 128 * KT;
+    unsigned qaddr = (unsigned)(2 * tcap + 2 * (qlen - 1 - rb + base + 32 + 2 * lane));
     const unsigned vcar = base == 0 ? ((unsigned)sc.q_b << 24) : 0u;  // v carry into slot 0 (r > 0)
     unsigned qnext[NREG];  // query codes of the row about to be computed (loaded one row ahead)
 #pragma unroll
-    for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
+    for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
 #pragma unroll 1
     for (int r = rb; r < re; ++r) {
       int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
@@ -497,11 +500,11 @@ __global__ __launch_bounds__(64) void extz2_wave_kernel(const PlanTask *__restri
       }
       const int off_hi = (hi0 | 15) - base;
       unsigned qcur[NREG];
-      qaddr -= 4;
+      qaddr -= 2;
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {
         qcur[k] = qnext[k];
-        qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 512 * k);
+        qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
       }
       // boundary cell t = r: y = 0, u = gap open (reference :122)
       if (!STEADY && off_hi + base >= r) {
@@ -856,7 +859,7 @@ size_t wave_lds_bytes(int qlen, int tlen, int nreg) {
   const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
   const size_t tcap = T16 + 128 * nreg + 32;
   const size_t qcap = (size_t)qlen + 128 * nreg + 36;
-  return 2 * tcap + 4 * qcap;
+  return 2 * tcap + 2 * qcap;
 }
 
 }  // namespace sdf

@@ -369,7 +369,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         size_t lds = 2048;
         if (p.nreg) {
           bs = p.nreg;
-          lds = (wave_lds_bytes(p.qlen, p.tlen, p.nreg) + 2047) & ~(size_t)2047;
+          lds = (wave_lds_bytes(p.qlen, p.tlen, p.nreg) + 1023) & ~(size_t)1023;
         } else {
           const size_t need = general_lds_bytes(p.qlen, p.tlen);
           while (lds < need) lds *= 2;
