@@ -153,6 +153,7 @@ def main():
     import torch.distributed as dist
 
     import sedef_amd
+    from sedef_amd.dist import allgatherv_results
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,16 +193,8 @@ def main():
     def step():
         used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_out.data_ptr(), d_cig.data_ptr(),
                                       cig_cap, want=want, stream=stream)
-        if world > 1:  # all-gatherv of result records + CIGAR words: counts, then padded payloads
-            cnt = torch.tensor([used], dtype=torch.int64, device=dev)
-            cnts = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(cnts, cnt)
-            mx = int(cnts.max().item())
-            recs = torch.empty(world * n * 16, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(recs, d_out)
-            cg = torch.empty(world * mx, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(cg, d_cig[:mx] if mx <= cig_cap else d_cig)
-            gathered["recs"], gathered["cig"], gathered["cnts"] = recs, cg, cnts
+        if world > 1:  # all-gatherv of result records + CIGAR words over RCCL
+            gathered["recs"], gathered["cig"], gathered["cnts"] = allgatherv_results(d_out, d_cig, used)
         return used
 
     def sync():
@@ -243,8 +236,9 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get("bytes_per_launch")
+        if os.path.exists(tp) and n == 100000 and w == 128 and args.qlen == 1000:
+            # measured once with rocprofv3 PMC passes on this exact workload (profiles/r01_hbm_traffic.json)
+            traffic = json.load(open(tp)).get("bytes_per_step") / max(launches / args.steps, 1)
         value = cells_all * args.steps / dt / 1e9
         line = {
             "metric": "aligned DP cells/sec (Gcell/s) on `sedef align` batch",
