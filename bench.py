@@ -160,11 +160,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
+    # BENCH_DEBUG_ONE_GPU=1: dry-run of the multi-rank path on a single-GPU box (all ranks on
+    # device 0, gloo instead of RCCL).  Never used for reported numbers.
+    debug_one_gpu = os.environ.get("BENCH_DEBUG_ONE_GPU") == "1"
+    if debug_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if debug_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n, w = args.tasks, args.band
     pool, q_off, qlen, t_off, tlen = synth_batch(n, args.qlen, seed=42 + rank)
@@ -194,7 +202,10 @@ def main():
         used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_out.data_ptr(), d_cig.data_ptr(),
                                       cig_cap, want=want, stream=stream)
         if world > 1:  # all-gatherv of result records + CIGAR words over RCCL
-            gathered["recs"], gathered["cig"], gathered["cnts"] = allgatherv_results(d_out, d_cig, used)
+            if debug_one_gpu:
+                gathered["recs"], gathered["cig"], gathered["cnts"] = allgatherv_results(d_out.cpu(), d_cig.cpu(), used)
+            else:
+                gathered["recs"], gathered["cig"], gathered["cnts"] = allgatherv_results(d_out, d_cig, used)
         return used
 
     def sync():
@@ -218,10 +229,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if debug_one_gpu else dev
+        tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([cells_rank], dtype=torch.int64, device=dev)
+        tot = torch.tensor([cells_rank], dtype=torch.int64, device=rdev)
         dist.all_reduce(tot)
         cells_all = int(tot.item())
     else:

@@ -348,7 +348,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // launch classes: (threads per task, LDS bytes rounded to a power of two)
   struct Cls {
     int bs;  // 64 / 256: general kernel with that many threads; 1, 2, 4: wave kernel with NREG
-    size_t lds;
+    size_t lds;       // class key
+    size_t need_max;  // largest real requirement in the class: what the launch asks for
     std::vector<int32_t> idx;
   };
   std::vector<int32_t> order(np);
@@ -366,12 +367,15 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         const PlanTask &p = plan[k];
         const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
         int bs = width > 256 ? 256 : 64;
-        size_t lds = 2048;
+        size_t lds = 2048, need;
         if (p.nreg) {
           bs = p.nreg;
-          lds = (wave_lds_bytes(p.qlen, p.tlen, p.nreg) + 1023) & ~(size_t)1023;
+          // one class for everything up to 6 KiB (>= 6 waves/SIMD either way), powers of two above
+          need = wave_lds_bytes(p.qlen, p.tlen, p.nreg);
+          lds = 6144;
+          while (lds < need) lds *= 2;
         } else {
-          const size_t need = general_lds_bytes(p.qlen, p.tlen);
+          need = general_lds_bytes(p.qlen, p.tlen);
           while (lds < need) lds *= 2;
         }
         if (lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
@@ -379,15 +383,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         for (auto &x : cls)
           if (x.bs == bs && x.lds == lds) c = &x;
         if (!c) {
-          cls.push_back({bs, lds, {}});
+          cls.push_back({bs, lds, 0, {}});
           c = &cls.back();
         }
+        c->need_max = std::max(c->need_max, need);
         c->idx.push_back((int32_t)(k - subs[si].s));
       }
       // big classes first so the long tasks start early
       std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.lds > b.lds; });
       for (auto &c : cls) {
-        sub_launches[si].push_back({c.bs, c.lds, cursor, c.idx.size()});
+        sub_launches[si].push_back({c.bs, std::min(c.lds, (c.need_max + 511) & ~(size_t)511), cursor, c.idx.size()});
         std::copy(c.idx.begin(), c.idx.end(), order.begin() + cursor);
         cursor += c.idx.size();
       }
