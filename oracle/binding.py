@@ -221,3 +221,43 @@ def mutate(rng, s, sub=0.06, dele=0.02, ins=0.02):
     if not out:
         out = [0]
     return np.array(out, dtype=np.uint8)
+
+
+# ---- reference Alignment / Hit classes (oracle/_ref/libref_align.so; built by `make -C oracle refalign`) ----
+def build_reference_align():
+    so = os.path.join(_HERE, "_ref", "libref_align.so")
+    if os.path.exists(so):
+        return so
+    if os.path.exists("/root/reference/src/align.cc"):
+        subprocess.check_call(["make", "-C", _HERE, "refalign"], stdout=subprocess.DEVNULL)
+        return so
+    return None
+
+
+class ReferenceAlign:
+    """The reference's own Alignment / Hit code (src/align.cc, src/hit.cc) behind oracle/ref_align_driver.cc.
+    Loaded with RTLD_LAZY: `split` and `rc` (src/util.cc, needs Boost) are unresolved and never called."""
+
+    def __init__(self):
+        so = build_reference_align()
+        if so is None:
+            raise FileNotFoundError("oracle/_ref/libref_align.so not built and /root/reference absent")
+        dl = C.CDLL(None)
+        dl.dlopen.restype = C.c_void_p
+        dl.dlopen.argtypes = [C.c_char_p, C.c_int]
+        h = dl.dlopen(so.encode(), 1)
+        if not h:
+            raise OSError("dlopen failed: " + so)
+        self.lib = C.CDLL(so, handle=h)
+        self.buf = C.create_string_buffer(4 << 20)
+
+    def alignment_pair(self, fa, fb):
+        cnt = (C.c_int * 5)()
+        rc = self.lib.ref_alignment_pair(fa.encode(), fb.encode(), self.buf, len(self.buf), cnt)
+        assert rc == 0
+        return self.buf.value.decode(), list(cnt)
+
+    def guide_from_chains(self, q, r, spec, side):
+        rc = self.lib.ref_guide_from_chains(q.encode(), r.encode(), spec.encode(), side, self.buf, len(self.buf))
+        assert rc == 0
+        return self.buf.value.decode()

@@ -1,0 +1,96 @@
+// TEST INFRASTRUCTURE: thin C driver around the REFERENCE's own Alignment / Hit classes
+// (src/align.{h,cc}, src/hit.{h,cc}), compiled together with the reference sources that build
+// without Boost (see Makefile `refalign`).  It only constructs objects through the reference's public
+// interface and prints what it returns; the refinement loop below calls the reference's merge() and
+// guide constructor in the order refine_chains does (src/refine.cc:163-183).
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "align.h"
+#include "hit.h"
+
+using namespace std;
+
+static vector<vector<Anchor>> parse_chains(const char *spec) {
+  vector<vector<Anchor>> chains(1);
+  int q, r, l, n = 0;
+  const char *p = spec;
+  while (*p) {
+    if (*p == '|') {
+      chains.push_back({});
+      p++;
+      continue;
+    }
+    if (sscanf(p, "%d,%d,%d%n", &q, &r, &l, &n) == 3) {
+      chains.back().push_back(Anchor{q, r, l, 0});
+      p += n;
+      if (*p == ';') p++;
+    } else {
+      break;
+    }
+  }
+  if (chains.back().empty()) chains.pop_back();
+  return chains;
+}
+
+static int emit(const string &s, char *buf, size_t cap) {
+  if (s.size() + 1 > cap) return -2;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return 0;
+}
+
+extern "C" {
+
+int ref_alignment_pair(const char *fa, const char *fb, char *cigar, size_t cap, int *counts) {
+  Alignment al{string(fa), string(fb)};
+  counts[0] = al.matches();
+  counts[1] = al.mismatches();
+  counts[2] = al.gaps();
+  counts[3] = al.gap_bases();
+  counts[4] = al.span();
+  return emit(al.cigar_string(), cigar, cap);
+}
+
+// chains: "q,r,l;q,r,l|q,r,l;..." (anchors of each chain in order).  Builds every chain alignment
+// (src/align.cc:199-270), merges overlapping neighbours and builds the guide alignment with side
+// extension.  Output: "qs qe rs re cigar matches mismatches gaps gap_bases|to_bed line".
+int ref_guide_from_chains(const char *qstr_, const char *rstr_, const char *spec, int side, char *out, size_t cap) {
+  const string qstr = qstr_, rstr = rstr_;
+  auto chains = parse_chains(spec);
+  auto qs = make_shared<Sequence>("QRY", qstr);
+  auto rs = make_shared<Sequence>("REF", rstr);
+  vector<Hit> hits;
+  for (auto &c : chains) {
+    vector<int> idx;
+    for (int i = 0; i < (int)c.size(); i++) idx.push_back(i);
+    Hit h{qs, 0, 0, rs, 0, 0, 0, "", "", {}};
+    h.aln = Alignment(qstr, rstr, c, idx);
+    update_from_alignment(h);
+    hits.push_back(h);
+  }
+  vector<Hit> guide;
+  Hit *prev = &hits[0];
+  for (int pi = 1; pi < (int)hits.size(); pi++) {
+    auto &cur = hits[pi];
+    if (cur.query_start < prev->query_end || cur.ref_start < prev->ref_end) {
+      prev->aln.merge(cur.aln, qstr, rstr);
+      update_from_alignment(*prev);
+    } else {
+      guide.push_back(*prev);
+      prev = &cur;
+    }
+  }
+  guide.push_back(*prev);
+  Hit fin{qs, 0, 0, rs, 0, 0, 0, "name", "cmt", {}};
+  fin.aln = Alignment(qstr, rstr, guide, side);
+  update_from_alignment(fin);
+  ostringstream os;
+  os << fin.query_start << " " << fin.query_end << " " << fin.ref_start << " " << fin.ref_end << " "
+     << fin.aln.cigar_string() << " " << fin.aln.matches() << " " << fin.aln.mismatches() << " " << fin.aln.gaps()
+     << " " << fin.aln.gap_bases() << "|" << fin.to_bed(false);
+  return emit(os.str(), out, cap);
+}
+}

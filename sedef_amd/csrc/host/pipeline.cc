@@ -1,0 +1,558 @@
+// fast_align + refine_chains as a resumable per-pair job, the DP providers, and the stage driver
+// (restates reference src/chain.cc:203-268, src/refine.cc:23-193, src/align_main.cc:200-337).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <set>
+
+#include "../../../include/sedef_hip.h"
+#include "sedef_host.h"
+
+namespace sdfh {
+
+void set_alignment_scoring(const Params &p);
+
+// ======================================================================================================
+// DP providers: align_helper (src/align.cc:39-68) for a batch of requests
+// ======================================================================================================
+namespace {
+
+struct TaskRef {
+  size_t req;
+  size_t q_off, t_off;
+  int qlen, tlen;
+};
+
+// chunking of one request into DP tasks (src/align.cc:46-57): both sequences advance by the same SP
+void expand(const std::vector<DpRequest> &reqs, const Params &p, std::vector<TaskRef> &tasks,
+            std::vector<uint8_t> &pool) {
+  size_t total = 0;
+  for (auto &r : reqs) total += r.q.size() + r.t.size();
+  pool.resize(total);
+  size_t off = 0;
+  for (size_t k = 0; k < reqs.size(); k++) {
+    const DpRequest &r = reqs[k];
+    const size_t qo = off;
+    memcpy(pool.data() + off, r.q.data(), r.q.size());
+    off += r.q.size();
+    const size_t to = off;
+    memcpy(pool.data() + off, r.t.data(), r.t.size());
+    off += r.t.size();
+    const size_t lim = std::min(r.q.size(), r.t.size());
+    for (size_t sp = 0; sp < lim; sp += (size_t)p.max_ksw_seq_len) {
+      TaskRef t;
+      t.req = k;
+      t.q_off = qo + sp;
+      t.t_off = to + sp;
+      t.qlen = (int)std::min<size_t>(p.max_ksw_seq_len, r.q.size() - sp);
+      t.tlen = (int)std::min<size_t>(p.max_ksw_seq_len, r.t.size() - sp);
+      tasks.push_back(t);
+    }
+  }
+}
+
+inline void append_ops(Cigar &c, const uint32_t *w, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    const int idx = w[i] & 0xf, len = (int)(w[i] >> 4);
+    if (idx < 3) c.push_back({"MDI"[idx], len});  // ksw I (query) -> 'D', ksw D (target) -> 'I'
+  }
+}
+
+void fill_mat(const Params &p, int8_t mat[25]) {  // src/align.cc:41-44
+  const int8_t a = (int8_t)p.match, b = p.mismatch < 0 ? (int8_t)p.mismatch : (int8_t)(-p.mismatch);
+  const int8_t m[25] = {a, b, b, b, 0, b, a, b, b, 0, b, b, a, b, 0, b, b, b, a, 0, 0, 0, 0, 0, 0};
+  memcpy(mat, m, 25);
+}
+
+class GpuProvider : public DpProvider {
+ public:
+  explicit GpuProvider(int device) {
+    ctx_ = sdf_create(device, 0);
+    if (!ctx_) throw std::string("GPU DP backend unavailable: ") + sdf_last_error(nullptr);
+  }
+  ~GpuProvider() override { sdf_destroy(ctx_); }
+  std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) override {
+    std::vector<Cigar> out(reqs.size());
+    if (reqs.empty()) return out;
+    std::vector<TaskRef> tr;
+    std::vector<uint8_t> pool;
+    expand(reqs, p, tr, pool);
+    if (tr.empty()) return out;
+    std::vector<sdf_task> tasks(tr.size());
+    size_t cap = 0;
+    for (size_t k = 0; k < tr.size(); k++) {
+      sdf_task &t = tasks[k];
+      memset(&t, 0, sizeof(t));
+      t.q_off = (int64_t)tr[k].q_off;
+      t.t_off = (int64_t)tr[k].t_off;
+      t.qlen = tr[k].qlen;
+      t.tlen = tr[k].tlen;
+      t.w = -1;      // src/align.cc:86
+      t.zdrop = -1;  // src/align.cc:54
+      t.flag = 0;
+      cap += (size_t)t.qlen + t.tlen + 2;
+      cells += (int64_t)t.qlen * t.tlen;
+    }
+    tasks_ += 0;
+    this->tasks += (int64_t)tr.size();
+    sdf_scoring sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.m = 5;
+    fill_mat(p, sc.mat);
+    sc.gapo = (int8_t)(-p.gap_open);
+    sc.gape = (int8_t)(-p.gap_extend);
+    std::vector<sdf_result> res(tr.size());
+    std::vector<uint32_t> cig(cap);
+    size_t used = 0;
+    const int rc = sdf_extz2_batch(ctx_, &sc, tasks.data(), tasks.size(), pool.data(), pool.size(),
+                                   SDF_WANT_CIGAR | SDF_WANT_SCORE, res.data(), cig.data(), cap, &used);
+    if (rc != SDF_OK) throw std::string("DP batch failed: ") + sdf_last_error(ctx_);
+    for (size_t k = 0; k < tr.size(); k++) append_ops(out[tr[k].req], cig.data() + res[k].cigar_off, res[k].n_cigar);
+    return out;
+  }
+
+ private:
+  sdf_ctx *ctx_;
+  int64_t tasks_ = 0;
+};
+
+struct OracleResult {  // layout of sdfo_result (oracle/extz2_oracle.h)
+  uint32_t max;
+  int32_t zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score;
+  int64_t n_cigar;
+  uint32_t *cigar;
+};
+
+class TestProvider : public DpProvider {
+ public:
+  explicit TestProvider(test_dp_fn fn) : fn_(fn) {}
+  std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) override {
+    std::vector<Cigar> out(reqs.size());
+    std::vector<TaskRef> tr;
+    std::vector<uint8_t> pool;
+    expand(reqs, p, tr, pool);
+    int8_t mat[25];
+    fill_mat(p, mat);
+    for (auto &t : tr) {
+      OracleResult r;
+      memset(&r, 0, sizeof(r));
+      fn_(t.qlen, pool.data() + t.q_off, t.tlen, pool.data() + t.t_off, 5, mat, -p.gap_open, -p.gap_extend, -1, -1,
+          0, &r);
+      append_ops(out[t.req], r.cigar, r.n_cigar);
+      free(r.cigar);
+      tasks++;
+      cells += (int64_t)t.qlen * t.tlen;
+    }
+    return out;
+  }
+
+ private:
+  test_dp_fn fn_;
+};
+
+}  // namespace
+
+std::unique_ptr<DpProvider> make_gpu_provider(int device) { return std::unique_ptr<DpProvider>(new GpuProvider(device)); }
+std::unique_ptr<DpProvider> make_test_provider(test_dp_fn fn) { return std::unique_ptr<DpProvider>(new TestProvider(fn)); }
+
+// ======================================================================================================
+// PairJob
+// ======================================================================================================
+struct PairJob::PathState {
+  std::deque<int> idx;       // chain hits of the path, in order
+  int qlo, qhi, rlo, rhi;    // extent from the chain coordinates (before any merge)
+  bool est_ok = true;
+  // progress
+  size_t pi = 1;
+  int prev = -1;             // index into hits_
+  std::vector<Hit> guide;
+  bool merging = false;      // waiting for the gap DP of a merge
+  bool building = false;     // waiting for the DPs of the final guide alignment
+  bool finished = false;
+  Hit result;
+};
+
+PairJob::PairJob(const std::string &query, const std::string &ref, const Hit &orig, const Params &p)
+    : query_(query), ref_(ref), orig_(orig), p_(p) {}
+
+void PairJob::stage_start(std::vector<DpRequest> &out) {  // src/chain.cc:203-258
+  query_ptr_ = std::make_shared<Sequence>("QRY", query_);
+  ref_ptr_ = std::make_shared<Sequence>("REF", ref_);
+  anchors_ = generate_anchors(query_, ref_, orig_, p_.kmer);
+  auto chains = chain_anchors(anchors_, p_);
+  const auto &chain = chains.first;
+  const auto &bounds = chains.second;
+  const double min_span = p_.min_read_size * (1 - p_.max_error);
+  for (size_t bi = 1; bi < bounds.size(); bi++) {
+    const bool has_u = bounds[bi].second;
+    const int be = bounds[bi].first, bs = bounds[bi - 1].first;
+    const int up = bounds[bi].second;
+    const int qlo = anchors_[chain[be - 1]].q, qhi = anchors_[chain[bs]].q + anchors_[chain[bs]].l;
+    const int rlo = anchors_[chain[be - 1]].r, rhi = anchors_[chain[bs]].r + anchors_[chain[bs]].l;
+    const int span = std::max(rhi - rlo, qhi - qlo);
+    if ((!has_u || span < p_.min_uppercase_match) && span < min_span) continue;
+    Hit a;
+    a.query = query_ptr_;
+    a.query_start = qlo;
+    a.query_end = qhi;
+    a.ref = ref_ptr_;
+    a.ref_start = rlo;
+    a.ref_end = rhi;
+    a.jaccard = up;
+    guides_.push_back(std::vector<int>());
+    for (int k = be - 1; k >= bs; k--) guides_.back().push_back(chain[k]);
+    hits_.push_back(a);
+  }
+  DpSession rec;
+  rec.recording = true;
+  rec.requests = &out;
+  for (size_t k = 0; k < hits_.size(); k++) Alignment tmp(query_, ref_, anchors_, guides_[k], rec);
+}
+
+void PairJob::stage_chain_finish(const std::vector<Cigar> &results) {
+  DpSession rep;
+  rep.recording = false;
+  rep.results = &results;
+  for (size_t k = 0; k < hits_.size(); k++) {
+    hits_[k].aln = Alignment(query_, ref_, anchors_, guides_[k], rep);
+    update_from_alignment(hits_[k]);
+  }
+  std::vector<Anchor>().swap(anchors_);
+  plan_paths();
+}
+
+void PairJob::plan_paths() {  // src/refine.cc:23-147
+  std::vector<Hit> &anchors = hits_;
+  std::sort(anchors.begin(), anchors.end());
+  const bool same_chr = orig_.query->name == orig_.ref->name && orig_.query->is_rc == orig_.ref->is_rc;
+  std::vector<int> score;
+  for (auto &a : anchors)
+    score.push_back(p_.refine_match * a.aln.matches() - p_.refine_mismatch * a.aln.mismatches() -
+                    p_.refine_gap * a.aln.gap_bases());  // double -> int
+  std::vector<int> dp(anchors.size(), 0), prev(anchors.size(), -1);
+  std::set<std::pair<int, int>, std::greater<std::pair<int, int>>> maxes;
+  for (int ai = 0; ai < (int)anchors.size(); ai++) {
+    if (same_chr) {
+      auto &c = anchors[ai];
+      const int qlo = c.query_start, qhi = c.query_end, rlo = c.ref_start, rhi = c.ref_end;
+      const int qo = std::max(0, std::min(orig_.query_start + qhi, orig_.ref_start + rhi) -
+                                     std::max(orig_.query_start + qlo, orig_.ref_start + rlo));
+      if ((rhi - rlo) - qo < p_.refine_side_align && (qhi - qlo) - qo < p_.refine_side_align) continue;
+    }
+    dp[ai] = score[ai];
+    for (int aj = ai - 1; aj >= 0; aj--) {
+      auto &c = anchors[ai];
+      auto &p = anchors[aj];
+      int cqs = c.query_start;
+      if (cqs < p.query_end) cqs = p.query_end;
+      int crs = c.ref_start;
+      if (crs < p.ref_end) crs = p.ref_end;
+      if (p.query_end >= c.query_end || p.ref_end >= c.ref_end) continue;
+      if (p.ref_start >= c.ref_start) continue;
+      const int ma = std::max(cqs - p.query_end, crs - p.ref_end);
+      const int mi = std::min(cqs - p.query_end, crs - p.ref_end);
+      if (ma >= p_.refine_max_gap) continue;
+      if (same_chr) {
+        const int qlo = p.query_end, qhi = cqs, rlo = p.ref_end, rhi = crs;
+        const int qo = std::max(0, std::min(orig_.query_start + qhi, orig_.ref_start + rhi) -
+                                       std::max(orig_.query_start + qlo, orig_.ref_start + rlo));
+        if (qo >= 1) continue;
+      }
+      const int mis = p_.refine_mismatch * mi, gap = p_.refine_gapopen + p_.refine_gap * (ma - mi);
+      const int sco = dp[aj] + score[ai] - mis - gap;
+      if (sco >= dp[ai]) {
+        dp[ai] = sco;
+        prev[ai] = aj;
+      }
+    }
+    maxes.insert({dp[ai], ai});
+  }
+  std::vector<bool> used(anchors.size(), false);
+  for (auto &m : maxes) {
+    if (m.first == 0) break;
+    int maxi = m.second;
+    if (used[maxi]) continue;
+    auto ps = std::make_shared<PathState>();
+    while (maxi != -1 && !used[maxi]) {
+      ps->idx.push_front(maxi);
+      used[maxi] = true;
+      maxi = prev[maxi];
+    }
+    ps->qlo = anchors[ps->idx.front()].query_start;
+    ps->qhi = anchors[ps->idx.back()].query_end;
+    ps->rlo = anchors[ps->idx.front()].ref_start;
+    ps->rhi = anchors[ps->idx.back()].ref_end;
+    int est_size = anchors[ps->idx[0]].aln.span();
+    for (size_t i = 1; i < ps->idx.size(); i++) {
+      est_size += anchors[ps->idx[i]].aln.span();
+      est_size += std::max(anchors[ps->idx[i]].query_start - anchors[ps->idx[i - 1]].query_end,
+                           anchors[ps->idx[i]].ref_start - anchors[ps->idx[i - 1]].ref_end);
+    }
+    ps->est_ok = est_size >= p_.refine_min_read - p_.refine_side_align;
+    ps->prev = ps->idx[0];
+    paths_.push_back(ps);
+  }
+}
+
+std::vector<DpRequest> PairJob::advance(const std::vector<Cigar> &results) {
+  std::vector<DpRequest> out;
+  if (stage_ == START) {
+    stage_start(out);
+    stage_ = CHAIN_ALN;
+    if (!out.empty()) return out;
+    // no DP needed: fall through with an empty result set
+    stage_chain_finish(std::vector<Cigar>());
+    stage_ = PATHS;
+  } else if (stage_ == CHAIN_ALN) {
+    stage_chain_finish(results);
+    stage_ = PATHS;
+  }
+  if (stage_ != PATHS) return out;
+
+  // distribute the results of the previous round to the paths that were waiting, in request order
+  size_t cursor = 0;
+  std::vector<int> waiting;
+  waiting.swap(wait_paths_);
+  std::vector<size_t> counts;
+  counts.swap(wait_counts_);
+  std::vector<std::vector<Cigar>> path_results(paths_.size());
+  for (size_t w = 0; w < waiting.size(); w++) {
+    path_results[waiting[w]].assign(results.begin() + cursor, results.begin() + cursor + counts[w]);
+    cursor += counts[w];
+  }
+
+  const std::string &qseq = query_ptr_->seq, &rseq = ref_ptr_->seq;
+  for (size_t pk = 0; pk < paths_.size(); pk++) {
+    PathState &ps = *paths_[pk];
+    if (ps.finished || !ps.est_ok) continue;
+    std::vector<Cigar> have;
+    have.swap(path_results[pk]);
+    bool have_results = ps.merging || ps.building;
+    for (;;) {
+      if (ps.building) {  // results of the final guide alignment are here
+        DpSession rep;
+        rep.recording = false;
+        rep.results = &have;
+        ps.result.aln = Alignment(qseq, rseq, ps.guide, p_.refine_side_align, rep);
+        update_from_alignment(ps.result);
+        ps.finished = true;
+        break;
+      }
+      if (ps.merging) {  // results of a merge's gap DP are here: do the real merge
+        Hit &prev = hits_[ps.prev];
+        Hit &cur = hits_[ps.idx[ps.pi]];
+        DpSession rep;
+        rep.recording = false;
+        rep.results = &have;
+        prev.aln.merge(cur.aln, qseq, rseq, rep);
+        update_from_alignment(prev);
+        ps.merging = false;
+        ps.pi++;
+        have.clear();
+        have_results = false;
+      }
+      // walk the path (src/refine.cc:165-179)
+      bool waiting_now = false;
+      while (ps.pi < ps.idx.size()) {
+        Hit &prev = hits_[ps.prev];
+        Hit &cur = hits_[ps.idx[ps.pi]];
+        if (cur.query_start < prev.query_end || cur.ref_start < prev.ref_end) {
+          // enumerate the merge's DP request on copies
+          std::vector<DpRequest> reqs;
+          DpSession rec;
+          rec.recording = true;
+          rec.requests = &reqs;
+          Alignment pa = prev.aln, ca = cur.aln;
+          pa.merge(ca, qseq, rseq, rec);
+          if (reqs.empty()) {
+            std::vector<Cigar> none;
+            DpSession rep;
+            rep.recording = false;
+            rep.results = &none;
+            prev.aln.merge(cur.aln, qseq, rseq, rep);
+            update_from_alignment(prev);
+            ps.pi++;
+            continue;
+          }
+          ps.merging = true;
+          wait_paths_.push_back((int)pk);
+          wait_counts_.push_back(reqs.size());
+          out.insert(out.end(), reqs.begin(), reqs.end());
+          waiting_now = true;
+          break;
+        }
+        ps.guide.push_back(prev);
+        ps.prev = ps.idx[ps.pi];
+        ps.pi++;
+      }
+      if (waiting_now) break;
+      // end of the path: the refined hit (src/refine.cc:163,180-183)
+      ps.guide.push_back(hits_[ps.prev]);
+      ps.result = Hit();
+      ps.result.query = hits_.front().query;
+      ps.result.query_start = ps.qlo;
+      ps.result.query_end = ps.qhi;
+      ps.result.ref = hits_.front().ref;
+      ps.result.ref_start = ps.rlo;
+      ps.result.ref_end = ps.rhi;
+      std::vector<DpRequest> reqs;
+      DpSession rec;
+      rec.recording = true;
+      rec.requests = &reqs;
+      { Alignment tmp(qseq, rseq, ps.guide, p_.refine_side_align, rec); }
+      ps.building = true;
+      if (reqs.empty()) {
+        have.clear();
+        continue;  // build immediately
+      }
+      wait_paths_.push_back((int)pk);
+      wait_counts_.push_back(reqs.size());
+      out.insert(out.end(), reqs.begin(), reqs.end());
+      break;
+    }
+    (void)have_results;
+  }
+  if (out.empty()) {
+    finish_paths();
+    stage_ = DONE;
+  }
+  return out;
+}
+
+void PairJob::finish_paths() {  // acceptance replay: src/refine.cc:143-162,184-190
+  for (auto &pp : paths_) {
+    PathState &ps = *pp;
+    if (!ps.est_ok) continue;
+    bool overlap = false;
+    for (auto &h : final_hits_) {
+      const int qo = std::max(0, std::min(ps.qhi, h.query_end) - std::max(ps.qlo, h.query_start));
+      const int ro = std::max(0, std::min(ps.rhi, h.ref_end) - std::max(ps.rlo, h.ref_start));
+      if (ps.qhi - ps.qlo - qo < p_.refine_side_align && ps.rhi - ps.rlo - ro < p_.refine_side_align) {
+        overlap = true;
+        break;
+      }
+    }
+    if (overlap) continue;
+    if (ps.result.aln.span() >= p_.refine_min_read) final_hits_.push_back(ps.result);
+  }
+  paths_.clear();
+  hits_.clear();
+}
+
+// ======================================================================================================
+// Stage driver
+// ======================================================================================================
+static std::vector<Hit> read_schedule(const std::string &bed_path, FILE *log) {  // src/align_main.cc:200-283, nbins=1
+  std::ifstream fin(bed_path.c_str());
+  if (!fin.is_open()) throw "BED file " + bed_path + " does not exist";
+  std::vector<Hit> hits;
+  std::string s;
+  while (std::getline(fin, s)) hits.push_back(Hit::from_bed(s));
+  fprintf(log, "Read %d alignments in %s\n", (int)hits.size(), bed_path.c_str());
+  fprintf(log, "Read total %d alignments\n", (int)hits.size());
+  int max_complexity = 0;
+  auto cx = [](const Hit &h) {
+    return (int)std::sqrt(double(h.query_end - h.query_start) * double(h.ref_end - h.ref_start));
+  };
+  for (auto &h : hits) max_complexity = std::max(max_complexity, cx(h));
+  std::vector<std::vector<Hit>> bins(max_complexity / 1000 + 1);
+  for (auto &h : hits) bins[cx(h) / 1000].push_back(h);
+  std::vector<Hit> order;
+  for (auto &b : bins)
+    for (auto &h : b) order.push_back(h);
+  return order;
+}
+
+GenerateStats generate_alignments(const std::string &ref_path, const std::string &bed_path, int kmer_size,
+                                  const Params &p_in, DpProvider &dp, FILE *out, FILE *log, int super_batch) {
+  const auto t0 = std::chrono::steady_clock::now();
+  Params p = p_in;
+  p.kmer = kmer_size;
+  set_alignment_scoring(p);
+  GenerateStats st;
+  std::vector<Hit> schedule = read_schedule(bed_path, log);
+  FastaReference fr(ref_path);
+  fprintf(log, "Using k-mer size %d\n", kmer_size);
+  const int total = (int)schedule.size();
+
+  struct Item {
+    Hit h;
+    std::string fa, fb;
+    std::unique_ptr<PairJob> job;
+    std::vector<DpRequest> pending;
+  };
+  for (int base = 0; base < total; base += super_batch) {
+    const int n = std::min(super_batch, total - base);
+    std::vector<Item> items(n);
+    for (int k = 0; k < n; k++) {  // src/align_main.cc:299-306
+      Item &it = items[k];
+      it.h = schedule[base + k];
+      it.fa = fr.get_sequence(it.h.query->name, it.h.query_start, &it.h.query_end);
+      it.fb = fr.get_sequence(it.h.ref->name, it.h.ref_start, &it.h.ref_end);
+      if (it.h.ref->is_rc) it.fb = rc(it.fb);
+      it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
+    }
+    // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch
+    std::vector<std::vector<Cigar>> results(n);
+    for (;;) {
+      std::vector<DpRequest> batch;
+      std::vector<std::pair<int, size_t>> owners;
+      bool any = false;
+      for (int k = 0; k < n; k++) {
+        Item &it = items[k];
+        if (it.job->done()) continue;
+        std::vector<DpRequest> reqs = it.job->advance(results[k]);
+        results[k].clear();
+        if (!reqs.empty()) {
+          owners.push_back({k, reqs.size()});
+          for (auto &r : reqs) batch.push_back(std::move(r));
+          any = true;
+        }
+      }
+      if (!any) break;
+      st.rounds++;
+      std::vector<Cigar> got = dp.run(batch, p);
+      size_t cur = 0;
+      for (auto &o : owners) {
+        results[o.first].assign(got.begin() + cur, got.begin() + cur + o.second);
+        cur += o.second;
+      }
+    }
+    for (int k = 0; k < n; k++) {  // src/align_main.cc:314-331
+      Item &it = items[k];
+      st.lines++;
+      for (auto &hh : it.job->hits()) {
+        hh.query_start += it.h.query_start;
+        hh.query_end += it.h.query_start;
+        if (it.h.ref->is_rc) {
+          std::swap(hh.ref_start, hh.ref_end);
+          hh.ref_start = it.h.ref_end - hh.ref_start;
+          hh.ref_end = it.h.ref_end - hh.ref_end;
+          hh.ref->is_rc = true;
+        } else {
+          hh.ref_start += it.h.ref_start;
+          hh.ref_end += it.h.ref_start;
+        }
+        hh.query->name = it.h.query->name;
+        hh.ref->name = it.h.ref->name;
+        st.total_written++;
+        fprintf(out, "%s\t%s\n", hh.to_bed(false).c_str(), it.h.to_bed(false).c_str());
+      }
+    }
+    fprintf(log, "\r Processing %d out of %d (%.1f%%)", std::min(base + n, total), total,
+            100.0 * std::min(base + n, total) / std::max(total, 1));
+  }
+  st.dp_tasks = dp.tasks;
+  st.dp_cells = dp.cells;
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(log, "\nFinished BED %s in %.2fs (%d lines, generated %d hits)\n", bed_path.c_str(), secs, st.lines,
+          st.total_written);
+  return st;
+}
+
+}  // namespace sdfh

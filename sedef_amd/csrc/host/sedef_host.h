@@ -1,0 +1,218 @@
+// Host side of the `sedef align generate` stage above the DP C ABI (include/sedef_hip.h).
+//
+// Restates, in a batched form, the reference's per-pair logic around the DP kernel:
+//   Alignment (src/align.{h,cc}), Hit / BED I/O (src/hit.{h,cc}), FASTA access (src/fasta.{h,cc}),
+//   seed chaining (src/chain.cc, src/segment.{h,tpp}), chain refinement (src/refine.cc) and the
+//   stage driver (src/align_main.cc:285-337).
+// Every DP the reference runs inline through align_helper (src/align.cc:39-68) is collected here into
+// batches for the GPU: the per-pair code is run once in "recording" mode to enumerate its DP requests
+// (their inputs never depend on earlier DP results inside one phase), the batch goes to
+// sdf_extz2_batch, and the same code is run again with the results.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace sdfh {
+
+typedef std::deque<std::pair<char, int>> Cigar;
+
+// ---- tunables (reference: src/globals.{h,cc}) ------------------------------------------------
+struct Params {
+  int match = 5, mismatch = -4, gap_open = -40, gap_extend = -1;  // Align::* (globals.cc:25-28)
+  int max_ksw_seq_len = 60 * 1000;                                 // Align::MAX_KSW_SEQ_LEN
+  int kmer = 11;
+  // Chain::* / Chain::Refine::* / Search::* values the stage reads (globals.h:71-87, globals.cc:20-30)
+  int min_uppercase_match = 90, match_chain_score = 4, max_chain_gap = 210;
+  double refine_match = 10, refine_mismatch = 1, refine_gap = 0.5, refine_gapopen = 100;
+  int refine_min_read = 900, refine_side_align = 500, refine_max_gap = 10 * 1000;
+  int min_read_size = 700;
+  double max_error = 0.30;
+};
+
+// ---- DP requests ---------------------------------------------------------------------------------
+// One align_helper call: the two strings are ALREADY mapped through align_dna (codes 0..4 as chars).
+struct DpRequest {
+  std::string q, t;
+};
+
+// Runs a batch of align_helper-equivalent requests; returns one CIGAR (ops M/D/I) per request.
+class DpProvider {
+ public:
+  virtual ~DpProvider() {}
+  virtual std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) = 0;
+  int64_t tasks = 0, cells = 0;  // statistics
+};
+
+// The product provider: sdf_extz2_batch on a HIP device.  Throws std::string when no device / library.
+std::unique_ptr<DpProvider> make_gpu_provider(int device);
+
+// TEST HOOK: a provider that calls a single-task function with the oracle's signature
+// (oracle/extz2_oracle.h: sdfo_extz2).  Never constructed by the CLI.
+typedef void (*test_dp_fn)(int, const uint8_t *, int, const uint8_t *, int, const int8_t *, int, int, int, int,
+                           int, void *);
+std::unique_ptr<DpProvider> make_test_provider(test_dp_fn fn);
+
+// DP access handed to the restated reference code: records requests or replays results.
+struct DpSession {
+  bool recording = true;
+  std::vector<DpRequest> *requests = nullptr;  // recording: appended to
+  const std::vector<Cigar> *results = nullptr; // replay: consumed in order
+  size_t cursor = 0;
+  Cigar align(const std::string &q_codes, const std::string &t_codes);
+};
+
+// ---- sequences / hits ----------------------------------------------------------------------------
+struct Sequence {  // reference: src/hash.h:51-57, src/hash.cc:104-109
+  std::string name, seq;
+  bool is_rc;
+  Sequence(const std::string &name, const std::string &seq, bool is_rc = false);
+};
+
+struct Hit;
+
+struct Anchor {  // reference: src/align.h:25-28
+  int q, r, l;
+  int has_u;
+};
+
+class Alignment {  // reference: src/align.h:32-103
+ public:
+  std::string chr_a;
+  int start_a = 0, end_a = 0;
+  std::string chr_b;
+  int start_b = 0, end_b = 0;
+  std::string a, b;
+  std::string align_a, align_b, alignment;
+  Cigar cigar;
+  struct AlignmentError {
+    int gaps, gap_bases, mismatches, matches;
+  } error = {0, 0, 0, 0};
+
+  Alignment();
+  Alignment(const std::string &fa, const std::string &fb, DpSession &dp);
+  Alignment(const std::string &fa, const std::string &fb, const std::string &cigar);
+  Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Hit> &guide, int side,
+            DpSession &dp);
+  Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Anchor> &guide,
+            const std::vector<int> &guide_idx, DpSession &dp);
+
+  void populate_nice_alignment();
+  void trim();
+  void trim_front();
+  void trim_back();
+  void prepend_cigar(const Cigar &app);
+  void append_cigar(const Cigar &app);
+  void cigar_from_alignment();
+  void swap();
+  void merge(Alignment &cur, const std::string &qstr, const std::string &rstr, DpSession &dp);
+
+  std::string cigar_string() const;
+  int span() const { return (int)alignment.size(); }
+  int matches() const { return error.matches; }
+  int mismatches() const { return error.mismatches; }
+  int gap_bases() const { return error.gap_bases; }
+  int gaps() const { return error.gaps; }
+  double gap_error() const;
+  double mismatch_error() const;
+  double total_error() const { return mismatch_error() + gap_error(); }
+};
+
+struct Hit {  // reference: src/hit.h:23-51
+  std::shared_ptr<Sequence> query;
+  int query_start = 0, query_end = 0;
+  std::shared_ptr<Sequence> ref;
+  int ref_start = 0, ref_end = 0;
+  int jaccard = 0;
+  std::string name, comment;
+  Alignment aln;
+
+  static Hit from_bed(const std::string &bed, std::string *cigar = nullptr);
+  std::string to_bed(bool do_rc = true, bool with_cigar = true) const;
+  bool operator<(const Hit &h) const;
+  void extend(double factor, int max_extend);
+};
+void update_from_alignment(Hit &h);
+
+// ---- FASTA (reference: src/fasta.{h,cc}) -----------------------------------------------------------
+struct FastaIndexEntry {
+  std::string name;
+  int length;
+  long long offset;
+  int line_blen, line_len;
+};
+class FastaReference {
+ public:
+  explicit FastaReference(const std::string &filename);
+  ~FastaReference();
+  std::string get_sequence(const std::string &seqname, int start = 0, int *end = nullptr);
+
+ private:
+  int fd_ = -1;
+  void *mm_ = nullptr;
+  size_t size_ = 0;
+  std::map<std::string, FastaIndexEntry> index_;
+};
+
+// ---- utilities (reference: src/util.cc:33-48, src/common.h:56-99) ----------------------------------
+void set_alignment_scoring(const Params &p);  // Align::MATCH and co. are process-wide (src/globals.cc:25-28)
+std::vector<std::string> split(const std::string &s, char delim);
+std::string rc(const std::string &s);
+char align_dna(char c);
+char hash_dna(char c);
+
+// ---- chaining (reference: src/chain.cc) ------------------------------------------------------------
+std::vector<Anchor> generate_anchors(const std::string &query, const std::string &ref, const Hit &orig,
+                                     int kmer_size);
+// returns (path, boundaries) exactly as chain_anchors (src/chain.cc:103-199)
+std::pair<std::vector<int>, std::vector<std::pair<int, bool>>> chain_anchors(std::vector<Anchor> &anchors,
+                                                                            const Params &p);
+
+// ---- per-pair job: fast_align (src/chain.cc:203-268) + refine_chains (src/refine.cc:23-193), staged ----
+class PairJob {
+ public:
+  PairJob(const std::string &query, const std::string &ref, const Hit &orig, const Params &p);
+  // Advances as far as possible.  Returns the DP requests it is waiting for (empty => finished).
+  // Call again with the results of the previous return value, in the same order.
+  std::vector<DpRequest> advance(const std::vector<Cigar> &results);
+  bool done() const { return stage_ == DONE; }
+  std::vector<Hit> &hits() { return final_hits_; }
+
+ private:
+  enum Stage { START, CHAIN_ALN, PATHS, DONE };
+  struct PathState;
+  void stage_start(std::vector<DpRequest> &out);
+  void stage_chain_finish(const std::vector<Cigar> &results);
+  void plan_paths();
+  void finish_paths();
+
+  const std::string &query_, &ref_;
+  Hit orig_;
+  Params p_;
+  Stage stage_ = START;
+  std::shared_ptr<Sequence> query_ptr_, ref_ptr_;
+  std::vector<Anchor> anchors_;
+  std::vector<std::vector<int>> guides_;
+  std::vector<Hit> hits_;
+  std::vector<std::shared_ptr<PathState>> paths_;
+  std::vector<size_t> wait_counts_;  // requests issued per waiting path, in order
+  std::vector<int> wait_paths_;
+  std::vector<Hit> final_hits_;
+};
+
+// ---- stage driver (reference: src/align_main.cc:200-337) ---------------------------------------------
+struct GenerateStats {
+  int lines = 0, total_written = 0;
+  int64_t dp_tasks = 0, dp_cells = 0;
+  int rounds = 0;
+};
+// Reads the bucket BED, aligns every candidate pair, writes the BEDPE lines to `out` in the reference's order.
+GenerateStats generate_alignments(const std::string &ref_path, const std::string &bed_path, int kmer_size,
+                                  const Params &p, DpProvider &dp, FILE *out, FILE *log, int super_batch = 256);
+
+}  // namespace sdfh

@@ -1,0 +1,107 @@
+// `sedef` command line for the align stage (restates the CLI contract of reference src/main.cc:104-157 and
+// src/align_main.cc:341-373): `sedef align generate -k K [--match N --mismatch N --gap-open N --gap-extend N]
+// genome.fa bucket.bed`.  stdout carries only the BEDPE lines; everything else goes to stderr.
+// The DP runs on the GPU; without a HIP device the command fails with exit code 1.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sedef_host.h"
+
+using namespace sdfh;
+
+namespace {
+// argh PREFER_PARAM_FOR_UNREG_OPTION (reference: extern/argh.h:211-232): any -x/--x followed by a token that
+// is not itself an option takes it as its value (negative numbers are values); the rest are positionals.
+struct Args {
+  std::vector<std::string> pos;
+  std::vector<std::pair<std::string, std::string>> params;
+  static bool is_number(const std::string &s) {
+    char *e = nullptr;
+    strtod(s.c_str(), &e);
+    return e && *e == 0 && !s.empty();
+  }
+  static bool is_option(const std::string &s) { return s.size() > 1 && s[0] == '-' && !is_number(s); }
+  Args(int argc, char **argv) {
+    for (int i = 0; i < argc; i++) {
+      std::string a = argv[i];
+      if (!is_option(a)) {
+        pos.push_back(a);
+        continue;
+      }
+      std::string name = a.substr(a.find_first_not_of('-'));
+      const size_t eq = name.find('=');
+      if (eq != std::string::npos) {
+        params.push_back({name.substr(0, eq), name.substr(eq + 1)});
+      } else if (i + 1 < argc && !is_option(argv[i + 1])) {
+        params.push_back({name, argv[++i]});
+      }
+    }
+  }
+  bool get(std::initializer_list<const char *> names, int &v) const {
+    for (auto &p : params)
+      for (auto n : names)
+        if (p.first == n) {
+          v = atoi(p.second.c_str());
+          return true;
+        }
+    return false;
+  }
+};
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 2) {
+    fprintf(stderr, "Arguments missing: please run sedef help for more information.\n");
+    return 1;
+  }
+  fprintf(stderr, "SEDEF align stage on MI355X (sedef_amd); arguments: ");
+  for (int i = 0; i < argc; i++) fprintf(stderr, " %s", argv[i]);
+  fprintf(stderr, "\n");
+  const std::string command = argv[1];
+  if (argc < 3 && command != "help") {
+    fprintf(stderr, "Arguments missing: please run sedef help for more information.\n");
+    return 1;
+  }
+  try {
+    if (command == "help") {
+      fprintf(stderr,
+              "sedef align generate -k [kmer] [genome.fa] [initial.bed]\n"
+              "  generates true alignments for [initial.bed] (BEDPE on stdout)\n"
+              "  params: -k/--kmer, --match, --mismatch, --gap-open, --gap-extend (default 5, -4, -40, -1)\n"
+              "Other SEDEF stages (search, stats, translate, align bucket) are not part of this build.\n");
+      return 0;
+    } else if (command == "align") {
+      Args a(argc - 2, argv + 2);
+      Params p;
+      a.get({"match"}, p.match);
+      a.get({"mismatch"}, p.mismatch);
+      a.get({"gap-open"}, p.gap_open);
+      a.get({"gap-extend"}, p.gap_extend);
+      if (a.pos.size() < 3) throw std::string("Not enough arguments to align");
+      if (a.pos[0] == "generate") {
+        int k;
+        if (!a.get({"k", "kmer"}, k)) throw std::string("Must provide k-mer size (--kmer)");
+        const char *dv = getenv("SDF_DEVICE");
+        auto dp = make_gpu_provider(dv ? atoi(dv) : 0);
+        generate_alignments(a.pos[1], a.pos[2], k, p, *dp, stdout, stderr);
+      } else if (a.pos[0] == "bucket") {
+        throw std::string("align bucket is not part of this build (next row of the scope table)");
+      } else {
+        throw std::string("Unknown align command");
+      }
+    } else {
+      fprintf(stderr, "Whoops, invalid command!\n");
+    }
+  } catch (std::string &s) {
+    fprintf(stderr, "Error: %s\n", s.c_str());
+    fprintf(stderr, "Double-check the parameters: run sedef --help for explanation.\n");
+    return 1;
+  } catch (std::exception &e) {
+    fprintf(stderr, "Error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,103 @@
+"""ctypes access to the host pipeline library (sedef_amd/lib/libsedef_host.so, sources in csrc/host/).
+
+`test_dp` parameters are the library's TEST HOOK: a C function with the oracle's single-task signature that
+replaces the GPU provider.  Product code (the `sedef` CLI) never passes one."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_SRC = os.path.join(_HERE, "csrc", "host")
+LIB = os.path.join(_HERE, "lib", "libsedef_host.so")
+CLI = os.path.join(_HERE, "bin", "sedef")
+_SOURCES = ["alignment.cc", "hit_fasta.cc", "chain.cc", "pipeline.cc", "host_cabi.cc"]
+
+
+def build_host(force=False):
+    """g++ build of the host library and the `sedef` CLI (needs libsedef_hip.so next to it)."""
+    srcs = [os.path.join(HOST_SRC, f) for f in _SOURCES]
+    deps = srcs + [os.path.join(HOST_SRC, "sedef_host.h"), os.path.join(HOST_SRC, "sedef_main.cc")]
+    fresh = os.path.exists(LIB) and os.path.exists(CLI) and all(
+        os.path.getmtime(d) <= min(os.path.getmtime(LIB), os.path.getmtime(CLI)) for d in deps)
+    if fresh and not force:
+        return LIB
+    gxx = shutil.which("g++") or "g++"
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    libdir = os.path.join(_HERE, "lib")
+    subprocess.check_call([gxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", LIB] + srcs +
+                          ["-L" + libdir, "-lsedef_hip", "-Wl,-rpath,$ORIGIN"])
+    subprocess.check_call([gxx, "-O2", "-std=c++17", "-Wall", "-o", CLI, os.path.join(HOST_SRC, "sedef_main.cc"),
+                           "-L" + libdir, "-lsedef_host", "-lsedef_hip", "-Wl,-rpath,$ORIGIN/../lib"])
+    return LIB
+
+
+_lib = None
+
+
+def load_host():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError("%s is missing: run __graft_entry__.build()" % LIB)
+        _lib = C.CDLL(LIB)
+        _lib.sdfh_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _err(lib, rc):
+    if rc != 0:
+        raise RuntimeError("host pipeline error %d: %s" % (rc, lib.sdfh_last_error().decode()))
+
+
+def generate(ref_path, bed_path, kmer, out_path, match=5, mismatch=-4, gap_open=-40, gap_extend=-1, test_dp=None,
+             device=0):
+    """`sedef align generate` (reference: src/align_main.cc:285-337). Returns (lines, hits, dp_tasks, dp_cells, rounds)."""
+    lib = load_host()
+    stats = (C.c_longlong * 5)()
+    rc = lib.sdfh_generate(ref_path.encode(), bed_path.encode(), kmer, out_path.encode(), match, mismatch, gap_open,
+                           gap_extend, test_dp, device, stats)
+    _err(lib, rc)
+    return tuple(int(x) for x in stats)
+
+
+_buf = None
+
+
+def _buffer():
+    global _buf
+    if _buf is None:
+        _buf = C.create_string_buffer(4 << 20)
+    return _buf
+
+
+def alignment_pair(fa, fb, test_dp=None, device=0):
+    lib, buf = load_host(), _buffer()
+    cnt = (C.c_int * 5)()
+    _err(lib, lib.sdfh_alignment_pair(fa.encode(), fb.encode(), test_dp, device, buf, len(buf), cnt))
+    return buf.value.decode(), list(cnt)
+
+
+def guide_from_chains(q, r, spec, side, test_dp=None, device=0):
+    lib, buf = load_host(), _buffer()
+    _err(lib, lib.sdfh_guide_from_chains(q.encode(), r.encode(), spec.encode(), side, test_dp, device, buf, len(buf)))
+    return buf.value.decode()
+
+
+def chains(q, r, kmer=11):
+    lib, buf = load_host(), _buffer()
+    lib.sdfh_chains.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    _err(lib, lib.sdfh_chains(q.encode(), r.encode(), kmer, buf, len(buf)))
+    out = []
+    for c in buf.value.decode().split("|"):
+        if c:
+            out.append([tuple(int(x) for x in a.split()) for a in c.split(";") if a])
+    return out
+
+
+def fasta_get(path, name, start, end):
+    lib, buf = load_host(), _buffer()
+    e = C.c_int(end)
+    _err(lib, lib.sdfh_fasta_get(path.encode(), name.encode(), start, C.byref(e), buf, len(buf)))
+    return buf.value.decode(), e.value

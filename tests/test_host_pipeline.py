@@ -1,0 +1,199 @@
+"""Host pipeline above the C ABI (sedef_amd/csrc/host): Alignment / Hit / FASTA / chaining / refinement / driver.
+
+CPU tests inject the CPU oracle as the DP through the library's test hook; GPU tests use the product path
+(sdf_extz2_batch) and must reproduce the CPU-hook results byte for byte."""
+import ctypes as C
+import gzip
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hostgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host():
+    from sedef_amd import host as h
+    from sedef_amd.build import build_library
+    build_library()
+    h.build_host()
+    return h
+
+
+@pytest.fixture(scope="module")
+def oracle_dp(oracle):
+    return C.cast(oracle.lib.sdfo_extz2, C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def host_golden():
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "host_align_kat.json.gz"), "rb") as f:
+        return json.loads(f.read().decode())
+
+
+# ---------------------------------------------------------------- A1-A7, D2: pinned by the reference classes
+def test_alignment_pair_matches_reference_golden(host, oracle_dp, host_golden):
+    for c in host_golden["pairs"]:
+        cig, cnt = host.alignment_pair(c["a"], c["b"], test_dp=oracle_dp)
+        assert cig == c["cigar"] and cnt == c["counts"]
+
+
+def test_chain_merge_guide_to_bed_match_reference_golden(host, oracle_dp, host_golden):
+    assert len(host_golden["guides"]) >= 30
+    for c in host_golden["guides"]:
+        assert host.guide_from_chains(c["q"], c["r"], c["spec"], c["side"], test_dp=oracle_dp) == c["expect"]
+
+
+def test_alignment_live_vs_reference_classes(host, oracle_dp):
+    from oracle.binding import ReferenceAlign
+    try:
+        ref = ReferenceAlign()
+    except Exception:
+        pytest.skip("oracle/_ref/libref_align.so not built and /root/reference absent")
+    rng = np.random.default_rng(2)
+    for it in range(120):
+        a = hostgen.rseq(rng, int(rng.integers(1, 600)), 0.01 if it % 3 == 0 else 0)
+        b = hostgen.mut(rng, a, rng.random() * 0.2)
+        assert host.alignment_pair(a, b, test_dp=oracle_dp) == ref.alignment_pair(a, b)
+    n = 0
+    while n < 60:
+        c = hostgen.chain_case(rng, host)
+        if c is None:
+            continue
+        n += 1
+        assert host.guide_from_chains(*c, test_dp=oracle_dp) == ref.guide_from_chains(*c)
+
+
+# ---------------------------------------------------------------- D3 FASTA
+def test_fasta_random_access(host, tmp_path):
+    s, _ = hostgen.make_genome(str(tmp_path / "g.fa"), seed=3, glen=5000, nsd=0)
+    fa = str(tmp_path / "g.fa")
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = int(rng.integers(-5, 5100))
+        b = int(rng.integers(a, 5300))
+        got, end = host.fasta_get(fa, "chrT", a, b)
+        aa = max(a, 0)
+        assert end == min(b, 5000)
+        assert got == s[aa:min(b, 5000)]
+    with pytest.raises(RuntimeError):
+        host.fasta_get(fa, "nope", 0, 10)
+
+
+# ---------------------------------------------------------------- C1-C3: chaining invariants (parity unpinned)
+def test_chains_are_exact_colinear_matches(host):
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        q = hostgen.rseq(rng, 3000, 0.003)
+        r = hostgen.rseq(rng, 200) + hostgen.mut(rng, q, 0.08) + hostgen.rseq(rng, 300)
+        for chain in host.chains(q, r, 11):
+            pq = pr = -1
+            for (aq, ar, al, hu) in chain:
+                assert al >= 11 and hu in (0, 1)
+                assert q[aq:aq + al].upper() == r[ar:ar + al].upper() and "N" not in q[aq:aq + al].upper()
+                # maximal to the right; strictly after the previous anchor in both sequences, gap <= 210
+                assert aq + al == len(q) or ar + al == len(r) or q[aq + al].upper() != r[ar + al].upper() or \
+                    "N" in (q[aq + al].upper(), r[ar + al].upper())
+                if pq >= 0:
+                    assert aq >= pq and ar >= pr and aq - pq <= 210 and ar - pr <= 210
+                pq, pr = aq + al, ar + al
+
+
+# ---------------------------------------------------------------- D1 + R1: the stage
+def _check_bedpe(lines, genome):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    for ln in lines:
+        f = ln.split("\t")
+        assert len(f) == 28
+        qs, qe, rs, re_ = int(f[1]), int(f[2]), int(f[4]), int(f[5])
+        ops = re.findall(r"(\d+)([MID])", f[12])
+        qn = sum(int(n) for n, o in ops if o in "MD")
+        rn = sum(int(n) for n, o in ops if o in "MI")
+        assert qn == qe - qs and rn == re_ - rs and int(f[11]) == sum(int(n) for n, o in ops)
+        assert int(f[11]) >= 900
+        a = genome[qs:qe].upper()
+        b = genome[rs:re_].upper()
+        if f[9] == "-":
+            b = "".join(comp[c] for c in b[::-1])
+        i = j = mm = ma = 0
+        for n, o in ops:
+            n = int(n)
+            if o == "M":
+                for k in range(n):
+                    if a[i + k] == b[j + k] and a[i + k] != "N":
+                        ma += 1
+                    else:
+                        mm += 1
+                i += n
+                j += n
+            elif o == "D":
+                i += n
+            else:
+                j += n
+        gb = sum(int(n) for n, o in ops if o != "M")
+        assert f[13].startswith("m=%.1f;g=%.1f" % (100.0 * mm / (ma + mm + gb), 100.0 * gb / (ma + mm + gb)))
+
+
+def test_generate_stage_cpu_hook(host, oracle_dp, tmp_path):
+    fa = str(tmp_path / "genome.fa")
+    genome, beds = hostgen.make_genome(fa, seed=1)
+    out = str(tmp_path / "out.bed")
+    lines, hits, tasks, cells, rounds = host.generate(fa, fa + ".bed", 11, out, test_dp=oracle_dp)
+    assert lines == len(beds) and hits >= 4 and tasks > 50 and 2 <= rounds <= 6
+    got = open(out).read().splitlines()
+    assert len(got) == hits
+    _check_bedpe(got, genome)
+    # deterministic
+    out2 = str(tmp_path / "out2.bed")
+    host.generate(fa, fa + ".bed", 11, out2, test_dp=oracle_dp)
+    assert open(out2).read() == open(out).read()
+
+
+def test_cli_contract_without_gpu(host, tmp_path):
+    """argv grammar / exit codes of the reference CLI (src/main.cc:104-157, src/align_main.cc:341-373)."""
+    from sedef_amd.host import CLI
+    r = subprocess.run([CLI], capture_output=True, text=True)
+    assert r.returncode == 1 and "Arguments missing" in r.stderr
+    r = subprocess.run([CLI, "align", "generate", "x.fa"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error: Not enough arguments to align" in r.stderr and r.stdout == ""
+    r = subprocess.run([CLI, "align", "generate", "x.fa", "y.bed"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Must provide k-mer size" in r.stderr
+    r = subprocess.run([CLI, "help"], capture_output=True, text=True)
+    assert r.returncode == 0
+    import sedef_amd
+    if sedef_amd.load_library().sdf_device_count() == 0:  # no HIP device: loud failure, no CPU fallback
+        fa = str(tmp_path / "g.fa")
+        hostgen.make_genome(fa, seed=2, glen=20000, nsd=1)
+        r = subprocess.run([CLI, "align", "generate", "-k", "11", fa, fa + ".bed"], capture_output=True, text=True)
+        assert r.returncode == 1 and "GPU DP backend unavailable" in r.stderr and r.stdout == ""
+
+
+# ---------------------------------------------------------------- GPU: product path == CPU-hook path
+@pytest.mark.gpu
+def test_generate_stage_gpu_equals_cpu_hook(host, oracle_dp, tmp_path):
+    from sedef_amd.host import CLI
+    for seed, glen, nsd in ((1, 60000, 6), (5, 120000, 12)):
+        fa = str(tmp_path / ("genome%d.fa" % seed))
+        genome, beds = hostgen.make_genome(fa, seed=seed, glen=glen, nsd=nsd)
+        cpu, gpu = str(tmp_path / "cpu.bed"), str(tmp_path / "gpu.bed")
+        host.generate(fa, fa + ".bed", 11, cpu, test_dp=oracle_dp)
+        host.generate(fa, fa + ".bed", 11, gpu)  # GPU provider
+        assert open(gpu).read() == open(cpu).read()
+        r = subprocess.run([CLI, "align", "generate", "-k", "11", fa, fa + ".bed"], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == open(cpu).read() and "Finished" in r.stderr
+        _check_bedpe(r.stdout.splitlines(), genome)
+
+
+@pytest.mark.gpu
+def test_alignment_golden_on_gpu(host, host_golden):
+    for c in host_golden["pairs"]:
+        cig, cnt = host.alignment_pair(c["a"], c["b"])
+        assert cig == c["cigar"] and cnt == c["counts"]
+    for c in host_golden["guides"]:
+        assert host.guide_from_chains(c["q"], c["r"], c["spec"], c["side"]) == c["expect"]
