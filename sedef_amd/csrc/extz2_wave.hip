@@ -244,7 +244,7 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
   }
 
 template <int NREG>
-__global__ __launch_bounds__(64, NREG <= 2 ? 7 : 4) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
+__global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
                                                         const int32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ pool, ScoreK sc,
                                                         uint8_t *__restrict__ dirbase,
@@ -853,6 +853,8 @@ template __global__ void extz2_wave_kernel<1>(const PlanTask *, const int32_t *,
 template __global__ void extz2_wave_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
                                               uint8_t *, sdf_result *);
 template __global__ void extz2_wave_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                              uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<8>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
                                               uint8_t *, sdf_result *);
 
 size_t wave_lds_bytes(int qlen, int tlen, int nreg) {

@@ -148,6 +148,8 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipGetLastError();
   const char *fg = getenv("SDF_FORCE_GENERAL");
   ctx->force_general = fg && fg[0] == '1';
@@ -289,8 +291,10 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       const bool plain = !(want & SDF_WANT_EXT) && t.zdrop < 0 &&
                          !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY)) && sc->gapo >= 0 && band_whole;
       if (plain && !ctx->force_general) {
-        const int need = p.ncol16 + 32;
-        const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : 0;
+        // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
+        // beyond the target's last 16-cell block (cells past it are not part of any window)
+        const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
+        const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : need <= 1024 ? 8 : 0;
         if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)ctx->max_dyn_lds) p.nreg = nreg;
       }
     }
@@ -347,7 +351,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
 
   // launch classes: (threads per task, LDS bytes rounded to a power of two)
   struct Cls {
-    int bs;  // 64 / 256: general kernel with that many threads; 1, 2, 4: wave kernel with NREG
+    int bs;  // 64 / 256: general kernel with that many threads; 1, 2, 4, 8: wave kernel with NREG
     size_t lds;       // class key
     size_t need_max;  // largest real requirement in the class: what the launch asks for
     std::vector<int32_t> idx;
@@ -429,6 +433,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
                            d_order + L.off, d_pool, sk, d_dir, d_out);
       else if (L.bs == 4)
         hipLaunchKernelGGL(extz2_wave_kernel<4>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
+                           d_order + L.off, d_pool, sk, d_dir, d_out);
+      else if (L.bs == 8)
+        hipLaunchKernelGGL(extz2_wave_kernel<8>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
                            d_order + L.off, d_pool, sk, d_dir, d_out);
       else if (L.bs == 64)
         hipLaunchKernelGGL(extz2_general_kernel<64>, dim3((unsigned)L.cnt), dim3(64), L.lds, st,

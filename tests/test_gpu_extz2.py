@@ -200,3 +200,18 @@ def test_wave_kernel_other_scorings(engine, oracle):
             pairs.append((q, mutate(rng, q, d, d / 3, d / 3)))
         w = int(rng.choice([3, 16, 40, 100]))
         _check_fast(engine, oracle, pairs, [w] * len(pairs), mat=sedef_mat(ma, mi), gapo=go, gape=ge)
+
+
+def test_wave_kernel_full_band_sedef_shapes(engine, oracle):
+    """w=-1 (every SEDEF call): gap fills, 500x500 side extensions, <=1000^2 gaps -> NREG 1..8."""
+    rng = np.random.default_rng(2026)
+    pairs = []
+    for ql, tl in [(210, 209), (37, 3), (3, 180), (500, 500), (500, 431), (431, 500), (1000, 1000), (1000, 640),
+                   (640, 1000), (977, 1000), (1, 1), (1, 300), (300, 1), (16, 16), (17, 15), (129, 127), (513, 511),
+                   (1008, 1008), (1024, 990), (800, 120), (120, 800)]:
+        for _ in range(2):
+            q = random_codes(rng, ql, 0.01 if rng.random() < 0.3 else 0.0)
+            t = mutate(rng, q, 0.05, 0.02, 0.02)
+            t = t[:tl] if len(t) >= tl else np.concatenate([t, random_codes(rng, tl - len(t))])
+            pairs.append((q, t))
+    _check_fast(engine, oracle, pairs, [-1] * len(pairs))
