@@ -317,12 +317,29 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_w
   int32_t ez_score = SDF_NEG_INF, ez_mte = SDF_NEG_INF, ez_mte_q = -1, ez_zdropped = 0;
   int drop_row = -1;  // row of the current block at which the reference window left slots 0..15
   int r0 = 0;
+  unsigned qaddr = 0u, qnext[NREG];  // LDS address / prefetched query codes of row `qrow` (lean rows)
+  int qrow = -1;
+#pragma unroll
+  for (int k = 0; k < NREG; ++k) qnext[k] = 0u;
+  unsigned hacc = 0u;  // lane-distributed part of the H path sum (lean rows), folded lazily
+  int hcnt = 0;        // number of path steps in hacc (each subtracts q+e)
+  auto fold_h = [&]() {  // bring the scalar path value up to date
+    if (hcnt) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
+      h_under += (int32_t)hacc - hcnt * sc.qe;
+      h_top = h_under;
+      hacc = 0u;
+      hcnt = 0;
+    }
+  };
 
   // ------------------------------------------------------------------------------------------
   // General row: every special case of the reference (first/last rows, boundary cell t = r,
   // clipping by the sequence ends, carry-in artefacts).  Returns false when the band is exhausted.
   // ------------------------------------------------------------------------------------------
   auto slow_row = [&](const int r) -> bool {
+    fold_h();
     // band of this row (reference :101-115); eligibility guarantees it is never empty
     int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
     lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
@@ -482,13 +499,14 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_w
     constexpr bool SCALARH = decltype(scalarh_c)::value;
     constexpr bool STEADY = decltype(steady_c)::value;
     constexpr int KT = NREG - 1;
-    unsigned hacc = 0u;  // per-lane share of the H path sum
-    int hcnt = 0;        // number of path steps taken (each subtracts q+e)
-    unsigned qaddr = (unsigned)(2 * tcap + 2 * (qlen - 1 - rb + base + 32 + 2 * lane));
-    const unsigned vcar = base == 0 ? ((unsigned)sc.q_b << 24) : 0u;  // v carry into slot 0 (r > 0)
-    unsigned qnext[NREG];  // query codes of the row about to be computed (loaded one row ahead)
+    if (SCALARH) fold_h();
+    if (qrow != rb) {  // (re)start the one-row-ahead query fetch at this row
+      qaddr = (unsigned)(2 * tcap + 2 * (qlen - 1 - rb + base + 32 + 2 * lane));
 #pragma unroll
-    for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+      for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+    }
+    qrow = re;
+    const unsigned vcar = base == 0 ? ((unsigned)sc.q_b << 24) : 0u;  // v carry into slot 0 (r > 0)
 #pragma unroll 1
     for (int r = rb; r < re; ++r) {
       int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
@@ -636,12 +654,6 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_w
         }
       }
     }
-    if (!SCALARH) {  // fold the lane-distributed sum back into the scalar path value
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
-      h_under += (int32_t)hacc - hcnt * sc.qe;
-      h_top = h_under;
-    }
   };
   // U,V,X,Y of the cells t in [t_from, t_to] back to "never computed" (both bounds block aligned)
   auto zero_cells = [&](const int t_from, const int t_to) {
@@ -692,6 +704,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_w
 #undef SDF_SHIFT8
         }
         base = b0.lo;
+        qrow = -1;  // the window moved: query addresses change
 #pragma unroll
         for (int k = 0; k < NREG; ++k)
           Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + base + 128 * k + 2 * lane);
@@ -831,6 +844,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_w
     for (int k = 0; k < NREG; ++k) Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
   }
 
+  fold_h();
   if (lane == 0) {
     sdf_result o;
     o.score = ez_score;
