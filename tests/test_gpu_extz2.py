@@ -215,3 +215,56 @@ def test_wave_kernel_full_band_sedef_shapes(engine, oracle):
             t = t[:tl] if len(t) >= tl else np.concatenate([t, random_codes(rng, tl - len(t))])
             pairs.append((q, t))
     _check_fast(engine, oracle, pairs, [-1] * len(pairs))
+
+
+def _fnv(words):
+    h = np.uint64(1469598103934665603)
+    with np.errstate(over="ignore"):
+        for w in words.tolist():
+            h = (h ^ np.uint64(w)) * np.uint64(1099511628211)
+    return int(h)
+
+
+def test_config2_batch_checksums(engine, oracle):
+    """BASELINE config 2 inputs (seed 42): per-task CIGAR checksums and scores of a 3000-task slice against
+    the CPU path (reference kernel when oracle/_ref is present, else the oracle port), and size-independent
+    properties on every task: CIGAR consumes exactly both sequences, counters add up."""
+    import bench
+    import sedef_amd
+    from oracle.binding import Reference
+    n = 3000
+    pool, q_off, qlen, t_off, tlen = bench.synth_batch(n, 1000, seed=42)
+    tasks = np.zeros(n, sedef_amd.TASK_DTYPE)
+    tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"] = q_off, t_off, qlen, tlen
+    tasks["w"], tasks["zdrop"] = 128, -1
+    res, cig = engine.align_batch(tasks, pool, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    try:
+        cpu = Reference()
+    except Exception:
+        cpu = oracle
+    score, h = cpu.batch(pool, q_off, qlen, t_off, tlen, w=128)
+    assert np.array_equal(res["score"], score)
+    for k in range(n):
+        c = cig[int(res["cigar_off"][k]):int(res["cigar_off"][k]) + int(res["n_cigar"][k])]
+        assert _fnv(c) == int(h[k]), k
+        ops, lens = c & 0xf, c >> 4
+        assert int(lens[ops != 2].sum()) == qlen[k] and int(lens[ops != 1].sum()) == tlen[k]
+        assert int(res["matches"][k] + res["mismatches"][k]) == int(lens[ops == 0].sum())
+        assert int(res["gap_bases"][k]) == int(lens[ops != 0].sum()) and int(res["gaps"][k]) == int((ops != 0).sum())
+
+
+def test_general_and_wave_kernels_agree_at_scale(engine):
+    """Idempotence / cross-kernel property at BASELINE sizes: the two independent DP kernels produce the same
+    CIGARs and scores on 2000 config-2 tasks (want=ALL routes to the LDS kernel, want=CIGAR|SCORE to the wave kernel)."""
+    import bench
+    import sedef_amd
+    n = 2000
+    pool, q_off, qlen, t_off, tlen = bench.synth_batch(n, 1000, seed=7)
+    tasks = np.zeros(n, sedef_amd.TASK_DTYPE)
+    tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"] = q_off, t_off, qlen, tlen
+    tasks["w"], tasks["zdrop"] = 128, -1
+    r1, c1 = engine.align_batch(tasks, pool, want=sedef_amd.extz2.WANT_ALL)
+    r2, c2 = engine.align_batch(tasks, pool, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    for f in ("score", "mte", "mte_q", "n_cigar", "cigar_off", "matches", "mismatches", "gaps", "gap_bases"):
+        assert np.array_equal(r1[f], r2[f]), f
+    assert np.array_equal(c1, c2)
