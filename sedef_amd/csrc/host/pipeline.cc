@@ -7,8 +7,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <atomic>
 #include <functional>
 #include <set>
+#include <thread>
 
 #include "../../../include/sedef_hip.h"
 #include "sedef_host.h"
@@ -447,6 +449,35 @@ void PairJob::finish_paths() {  // acceptance replay: src/refine.cc:143-162,184-
 // ======================================================================================================
 // Stage driver
 // ======================================================================================================
+// The per-pair host work (anchors, chaining, refinement, CIGAR algebra) is independent across pairs: run it on
+// all host cores (SDF_HOST_THREADS overrides).  The reference runs one single-threaded process per bucket.
+static void parallel_for(int n, const std::function<void(int)> &body) {
+  static int nthreads = [] {
+    const char *e = getenv("SDF_HOST_THREADS");
+    int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    return t < 1 ? 1 : (t > 64 ? 64 : t);
+  }();
+  const int nt = std::min(nthreads, n);
+  if (nt <= 1) {
+    for (int i = 0; i < n; i++) body(i);
+    return;
+  }
+  std::atomic<int> next(0);
+  std::vector<std::string> errors(nt);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; t++)
+    pool.emplace_back([&, t] {
+      try {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
+      } catch (std::string &s) {
+        errors[t] = s.empty() ? std::string("error") : s;
+      }
+    });
+  for (auto &th : pool) th.join();
+  for (auto &e : errors)
+    if (!e.empty()) throw e;
+}
+
 static std::vector<Hit> read_schedule(const std::string &bed_path, FILE *log) {  // src/align_main.cc:200-283, nbins=1
   std::ifstream fin(bed_path.c_str());
   if (!fin.is_open()) throw "BED file " + bed_path + " does not exist";
@@ -503,14 +534,19 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       std::vector<DpRequest> batch;
       std::vector<std::pair<int, size_t>> owners;
       bool any = false;
+      parallel_for(n, [&](int k) {
+        Item &it = items[k];
+        it.pending.clear();
+        if (it.job->done()) return;
+        it.pending = it.job->advance(results[k]);
+        results[k].clear();
+      });
       for (int k = 0; k < n; k++) {
         Item &it = items[k];
-        if (it.job->done()) continue;
-        std::vector<DpRequest> reqs = it.job->advance(results[k]);
-        results[k].clear();
-        if (!reqs.empty()) {
-          owners.push_back({k, reqs.size()});
-          for (auto &r : reqs) batch.push_back(std::move(r));
+        if (!it.pending.empty()) {
+          owners.push_back({k, it.pending.size()});
+          for (auto &r : it.pending) batch.push_back(std::move(r));
+          it.pending.clear();
           any = true;
         }
       }

@@ -27,9 +27,9 @@ def build_host(force=False):
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     libdir = os.path.join(_HERE, "lib")
     subprocess.check_call([gxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", LIB] + srcs +
-                          ["-L" + libdir, "-lsedef_hip", "-Wl,-rpath,$ORIGIN"])
+                          ["-L" + libdir, "-lsedef_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     subprocess.check_call([gxx, "-O2", "-std=c++17", "-Wall", "-o", CLI, os.path.join(HOST_SRC, "sedef_main.cc"),
-                           "-L" + libdir, "-lsedef_host", "-lsedef_hip", "-Wl,-rpath,$ORIGIN/../lib"])
+                           "-L" + libdir, "-lsedef_host", "-lsedef_hip", "-lpthread", "-Wl,-rpath,$ORIGIN/../lib"])
     return LIB
 
 
