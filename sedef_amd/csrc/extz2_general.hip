@@ -69,12 +69,15 @@ __device__ __forceinline__ uint32_t packed_code(const uint32_t *codes, const uin
   return n ? wild : c;
 }
 
-template <int BS>
+// GLOBAL: the arena and H[] of tasks too long for LDS (> ~14k) live in an HBM scratch slab per workgroup;
+// same code, same barriers (they order the workgroup's global accesses as well).
+template <int BS, bool GLOBAL>
 __global__ __launch_bounds__(BS) void extz2_general_kernel(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
     const uint32_t *__restrict__ pool, ScoreK sc, uint8_t *__restrict__ dirbase,
-    sdf_result *__restrict__ res) {
-  extern __shared__ __align__(16) uint8_t lds[];
+    sdf_result *__restrict__ res, uint8_t *__restrict__ gscratch, size_t gstride) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  uint8_t *lds = GLOBAL ? gscratch + (size_t)blockIdx.x * gstride : lds_raw;
   const PlanTask tk = plan[order[blockIdx.x]];
   const int tid = threadIdx.x;
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
   uint8_t *SF = S + T16, *QR = SF + T16;
   const int arena = 6 * T16 + Q16 + 16;
   int32_t *H = reinterpret_cast<int32_t *>(lds + arena);
-  BestCell *red = reinterpret_cast<BestCell *>(H + T16);
+  BestCell *red = GLOBAL ? reinterpret_cast<BestCell *>(lds_raw) : reinterpret_cast<BestCell *>(H + T16);
   int *stop_flag = reinterpret_cast<int *>(red + 4);
 
   for (int k = tid * 4; k < arena; k += BS * 4) *reinterpret_cast<uint32_t *>(lds + k) = 0u;
@@ -330,11 +333,12 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
   }
 }
 
-template __global__ void extz2_general_kernel<64>(const PlanTask *, const int32_t *, const uint32_t *,
-                                                  ScoreK, uint8_t *, sdf_result *);
-template __global__ void extz2_general_kernel<256>(const PlanTask *, const int32_t *,
-                                                   const uint32_t *, ScoreK, uint8_t *,
-                                                   sdf_result *);
+template __global__ void extz2_general_kernel<64, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                         ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<256, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                          ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<256, true>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                         ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
 
 size_t general_lds_bytes(int qlen, int tlen) {
   const size_t T16 = (size_t)(tlen + 15) / 16 * 16, Q16 = (size_t)(qlen + 15) / 16 * 16;

@@ -14,9 +14,9 @@
 #include "sdf_internal.h"
 
 namespace sdf {
-template <int BS>
-__global__ void extz2_general_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
-                                     uint8_t *, sdf_result *);
+template <int BS, bool GLOBAL>
+__global__ void extz2_general_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                     sdf_result *, uint8_t *, size_t);
 size_t general_lds_bytes(int qlen, int tlen);
 template <int NREG>
 __global__ void extz2_wave_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
@@ -79,7 +79,7 @@ struct sdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   size_t ws_budget = 0;
-  DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf;
+  DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
   std::vector<hipEvent_t> events;
   float ms[4] = {0, 0, 0, 0};
@@ -137,9 +137,9 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->ws_budget = budget;
   // allow the general kernel its full 160 KiB of LDS
   const int want_lds = 160 * 1024;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<64>),
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<64, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256>),
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess)
     ctx->max_dyn_lds = want_lds;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<1>),
@@ -161,7 +161,7 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
-  for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf,
+  for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
                     &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
     b->release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -302,10 +302,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
     p.cig_slot = stage_words;
     stage_words += p.cig_cap;
-    if (!p.nreg && general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds) {
-      ctx->err = "task too long for the LDS-resident kernel (qlen/tlen above ~14k)";
-      return SDF_ERR_UNSUPPORTED;
-    }
+    if (!p.nreg && general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds)
+      p.pad_ = 1;  // state in an HBM scratch slab instead of LDS
     plan.push_back(p);
   }
   const size_t np = plan.size();
@@ -378,11 +376,15 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           need = wave_lds_bytes(p.qlen, p.tlen, p.nreg);
           lds = 6144;
           while (lds < need) lds *= 2;
+        } else if (p.pad_) {  // HBM-resident state: one class, slab = largest requirement
+          bs = 1000;
+          need = general_lds_bytes(p.qlen, p.tlen);
+          lds = (size_t)1 << 40;
         } else {
           need = general_lds_bytes(p.qlen, p.tlen);
           while (lds < need) lds *= 2;
         }
-        if (lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
+        if (bs != 1000 && lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
         Cls *c = nullptr;
         for (auto &x : cls)
           if (x.bs == bs && x.lds == lds) c = &x;
@@ -396,7 +398,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       // big classes first so the long tasks start early
       std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.lds > b.lds; });
       for (auto &c : cls) {
-        sub_launches[si].push_back({c.bs, std::min(c.lds, (c.need_max + 511) & ~(size_t)511), cursor, c.idx.size()});
+        sub_launches[si].push_back({c.bs, c.bs == 1000 ? ((c.need_max + 255) & ~(size_t)255) : std::min(c.lds, (c.need_max + 511) & ~(size_t)511), cursor, c.idx.size()});
         std::copy(c.idx.begin(), c.idx.end(), order.begin() + cursor);
         cursor += c.idx.size();
       }
@@ -438,11 +440,21 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         hipLaunchKernelGGL(extz2_wave_kernel<8>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
                            d_order + L.off, d_pool, sk, d_dir, d_out);
       else if (L.bs == 64)
-        hipLaunchKernelGGL(extz2_general_kernel<64>, dim3((unsigned)L.cnt), dim3(64), L.lds, st,
-                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out);
-      else
-        hipLaunchKernelGGL(extz2_general_kernel<256>, dim3((unsigned)L.cnt), dim3(256), L.lds, st,
-                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out);
+        hipLaunchKernelGGL((extz2_general_kernel<64, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, st,
+                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out, (uint8_t *)nullptr, (size_t)0);
+      else if (L.bs == 256)
+        hipLaunchKernelGGL((extz2_general_kernel<256, false>), dim3((unsigned)L.cnt), dim3(256), L.lds, st,
+                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out, (uint8_t *)nullptr, (size_t)0);
+      else {  // L.lds = per-workgroup slab bytes in HBM
+        if (ctx->gstate_buf.reserve(L.lds * L.cnt) != hipSuccess) {
+          ctx->err = "cannot allocate the HBM state slabs for very long tasks";
+          (void)hipGetLastError();
+          return SDF_ERR_NOMEM;
+        }
+        hipLaunchKernelGGL((extz2_general_kernel<256, true>), dim3((unsigned)L.cnt), dim3(256), 256, st,
+                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out, (uint8_t *)ctx->gstate_buf.p,
+                           L.lds);
+      }
       ++ctx->launches;
     }
     SDF_HIP(hipEventRecord(e1, st));

@@ -268,3 +268,19 @@ def test_general_and_wave_kernels_agree_at_scale(engine):
     for f in ("score", "mte", "mte_q", "n_cigar", "cigar_off", "matches", "mismatches", "gaps", "gap_bases"):
         assert np.array_equal(r1[f], r2[f]), f
     assert np.array_equal(c1, c2)
+
+
+def test_very_long_task_hbm_state(engine, oracle):
+    """Longer than LDS can hold (> ~14k): the general kernel keeps its arena in an HBM slab."""
+    rng = np.random.default_rng(31)
+    q = random_codes(rng, 16500, 0.001)
+    t = mutate(rng, q, 0.04, 0.01, 0.01)
+    k = 7000
+    t = np.concatenate([t[:k], random_codes(rng, 900), t[k:]])
+    for w, want in ((-1, 7), (300, 7)):
+        res, cig = engine.align_pairs([(q, t)], w=w, want=want)
+        exp = oracle.extz2(q, t, w=w)
+        got = _rec_to_dict(res[0], cig)
+        for f in FIELDS:
+            assert got[f] == exp[f], (f, w)
+        assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"])
