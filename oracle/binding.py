@@ -261,3 +261,8 @@ class ReferenceAlign:
         rc = self.lib.ref_guide_from_chains(q.encode(), r.encode(), spec.encode(), side, self.buf, len(self.buf))
         assert rc == 0
         return self.buf.value.decode()
+
+    def merge(self, spec, merge_dist):
+        rc = self.lib.ref_merge(spec.encode(), merge_dist, self.buf, len(self.buf))
+        assert rc == 0
+        return self.buf.value.decode()

@@ -11,6 +11,7 @@
 
 #include "align.h"
 #include "hit.h"
+#include "merge.h"
 
 using namespace std;
 
@@ -93,4 +94,24 @@ int ref_guide_from_chains(const char *qstr_, const char *rstr_, const char *spec
      << " " << fin.aln.gap_bases() << "|" << fin.to_bed(false);
   return emit(os.str(), out, cap);
 }
+
+// merge() (src/merge.cc:35-109).  Hits arrive as "qname qs qe rname rs re rc" per line; Hit objects are
+// filled field by field (Hit::from_bed needs split(), which lives in the Boost-dependent src/util.cc).
+int ref_merge(const char *spec, int merge_dist, char *out, size_t cap) {
+  vector<Hit> hits;
+  istringstream is(spec);
+  string qn, rn;
+  int qs, qe, rs, re, rcf;
+  while (is >> qn >> qs >> qe >> rn >> rs >> re >> rcf) {
+    auto q = make_shared<Sequence>(qn, "", false);
+    auto r = make_shared<Sequence>(rn, "", false);
+    r->is_rc = rcf != 0;
+    hits.push_back(Hit{q, qs, qe, r, rs, re, 0, "", "", {}});
+  }
+  auto res = merge(hits, merge_dist);
+  ostringstream os;
+  for (auto &h : res) os << h.to_bed(false) << "\n";
+  return emit(os.str(), out, cap);
 }
+}
+

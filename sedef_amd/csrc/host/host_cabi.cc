@@ -254,6 +254,34 @@ int sdfh_fasta_get(const char *path, const char *name, int start, int *end, char
   }
 }
 
+// merge() of src/merge.cc:35-109 on BED lines (one per line in `lines`); output: merged BED lines
+int sdfh_merge(const char *lines, int merge_dist, char *buf, size_t cap) {
+  try {
+    std::vector<Hit> hits;
+    for (auto &l : split(lines, '\n'))
+      if (!l.empty()) hits.push_back(Hit::from_bed(l));
+    auto res = merge_hits(hits, merge_dist);
+    std::string out;
+    for (auto &h : res) out += h.to_bed(false) + "\n";
+    return copy_out(out, buf, cap);
+  } catch (std::string &s) {
+    g_err = s;
+    return -1;
+  }
+}
+
+// `sedef align bucket -n N bed_path out_dir genome.fa` (reference: src/align_main.cc:38-198)
+int sdfh_bucket(const char *bed_path, int nbins, const char *out_dir, const char *reference) {
+  try {
+    BucketParams bp;
+    bucket_alignments_extern(bed_path, nbins, out_dir, true, reference, bp, stderr);
+    return 0;
+  } catch (std::string &s) {
+    g_err = s;
+    return -1;
+  }
+}
+
 // Chain extraction for one pair: anchors + chains (reference: src/chain.cc:24-199).  Writes
 // "q r l has_u" per anchor of each kept chain, chains separated by "|" -- for self-consistency tests.
 int sdfh_chains(const char *query, const char *ref, int kmer, char *buf, size_t cap) {

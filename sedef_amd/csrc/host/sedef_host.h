@@ -205,6 +205,17 @@ class PairJob {
   std::vector<Hit> final_hits_;
 };
 
+// ---- `align bucket` (reference: src/align_main.cc:38-198, src/merge.cc, src/search_main.cc:93-120) -----------
+struct BucketParams {  // Globals::Extend (src/globals.cc:32-34)
+  double extend_ratio = 5;
+  int max_extend = 15 * 1000;
+  int merge_dist = 250;
+};
+std::vector<Hit> merge_hits(std::vector<Hit> &hits, int merge_dist);
+std::vector<std::vector<std::string>> generate_translation(const std::string &ref_path);
+void bucket_alignments_extern(const std::string &bed_path, int nbins, const std::string &output_dir, bool extend,
+                              const std::string &reference, const BucketParams &bp, FILE *log);
+
 // ---- stage driver (reference: src/align_main.cc:200-337) ---------------------------------------------
 struct GenerateStats {
   int lines = 0, total_written = 0;

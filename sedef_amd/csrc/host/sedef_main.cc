@@ -40,6 +40,15 @@ struct Args {
       }
     }
   }
+  bool getd(std::initializer_list<const char *> names, double &v) const {
+    for (auto &p : params)
+      for (auto n : names)
+        if (p.first == n) {
+          v = atof(p.second.c_str());
+          return true;
+        }
+    return false;
+  }
   bool get(std::initializer_list<const char *> names, int &v) const {
     for (auto &p : params)
       for (auto n : names)
@@ -71,7 +80,9 @@ int main(int argc, char **argv) {
               "sedef align generate -k [kmer] [genome.fa] [initial.bed]\n"
               "  generates true alignments for [initial.bed] (BEDPE on stdout)\n"
               "  params: -k/--kmer, --match, --mismatch, --gap-open, --gap-extend (default 5, -4, -40, -1)\n"
-              "Other SEDEF stages (search, stats, translate, align bucket) are not part of this build.\n");
+              "sedef align bucket -n [count] [bed_directory(/)] [buckets/] [genome.fa]\n"
+              "  bucket BEDs into [count] files for the alignment stage (--extend-ratio, --max-extend, --merge-dist)\n"
+              "Other SEDEF stages (search, stats, translate) are not part of this build.\n");
       return 0;
     } else if (command == "align") {
       Args a(argc - 2, argv + 2);
@@ -88,7 +99,14 @@ int main(int argc, char **argv) {
         auto dp = make_gpu_provider(dv ? atoi(dv) : 0);
         generate_alignments(a.pos[1], a.pos[2], k, p, *dp, stdout, stderr);
       } else if (a.pos[0] == "bucket") {
-        throw std::string("align bucket is not part of this build (next row of the scope table)");
+        int nbins;
+        if (!a.get({"n", "bins"}, nbins)) throw std::string("Must provide number of bins (--bins)");
+        BucketParams bp;
+        a.getd({"extend-ratio"}, bp.extend_ratio);
+        a.get({"max-extend"}, bp.max_extend);
+        a.get({"merge-dist"}, bp.merge_dist);
+        if (a.pos.size() < 4) throw std::string("Not enough arguments to align");
+        bucket_alignments_extern(a.pos[1], nbins, a.pos[2], true, a.pos[3], bp, stderr);
       } else {
         throw std::string("Unknown align command");
       }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_SRC = os.path.join(_HERE, "csrc", "host")
 LIB = os.path.join(_HERE, "lib", "libsedef_host.so")
 CLI = os.path.join(_HERE, "bin", "sedef")
-_SOURCES = ["alignment.cc", "hit_fasta.cc", "chain.cc", "pipeline.cc", "host_cabi.cc"]
+_SOURCES = ["alignment.cc", "hit_fasta.cc", "chain.cc", "pipeline.cc", "bucket.cc", "host_cabi.cc"]
 
 
 def build_host(force=False):
@@ -101,3 +101,14 @@ def fasta_get(path, name, start, end):
     e = C.c_int(end)
     _err(lib, lib.sdfh_fasta_get(path.encode(), name.encode(), start, C.byref(e), buf, len(buf)))
     return buf.value.decode(), e.value
+
+
+def merge(bed_lines, merge_dist=250):
+    lib, buf = load_host(), _buffer()
+    _err(lib, lib.sdfh_merge("\n".join(bed_lines).encode(), merge_dist, buf, len(buf)))
+    return buf.value.decode()
+
+
+def bucket(bed_path, nbins, out_dir, reference):
+    lib = load_host()
+    _err(lib, lib.sdfh_bucket(bed_path.encode(), nbins, out_dir.encode(), reference.encode()))

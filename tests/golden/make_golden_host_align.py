@@ -4,7 +4,7 @@
 Build container only: compiles src/align.cc, src/hit.cc, ... unmodified (oracle/Makefile `refalign`) and
 records, for seeded inputs, what the reference returns for (1) Alignment(fa, fb) -- CIGAR string and the
 populate_nice_alignment counters -- and (2) chain alignments + merge + guide alignment with side
-extension + Hit::to_bed.  Inputs and expected outputs only."""
+extension + Hit::to_bed, (3) merge() of src/merge.cc on random seed hits.  Inputs and expected outputs only."""
 import gzip
 import json
 import os
@@ -35,9 +35,13 @@ def main():
             continue
         q, r, spec, side = c
         guides.append(dict(q=q, r=r, spec=spec, side=side, expect=ref.guide_from_chains(q, r, spec, side)))
+    merges = []
+    for _ in range(40):
+        lines, spec = hostgen.merge_case(rng)
+        merges.append(dict(lines=lines, expect=ref.merge(spec, 250)))
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_align_kat.json.gz")
     blob = json.dumps(dict(source="reference src/align.cc + src/hit.cc via oracle/_ref/libref_align.so",
-                           pairs=pairs, guides=guides), separators=(",", ":")).encode()
+                           pairs=pairs, guides=guides, merges=merges), separators=(",", ":")).encode()
     with gzip.GzipFile(out, "wb", mtime=0) as f:
         f.write(blob)
     print("wrote %s: %d pairs, %d guides, %d bytes" % (out, len(pairs), len(guides), os.path.getsize(out)))

@@ -108,3 +108,23 @@ def make_genome(path, seed=1, glen=60000, nsd=6):
                 max(0, a - 300), min(glen, e + 300), max(0, b - 300), min(glen + 50, e2 + 300),
                 "-" if rcf else "+", max(e - a, e2 - b)))
     return s, beds
+
+
+def merge_case(rng):
+    """Random seed hits as (BED lines for our library, spec lines for the reference driver)."""
+    n = int(rng.integers(1, 40))
+    lines, spec = [], []
+    for _ in range(n):
+        qn = str(rng.choice(["chr1", "chr2"]))
+        rn = str(rng.choice(["chr1", "chr2", "chr3"]))
+        qs, L = int(rng.integers(0, 5000)), int(rng.integers(100, 1500))
+        rs, L2 = int(rng.integers(0, 5000)), int(rng.integers(100, 1500))
+        rcf = int(rng.random() < 0.3)
+        if rng.random() < 0.2 and lines:  # exact duplicates: ties in the sort key
+            lines.append(lines[-1])
+            spec.append(spec[-1])
+            continue
+        lines.append("%s\t%d\t%d\t%s\t%d\t%d\t\t\t+\t%s\t0\t0\t\t" % (qn, qs, qs + L, rn, rs, rs + L2,
+                                                                       "-" if rcf else "+"))
+        spec.append("%s %d %d %s %d %d %d" % (qn, qs, qs + L, rn, rs, rs + L2, rcf))
+    return lines, "\n".join(spec)

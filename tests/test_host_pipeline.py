@@ -70,6 +70,56 @@ def test_alignment_live_vs_reference_classes(host, oracle_dp):
         assert host.guide_from_chains(*c, test_dp=oracle_dp) == ref.guide_from_chains(*c)
 
 
+def test_merge_matches_reference_golden(host, host_golden):
+    assert len(host_golden["merges"]) >= 40
+    for c in host_golden["merges"]:
+        assert host.merge(c["lines"], 250) == c["expect"]
+
+
+def test_merge_live_vs_reference(host):
+    from oracle.binding import ReferenceAlign
+    try:
+        ref = ReferenceAlign()
+    except Exception:
+        pytest.skip("oracle/_ref/libref_align.so not built and /root/reference absent")
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        lines, spec = hostgen.merge_case(rng)
+        assert host.merge(lines, 250) == ref.merge(spec, 250)
+
+
+def test_bucket_stage(host, oracle_dp, tmp_path):
+    """`align bucket`: every seed ends up (extended, possibly merged) in exactly one bucket; buckets feed `generate`."""
+    fa = str(tmp_path / "genome.fa")
+    genome, beds = hostgen.make_genome(fa, seed=4, glen=80000, nsd=8)
+    seeds = tmp_path / "seeds"
+    seeds.mkdir()
+    rng = np.random.default_rng(0)
+    with open(seeds / "a.bed", "w") as f:  # several overlapping seeds per planted duplication
+        for (a, e, b, e2, rcf) in beds:
+            for _ in range(3):
+                o = int(rng.integers(0, 300))
+                f.write("chrT\t%d\t%d\tchrT\t%d\t%d\t\t\t+\t%s\t%d\t0\t\tOK\n" % (
+                    a + o, a + o + 800, b + o, b + o + 800, "-" if rcf else "+", 800))
+    out = tmp_path / "buckets"
+    out.mkdir()
+    host.bucket(str(seeds), 3, str(out), fa)
+    files = sorted(os.listdir(out))
+    assert files == ["bucket_0000", "bucket_0001", "bucket_0002"]
+    lines = [ln for fn in files for ln in open(out / fn).read().splitlines()]
+    assert 1 <= len(lines) <= len(beds) * 3
+    for ln in lines:
+        f = ln.split("\t")
+        assert len(f) >= 12 and int(f[1]) < int(f[2]) and int(f[4]) < int(f[5]) and f[8] == "+"
+    # merged + extended seeds cover the planted duplications; the buckets align
+    res = tmp_path / "aligned.bed"
+    total = 0
+    for fn in files:
+        st = host.generate(fa, str(out / fn), 11, str(res), test_dp=oracle_dp)
+        total += st[1]
+    assert total >= 4
+
+
 # ---------------------------------------------------------------- D3 FASTA
 def test_fasta_random_access(host, tmp_path):
     s, _ = hostgen.make_genome(str(tmp_path / "g.fa"), seed=3, glen=5000, nsd=0)
