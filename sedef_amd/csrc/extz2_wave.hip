@@ -68,9 +68,7 @@ __device__ __forceinline__ unsigned pk_nonzero_(unsigned a, unsigned one_opaque)
 #define pk_nonzero(a) pk_nonzero_((a), one2)
 // F <- (F << 1) | bit, as the single instruction it is
 __device__ __forceinline__ unsigned shl1_or(unsigned f, unsigned bit) {
-  unsigned d;
-  asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(d) : "v"(f), "v"(bit));
-  return d;
+  return (f << 1) + bit;  // bit 0 of f << 1 is clear: + == |, and it selects as one v_lshl_add_u32
 }
 __device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
   return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) +
@@ -506,6 +504,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_w
       for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
     }
     qrow = re;
+    if (STEADY && !SCALARH) hcnt += re - rb;  // every steady row takes one path step
     const unsigned vcar = base == 0 ? ((unsigned)sc.q_b << 24) : 0u;  // v carry into slot 0 (r > 0)
 #pragma unroll 1
     for (int r = rb; r < re; ++r) {
@@ -650,7 +649,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_w
               }
           }
           if (lane == ((sl & 127) >> 1)) hacc += (val >> sh) & 0xffu;
-          ++hcnt;
+          if (!STEADY) ++hcnt;
         }
       }
     }
