@@ -284,3 +284,35 @@ def test_very_long_task_hbm_state(engine, oracle):
         for f in FIELDS:
             assert got[f] == exp[f], (f, w)
         assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"])
+
+
+def test_wave_kernel_fuzz_all_register_counts(engine, oracle):
+    """Random shapes up to 1100 with bands that map onto every NREG variant (and onto the general kernel
+    beyond 1024 window cells), unrelated as well as related sequences."""
+    rng = np.random.default_rng(4242)
+    pairs, ws = [], []
+    for _ in range(500):
+        ql = int(rng.integers(1, 1100))
+        q = random_codes(rng, ql, 0.01 if rng.random() < 0.2 else 0.0)
+        if rng.random() < 0.25:
+            t = random_codes(rng, int(rng.integers(1, 1100)))
+        else:
+            d = rng.random() * 0.1
+            t = mutate(rng, q, d, d / 3, d / 3)
+            if rng.random() < 0.3:
+                k = int(rng.integers(0, len(t)))
+                t = np.concatenate([t[:k], random_codes(rng, int(rng.integers(1, 300))), t[k:]])
+        pairs.append((q, t))
+        ws.append(int(rng.choice([-1, -1, 3, 20, 50, 120, 200, 260, 400, 480, 700])))
+    _check_fast(engine, oracle, pairs, ws)
+
+
+def test_tiny_tasks_bulk(engine, oracle):
+    """SEDEF's most frequent call shape: gap fills of a few bases (w=-1)."""
+    rng = np.random.default_rng(99)
+    pairs = []
+    for _ in range(3000):
+        q = random_codes(rng, int(rng.integers(1, 24)))
+        t = random_codes(rng, int(rng.integers(1, 24))) if rng.random() < 0.5 else mutate(rng, q, 0.1, 0.05, 0.05)
+        pairs.append((q, t))
+    _check_fast(engine, oracle, pairs, [-1] * len(pairs))
