@@ -150,6 +150,26 @@ float sdf_last_ms(const sdf_ctx *ctx, int which);
 /* Number of DP kernel launches in the last batch call and algorithmic bytes they moved. */
 int sdf_last_launches(const sdf_ctx *ctx);
 
+/* ---- seed anchors on the GPU (next row of the scope table) -----------------------------------
+ * Replaces generate_anchors (reference: src/chain.cc:24-101) for a batch of candidate pairs: maximal exact
+ * k-mer matches, in the reference's order (query position, then reference position).  Sequences are the raw
+ * FASTA characters (case = soft-masking, N = unknown).  kmer <= 11, sequences shorter than 4 Mb. */
+typedef struct {
+  int64_t q_off, r_off; /* byte offsets of query / reference characters in seq_pool */
+  int32_t qlen, rlen;
+  int32_t same_chr;     /* 1: same chromosome and strand -> k-mers within `kmer` of the main diagonal are skipped */
+  int32_t delta;        /* ref_start - query_start of the pair (src/chain.cc:67-69) */
+} sdf_anchor_pair;
+
+typedef struct {
+  int32_t q, r, l, has_u; /* reference: struct Anchor, src/align.h:25-28 */
+} sdf_anchor;
+
+/* out[out_off[i] .. out_off[i+1]) are the anchors of pair i (out_off has n+1 entries).  *out_used receives the
+ * total; with SDF_ERR_CIGAR_OVERFLOW it holds the capacity needed. */
+int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *seq_pool, size_t pool_bytes,
+                      int kmer, sdf_anchor *out, size_t out_cap, int64_t *out_off, size_t *out_used);
+
 /* ---- one-task drop-in: same contract as ksw_extz2_sse (extern/ksw2.h:50).  `km` is ignored
  * like in the reference build (no HAVE_KALLOC).  Uses a process-wide context on device 0 (or
  * the device named by SDF_DEVICE).  On a fatal error prints to stderr and exits with 120, the

@@ -1,0 +1,162 @@
+// GPU seed anchors: maximal exact k-mer matches between the two sequences of a candidate pair.
+//
+// Restates generate_anchors (reference: src/chain.cc:24-101) as sort / search / scan kernels and returns the
+// anchors in the reference's order (query position ascending, then reference position ascending):
+//   1. every reference k-mer (2 bits per base, windows with an N skipped, :28-40) becomes a 64-bit key
+//      pair:20 | hash:22 | position:22; one radix sort groups equal k-mers of a pair, positions ascending;
+//   2. every query k-mer finds its run of equal keys by binary search; runs of >= 1000 are disabled (:61);
+//   3. an exclusive scan of the run lengths enumerates the candidate (q, r) pairs in reference order;
+//   4. a candidate starts an anchor iff no earlier enabled k-mer of the same uninterrupted match run lies on its
+//      diagonal -- that is what the per-diagonal `slide[]` bookkeeping (:42,70-72,92) amounts to, because an
+//      anchor always extends to the end of its run; starts are extended to the right (:76-85) and compacted.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+
+struct AnchorPairDev {
+  int64_t q_off, r_off;    // byte offsets of the raw sequences in the pool
+  int32_t qlen, rlen;
+  int32_t same_chr, delta;  // near-diagonal filter of self comparisons (:67-69)
+  int64_t rk_start, qk_start;  // first global k-mer index of this pair's reference / query
+};
+
+__device__ __forceinline__ int up(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+__device__ __forceinline__ bool is_upper(int c) { return c >= 'A' && c <= 'Z'; }
+__device__ __forceinline__ int base2(int c) {  // hash_dna (src/common.h:69,89): ACGT -> 0..3, anything else 0
+  c = up(c);
+  return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
+}
+// hash of the k-mer starting at s; returns false if the window holds an N
+__device__ __forceinline__ bool kmer_at(const char *s, int k, uint32_t &h) {
+  h = 0;
+  bool ok = true;
+  for (int i = 0; i < k; i++) {
+    const int c = s[i];
+    ok = ok && up(c) != 'N';
+    h = (h << 2) | (uint32_t)base2(c);
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void ref_keys_kernel(const AnchorPairDev *pairs, const char *pool, int k,
+                                                       unsigned long long *keys) {
+  const AnchorPairDev p = pairs[blockIdx.y];
+  const int nk = p.rlen - k + 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
+    uint32_t h;
+    const bool ok = kmer_at(pool + p.r_off + i, k, h);
+    keys[p.rk_start + i] = ok ? (((unsigned long long)blockIdx.y << 44) | ((unsigned long long)h << 22) | (unsigned)i)
+                              : ~0ull;
+  }
+}
+
+__device__ __forceinline__ long long lower_bound_u64(const unsigned long long *a, long long n, unsigned long long v) {
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void query_lookup_kernel(const AnchorPairDev *pairs, const char *pool, int k,
+                                                           const unsigned long long *keys, long long nkeys,
+                                                           uint32_t *qlo, uint32_t *qcnt, uint32_t *qeff,
+                                                           uint32_t *qpair) {
+  const AnchorPairDev p = pairs[blockIdx.y];
+  const int nk = p.qlen - k + 1;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
+    uint32_t h;
+    const bool ok = kmer_at(pool + p.q_off + i, k, h);
+    uint32_t lo = 0, cnt = 0;
+    if (ok) {
+      const unsigned long long base = ((unsigned long long)blockIdx.y << 44) | ((unsigned long long)h << 22);
+      const long long a = lower_bound_u64(keys, nkeys, base);
+      const long long b = lower_bound_u64(keys, nkeys, base + (1ull << 22));
+      lo = (uint32_t)a;
+      cnt = (uint32_t)(b - a);
+    }
+    const long long g = p.qk_start + i;
+    qlo[g] = lo;
+    qcnt[g] = cnt;
+    qeff[g] = cnt < 1000 ? cnt : 0;  // it->second.size() >= 1000 -> skipped (:61)
+    qpair[g] = blockIdx.y;
+  }
+}
+
+struct CandOut {
+  int32_t q, r, l, has_u;
+};
+
+__global__ __launch_bounds__(256) void candidates_kernel(const AnchorPairDev *pairs, const char *pool, int k,
+                                                         const unsigned long long *keys, const uint32_t *qlo,
+                                                         const uint32_t *qcnt, const unsigned long long *cand_off,
+                                                         const uint32_t *qpair, long long nq, long long ncand,
+                                                         uint32_t *flag, CandOut *cand) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncand) return;
+  // owner query k-mer: last g with cand_off[g] <= c
+  long long lo = 0, hi = nq;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (cand_off[mid] <= (unsigned long long)c) lo = mid + 1; else hi = mid;
+  }
+  const long long g = lo - 1;
+  const AnchorPairDev p = pairs[qpair[g]];
+  const int q = (int)(g - p.qk_start);
+  const int j = (int)((unsigned long long)c - cand_off[g]);
+  const int r = (int)(keys[qlo[g] + j] & ((1u << 22) - 1));
+  const char *Q = pool + p.q_off, *R = pool + p.r_off;
+  bool start = !(p.same_chr && abs(p.delta + r - q) <= k);
+  // an earlier enabled k-mer of the same match run on this diagonal already covers this one
+  for (int s = 1; start; s++) {
+    const int qq = q - s, rr = r - s;
+    if (qq < 0 || rr < 0) break;
+    const int cq = up(Q[qq]), cr = up(R[rr]);
+    if (cq == 'N' || cr == 'N' || cq != cr) break;
+    if (qcnt[g - s] < 1000) start = false;  // enabled: its anchor (or an even earlier one) extends over q
+  }
+  uint32_t f = 0;
+  if (start) {
+    int len = 0;
+    bool hu = false;
+    for (; q + len < p.qlen && r + len < p.rlen; len++) {
+      const int a = Q[q + len], b = R[r + len];
+      if (up(a) == 'N' || up(b) == 'N' || up(a) != up(b)) break;
+      hu = hu || is_upper(a) || is_upper(b);
+    }
+    if (len >= k) {
+      f = 1;
+      cand[c] = CandOut{q, r, len, hu ? 1 : 0};
+    }
+  }
+  flag[c] = f;
+}
+
+__global__ __launch_bounds__(256) void anchors_compact_kernel(const uint32_t *flag, const unsigned long long *pos,
+                                                              const CandOut *cand, long long ncand, CandOut *out,
+                                                              unsigned long long cap) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncand || !flag[c]) return;
+  if (pos[c] < cap) out[pos[c]] = cand[c];
+}
+
+// anchors before pair p = kept candidates before the first candidate of the pair's first query k-mer
+__global__ void anchor_offsets_kernel(const AnchorPairDev *pairs, int npairs, const unsigned long long *cand_off,
+                                      const unsigned long long *pos, long long ncand, unsigned long long total,
+                                      long long nq, long long *out_off) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > npairs) return;
+  if (p == npairs) {
+    out_off[p] = (long long)total;
+    return;
+  }
+  const long long g = pairs[p].qk_start;
+  const unsigned long long c0 = g < nq ? cand_off[g] : (unsigned long long)ncand;
+  out_off[p] = c0 < (unsigned long long)ncand ? (long long)pos[c0] : (long long)total;
+}
+
+}  // namespace sdf

@@ -282,6 +282,29 @@ int sdfh_bucket(const char *bed_path, int nbins, const char *out_dir, const char
   }
 }
 
+// generate_anchors on the host (reference: src/chain.cc:24-101): "q r l has_u;" per anchor, in order
+int sdfh_anchors(const char *query, const char *ref, int kmer, int same_chr, int qstart, int rstart, char *buf,
+                 size_t cap) {
+  try {
+    Hit orig;
+    orig.query = std::make_shared<Sequence>("A", "");
+    orig.ref = std::make_shared<Sequence>(same_chr ? "A" : "B", "");
+    orig.query_start = qstart;
+    orig.ref_start = rstart;
+    std::vector<Anchor> an = generate_anchors(query, ref, orig, kmer);
+    std::string out;
+    char t[96];
+    for (auto &a : an) {
+      snprintf(t, sizeof t, "%d %d %d %d;", a.q, a.r, a.l, a.has_u);
+      out += t;
+    }
+    return copy_out(out, buf, cap);
+  } catch (std::string &s) {
+    g_err = s;
+    return -1;
+  }
+}
+
 // Chain extraction for one pair: anchors + chains (reference: src/chain.cc:24-199).  Writes
 // "q r l has_u" per anchor of each kept chain, chains separated by "|" -- for self-consistency tests.
 int sdfh_chains(const char *query, const char *ref, int kmer, char *buf, size_t cap) {

@@ -118,6 +118,50 @@ class GpuProvider : public DpProvider {
     return out;
   }
 
+  // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
+  bool anchors(const std::vector<AnchorJob> &jobs, int kmer, std::vector<std::vector<Anchor>> &out) override {
+    static const bool enabled = [] {
+      const char *e = getenv("SDF_GPU_ANCHORS");
+      return !(e && e[0] == '0');
+    }();
+    if (!enabled || kmer > 11 || jobs.empty()) return false;
+    std::vector<sdf_anchor_pair> pairs(jobs.size());
+    size_t total = 0;
+    for (auto &j : jobs) total += j.query->size() + j.ref->size();
+    std::string pool;
+    pool.reserve(total);
+    for (size_t k = 0; k < jobs.size(); k++) {
+      if (jobs[k].query->size() >= (1u << 22) || jobs[k].ref->size() >= (1u << 22)) return false;
+      pairs[k].q_off = (int64_t)pool.size();
+      pool += *jobs[k].query;
+      pairs[k].r_off = (int64_t)pool.size();
+      pool += *jobs[k].ref;
+      pairs[k].qlen = (int32_t)jobs[k].query->size();
+      pairs[k].rlen = (int32_t)jobs[k].ref->size();
+      pairs[k].same_chr = jobs[k].same_chr;
+      pairs[k].delta = jobs[k].delta;
+    }
+    std::vector<int64_t> off(jobs.size() + 1);
+    std::vector<sdf_anchor> buf(std::max<size_t>(total / 8, 4096));
+    size_t used = 0;
+    int rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.data(), pool.size(), kmer, buf.data(), buf.size(),
+                               off.data(), &used);
+    if (rc == SDF_ERR_CIGAR_OVERFLOW) {
+      buf.resize(used);
+      rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.data(), pool.size(), kmer, buf.data(), buf.size(),
+                             off.data(), &used);
+    }
+    if (rc == SDF_ERR_UNSUPPORTED || rc == SDF_ERR_NOMEM) return false;
+    if (rc != SDF_OK) throw std::string("GPU anchors failed: ") + sdf_last_error(ctx_);
+    out.resize(jobs.size());
+    static_assert(sizeof(sdf_anchor) == sizeof(Anchor), "layouts must agree");
+    for (size_t k = 0; k < jobs.size(); k++) {
+      out[k].resize((size_t)(off[k + 1] - off[k]));
+      if (!out[k].empty()) memcpy(out[k].data(), buf.data() + off[k], out[k].size() * sizeof(Anchor));
+    }
+    return true;
+  }
+
  private:
   sdf_ctx *ctx_;
   int64_t tasks_ = 0;
@@ -165,6 +209,16 @@ std::unique_ptr<DpProvider> make_test_provider(test_dp_fn fn) { return std::uniq
 // ======================================================================================================
 // PairJob
 // ======================================================================================================
+namespace {
+std::atomic<long long> g_us_chain(0), g_us_rest(0);  // host CPU time (summed over threads), microseconds
+struct ScopedUs {
+  std::atomic<long long> &acc;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit ScopedUs(std::atomic<long long> &a) : acc(a) {}
+  ~ScopedUs() { acc += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 struct PairJob::PathState {
   std::deque<int> idx;       // chain hits of the path, in order
   int qlo, qhi, rlo, rhi;    // extent from the chain coordinates (before any merge)
@@ -185,7 +239,7 @@ PairJob::PairJob(const std::string &query, const std::string &ref, const Hit &or
 void PairJob::stage_start(std::vector<DpRequest> &out) {  // src/chain.cc:203-258
   query_ptr_ = std::make_shared<Sequence>("QRY", query_);
   ref_ptr_ = std::make_shared<Sequence>("REF", ref_);
-  anchors_ = generate_anchors(query_, ref_, orig_, p_.kmer);
+  if (!have_anchors_) anchors_ = generate_anchors(query_, ref_, orig_, p_.kmer);
   auto chains = chain_anchors(anchors_, p_);
   const auto &chain = chains.first;
   const auto &bounds = chains.second;
@@ -303,6 +357,7 @@ void PairJob::plan_paths() {  // src/refine.cc:23-147
 
 std::vector<DpRequest> PairJob::advance(const std::vector<Cigar> &results) {
   std::vector<DpRequest> out;
+  ScopedUs timer(stage_ == START ? g_us_chain : g_us_rest);
   if (stage_ == START) {
     stage_start(out);
     stage_ = CHAIN_ALN;
@@ -506,6 +561,9 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   p.kmer = kmer_size;
   set_alignment_scoring(p);
   GenerateStats st;
+  double dp_secs = 0, anchor_secs = 0;
+  g_us_chain = 0;
+  g_us_rest = 0;
   std::vector<Hit> schedule = read_schedule(bed_path, log);
   FastaReference fr(ref_path);
   fprintf(log, "Using k-mer size %d\n", kmer_size);
@@ -527,6 +585,20 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       it.fb = fr.get_sequence(it.h.ref->name, it.h.ref_start, &it.h.ref_end);
       if (it.h.ref->is_rc) it.fb = rc(it.fb);
       it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
+    }
+    {  // seed anchors of the whole super-batch in one device pass, when the provider offers it
+      std::vector<DpProvider::AnchorJob> aj(n);
+      for (int k = 0; k < n; k++) {
+        const Hit &h = items[k].h;
+        aj[k] = {&items[k].fa, &items[k].fb, h.query->name == h.ref->name && h.query->is_rc == h.ref->is_rc,
+                 h.ref_start - h.query_start};
+      }
+      std::vector<std::vector<Anchor>> got;
+      const auto ta = std::chrono::steady_clock::now();
+      if (dp.anchors(aj, p.kmer, got)) {
+        for (int k = 0; k < n; k++) items[k].job->set_anchors(std::move(got[k]));
+        anchor_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+      }
     }
     // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch
     std::vector<std::vector<Cigar>> results(n);
@@ -552,7 +624,9 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       }
       if (!any) break;
       st.rounds++;
+      const auto td = std::chrono::steady_clock::now();
       std::vector<Cigar> got = dp.run(batch, p);
+      dp_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - td).count();
       size_t cur = 0;
       for (auto &o : owners) {
         results[o.first].assign(got.begin() + cur, got.begin() + cur + o.second);
@@ -588,6 +662,10 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   fprintf(log, "\nFinished BED %s in %.2fs (%d lines, generated %d hits)\n", bed_path.c_str(), secs, st.lines,
           st.total_written);
+  fprintf(log, "  [host CPU: anchors+chaining %.2fs, stitching+refinement %.2fs (summed over threads); device anchors %.2fs wall; DP "
+               "provider %.2fs wall in %d rounds, %lld tasks, %.3g cells]\n",
+          g_us_chain.load() / 1e6, g_us_rest.load() / 1e6, anchor_secs, dp_secs, st.rounds, (long long)dp.tasks,
+          (double)dp.cells);
   return st;
 }
 

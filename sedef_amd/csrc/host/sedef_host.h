@@ -35,6 +35,11 @@ struct Params {
   double max_error = 0.30;
 };
 
+struct Anchor {  // reference: src/align.h:25-28
+  int q, r, l;
+  int has_u;
+};
+
 // ---- DP requests ---------------------------------------------------------------------------------
 // One align_helper call: the two strings are ALREADY mapped through align_dna (codes 0..4 as chars).
 struct DpRequest {
@@ -46,6 +51,16 @@ class DpProvider {
  public:
   virtual ~DpProvider() {}
   virtual std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) = 0;
+  // Optional: generate_anchors for a batch of pairs on the device.  Returns false if the provider cannot do it
+  // for these inputs (the caller then computes them on the host with generate_anchors()).
+  struct AnchorJob {
+    const std::string *query, *ref;
+    bool same_chr;
+    int delta;
+  };
+  virtual bool anchors(const std::vector<AnchorJob> &, int /*kmer*/, std::vector<std::vector<Anchor>> &) {
+    return false;
+  }
   int64_t tasks = 0, cells = 0;  // statistics
 };
 
@@ -75,11 +90,6 @@ struct Sequence {  // reference: src/hash.h:51-57, src/hash.cc:104-109
 };
 
 struct Hit;
-
-struct Anchor {  // reference: src/align.h:25-28
-  int q, r, l;
-  int has_u;
-};
 
 class Alignment {  // reference: src/align.h:32-103
  public:
@@ -181,6 +191,10 @@ class PairJob {
   // Call again with the results of the previous return value, in the same order.
   std::vector<DpRequest> advance(const std::vector<Cigar> &results);
   bool done() const { return stage_ == DONE; }
+  void set_anchors(std::vector<Anchor> a) {  // anchors computed elsewhere (GPU batch)
+    anchors_ = std::move(a);
+    have_anchors_ = true;
+  }
   std::vector<Hit> &hits() { return final_hits_; }
 
  private:
@@ -195,6 +209,7 @@ class PairJob {
   Hit orig_;
   Params p_;
   Stage stage_ = START;
+  bool have_anchors_ = false;
   std::shared_ptr<Sequence> query_ptr_, ref_ptr_;
   std::vector<Anchor> anchors_;
   std::vector<std::vector<int>> guides_;

@@ -80,6 +80,7 @@ struct sdf_ctx {
   hipStream_t stream = nullptr;
   size_t ws_budget = 0;
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
+  DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
   std::vector<hipEvent_t> events;
   float ms[4] = {0, 0, 0, 0};
@@ -161,6 +162,9 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
+  for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
+                    &ctx->an_pos, &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff})
+    b->release();
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
                     &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
     b->release();
@@ -548,6 +552,133 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
   SDF_HIP(hipMemcpy(out, ctx->h_out.p, n * sizeof(sdf_result), hipMemcpyDeviceToHost));
   if (used && cigar_pool) SDF_HIP(hipMemcpy(cigar_pool, ctx->h_cig.p, used * 4, hipMemcpyDeviceToHost));
   return SDF_OK;
+}
+
+// ---- seed anchors (reference: src/chain.cc:24-101) ---------------------------------------------------
+static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *d_pool, int kmer,
+                         sdf_anchor *out, size_t out_cap, int64_t *out_off, size_t *out_used, hipStream_t st) {
+  using namespace sdf;
+  std::vector<AnchorPairDev> hp(n);
+  long long nrk = 0, nqk = 0;
+  for (size_t i = 0; i < n; i++) {
+    AnchorPairDev &d = hp[i];
+    d.q_off = pairs[i].q_off;
+    d.r_off = pairs[i].r_off;
+    d.qlen = pairs[i].qlen;
+    d.rlen = pairs[i].rlen;
+    d.same_chr = pairs[i].same_chr;
+    d.delta = pairs[i].delta;
+    d.rk_start = nrk;
+    d.qk_start = nqk;
+    nrk += std::max(0, d.rlen - kmer + 1);
+    nqk += std::max(0, d.qlen - kmer + 1);
+  }
+  for (size_t i = 0; i <= n; i++) out_off[i] = 0;
+  *out_used = 0;
+  if (nrk == 0 || nqk == 0) return SDF_OK;
+  SDF_HIP(ctx->an_pairs.reserve(n * sizeof(AnchorPairDev)));
+  SDF_HIP(ctx->an_keys.reserve((size_t)nrk * 8));
+  SDF_HIP(ctx->an_keys2.reserve((size_t)nrk * 8));
+  SDF_HIP(ctx->an_q.reserve((size_t)nqk * 16));
+  SDF_HIP(ctx->an_off.reserve((size_t)(nqk + 1) * 8));
+  SDF_HIP(ctx->an_outoff.reserve((n + 1) * 8));
+  AnchorPairDev *d_pairs = (AnchorPairDev *)ctx->an_pairs.p;
+  unsigned long long *d_keys = (unsigned long long *)ctx->an_keys.p, *d_keys2 = (unsigned long long *)ctx->an_keys2.p;
+  uint32_t *d_qlo = (uint32_t *)ctx->an_q.p, *d_qcnt = d_qlo + nqk, *d_qeff = d_qcnt + nqk, *d_qpair = d_qeff + nqk;
+  unsigned long long *d_off = (unsigned long long *)ctx->an_off.p;
+  SDF_HIP(hipMemcpyAsync(d_pairs, hp.data(), n * sizeof(AnchorPairDev), hipMemcpyHostToDevice, st));
+  const dim3 grid(32, (unsigned)n);
+  hipLaunchKernelGGL(ref_keys_kernel, grid, dim3(256), 0, st, d_pairs, d_pool, kmer, d_keys);
+  size_t tmp_bytes = 0;
+  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, 64, st));
+  size_t scan_bytes = 0;
+  SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (unsigned long long *)nullptr,
+                                           (int)(nqk + 1), st));
+  SDF_HIP(ctx->an_tmp.reserve(std::max(tmp_bytes, scan_bytes) + 256));
+  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(ctx->an_tmp.p, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, 64, st));
+  hipLaunchKernelGGL(query_lookup_kernel, grid, dim3(256), 0, st, d_pairs, d_pool, kmer, d_keys2, nrk, d_qlo, d_qcnt,
+                     d_qeff, d_qpair);
+  // exclusive scan over nqk+1 entries (the extra input element is ignored by the exclusive form)
+  SDF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->an_tmp.p, scan_bytes, d_qeff, d_off, (int)(nqk + 1), st));
+  unsigned long long ncand = 0;
+  SDF_HIP(hipMemcpyAsync(&ncand, d_off + nqk, 8, hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  if (ncand == 0) return SDF_OK;
+  if (ncand > (1ull << 30)) {
+    ctx->err = "anchor candidates exceed 2^30 in one batch";
+    return SDF_ERR_NOMEM;
+  }
+  SDF_HIP(ctx->an_flag.reserve((size_t)(ncand + 1) * 4));
+  SDF_HIP(ctx->an_pos.reserve((size_t)(ncand + 1) * 8));
+  SDF_HIP(ctx->an_cand.reserve((size_t)ncand * sizeof(CandOut)));
+  uint32_t *d_flag = (uint32_t *)ctx->an_flag.p;
+  unsigned long long *d_pos = (unsigned long long *)ctx->an_pos.p;
+  CandOut *d_cand = (CandOut *)ctx->an_cand.p;
+  const unsigned nb = (unsigned)((ncand + 255) / 256);
+  hipLaunchKernelGGL(candidates_kernel, dim3(nb), dim3(256), 0, st, d_pairs, d_pool, kmer, d_keys2, d_qlo, d_qcnt, d_off,
+                     d_qpair, nqk, (long long)ncand, d_flag, d_cand);
+  SDF_HIP(hipMemsetAsync(d_flag + ncand, 0, 4, st));
+  size_t scan2 = 0;
+  SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, d_flag, d_pos, (int)(ncand + 1), st));
+  SDF_HIP(ctx->an_tmp.reserve(scan2 + 256));
+  SDF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->an_tmp.p, scan2, d_flag, d_pos, (int)(ncand + 1), st));
+  unsigned long long total = 0;
+  SDF_HIP(hipMemcpyAsync(&total, d_pos + ncand, 8, hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  *out_used = (size_t)total;
+  long long *d_outoff = (long long *)ctx->an_outoff.p;
+  hipLaunchKernelGGL(anchor_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, d_pairs, (int)n, d_off,
+                     d_pos, (long long)ncand, total, nqk, d_outoff);
+  SDF_HIP(hipMemcpyAsync(out_off, d_outoff, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+  if (total > out_cap) {
+    SDF_HIP(hipStreamSynchronize(st));
+    ctx->err = "anchor output buffer too small";
+    return SDF_ERR_CIGAR_OVERFLOW;
+  }
+  if (total) {
+    SDF_HIP(ctx->an_out.reserve((size_t)total * sizeof(CandOut)));
+    hipLaunchKernelGGL(anchors_compact_kernel, dim3(nb), dim3(256), 0, st, d_flag, d_pos, d_cand, (long long)ncand,
+                       (CandOut *)ctx->an_out.p, total);
+    SDF_HIP(hipMemcpyAsync(out, ctx->an_out.p, (size_t)total * sizeof(sdf_anchor), hipMemcpyDeviceToHost, st));
+  }
+  SDF_HIP(hipStreamSynchronize(st));
+  SDF_HIP(hipGetLastError());
+  return SDF_OK;
+}
+
+extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *seq_pool,
+                                 size_t pool_bytes, int kmer, sdf_anchor *out, size_t out_cap, int64_t *out_off,
+                                 size_t *out_used) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  if (out_used) *out_used = 0;
+  if (!pairs || !out_off || !out_used || (!seq_pool && pool_bytes) || n >= (1u << 20)) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  if (kmer < 1 || kmer > 11) {
+    ctx->err = "GPU anchors implement k-mer sizes up to 11";
+    return SDF_ERR_UNSUPPORTED;
+  }
+  for (size_t i = 0; i < n; i++) {
+    const sdf_anchor_pair &p = pairs[i];
+    if (p.qlen < 0 || p.rlen < 0 || p.qlen >= (1 << 22) || p.rlen >= (1 << 22)) {
+      ctx->err = "GPU anchors implement sequences shorter than 4 Mb";
+      return SDF_ERR_UNSUPPORTED;
+    }
+    if (p.q_off < 0 || p.r_off < 0 || (size_t)p.q_off + p.qlen > pool_bytes || (size_t)p.r_off + p.rlen > pool_bytes) {
+      ctx->err = "pair sequence range outside the pool";
+      return SDF_ERR_INVALID;
+    }
+  }
+  SDF_HIP(hipSetDevice(ctx->device));
+  if (n == 0) {
+    out_off[0] = 0;
+    return SDF_OK;
+  }
+  SDF_HIP(ctx->an_pool.reserve(pool_bytes + 16));
+  SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+  return anchors_range(ctx, pairs, n, (const char *)ctx->an_pool.p, kmer, out, out_cap, out_off, out_used, ctx->stream);
 }
 
 // ---- one-task drop-in with the reference's exact signature (extern/ksw2.h:50) -----------------

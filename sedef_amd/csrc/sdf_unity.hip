@@ -2,4 +2,5 @@
 #include "extz2_general.hip"
 #include "extz2_wave.hip"
 #include "traceback.hip"
+#include "anchors.hip"
 #include "sdf_api.hip"

@@ -21,7 +21,10 @@ RESULT_DTYPE = np.dtype([("score", "<i4"), ("max", "<i4"), ("max_q", "<i4"), ("m
                          ("zdropped", "<i4"), ("n_cigar", "<i4"), ("cigar_off", "<i8"),
                          ("matches", "<i4"), ("mismatches", "<i4"), ("gaps", "<i4"),
                          ("gap_bases", "<i4")])
-assert TASK_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 64
+ANCHOR_PAIR_DTYPE = np.dtype([("q_off", "<i8"), ("r_off", "<i8"), ("qlen", "<i4"), ("rlen", "<i4"),
+                              ("same_chr", "<i4"), ("delta", "<i4")])
+ANCHOR_DTYPE = np.dtype([("q", "<i4"), ("r", "<i4"), ("l", "<i4"), ("has_u", "<i4")])
+assert TASK_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 64 and ANCHOR_PAIR_DTYPE.itemsize == 32
 
 
 class SdfError(RuntimeError):
@@ -68,6 +71,9 @@ def load_library():
     L.sdf_extz2_batch_device.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                          C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    L.sdf_anchors_batch.restype = C.c_int
+    L.sdf_anchors_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
     L.sdf_last_ms.restype = C.c_float
     L.sdf_last_ms.argtypes = [C.c_void_p, C.c_int]
     L.sdf_last_launches.restype = C.c_int
@@ -179,6 +185,32 @@ class Extz2Engine:
                                              stream)
         self._check(rc)
         return used.value
+
+    def anchors_batch(self, pairs, kmer=11):
+        """GPU generate_anchors.  pairs: list of (query str, ref str, same_chr, delta).  Returns one list of
+        (q, r, l, has_u) per pair (include/sedef_hip.h: sdf_anchors_batch)."""
+        n = len(pairs)
+        desc = np.zeros(n, ANCHOR_PAIR_DTYPE)
+        chunks, off = [], 0
+        for k, (q, r, same, delta) in enumerate(pairs):
+            qb, rb = q.encode(), r.encode()
+            desc[k] = (off, off + len(qb), len(qb), len(rb), int(same), int(delta))
+            off += len(qb) + len(rb)
+            chunks += [qb, rb]
+        pool = b"".join(chunks)
+        cap = max(1024, off)
+        while True:
+            out = np.zeros(cap, ANCHOR_DTYPE)
+            offs = np.zeros(n + 1, np.int64)
+            used = C.c_size_t(0)
+            rc = self.lib.sdf_anchors_batch(self.ctx, desc.ctypes.data, n, pool, len(pool), kmer, out.ctypes.data, cap,
+                                            offs.ctypes.data, C.byref(used))
+            if rc == -5:
+                cap = used.value
+                continue
+            self._check(rc)
+            break
+        return [[tuple(int(x) for x in a) for a in out[offs[k]:offs[k + 1]]] for k in range(n)]
 
     def last_ms(self, which):
         return float(self.lib.sdf_last_ms(self.ctx, which))

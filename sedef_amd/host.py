@@ -112,3 +112,11 @@ def merge(bed_lines, merge_dist=250):
 def bucket(bed_path, nbins, out_dir, reference):
     lib = load_host()
     _err(lib, lib.sdfh_bucket(bed_path.encode(), nbins, out_dir.encode(), reference.encode()))
+
+
+def anchors(q, r, kmer=11, same_chr=False, qstart=0, rstart=0):
+    """Host generate_anchors (reference: src/chain.cc:24-101) -> list of (q, r, l, has_u)."""
+    lib, buf = load_host(), _buffer()
+    lib.sdfh_anchors.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    _err(lib, lib.sdfh_anchors(q.encode(), r.encode(), kmer, int(same_chr), qstart, rstart, buf, len(buf)))
+    return [tuple(int(x) for x in a.split()) for a in buf.value.decode().split(";") if a]

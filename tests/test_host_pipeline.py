@@ -247,3 +247,26 @@ def test_alignment_golden_on_gpu(host, host_golden):
         assert cig == c["cigar"] and cnt == c["counts"]
     for c in host_golden["guides"]:
         assert host.guide_from_chains(c["q"], c["r"], c["spec"], c["side"]) == c["expect"]
+
+
+@pytest.mark.gpu
+def test_gpu_anchors_equal_host_anchors(host):
+    """sdf_anchors_batch (GPU sort/search/scan) returns exactly generate_anchors' list, in its order."""
+    import sedef_amd
+    eng = sedef_amd.Extz2Engine(0)
+    rng = np.random.default_rng(17)
+    pairs = []
+    for it in range(40):
+        q = hostgen.rseq(rng, int(rng.integers(5, 4000)), 0.004 if it % 2 else 0.0)
+        r = hostgen.rseq(rng, int(rng.integers(0, 300))) + hostgen.mut(rng, q, rng.random() * 0.1) + \
+            hostgen.rseq(rng, int(rng.integers(0, 300)))
+        if it % 5 == 0:  # low-complexity stretch: k-mers with >= 1000 occurrences are skipped
+            rep = "ACGTTGCAACGT" * 200
+            q, r = q[:500] + rep + q[500:], r[:300] + rep + rep[:700] + r[300:]
+        same = it % 3 == 0
+        pairs.append((q, r, same, int(rng.integers(-30, 30)) if same else 0))
+    pairs.append(("ACGT", "ACGTACGTACGTACGT", False, 0))  # shorter than k
+    got = eng.anchors_batch(pairs, 11)
+    for (q, r, same, delta), g in zip(pairs, got):
+        exp = host.anchors(q, r, 11, same_chr=same, qstart=0, rstart=delta)
+        assert g == exp, (len(q), len(r), same, delta, len(g), len(exp))
