@@ -217,7 +217,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    dp_ms, tb_ms, cp_ms, launches = 0.0, 0.0, 0.0, 0
+    dp_ms, tb_ms, cp_ms, launches, plan_ms, call_ms = 0.0, 0.0, 0.0, 0, 0.0, 0.0
     t0 = time.perf_counter()
     used = 0
     for _ in range(args.steps):
@@ -225,6 +225,8 @@ def main():
         dp_ms += eng.last_ms(0)
         tb_ms += eng.last_ms(1)
         cp_ms += eng.last_ms(2)
+        plan_ms += eng.last_ms(4)
+        call_ms += eng.last_ms(5)
         launches += eng.last_launches()
     sync()
     dt = time.perf_counter() - t0
@@ -263,7 +265,9 @@ def main():
                        "tasks_per_gpu": n, "band": w, "cells_per_step_per_gpu": cells_rank,
                        "parallelism": "task-sharded x%d + all-gatherv of result records" % world},
             "kernel_ms_per_step": {"dp": round(dp_ms / args.steps, 3), "traceback": round(tb_ms / args.steps, 3),
-                                   "compact": round(cp_ms / args.steps, 3)},
+                                   "compact": round(cp_ms / args.steps, 3),
+                                   "host_planning": round(plan_ms / args.steps, 3),
+                                   "host_call_total": round(call_ms / args.steps, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "extz2 DP", "launches_per_step": launches / args.steps,

@@ -145,7 +145,8 @@ int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *
 int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w);
 
 /* Timing of the last batch call, from HIP events recorded on the launch stream:
- * which = 0 DP kernels, 1 traceback, 2 CIGAR compaction, 3 whole call (stream time). */
+ * which = 0 DP kernels, 1 traceback, 2 CIGAR compaction, 3 whole call (stream time);
+ * 4 host-side planning before the first launch, 5 whole call on the host clock. */
 float sdf_last_ms(const sdf_ctx *ctx, int which);
 /* Number of DP kernel launches in the last batch call and algorithmic bytes they moved. */
 int sdf_last_launches(const sdf_ctx *ctx);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,7 +84,7 @@ struct sdf_ctx {
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
   std::vector<hipEvent_t> events;
-  float ms[4] = {0, 0, 0, 0};
+  float ms[6] = {0, 0, 0, 0, 0, 0};  // 0 DP, 1 traceback, 2 compaction, 3 stream total, 4 host planning, 5 host total
   int launches = 0;
   std::string err;
   int max_dyn_lds = 64 * 1024;
@@ -201,7 +202,7 @@ extern "C" int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w) {
 }
 
 extern "C" float sdf_last_ms(const sdf_ctx *ctx, int which) {
-  if (!ctx || which < 0 || which > 3) return 0.f;
+  if (!ctx || which < 0 || which > 5) return 0.f;
   return ctx->ms[which];
 }
 
@@ -247,8 +248,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
                                       size_t *cigar_used, void *stream_) {
   if (!ctx) return SDF_ERR_INVALID;
   ctx->err.clear();
-  ctx->ms[0] = ctx->ms[1] = ctx->ms[2] = ctx->ms[3] = 0.f;
+  for (float &m : ctx->ms) m = 0.f;
   ctx->launches = 0;
+  const auto host_t0 = std::chrono::steady_clock::now();
   if (cigar_used) *cigar_used = 0;
   if (n == 0) return SDF_OK;
   if (!tasks || !d_out || n > 0x7fffffffu) {
@@ -409,6 +411,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     }
   }
 
+  ctx->ms[4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   PlanTask *d_plan = (PlanTask *)ctx->plan_buf.p;
   int32_t *d_order = (int32_t *)ctx->order_buf.p;
   unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
@@ -503,6 +506,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   }
   (void)hipEventElapsedTime(&ctx->ms[2], ev_c0, ev_c1);
   (void)hipEventElapsedTime(&ctx->ms[3], ev_begin, ev_end);
+  ctx->ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   return SDF_OK;
 }
 
