@@ -242,7 +242,7 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
   }
 
 template <int NREG>
-__global__ __launch_bounds__(64, NREG <= 2 ? 7 : NREG <= 4 ? 4 : 2) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
+__global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
                                                         const int32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ pool, ScoreK sc,
                                                         uint8_t *__restrict__ dirbase,
