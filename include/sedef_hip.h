@@ -150,6 +150,9 @@ int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w);
 float sdf_last_ms(const sdf_ctx *ctx, int which);
 /* Number of DP kernel launches in the last batch call and algorithmic bytes they moved. */
 int sdf_last_launches(const sdf_ctx *ctx);
+/* Number of tasks of the last batch call that ran two per wavefront: tasks with the same (qlen, tlen, w, flag)
+ * share the reference's band schedule (extern/ksw2_extz2_sse.cc:101-115) and are packed side by side. */
+long long sdf_last_paired(const sdf_ctx *ctx);
 
 /* ---- seed anchors on the GPU (next row of the scope table) -----------------------------------
  * Replaces generate_anchors (reference: src/chain.cc:24-101) for a batch of candidate pairs: maximal exact

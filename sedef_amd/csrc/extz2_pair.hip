@@ -1,0 +1,707 @@
+// Register-resident extz2 DP kernel for gfx950: one wavefront per PAIR of DP tasks of equal geometry.
+//
+// Same results as extz2_wave.hip (and therefore as the reference kernel,
+// extern/ksw2_extz2_sse.cc:23-298) for the fields SEDEF consumes -- CIGAR, score, mte.  The band
+// schedule of the reference (which cells are computed on which anti-diagonal, where the 16-cell
+// blocks start, which scores are refreshed) depends on (qlen, tlen, w) only, so two tasks with the
+// same triple share every lane predicate and every scalar decision.  They are packed side by side
+// in the 16-bit halves of each register:
+//
+//   * lane l of register k owns window slot 64k+l of BOTH tasks: task A in the low half, task B
+//     in the high half (value<<8 each, as in extz2_wave.hip: the packed 16-bit ALU reproduces the
+//     reference's wrap-around int8 arithmetic);
+//   * the (r-1, t-1) neighbour is a plain wavefront DPP shift (no half-word realignment), window
+//     ranges are whole-lane compares (no SDWA half selects), the per-row scalar work is shared;
+//   * a window of `need` slots takes ceil(need/64) registers for two tasks instead of
+//     ceil(need/128) per task -- at w=128 (176 slots) 1.5 instead of 2 register-rows per task-row;
+//   * direction flags leave as 8 bytes per lane per task per 16 rows (four 16-bit row masks),
+//     0.5 B per slot as before.
+//
+// This file is compiled inside sdf_unity.hip after extz2_wave.hip and uses its helpers
+// (pk_*, SDF_OPQ, SDF_CORE).  Special rows (first rows, captured carries, the sign-extension
+// artefact of the reference's carry-in) are data dependent: if either task needs the general row,
+// both take it -- it is exact for every row.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+
+// byte code of a base: 0..3, or 0x80|wild for N
+__device__ __forceinline__ uint32_t pool_code8(const uint32_t *codes, const uint32_t *nmask, int k,
+                                               uint32_t wild) {
+  const uint32_t c = (codes[k >> 4] >> ((k & 15) * 2)) & 3u;
+  const uint32_t n = (nmask[k >> 5] >> (k & 31)) & 1u;
+  return n ? (0x80u | wild) : c;
+}
+
+// lanes [a, b) (a >= 0)
+__device__ __forceinline__ bool lane_in(int lane, int a, int b) {
+  return (unsigned)(lane - a) < (unsigned)(b > a ? b - a : 0);
+}
+
+// 0xff00 in the halves whose value is negative (the reference's sign-extended carry, :145-146)
+__device__ __forceinline__ unsigned sign_smear(unsigned c) {
+  return ((c & 0x8000u) ? 0xff00u : 0u) | ((c & 0x80000000u) ? 0xff000000u : 0u);
+}
+
+// fresh (score + 2(q+e)) << 8 of the lane's cell of both tasks from the target / query byte codes
+#define SDF_PFRESH(z, tc, qword, QSEL, WITH_N)                          \
+  {                                                                     \
+    const unsigned qc_ = __builtin_amdgcn_perm(0u, (qword), (QSEL)); /* bytes -> halves */ \
+    const unsigned d_ = pk_sub(tc, qc_);                                \
+    const unsigned m_ = pk_nonzero(d_);                                 \
+    z = pk_mad(m_, z_delta, z_match_v);                                 \
+    if (WITH_N) {                                                       \
+      unsigned nn_ = pk_ashr15(pk_shl((tc) | qc_, 8));                  \
+      SDF_OPQ(nn_);                                                     \
+      z = (z_wild & nn_) | (z & ~nn_);                                  \
+    }                                                                   \
+  }
+
+template <int NREG>
+__global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 : 2) void extz2_pair_kernel(
+    const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
+    ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NSLOT = 64 * NREG;
+  const PlanTask tk = plan[order[2 * blockIdx.x]];       // task A (low halves)
+  const PlanTask tkb = plan[order[2 * blockIdx.x + 1]];  // task B (high halves): same qlen, tlen, w, flag
+  const int lane = threadIdx.x;
+  const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
+  const int T16 = (tlen + 15) / 16 * 16;
+  const int tcap = T16 + NSLOT + 32;   // target bytes (A | B << 8), zero padded
+  const int qcap = qlen + NSLOT + 36;  // reversed query with a 32-element front pad, same packing
+  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);
+  uint16_t *W = reinterpret_cast<uint16_t *>(lds + 2 * tcap);  // W[j] = QR[j-32], QR[e] = query[qlen-1-e]
+
+  // ---- unpack the 2-bit / N-mask sequences of both tasks into LDS ----
+  int has_n;
+  {
+    const uint32_t *twa = pool + tk.t_word, *tna = twa + (tlen + 15) / 16;
+    const uint32_t *qwa = pool + tk.q_word, *qna = qwa + (qlen + 15) / 16;
+    const uint32_t *twb = pool + tkb.t_word, *tnb = twb + (tlen + 15) / 16;
+    const uint32_t *qwb = pool + tkb.q_word, *qnb = qwb + (qlen + 15) / 16;
+    uint32_t n_seen = 0;
+    for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tna[k] | tnb[k];
+    for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qna[k] | qnb[k];
+    has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0));  // wave-uniform
+    for (int t = lane; t < tcap; t += 64)
+      Tb[t] = t < tlen ? (uint16_t)(pool_code8(twa, tna, t, sc.wild) | (pool_code8(twb, tnb, t, sc.wild) << 8)) : 0;
+    for (int j = lane; j < qcap; j += 64) {
+      const int e = j - 32;
+      const bool in = e >= 0 && e < qlen;
+      W[j] = in ? (uint16_t)(pool_code8(qwa, qna, qlen - 1 - e, sc.wild) |
+                             (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 8))
+                : 0;
+    }
+  }
+  __syncthreads();
+
+  // ---- constants of the <<8 difference domain ----
+  const unsigned qb2 = ((unsigned)sc.q_b << 8) * 0x00010001u;
+  const unsigned qv = qb2;
+  const unsigned capv = ((unsigned)sc.cap_b << 8) * 0x00010001u;
+  const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
+  const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
+  const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
+  const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
+  unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16
+  SDF_OPQ(one2);
+  unsigned z_match_v = z_match;  // kept in a VGPR: v_pk_mad_u16 takes one scalar operand only
+  SDF_OPQ(z_match_v);
+
+  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], Tc[NREG];
+  unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
+  unsigned xt1[NREG], vt1[NREG];  // x, v of the (r-1, t-1) neighbours; persistent so that the two-step DPP shift
+                                  // writes in place (every lane is overwritten each row)
+#pragma unroll
+  for (int k = 0; k < NREG; ++k) {
+    xt1[k] = vt1[k] = 0u;
+    U[k] = V[k] = X[k] = Y[k] = 0u;
+    S[k] = z_wild;
+    Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
+    Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[64 * k + lane], 0x0c010c00u);
+  }
+
+  const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
+  uint2 *dir_a = reinterpret_cast<uint2 *>(dirbase + tk.dir_off);
+  uint2 *dir_b = reinterpret_cast<uint2 *>(dirbase + tkb.dir_off);
+  const int nrow = qlen + tlen - 1;
+  const int bperm_idx = ((lane + 16) & 63) * 4;
+
+  int base = 0;
+  int prev_lo = -1;
+  unsigned carry_x = 0u, carry_v = 0u;  // packed (r-1) values shifted into slot 0 on the first row of a block
+  bool zero_low = false;  // slots below the reference window still hold x,v that must read as 0
+  int32_t h_top[2] = {0, 0}, h_under[2] = {0, 0};  // H of the top cell / of the cell the next top cell reads
+  int32_t ez_score[2] = {SDF_NEG_INF, SDF_NEG_INF}, ez_mte[2] = {SDF_NEG_INF, SDF_NEG_INF}, ez_mte_q[2] = {-1, -1};
+  int32_t ez_zdropped = 0;
+  int drop_row = -1;  // row of the current block at which the reference window left slots 0..15
+  int r0 = 0;
+  // query codes of the next row, prefetched: two registers' 16-bit LDS values per VGPR (d16 loads; a lone last
+  // register is fetched twice rather than zero-extended on the vector ALU)
+  constexpr int NQ = (NREG + 1) / 2;
+  unsigned qaddr = 0u;
+  u16x2 qnext[NQ];  // LDS address / prefetched query codes of row `qrow` (lean rows)
+  int qrow = -1;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) qnext[j] = (u16x2){0, 0};
+  auto fetch_q = [&]() {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      u16x2 t;
+      t.x = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * j);
+      t.y = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * j + (2 * j + 1 < NREG ? 128 : 0));
+      qnext[j] = t;
+    }
+  };
+  unsigned hacc_a = 0u, hacc_b = 0u;  // lane-distributed parts of the H path sums (lean rows), folded lazily
+  int hcnt = 0;                       // number of path steps in them (each subtracts q+e)
+  auto fold_h = [&]() {  // bring the scalar path values up to date
+    if (hcnt) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        hacc_a += (unsigned)__shfl_xor((int)hacc_a, off);
+        hacc_b += (unsigned)__shfl_xor((int)hacc_b, off);
+      }
+      h_under[0] += (int32_t)hacc_a - hcnt * sc.qe;
+      h_under[1] += (int32_t)hacc_b - hcnt * sc.qe;
+      h_top[0] = h_under[0];
+      h_top[1] = h_under[1];
+      hacc_a = hacc_b = 0u;
+      hcnt = 0;
+    }
+  };
+  // scalar H bookkeeping of one row for both tasks from the packed u (top cell) / v (cell under it)
+  auto h_row = [&](const int r, const int hi0, const int lo0, const int hi, const bool first, const bool want_top,
+                   const bool top_from_under, const bool up, const unsigned uh, const unsigned vu) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int32_t uht = (int32_t)((uh >> (16 * t + 8)) & 0xffu), vut = (int32_t)((vu >> (16 * t + 8)) & 0xffu);
+      if (want_top) {
+        if (first) h_top[t] = uht - 2 * sc.qe;
+        else h_top[t] = (top_from_under ? h_under[t] : h_top[t]) + uht - sc.qe;
+      }
+      if (up || first) {
+        h_under[t] = h_top[t];
+      } else if (hi0 - 1 >= lo0) {
+        h_under[t] += vut - sc.qe;
+      }
+      if (hi0 == tlen - 1) {
+        if (h_top[t] > ez_mte[t]) {
+          ez_mte[t] = h_top[t];
+          ez_mte_q[t] = r - hi;
+        }
+        if (r == nrow - 1) ez_score[t] = h_top[t];
+      }
+    }
+  };
+
+  // ------------------------------------------------------------------------------------------
+  // General row: every special case of the reference (first/last rows, boundary cell t = r,
+  // clipping by the sequence ends, carry-in artefacts).  Returns false when the band is exhausted.
+  // ------------------------------------------------------------------------------------------
+  auto slow_row = [&](const int r) -> bool {
+    fold_h();
+    int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
+    lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
+    lo0 = lo0 < 0 ? 0 : lo0;
+    hi0 = hi0 > r ? r : hi0;
+    hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
+    if (lo0 > hi0) return false;
+    const int lo = lo0 & ~15, hi = hi0 | 15;
+    const int off_lo = lo - base;  // 0 or 16
+    const int off_hi = hi - base;  // last enabled slot
+    // the reference rebased at this row: slot off_lo's (r-1,t-1) neighbour is slot 15 (natural);
+    // on later rows that neighbour reads as 0
+    const bool ref_rebased = lo != prev_lo && prev_lo >= 0;
+    if (ref_rebased && off_lo == 16) drop_row = r;
+    if (off_lo == 16 && !ref_rebased && !zero_low) {
+      if (lane < 16) {
+        X[0] = 0u;
+        V[0] = 0u;
+      }
+      zero_low = true;
+    }
+    // ---- boundary cell t = r: y = 0, u = gap open (reference :122) ----
+    if (hi >= r) {
+      const int sr = r - base;
+      const unsigned uval = r ? qb2 : 0u;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k)
+        if ((sr >> 6) == k && lane == (sr & 63)) {
+          U[k] = uval;
+          Y[k] = 0u;
+        }
+    }
+    // ---- (r-1, t-1) neighbours: shift x and v up by one slot ----
+    {
+      // carry into slot 0: x = 0, v = gap open when the window starts at t = 0 (r > 0); the
+      // captured (r-1) values when the reference re-bases exactly at a block start
+      const unsigned vcarry = (base == 0 && r > 0) ? qb2 : (r == r0 ? carry_v : 0u);
+      const unsigned xcarry = (base != 0 && r == r0) ? carry_x : 0u;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        if (k == 0) {
+          xt1[0] = (unsigned)__builtin_amdgcn_update_dpp((int)xcarry, (int)X[0], 0x138, 0xf, 0xf, false);
+          vt1[0] = (unsigned)__builtin_amdgcn_update_dpp((int)vcarry, (int)V[0], 0x138, 0xf, 0xf, false);
+        } else {
+          const int x0 = __builtin_amdgcn_update_dpp((int)xt1[k], (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          xt1[k] = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+          const int v0 = __builtin_amdgcn_update_dpp((int)vt1[k], (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          vt1[k] = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+        }
+      }
+      // sign-extension artefact of the reference's carry-in (:145-146): a negative v carry also
+      // sets lanes 1..3 of the first block.  Only possible on the reference's rebase rows.
+      if (ref_rebased) {
+        if (off_lo == 16) {
+          const unsigned sm = sign_smear((unsigned)__builtin_amdgcn_readlane((int)V[0], 15));
+          if (sm && lane_in(lane, 17, 20)) vt1[0] |= sm;
+        } else if (r == r0) {
+          const unsigned sm = sign_smear(carry_v);
+          if (sm && lane_in(lane, 1, 4)) vt1[0] |= sm;
+        }
+      }
+    }
+    // ---- scores: refresh [lo0, lo0 + 16*n), keep the old value elsewhere ----
+    {
+      const int ra = lo0 - base;
+      const int rb = ra + ((hi0 - lo0) & ~15) + 16;
+      const int cq = qlen - 1 - r + base + 32;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        const int a_ = ra - 64 * k, b_ = rb - 64 * k;
+        if (b_ > 0 && a_ < 64) {
+          const unsigned qc = W[cq + 64 * k + lane];
+          unsigned z;
+          SDF_PFRESH(z, Tc[k], qc, 0x0c010c00u, has_n)
+          if (a_ <= 0 && b_ >= 64) S[k] = z;
+          else if (lane_in(lane, a_ < 0 ? 0 : a_, b_)) S[k] = z;
+        }
+      }
+    }
+    // ---- the recurrence on the reference's widened range [lo, hi] ----
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int l0 = off_lo - 64 * k <= 0 ? 0 : off_lo - 64 * k;
+      const int l1 = off_hi - 64 * k;
+      if (l1 >= l0 && l0 < 64) {
+        if ((unsigned)(lane - l0) <= (unsigned)(l1 - l0)) SDF_CORE(k)
+      }
+    }
+    // ---- exact H of the top cell and of the cell under the band edge (score, mte) ----
+    {
+      const int st = hi0 - base;  // slot of the top cell
+      unsigned uh = 0, vu = 0;
+      int hin = (r + 1 + w) >> 1;  // next row's top cell: does it move up?
+      hin = hin > r + 1 ? r + 1 : hin;
+      hin = hin > tlen - 1 ? tlen - 1 : hin;
+      const bool up = hin == hi0 + 1 || hin == 0;
+      const bool want_top = up || hi0 == tlen - 1 || hi0 == 0;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        if (want_top && (st >> 6) == k) {  // two scalar reads, scalar select (no select between register arrays)
+          const unsigned ru = (unsigned)__builtin_amdgcn_readlane((int)U[k], st & 63);
+          const unsigned rv = (unsigned)__builtin_amdgcn_readlane((int)V[k], st & 63);
+          uh = hi0 > 0 ? ru : rv;
+        }
+        if (!up && st > 0 && ((st - 1) >> 6) == k) vu = (unsigned)__builtin_amdgcn_readlane((int)V[k], (st - 1) & 63);
+      }
+      h_row(r, hi0, lo0, hi, r == 0, want_top, hi0 > 0, up, uh, vu);
+    }
+    prev_lo = lo;
+    return true;
+  };
+
+  // ------------------------------------------------------------------------------------------
+  // Lean rows [rb, re) of one block (rb >= 1): the general row with the rare cases taken out and
+  // everything constant over the segment hoisted (see extz2_wave.hip for the LOW16 / SCALARH /
+  // STEADY regimes).  Lanes above the window top are NOT masked; the caller zeroes them when the
+  // window grows over them.
+  // ------------------------------------------------------------------------------------------
+  auto lean_rows_n = [&](auto low16_c, auto scalarh_c, auto steady_c, auto hasn_c, const int rb, const int re) {
+    constexpr bool HASN = decltype(hasn_c)::value;  // N handling compiled in or out (no per-row test)
+    constexpr bool LOW16 = decltype(low16_c)::value;
+    constexpr bool SCALARH = decltype(scalarh_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    constexpr int KT = NREG - 1;
+    if (SCALARH) fold_h();
+    if (qrow != rb) {  // (re)start the one-row-ahead query fetch at this row
+      qaddr = (unsigned)(2 * tcap + 2 * (qlen - 1 - rb + base + 32 + lane));
+      fetch_q();
+      qaddr -= 2;  // address of the row after `qnext`
+    }
+    qrow = re;
+    if (STEADY && !SCALARH) hcnt += re - rb;  // every steady row takes one path step
+    const unsigned vcar = base == 0 ? qb2 : 0u;  // v carry into slot 0 (r > 0)
+#pragma unroll 1
+    for (int r = rb; r < re; ++r) {
+      int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
+      if (!STEADY) {
+        lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
+        lo0 = lo0 < 0 ? 0 : lo0;
+        hi0 = hi0 > r ? r : hi0;
+        hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
+      }
+      const int off_hi = (hi0 | 15) - base;
+      unsigned qcur[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) qcur[j] = __builtin_bit_cast(unsigned, qnext[j]);
+      fetch_q();
+      qaddr -= 2;
+      // boundary cell t = r: y = 0, u = gap open (reference :122)
+      if (!STEADY && off_hi + base >= r) {
+        const int sr = r - base;
+        const bool mine = lane == (sr & 63);
+#pragma unroll
+        for (int k = 0; k < NREG; ++k)
+          if ((sr >> 6) == k) {
+            U[k] = mine ? qb2 : U[k];
+            Y[k] = mine ? 0u : Y[k];
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        if (k == 0) {
+          xt1[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X[0], 0x138, 0xf, 0xf, true);
+          if (STEADY) vt1[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)V[0], 0x138, 0xf, 0xf, true);
+          else vt1[0] = (unsigned)__builtin_amdgcn_update_dpp((int)vcar, (int)V[0], 0x138, 0xf, 0xf, false);
+        } else {  // lane 0 from the register below, lanes 1..63 from this one: all lanes overwritten in place
+          const int x0 = __builtin_amdgcn_update_dpp((int)xt1[k], (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          xt1[k] = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+          const int v0 = __builtin_amdgcn_update_dpp((int)vt1[k], (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          vt1[k] = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+        }
+      }
+      // scores: refreshed slots are [ra, rbe)
+      const int ra = lo0 - base;
+      const int rbe = ra + ((hi0 - lo0) & ~15) + 16;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        const int b_ = rbe - 64 * k;
+        if (STEADY) {
+          unsigned z;
+          SDF_PFRESH(z, Tc[k], qcur[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u, HASN)
+          if (NREG == 1) S[0] = lane_in(lane, ra, b_) ? z : S[0];
+          else if (k == 0) S[0] = lane >= ra ? z : S[0];
+          else if (k == KT) S[k] = lane < b_ ? z : S[k];
+          else S[k] = z;
+        } else if (b_ > 0) {
+          unsigned z;
+          SDF_PFRESH(z, Tc[k], qcur[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u, HASN)
+          if (k == 0) {
+            if (b_ >= 64) S[0] = lane >= ra ? z : S[0];
+            else S[0] = lane_in(lane, ra, b_) ? z : S[0];
+          } else if (b_ >= 64) {
+            S[k] = z;
+          } else {
+            S[k] = lane < b_ ? z : S[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        if (STEADY || off_hi >= 64 * k) {
+          if (k == 0 && LOW16) {
+            if (lane >= 16) SDF_CORE(0)
+          } else {
+            SDF_CORE(k)
+          }
+        }
+      }
+      if (SCALARH) {
+        // top cell H every row: h_top = H(cell under the edge, previous row) + u(top) - (q+e)
+        const int st = hi0 - base;
+        unsigned uh = 0u, vu = 0u;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          if ((st >> 6) == k) uh = (unsigned)__builtin_amdgcn_readlane((int)U[k], st & 63);
+          if (((st - 1) >> 6) == k) vu = (unsigned)__builtin_amdgcn_readlane((int)V[k], (st - 1) & 63);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          h_top[t] = h_under[t] + (int32_t)((uh >> (16 * t + 8)) & 0xffu) - sc.qe;
+          if (hi0 - 1 >= lo0) h_under[t] += (int32_t)((vu >> (16 * t + 8)) & 0xffu) - sc.qe;
+          if (h_top[t] > ez_mte[t]) {
+            ez_mte[t] = h_top[t];
+            ez_mte_q[t] = r - (hi0 | 15);
+          }
+          if (r == nrow - 1) ez_score[t] = h_top[t];
+        }
+      } else {
+        // H path: rows whose successor moves the top cell up read u of the top cell, the others
+        // read v of the cell under it.  Added up inside the owning lane, reduced once at the end.
+        int up;
+        if (STEADY) {
+          up = (r + w) & 1;
+        } else {
+          int hin = (r + 1 + w) >> 1;
+          hin = hin > r + 1 ? r + 1 : hin;
+          hin = hin > tlen - 1 ? tlen - 1 : hin;
+          up = hin == hi0 + 1;
+        }
+        if (STEADY || up || hi0 - 1 >= lo0) {
+          const int sl = hi0 - base - 1 + up;
+          // selects between VALUES read first: a select between the arrays themselves would turn them
+          // into an indexed stack object
+          unsigned val = 0u;
+          if (STEADY) {
+            constexpr int KL = KT > 0 ? KT - 1 : 0;
+            const unsigned u_hi = U[KT], v_hi = V[KT], u_lo = U[KL], v_lo = V[KL];
+            const unsigned c_hi = up ? u_hi : v_hi, c_lo = up ? u_lo : v_lo;
+            val = (NREG > 1 && sl < 64 * KT) ? c_lo : c_hi;
+          } else {
+#pragma unroll
+            for (int k = 0; k < NREG; ++k) {
+              const unsigned uk = U[k], vk = V[k];
+              const unsigned ck = up ? uk : vk;
+              val = (sl >> 6) == k ? ck : val;
+            }
+          }
+          if (lane == (sl & 63)) {
+            hacc_a += (val >> 8) & 0xffu;
+            hacc_b += val >> 24;
+          }
+          if (!STEADY) ++hcnt;
+        }
+      }
+    }
+  };
+  auto lean_rows = [&](auto low16_c, auto scalarh_c, auto steady_c, const int rb, const int re) {
+    if (has_n) lean_rows_n(low16_c, scalarh_c, steady_c, std::true_type{}, rb, re);
+    else lean_rows_n(low16_c, scalarh_c, steady_c, std::false_type{}, rb, re);
+  };
+  // U,V,X,Y of the cells t in [t_from, t_to] back to "never computed" (both bounds block aligned)
+  auto zero_cells = [&](const int t_from, const int t_to) {
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int a_ = t_from - base - 64 * k, b_ = t_to - base - 64 * k;
+      if (b_ >= 0 && a_ < 64) {
+        const int la = a_ <= 0 ? 0 : a_;
+        if ((unsigned)(lane - la) <= (unsigned)(b_ - la)) {
+          U[k] = 0u;
+          V[k] = 0u;
+          X[k] = 0u;
+          Y[k] = 0u;
+        }
+      }
+    }
+  };
+  int win_hi = -1;    // last cell of the reference window so far (cells above it were never computed)
+  int dirty_hi = -1;  // cells in (win_hi, dirty_hi] may hold scratch values left by lean rows
+
+  for (r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
+    // ---- block start: re-base the window to the reference's band start of this row ----
+    {
+      Band b0;
+      if (!band_of(r0, qlen, tlen, w, b0)) {
+        ez_zdropped = 1;
+        break;
+      }
+      carry_x = carry_v = 0u;
+      if (b0.lo != base) {  // always +16: shift everything down by 16 lanes
+        if (prev_lo == base) {  // the reference re-bases at this very row: its carry-in is the
+          carry_x = (unsigned)__builtin_amdgcn_readlane((int)X[0], 15);  // (r-1) value of the cell just
+          carry_v = (unsigned)__builtin_amdgcn_readlane((int)V[0], 15);  // below the new window
+        }
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          const bool from_next = lane >= 48;
+          unsigned a0, a1;
+#define SDF_SHIFT16(A, INIT)                                                             \
+  a0 = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_idx, (int)A[k]);                     \
+  a1 = (k + 1 < NREG) ? (unsigned)__builtin_amdgcn_ds_bpermute(bperm_idx, (int)A[k + 1 < NREG ? k + 1 : k]) : (INIT); \
+  A[k] = from_next ? a1 : a0;
+          SDF_SHIFT16(U, 0u)
+          SDF_SHIFT16(V, 0u)
+          SDF_SHIFT16(X, 0u)
+          SDF_SHIFT16(Y, 0u)
+          SDF_SHIFT16(S, z_wild)
+#undef SDF_SHIFT16
+        }
+        base = b0.lo;
+        qrow = -1;  // the window moved: query addresses change
+#pragma unroll
+        for (int k = 0; k < NREG; ++k)
+          Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[base + 64 * k + lane], 0x0c010c00u);
+        zero_low = false;
+      }
+    }
+    const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
+    drop_row = -1;
+    int r = r0;
+    // rows of this block: lean segments between the rows at which the reference window changes
+    {
+      constexpr int KT = NREG - 1;
+      const int rl = r0 + 15;
+      // pure band regime on all 16 rows, no boundary cell, refresh range spanning registers 0..KT
+      bool steady = w >= 2 && r0 + 16 <= nrow && base >= 16 && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
+                    ((rl + w) >> 1) < tlen - 1 && ((r0 + w) >> 1) + 15 < r0;
+      if (steady) {
+        const int lo0a = (r0 - w + 1) >> 1, hi0a = (r0 + w) >> 1;
+        steady = lo0a + ((w - 1) & ~15) + 16 - base >= 64 * KT && (hi0a | 15) - base >= 64 * KT &&
+                 hi0a - 1 - base >= 64 * KT - 64;
+      }
+      const bool lean_ok = tlen >= 2 && w >= 1;
+      bool low16 = false;
+      while (r < rend) {
+        int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
+        lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
+        lo0 = lo0 < 0 ? 0 : lo0;
+        hi0 = hi0 > r ? r : hi0;
+        hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
+        if (lo0 > hi0) {
+          ez_zdropped = 1;
+          break;
+        }
+        const int lo = lo0 & ~15, hi = hi0 | 15;
+        if (hi > win_hi) {  // the window grows over cells that must read as "never computed"
+          if (dirty_hi > win_hi) zero_cells(win_hi + 1, hi < dirty_hi ? hi : dirty_hi);
+          win_hi = hi;
+          if (dirty_hi < win_hi) dirty_hi = win_hi;
+        }
+        const bool rebase_row = lo != prev_lo && prev_lo >= 0;
+        bool special = !lean_ok || r == 0 || (r == r0 && (carry_x | carry_v) != 0u);
+        if (rebase_row && !special) {
+          // natural neighbour, but mind the sign-extension artefact of a negative carry (either task)
+          const unsigned cvh = lo - base == 16 ? (unsigned)__builtin_amdgcn_readlane((int)V[0], 15) : carry_v;
+          special = (cvh & 0x80008000u) != 0u;
+        }
+        if (special) {
+          if (dirty_hi > win_hi) zero_cells(win_hi + 1, dirty_hi);
+          dirty_hi = win_hi;
+          if (!slow_row(r)) {
+            ez_zdropped = 1;
+            break;
+          }
+          low16 = prev_lo - base == 16;
+          ++r;
+          continue;
+        }
+        if (rebase_row) {
+          if (lo - base == 16) {
+            drop_row = r;
+            low16 = true;
+          }
+        } else if (low16 && !zero_low) {
+          if (lane < 16) {
+            X[0] = 0u;
+            V[0] = 0u;
+          }
+          zero_low = true;
+        }
+        // rows until the reference window changes again (closed forms of the band geometry)
+        int stop = rend;
+        if (rebase_row) {
+          stop = r + 1;  // the re-base row runs alone: slots 0..15 are zeroed right after it
+        } else {
+          int rr = lo + 15 + qlen;
+          const int rr2 = 2 * (lo + 16) + w - 1;
+          rr = rr2 < rr ? rr2 : rr;
+          if (rr > r && rr < stop) stop = rr;
+          const int h1 = hi + 1;
+          if (h1 <= tlen - 1) {
+            int rh = 2 * h1 - w;
+            rh = rh < h1 ? h1 : rh;
+            if (rh > r && rh < stop) stop = rh;
+          }
+          int rt = 2 * (tlen - 1) - w;
+          rt = rt < tlen - 1 ? tlen - 1 : rt;
+          if (rt > r && rt < stop) stop = rt;
+        }
+        const bool scalarh = hi0 == tlen - 1;
+        if (scalarh) {
+          if (low16) lean_rows(std::true_type{}, std::true_type{}, std::false_type{}, r, stop);
+          else lean_rows(std::false_type{}, std::true_type{}, std::false_type{}, r, stop);
+        } else if (steady) {
+          if (low16) lean_rows(std::true_type{}, std::false_type{}, std::true_type{}, r, stop);
+          else lean_rows(std::false_type{}, std::false_type{}, std::true_type{}, r, stop);
+        } else {
+          if (low16) lean_rows(std::true_type{}, std::false_type{}, std::false_type{}, r, stop);
+          else lean_rows(std::false_type{}, std::false_type{}, std::false_type{}, r, stop);
+        }
+        {  // the top register of the window now holds scratch values above the window
+          const int top = base + 64 * (((win_hi - base) >> 6) + 1) - 1;
+          if (top > dirty_hi) dirty_hi = top;
+        }
+        prev_lo = lo;
+        r = stop;
+      }
+      if (dirty_hi > win_hi) zero_cells(win_hi + 1, dirty_hi);  // clean lanes for the re-base shift
+      dirty_hi = win_hi;
+    }
+    // ---- block end: direction flags of these (<=16) rows leave for HBM ----
+    if (with_dir) {
+      const int done = r - r0;
+      const int rbk = r0 >> 4;
+      if (drop_row >= 0 && lane < 16) {  // lanes that stopped shifting when their slots were dropped
+        const unsigned sh = (unsigned)(r - drop_row);
+        Fa[0] = pk_shl(Fa[0], sh);
+        Fb[0] = pk_shl(Fb[0], sh);
+        Fx[0] = pk_shl(Fx[0], sh);
+        Fy[0] = pk_shl(Fy[0], sh);
+      }
+      if (done > 0) {
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          unsigned fa = Fa[k], fb = Fb[k], fx = Fx[k], fy = Fy[k];
+          if (done < 16) {
+            const unsigned sh = 16 - done;
+            fa = pk_shl(fa, sh);
+            fb = pk_shl(fb, sh);
+            fx = pk_shl(fx, sh);
+            fy = pk_shl(fy, sh);
+          }
+          // per task: (a | b << 16, x | y << 16), bit 15 - (r % 16) of each 16-bit mask is row r
+          const int64_t at = ((int64_t)rbk * NREG + k) * 64 + lane;
+          dir_a[at] = make_uint2(__builtin_amdgcn_perm(fb, fa, 0x05040100u), __builtin_amdgcn_perm(fy, fx, 0x05040100u));
+          dir_b[at] = make_uint2(__builtin_amdgcn_perm(fb, fa, 0x07060302u), __builtin_amdgcn_perm(fy, fx, 0x07060302u));
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
+  }
+
+  fold_h();
+  if (lane < 2) {
+    const bool second = lane == 1;
+    sdf_result o;
+    o.score = second ? ez_score[1] : ez_score[0];
+    o.max = 0;
+    o.max_q = o.max_t = -1;
+    o.mqe = SDF_NEG_INF;
+    o.mqe_t = -1;
+    o.mte = second ? ez_mte[1] : ez_mte[0];
+    o.mte_q = second ? ez_mte_q[1] : ez_mte_q[0];
+    o.zdropped = ez_zdropped;
+    o.n_cigar = 0;
+    o.cigar_off = 0;
+    o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
+    res[second ? tkb.out_idx : tk.out_idx] = o;
+  }
+}
+
+#define SDF_PAIR_INST(N)                                                                                        \
+  template __global__ void extz2_pair_kernel<N>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, \
+                                                uint8_t *, sdf_result *);
+SDF_PAIR_INST(1)
+SDF_PAIR_INST(2)
+SDF_PAIR_INST(3)
+SDF_PAIR_INST(4)
+SDF_PAIR_INST(6)
+SDF_PAIR_INST(8)
+#undef SDF_PAIR_INST
+
+size_t pair_lds_bytes(int qlen, int tlen, int nreg) {
+  const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
+  const size_t tcap = T16 + 64 * nreg + 32;
+  const size_t qcap = (size_t)qlen + 64 * nreg + 36;
+  return 2 * tcap + 2 * qcap;
+}
+
+}  // namespace sdf

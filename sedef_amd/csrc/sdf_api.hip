@@ -23,6 +23,10 @@ template <int NREG>
 __global__ void extz2_wave_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                   sdf_result *);
 size_t wave_lds_bytes(int qlen, int tlen, int nreg);
+template <int NREG>
+__global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                  sdf_result *);
+size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *,
                                  sdf_result *, uint32_t *);
 __global__ void cigar_scan_kernel(sdf_result *, int, unsigned long long *);
@@ -86,9 +90,11 @@ struct sdf_ctx {
   std::vector<hipEvent_t> events;
   float ms[6] = {0, 0, 0, 0, 0, 0};  // 0 DP, 1 traceback, 2 compaction, 3 stream total, 4 host planning, 5 host total
   int launches = 0;
+  long long paired = 0;  // tasks of the last batch that ran two per wavefront (extz2_pair.hip)
   std::string err;
   int max_dyn_lds = 64 * 1024;
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
+  bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
 };
 
 #define SDF_HIP(call)                                                                          \
@@ -152,9 +158,16 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+#define SDF_PAIR_ATTR(N)                                                                   \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N>),         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  SDF_PAIR_ATTR(1) SDF_PAIR_ATTR(2) SDF_PAIR_ATTR(3) SDF_PAIR_ATTR(4) SDF_PAIR_ATTR(6) SDF_PAIR_ATTR(8)
+#undef SDF_PAIR_ATTR
   (void)hipGetLastError();
   const char *fg = getenv("SDF_FORCE_GENERAL");
   ctx->force_general = fg && fg[0] == '1';
+  const char *np = getenv("SDF_NO_PAIR");
+  ctx->no_pair = np && np[0] == '1';
   return ctx;
 }
 
@@ -207,6 +220,7 @@ extern "C" float sdf_last_ms(const sdf_ctx *ctx, int which) {
 }
 
 extern "C" int sdf_last_launches(const sdf_ctx *ctx) { return ctx ? ctx->launches : 0; }
+extern "C" long long sdf_last_paired(const sdf_ctx *ctx) { return ctx ? ctx->paired : 0; }
 
 namespace {
 
@@ -250,6 +264,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   ctx->err.clear();
   for (float &m : ctx->ms) m = 0.f;
   ctx->launches = 0;
+  ctx->paired = 0;
   const auto host_t0 = std::chrono::steady_clock::now();
   if (cigar_used) *cigar_used = 0;
   if (n == 0) return SDF_OK;
@@ -267,6 +282,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // ---- plan ----
   std::vector<PlanTask> plan;
   plan.reserve(n);
+  std::vector<int32_t> win_need;  // window slots of the wave-eligible tasks (0: general kernel)
+  win_need.reserve(n);
   int64_t stage_words = 0;
   for (size_t k = 0; k < n; ++k) {
     const sdf_task &t = tasks[k];
@@ -301,8 +318,12 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         // beyond the target's last 16-cell block (cells past it are not part of any window)
         const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
         const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : need <= 1024 ? 8 : 0;
-        if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)ctx->max_dyn_lds) p.nreg = nreg;
+        if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)ctx->max_dyn_lds) {
+          p.nreg = nreg;
+          win_need.push_back(need);
+        }
       }
+      if (!p.nreg) win_need.push_back(0);
     }
     p.dir_off = 0;
     p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
@@ -341,6 +362,69 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     }
     if (np > s) subs.push_back({s, np, acc});
   }
+  // Pair kernel: two wave-eligible tasks of one sub-batch with the same (qlen, tlen, w, flag) and a window of at
+  // most 512 slots share a wavefront (extz2_pair.hip).  partner[k] = the other task, or -1.
+  std::vector<int32_t> partner(np, -1);
+  if (!ctx->no_pair && !ctx->force_general) {
+    // one pass with an open-addressing table keyed by the geometry: entry = (first task seen with the key, the
+    // task of that key still waiting for a partner or -1)
+    std::vector<std::pair<int32_t, int32_t>> table;
+    for (auto &sb : subs) {
+      size_t cap = 64;
+      while (cap < 2 * (sb.e - sb.s)) cap *= 2;
+      table.assign(cap, {-1, -1});
+      bool any = false;
+      for (size_t k = sb.s; k < sb.e; ++k) {
+        PlanTask &y = plan[k];
+        if (!y.nreg || win_need[k] > 512) continue;
+        uint64_t h = ((uint64_t)(uint32_t)y.qlen * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)y.tlen * 0xC2B2AE3D27D4EB4Full) ^
+                     ((uint64_t)(uint32_t)y.w * 0x165667B19E3779F9ull) ^ ((uint64_t)(uint32_t)y.flag << 40);
+        h ^= h >> 29;
+        size_t slot = (size_t)h & (cap - 1);
+        for (;; slot = (slot + 1) & (cap - 1)) {
+          auto &e = table[slot];
+          if (e.first < 0) {
+            e = {(int32_t)k, (int32_t)k};
+            break;
+          }
+          const PlanTask &x = plan[e.first];
+          if (x.qlen != y.qlen || x.tlen != y.tlen || x.w != y.w || x.flag != y.flag) continue;
+          if (e.second < 0) {
+            e.second = (int32_t)k;
+            break;
+          }
+          PlanTask &z = plan[e.second];
+          const int regs = (win_need[k] + 63) / 64;
+          const int nreg = regs <= 4 ? regs : regs <= 6 ? 6 : 8;
+          if (pair_lds_bytes(y.qlen, y.tlen, nreg) > (size_t)ctx->max_dyn_lds) break;
+          z.nreg = y.nreg = nreg;
+          z.pad_ = y.pad_ = 2;
+          partner[k] = e.second;
+          partner[e.second] = (int32_t)k;
+          ctx->paired += 2;
+          e.second = -1;
+          any = true;
+          break;
+        }
+      }
+      if (any) {  // the flag records of paired tasks are smaller: lay the sub-batch out again
+        size_t acc = 0;
+        for (size_t k = sb.s; k < sb.e; ++k) {
+          PlanTask &p = plan[k];
+          size_t need = 0;
+          if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
+            const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
+            if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
+            else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
+            else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+          }
+          p.dir_off = (int64_t)acc;
+          acc += need;
+        }
+        sb.dir_bytes = acc;
+      }
+    }
+  }
   size_t max_dir = 16;
   for (auto &sb : subs) max_dir = std::max(max_dir, sb.dir_bytes);
   if (ctx->dir_ws.reserve(max_dir) != hipSuccess) {
@@ -376,7 +460,13 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
         int bs = width > 256 ? 256 : 64;
         size_t lds = 2048, need;
-        if (p.nreg) {
+        if (p.pad_ == 2) {
+          if (partner[k] < (int32_t)k) continue;  // placed together with its partner
+          bs = 100 + p.nreg;
+          need = pair_lds_bytes(p.qlen, p.tlen, p.nreg);
+          lds = 6144;
+          while (lds < need) lds *= 2;
+        } else if (p.nreg) {
           bs = p.nreg;
           // one class for everything up to 6 KiB (>= 6 waves/SIMD either way), powers of two above
           need = wave_lds_bytes(p.qlen, p.tlen, p.nreg);
@@ -400,6 +490,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         }
         c->need_max = std::max(c->need_max, need);
         c->idx.push_back((int32_t)(k - subs[si].s));
+        if (p.pad_ == 2) c->idx.push_back((int32_t)((size_t)partner[k] - subs[si].s));
       }
       // big classes first so the long tasks start early
       std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.lds > b.lds; });
@@ -446,6 +537,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       else if (L.bs == 8)
         hipLaunchKernelGGL(extz2_wave_kernel<8>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
                            d_order + L.off, d_pool, sk, d_dir, d_out);
+#define SDF_PAIR_LAUNCH(N)                                                                                   \
+  else if (L.bs == 100 + N) hipLaunchKernelGGL(extz2_pair_kernel<N>, dim3((unsigned)(L.cnt / 2)), dim3(64), L.lds, \
+                                               st, d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out);
+      SDF_PAIR_LAUNCH(1)
+      SDF_PAIR_LAUNCH(2)
+      SDF_PAIR_LAUNCH(3)
+      SDF_PAIR_LAUNCH(4)
+      SDF_PAIR_LAUNCH(6)
+      SDF_PAIR_LAUNCH(8)
+#undef SDF_PAIR_LAUNCH
       else if (L.bs == 64)
         hipLaunchKernelGGL((extz2_general_kernel<64, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, st,
                            d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out, (uint8_t *)nullptr, (size_t)0);

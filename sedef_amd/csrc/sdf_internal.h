@@ -34,7 +34,8 @@ struct PlanTask {
   int32_t cig_cap;   // words in the staging slot
   int32_t nreg;      // 0: general kernel, byte-per-cell direction rows; >0: wave kernel with nreg
                      // packed registers, direction flags in 16-row x 128-slot bit blocks
-  int32_t pad_;
+  int32_t pad_;      // 1: general kernel with its state in an HBM slab; 2: pair kernel (extz2_pair.hip): nreg counts
+                     // 64-slot registers and the flags are per-task uint2 records
 };
 
 // Per-anti-diagonal band geometry (reference: extern/ksw2_extz2_sse.cc:101-115).

@@ -94,6 +94,33 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     if (forced < 0) {
       if (tk.nreg == 0) {
         d = dir[(int64_t)r * stride + (i - b.lo)];
+      } else if (tk.pad_ == 2) {
+        // pair-kernel layout: per register k (64 slots) and lane one uint2 (a | b << 16, x | y << 16) of
+        // 16-bit row masks; a 64-byte line holds 8 slots x 16 rows
+        const int rb = r >> 4;
+        if (rb != blk_rb) {
+          Band b0;
+          band_of(rb << 4, tk.qlen, tk.tlen, tk.w, b0);
+          blk_rb = rb;
+          blk_base = b0.lo;
+        }
+        const int slot = (int)i - blk_base;
+        const int64_t idx = ((int64_t)rb * tk.nreg + (slot >> 6)) * 64 + (slot & 63);
+        if ((idx >> 3) != cached_line) {
+          cached_line = idx >> 3;
+          const uint4 *ln = dirw + (cached_line << 2);
+          c0 = ln[0];
+          c1 = ln[1];
+          c2 = ln[2];
+          c3 = ln[3];
+        }
+        const int sel = (int)(idx & 7) >> 1;
+        const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
+        const uint32_t wab = (idx & 1) ? cached.z : cached.x, wxy = (idx & 1) ? cached.w : cached.y;
+        const int bit = 15 - (r & 15);
+        const uint32_t fa = (wab >> bit) & 1u, fb = (wab >> (bit + 16)) & 1u;
+        const uint32_t fx = (wxy >> bit) & 1u, fy = (wxy >> (bit + 16)) & 1u;
+        d = (fb ? 2u : fa) | (fx << 3) | (fy << 4);
       } else {
         const int rb = r >> 4;
         if (rb != blk_rb) {

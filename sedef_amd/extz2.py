@@ -78,6 +78,8 @@ def load_library():
     L.sdf_last_ms.argtypes = [C.c_void_p, C.c_int]
     L.sdf_last_launches.restype = C.c_int
     L.sdf_last_launches.argtypes = [C.c_void_p]
+    L.sdf_last_paired.restype = C.c_longlong
+    L.sdf_last_paired.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -217,6 +219,10 @@ class Extz2Engine:
 
     def last_launches(self):
         return int(self.lib.sdf_last_launches(self.ctx))
+
+    def last_paired(self):
+        """Tasks of the last batch that ran two per wavefront (same-geometry pairs)."""
+        return int(self.lib.sdf_last_paired(self.ctx))
 
 
 _default_engine = None

@@ -316,3 +316,113 @@ def test_tiny_tasks_bulk(engine, oracle):
         t = random_codes(rng, int(rng.integers(1, 24))) if rng.random() < 0.5 else mutate(rng, q, 0.1, 0.05, 0.05)
         pairs.append((q, t))
     _check_fast(engine, oracle, pairs, [-1] * len(pairs))
+
+
+# ---- pair kernel: two tasks of equal (qlen, tlen, w) per wavefront (extz2_pair.hip) ----
+def _fit(rng, t, tl):
+    return t[:tl] if len(t) >= tl else np.concatenate([t, random_codes(rng, tl - len(t))])
+
+
+def _same_geometry_tasks(rng, ql, tl, copies, n_frac=0.0):
+    """`copies` tasks with the same lengths and unrelated contents (related, diverged, random, N runs)."""
+    out = []
+    for _ in range(copies):
+        q = random_codes(rng, ql, n_frac if rng.random() < 0.4 else 0.0)
+        kind = rng.random()
+        if kind < 0.2:
+            t = random_codes(rng, tl)
+        else:
+            d = rng.random() * 0.15
+            t = mutate(rng, q, d, d / 3, d / 3)
+            if kind > 0.7 and len(t) > 4:
+                k, L = int(rng.integers(0, len(t))), int(rng.integers(1, 120))
+                t = np.concatenate([t[:k], random_codes(rng, L), t[k:]]) if rng.random() < 0.5 else \
+                    np.concatenate([t[:k], t[k + L:]])
+            t = _fit(rng, t, tl)
+        out.append((q, t))
+    return out
+
+
+def test_pair_kernel_fuzz_banded(engine, oracle):
+    rng = np.random.default_rng(777)
+    pairs, ws = [], []
+    for _ in range(450):
+        ql = int(rng.integers(1, 900))
+        tl = max(1, ql + int(rng.integers(-60, 60)))
+        w = int(rng.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 64, 100, 128, 200, 300]))
+        copies = int(rng.choice([2, 2, 3, 4]))
+        pairs += _same_geometry_tasks(rng, ql, tl, copies, 0.02)
+        ws += [w] * copies
+    perm = rng.permutation(len(pairs))  # partners are found by the planner, not by adjacency
+    pairs, ws = [pairs[i] for i in perm], [ws[i] for i in perm]
+    _check_fast(engine, oracle, pairs, ws)
+    assert engine.last_paired() >= 600  # narrow bands that cannot reach the corner go to the general kernel
+
+
+def test_pair_kernel_all_register_counts(engine, oracle):
+    """Windows of 16..512 slots -> 1, 2, 3, 4, 6, 8 registers; full band and banded; wider windows and odd
+    tasks out stay on the one-task wave kernel inside the same batch."""
+    rng = np.random.default_rng(778)
+    pairs, ws = [], []
+    for ql, tl, w in [(8, 8, -1), (30, 30, -1), (60, 50, -1), (100, 120, -1), (150, 150, -1), (210, 209, -1),
+                      (300, 280, -1), (400, 410, -1), (500, 500, -1), (480, 500, -1), (500, 431, -1),
+                      (1000, 1000, 20), (1000, 990, 60), (1000, 1010, 100), (1000, 1003, 128), (990, 1000, 128),
+                      (1000, 1000, 160), (1000, 980, 200), (1000, 1000, 260), (1000, 1000, 350), (900, 1000, 440),
+                      (1000, 1000, 470), (1000, 1000, 500), (700, 700, -1), (1, 1, -1), (1, 40, -1), (40, 1, -1),
+                      (16, 16, 3), (17, 15, 1), (2000, 2000, 128), (3000, 2990, 64)]:
+        copies = 3
+        pairs += _same_geometry_tasks(rng, ql, tl, copies, 0.01)
+        ws += [w] * copies
+    _check_fast(engine, oracle, pairs, ws)
+    assert engine.last_paired() >= 50
+
+
+def test_pair_kernel_other_scorings(engine, oracle):
+    rng = np.random.default_rng(779)
+    for _ in range(40):
+        ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
+        go, ge = int(rng.integers(0, 70)), int(rng.integers(0, 6))
+        pairs, ws = [], []
+        for _ in range(5):
+            ql = int(rng.integers(1, 400))
+            pairs += _same_geometry_tasks(rng, ql, max(1, ql + int(rng.integers(-20, 20))), 2, 0.03)
+            ws += [int(rng.choice([3, 16, 40, 100, -1]))] * 2
+        _check_fast(engine, oracle, pairs, ws, mat=sedef_mat(ma, mi), gapo=go, gape=ge)
+
+
+def test_pair_kernel_golden_doubled(engine, golden_cases):
+    """Every golden case twice in one batch: each meets its twin in a wavefront; both halves must be right."""
+    import sedef_amd
+    sel = [c for c in golden_cases if (c["flag"] & ~0x81) == 0 and c["zdrop"] < 0
+           and (c["match"], c["mismatch"], c["gapo"], c["gape"]) == (5, -4, 40, 1)]
+    sel = sel + sel
+    pairs = [(codes(c["q"]), codes(c["t"])) for c in sel]
+    res, cig = engine.align_pairs(pairs, w=[c["w"] for c in sel], flag=[c["flag"] for c in sel],
+                                  want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    assert engine.last_paired() >= len(sel) // 2
+    for c, r in zip(sel, res):
+        exp = c["expect"]
+        got = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+        for fld in FAST_FIELDS:
+            assert int(r[fld]) == exp[fld], (c["tag"], fld, c["w"], len(c["q"]), len(c["t"]))
+        assert cigar_to_str(got) == exp["cigar"], (c["tag"], c["w"], len(c["q"]), len(c["t"]))
+
+
+def test_pair_and_wave_kernels_agree_at_scale(engine, monkeypatch):
+    """20,000 config-2 tasks: the batch with pairing (default) and with SDF_NO_PAIR=1 give the same bytes."""
+    import sedef_amd
+    import bench
+    n = 20000
+    pool, q_off, qlen, t_off, tlen = bench.synth_batch(n, 1000, 4321)
+    tasks = np.zeros(n, sedef_amd.TASK_DTYPE)
+    tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"] = q_off, t_off, qlen, tlen
+    tasks["w"], tasks["zdrop"] = 128, -1
+    want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
+    res1, cig1 = engine.align_batch(tasks, pool, want=want)
+    assert engine.last_paired() > 15000
+    monkeypatch.setenv("SDF_NO_PAIR", "1")
+    solo = sedef_amd.Extz2Engine(0)
+    res2, cig2 = solo.align_batch(tasks, pool, want=want)
+    assert solo.last_paired() == 0
+    assert res1.tobytes() == res2.tobytes()
+    assert np.array_equal(cig1, cig2)
