@@ -144,9 +144,13 @@ int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *
  * (sum over anti-diagonals of en0-st0+1, reference: extern/ksw2_extz2_sse.cc:101-114). */
 int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w);
 
-/* Timing of the last batch call, from HIP events recorded on the launch stream:
+/* Timing of the last batch call, from HIP events recorded on the launch streams:
  * which = 0 DP kernels, 1 traceback, 2 CIGAR compaction, 3 whole call (stream time);
- * 4 host-side planning before the first launch, 5 whole call on the host clock. */
+ * 4 host-side planning before the first launch, 5 whole call on the host clock.
+ * Large batches run as a pipeline of chunks (planning of chunk i+1, DP of chunk i+1 and traceback of chunk i
+ * overlap); 0 and 1 are then the time during which at least one DP / traceback kernel was in flight and
+ * 6 is the sum of the chunks' DP intervals.  SDF_PIPELINE=0 in the environment of sdf_create() keeps a batch
+ * in one chunk on one stream. */
 float sdf_last_ms(const sdf_ctx *ctx, int which);
 /* Number of DP kernel launches in the last batch call and algorithmic bytes they moved. */
 int sdf_last_launches(const sdf_ctx *ctx);

@@ -48,9 +48,9 @@ __device__ __forceinline__ unsigned sign_smear(unsigned c) {
 }
 
 // fresh (score + 2(q+e)) << 8 of the lane's cell of both tasks from the target / query byte codes
-#define SDF_PFRESH(z, tc, qword, QSEL, WITH_N)                          \
+#define SDF_PFRESH(z, tc, qword, WITH_N)                                \
   {                                                                     \
-    const unsigned qc_ = __builtin_amdgcn_perm(0u, (qword), (QSEL)); /* bytes -> halves */ \
+    const unsigned qc_ = (qword);                                       \
     const unsigned d_ = pk_sub(tc, qc_);                                \
     const unsigned m_ = pk_nonzero(d_);                                 \
     z = pk_mad(m_, z_delta, z_match_v);                                 \
@@ -73,9 +73,9 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
   const int T16 = (tlen + 15) / 16 * 16;
   const int tcap = T16 + NSLOT + 32;   // target bytes (A | B << 8), zero padded
-  const int qcap = qlen + NSLOT + 36;  // reversed query with a 32-element front pad, same packing
+  const int qcap = qlen + NSLOT + 36;  // reversed query with a 32-element front pad: A | B << 16, ready to use
   uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);
-  uint16_t *W = reinterpret_cast<uint16_t *>(lds + 2 * tcap);  // W[j] = QR[j-32], QR[e] = query[qlen-1-e]
+  uint32_t *W = reinterpret_cast<uint32_t *>(lds + 2 * tcap);  // W[j] = QR[j-32], QR[e] = query[qlen-1-e]
 
   // ---- unpack the 2-bit / N-mask sequences of both tasks into LDS ----
   int has_n;
@@ -93,9 +93,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
     for (int j = lane; j < qcap; j += 64) {
       const int e = j - 32;
       const bool in = e >= 0 && e < qlen;
-      W[j] = in ? (uint16_t)(pool_code8(qwa, qna, qlen - 1 - e, sc.wild) |
-                             (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 8))
-                : 0;
+      W[j] = in ? (pool_code8(qwa, qna, qlen - 1 - e, sc.wild) | (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 16)) : 0u;
     }
   }
   __syncthreads();
@@ -141,22 +139,13 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
   int32_t ez_zdropped = 0;
   int drop_row = -1;  // row of the current block at which the reference window left slots 0..15
   int r0 = 0;
-  // query codes of the next row, prefetched: two registers' 16-bit LDS values per VGPR (d16 loads; a lone last
-  // register is fetched twice rather than zero-extended on the vector ALU)
-  constexpr int NQ = (NREG + 1) / 2;
-  unsigned qaddr = 0u;
-  u16x2 qnext[NQ];  // LDS address / prefetched query codes of row `qrow` (lean rows)
-  int qrow = -1;
+  unsigned qaddr = 0u, qnext[NREG];  // LDS address of the next row to fetch / prefetched query codes (lean rows)
+  int qrow = -1;                     // row whose codes sit in qnext
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) qnext[j] = (u16x2){0, 0};
+  for (int k = 0; k < NREG; ++k) qnext[k] = 0u;
   auto fetch_q = [&]() {
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      u16x2 t;
-      t.x = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * j);
-      t.y = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * j + (2 * j + 1 < NREG ? 128 : 0));
-      qnext[j] = t;
-    }
+    for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 256 * k);
   };
   unsigned hacc_a = 0u, hacc_b = 0u;  // lane-distributed parts of the H path sums (lean rows), folded lazily
   int hcnt = 0;                       // number of path steps in them (each subtracts q+e)
@@ -278,7 +267,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
         if (b_ > 0 && a_ < 64) {
           const unsigned qc = W[cq + 64 * k + lane];
           unsigned z;
-          SDF_PFRESH(z, Tc[k], qc, 0x0c010c00u, has_n)
+          SDF_PFRESH(z, Tc[k], qc, has_n)
           if (a_ <= 0 && b_ >= 64) S[k] = z;
           else if (lane_in(lane, a_ < 0 ? 0 : a_, b_)) S[k] = z;
         }
@@ -331,9 +320,9 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
     constexpr int KT = NREG - 1;
     if (SCALARH) fold_h();
     if (qrow != rb) {  // (re)start the one-row-ahead query fetch at this row
-      qaddr = (unsigned)(2 * tcap + 2 * (qlen - 1 - rb + base + 32 + lane));
+      qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + lane));
       fetch_q();
-      qaddr -= 2;  // address of the row after `qnext`
+      qaddr -= 4;  // address of the row after `qnext`
     }
     qrow = re;
     if (STEADY && !SCALARH) hcnt += re - rb;  // every steady row takes one path step
@@ -348,11 +337,11 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
         hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
       }
       const int off_hi = (hi0 | 15) - base;
-      unsigned qcur[NQ];
+      unsigned qcur[NREG];
 #pragma unroll
-      for (int j = 0; j < NQ; ++j) qcur[j] = __builtin_bit_cast(unsigned, qnext[j]);
+      for (int k = 0; k < NREG; ++k) qcur[k] = qnext[k];
       fetch_q();
-      qaddr -= 2;
+      qaddr -= 4;
       // boundary cell t = r: y = 0, u = gap open (reference :122)
       if (!STEADY && off_hi + base >= r) {
         const int sr = r - base;
@@ -385,14 +374,14 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
         const int b_ = rbe - 64 * k;
         if (STEADY) {
           unsigned z;
-          SDF_PFRESH(z, Tc[k], qcur[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u, HASN)
+          SDF_PFRESH(z, Tc[k], qcur[k], HASN)
           if (NREG == 1) S[0] = lane_in(lane, ra, b_) ? z : S[0];
           else if (k == 0) S[0] = lane >= ra ? z : S[0];
           else if (k == KT) S[k] = lane < b_ ? z : S[k];
           else S[k] = z;
         } else if (b_ > 0) {
           unsigned z;
-          SDF_PFRESH(z, Tc[k], qcur[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u, HASN)
+          SDF_PFRESH(z, Tc[k], qcur[k], HASN)
           if (k == 0) {
             if (b_ >= 64) S[0] = lane >= ra ? z : S[0];
             else S[0] = lane_in(lane, ra, b_) ? z : S[0];
@@ -701,7 +690,7 @@ size_t pair_lds_bytes(int qlen, int tlen, int nreg) {
   const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
   const size_t tcap = T16 + 64 * nreg + 32;
   const size_t qcap = (size_t)qlen + 64 * nreg + 36;
-  return 2 * tcap + 2 * qcap;
+  return 2 * tcap + 4 * qcap;
 }
 
 }  // namespace sdf

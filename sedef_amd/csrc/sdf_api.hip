@@ -78,22 +78,46 @@ struct DevBuf {
   }
 };
 
+struct HostBuf {  // pinned host memory
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 }  // namespace
 
 struct sdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   size_t ws_budget = 0;
+  hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr, small_stream = nullptr;  // chunk pipeline
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
+  HostBuf host_plan, host_order;  // pinned staging of the plan
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
   std::vector<hipEvent_t> events;
-  float ms[6] = {0, 0, 0, 0, 0, 0};  // 0 DP, 1 traceback, 2 compaction, 3 stream total, 4 host planning, 5 host total
+  float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 DP, 1 traceback, 2 compaction, 3 stream total, 4 host planning before the
+                                           // first launch, 5 host total, 6 sum of the chunks' DP intervals
   int launches = 0;
   long long paired = 0;  // tasks of the last batch that ran two per wavefront (extz2_pair.hip)
   std::string err;
   int max_dyn_lds = 64 * 1024;
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
+  bool pipeline = true;        // SDF_PIPELINE=0: one chunk on one stream (isolated kernel timing)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
 };
 
@@ -168,6 +192,15 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->force_general = fg && fg[0] == '1';
   const char *np = getenv("SDF_NO_PAIR");
   ctx->no_pair = np && np[0] == '1';
+  const char *pl = getenv("SDF_PIPELINE");
+  ctx->pipeline = !(pl && pl[0] == '0');
+  if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->dp_stream[1], hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->tb_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->small_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->pipeline = false;
+  }
   return ctx;
 }
 
@@ -183,6 +216,10 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
                     &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
     b->release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
+    if (s) (void)hipStreamDestroy(s);
+  ctx->host_plan.release();
+  ctx->host_order.release();
   delete ctx;
 }
 
@@ -215,7 +252,7 @@ extern "C" int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w) {
 }
 
 extern "C" float sdf_last_ms(const sdf_ctx *ctx, int which) {
-  if (!ctx || which < 0 || which > 5) return 0.f;
+  if (!ctx || which < 0 || which > 6) return 0.f;
   return ctx->ms[which];
 }
 
@@ -279,121 +316,188 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   if (int rc = make_scorek(ctx, sc, sk, degenerate)) return rc;
   const bool want_cigar = (want & SDF_WANT_CIGAR) != 0;
 
-  // ---- plan ----
-  std::vector<PlanTask> plan;
-  plan.reserve(n);
-  std::vector<int32_t> win_need;  // window slots of the wave-eligible tasks (0: general kernel)
-  win_need.reserve(n);
-  int64_t stage_words = 0;
-  for (size_t k = 0; k < n; ++k) {
-    const sdf_task &t = tasks[k];
-    if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
-      ctx->err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
-      return SDF_ERR_UNSUPPORTED;
-    }
-    if (t.qlen <= 0 || t.tlen <= 0 || degenerate) continue;  // reference early return (:57,:81)
-    PlanTask p;
-    p.q_word = t.q_off;
-    p.t_word = t.t_off;
-    p.qlen = t.qlen;
-    p.tlen = t.tlen;
-    p.w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
-    p.zdrop = t.zdrop;
-    p.flag = t.flag | (want_cigar ? 0 : SDF_FLAG_SCORE_ONLY);
-    int nc = std::min(t.qlen, t.tlen);
-    nc = (std::min(nc, p.w + 1) + 15) / 16 + 1;
-    p.ncol16 = nc * 16;
-    p.out_idx = (int32_t)k;
-    p.pad_ = 0;
-    // register-resident wave kernel when only CIGAR/score/mte are wanted and the shape fits
-    p.nreg = 0;
-    {
-      const int nrow = t.qlen + t.tlen - 1;
-      Band bl;
-      const bool band_whole = (p.w >= 1 || nrow == 1) && band_of(nrow - 1, t.qlen, t.tlen, p.w, bl);
-      const bool plain = !(want & SDF_WANT_EXT) && t.zdrop < 0 &&
-                         !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY)) && sc->gapo >= 0 && band_whole;
-      if (plain && !ctx->force_general) {
-        // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
-        // beyond the target's last 16-cell block (cells past it are not part of any window)
-        const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
-        const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : need <= 1024 ? 8 : 0;
-        if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)ctx->max_dyn_lds) {
-          p.nreg = nreg;
-          win_need.push_back(need);
-        }
-      }
-      if (!p.nreg) win_need.push_back(0);
-    }
-    p.dir_off = 0;
-    p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
-    p.cig_slot = stage_words;
-    stage_words += p.cig_cap;
-    if (!p.nreg && general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds)
-      p.pad_ = 1;  // state in an HBM scratch slab instead of LDS
-    plan.push_back(p);
-  }
-  const size_t np = plan.size();
-
-  // sub-batches bounded by the direction-matrix workspace
-  struct Sub {
+  // ---- pre-pass: validation, CIGAR staging size, chunk boundaries ----
+  // The batch is cut into chunks that are planned, uploaded and launched one after the other: while the GPU
+  // runs chunk i the host plans chunk i+1, the big DP launches of consecutive chunks alternate between two
+  // streams (the next chunk fills the CUs while the previous one drains), launches of a few tasks (each a full
+  // task latency long, e.g. the tasks left without a partner) go to a stream of their own instead of holding
+  // up a big one, and the traceback of a chunk runs on a fourth stream next to the following chunk's DP.
+  // Direction-flag regions rotate over `nreg_ws` slices of the workspace.
+  const bool pipelined = ctx->pipeline && n >= 2048;
+  size_t nch = 1;
+  if (pipelined && n >= 32768) nch = std::min<size_t>(4, n / 16384);  // a traceback launch is ~2 ms of latency
+  const size_t max_regions = nch > 1 ? 4 : 1;
+  const size_t region_budget = ctx->ws_budget / max_regions;
+  const size_t chunk_target = (n + nch - 1) / nch;
+  struct Chunk {
     size_t s, e;
-    size_t dir_bytes;
   };
-  std::vector<Sub> subs;
+  std::vector<Chunk> chunks;
+  int64_t stage_total = 0;
+  size_t region_need = 16;
   {
     size_t s = 0, acc = 0;
-    for (size_t k = 0; k < np; ++k) {
-      PlanTask &p = plan[k];
-      size_t need = 0;
-      if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
-        if (p.nreg)
-          need = (size_t)((p.qlen + p.tlen - 1 + 15) / 16) * (size_t)p.nreg * 1024;
-        else
-          need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+    for (size_t k = 0; k < n; ++k) {
+      const sdf_task &t = tasks[k];
+      if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
+        ctx->err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
+        return SDF_ERR_UNSUPPORTED;
       }
-      if (acc + need > ctx->ws_budget && k > s) {
-        subs.push_back({s, k, acc});
+      size_t bound = 0;  // upper bound of the task's direction flags, whichever kernel takes it
+      if (t.qlen > 0 && t.tlen > 0 && !degenerate && want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
+        stage_total += (int64_t)t.qlen + t.tlen + 2;
+        const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+        const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
+        const size_t nrow = (size_t)t.qlen + t.tlen - 1;
+        const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
+        bound = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
+        if (need <= 1024) bound = std::max(bound, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+      }
+      if (k > s && (acc + bound > region_budget || k - s >= chunk_target)) {
+        chunks.push_back({s, k});
+        region_need = std::max(region_need, acc);
         s = k;
         acc = 0;
       }
-      p.dir_off = (int64_t)acc;
-      acc += need;
+      acc += bound;
     }
-    if (np > s) subs.push_back({s, np, acc});
+    chunks.push_back({s, n});
+    region_need = std::max(region_need, acc);
   }
-  // Pair kernel: two wave-eligible tasks of one sub-batch with the same (qlen, tlen, w, flag) and a window of at
-  // most 512 slots share a wavefront (extz2_pair.hip).  partner[k] = the other task, or -1.
-  std::vector<int32_t> partner(np, -1);
-  if (!ctx->no_pair && !ctx->force_general) {
-    // one pass with an open-addressing table keyed by the geometry: entry = (first task seen with the key, the
-    // task of that key still waiting for a partner or -1)
-    std::vector<std::pair<int32_t, int32_t>> table;
-    for (auto &sb : subs) {
+  region_need = (region_need + 255) & ~(size_t)255;
+  const size_t nreg_ws = std::min(max_regions, chunks.size());
+  if (ctx->dir_ws.reserve(region_need * nreg_ws) != hipSuccess) {
+    ctx->err = "cannot allocate the direction-matrix workspace";
+    (void)hipGetLastError();
+    return SDF_ERR_NOMEM;
+  }
+  SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(stage_total, 4) * 4));
+  SDF_HIP(ctx->plan_buf.reserve(n * sizeof(PlanTask)));
+  SDF_HIP(ctx->order_buf.reserve(2 * n * sizeof(int32_t)));  // a task paired with itself is listed twice
+  SDF_HIP(ctx->misc_buf.reserve(256));
+  SDF_HIP(ctx->host_plan.reserve(n * sizeof(PlanTask)));
+  SDF_HIP(ctx->host_order.reserve(2 * n * sizeof(int32_t)));
+  PlanTask *const plan = (PlanTask *)ctx->host_plan.p;  // pinned: the uploads below are asynchronous
+  int32_t *const order = (int32_t *)ctx->host_order.p;
+  PlanTask *d_plan = (PlanTask *)ctx->plan_buf.p;
+  int32_t *d_order = (int32_t *)ctx->order_buf.p;
+  unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
+  uint8_t *d_dir = (uint8_t *)ctx->dir_ws.p;
+  uint32_t *d_stage = (uint32_t *)ctx->stage_ws.p;
+
+  size_t evc = 0;
+  hipEvent_t ev_begin = next_event(ctx, evc);
+  hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out,
+                     (int)n);
+  SDF_HIP(hipEventRecord(ev_begin, st));
+  if (pipelined)
+    for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
+      SDF_HIP(hipStreamWaitEvent(s, ev_begin, 0));
+
+  struct Cls {
+    int bs;  // 64 / 256: general kernel with that many threads; 1, 2, 4, 8: wave kernel with NREG; 100 + NREG: pair
+             // kernel; 1000: general kernel with its state in HBM
+    size_t lds;       // class key
+    size_t need_max;  // largest real requirement in the class: what the launch asks for
+    std::vector<int32_t> idx;
+  };
+  struct ChunkEv {
+    hipEvent_t dp0, dp1, sm0, sm1, tb0, tb1;  // big DP launches, small DP launches, traceback (begin, end)
+  };
+  std::vector<ChunkEv> cev(chunks.size());
+  std::vector<int32_t> win_need, partner;
+  std::vector<std::pair<int32_t, int32_t>> table;
+  std::vector<Cls> cls;
+  size_t np = 0;           // planned tasks so far (= index of the next PlanTask)
+  size_t nord = 0;         // launch-order entries so far
+  int64_t stage_words = 0;
+  float plan_first_ms = 0.f;
+
+  for (size_t ci = 0; ci < chunks.size(); ++ci) {
+    const size_t pb = np;    // first PlanTask of this chunk
+    const size_t ob = nord;  // first launch-order entry of this chunk
+    // ---- plan the chunk ----
+    win_need.clear();
+    for (size_t k = chunks[ci].s; k < chunks[ci].e; ++k) {
+      const sdf_task &t = tasks[k];
+      if (t.qlen <= 0 || t.tlen <= 0 || degenerate) continue;  // reference early return (:57,:81)
+      PlanTask p;
+      p.q_word = t.q_off;
+      p.t_word = t.t_off;
+      p.qlen = t.qlen;
+      p.tlen = t.tlen;
+      p.w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+      p.zdrop = t.zdrop;
+      p.flag = t.flag | (want_cigar ? 0 : SDF_FLAG_SCORE_ONLY);
+      int nc = std::min(t.qlen, t.tlen);
+      nc = (std::min(nc, p.w + 1) + 15) / 16 + 1;
+      p.ncol16 = nc * 16;
+      p.out_idx = (int32_t)k;
+      p.pad_ = 0;
+      // register-resident wave kernel when only CIGAR/score/mte are wanted and the shape fits
+      p.nreg = 0;
+      int wneed = 0;
+      {
+        const int nrow = t.qlen + t.tlen - 1;
+        Band bl;
+        const bool band_whole = (p.w >= 1 || nrow == 1) && band_of(nrow - 1, t.qlen, t.tlen, p.w, bl);
+        const bool plain = !(want & SDF_WANT_EXT) && t.zdrop < 0 &&
+                           !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY)) && sc->gapo >= 0 && band_whole;
+        if (plain && !ctx->force_general) {
+          // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
+          // beyond the target's last 16-cell block (cells past it are not part of any window)
+          const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
+          const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : need <= 1024 ? 8 : 0;
+          if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)ctx->max_dyn_lds) {
+            p.nreg = nreg;
+            wneed = need;
+          }
+        }
+      }
+      win_need.push_back(wneed);
+      p.dir_off = 0;
+      p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
+      p.cig_slot = stage_words;
+      stage_words += p.cig_cap;
+      if (!p.nreg && general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds)
+        p.pad_ = 1;  // state in an HBM scratch slab instead of LDS
+      plan[np++] = p;
+    }
+    const size_t cnt = np - pb;
+    if (cnt == 0) {
+      cev[ci] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      continue;
+    }
+    PlanTask *cp = plan + pb;  // chunk-relative indexing below
+
+    // Pair kernel: two wave-eligible tasks of the chunk with the same (qlen, tlen, w, flag) and a window of at
+    // most 512 slots share a wavefront (extz2_pair.hip).  partner[k] = the other task, or -1.  One pass with an
+    // open-addressing table keyed by the geometry: entry = (first task seen with the key, the task of that key
+    // still waiting for a partner or -1).
+    partner.assign(cnt, -1);
+    if (!ctx->no_pair && !ctx->force_general) {
       size_t cap = 64;
-      while (cap < 2 * (sb.e - sb.s)) cap *= 2;
+      while (cap < 2 * cnt) cap *= 2;
       table.assign(cap, {-1, -1});
-      bool any = false;
-      for (size_t k = sb.s; k < sb.e; ++k) {
-        PlanTask &y = plan[k];
+      for (size_t k = 0; k < cnt; ++k) {
+        PlanTask &y = cp[k];
         if (!y.nreg || win_need[k] > 512) continue;
         uint64_t h = ((uint64_t)(uint32_t)y.qlen * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)y.tlen * 0xC2B2AE3D27D4EB4Full) ^
                      ((uint64_t)(uint32_t)y.w * 0x165667B19E3779F9ull) ^ ((uint64_t)(uint32_t)y.flag << 40);
         h ^= h >> 29;
-        size_t slot = (size_t)h & (cap - 1);
-        for (;; slot = (slot + 1) & (cap - 1)) {
+        for (size_t slot = (size_t)h & (cap - 1);; slot = (slot + 1) & (cap - 1)) {
           auto &e = table[slot];
           if (e.first < 0) {
             e = {(int32_t)k, (int32_t)k};
             break;
           }
-          const PlanTask &x = plan[e.first];
+          const PlanTask &x = cp[e.first];
           if (x.qlen != y.qlen || x.tlen != y.tlen || x.w != y.w || x.flag != y.flag) continue;
           if (e.second < 0) {
             e.second = (int32_t)k;
             break;
           }
-          PlanTask &z = plan[e.second];
+          PlanTask &z = cp[e.second];
           const int regs = (win_need[k] + 63) / 64;
           const int nreg = regs <= 4 ? regs : regs <= 6 ? 6 : 8;
           if (pair_lds_bytes(y.qlen, y.tlen, nreg) > (size_t)ctx->max_dyn_lds) break;
@@ -403,60 +507,53 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           partner[e.second] = (int32_t)k;
           ctx->paired += 2;
           e.second = -1;
-          any = true;
           break;
         }
       }
-      if (any) {  // the flag records of paired tasks are smaller: lay the sub-batch out again
-        size_t acc = 0;
-        for (size_t k = sb.s; k < sb.e; ++k) {
-          PlanTask &p = plan[k];
-          size_t need = 0;
-          if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
-            const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
-            if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
-            else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
-            else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
-          }
-          p.dir_off = (int64_t)acc;
-          acc += need;
-        }
-        sb.dir_bytes = acc;
+      // a task left without a partner is paired with itself (both halves compute the same task and write the
+      // same bytes) instead of occupying a launch of its own for a whole task latency
+      for (auto &e : table) {
+        if (e.second < 0) continue;
+        PlanTask &y = cp[e.second];
+        const int regs = (win_need[e.second] + 63) / 64;
+        const int nreg = regs <= 4 ? regs : regs <= 6 ? 6 : 8;
+        if (pair_lds_bytes(y.qlen, y.tlen, nreg) > (size_t)ctx->max_dyn_lds) continue;
+        y.nreg = nreg;
+        y.pad_ = 2;
+        partner[e.second] = e.second;
       }
     }
-  }
-  size_t max_dir = 16;
-  for (auto &sb : subs) max_dir = std::max(max_dir, sb.dir_bytes);
-  if (ctx->dir_ws.reserve(max_dir) != hipSuccess) {
-    ctx->err = "cannot allocate the direction-matrix workspace";
-    (void)hipGetLastError();
-    return SDF_ERR_NOMEM;
-  }
-  SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(stage_words, 4) * 4));
-  SDF_HIP(ctx->plan_buf.reserve(std::max<size_t>(np, 1) * sizeof(PlanTask)));
-  SDF_HIP(ctx->order_buf.reserve(std::max<size_t>(np, 1) * sizeof(int32_t)));
-  SDF_HIP(ctx->misc_buf.reserve(256));
-
-  // launch classes: (threads per task, LDS bytes rounded to a power of two)
-  struct Cls {
-    int bs;  // 64 / 256: general kernel with that many threads; 1, 2, 4, 8: wave kernel with NREG
-    size_t lds;       // class key
-    size_t need_max;  // largest real requirement in the class: what the launch asks for
-    std::vector<int32_t> idx;
-  };
-  std::vector<int32_t> order(np);
-  struct Launch {
-    int bs;
-    size_t lds;
-    size_t off, cnt;
-  };
-  std::vector<std::vector<Launch>> sub_launches(subs.size());
-  {
-    size_t cursor = 0;
-    for (size_t si = 0; si < subs.size(); ++si) {
-      std::vector<Cls> cls;
-      for (size_t k = subs[si].s; k < subs[si].e; ++k) {
-        const PlanTask &p = plan[k];
+    // direction-flag layout inside this chunk's workspace region
+    {
+      size_t acc = 0;
+      for (size_t k = 0; k < cnt; ++k) {
+        PlanTask &p = cp[k];
+        size_t need = 0;
+        if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
+          const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
+          if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
+          else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
+          else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+        }
+        p.dir_off = (int64_t)acc;
+        acc += need;
+      }
+      if (acc > region_need) {
+        ctx->err = "internal: direction-flag region overflow";
+        return SDF_ERR_INVALID;
+      }
+    }
+    // launch classes: (kernel, LDS bytes rounded to a power of two)
+    struct Launch {
+      int bs;
+      size_t lds;
+      size_t off, cnt;
+    };
+    std::vector<Launch> launches;
+    {
+      cls.clear();
+      for (size_t k = 0; k < cnt; ++k) {
+        const PlanTask &p = cp[k];
         const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
         int bs = width > 256 ? 256 : 64;
         size_t lds = 2048, need;
@@ -464,7 +561,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           if (partner[k] < (int32_t)k) continue;  // placed together with its partner
           bs = 100 + p.nreg;
           need = pair_lds_bytes(p.qlen, p.tlen, p.nreg);
-          lds = 6144;
+          lds = 8192;
           while (lds < need) lds *= 2;
         } else if (p.nreg) {
           bs = p.nreg;
@@ -489,57 +586,71 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           c = &cls.back();
         }
         c->need_max = std::max(c->need_max, need);
-        c->idx.push_back((int32_t)(k - subs[si].s));
-        if (p.pad_ == 2) c->idx.push_back((int32_t)((size_t)partner[k] - subs[si].s));
+        c->idx.push_back((int32_t)k);
+        if (p.pad_ == 2) c->idx.push_back(partner[k]);
       }
       // big classes first so the long tasks start early
       std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.lds > b.lds; });
+      size_t cursor = 0;
       for (auto &c : cls) {
-        sub_launches[si].push_back({c.bs, c.bs == 1000 ? ((c.need_max + 255) & ~(size_t)255) : std::min(c.lds, (c.need_max + 511) & ~(size_t)511), cursor, c.idx.size()});
-        std::copy(c.idx.begin(), c.idx.end(), order.begin() + cursor);
+        launches.push_back({c.bs,
+                            c.bs == 1000 ? ((c.need_max + 255) & ~(size_t)255)
+                                         : std::min(c.lds, (c.need_max + 511) & ~(size_t)511),
+                            cursor, c.idx.size()});
+        std::copy(c.idx.begin(), c.idx.end(), order + ob + cursor);
         cursor += c.idx.size();
       }
+      nord += cursor;
     }
-  }
+    if (ci == 0)
+      plan_first_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
 
-  ctx->ms[4] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
-  PlanTask *d_plan = (PlanTask *)ctx->plan_buf.p;
-  int32_t *d_order = (int32_t *)ctx->order_buf.p;
-  unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
-  uint8_t *d_dir = (uint8_t *)ctx->dir_ws.p;
-  uint32_t *d_stage = (uint32_t *)ctx->stage_ws.p;
-
-  size_t evc = 0;
-  hipEvent_t ev_begin = next_event(ctx, evc);
-  SDF_HIP(hipEventRecord(ev_begin, st));
-  if (np) {
-    SDF_HIP(hipMemcpyAsync(d_plan, plan.data(), np * sizeof(PlanTask), hipMemcpyHostToDevice, st));
-    SDF_HIP(hipMemcpyAsync(d_order, order.data(), np * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  }
-  hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out,
-                     (int)n);
-
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> dp_ev, tb_ev;
-  for (size_t si = 0; si < subs.size(); ++si) {
-    const Sub &sb = subs[si];
-    hipEvent_t e0 = next_event(ctx, evc), e1 = next_event(ctx, evc), e2 = next_event(ctx, evc);
-    SDF_HIP(hipEventRecord(e0, st));
-    for (const Launch &L : sub_launches[si]) {
+    // ---- upload and launch the chunk ----
+    hipStream_t sbig = pipelined ? ctx->dp_stream[ci & 1] : st;
+    hipStream_t ssmall = pipelined ? ctx->small_stream : st;
+    hipStream_t stb = pipelined ? ctx->tb_stream : st;
+    uint8_t *dir_reg = d_dir + (ci % nreg_ws) * region_need;
+    bool any_small = false;
+    if (pipelined)
+      for (const Launch &L : launches) any_small |= launches.size() > 1 && L.cnt < 2048;
+    if (pipelined && ci >= nreg_ws && cev[ci - nreg_ws].tb1) {  // the region's previous user has been traced back
+      SDF_HIP(hipStreamWaitEvent(sbig, cev[ci - nreg_ws].tb1, 0));
+      if (any_small) SDF_HIP(hipStreamWaitEvent(ssmall, cev[ci - nreg_ws].tb1, 0));
+    }
+    SDF_HIP(hipMemcpyAsync(d_plan + pb, cp, cnt * sizeof(PlanTask), hipMemcpyHostToDevice, sbig));
+    SDF_HIP(hipMemcpyAsync(d_order + ob, order + ob, (nord - ob) * sizeof(int32_t), hipMemcpyHostToDevice, sbig));
+    ChunkEv &ev = cev[ci];
+    ev.dp0 = next_event(ctx, evc);
+    ev.dp1 = next_event(ctx, evc);
+    ev.sm0 = ev.sm1 = nullptr;
+    ev.tb0 = next_event(ctx, evc);
+    ev.tb1 = next_event(ctx, evc);
+    SDF_HIP(hipEventRecord(ev.dp0, sbig));
+    if (any_small) {  // the plan has to be on the device before the small launches read it
+      ev.sm0 = next_event(ctx, evc);
+      ev.sm1 = next_event(ctx, evc);
+      SDF_HIP(hipStreamWaitEvent(ssmall, ev.dp0, 0));
+      SDF_HIP(hipEventRecord(ev.sm0, ssmall));
+    }
+    for (const Launch &L : launches) {
+      hipStream_t sdp = (any_small && L.cnt < 2048) ? ssmall : sbig;
+      const PlanTask *lp = d_plan + pb;
+      const int32_t *lo = d_order + ob + L.off;
       if (L.bs == 1)
-        hipLaunchKernelGGL(extz2_wave_kernel<1>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
-                           d_order + L.off, d_pool, sk, d_dir, d_out);
+        hipLaunchKernelGGL(extz2_wave_kernel<1>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
       else if (L.bs == 2)
-        hipLaunchKernelGGL(extz2_wave_kernel<2>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
-                           d_order + L.off, d_pool, sk, d_dir, d_out);
+        hipLaunchKernelGGL(extz2_wave_kernel<2>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
       else if (L.bs == 4)
-        hipLaunchKernelGGL(extz2_wave_kernel<4>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
-                           d_order + L.off, d_pool, sk, d_dir, d_out);
+        hipLaunchKernelGGL(extz2_wave_kernel<4>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
       else if (L.bs == 8)
-        hipLaunchKernelGGL(extz2_wave_kernel<8>, dim3((unsigned)L.cnt), dim3(64), L.lds, st, d_plan + sb.s,
-                           d_order + L.off, d_pool, sk, d_dir, d_out);
-#define SDF_PAIR_LAUNCH(N)                                                                                   \
+        hipLaunchKernelGGL(extz2_wave_kernel<8>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
+#define SDF_PAIR_LAUNCH(N)                                                                                     \
   else if (L.bs == 100 + N) hipLaunchKernelGGL(extz2_pair_kernel<N>, dim3((unsigned)(L.cnt / 2)), dim3(64), L.lds, \
-                                               st, d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out);
+                                               sdp, lp, lo, d_pool, sk, dir_reg, d_out);
       SDF_PAIR_LAUNCH(1)
       SDF_PAIR_LAUNCH(2)
       SDF_PAIR_LAUNCH(3)
@@ -548,33 +659,46 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       SDF_PAIR_LAUNCH(8)
 #undef SDF_PAIR_LAUNCH
       else if (L.bs == 64)
-        hipLaunchKernelGGL((extz2_general_kernel<64, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, st,
-                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out, (uint8_t *)nullptr, (size_t)0);
+        hipLaunchKernelGGL((extz2_general_kernel<64, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo,
+                           d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
       else if (L.bs == 256)
-        hipLaunchKernelGGL((extz2_general_kernel<256, false>), dim3((unsigned)L.cnt), dim3(256), L.lds, st,
-                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out, (uint8_t *)nullptr, (size_t)0);
+        hipLaunchKernelGGL((extz2_general_kernel<256, false>), dim3((unsigned)L.cnt), dim3(256), L.lds, sdp, lp, lo,
+                           d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
       else {  // L.lds = per-workgroup slab bytes in HBM
+        if (ctx->gstate_buf.cap < L.lds * L.cnt) {  // growing frees the old slabs: nothing may be using them
+          if (pipelined)
+            for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
+              SDF_HIP(hipStreamSynchronize(s));
+          else
+            SDF_HIP(hipStreamSynchronize(st));
+        }
         if (ctx->gstate_buf.reserve(L.lds * L.cnt) != hipSuccess) {
           ctx->err = "cannot allocate the HBM state slabs for very long tasks";
           (void)hipGetLastError();
           return SDF_ERR_NOMEM;
         }
-        hipLaunchKernelGGL((extz2_general_kernel<256, true>), dim3((unsigned)L.cnt), dim3(256), 256, st,
-                           d_plan + sb.s, d_order + L.off, d_pool, sk, d_dir, d_out, (uint8_t *)ctx->gstate_buf.p,
-                           L.lds);
+        hipLaunchKernelGGL((extz2_general_kernel<256, true>), dim3((unsigned)L.cnt), dim3(256), 256, sdp, lp, lo,
+                           d_pool, sk, dir_reg, d_out, (uint8_t *)ctx->gstate_buf.p, L.lds);
       }
       ++ctx->launches;
     }
-    SDF_HIP(hipEventRecord(e1, st));
-    if (want_cigar) {
-      const int cnt = (int)(sb.e - sb.s);
-      hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st,
-                         d_plan + sb.s, cnt, d_pool, d_dir, d_out, d_stage);
+    SDF_HIP(hipEventRecord(ev.dp1, sbig));
+    if (any_small) SDF_HIP(hipEventRecord(ev.sm1, ssmall));
+    if (pipelined) {
+      SDF_HIP(hipStreamWaitEvent(stb, ev.dp1, 0));
+      if (any_small) SDF_HIP(hipStreamWaitEvent(stb, ev.sm1, 0));
     }
-    SDF_HIP(hipEventRecord(e2, st));
-    dp_ev.push_back({e0, e1});
-    tb_ev.push_back({e1, e2});
+    SDF_HIP(hipEventRecord(ev.tb0, stb));
+    if (want_cigar)
+      hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, stb, d_plan + pb,
+                         (int)cnt, d_pool, dir_reg, d_out, d_stage);
+    SDF_HIP(hipEventRecord(ev.tb1, stb));
   }
+  ctx->ms[4] = plan_first_ms;
+  if (pipelined)
+    for (auto &ev : cev)
+      if (ev.tb1) SDF_HIP(hipStreamWaitEvent(st, ev.tb1, 0));
+
   hipEvent_t ev_c0 = next_event(ctx, evc), ev_c1 = next_event(ctx, evc), ev_end = next_event(ctx, evc);
   SDF_HIP(hipEventRecord(ev_c0, st));
   unsigned long long total = 0;
@@ -595,15 +719,45 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   SDF_HIP(hipEventRecord(ev_end, st));
   SDF_HIP(hipStreamSynchronize(st));
   SDF_HIP(hipGetLastError());
-  for (auto &p : dp_ev) {
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, p.first, p.second);
-    ctx->ms[0] += ms;
-  }
-  for (auto &p : tb_ev) {
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, p.first, p.second);
-    ctx->ms[1] += ms;
+  // DP / traceback time = length of the union of the chunks' intervals (chunks overlap when pipelined);
+  // ms[6] = sum of the chunks' DP intervals (what a kernel trace adds up)
+  {
+    auto span = [&](bool tb, float &sum) {
+      std::vector<std::pair<float, float>> iv;
+      sum = 0.f;
+      auto add = [&](hipEvent_t e0, hipEvent_t e1) {
+        float a = 0, b = 0;
+        (void)hipEventElapsedTime(&a, ev_begin, e0);
+        (void)hipEventElapsedTime(&b, ev_begin, e1);
+        iv.push_back({a, b});
+        sum += b - a;
+      };
+      for (auto &ev : cev) {
+        if (!ev.dp0) continue;
+        if (tb) {
+          add(ev.tb0, ev.tb1);
+        } else {
+          add(ev.dp0, ev.dp1);
+          if (ev.sm0) add(ev.sm0, ev.sm1);
+        }
+      }
+      std::sort(iv.begin(), iv.end());
+      float len = 0, end = -1e30f;
+      for (auto &p : iv) {
+        if (p.first > end) {
+          len += p.second - p.first;
+          end = p.second;
+        } else if (p.second > end) {
+          len += p.second - end;
+          end = p.second;
+        }
+      }
+      return len;
+    };
+    float s0 = 0, s1 = 0;
+    ctx->ms[0] = span(false, s0);
+    ctx->ms[1] = span(true, s1);
+    ctx->ms[6] = s0;
   }
   (void)hipEventElapsedTime(&ctx->ms[2], ev_c0, ev_c1);
   (void)hipEventElapsedTime(&ctx->ms[3], ev_begin, ev_end);

@@ -14,6 +14,22 @@ def engine():
     return sedef_amd.Extz2Engine(0)
 
 
+@pytest.fixture(scope="module")
+def solo_engine():
+    """Context with SDF_NO_PAIR=1: one task per wavefront (extz2_wave.hip) instead of the pair kernel."""
+    import os
+    import sedef_amd
+    old = os.environ.get("SDF_NO_PAIR")
+    os.environ["SDF_NO_PAIR"] = "1"
+    try:
+        return sedef_amd.Extz2Engine(0)
+    finally:
+        if old is None:
+            del os.environ["SDF_NO_PAIR"]
+        else:
+            os.environ["SDF_NO_PAIR"] = old
+
+
 def _rec_to_dict(r, cig):
     d = {k: int(r[k]) for k in FIELDS}
     d["cigar"] = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
@@ -144,13 +160,13 @@ def _check_fast(engine, oracle, pairs, ws, flags=None, **sc):
                 oracle.counts(exp["cigar"], q, t)
 
 
-def test_wave_kernel_golden(engine, golden_cases):
+def test_wave_kernel_golden(solo_engine, golden_cases):
     import sedef_amd
     sel = [c for c in golden_cases if (c["flag"] & ~0x81) == 0 and c["zdrop"] < 0
            and (c["match"], c["mismatch"], c["gapo"], c["gape"]) == (5, -4, 40, 1)]
     assert len(sel) > 150
     pairs = [(codes(c["q"]), codes(c["t"])) for c in sel]
-    res, cig = engine.align_pairs(pairs, w=[c["w"] for c in sel], flag=[c["flag"] for c in sel],
+    res, cig = solo_engine.align_pairs(pairs, w=[c["w"] for c in sel], flag=[c["flag"] for c in sel],
                                   want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
     for c, r in zip(sel, res):
         exp = c["expect"]
@@ -160,7 +176,7 @@ def test_wave_kernel_golden(engine, golden_cases):
         assert cigar_to_str(got) == exp["cigar"], (c["tag"], c["w"], len(c["q"]), len(c["t"]))
 
 
-def test_wave_kernel_fuzz_banded(engine, oracle):
+def test_wave_kernel_fuzz_banded(solo_engine, oracle):
     rng = np.random.default_rng(99)
     pairs, ws = [], []
     for _ in range(1200):
@@ -173,10 +189,10 @@ def test_wave_kernel_fuzz_banded(engine, oracle):
                 (np.concatenate([t[:k], t[k + L:]]) if len(t) - L > 1 else t)
         pairs.append((q, t))
         ws.append(int(rng.choice([1, 2, 7, 15, 16, 17, 31, 32, 33, 64, 100, 128, 200, 300])))
-    _check_fast(engine, oracle, pairs, ws)
+    _check_fast(solo_engine, oracle, pairs, ws)
 
 
-def test_wave_kernel_config2_shape(engine, oracle):
+def test_wave_kernel_config2_shape(solo_engine, oracle):
     """BASELINE config 2 shape (1000 x ~1000, w=128, 10 % divergence) + the other headline bands."""
     rng = np.random.default_rng(123)
     pairs, ws = [], []
@@ -185,10 +201,10 @@ def test_wave_kernel_config2_shape(engine, oracle):
             q = random_codes(rng, 1000)
             pairs.append((q, mutate(rng, q)))
             ws.append(w)
-    _check_fast(engine, oracle, pairs, ws)
+    _check_fast(solo_engine, oracle, pairs, ws)
 
 
-def test_wave_kernel_other_scorings(engine, oracle):
+def test_wave_kernel_other_scorings(solo_engine, oracle):
     rng = np.random.default_rng(321)
     for _ in range(40):
         ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
@@ -199,10 +215,10 @@ def test_wave_kernel_other_scorings(engine, oracle):
             d = rng.random() * 0.2
             pairs.append((q, mutate(rng, q, d, d / 3, d / 3)))
         w = int(rng.choice([3, 16, 40, 100]))
-        _check_fast(engine, oracle, pairs, [w] * len(pairs), mat=sedef_mat(ma, mi), gapo=go, gape=ge)
+        _check_fast(solo_engine, oracle, pairs, [w] * len(pairs), mat=sedef_mat(ma, mi), gapo=go, gape=ge)
 
 
-def test_wave_kernel_full_band_sedef_shapes(engine, oracle):
+def test_wave_kernel_full_band_sedef_shapes(solo_engine, oracle):
     """w=-1 (every SEDEF call): gap fills, 500x500 side extensions, <=1000^2 gaps -> NREG 1..8."""
     rng = np.random.default_rng(2026)
     pairs = []
@@ -214,7 +230,7 @@ def test_wave_kernel_full_band_sedef_shapes(engine, oracle):
             t = mutate(rng, q, 0.05, 0.02, 0.02)
             t = t[:tl] if len(t) >= tl else np.concatenate([t, random_codes(rng, tl - len(t))])
             pairs.append((q, t))
-    _check_fast(engine, oracle, pairs, [-1] * len(pairs))
+    _check_fast(solo_engine, oracle, pairs, [-1] * len(pairs))
 
 
 def _fnv(words):
@@ -286,7 +302,7 @@ def test_very_long_task_hbm_state(engine, oracle):
         assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"])
 
 
-def test_wave_kernel_fuzz_all_register_counts(engine, oracle):
+def test_wave_kernel_fuzz_all_register_counts(solo_engine, oracle):
     """Random shapes up to 1100 with bands that map onto every NREG variant (and onto the general kernel
     beyond 1024 window cells), unrelated as well as related sequences."""
     rng = np.random.default_rng(4242)
@@ -304,7 +320,7 @@ def test_wave_kernel_fuzz_all_register_counts(engine, oracle):
                 t = np.concatenate([t[:k], random_codes(rng, int(rng.integers(1, 300))), t[k:]])
         pairs.append((q, t))
         ws.append(int(rng.choice([-1, -1, 3, 20, 50, 120, 200, 260, 400, 480, 700])))
-    _check_fast(engine, oracle, pairs, ws)
+    _check_fast(solo_engine, oracle, pairs, ws)
 
 
 def test_tiny_tasks_bulk(engine, oracle):
@@ -408,7 +424,7 @@ def test_pair_kernel_golden_doubled(engine, golden_cases):
         assert cigar_to_str(got) == exp["cigar"], (c["tag"], c["w"], len(c["q"]), len(c["t"]))
 
 
-def test_pair_and_wave_kernels_agree_at_scale(engine, monkeypatch):
+def test_pair_and_wave_kernels_agree_at_scale(engine, solo_engine):
     """20,000 config-2 tasks: the batch with pairing (default) and with SDF_NO_PAIR=1 give the same bytes."""
     import sedef_amd
     import bench
@@ -420,9 +436,17 @@ def test_pair_and_wave_kernels_agree_at_scale(engine, monkeypatch):
     want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
     res1, cig1 = engine.align_batch(tasks, pool, want=want)
     assert engine.last_paired() > 15000
-    monkeypatch.setenv("SDF_NO_PAIR", "1")
-    solo = sedef_amd.Extz2Engine(0)
+    solo = solo_engine
     res2, cig2 = solo.align_batch(tasks, pool, want=want)
     assert solo.last_paired() == 0
     assert res1.tobytes() == res2.tobytes()
     assert np.array_equal(cig1, cig2)
+
+
+def test_pair_kernel_self_pairs(engine, oracle, golden_cases):
+    """Tasks without a same-geometry partner run as a pair with themselves: the one-task fuzz sets again, on the
+    default context."""
+    test_wave_kernel_golden(engine, golden_cases)
+    test_wave_kernel_fuzz_banded(engine, oracle)
+    test_wave_kernel_full_band_sedef_shapes(engine, oracle)
+    test_wave_kernel_fuzz_all_register_counts(engine, oracle)
