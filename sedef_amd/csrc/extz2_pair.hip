@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned sign_smear(unsigned c) {
   }
 
 template <int NREG>
-__global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 : 2) void extz2_pair_kernel(
+__global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 4 ? 3 : 2) void extz2_pair_kernel(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -220,11 +220,11 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
       const int sr = r - base;
       const unsigned uval = r ? qb2 : 0u;
 #pragma unroll
-      for (int k = 0; k < NREG; ++k)
-        if ((sr >> 6) == k && lane == (sr & 63)) {
-          U[k] = uval;
-          Y[k] = 0u;
-        }
+      for (int k = 0; k < NREG; ++k) {  // selects on every register: conditional stores into the arrays would be
+        const bool mine = (sr >> 6) == k && lane == (sr & 63);  // merged into one dynamically indexed store
+        U[k] = mine ? uval : U[k];
+        Y[k] = mine ? 0u : Y[k];
+      }
     }
     // ---- (r-1, t-1) neighbours: shift x and v up by one slot ----
     {
@@ -345,13 +345,12 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 3 ? 5 : NREG <= 4 ? 4 :
       // boundary cell t = r: y = 0, u = gap open (reference :122)
       if (!STEADY && off_hi + base >= r) {
         const int sr = r - base;
-        const bool mine = lane == (sr & 63);
 #pragma unroll
-        for (int k = 0; k < NREG; ++k)
-          if ((sr >> 6) == k) {
-            U[k] = mine ? qb2 : U[k];
-            Y[k] = mine ? 0u : Y[k];
-          }
+        for (int k = 0; k < NREG; ++k) {  // selects on every register (see slow_row)
+          const bool mine = (sr >> 6) == k && lane == (sr & 63);
+          U[k] = mine ? qb2 : U[k];
+          Y[k] = mine ? 0u : Y[k];
+        }
       }
 #pragma unroll
       for (int k = 0; k < NREG; ++k) {

@@ -365,11 +365,11 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
       const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
       const unsigned uval = r ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
 #pragma unroll
-      for (int k = 0; k < NREG; ++k)
-        if ((sr >> 7) == k && lane == ((sr & 127) >> 1)) {
-          U[k] = (U[k] & keep) | uval;
-          Y[k] &= keep;
-        }
+      for (int k = 0; k < NREG; ++k) {  // selects on every register: conditional stores into the arrays would be
+        const bool mine = (sr >> 7) == k && lane == ((sr & 127) >> 1);  // merged into a dynamically indexed store
+        U[k] = mine ? ((U[k] & keep) | uval) : U[k];
+        Y[k] = mine ? (Y[k] & keep) : Y[k];
+      }
     }
     // ---- (r-1, t-1) neighbours: shift x and v up by one slot ----
     unsigned xt1[NREG], vt1[NREG];
@@ -528,13 +528,12 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
         const int sr = r - base;
         const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
         const unsigned uval = ((unsigned)sc.q_b << 8) << ((sr & 1) * 16);
-        const bool mine = lane == ((sr & 127) >> 1);
 #pragma unroll
-        for (int k = 0; k < NREG; ++k)
-          if ((sr >> 7) == k) {
-            U[k] = mine ? ((U[k] & keep) | uval) : U[k];
-            Y[k] = mine ? (Y[k] & keep) : Y[k];
-          }
+        for (int k = 0; k < NREG; ++k) {  // selects on every register (see slow_row)
+          const bool mine = (sr >> 7) == k && lane == ((sr & 127) >> 1);
+          U[k] = mine ? ((U[k] & keep) | uval) : U[k];
+          Y[k] = mine ? (Y[k] & keep) : Y[k];
+        }
       }
       unsigned xt1[NREG], vt1[NREG];
 #pragma unroll
