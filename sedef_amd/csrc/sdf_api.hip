@@ -29,7 +29,9 @@ __global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint3
 size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *,
                                  sdf_result *, uint32_t *);
-__global__ void cigar_scan_kernel(sdf_result *, int, unsigned long long *);
+__global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
+__global__ void cigar_scan_parts_kernel(unsigned long long *, int, unsigned long long *);
+__global__ void cigar_scan_add_kernel(sdf_result *, int, const unsigned long long *);
 __global__ void cigar_compact_kernel(const PlanTask *, int, const sdf_result *, const uint32_t *,
                                      uint32_t *, unsigned long long);
 
@@ -328,7 +330,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   if (pipelined && n >= 32768) nch = std::min<size_t>(4, n / 16384);  // a traceback launch is ~2 ms of latency
   const size_t max_regions = nch > 1 ? 4 : 1;
   const size_t region_budget = ctx->ws_budget / max_regions;
-  const size_t chunk_target = (n + nch - 1) / nch;
+  const size_t first_target = nch > 1 ? std::max<size_t>(4096, n / (4 * nch + 1)) : n;
+  const size_t chunk_target = nch > 1 ? (n - first_target + nch - 1) / nch : n;
   struct Chunk {
     size_t s, e;
   };
@@ -353,7 +356,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         bound = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
         if (need <= 1024) bound = std::max(bound, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
       }
-      if (k > s && (acc + bound > region_budget || k - s >= chunk_target)) {
+      // the first chunk is a quarter of the others: the GPU starts after a quarter of the planning time
+      if (k > s && (acc + bound > region_budget || k - s >= (chunks.empty() && nch > 1 ? first_target : chunk_target))) {
         chunks.push_back({s, k});
         region_need = std::max(region_need, acc);
         s = k;
@@ -374,7 +378,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(stage_total, 4) * 4));
   SDF_HIP(ctx->plan_buf.reserve(n * sizeof(PlanTask)));
   SDF_HIP(ctx->order_buf.reserve(2 * n * sizeof(int32_t)));  // a task paired with itself is listed twice
-  SDF_HIP(ctx->misc_buf.reserve(256));
+  SDF_HIP(ctx->misc_buf.reserve(256 + ((n + 1023) / 1024 + 1) * 8));
   SDF_HIP(ctx->host_plan.reserve(n * sizeof(PlanTask)));
   SDF_HIP(ctx->host_order.reserve(2 * n * sizeof(int32_t)));
   PlanTask *const plan = (PlanTask *)ctx->host_plan.p;  // pinned: the uploads below are asynchronous
@@ -703,7 +707,14 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   SDF_HIP(hipEventRecord(ev_c0, st));
   unsigned long long total = 0;
   if (want_cigar) {
-    hipLaunchKernelGGL(cigar_scan_kernel, dim3(1), dim3(1024), 0, st, d_out, (int)n, d_total);
+    {
+      const int nb = (int)((n + 1023) / 1024);
+      unsigned long long *d_part = d_total + 32;
+      hipLaunchKernelGGL(cigar_scan_blocks_kernel, dim3((unsigned)nb), dim3(1024), 0, st, d_out, (int)n, d_part);
+      hipLaunchKernelGGL(cigar_scan_parts_kernel, dim3(1), dim3(1024), 0, st, d_part, nb, d_total);
+      hipLaunchKernelGGL(cigar_scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n,
+                         (const unsigned long long *)d_part);
+    }
     SDF_HIP(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, st));
     SDF_HIP(hipStreamSynchronize(st));
     if (cigar_used) *cigar_used = (size_t)total;

@@ -185,30 +185,61 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   res[tk.out_idx] = rr;
 }
 
-// Exclusive scan of n_cigar over result records in record order (single workgroup; the batch is
-// at most a few million records) -> cigar_off; total goes to *total.
-__global__ __launch_bounds__(1024) void cigar_scan_kernel(sdf_result *__restrict__ res, int n,
-                                                          unsigned long long *__restrict__ total) {
-  __shared__ unsigned long long part[1024];
-  const int tid = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int lo = tid * per, hi = min(n, lo + per);
-  unsigned long long s = 0;
-  for (int k = lo; k < hi; ++k) s += (unsigned long long)res[k].n_cigar;
-  part[tid] = s;
+// Exclusive scan of n_cigar over the result records in record order -> cigar_off, in three small launches:
+// per 1024-record block a local scan + the block total, a scan of the block totals (one workgroup), and the
+// addition of the block offsets.  `part` holds ceil(n / 1024) + 1 words; the grand total goes to *total.
+__global__ __launch_bounds__(1024) void cigar_scan_blocks_kernel(sdf_result *__restrict__ res, int n,
+                                                                 unsigned long long *__restrict__ part) {
+  __shared__ unsigned long long wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = blockIdx.x * 1024 + tid;
+  const unsigned long long mine = k < n ? (unsigned long long)res[k].n_cigar : 0ull;
+  unsigned long long inc = mine;  // inclusive scan inside the wavefront
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(inc, off);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) wsum[wv] = inc;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    unsigned long long v = tid >= off ? part[tid - off] : 0ull;
+  unsigned long long before = 0;
+  for (int q = 0; q < wv; ++q) before += wsum[q];
+  if (k < n) res[k].cigar_off = (int64_t)(before + inc - mine);
+  if (tid == 1023) part[blockIdx.x] = before + inc;
+}
+
+__global__ __launch_bounds__(1024) void cigar_scan_parts_kernel(unsigned long long *__restrict__ part, int nb,
+                                                                unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int k = base + tid;
+    const unsigned long long mine = k < nb ? part[k] : 0ull;
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long up = __shfl_up(inc, off);
+      if (lane >= off) inc += up;
+    }
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    part[tid] += v;
+    unsigned long long before = carry_s;
+    for (int q = 0; q < wv; ++q) before += wsum[q];
+    if (k < nb) part[k] = before + inc - mine;
+    __syncthreads();
+    if (tid == 1023) carry_s = before + inc;
     __syncthreads();
   }
-  unsigned long long base = tid ? part[tid - 1] : 0ull;
-  for (int k = lo; k < hi; ++k) {
-    res[k].cigar_off = (int64_t)base;
-    base += (unsigned long long)res[k].n_cigar;
-  }
-  if (tid == 1023) *total = part[1023];
+  if (tid == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(256) void cigar_scan_add_kernel(sdf_result *__restrict__ res, int n,
+                                                             const unsigned long long *__restrict__ part) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n) res[k].cigar_off += (int64_t)part[k >> 10];
 }
 
 // Copy every task's CIGAR from its staging slot to its compact position.  One wave per task.
