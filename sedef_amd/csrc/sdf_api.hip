@@ -27,8 +27,8 @@ template <int NREG>
 __global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                   sdf_result *);
 size_t pair_lds_bytes(int qlen, int tlen, int nreg);
-__global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *,
-                                 sdf_result *, uint32_t *);
+template <int LAYOUT>
+__global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
 __global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
 __global__ void cigar_scan_parts_kernel(unsigned long long *, int, unsigned long long *);
 __global__ void cigar_scan_add_kernel(sdf_result *, int, const unsigned long long *);
@@ -693,9 +693,17 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       if (any_small) SDF_HIP(hipStreamWaitEvent(stb, ev.sm1, 0));
     }
     SDF_HIP(hipEventRecord(ev.tb0, stb));
-    if (want_cigar)
-      hipLaunchKernelGGL(traceback_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, stb, d_plan + pb,
-                         (int)cnt, d_pool, dir_reg, d_out, d_stage);
+    if (want_cigar) {
+      unsigned layouts = 0;  // direction-flag layouts present in the chunk: one traceback instantiation each
+      for (size_t k = 0; k < cnt; ++k) layouts |= 1u << (cp[k].nreg == 0 ? 0 : cp[k].pad_ == 2 ? 2 : 1);
+      const dim3 tbg((unsigned)((cnt + 63) / 64));
+      if (layouts & 4u)
+        hipLaunchKernelGGL(traceback_kernel<2>, tbg, dim3(64), 0, stb, d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+      if (layouts & 2u)
+        hipLaunchKernelGGL(traceback_kernel<1>, tbg, dim3(64), 0, stb, d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+      if (layouts & 1u)
+        hipLaunchKernelGGL(traceback_kernel<0>, tbg, dim3(64), 0, stb, d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+    }
     SDF_HIP(hipEventRecord(ev.tb1, stb));
   }
   ctx->ms[4] = plan_first_ms;

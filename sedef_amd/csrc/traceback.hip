@@ -19,6 +19,11 @@ __device__ __forceinline__ uint32_t code_at(const uint32_t *codes, const uint32_
   return n ? 4u : c;
 }
 
+// LAYOUT: 0 = byte rows (general kernel), 1 = wave-kernel bit blocks, 2 = pair-kernel bit blocks.  One
+// instantiation per layout: in a common loop every step would wait for all outstanding loads at the point where
+// the three fetch paths meet.  Tasks of another layout leave at once (the host launches only the instantiations
+// a chunk needs).
+template <int LAYOUT>
 __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restrict__ plan, int n,
                                                        const uint32_t *__restrict__ pool,
                                                        const uint8_t *__restrict__ dirbase,
@@ -27,6 +32,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const PlanTask tk = plan[k];
+  if ((tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : 1) != LAYOUT) return;
   sdf_result rr = res[tk.out_idx];
   if (tk.flag & SDF_FLAG_SCORE_ONLY) return;
 
@@ -92,9 +98,9 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     if (i < b.lo) forced = 2;
     if (i > b.hi) forced = 1;
     if (forced < 0) {
-      if (tk.nreg == 0) {
+      if (LAYOUT == 0) {
         d = dir[(int64_t)r * stride + (i - b.lo)];
-      } else if (tk.pad_ == 2) {
+      } else if (LAYOUT == 2) {
         // pair-kernel layout: per register k (64 slots) and lane one uint2 (a | b << 16, x | y << 16) of
         // 16-bit row masks; a 64-byte line holds 8 slots x 16 rows
         const int rb = r >> 4;
@@ -184,6 +190,13 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   rr.gap_bases = gap_bases;
   res[tk.out_idx] = rr;
 }
+
+template __global__ void traceback_kernel<0>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
+                                             uint32_t *);
+template __global__ void traceback_kernel<1>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
+                                             uint32_t *);
+template __global__ void traceback_kernel<2>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
+                                             uint32_t *);
 
 // Exclusive scan of n_cigar over the result records in record order -> cigar_off, in three small launches:
 // per 1024-record block a local scan + the block total, a scan of the block totals (one workgroup), and the
