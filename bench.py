@@ -52,6 +52,86 @@ def synth_batch(n, qlen, seed, sub=0.06, dele=0.02, ins=0.02):
     return pool, q_off, qlen_a, t_off + n * qlen, tlen
 
 
+def _mutated_pairs(rng, qlens, sub=0.06, dele=0.02, ins=0.02, tlens=None):
+    """Per-task version of the mutation model for ragged batches: returns (pool, q_off, qlen, t_off, tlen)."""
+    chunks, q_off, t_off, tl, off = [], [], [], [], 0
+    for k, ql in enumerate(qlens):
+        q = rng.integers(0, 4, size=int(ql), dtype=np.uint8)
+        r = rng.random(int(ql))
+        base = q.copy()
+        m_sub = r < sub
+        base[m_sub] = rng.integers(0, 4, size=int(m_sub.sum()), dtype=np.uint8)
+        cnt = np.ones(int(ql), np.int64)
+        cnt[(r >= sub) & (r < sub + dele)] = 0
+        m_ins = (r >= sub + dele) & (r < sub + dele + ins)
+        cnt[m_ins] = 2
+        if cnt.sum() == 0:
+            cnt[0] = 1
+        t = np.repeat(base, cnt)
+        t[np.cumsum(cnt)[m_ins] - 1] = rng.integers(0, 4, size=int(m_ins.sum()), dtype=np.uint8)
+        if tlens is not None:  # forced target length: cut or extend with random bases
+            want = int(tlens[k])
+            t = t[:want] if len(t) >= want else np.concatenate([t, rng.integers(0, 4, size=want - len(t), dtype=np.uint8)])
+        q_off.append(off)
+        off += len(q)
+        t_off.append(off)
+        off += len(t)
+        tl.append(len(t))
+        chunks += [q, t]
+    return (np.concatenate(chunks), np.array(q_off, np.int64), np.array(qlens, np.int32), np.array(t_off, np.int64),
+            np.array(tl, np.int32))
+
+
+def synth_hg19_mixture(n, seed, big=3000):
+    """BASELINE configs[3] shape: the DP task-size mixture of captured `sedef align` task
+    streams, all w=-1: ~59 % gap fills of <=100 cells, ~40 % of <=1e4 cells, ~1.2 % 500x500 side extensions,
+    ~0.06 % up to 1000x1000 and ~0.06 % beyond 1e6 cells (here up to `big` x `big`).  Returns the batch and w."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    u = rng.random(n)
+    ql = np.empty(n, np.int64)
+    tl = np.empty(n, np.int64)
+    for k in range(n):
+        if u[k] < 0.59:
+            a, b = int(rng.integers(1, 11)), int(rng.integers(1, 11))
+        elif u[k] < 0.99:
+            a = int(rng.integers(5, 101))
+            b = max(1, min(209, a + int(rng.integers(-20, 21))))
+        elif u[k] < 0.9988:
+            a, b = 500, int(rng.choice([500, 500, 500, 431, 377]))
+        elif u[k] < 0.9994:
+            a, b = int(rng.integers(600, 1001)), int(rng.integers(600, 1001))
+        else:
+            a = int(rng.integers(1200, big + 1))
+            b = a
+        ql[k], tl[k] = a, b
+    return _mutated_pairs(rng, ql, tlens=tl), -1
+
+
+def synth_mm8_mixture(n, seed, max_len=20000):
+    """BASELINE configs[4] shape: lengths log-uniform 200..max_len, one band of
+    {64,128,256,512} per task, 5 % of the tasks with a one-sided 1-5 kb indel.  Returns the batch and w[]."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    ql = np.exp(rng.uniform(np.log(200), np.log(max_len), n)).astype(np.int64)
+    w = rng.choice([64, 128, 256, 512], size=n).astype(np.int32)
+    batch = list(_mutated_pairs(rng, ql))
+    pool, q_off, qlen, t_off, tlen = batch
+    # one-sided indel: cut 1-5 kb out of the middle of the target of every 20th task (where it is long enough)
+    chunks, new_t_off, new_tlen, off = [], [], [], 0
+    for k in range(n):
+        q = pool[q_off[k]:q_off[k] + qlen[k]]
+        t = pool[t_off[k]:t_off[k] + tlen[k]]
+        if k % 20 == 0 and len(t) > 6000:
+            cut = int(rng.integers(1000, 5001))
+            at = int(rng.integers(0, len(t) - cut))
+            t = np.concatenate([t[:at], t[at + cut:]])
+        chunks += [q, t]
+        new_t_off.append(off + len(q))
+        new_tlen.append(len(t))
+        off += len(q) + len(t)
+    q_off2 = np.array(new_t_off, np.int64) - qlen
+    return (np.concatenate(chunks), q_off2, qlen, np.array(new_t_off, np.int64), np.array(new_tlen, np.int32)), w
+
+
 def pack_batch(pool, q_off, qlen, t_off, tlen):
     """Packs every sequence (2-bit codes + N mask) into one uint32 pool; returns (words, q_word, t_word)."""
     import sedef_amd

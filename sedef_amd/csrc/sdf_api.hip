@@ -329,17 +329,26 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   size_t nch = 1;
   if (pipelined && n >= 32768) nch = std::min<size_t>(4, n / 16384);  // a traceback launch is ~2 ms of latency
   const size_t max_regions = nch > 1 ? 4 : 1;
-  const size_t region_budget = ctx->ws_budget / max_regions;
+  // Heavy tasks (>= 1 MB of direction flags: long sequences, one workgroup or wavefront busy for milliseconds)
+  // leave the chunk rotation: they are planned and launched FIRST, all together, on the caller's stream with a
+  // workspace slice of their own, and run next to the chunks of ordinary tasks instead of ending each chunk
+  // with a long tail.
+  const bool split_heavy = nch > 1;
+  const size_t heavy_budget = split_heavy ? ctx->ws_budget / 2 : 0;
+  const size_t region_budget = (ctx->ws_budget - heavy_budget) / max_regions;
   const size_t first_target = nch > 1 ? std::max<size_t>(4096, n / (4 * nch + 1)) : n;
   const size_t chunk_target = nch > 1 ? (n - first_target + nch - 1) / nch : n;
   struct Chunk {
     size_t s, e;
+    bool heavy;
   };
-  std::vector<Chunk> chunks;
+  std::vector<Chunk> chunks, heavy_chunks;
+  std::vector<uint8_t> heavy(split_heavy ? n : 0, 0);
   int64_t stage_total = 0;
-  size_t region_need = 16;
+  size_t region_need = 16, heavy_need = 0;
   {
-    size_t s = 0, acc = 0;
+    size_t s = 0, acc = 0, cnt = 0, hs = 0, hacc = 0;
+    bool hany = false;
     for (size_t k = 0; k < n; ++k) {
       const sdf_task &t = tasks[k];
       if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
@@ -356,21 +365,42 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         bound = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
         if (need <= 1024) bound = std::max(bound, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
       }
+      if (split_heavy && bound >= ((size_t)1 << 20)) {
+        heavy[k] = 1;
+        if (hany && hacc + bound > heavy_budget) {
+          heavy_chunks.push_back({hs, k, true});
+          heavy_need = std::max(heavy_need, hacc);
+          hs = k;
+          hacc = 0;
+        }
+        if (!hany) hs = k;
+        hany = true;
+        hacc += bound;
+        continue;
+      }
       // the first chunk is a quarter of the others: the GPU starts after a quarter of the planning time
-      if (k > s && (acc + bound > region_budget || k - s >= (chunks.empty() && nch > 1 ? first_target : chunk_target))) {
-        chunks.push_back({s, k});
+      if (k > s && (acc + bound > region_budget || cnt >= (chunks.empty() && nch > 1 ? first_target : chunk_target))) {
+        chunks.push_back({s, k, false});
         region_need = std::max(region_need, acc);
         s = k;
         acc = 0;
+        cnt = 0;
       }
       acc += bound;
+      ++cnt;
     }
-    chunks.push_back({s, n});
+    chunks.push_back({s, n, false});
     region_need = std::max(region_need, acc);
+    if (hany) {
+      heavy_chunks.push_back({hs, n, true});
+      heavy_need = std::max(heavy_need, hacc);
+    }
   }
   region_need = (region_need + 255) & ~(size_t)255;
+  heavy_need = (heavy_need + 255) & ~(size_t)255;
   const size_t nreg_ws = std::min(max_regions, chunks.size());
-  if (ctx->dir_ws.reserve(region_need * nreg_ws) != hipSuccess) {
+  chunks.insert(chunks.begin(), heavy_chunks.begin(), heavy_chunks.end());  // heavy first
+  if (ctx->dir_ws.reserve(region_need * nreg_ws + heavy_need) != hipSuccess) {
     ctx->err = "cannot allocate the direction-matrix workspace";
     (void)hipGetLastError();
     return SDF_ERR_NOMEM;
@@ -417,13 +447,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   int64_t stage_words = 0;
   float plan_first_ms = 0.f;
 
+  std::vector<size_t> normal_ids;  // chunk indices of the ordinary chunks, in launch order
   for (size_t ci = 0; ci < chunks.size(); ++ci) {
     const size_t pb = np;    // first PlanTask of this chunk
     const size_t ob = nord;  // first launch-order entry of this chunk
+    const bool heavy_chunk = chunks[ci].heavy;
     // ---- plan the chunk ----
     win_need.clear();
     for (size_t k = chunks[ci].s; k < chunks[ci].e; ++k) {
       const sdf_task &t = tasks[k];
+      if (split_heavy && (heavy[k] != 0) != heavy_chunk) continue;
       if (t.qlen <= 0 || t.tlen <= 0 || degenerate) continue;  // reference early return (:57,:81)
       PlanTask p;
       p.q_word = t.q_off;
@@ -542,7 +575,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         p.dir_off = (int64_t)acc;
         acc += need;
       }
-      if (acc > region_need) {
+      if (acc > (heavy_chunk ? heavy_need : region_need)) {
         ctx->err = "internal: direction-flag region overflow";
         return SDF_ERR_INVALID;
       }
@@ -610,17 +643,21 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       plan_first_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
 
     // ---- upload and launch the chunk ----
-    hipStream_t sbig = pipelined ? ctx->dp_stream[ci & 1] : st;
-    hipStream_t ssmall = pipelined ? ctx->small_stream : st;
-    hipStream_t stb = pipelined ? ctx->tb_stream : st;
-    uint8_t *dir_reg = d_dir + (ci % nreg_ws) * region_need;
+    // a heavy chunk runs entirely on the caller's stream, in order, with the workspace slice behind the regions
+    const bool piped = pipelined && !heavy_chunk;
+    const size_t nj = normal_ids.size();  // ordinal among the ordinary chunks
+    hipStream_t sbig = piped ? ctx->dp_stream[nj & 1] : st;
+    hipStream_t ssmall = piped ? ctx->small_stream : st;
+    hipStream_t stb = piped ? ctx->tb_stream : st;
+    uint8_t *dir_reg = heavy_chunk ? d_dir + nreg_ws * region_need : d_dir + (nj % nreg_ws) * region_need;
     bool any_small = false;
-    if (pipelined)
+    if (piped)
       for (const Launch &L : launches) any_small |= launches.size() > 1 && L.cnt < 2048;
-    if (pipelined && ci >= nreg_ws && cev[ci - nreg_ws].tb1) {  // the region's previous user has been traced back
-      SDF_HIP(hipStreamWaitEvent(sbig, cev[ci - nreg_ws].tb1, 0));
-      if (any_small) SDF_HIP(hipStreamWaitEvent(ssmall, cev[ci - nreg_ws].tb1, 0));
+    if (piped && nj >= nreg_ws && cev[normal_ids[nj - nreg_ws]].tb1) {  // the region's previous user is traced back
+      SDF_HIP(hipStreamWaitEvent(sbig, cev[normal_ids[nj - nreg_ws]].tb1, 0));
+      if (any_small) SDF_HIP(hipStreamWaitEvent(ssmall, cev[normal_ids[nj - nreg_ws]].tb1, 0));
     }
+    if (!heavy_chunk) normal_ids.push_back(ci);
     SDF_HIP(hipMemcpyAsync(d_plan + pb, cp, cnt * sizeof(PlanTask), hipMemcpyHostToDevice, sbig));
     SDF_HIP(hipMemcpyAsync(d_order + ob, order + ob, (nord - ob) * sizeof(int32_t), hipMemcpyHostToDevice, sbig));
     ChunkEv &ev = cev[ci];
@@ -688,7 +725,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     }
     SDF_HIP(hipEventRecord(ev.dp1, sbig));
     if (any_small) SDF_HIP(hipEventRecord(ev.sm1, ssmall));
-    if (pipelined) {
+    if (piped) {
       SDF_HIP(hipStreamWaitEvent(stb, ev.dp1, 0));
       if (any_small) SDF_HIP(hipStreamWaitEvent(stb, ev.sm1, 0));
     }

@@ -450,3 +450,51 @@ def test_pair_kernel_self_pairs(engine, oracle, golden_cases):
     test_wave_kernel_fuzz_banded(engine, oracle)
     test_wave_kernel_full_band_sedef_shapes(engine, oracle)
     test_wave_kernel_fuzz_all_register_counts(engine, oracle)
+
+
+# ---- BASELINE configs[3] / configs[4] shapes as parity cases (the bench line is configs[1]) ----
+def _batch_vs_cpu(engine, oracle, batch, w):
+    """Every task of the batch through the product path (CIGAR + score + counts) against the CPU path: scores,
+    CIGAR checksums, and the CIGAR consuming exactly both sequences."""
+    import sedef_amd
+    from oracle.binding import Reference
+    pool, q_off, qlen, t_off, tlen = batch
+    n = len(qlen)
+    tasks = np.zeros(n, sedef_amd.TASK_DTYPE)
+    tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"] = q_off, t_off, qlen, tlen
+    tasks["w"], tasks["zdrop"] = w, -1
+    res, cig = engine.align_batch(tasks, pool, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    try:
+        cpu = Reference()
+    except Exception:
+        cpu = oracle
+    ws = np.broadcast_to(np.asarray(w, np.int32), (n,))
+    for wv in np.unique(ws):
+        sel = np.nonzero(ws == wv)[0]
+        score, h = cpu.batch(pool, q_off[sel], qlen[sel], t_off[sel], tlen[sel], w=int(wv))
+        assert np.array_equal(res["score"][sel], score), int(wv)
+        for k, hk in zip(sel, h):
+            c = cig[int(res["cigar_off"][k]):int(res["cigar_off"][k]) + int(res["n_cigar"][k])]
+            assert _fnv(c) == int(hk), (int(k), int(qlen[k]), int(tlen[k]), int(wv))
+            if len(c) and not int(res["zdropped"][k]):  # (a band that cannot reach the corner stops early)
+                ops, lens = c & 0xf, c >> 4
+                assert int(lens[ops != 2].sum()) == qlen[k] and int(lens[ops != 1].sum()) == tlen[k]
+                assert int(res["matches"][k] + res["mismatches"][k]) == int(lens[ops == 0].sum())
+    return res
+
+
+def test_config4_hg19_task_mixture(engine, oracle):
+    """configs[3]: hg19-shaped task-size mixture, w=-1 (SEDEF's real mode): tiny gap fills, 500x500 side
+    extensions, a few tasks beyond 1e6 cells -- every kernel and the planner's pairing in one batch."""
+    import bench
+    batch, w = bench.synth_hg19_mixture(30000, seed=404, big=2500)
+    _batch_vs_cpu(engine, oracle, batch, w)
+    assert engine.last_paired() > 20000
+
+
+def test_config5_mm8_mixed_bands(engine, oracle):
+    """configs[4]: lengths log-uniform 200..20,000, bands 64..512 mixed inside one batch, one-sided kb-scale
+    indels (band cannot reach the corner -> the reference's early stop, zdropped / empty CIGAR, must match)."""
+    import bench
+    batch, w = bench.synth_mm8_mixture(240, seed=505, max_len=20000)
+    _batch_vs_cpu(engine, oracle, batch, w)
