@@ -333,7 +333,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // leave the chunk rotation: they are planned and launched FIRST, all together, on the caller's stream with a
   // workspace slice of their own, and run next to the chunks of ordinary tasks instead of ending each chunk
   // with a long tail.
-  const bool split_heavy = nch > 1;
+  const bool split_heavy = pipelined;
   const size_t heavy_budget = split_heavy ? ctx->ws_budget / 2 : 0;
   const size_t region_budget = (ctx->ws_budget - heavy_budget) / max_regions;
   const size_t first_target = nch > 1 ? std::max<size_t>(4096, n / (4 * nch + 1)) : n;
@@ -673,8 +673,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       SDF_HIP(hipStreamWaitEvent(ssmall, ev.dp0, 0));
       SDF_HIP(hipEventRecord(ev.sm0, ssmall));
     }
+    // a heavy chunk's launch classes (each ends in a tail as long as its longest task) run side by side
+    hipStream_t hstreams[4] = {st, ctx->dp_stream[0], ctx->dp_stream[1], ctx->small_stream};
+    std::vector<hipEvent_t> hev;
+    const bool spread = heavy_chunk && pipelined && launches.size() > 1;
+    if (spread)
+      for (int q = 1; q < 4; ++q) SDF_HIP(hipStreamWaitEvent(hstreams[q], ev.dp0, 0));  // plan uploaded
+    size_t li = 0;
     for (const Launch &L : launches) {
-      hipStream_t sdp = (any_small && L.cnt < 2048) ? ssmall : sbig;
+      hipStream_t sdp = spread ? hstreams[li % 4] : (any_small && L.cnt < 2048) ? ssmall : sbig;
+      ++li;
       const PlanTask *lp = d_plan + pb;
       const int32_t *lo = d_order + ob + L.off;
       if (L.bs == 1)
@@ -722,6 +730,13 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
                            d_pool, sk, dir_reg, d_out, (uint8_t *)ctx->gstate_buf.p, L.lds);
       }
       ++ctx->launches;
+    }
+    if (spread) {  // the caller's stream collects the other three
+      for (int q = 1; q < 4 && (size_t)q < launches.size(); ++q) {
+        hipEvent_t e = next_event(ctx, evc);
+        SDF_HIP(hipEventRecord(e, hstreams[q]));
+        SDF_HIP(hipStreamWaitEvent(st, e, 0));
+      }
     }
     SDF_HIP(hipEventRecord(ev.dp1, sbig));
     if (any_small) SDF_HIP(hipEventRecord(ev.sm1, ssmall));
