@@ -87,7 +87,7 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
   const int arena = 6 * T16 + Q16 + 16;
   int32_t *H = reinterpret_cast<int32_t *>(lds + arena);
   BestCell *red = GLOBAL ? reinterpret_cast<BestCell *>(lds_raw) : reinterpret_cast<BestCell *>(H + T16);
-  int *stop_flag = reinterpret_cast<int *>(red + 4);
+  int *stop_flag = reinterpret_cast<int *>(red + 16);  // one slot per wavefront of the largest workgroup (1024)
 
   for (int k = tid * 4; k < arena; k += BS * 4) *reinterpret_cast<uint32_t *>(lds + k) = 0u;
   for (int k = tid; k < T16; k += BS) H[k] = SDF_NEG_INF;
@@ -337,12 +337,16 @@ template __global__ void extz2_general_kernel<64, false>(const PlanTask *, const
                                                          ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
 template __global__ void extz2_general_kernel<256, false>(const PlanTask *, const int32_t *, const uint32_t *,
                                                           ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<1024, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                          ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<1024, true>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                         ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
 template __global__ void extz2_general_kernel<256, true>(const PlanTask *, const int32_t *, const uint32_t *,
                                                          ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
 
 size_t general_lds_bytes(int qlen, int tlen) {
   const size_t T16 = (size_t)(tlen + 15) / 16 * 16, Q16 = (size_t)(qlen + 15) / 16 * 16;
-  return 6 * T16 + Q16 + 16 + 4 * T16 + 4 * sizeof(BestCell) + 16;
+  return 6 * T16 + Q16 + 16 + 4 * T16 + 16 * sizeof(BestCell) + 16;
 }
 
 }  // namespace sdf

@@ -174,6 +174,8 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<64, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
       hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256, false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<1024, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess)
     ctx->max_dyn_lds = want_lds;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<1>),
@@ -592,7 +594,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       for (size_t k = 0; k < cnt; ++k) {
         const PlanTask &p = cp[k];
         const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
-        int bs = width > 256 ? 256 : 64;
+        int bs = width > 1024 ? 1024 : width > 256 ? 256 : 64;  // 4 cells per thread and pass over the row
         size_t lds = 2048, need;
         if (p.pad_ == 2) {
           if (partner[k] < (int32_t)k) continue;  // placed together with its partner
@@ -607,14 +609,14 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           lds = 6144;
           while (lds < need) lds *= 2;
         } else if (p.pad_) {  // HBM-resident state: one class, slab = largest requirement
-          bs = 1000;
+          bs = width > 1024 ? 1001 : 1000;
           need = general_lds_bytes(p.qlen, p.tlen);
           lds = (size_t)1 << 40;
         } else {
           need = general_lds_bytes(p.qlen, p.tlen);
           while (lds < need) lds *= 2;
         }
-        if (bs != 1000 && lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
+        if (bs < 1000 && lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
         Cls *c = nullptr;
         for (auto &x : cls)
           if (x.bs == bs && x.lds == lds) c = &x;
@@ -631,7 +633,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       size_t cursor = 0;
       for (auto &c : cls) {
         launches.push_back({c.bs,
-                            c.bs == 1000 ? ((c.need_max + 255) & ~(size_t)255)
+                            c.bs >= 1000 ? ((c.need_max + 255) & ~(size_t)255)
                                          : std::min(c.lds, (c.need_max + 511) & ~(size_t)511),
                             cursor, c.idx.size()});
         std::copy(c.idx.begin(), c.idx.end(), order + ob + cursor);
@@ -679,7 +681,21 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     const bool spread = heavy_chunk && pipelined && launches.size() > 1;
     if (spread)
       for (int q = 1; q < 4; ++q) SDF_HIP(hipStreamWaitEvent(hstreams[q], ev.dp0, 0));  // plan uploaded
-    size_t li = 0;
+    size_t li = 0, gs_off = 0;
+    {  // HBM state slabs of the very long tasks of this chunk: one allocation, a slice per launch
+      size_t gs_total = 0;
+      for (const Launch &L : launches)
+        if (L.bs >= 1000) gs_total += L.lds * L.cnt;
+      if (gs_total > ctx->gstate_buf.cap) {  // growing frees the old slabs: nothing may be using them
+        for (hipStream_t q : {st, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
+          if (q) SDF_HIP(hipStreamSynchronize(q));
+        if (ctx->gstate_buf.reserve(gs_total) != hipSuccess) {
+          ctx->err = "cannot allocate the HBM state slabs for very long tasks";
+          (void)hipGetLastError();
+          return SDF_ERR_NOMEM;
+        }
+      }
+    }
     for (const Launch &L : launches) {
       hipStream_t sdp = spread ? hstreams[li % 4] : (any_small && L.cnt < 2048) ? ssmall : sbig;
       ++li;
@@ -713,21 +729,18 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       else if (L.bs == 256)
         hipLaunchKernelGGL((extz2_general_kernel<256, false>), dim3((unsigned)L.cnt), dim3(256), L.lds, sdp, lp, lo,
                            d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
-      else {  // L.lds = per-workgroup slab bytes in HBM
-        if (ctx->gstate_buf.cap < L.lds * L.cnt) {  // growing frees the old slabs: nothing may be using them
-          if (pipelined)
-            for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
-              SDF_HIP(hipStreamSynchronize(s));
-          else
-            SDF_HIP(hipStreamSynchronize(st));
-        }
-        if (ctx->gstate_buf.reserve(L.lds * L.cnt) != hipSuccess) {
-          ctx->err = "cannot allocate the HBM state slabs for very long tasks";
-          (void)hipGetLastError();
-          return SDF_ERR_NOMEM;
-        }
-        hipLaunchKernelGGL((extz2_general_kernel<256, true>), dim3((unsigned)L.cnt), dim3(256), 256, sdp, lp, lo,
-                           d_pool, sk, dir_reg, d_out, (uint8_t *)ctx->gstate_buf.p, L.lds);
+      else if (L.bs == 1024)
+        hipLaunchKernelGGL((extz2_general_kernel<1024, false>), dim3((unsigned)L.cnt), dim3(1024), L.lds, sdp, lp, lo,
+                           d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
+      else {  // L.lds = per-workgroup slab bytes in HBM; the chunk's slabs were reserved above
+        uint8_t *slabs = (uint8_t *)ctx->gstate_buf.p + gs_off;
+        gs_off += L.lds * L.cnt;
+        if (L.bs == 1001)
+          hipLaunchKernelGGL((extz2_general_kernel<1024, true>), dim3((unsigned)L.cnt), dim3(1024), 512, sdp, lp, lo,
+                             d_pool, sk, dir_reg, d_out, slabs, L.lds);
+        else
+          hipLaunchKernelGGL((extz2_general_kernel<256, true>), dim3((unsigned)L.cnt), dim3(256), 512, sdp, lp, lo,
+                             d_pool, sk, dir_reg, d_out, slabs, L.lds);
       }
       ++ctx->launches;
     }
