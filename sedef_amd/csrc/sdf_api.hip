@@ -436,6 +436,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     size_t lds;       // class key
     size_t need_max;  // largest real requirement in the class: what the launch asks for
     std::vector<int32_t> idx;
+    double est = 0;   // duration estimate of the launch: its longest task (cells / per-workgroup rate of the kernel)
   };
   struct ChunkEv {
     hipEvent_t dp0, dp1, sm0, sm1, tb0, tb1;  // big DP launches, small DP launches, traceback (begin, end)
@@ -587,6 +588,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       int bs;
       size_t lds;
       size_t off, cnt;
+      double est;
     };
     std::vector<Launch> launches;
     {
@@ -625,17 +627,21 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           c = &cls.back();
         }
         c->need_max = std::max(c->need_max, need);
+        {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
+          const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 100 ? 0.25 : 0.13;
+          c->est = std::max(c->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
+        }
         c->idx.push_back((int32_t)k);
         if (p.pad_ == 2) c->idx.push_back(partner[k]);
       }
-      // big classes first so the long tasks start early
-      std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.lds > b.lds; });
+      // longest launches first so the long tasks start early
+      std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.est > b.est; });
       size_t cursor = 0;
       for (auto &c : cls) {
         launches.push_back({c.bs,
                             c.bs >= 1000 ? ((c.need_max + 255) & ~(size_t)255)
                                          : std::min(c.lds, (c.need_max + 511) & ~(size_t)511),
-                            cursor, c.idx.size()});
+                            cursor, c.idx.size(), c.est});
         std::copy(c.idx.begin(), c.idx.end(), order + ob + cursor);
         cursor += c.idx.size();
       }
@@ -681,7 +687,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     const bool spread = heavy_chunk && pipelined && launches.size() > 1;
     if (spread)
       for (int q = 1; q < 4; ++q) SDF_HIP(hipStreamWaitEvent(hstreams[q], ev.dp0, 0));  // plan uploaded
-    size_t li = 0, gs_off = 0;
+    size_t gs_off = 0;
+    double hload[4] = {0, 0, 0, 0};  // estimated work queued on each stream of a spread heavy chunk
     {  // HBM state slabs of the very long tasks of this chunk: one allocation, a slice per launch
       size_t gs_total = 0;
       for (const Launch &L : launches)
@@ -697,8 +704,11 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       }
     }
     for (const Launch &L : launches) {
-      hipStream_t sdp = spread ? hstreams[li % 4] : (any_small && L.cnt < 2048) ? ssmall : sbig;
-      ++li;
+      int hq = 0;  // longest first, each to the least loaded stream
+      for (int q = 1; q < 4; ++q)
+        if (hload[q] < hload[hq]) hq = q;
+      hload[hq] += L.est;
+      hipStream_t sdp = spread ? hstreams[hq] : (any_small && L.cnt < 2048) ? ssmall : sbig;
       const PlanTask *lp = d_plan + pb;
       const int32_t *lo = d_order + ob + L.off;
       if (L.bs == 1)
