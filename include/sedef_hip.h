@@ -110,7 +110,7 @@ typedef struct {
 /* ---- context ---------------------------------------------------------------------------- */
 int sdf_device_count(void);
 /* device: HIP ordinal.  workspace_bytes: HBM budget for direction matrices per internal
- * sub-batch (0 = default 24 GiB, clamped to free memory).  Returns NULL on failure
+ * batch (0 = default 64 GiB, clamped to half of the free memory).  Returns NULL on failure
  * (sdf_last_error(NULL) has the reason). */
 sdf_ctx *sdf_create(int device, size_t workspace_bytes);
 void sdf_destroy(sdf_ctx *ctx);

@@ -62,6 +62,9 @@ struct Args {
 }  // namespace
 
 int main(int argc, char **argv) {
+  // the DP path keeps four streams busy; give the HIP runtime more hardware queues than its default of four so
+  // that no two of them share one (has to be in the environment before the runtime initialises)
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   if (argc < 2) {
     fprintf(stderr, "Arguments missing: please run sedef help for more information.\n");
     return 1;

@@ -106,7 +106,7 @@ struct sdf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   size_t ws_budget = 0;
-  hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr, small_stream = nullptr;  // chunk pipeline
+  hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr;  // chunk pipeline
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   HostBuf host_plan, host_order;  // pinned staging of the plan
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
@@ -166,7 +166,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   }
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
-  size_t budget = workspace_bytes ? workspace_bytes : (size_t)24 << 30;
+  size_t budget = workspace_bytes ? workspace_bytes : (size_t)64 << 30;
   if (free_b && budget > free_b / 2) budget = free_b / 2;
   ctx->ws_budget = budget;
   // allow the general kernel its full 160 KiB of LDS
@@ -200,11 +200,13 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->dp_stream[1], hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->tb_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->small_stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&ctx->tb_stream, hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError();
     ctx->pipeline = false;
   }
+  // (three streams of our own: the runtime multiplexes streams onto GPU_MAX_HW_QUEUES -- default 4 -- hardware
+  // queues, and two of ours landing on one queue serialises what the pipeline wants side by side; with the
+  // caller's stream that makes four)
   return ctx;
 }
 
@@ -220,7 +222,7 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
                     &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
     b->release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
+  for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream})
     if (s) (void)hipStreamDestroy(s);
   ctx->host_plan.release();
   ctx->host_order.release();
@@ -324,20 +326,17 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // The batch is cut into chunks that are planned, uploaded and launched one after the other: while the GPU
   // runs chunk i the host plans chunk i+1, the big DP launches of consecutive chunks alternate between two
   // streams (the next chunk fills the CUs while the previous one drains), launches of a few tasks (each a full
-  // task latency long, e.g. the tasks left without a partner) go to a stream of their own instead of holding
-  // up a big one, and the traceback of a chunk runs on a fourth stream next to the following chunk's DP.
+  // task latency long) go, longest first, to whichever of the four streams has the least work queued, and the
+  // traceback of a chunk runs on the fourth stream next to the following chunk's DP.
   // Direction-flag regions rotate over `nreg_ws` slices of the workspace.
   const bool pipelined = ctx->pipeline && n >= 2048;
   size_t nch = 1;
   if (pipelined && n >= 32768) nch = std::min<size_t>(4, n / 16384);  // a traceback launch is ~2 ms of latency
   const size_t max_regions = nch > 1 ? 4 : 1;
   // Heavy tasks (>= 1 MB of direction flags: long sequences, one workgroup or wavefront busy for milliseconds)
-  // leave the chunk rotation: they are planned and launched FIRST, all together, on the caller's stream with a
-  // workspace slice of their own, and run next to the chunks of ordinary tasks instead of ending each chunk
+  // leave the chunk rotation: they are planned and launched FIRST, all together, with a workspace slice of
+  // their own, and run next to the chunks of ordinary tasks instead of ending each chunk
   // with a long tail.
-  const bool split_heavy = pipelined;
-  const size_t heavy_budget = split_heavy ? ctx->ws_budget / 2 : 0;
-  const size_t region_budget = (ctx->ws_budget - heavy_budget) / max_regions;
   const size_t first_target = nch > 1 ? std::max<size_t>(4096, n / (4 * nch + 1)) : n;
   const size_t chunk_target = nch > 1 ? (n - first_target + nch - 1) / nch : n;
   struct Chunk {
@@ -345,31 +344,41 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     bool heavy;
   };
   std::vector<Chunk> chunks, heavy_chunks;
-  std::vector<uint8_t> heavy(split_heavy ? n : 0, 0);
+  std::vector<size_t> bound(n, 0);  // upper bound of each task's direction flags, whichever kernel takes it
   int64_t stage_total = 0;
+  size_t n_heavy = 0;
+  for (size_t k = 0; k < n; ++k) {
+    const sdf_task &t = tasks[k];
+    if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
+      ctx->err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
+      return SDF_ERR_UNSUPPORTED;
+    }
+    if (t.qlen > 0 && t.tlen > 0 && !degenerate && want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
+      stage_total += (int64_t)t.qlen + t.tlen + 2;
+      const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+      const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
+      const size_t nrow = (size_t)t.qlen + t.tlen - 1;
+      const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
+      size_t bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
+      if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+      bound[k] = bd;
+      n_heavy += bd >= ((size_t)1 << 20);
+    }
+  }
+  // (a batch that is mostly long tasks is an ordinary batch of long tasks: nothing to take out of the rotation)
+  const bool split_heavy = pipelined && n_heavy * 4 <= n;
+  const size_t heavy_budget = split_heavy && n_heavy ? ctx->ws_budget / 4 : 0;
+  const size_t region_budget = (ctx->ws_budget - heavy_budget) / max_regions;
+  std::vector<uint8_t> heavy(split_heavy ? n : 0, 0);
   size_t region_need = 16, heavy_need = 0;
   {
     size_t s = 0, acc = 0, cnt = 0, hs = 0, hacc = 0;
     bool hany = false;
     for (size_t k = 0; k < n; ++k) {
-      const sdf_task &t = tasks[k];
-      if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
-        ctx->err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
-        return SDF_ERR_UNSUPPORTED;
-      }
-      size_t bound = 0;  // upper bound of the task's direction flags, whichever kernel takes it
-      if (t.qlen > 0 && t.tlen > 0 && !degenerate && want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
-        stage_total += (int64_t)t.qlen + t.tlen + 2;
-        const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
-        const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
-        const size_t nrow = (size_t)t.qlen + t.tlen - 1;
-        const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
-        bound = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
-        if (need <= 1024) bound = std::max(bound, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
-      }
-      if (split_heavy && bound >= ((size_t)1 << 20)) {
+      const size_t bd = bound[k];
+      if (split_heavy && bd >= ((size_t)1 << 20)) {
         heavy[k] = 1;
-        if (hany && hacc + bound > heavy_budget) {
+        if (hany && hacc + bd > heavy_budget) {
           heavy_chunks.push_back({hs, k, true});
           heavy_need = std::max(heavy_need, hacc);
           hs = k;
@@ -377,18 +386,18 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         }
         if (!hany) hs = k;
         hany = true;
-        hacc += bound;
+        hacc += bd;
         continue;
       }
       // the first chunk is a quarter of the others: the GPU starts after a quarter of the planning time
-      if (k > s && (acc + bound > region_budget || cnt >= (chunks.empty() && nch > 1 ? first_target : chunk_target))) {
+      if (k > s && (acc + bd > region_budget || cnt >= (chunks.empty() && nch > 1 ? first_target : chunk_target))) {
         chunks.push_back({s, k, false});
         region_need = std::max(region_need, acc);
         s = k;
         acc = 0;
         cnt = 0;
       }
-      acc += bound;
+      acc += bd;
       ++cnt;
     }
     chunks.push_back({s, n, false});
@@ -427,8 +436,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
                      (int)n);
   SDF_HIP(hipEventRecord(ev_begin, st));
   if (pipelined)
-    for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
-      SDF_HIP(hipStreamWaitEvent(s, ev_begin, 0));
+    for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream}) SDF_HIP(hipStreamWaitEvent(s, ev_begin, 0));
 
   struct Cls {
     int bs;  // 64 / 256: general kernel with that many threads; 1, 2, 4, 8: wave kernel with NREG; 100 + NREG: pair
@@ -439,7 +447,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     double est = 0;   // duration estimate of the launch: its longest task (cells / per-workgroup rate of the kernel)
   };
   struct ChunkEv {
-    hipEvent_t dp0, dp1, sm0, sm1, tb0, tb1;  // big DP launches, small DP launches, traceback (begin, end)
+    hipEvent_t dp0, dpe[4], tb0, tb1;  // plan uploaded; end of the DP launches per stream; traceback (begin, end)
   };
   std::vector<ChunkEv> cev(chunks.size());
   std::vector<int32_t> win_need, partner;
@@ -449,6 +457,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   size_t nord = 0;         // launch-order entries so far
   int64_t stage_words = 0;
   float plan_first_ms = 0.f;
+  double qload[4] = {0, 0, 0, 0};  // estimated DP work queued on each stream during this call
 
   std::vector<size_t> normal_ids;  // chunk indices of the ordinary chunks, in launch order
   for (size_t ci = 0; ci < chunks.size(); ++ci) {
@@ -505,7 +514,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     }
     const size_t cnt = np - pb;
     if (cnt == 0) {
-      cev[ci] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      cev[ci] = ChunkEv{};
       continue;
     }
     PlanTask *cp = plan + pb;  // chunk-relative indexing below
@@ -651,50 +660,36 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       plan_first_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
 
     // ---- upload and launch the chunk ----
-    // a heavy chunk runs entirely on the caller's stream, in order, with the workspace slice behind the regions
+    // Streams: Q[0] the caller's, Q[1], Q[2] the two DP streams, Q[3] traceback.  The big launches (>= 2048 tasks)
+    // of ordinary chunks alternate between the DP streams; every other launch (a class of a few tasks ends in a
+    // tail as long as its longest task) goes, longest first, to the stream with the least estimated work queued.
+    // A heavy chunk uploads and traces back on the caller's stream and uses the workspace slice behind the regions.
     const bool piped = pipelined && !heavy_chunk;
     const size_t nj = normal_ids.size();  // ordinal among the ordinary chunks
-    hipStream_t sbig = piped ? ctx->dp_stream[nj & 1] : st;
-    hipStream_t ssmall = piped ? ctx->small_stream : st;
-    hipStream_t stb = piped ? ctx->tb_stream : st;
+    hipStream_t Q[4] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
+                        pipelined ? ctx->tb_stream : st};
+    const int ui = piped ? 1 + (int)(nj & 1) : 0;  // upload stream (and the big launches')
+    hipStream_t stb = piped ? Q[3] : st;
     uint8_t *dir_reg = heavy_chunk ? d_dir + nreg_ws * region_need : d_dir + (nj % nreg_ws) * region_need;
-    bool any_small = false;
-    if (piped)
-      for (const Launch &L : launches) any_small |= launches.size() > 1 && L.cnt < 2048;
-    if (piped && nj >= nreg_ws && cev[normal_ids[nj - nreg_ws]].tb1) {  // the region's previous user is traced back
-      SDF_HIP(hipStreamWaitEvent(sbig, cev[normal_ids[nj - nreg_ws]].tb1, 0));
-      if (any_small) SDF_HIP(hipStreamWaitEvent(ssmall, cev[normal_ids[nj - nreg_ws]].tb1, 0));
-    }
+    hipEvent_t region_ev = nullptr;  // the region's previous user has been traced back
+    if (piped && nj >= nreg_ws) region_ev = cev[normal_ids[nj - nreg_ws]].tb1;
     if (!heavy_chunk) normal_ids.push_back(ci);
-    SDF_HIP(hipMemcpyAsync(d_plan + pb, cp, cnt * sizeof(PlanTask), hipMemcpyHostToDevice, sbig));
-    SDF_HIP(hipMemcpyAsync(d_order + ob, order + ob, (nord - ob) * sizeof(int32_t), hipMemcpyHostToDevice, sbig));
+    SDF_HIP(hipMemcpyAsync(d_plan + pb, cp, cnt * sizeof(PlanTask), hipMemcpyHostToDevice, Q[ui]));
+    SDF_HIP(hipMemcpyAsync(d_order + ob, order + ob, (nord - ob) * sizeof(int32_t), hipMemcpyHostToDevice, Q[ui]));
     ChunkEv &ev = cev[ci];
     ev.dp0 = next_event(ctx, evc);
-    ev.dp1 = next_event(ctx, evc);
-    ev.sm0 = ev.sm1 = nullptr;
+    for (auto &e : ev.dpe) e = nullptr;
     ev.tb0 = next_event(ctx, evc);
     ev.tb1 = next_event(ctx, evc);
-    SDF_HIP(hipEventRecord(ev.dp0, sbig));
-    if (any_small) {  // the plan has to be on the device before the small launches read it
-      ev.sm0 = next_event(ctx, evc);
-      ev.sm1 = next_event(ctx, evc);
-      SDF_HIP(hipStreamWaitEvent(ssmall, ev.dp0, 0));
-      SDF_HIP(hipEventRecord(ev.sm0, ssmall));
-    }
-    // a heavy chunk's launch classes (each ends in a tail as long as its longest task) run side by side
-    hipStream_t hstreams[4] = {st, ctx->dp_stream[0], ctx->dp_stream[1], ctx->small_stream};
-    std::vector<hipEvent_t> hev;
-    const bool spread = heavy_chunk && pipelined && launches.size() > 1;
-    if (spread)
-      for (int q = 1; q < 4; ++q) SDF_HIP(hipStreamWaitEvent(hstreams[q], ev.dp0, 0));  // plan uploaded
+    SDF_HIP(hipEventRecord(ev.dp0, Q[ui]));
+    bool used[4] = {false, false, false, false};
     size_t gs_off = 0;
-    double hload[4] = {0, 0, 0, 0};  // estimated work queued on each stream of a spread heavy chunk
     {  // HBM state slabs of the very long tasks of this chunk: one allocation, a slice per launch
       size_t gs_total = 0;
       for (const Launch &L : launches)
         if (L.bs >= 1000) gs_total += L.lds * L.cnt;
       if (gs_total > ctx->gstate_buf.cap) {  // growing frees the old slabs: nothing may be using them
-        for (hipStream_t q : {st, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->small_stream})
+        for (hipStream_t q : {st, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream})
           if (q) SDF_HIP(hipStreamSynchronize(q));
         if (ctx->gstate_buf.reserve(gs_total) != hipSuccess) {
           ctx->err = "cannot allocate the HBM state slabs for very long tasks";
@@ -704,11 +699,22 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       }
     }
     for (const Launch &L : launches) {
-      int hq = 0;  // longest first, each to the least loaded stream
-      for (int q = 1; q < 4; ++q)
-        if (hload[q] < hload[hq]) hq = q;
-      hload[hq] += L.est;
-      hipStream_t sdp = spread ? hstreams[hq] : (any_small && L.cnt < 2048) ? ssmall : sbig;
+      int qi = 0;
+      if (pipelined) {
+        if (piped && L.cnt >= 2048) {
+          qi = ui;
+        } else {
+          for (int q = 1; q < 4; ++q)
+            if (qload[q] < qload[qi]) qi = q;
+        }
+      }
+      qload[qi] += L.est;
+      hipStream_t sdp = Q[qi];
+      if (!used[qi]) {
+        used[qi] = true;
+        if (pipelined && qi != ui) SDF_HIP(hipStreamWaitEvent(sdp, ev.dp0, 0));  // plan uploaded
+        if (region_ev) SDF_HIP(hipStreamWaitEvent(sdp, region_ev, 0));
+      }
       const PlanTask *lp = d_plan + pb;
       const int32_t *lo = d_order + ob + L.off;
       if (L.bs == 1)
@@ -754,18 +760,11 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       }
       ++ctx->launches;
     }
-    if (spread) {  // the caller's stream collects the other three
-      for (int q = 1; q < 4 && (size_t)q < launches.size(); ++q) {
-        hipEvent_t e = next_event(ctx, evc);
-        SDF_HIP(hipEventRecord(e, hstreams[q]));
-        SDF_HIP(hipStreamWaitEvent(st, e, 0));
-      }
-    }
-    SDF_HIP(hipEventRecord(ev.dp1, sbig));
-    if (any_small) SDF_HIP(hipEventRecord(ev.sm1, ssmall));
-    if (piped) {
-      SDF_HIP(hipStreamWaitEvent(stb, ev.dp1, 0));
-      if (any_small) SDF_HIP(hipStreamWaitEvent(stb, ev.sm1, 0));
+    for (int q = 0; q < 4; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
+      if (!used[q]) continue;
+      ev.dpe[q] = next_event(ctx, evc);
+      SDF_HIP(hipEventRecord(ev.dpe[q], Q[q]));
+      if (pipelined && Q[q] != stb) SDF_HIP(hipStreamWaitEvent(stb, ev.dpe[q], 0));
     }
     SDF_HIP(hipEventRecord(ev.tb0, stb));
     if (want_cigar) {
@@ -831,8 +830,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         if (tb) {
           add(ev.tb0, ev.tb1);
         } else {
-          add(ev.dp0, ev.dp1);
-          if (ev.sm0) add(ev.sm0, ev.sm1);
+          for (hipEvent_t e : ev.dpe)
+            if (e) add(ev.dp0, e);
         }
       }
       std::sort(iv.begin(), iv.end());
