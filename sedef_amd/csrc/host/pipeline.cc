@@ -510,6 +510,14 @@ static void parallel_for(int n, const std::function<void(int)> &body) {
   static int nthreads = [] {
     const char *e = getenv("SDF_HOST_THREADS");
     int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (!e) {  // a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") counts, not the host's core count
+      if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+          t = std::min<long long>(t, std::max<long long>(1, (quota + period - 1) / period));
+        fclose(f);
+      }
+    }
     return t < 1 ? 1 : (t > 64 ? 64 : t);
   }();
   const int nt = std::min(nthreads, n);
@@ -575,8 +583,19 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     std::unique_ptr<PairJob> job;
     std::vector<DpRequest> pending;
   };
-  for (int base = 0; base < total; base += super_batch) {
-    const int n = std::min(super_batch, total - base);
+  // Pairs per super-batch: every round of a super-batch is one device batch call (planning, launches, one
+  // synchronisation), so few large super-batches beat many small ones; bounded by the sequence bytes held at once.
+  if (const char *sb = getenv("SDF_SUPER_BATCH")) super_batch = std::max(1, atoi(sb));
+  for (int base = 0, n = 0; base < total; base += n) {
+    {
+      int64_t bytes = 0;
+      n = 0;
+      while (base + n < total && n < super_batch && bytes < ((int64_t)1 << 30)) {
+        const Hit &h = schedule[base + n];
+        bytes += (int64_t)(h.query_end - h.query_start) + (h.ref_end - h.ref_start);
+        ++n;
+      }
+    }
     std::vector<Item> items(n);
     for (int k = 0; k < n; k++) {  // src/align_main.cc:299-306
       Item &it = items[k];

@@ -239,6 +239,6 @@ struct GenerateStats {
 };
 // Reads the bucket BED, aligns every candidate pair, writes the BEDPE lines to `out` in the reference's order.
 GenerateStats generate_alignments(const std::string &ref_path, const std::string &bed_path, int kmer_size,
-                                  const Params &p, DpProvider &dp, FILE *out, FILE *log, int super_batch = 256);
+                                  const Params &p, DpProvider &dp, FILE *out, FILE *log, int super_batch = 8192);
 
 }  // namespace sdfh
