@@ -213,7 +213,8 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
 extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (hipStream_t q : {ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream})
+    if (q) (void)hipStreamSynchronize(q);
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
   for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
                     &ctx->an_pos, &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff})
