@@ -71,7 +71,11 @@ __device__ __forceinline__ uint32_t packed_code(const uint32_t *codes, const uin
 
 // GLOBAL: the arena and H[] of tasks too long for LDS (> ~14k) live in an HBM scratch slab per workgroup;
 // same code, same barriers (they order the workgroup's global accesses as well).
-template <int BS, bool GLOBAL>
+// PLAIN: only CIGAR / score / mte are wanted, zdrop < 0, left-aligned gaps (what SEDEF asks for): the recurrence
+// runs on the packed 16-bit ALU, two cells per instruction as in extz2_wave.hip, and the exact H is followed along
+// the band's upper edge only (thread 0, O(1) per row) instead of being updated for every cell of every row.  The
+// memory layout, the order of the LDS accesses and every artefact of the reference stay as in the full version.
+template <int BS, bool GLOBAL, bool PLAIN>
 __global__ __launch_bounds__(BS) void extz2_general_kernel(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
     const uint32_t *__restrict__ pool, ScoreK sc, uint8_t *__restrict__ dirbase,
@@ -90,7 +94,8 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
   int *stop_flag = reinterpret_cast<int *>(red + 16);  // one slot per wavefront of the largest workgroup (1024)
 
   for (int k = tid * 4; k < arena; k += BS * 4) *reinterpret_cast<uint32_t *>(lds + k) = 0u;
-  for (int k = tid; k < T16; k += BS) H[k] = SDF_NEG_INF;
+  if (!PLAIN)
+    for (int k = tid; k < T16; k += BS) H[k] = SDF_NEG_INF;
   if (tid == 0) *stop_flag = 0;
   __syncthreads();
   {
@@ -115,6 +120,13 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
   int32_t ez_score = SDF_NEG_INF, ez_zdropped = 0;
   BestCell best = {0, -1, 0, -1};  // running arg-max over all cells (zdrop < 0 mode)
   int prev_lo = -1, prev_hi = -1;
+  int32_t h_top = 0, h_under = 0;  // PLAIN: H of the top cell / of the cell the next top cell reads (thread 0)
+  // PLAIN: constants of the << 8 difference domain
+  const unsigned qv2 = ((unsigned)sc.q_b << 8) * 0x00010001u;
+  const unsigned capv2 = ((unsigned)sc.cap_b << 8) * 0x00010001u;
+  const unsigned qe2v = ((unsigned)sc.qe2_b << 8) * 0x00010001u;
+  unsigned one2 = 0x00010001u;
+  SDF_OPQ(one2);
 
   for (int r = 0; r < nrow; ++r) {
     Band b;
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
     }
     int32_t h_diag_prev = 0;
     if (tid == 0) {
-      h_diag_prev = b.hi0 > 0 ? H[b.hi0 - 1] : H[b.hi0];
+      if (!PLAIN) h_diag_prev = b.hi0 > 0 ? H[b.hi0 - 1] : H[b.hi0];
       if (b.hi >= r) {
         Y[r] = 0;
         U[r] = r ? sc.q_b : 0;
@@ -178,7 +190,50 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
         }
       }
       __syncthreads();
-      if (act) {
+      if (PLAIN && act) {
+        // bytes -> value << 8 in 16-bit halves: cells (0,1) and (2,3) of the thread
+        const uint32_t smx = (t == b.lo && cx < 0) ? 0xff00u : 0u, smv = (t == b.lo && cv < 0) ? 0xff00u : 0u;
+        uint32_t un[2], vn[2], xn[2], yn[2], dd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t sel = h ? 0x030c020cu : 0x010c000cu;
+          const uint32_t uo = __builtin_amdgcn_perm(0u, u4, sel), yo = __builtin_amdgcn_perm(0u, y4, sel);
+          const uint32_t so = __builtin_amdgcn_perm(0u, s4, sel);
+          // (r-1, t-1) neighbours: (carry, cell 0) for the low pair, (cell 1, cell 2) for the high pair; a negative
+          // carry byte is sign-extended over cells 1..3 of the first block (reference :145-146)
+          uint32_t xt1 = h ? __builtin_amdgcn_perm(0u, x4, 0x020c010cu) : __builtin_amdgcn_perm(x4, xl, 0x040c000cu);
+          uint32_t vt1 = h ? __builtin_amdgcn_perm(0u, v4, 0x020c010cu) : __builtin_amdgcn_perm(v4, vl, 0x040c000cu);
+          xt1 |= h ? smx * 0x00010001u : smx << 16;
+          vt1 |= h ? smv * 0x00010001u : smv << 16;
+          const uint32_t z0 = pk_add(so, qe2v);
+          const uint32_t a_ = pk_add(xt1, vt1), bb_ = pk_add(yo, uo);
+          const uint32_t z1 = pk_maxi(z0, a_);
+          const uint32_t fa_ = pk_sub(z1, z0);  // != 0 <=> a > z (signed)
+          const uint32_t zb_ = pk_maxi(z1, bb_);
+          const uint32_t fb_ = pk_sub(zb_, z1);  // != 0 <=> b > max(z, a)
+          const uint32_t z3 = pk_minu(pk_maxu(z1, bb_), capv2);
+          un[h] = pk_sub(z3, vt1);
+          vn[h] = pk_sub(z3, uo);
+          const uint32_t zq = pk_sub(z3, qv2);
+          xn[h] = pk_maxi(pk_sub(a_, zq), 0u);
+          yn[h] = pk_maxi(pk_sub(bb_, zq), 0u);
+          // direction byte: 2 if b won, else 1 if a won; | 0x08 if x > 0; | 0x10 if y > 0
+          const uint32_t fa1 = pk_nonzero(fa_), fb1 = pk_nonzero(fb_);
+          uint32_t d = pk_maxu(fa1, pk_add(fb1, fb1));
+          d = pk_mad(pk_nonzero(xn[h]), 0x00080008u, d);
+          d = pk_mad(pk_nonzero(yn[h]), 0x00100010u, d);
+          dd[h] = d;
+        }
+        // value << 8 halves -> bytes (bytes 1, 3 of each register); direction bytes are bytes 0, 2
+        *reinterpret_cast<uint32_t *>(U + t) = __builtin_amdgcn_perm(un[1], un[0], 0x07050301u);
+        *reinterpret_cast<uint32_t *>(V + t) = __builtin_amdgcn_perm(vn[1], vn[0], 0x07050301u);
+        *reinterpret_cast<uint32_t *>(X + t) = __builtin_amdgcn_perm(xn[1], xn[0], 0x07050301u);
+        *reinterpret_cast<uint32_t *>(Y + t) = __builtin_amdgcn_perm(yn[1], yn[0], 0x07050301u);
+        if (with_dir)
+          *reinterpret_cast<uint32_t *>(dir + (int64_t)r * stride + (t - b.lo)) =
+              __builtin_amdgcn_perm(dd[1], dd[0], 0x06040200u);
+      }
+      if (!PLAIN && act) {
         // a negative carry byte is sign-extended over lanes 1..3 of the first block
         const uint32_t smx = (t == b.lo && cx < 0) ? 0xffu : 0u;
         const uint32_t smv = (t == b.lo && cv < 0) ? 0xffu : 0u;
@@ -245,7 +300,30 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
 
     // ---- exact H[] and the row arg-max (reference :222-258) ----
     BestCell rowbest = {SDF_NEG_INF, r, 0x7fffffff, -1};
-    if (r > 0) {
+    if (PLAIN) {
+      // exact H of the top cell and of the cell under the band edge only (see slow_row in extz2_wave.hip)
+      if (tid == 0) {
+        int hin = (r + 1 + w) >> 1;  // next row's top cell: does it move up?
+        hin = hin > r + 1 ? r + 1 : hin;
+        hin = hin > tlen - 1 ? tlen - 1 : hin;
+        const bool up = hin == b.hi0 + 1 || hin == 0;
+        const bool want_top = up || b.hi0 == tlen - 1 || b.hi0 == 0;
+        if (want_top) {
+          const int32_t uh = b.hi0 > 0 ? (int32_t)U[b.hi0] : (int32_t)V[b.hi0];
+          if (r == 0) h_top = uh - 2 * sc.qe;
+          else h_top = (b.hi0 > 0 ? h_under : h_top) + uh - sc.qe;
+        }
+        if (up || r == 0) h_under = h_top;
+        else if (b.hi0 - 1 >= b.lo0) h_under += (int32_t)V[b.hi0 - 1] - sc.qe;
+        if (b.hi0 == tlen - 1) {
+          if (h_top > ez_mte) {
+            ez_mte = h_top;
+            ez_mte_q = r - b.hi;
+          }
+          if (r == nrow - 1) ez_score = h_top;
+        }
+      }
+    } else if (r > 0) {
       const int vec_end = b.lo0 + (b.hi0 - b.lo0) / 4 * 4;
       for (int t = b.lo0 + tid; t < b.hi0; t += BS) {
         const int32_t h = H[t] + (int32_t)V[t] - sc.qe;
@@ -271,7 +349,7 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
 
     // ---- ksw_extz_t bookkeeping (reference :259-267) ----
     if (zd_mode) rowbest = block_best<BS>(rowbest, red);
-    if (tid == 0) {
+    if (!PLAIN && tid == 0) {
       if (b.hi0 == tlen - 1 && H[b.hi0] > ez_mte) {
         ez_mte = H[b.hi0];
         ez_mte_q = r - b.hi;
@@ -307,7 +385,7 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
     prev_hi = b.hi;
   }
 
-  if (!zd_mode) {
+  if (!PLAIN && !zd_mode) {
     best = block_best<BS>(best, red);
     if (tid == 0 && best.r >= 0) {
       ez_max = best.H;
@@ -333,16 +411,22 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
   }
 }
 
-template __global__ void extz2_general_kernel<64, false>(const PlanTask *, const int32_t *, const uint32_t *,
-                                                         ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
-template __global__ void extz2_general_kernel<256, false>(const PlanTask *, const int32_t *, const uint32_t *,
-                                                          ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
-template __global__ void extz2_general_kernel<1024, false>(const PlanTask *, const int32_t *, const uint32_t *,
-                                                          ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
-template __global__ void extz2_general_kernel<1024, true>(const PlanTask *, const int32_t *, const uint32_t *,
-                                                         ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
-template __global__ void extz2_general_kernel<256, true>(const PlanTask *, const int32_t *, const uint32_t *,
-                                                         ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<64, false, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<256, false, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<1024, false, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<1024, true, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<256, true, false>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<1024, false, true>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<1024, true, true>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
+template __global__ void extz2_general_kernel<256, false, true>(const PlanTask *, const int32_t *, const uint32_t *,
+                                                                ScoreK, uint8_t *, sdf_result *, uint8_t *, size_t);
 
 size_t general_lds_bytes(int qlen, int tlen) {
   const size_t T16 = (size_t)(tlen + 15) / 16 * 16, Q16 = (size_t)(qlen + 15) / 16 * 16;

@@ -37,51 +37,6 @@
 
 namespace sdf {
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef short i16x2 __attribute__((ext_vector_type(2)));
-
-#define SDF_OPQ(x) asm("" : "+v"(x))  // make a value opaque to instcombine (keeps the packed forms)
-
-__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) {
-  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
-}
-__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) {
-  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
-}
-__device__ __forceinline__ unsigned pk_maxi(unsigned a, unsigned b) {
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a),
-                                                                __builtin_bit_cast(i16x2, b)));
-}
-__device__ __forceinline__ unsigned pk_maxu(unsigned a, unsigned b) {
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
-                                                                __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) {
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a),
-                                                                __builtin_bit_cast(u16x2, b)));
-}
-// min(x, 1) per half = "x != 0" as 0/1.  Written as the instruction itself: the optimiser would
-// otherwise turn it into per-half compares + selects.
-__device__ __forceinline__ unsigned pk_nonzero_(unsigned a, unsigned one_opaque) {
-  return pk_minu(a, one_opaque);
-}
-#define pk_nonzero(a) pk_nonzero_((a), one2)
-// F <- (F << 1) | bit, as the single instruction it is
-__device__ __forceinline__ unsigned shl1_or(unsigned f, unsigned bit) {
-  return (f << 1) + bit;  // bit 0 of f << 1 is clear: + == |, and it selects as one v_lshl_add_u32
-}
-__device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
-  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) +
-                                          __builtin_bit_cast(u16x2, c));
-}
-__device__ __forceinline__ unsigned pk_ashr15(unsigned a) {
-  return __builtin_bit_cast(unsigned, __builtin_bit_cast(i16x2, a) >> (i16x2){15, 15});
-}
-__device__ __forceinline__ unsigned pk_shl(unsigned a, unsigned n) {
-  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a)
-                                          << (u16x2){(unsigned short)n, (unsigned short)n});
-}
-
 // lane mask with bits [lo, hi) set (0 <= lo, hi; clamped to 64)
 __device__ __forceinline__ unsigned long long lane_range(int lo, int hi) {
   lo = lo < 0 ? 0 : lo;

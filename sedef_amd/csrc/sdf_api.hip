@@ -15,7 +15,7 @@
 #include "sdf_internal.h"
 
 namespace sdf {
-template <int BS, bool GLOBAL>
+template <int BS, bool GLOBAL, bool PLAIN>
 __global__ void extz2_general_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                      sdf_result *, uint8_t *, size_t);
 size_t general_lds_bytes(int qlen, int tlen);
@@ -171,11 +171,15 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->ws_budget = budget;
   // allow the general kernel its full 160 KiB of LDS
   const int want_lds = 160 * 1024;
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<64, false>),
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<64, false, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256, false>),
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256, false, false>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<1024, false>),
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<1024, false, false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<1024, false, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256, false, true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess)
     ctx->max_dyn_lds = want_lds;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<1>),
@@ -487,12 +491,14 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       // register-resident wave kernel when only CIGAR/score/mte are wanted and the shape fits
       p.nreg = 0;
       int wneed = 0;
+      bool plain_ok = false;
       {
         const int nrow = t.qlen + t.tlen - 1;
         Band bl;
         const bool band_whole = (p.w >= 1 || nrow == 1) && band_of(nrow - 1, t.qlen, t.tlen, p.w, bl);
         const bool plain = !(want & SDF_WANT_EXT) && t.zdrop < 0 &&
                            !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY)) && sc->gapo >= 0 && band_whole;
+        plain_ok = plain && !ctx->force_general;
         if (plain && !ctx->force_general) {
           // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
           // beyond the target's last 16-cell block (cells past it are not part of any window)
@@ -509,8 +515,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
       p.cig_slot = stage_words;
       stage_words += p.cig_cap;
-      if (!p.nreg && general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds)
-        p.pad_ = 1;  // state in an HBM scratch slab instead of LDS
+      if (!p.nreg) {
+        // general kernel: state in LDS, or in an HBM scratch slab when it does not fit; the PLAIN flavour (packed
+        // recurrence, H along the band edge only) when nothing but CIGAR / score / mte is wanted and the window
+        // is wide enough for the 256- or 1024-thread instantiation
+        const bool hbm = general_lds_bytes(t.qlen, t.tlen) > (size_t)ctx->max_dyn_lds;
+        const int width = std::min(p.ncol16, (t.tlen + 15) / 16 * 16);
+        if (plain_ok && !hbm && width > 256) p.pad_ = 3;
+        else if (plain_ok && hbm && width > 1024) p.pad_ = 4;
+        else p.pad_ = hbm ? 1 : 0;
+      }
       plan[np++] = p;
     }
     const size_t cnt = np - pb;
@@ -620,15 +634,17 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           need = wave_lds_bytes(p.qlen, p.tlen, p.nreg);
           lds = 6144;
           while (lds < need) lds *= 2;
-        } else if (p.pad_) {  // HBM-resident state: one class, slab = largest requirement
-          bs = width > 1024 ? 1001 : 1000;
+        } else if (p.pad_ == 1 || p.pad_ == 4) {  // HBM-resident state: one class, slab = largest requirement
+          bs = p.pad_ == 4 ? 2001 : width > 1024 ? 1001 : 1000;
           need = general_lds_bytes(p.qlen, p.tlen);
           lds = (size_t)1 << 40;
         } else {
+          if (p.pad_ == 3) bs += 2000;  // PLAIN flavour: 2256 / 3024
           need = general_lds_bytes(p.qlen, p.tlen);
           while (lds < need) lds *= 2;
         }
-        if (bs < 1000 && lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
+        const bool hbm_cls = bs == 1000 || bs == 1001 || bs == 2001;
+        if (!hbm_cls && lds > (size_t)ctx->max_dyn_lds) lds = ctx->max_dyn_lds;
         Cls *c = nullptr;
         for (auto &x : cls)
           if (x.bs == bs && x.lds == lds) c = &x;
@@ -638,7 +654,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         }
         c->need_max = std::max(c->need_max, need);
         {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
-          const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 100 ? 0.25 : 0.13;
+          const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.3 : bs == 2256 ? 0.2 : bs == 3024 ? 0.6
+                              : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 100 ? 0.25 : 0.13;
           c->est = std::max(c->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
         }
         c->idx.push_back((int32_t)k);
@@ -649,7 +666,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       size_t cursor = 0;
       for (auto &c : cls) {
         launches.push_back({c.bs,
-                            c.bs >= 1000 ? ((c.need_max + 255) & ~(size_t)255)
+                            (c.bs == 1000 || c.bs == 1001 || c.bs == 2001) ? ((c.need_max + 255) & ~(size_t)255)
                                          : std::min(c.lds, (c.need_max + 511) & ~(size_t)511),
                             cursor, c.idx.size(), c.est});
         std::copy(c.idx.begin(), c.idx.end(), order + ob + cursor);
@@ -688,7 +705,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     {  // HBM state slabs of the very long tasks of this chunk: one allocation, a slice per launch
       size_t gs_total = 0;
       for (const Launch &L : launches)
-        if (L.bs >= 1000) gs_total += L.lds * L.cnt;
+        if (L.bs == 1000 || L.bs == 1001 || L.bs == 2001) gs_total += L.lds * L.cnt;
       if (gs_total > ctx->gstate_buf.cap) {  // growing frees the old slabs: nothing may be using them
         for (hipStream_t q : {st, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream})
           if (q) SDF_HIP(hipStreamSynchronize(q));
@@ -741,22 +758,31 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       SDF_PAIR_LAUNCH(8)
 #undef SDF_PAIR_LAUNCH
       else if (L.bs == 64)
-        hipLaunchKernelGGL((extz2_general_kernel<64, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo,
+        hipLaunchKernelGGL((extz2_general_kernel<64, false, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo,
                            d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
       else if (L.bs == 256)
-        hipLaunchKernelGGL((extz2_general_kernel<256, false>), dim3((unsigned)L.cnt), dim3(256), L.lds, sdp, lp, lo,
+        hipLaunchKernelGGL((extz2_general_kernel<256, false, false>), dim3((unsigned)L.cnt), dim3(256), L.lds, sdp, lp, lo,
                            d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
       else if (L.bs == 1024)
-        hipLaunchKernelGGL((extz2_general_kernel<1024, false>), dim3((unsigned)L.cnt), dim3(1024), L.lds, sdp, lp, lo,
+        hipLaunchKernelGGL((extz2_general_kernel<1024, false, false>), dim3((unsigned)L.cnt), dim3(1024), L.lds, sdp, lp, lo,
+                           d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
+      else if (L.bs == 2256)
+        hipLaunchKernelGGL((extz2_general_kernel<256, false, true>), dim3((unsigned)L.cnt), dim3(256), L.lds, sdp, lp, lo,
+                           d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
+      else if (L.bs == 3024)
+        hipLaunchKernelGGL((extz2_general_kernel<1024, false, true>), dim3((unsigned)L.cnt), dim3(1024), L.lds, sdp, lp, lo,
                            d_pool, sk, dir_reg, d_out, (uint8_t *)nullptr, (size_t)0);
       else {  // L.lds = per-workgroup slab bytes in HBM; the chunk's slabs were reserved above
         uint8_t *slabs = (uint8_t *)ctx->gstate_buf.p + gs_off;
         gs_off += L.lds * L.cnt;
-        if (L.bs == 1001)
-          hipLaunchKernelGGL((extz2_general_kernel<1024, true>), dim3((unsigned)L.cnt), dim3(1024), 512, sdp, lp, lo,
+        if (L.bs == 2001)
+          hipLaunchKernelGGL((extz2_general_kernel<1024, true, true>), dim3((unsigned)L.cnt), dim3(1024), 512, sdp, lp, lo,
+                             d_pool, sk, dir_reg, d_out, slabs, L.lds);
+        else if (L.bs == 1001)
+          hipLaunchKernelGGL((extz2_general_kernel<1024, true, false>), dim3((unsigned)L.cnt), dim3(1024), 512, sdp, lp, lo,
                              d_pool, sk, dir_reg, d_out, slabs, L.lds);
         else
-          hipLaunchKernelGGL((extz2_general_kernel<256, true>), dim3((unsigned)L.cnt), dim3(256), 512, sdp, lp, lo,
+          hipLaunchKernelGGL((extz2_general_kernel<256, true, false>), dim3((unsigned)L.cnt), dim3(256), 512, sdp, lp, lo,
                              d_pool, sk, dir_reg, d_out, slabs, L.lds);
       }
       ++ctx->launches;

@@ -35,7 +35,8 @@ struct PlanTask {
   int32_t nreg;      // 0: general kernel, byte-per-cell direction rows; >0: wave kernel with nreg
                      // packed registers, direction flags in 16-row x 128-slot bit blocks
   int32_t pad_;      // 1: general kernel with its state in an HBM slab; 2: pair kernel (extz2_pair.hip): nreg counts
-                     // 64-slot registers and the flags are per-task uint2 records
+                     // 64-slot registers and the flags are per-task uint2 records; 3 / 4: general kernel, PLAIN
+                     // flavour (packed recurrence, H along the band edge only), state in LDS / in an HBM slab
 };
 
 // Per-anti-diagonal band geometry (reference: extern/ksw2_extz2_sse.cc:101-115).
@@ -56,5 +57,55 @@ __host__ __device__ inline bool band_of(int r, int qlen, int tlen, int w, Band &
   b.hi = (hi + 16) / 16 * 16 - 1;
   return lo <= hi;
 }
+
+#ifdef __HIPCC__
+// ---- packed 16-bit helpers of the DP kernels: every state byte of the reference is held as value << 8 in a
+// 16-bit half, so the packed ALU reproduces the reference's wrap-around int8 arithmetic two cells at a time ----
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+#define SDF_OPQ(x) asm("" : "+v"(x))  // make a value opaque to instcombine (keeps the packed forms)
+
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ unsigned pk_maxi(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a),
+                                                                __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_maxu(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
+                                                                __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a),
+                                                                __builtin_bit_cast(u16x2, b)));
+}
+// min(x, 1) per half = "x != 0" as 0/1.  Written as the instruction itself: the optimiser would
+// otherwise turn it into per-half compares + selects.
+__device__ __forceinline__ unsigned pk_nonzero_(unsigned a, unsigned one_opaque) {
+  return pk_minu(a, one_opaque);
+}
+#define pk_nonzero(a) pk_nonzero_((a), one2)
+// F <- (F << 1) | bit, as the single instruction it is
+__device__ __forceinline__ unsigned shl1_or(unsigned f, unsigned bit) {
+  return (f << 1) + bit;  // bit 0 of f << 1 is clear: + == |, and it selects as one v_lshl_add_u32
+}
+__device__ __forceinline__ unsigned pk_mad(unsigned a, unsigned b, unsigned c) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) +
+                                          __builtin_bit_cast(u16x2, c));
+}
+__device__ __forceinline__ unsigned pk_ashr15(unsigned a) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(i16x2, a) >> (i16x2){15, 15});
+}
+__device__ __forceinline__ unsigned pk_shl(unsigned a, unsigned n) {
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(u16x2, a)
+                                          << (u16x2){(unsigned short)n, (unsigned short)n});
+}
+
+#endif  // __HIPCC__
 
 }  // namespace sdf

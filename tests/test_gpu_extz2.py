@@ -498,3 +498,31 @@ def test_config5_mm8_mixed_bands(engine, oracle):
     import bench
     batch, w = bench.synth_mm8_mixture(240, seed=505, max_len=20000)
     _batch_vs_cpu(engine, oracle, batch, w)
+
+
+def test_plain_general_kernel_wide_windows(engine, oracle):
+    """Windows beyond 1024 cells with only CIGAR / score / mte wanted: the PLAIN flavour of the general kernel
+    (packed recurrence, H along the band edge) in its 256- and 1024-thread, LDS and HBM-state instantiations,
+    against the oracle; full band and wide bands, N runs, big indels, unrelated sequences."""
+    rng = np.random.default_rng(9090)
+    pairs, ws = [], []
+    for ql, tl, w in [(1100, 1100, -1), (1500, 1300, -1), (2100, 2300, -1), (3000, 3000, -1), (1025, 4000, -1),
+                      (4000, 1040, -1), (2500, 2500, 700), (3000, 2800, 1100), (6000, 5800, 1500), (5000, 5000, -1),
+                      (1200, 1200, 600), (2000, 2100, 520)]:
+        for kind in range(2):
+            q = random_codes(rng, ql, 0.005 if kind else 0.0)
+            if kind and ql > 2000:
+                t = random_codes(rng, tl)  # unrelated
+            else:
+                t = mutate(rng, q, 0.06, 0.02, 0.02)
+                k = int(rng.integers(0, len(t)))
+                t = np.concatenate([t[:k], random_codes(rng, int(rng.integers(1, 300))), t[k:]])
+                t = _fit(rng, t, tl)
+            pairs.append((q, t))
+            ws.append(w)
+    _check_fast(engine, oracle, pairs, ws)
+    # HBM-state instantiation (> ~14k bases)
+    q = random_codes(rng, 15500, 0.001)
+    t = mutate(rng, q, 0.04, 0.01, 0.01)
+    t = np.concatenate([t[:6000], random_codes(rng, 700), t[6000:]])
+    _check_fast(engine, oracle, [(q, t), (q[:15000], t[:15100])], [-1, 1400])
