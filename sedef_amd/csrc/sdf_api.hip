@@ -351,7 +351,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   std::vector<Chunk> chunks, heavy_chunks;
   std::vector<size_t> bound(n, 0);  // upper bound of each task's direction flags, whichever kernel takes it
   int64_t stage_total = 0;
-  size_t n_heavy = 0;
+  size_t n_heavy = 0, heavy_bytes = 0;
   for (size_t k = 0; k < n; ++k) {
     const sdf_task &t = tasks[k];
     if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
@@ -367,12 +367,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       size_t bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
       if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
       bound[k] = bd;
-      n_heavy += bd >= ((size_t)1 << 20);
+      if (bd >= ((size_t)1 << 20)) {
+        ++n_heavy;
+        heavy_bytes += bd;
+      }
     }
   }
   // (a batch that is mostly long tasks is an ordinary batch of long tasks: nothing to take out of the rotation)
   const bool split_heavy = pipelined && n_heavy * 4 <= n;
-  const size_t heavy_budget = split_heavy && n_heavy ? ctx->ws_budget / 4 : 0;
+  // the heavy slice: what the heavy tasks need, up to half of the workspace
+  const size_t heavy_budget = split_heavy && n_heavy ? std::min(heavy_bytes + 256, ctx->ws_budget / 2) : 0;
   const size_t region_budget = (ctx->ws_budget - heavy_budget) / max_regions;
   std::vector<uint8_t> heavy(split_heavy ? n : 0, 0);
   size_t region_need = 16, heavy_need = 0;
@@ -465,6 +469,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   double qload[4] = {0, 0, 0, 0};  // estimated DP work queued on each stream during this call
 
   std::vector<size_t> normal_ids;  // chunk indices of the ordinary chunks, in launch order
+  const bool have_heavy = !chunks.empty() && chunks[0].heavy;
   for (size_t ci = 0; ci < chunks.size(); ++ci) {
     const size_t pb = np;    // first PlanTask of this chunk
     const size_t ob = nord;  // first launch-order entry of this chunk
@@ -686,7 +691,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     const size_t nj = normal_ids.size();  // ordinal among the ordinary chunks
     hipStream_t Q[4] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
                         pipelined ? ctx->tb_stream : st};
-    const int ui = piped ? 1 + (int)(nj & 1) : 0;  // upload stream (and the big launches')
+    const int ui = piped ? (have_heavy ? 2 : 1 + (int)(nj & 1)) : 0;  // upload stream (and the big launches')
     hipStream_t stb = piped ? Q[3] : st;
     uint8_t *dir_reg = heavy_chunk ? d_dir + nreg_ws * region_need : d_dir + (nj % nreg_ws) * region_need;
     hipEvent_t region_ev = nullptr;  // the region's previous user has been traced back
@@ -717,10 +722,15 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       }
     }
     for (const Launch &L : launches) {
+      // with heavy tasks in the batch the streams are divided: Q[0], Q[1] for the heavy launches (tens of
+      // milliseconds each), Q[2] (DP) and Q[3] (small launches, traceback) for the ordinary chunks, which would
+      // otherwise queue behind them
       int qi = 0;
       if (pipelined) {
         if (piped && L.cnt >= 2048) {
           qi = ui;
+        } else if (have_heavy) {
+          qi = heavy_chunk ? (qload[1] < qload[0] ? 1 : 0) : (qload[3] < qload[2] ? 3 : 2);
         } else {
           for (int q = 1; q < 4; ++q)
             if (qload[q] < qload[qi]) qi = q;
