@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -352,25 +354,51 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   std::vector<size_t> bound(n, 0);  // upper bound of each task's direction flags, whichever kernel takes it
   int64_t stage_total = 0;
   size_t n_heavy = 0, heavy_bytes = 0;
-  for (size_t k = 0; k < n; ++k) {
-    const sdf_task &t = tasks[k];
-    if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
-      ctx->err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
-      return SDF_ERR_UNSUPPORTED;
-    }
-    if (t.qlen > 0 && t.tlen > 0 && !degenerate && want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
-      stage_total += (int64_t)t.qlen + t.tlen + 2;
-      const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
-      const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
-      const size_t nrow = (size_t)t.qlen + t.tlen - 1;
-      const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
-      size_t bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
-      if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
-      bound[k] = bd;
-      if (bd >= ((size_t)1 << 20)) {
-        ++n_heavy;
-        heavy_bytes += bd;
+  {
+    // (four host threads for batches of hundreds of thousands of tasks: this pass is all the planning the GPU
+    // waits for besides the first chunk)
+    struct Part {
+      int64_t stage = 0;
+      size_t nh = 0, hb = 0;
+      bool bad = false;
+    };
+    auto scan = [&](size_t lo, size_t hi, Part &pt) {
+      for (size_t k = lo; k < hi; ++k) {
+        const sdf_task &t = tasks[k];
+        if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
+          pt.bad = true;
+          return;
+        }
+        if (t.qlen > 0 && t.tlen > 0 && !degenerate && want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
+          pt.stage += (int64_t)t.qlen + t.tlen + 2;
+          const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+          const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
+          const size_t nrow = (size_t)t.qlen + t.tlen - 1;
+          const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
+          size_t bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
+          if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+          bound[k] = bd;
+          if (bd >= ((size_t)1 << 20)) {
+            ++pt.nh;
+            pt.hb += bd;
+          }
+        }
       }
+    };
+    const int nthr = n >= 200000 ? 4 : 1;
+    Part parts[4];
+    std::vector<std::thread> thr;
+    for (int q = 1; q < nthr; ++q) thr.emplace_back(scan, n * q / nthr, n * (q + 1) / nthr, std::ref(parts[q]));
+    scan(0, n / nthr, parts[0]);
+    for (auto &th : thr) th.join();
+    for (int q = 0; q < nthr; ++q) {
+      if (parts[q].bad) {
+        ctx->err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
+        return SDF_ERR_UNSUPPORTED;
+      }
+      stage_total += parts[q].stage;
+      n_heavy += parts[q].nh;
+      heavy_bytes += parts[q].hb;
     }
   }
   // (a batch that is mostly long tasks is an ordinary batch of long tasks: nothing to take out of the rotation)
