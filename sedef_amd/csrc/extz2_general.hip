@@ -71,10 +71,11 @@ __device__ __forceinline__ uint32_t packed_code(const uint32_t *codes, const uin
 
 // GLOBAL: the arena and H[] of tasks too long for LDS (> ~14k) live in an HBM scratch slab per workgroup;
 // same code, same barriers (they order the workgroup's global accesses as well).
-// PLAIN: only CIGAR / score / mte are wanted, zdrop < 0, left-aligned gaps (what SEDEF asks for): the recurrence
-// runs on the packed 16-bit ALU, two cells per instruction as in extz2_wave.hip, and the exact H is followed along
-// the band's upper edge only (thread 0, O(1) per row) instead of being updated for every cell of every row.  The
-// memory layout, the order of the LDS accesses and every artefact of the reference stay as in the full version.
+// The recurrence of tasks with left-aligned gaps runs on the packed 16-bit ALU, two cells per instruction as in
+// extz2_wave.hip.  PLAIN: only CIGAR / score / mte are wanted, zdrop < 0, left-aligned gaps (what SEDEF asks for):
+// the exact H is followed along the band's upper edge only (thread 0, O(1) per row) instead of being updated for
+// every cell of every row.  The memory layout, the order of the LDS accesses and every artefact of the reference
+// stay as in the full version.
 template <int BS, bool GLOBAL, bool PLAIN>
 __global__ __launch_bounds__(BS) void extz2_general_kernel(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
         }
       }
       __syncthreads();
-      if (PLAIN && act) {
+      if ((PLAIN || !right) && act) {  // left-aligned gaps (every SEDEF call): the packed 16-bit recurrence
         // bytes -> value << 8 in 16-bit halves: cells (0,1) and (2,3) of the thread
         const uint32_t smx = (t == b.lo && cx < 0) ? 0xff00u : 0u, smv = (t == b.lo && cv < 0) ? 0xff00u : 0u;
         uint32_t un[2], vn[2], xn[2], yn[2], dd[2];
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
           *reinterpret_cast<uint32_t *>(dir + (int64_t)r * stride + (t - b.lo)) =
               __builtin_amdgcn_perm(dd[1], dd[0], 0x06040200u);
       }
-      if (!PLAIN && act) {
+      if (!PLAIN && right && act) {  // right-aligned gaps: scalar byte arithmetic
         // a negative carry byte is sign-extended over lanes 1..3 of the first block
         const uint32_t smx = (t == b.lo && cx < 0) ? 0xffu : 0u;
         const uint32_t smv = (t == b.lo && cv < 0) ? 0xffu : 0u;
