@@ -694,6 +694,20 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         c->idx.push_back((int32_t)k);
         if (p.pad_ == 2) c->idx.push_back(partner[k]);
       }
+      // Small classes of one kernel (< 2048 tasks: occupancy is not what limits them, their longest task is) are
+      // merged into one launch with the largest LDS size among them: fewer launches queued one behind the other.
+      for (size_t a = 0; a < cls.size(); ++a) {
+        if (cls[a].idx.empty() || cls[a].idx.size() >= 2048) continue;
+        for (size_t b = a + 1; b < cls.size(); ++b) {
+          if (cls[b].bs != cls[a].bs || cls[b].idx.empty() || cls[b].idx.size() >= 2048) continue;
+          cls[a].lds = std::max(cls[a].lds, cls[b].lds);
+          cls[a].need_max = std::max(cls[a].need_max, cls[b].need_max);
+          cls[a].est = std::max(cls[a].est, cls[b].est);
+          cls[a].idx.insert(cls[a].idx.end(), cls[b].idx.begin(), cls[b].idx.end());
+          cls[b].idx.clear();
+        }
+      }
+      cls.erase(std::remove_if(cls.begin(), cls.end(), [](const Cls &c) { return c.idx.empty(); }), cls.end());
       // longest launches first so the long tasks start early
       std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.est > b.est; });
       size_t cursor = 0;
