@@ -850,12 +850,39 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       unsigned layouts = 0;  // direction-flag layouts present in the chunk: one traceback instantiation each
       for (size_t k = 0; k < cnt; ++k) layouts |= 1u << (cp[k].nreg == 0 ? 0 : cp[k].pad_ == 2 ? 2 : 1);
       const dim3 tbg((unsigned)((cnt + 63) / 64));
+      // A walk is one step per anti-diagonal, ~1 us each: a launch lasts as long as its longest task.  When a chunk
+      // of few tasks mixes layouts, the instantiations run side by side on different streams (each after the
+      // chunk's DP, collected again by the chunk's traceback stream) rather than one after the other.
+      const bool side_by_side = pipelined && cnt < 32768 && (layouts & (layouts - 1)) != 0;
+      int used_tb = 0;
+      hipStream_t tbs[3] = {stb, stb, stb};
+      if (side_by_side) {  // (a batch with heavy tasks keeps its stream division: Q[0], Q[1] heavy, Q[2], Q[3] ordinary)
+        int j = 1;
+        for (int q = 0; q < 4 && j < 3; ++q) {
+          if (Q[q] == stb) continue;
+          if (have_heavy && (heavy_chunk ? q >= 2 : q < 2)) continue;
+          tbs[j++] = Q[q];
+        }
+      }
+      auto tb_on = [&]() -> hipStream_t {
+        hipStream_t s2 = tbs[used_tb < 3 ? used_tb : 2];
+        if (side_by_side && s2 != stb) (void)hipStreamWaitEvent(s2, ev.tb0, 0);
+        ++used_tb;
+        return s2;
+      };
       if (layouts & 4u)
-        hipLaunchKernelGGL(traceback_kernel<2>, tbg, dim3(64), 0, stb, d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+        hipLaunchKernelGGL(traceback_kernel<2>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
       if (layouts & 2u)
-        hipLaunchKernelGGL(traceback_kernel<1>, tbg, dim3(64), 0, stb, d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+        hipLaunchKernelGGL(traceback_kernel<1>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
       if (layouts & 1u)
-        hipLaunchKernelGGL(traceback_kernel<0>, tbg, dim3(64), 0, stb, d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+        hipLaunchKernelGGL(traceback_kernel<0>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+      if (side_by_side)
+        for (int j = 1; j < used_tb && j < 3; ++j) {
+          if (tbs[j] == stb) continue;
+          hipEvent_t e = next_event(ctx, evc);
+          SDF_HIP(hipEventRecord(e, tbs[j]));
+          SDF_HIP(hipStreamWaitEvent(stb, e, 0));
+        }
     }
     SDF_HIP(hipEventRecord(ev.tb1, stb));
   }
