@@ -47,6 +47,17 @@ __device__ __forceinline__ unsigned sign_smear(unsigned c) {
   return ((c & 0x8000u) ? 0xff00u : 0u) | ((c & 0x80000000u) ? 0xff000000u : 0u);
 }
 
+// entries of the LDS sequence windows: the whole (padded) sequence when it is short, else the window slots plus
+// 1024 entries of slack (multiples of 4 keep the query window dword aligned behind the target window)
+__host__ __device__ inline int pair_tcap(int tlen, int nreg) {
+  const int whole = (tlen + 15) / 16 * 16 + 64 * nreg + 32, win = 64 * nreg + 1024 + 64;
+  return whole < win ? whole : win;
+}
+__host__ __device__ inline int pair_qcap(int qlen, int nreg) {
+  const int whole = qlen + 64 * nreg + 36, win = 64 * nreg + 1024 + 68;
+  return whole < win ? whole : win;
+}
+
 // fresh (score + 2(q+e)) << 8 of the lane's cell of both tasks from the target / query byte codes
 #define SDF_PFRESH(z, tc, qword, WITH_N)                                \
   {                                                                     \
@@ -61,7 +72,8 @@ __device__ __forceinline__ unsigned sign_smear(unsigned c) {
     }                                                                   \
   }
 
-template <int NREG>
+// STREAM: the sequences do not fit the LDS windows whole (long tasks); without it the window code compiles out.
+template <int NREG, bool STREAM>
 __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 4 ? 3 : 2) void extz2_pair_kernel(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
@@ -71,30 +83,50 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
   const PlanTask tkb = plan[order[2 * blockIdx.x + 1]];  // task B (high halves): same qlen, tlen, w, flag
   const int lane = threadIdx.x;
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
-  const int T16 = (tlen + 15) / 16 * 16;
-  const int tcap = T16 + NSLOT + 32;   // target bytes (A | B << 8), zero padded
-  const int qcap = qlen + NSLOT + 36;  // reversed query with a 32-element front pad: A | B << 16, ready to use
+  // Sequence windows in LDS.  Tb[i] = target position tt0 + i (bytes A | B << 8, zero beyond the ends); W[i] =
+  // entry we0 + i of the reversed query with a 32-element front pad (entry j = QR[j-32], QR[e] = query[qlen-1-e];
+  // A | B << 16, ready to use).  Short sequences fit whole (tt0 = we0 = 0 for ever); of long ones only the part
+  // the band is moving through is resident (1024 entries of slack) and the windows are re-filled from the packed
+  // pool when a block start finds them too far behind: the LDS footprint does not grow with the sequence length.
+  const int tcap = pair_tcap(tlen, NREG), qcap = pair_qcap(qlen, NREG);
   uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);
-  uint32_t *W = reinterpret_cast<uint32_t *>(lds + 2 * tcap);  // W[j] = QR[j-32], QR[e] = query[qlen-1-e]
+  uint32_t *W = reinterpret_cast<uint32_t *>(lds + 2 * tcap);
+  const int64_t tw_a = tk.t_word, tw_b = tkb.t_word, qw_a = tk.q_word, qw_b = tkb.q_word;
+  int tt0_v = 0, we0_v = 0;  // window origins (always 0 without STREAM)
+#define tt0 (STREAM ? tt0_v : 0)
+#define we0 (STREAM ? we0_v : 0)
+  auto fill_target = [&](const int from) {  // (pointers rebuilt here: re-fills are rare, registers are not)
+    const uint32_t *twa = pool + tw_a, *tna = twa + (tlen + 15) / 16;
+    const uint32_t *twb = pool + tw_b, *tnb = twb + (tlen + 15) / 16;
+    tt0_v = from;
+    for (int i = lane; i < tcap; i += 64) {
+      const int t = from + i;
+      Tb[i] = t < tlen ? (uint16_t)(pool_code8(twa, tna, t, sc.wild) | (pool_code8(twb, tnb, t, sc.wild) << 8)) : 0;
+    }
+  };
+  auto fill_query = [&](const int from) {
+    const uint32_t *qwa = pool + qw_a, *qna = qwa + (qlen + 15) / 16;
+    const uint32_t *qwb = pool + qw_b, *qnb = qwb + (qlen + 15) / 16;
+    we0_v = from;
+    for (int i = lane; i < qcap; i += 64) {
+      const int e = from + i - 32;
+      const bool in = e >= 0 && e < qlen;
+      W[i] = in ? (pool_code8(qwa, qna, qlen - 1 - e, sc.wild) | (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 16)) : 0u;
+    }
+  };
 
   // ---- unpack the 2-bit / N-mask sequences of both tasks into LDS ----
   int has_n;
   {
-    const uint32_t *twa = pool + tk.t_word, *tna = twa + (tlen + 15) / 16;
-    const uint32_t *qwa = pool + tk.q_word, *qna = qwa + (qlen + 15) / 16;
-    const uint32_t *twb = pool + tkb.t_word, *tnb = twb + (tlen + 15) / 16;
-    const uint32_t *qwb = pool + tkb.q_word, *qnb = qwb + (qlen + 15) / 16;
+    const uint32_t *tna = pool + tw_a + (tlen + 15) / 16, *tnb = pool + tw_b + (tlen + 15) / 16;
+    const uint32_t *qna = pool + qw_a + (qlen + 15) / 16, *qnb = pool + qw_b + (qlen + 15) / 16;
     uint32_t n_seen = 0;
     for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tna[k] | tnb[k];
     for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qna[k] | qnb[k];
     has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0));  // wave-uniform
-    for (int t = lane; t < tcap; t += 64)
-      Tb[t] = t < tlen ? (uint16_t)(pool_code8(twa, tna, t, sc.wild) | (pool_code8(twb, tnb, t, sc.wild) << 8)) : 0;
-    for (int j = lane; j < qcap; j += 64) {
-      const int e = j - 32;
-      const bool in = e >= 0 && e < qlen;
-      W[j] = in ? (pool_code8(qwa, qna, qlen - 1 - e, sc.wild) | (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 16)) : 0u;
-    }
+    fill_target(0);
+    // row 0 reads entries up to qlen + NSLOT + 31: the window's top there
+    fill_query(qlen + NSLOT + 36 > qcap ? qlen + NSLOT + 36 - qcap : 0);
   }
   __syncthreads();
 
@@ -265,7 +297,7 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
       for (int k = 0; k < NREG; ++k) {
         const int a_ = ra - 64 * k, b_ = rb - 64 * k;
         if (b_ > 0 && a_ < 64) {
-          const unsigned qc = W[cq + 64 * k + lane];
+          const unsigned qc = W[cq - we0 + 64 * k + lane];
           unsigned z;
           SDF_PFRESH(z, Tc[k], qc, has_n)
           if (a_ <= 0 && b_ >= 64) S[k] = z;
@@ -320,7 +352,7 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
     constexpr int KT = NREG - 1;
     if (SCALARH) fold_h();
     if (qrow != rb) {  // (re)start the one-row-ahead query fetch at this row
-      qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 + lane));
+      qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 - we0 + lane));
       fetch_q();
       qaddr -= 4;  // address of the row after `qnext`
     }
@@ -513,10 +545,24 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
         }
         base = b0.lo;
         qrow = -1;  // the window moved: query addresses change
+        if (STREAM && __builtin_expect(base + NSLOT > tt0 + tcap, 0)) {  // the band has moved beyond the resident part of the target
+          fill_target(base);
+          __syncthreads();
+        }
 #pragma unroll
         for (int k = 0; k < NREG; ++k)
-          Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[base + 64 * k + lane], 0x0c010c00u);
+          Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[base - tt0 + 64 * k + lane], 0x0c010c00u);
         zero_low = false;
+      }
+      {  // reversed-query entries this block reads (rows r0 .. r0+16, the last one as a prefetch): resident?
+        const int e_lo = qlen - 1 - (r0 + 16) + base + 32, e_hi = qlen - 1 - r0 + base + 32 + NSLOT - 1;
+        if (STREAM && __builtin_expect(e_lo < we0 || e_hi >= we0 + qcap, 0)) {
+          // they move towards lower entries as the rows advance: the block's range goes to the window's top
+          const int from = e_hi + 1 - qcap;
+          fill_query(from < 0 ? 0 : from);
+          __syncthreads();
+          qrow = -1;
+        }
       }
     }
     const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
@@ -674,9 +720,14 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
   }
 }
 
+#undef tt0
+#undef we0
+
 #define SDF_PAIR_INST(N)                                                                                        \
-  template __global__ void extz2_pair_kernel<N>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, \
-                                                uint8_t *, sdf_result *);
+  template __global__ void extz2_pair_kernel<N, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, \
+                                                       uint8_t *, sdf_result *);                               \
+  template __global__ void extz2_pair_kernel<N, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,  \
+                                                      uint8_t *, sdf_result *);
 SDF_PAIR_INST(1)
 SDF_PAIR_INST(2)
 SDF_PAIR_INST(3)
@@ -685,11 +736,13 @@ SDF_PAIR_INST(6)
 SDF_PAIR_INST(8)
 #undef SDF_PAIR_INST
 
+// the windows hold the sequences whole?
+bool pair_fits_whole(int qlen, int tlen, int nreg) {
+  return pair_tcap(tlen, nreg) == (tlen + 15) / 16 * 16 + 64 * nreg + 32 && pair_qcap(qlen, nreg) == qlen + 64 * nreg + 36;
+}
+
 size_t pair_lds_bytes(int qlen, int tlen, int nreg) {
-  const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
-  const size_t tcap = T16 + 64 * nreg + 32;
-  const size_t qcap = (size_t)qlen + 64 * nreg + 36;
-  return 2 * tcap + 4 * qcap;
+  return 2 * (size_t)pair_tcap(tlen, nreg) + 4 * (size_t)pair_qcap(qlen, nreg);
 }
 
 }  // namespace sdf

@@ -25,10 +25,11 @@ template <int NREG>
 __global__ void extz2_wave_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                   sdf_result *);
 size_t wave_lds_bytes(int qlen, int tlen, int nreg);
-template <int NREG>
+template <int NREG, bool STREAM>
 __global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                   sdf_result *);
 size_t pair_lds_bytes(int qlen, int tlen, int nreg);
+bool pair_fits_whole(int qlen, int tlen, int nreg);
 template <int LAYOUT>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
 __global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
@@ -193,7 +194,9 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
 #define SDF_PAIR_ATTR(N)                                                                   \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N>),         \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N, false>),  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);         \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N, true>),   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   SDF_PAIR_ATTR(1) SDF_PAIR_ATTR(2) SDF_PAIR_ATTR(3) SDF_PAIR_ATTR(4) SDF_PAIR_ATTR(6) SDF_PAIR_ATTR(8)
 #undef SDF_PAIR_ATTR
@@ -657,7 +660,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         size_t lds = 2048, need;
         if (p.pad_ == 2) {
           if (partner[k] < (int32_t)k) continue;  // placed together with its partner
-          bs = 100 + p.nreg;
+          // 100 + NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
+          bs = 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
           need = pair_lds_bytes(p.qlen, p.tlen, p.nreg);
           lds = 8192;
           while (lds < need) lds *= 2;
@@ -688,7 +692,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         c->need_max = std::max(c->need_max, need);
         {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
           const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.3 : bs == 2256 ? 0.2 : bs == 3024 ? 0.6
-                              : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 100 ? 0.25 : 0.13;
+                              : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..118)
           c->est = std::max(c->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
         }
         c->idx.push_back((int32_t)k);
@@ -800,8 +804,10 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         hipLaunchKernelGGL(extz2_wave_kernel<8>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
                            dir_reg, d_out);
 #define SDF_PAIR_LAUNCH(N)                                                                                     \
-  else if (L.bs == 100 + N) hipLaunchKernelGGL(extz2_pair_kernel<N>, dim3((unsigned)(L.cnt / 2)), dim3(64), L.lds, \
-                                               sdp, lp, lo, d_pool, sk, dir_reg, d_out);
+  else if (L.bs == 100 + N) hipLaunchKernelGGL((extz2_pair_kernel<N, false>), dim3((unsigned)(L.cnt / 2)), dim3(64), \
+                                               L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);                 \
+  else if (L.bs == 110 + N) hipLaunchKernelGGL((extz2_pair_kernel<N, true>), dim3((unsigned)(L.cnt / 2)), dim3(64), \
+                                               L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);
       SDF_PAIR_LAUNCH(1)
       SDF_PAIR_LAUNCH(2)
       SDF_PAIR_LAUNCH(3)

@@ -526,3 +526,25 @@ def test_plain_general_kernel_wide_windows(engine, oracle):
     t = mutate(rng, q, 0.04, 0.01, 0.01)
     t = np.concatenate([t[:6000], random_codes(rng, 700), t[6000:]])
     _check_fast(engine, oracle, [(q, t), (q[:15000], t[:15100])], [-1, 1400])
+
+
+def test_pair_kernel_long_sequences_streamed_windows(engine, oracle):
+    """Sequences far longer than the LDS windows of the pair kernel (window slots + 1024 entries): the target and
+    reversed-query windows are re-filled from the packed pool as the band moves; N runs and indels near the band
+    edge included; several same-geometry tasks per shape so that pairs form."""
+    rng = np.random.default_rng(6060)
+    pairs, ws = [], []
+    for ql, tl, w in [(3000, 3000, 64), (5000, 5010, 100), (9000, 8990, 128), (20000, 20000, 200), (12000, 12100, 300),
+                      (2500, 2400, 440), (1500, 1500, 17), (30000, 30020, 64)]:
+        for _ in range(3):
+            q = random_codes(rng, ql, 0.003 if rng.random() < 0.5 else 0.0)
+            d = rng.random() * 0.08
+            t = mutate(rng, q, d, d / 4, d / 4)
+            if rng.random() < 0.5 and len(t) > 200:
+                k, L = int(rng.integers(0, len(t) - 100)), int(rng.integers(1, max(2, w // 2)))
+                t = np.concatenate([t[:k], random_codes(rng, L), t[k:]]) if rng.random() < 0.5 else \
+                    np.concatenate([t[:k], t[k + L:]])
+            pairs.append((q, _fit(rng, t, tl)))
+            ws.append(w)
+    _check_fast(engine, oracle, pairs, ws)
+    assert engine.last_paired() >= 14
