@@ -196,7 +196,19 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
     }                                                                   \
   }
 
-template <int NREG>
+// entries of the LDS sequence windows: the whole (padded) sequence when it is short, else the window slots plus
+// 1024 entries of slack (see extz2_pair.hip)
+__host__ __device__ inline int wave_tcap(int tlen, int nreg) {
+  const int whole = (tlen + 15) / 16 * 16 + 128 * nreg + 32, win = 128 * nreg + 1024 + 64;
+  return whole < win ? whole : win;
+}
+__host__ __device__ inline int wave_qcap(int qlen, int nreg) {
+  const int whole = qlen + 128 * nreg + 36, win = 128 * nreg + 1024 + 68;
+  return whole < win ? whole : win;
+}
+
+// STREAM: the sequences do not fit the LDS windows whole (long tasks); without it the window code compiles out.
+template <int NREG, bool STREAM>
 __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
                                                         const int32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ pool, ScoreK sc,
@@ -207,31 +219,49 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
   const PlanTask tk = plan[order[blockIdx.x]];
   const int lane = threadIdx.x;
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
-  const int T16 = (tlen + 15) / 16 * 16;
-  const int tcap = T16 + NSLOT + 32;      // target codes (u16), zero padded
-  const int qcap = qlen + NSLOT + 36;     // reversed query with a 32-element front pad, as byte
-  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);            // PAIRS: W[j] = QR[j-32] | QR[j-31] << 8
-  uint16_t *W = reinterpret_cast<uint16_t *>(lds + 2 * tcap);  // (any j is one aligned 16-bit load;
-                                                               //  N is 0x80|wild in a byte)
-
-  // ---- unpack the 2-bit / N-mask sequences into LDS ----
-  bool has_n;
-  {
-    const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen + 15) / 16;
-    const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
-    uint32_t n_seen = 0;
-    for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tn[k];
-    for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qn[k];
-    has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0)) != 0;  // wave-uniform
-    for (int t = lane; t < tcap; t += 64) Tb[t] = t < tlen ? (uint16_t)pool_code16(tw, tn, t, sc.wild) : 0;
-    for (int j = lane; j < qcap; j += 64) {
-      const int e0 = j - 32, e1 = j - 31;  // QR indices; QR[e] = query[qlen-1-e], 0 outside
+  // Sequence windows in LDS.  Tb[i] = target position tt0 + i (16-bit codes, zero beyond the ends); W[i] = entry
+  // we0 + i of the reversed query with a 32-element front pad, as byte PAIRS: entry j = QR[j-32] | QR[j-31] << 8
+  // (any j is one aligned 16-bit load; N is 0x80|wild in a byte).  Short sequences fit whole; of long ones only the
+  // part the band is moving through is resident and the windows are re-filled at block starts (STREAM).
+  const int tcap = wave_tcap(tlen, NREG), qcap = wave_qcap(qlen, NREG);
+  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);
+  uint16_t *W = reinterpret_cast<uint16_t *>(lds + 2 * tcap);
+  const int64_t tw_off = tk.t_word, qw_off = tk.q_word;
+  int tt0_v = 0, we0_v = 0;  // window origins (always 0 without STREAM)
+#define tt0 (STREAM ? tt0_v : 0)
+#define we0 (STREAM ? we0_v : 0)
+  auto fill_target = [&](const int from) {  // (pointers rebuilt here: re-fills are rare, registers are not)
+    const uint32_t *tw = pool + tw_off, *tn = tw + (tlen + 15) / 16;
+    tt0_v = from;
+    for (int i = lane; i < tcap; i += 64) {
+      const int t = from + i;
+      Tb[i] = t < tlen ? (uint16_t)pool_code16(tw, tn, t, sc.wild) : 0;
+    }
+  };
+  auto fill_query = [&](const int from) {
+    const uint32_t *qw = pool + qw_off, *qn = qw + (qlen + 15) / 16;
+    we0_v = from;
+    for (int i = lane; i < qcap; i += 64) {
+      const int e0 = from + i - 32, e1 = e0 + 1;  // QR indices; QR[e] = query[qlen-1-e], 0 outside
       uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
       uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
       v0 = (v0 & 0x7fu) | ((v0 >> 8) & 0x80u);
       v1 = (v1 & 0x7fu) | ((v1 >> 8) & 0x80u);
-      W[j] = (uint16_t)(v0 | (v1 << 8));
+      W[i] = (uint16_t)(v0 | (v1 << 8));
     }
+  };
+
+  // ---- unpack the 2-bit / N-mask sequences into LDS ----
+  bool has_n;
+  {
+    const uint32_t *tn = pool + tw_off + (tlen + 15) / 16, *qn = pool + qw_off + (qlen + 15) / 16;
+    uint32_t n_seen = 0;
+    for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tn[k];
+    for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qn[k];
+    has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0)) != 0;  // wave-uniform
+    fill_target(0);
+    // row 0 reads entries up to qlen + NSLOT + 31: the window's top there
+    fill_query(qlen + NSLOT + 36 > qcap ? qlen + NSLOT + 36 - qcap : 0);
   }
   __syncthreads();
 
@@ -376,7 +406,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
       for (int k = 0; k < NREG; ++k) {
         const int a_ = ra - 128 * k, b_ = rb - 128 * k;
         if (b_ > 0 && a_ < 128) {
-          const unsigned qc = W[cq + 128 * k + 2 * lane];  // zero-extended byte pair
+          const unsigned qc = W[cq - we0 + 128 * k + 2 * lane];  // zero-extended byte pair
           unsigned z;
           SDF_FRESH(z, Tc[k], qc)
           if (a_ <= 0 && b_ >= 128) {
@@ -454,7 +484,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
     constexpr int KT = NREG - 1;
     if (SCALARH) fold_h();
     if (qrow != rb) {  // (re)start the one-row-ahead query fetch at this row
-      qaddr = (unsigned)(2 * tcap + 2 * (qlen - 1 - rb + base + 32 + 2 * lane));
+      qaddr = (unsigned)(2 * tcap + 2 * (qlen - 1 - rb + base + 32 - we0 + 2 * lane));
 #pragma unroll
       for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
     }
@@ -658,10 +688,24 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
         }
         base = b0.lo;
         qrow = -1;  // the window moved: query addresses change
+        if (STREAM && __builtin_expect(base + NSLOT > tt0 + tcap, 0)) {  // beyond the resident part of the target
+          fill_target(base);
+          __syncthreads();
+        }
 #pragma unroll
         for (int k = 0; k < NREG; ++k)
-          Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + base + 128 * k + 2 * lane);
+          Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + (base - tt0) + 128 * k + 2 * lane);
         zero_low = false;
+      }
+      if (STREAM) {  // reversed-query entries this block reads (rows r0 .. r0+16, the last as a prefetch): resident?
+        const int e_lo = qlen - 1 - (r0 + 16) + base + 32, e_hi = qlen - 1 - r0 + base + 32 + NSLOT - 1;
+        if (__builtin_expect(e_lo < we0 || e_hi >= we0 + qcap, 0)) {
+          // they move towards lower entries as the rows advance: the block's range goes to the window's top
+          const int from = e_hi + 1 - qcap;
+          fill_query(from < 0 ? 0 : from);
+          __syncthreads();
+          qrow = -1;
+        }
       }
     }
     const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
@@ -815,20 +859,33 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
   }
 }
 
-template __global__ void extz2_wave_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
-                                              uint8_t *, sdf_result *);
-template __global__ void extz2_wave_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
-                                              uint8_t *, sdf_result *);
-template __global__ void extz2_wave_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
-                                              uint8_t *, sdf_result *);
-template __global__ void extz2_wave_kernel<8>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
-                                              uint8_t *, sdf_result *);
+#undef tt0
+#undef we0
+
+template __global__ void extz2_wave_kernel<1, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<1, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<2, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<2, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<4, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<4, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<8, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<8, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+
+// the windows hold the sequences whole?
+bool wave_fits_whole(int qlen, int tlen, int nreg) {
+  return wave_tcap(tlen, nreg) == (tlen + 15) / 16 * 16 + 128 * nreg + 32 && wave_qcap(qlen, nreg) == qlen + 128 * nreg + 36;
+}
 
 size_t wave_lds_bytes(int qlen, int tlen, int nreg) {
-  const size_t T16 = (size_t)(tlen + 15) / 16 * 16;
-  const size_t tcap = T16 + 128 * nreg + 32;
-  const size_t qcap = (size_t)qlen + 128 * nreg + 36;
-  return 2 * tcap + 2 * qcap;
+  return 2 * (size_t)wave_tcap(tlen, nreg) + 2 * (size_t)wave_qcap(qlen, nreg);
 }
 
 }  // namespace sdf

@@ -21,10 +21,11 @@ template <int BS, bool GLOBAL, bool PLAIN>
 __global__ void extz2_general_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                      sdf_result *, uint8_t *, size_t);
 size_t general_lds_bytes(int qlen, int tlen);
-template <int NREG>
+template <int NREG, bool STREAM>
 __global__ void extz2_wave_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                   sdf_result *);
 size_t wave_lds_bytes(int qlen, int tlen, int nreg);
+bool wave_fits_whole(int qlen, int tlen, int nreg);
 template <int NREG, bool STREAM>
 __global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                   sdf_result *);
@@ -185,13 +186,21 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
       hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_general_kernel<256, false, true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, want_lds) == hipSuccess)
     ctx->max_dyn_lds = want_lds;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<1>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<1, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<2>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<1, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<4>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<2, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<8>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<2, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<4, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<4, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<8, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<8, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
 #define SDF_PAIR_ATTR(N)                                                                   \
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N, false>),  \
@@ -666,7 +675,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           lds = 8192;
           while (lds < need) lds *= 2;
         } else if (p.nreg) {
-          bs = p.nreg;
+          // NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
+          bs = p.nreg + (wave_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
           // one class for everything up to 6 KiB (>= 6 waves/SIMD either way), powers of two above
           need = wave_lds_bytes(p.qlen, p.tlen, p.nreg);
           lds = 6144;
@@ -792,16 +802,28 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       const PlanTask *lp = d_plan + pb;
       const int32_t *lo = d_order + ob + L.off;
       if (L.bs == 1)
-        hipLaunchKernelGGL(extz2_wave_kernel<1>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+        hipLaunchKernelGGL((extz2_wave_kernel<1, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
+      else if (L.bs == 11)
+        hipLaunchKernelGGL((extz2_wave_kernel<1, true>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
                            dir_reg, d_out);
       else if (L.bs == 2)
-        hipLaunchKernelGGL(extz2_wave_kernel<2>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+        hipLaunchKernelGGL((extz2_wave_kernel<2, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
+      else if (L.bs == 12)
+        hipLaunchKernelGGL((extz2_wave_kernel<2, true>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
                            dir_reg, d_out);
       else if (L.bs == 4)
-        hipLaunchKernelGGL(extz2_wave_kernel<4>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+        hipLaunchKernelGGL((extz2_wave_kernel<4, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
+      else if (L.bs == 14)
+        hipLaunchKernelGGL((extz2_wave_kernel<4, true>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
                            dir_reg, d_out);
       else if (L.bs == 8)
-        hipLaunchKernelGGL(extz2_wave_kernel<8>, dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+        hipLaunchKernelGGL((extz2_wave_kernel<8, false>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
+                           dir_reg, d_out);
+      else if (L.bs == 18)
+        hipLaunchKernelGGL((extz2_wave_kernel<8, true>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
                            dir_reg, d_out);
 #define SDF_PAIR_LAUNCH(N)                                                                                     \
   else if (L.bs == 100 + N) hipLaunchKernelGGL((extz2_pair_kernel<N, false>), dim3((unsigned)(L.cnt / 2)), dim3(64), \

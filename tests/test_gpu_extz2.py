@@ -548,3 +548,24 @@ def test_pair_kernel_long_sequences_streamed_windows(engine, oracle):
             ws.append(w)
     _check_fast(engine, oracle, pairs, ws)
     assert engine.last_paired() >= 14
+
+
+def test_wave_kernel_long_sequences_streamed_windows(engine, solo_engine, oracle):
+    """Long sequences through the one-task-per-wavefront kernel: its LDS sequence windows are re-filled as the band
+    moves (bands of 513..1000 cells take this kernel in the default context too; narrower ones with SDF_NO_PAIR)."""
+    rng = np.random.default_rng(7070)
+    pairs, ws = [], []
+    for ql, tl, w in [(4000, 4000, 64), (9000, 9050, 128), (20000, 19990, 300), (20000, 20000, 512), (8000, 8000, 700),
+                      (6000, 6100, 990), (2500, 2500, 17), (25000, 25000, 40)]:
+        for _ in range(2):
+            q = random_codes(rng, ql, 0.003 if rng.random() < 0.5 else 0.0)
+            d = rng.random() * 0.08
+            t = mutate(rng, q, d, d / 4, d / 4)
+            if rng.random() < 0.5:
+                k, L = int(rng.integers(0, len(t) - 100)), int(rng.integers(1, max(2, w // 2)))
+                t = np.concatenate([t[:k], random_codes(rng, L), t[k:]]) if rng.random() < 0.5 else \
+                    np.concatenate([t[:k], t[k + L:]])
+            pairs.append((q, _fit(rng, t, tl)))
+            ws.append(w)
+    _check_fast(solo_engine, oracle, pairs, ws)
+    _check_fast(engine, oracle, pairs, ws)
