@@ -31,6 +31,11 @@ __global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint3
                                   sdf_result *);
 size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 bool pair_fits_whole(int qlen, int tlen, int nreg);
+template <int NREG>
+__global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                    sdf_result *);
+size_t stripe_lds_bytes(int qlen, int nstripe, int nreg);
+size_t stripe_dir_bytes(int qlen, int nreg);
 template <int LAYOUT>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
 __global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
@@ -124,6 +129,7 @@ struct sdf_ctx {
   int max_dyn_lds = 64 * 1024;
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
   bool pipeline = true;        // SDF_PIPELINE=0: one chunk on one stream (isolated kernel timing)
+  bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
 };
 
@@ -214,6 +220,13 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->force_general = fg && fg[0] == '1';
   const char *np = getenv("SDF_NO_PAIR");
   ctx->no_pair = np && np[0] == '1';
+  for (const void *f : {reinterpret_cast<const void *>(&extz2_stripe_kernel<1>),
+                        reinterpret_cast<const void *>(&extz2_stripe_kernel<2>),
+                        reinterpret_cast<const void *>(&extz2_stripe_kernel<4>)})
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipGetLastError();
+  const char *ns = getenv("SDF_NO_STRIPE");
+  ctx->no_stripe = ns && ns[0] == '1';
   const char *pl = getenv("SDF_PIPELINE");
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
@@ -494,6 +507,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     size_t need_max;  // largest real requirement in the class: what the launch asks for
     std::vector<int32_t> idx;
     double est = 0;   // duration estimate of the launch: its longest task (cells / per-workgroup rate of the kernel)
+    int kmax = 0;     // stripe kernel: wavefronts per workgroup (largest stripe count in the class)
   };
   struct ChunkEv {
     hipEvent_t dp0, dpe[4], tb0, tb1;  // plan uploaded; end of the DP launches per stream; traceback (begin, end)
@@ -560,6 +574,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
       p.cig_slot = stage_words;
       stage_words += p.cig_cap;
+      if (!p.nreg && plain_ok && !ctx->no_stripe && p.w >= std::max(t.qlen, t.tlen) && t.tlen > 1024 && t.tlen <= 8192) {
+        // wide full-band task: a workgroup of wavefronts, one per stripe of 128 * nreg target positions
+        const int nreg = t.tlen <= 2048 ? 1 : t.tlen <= 4096 ? 2 : 4;
+        const int nst = (t.tlen + 128 * nreg - 1) / (128 * nreg);
+        // (a last stripe of one cell would need the H of the cell under the target's end from its neighbour)
+        if (t.tlen % (128 * nreg) != 1 && stripe_lds_bytes(t.qlen, nst, nreg) <= (size_t)ctx->max_dyn_lds) {
+          p.nreg = nreg;
+          p.pad_ = 5;
+        }
+      }
       if (!p.nreg) {
         // general kernel: state in LDS, or in an HBM scratch slab when it does not fit; the PLAIN flavour (packed
         // recurrence, H along the band edge only) when nothing but CIGAR / score / mte is wanted and the window
@@ -573,6 +597,14 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       plan[np++] = p;
     }
     const size_t cnt = np - pb;
+    {  // the stripe tasks of a chunk share one stripe width (the widest any of them needs): one launch, all of them
+       // side by side, instead of one launch per width queued behind each other
+      int snreg = 0;
+      for (size_t k = pb; k < np; ++k)
+        if (plan[k].pad_ == 5) snreg = std::max(snreg, plan[k].nreg);
+      for (size_t k = pb; k < np; ++k)
+        if (plan[k].pad_ == 5) plan[k].nreg = snreg;
+    }
     if (cnt == 0) {
       cev[ci] = ChunkEv{};
       continue;
@@ -590,7 +622,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       table.assign(cap, {-1, -1});
       for (size_t k = 0; k < cnt; ++k) {
         PlanTask &y = cp[k];
-        if (!y.nreg || win_need[k] > 512) continue;
+        if (!y.nreg || y.pad_ != 0 || win_need[k] > 512) continue;  // wave-kernel tasks only
         uint64_t h = ((uint64_t)(uint32_t)y.qlen * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)y.tlen * 0xC2B2AE3D27D4EB4Full) ^
                      ((uint64_t)(uint32_t)y.w * 0x165667B19E3779F9ull) ^ ((uint64_t)(uint32_t)y.flag << 40);
         h ^= h >> 29;
@@ -641,6 +673,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
           const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
           if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
+          else if (p.pad_ == 5)
+            need = (size_t)((p.tlen + 128 * p.nreg - 1) / (128 * p.nreg)) * stripe_dir_bytes(p.qlen, p.nreg);
           else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
           else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
         }
@@ -658,6 +692,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       size_t lds;
       size_t off, cnt;
       double est;
+      int kmax;
     };
     std::vector<Launch> launches;
     {
@@ -673,6 +708,11 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           bs = 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
           need = pair_lds_bytes(p.qlen, p.tlen, p.nreg);
           lds = 8192;
+          while (lds < need) lds *= 2;
+        } else if (p.pad_ == 5) {
+          bs = 200 + p.nreg;  // stripe kernel; LDS by the stripe count and the query length
+          need = stripe_lds_bytes(p.qlen, (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg), p.nreg);
+          lds = 32768;
           while (lds < need) lds *= 2;
         } else if (p.nreg) {
           // NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
@@ -700,9 +740,10 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           c = &cls.back();
         }
         c->need_max = std::max(c->need_max, need);
+        if (p.pad_ == 5) c->kmax = std::max(c->kmax, (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg));
         {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
-          const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.3 : bs == 2256 ? 0.2 : bs == 3024 ? 0.6
-                              : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..118)
+          const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.6 : bs == 2256 ? 0.3 : bs == 3024 ? 0.85
+                              : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..118)
           c->est = std::max(c->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
         }
         c->idx.push_back((int32_t)k);
@@ -717,6 +758,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           cls[a].lds = std::max(cls[a].lds, cls[b].lds);
           cls[a].need_max = std::max(cls[a].need_max, cls[b].need_max);
           cls[a].est = std::max(cls[a].est, cls[b].est);
+          cls[a].kmax = std::max(cls[a].kmax, cls[b].kmax);
           cls[a].idx.insert(cls[a].idx.end(), cls[b].idx.begin(), cls[b].idx.end());
           cls[b].idx.clear();
         }
@@ -729,7 +771,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         launches.push_back({c.bs,
                             (c.bs == 1000 || c.bs == 1001 || c.bs == 2001) ? ((c.need_max + 255) & ~(size_t)255)
                                          : std::min(c.lds, (c.need_max + 511) & ~(size_t)511),
-                            cursor, c.idx.size(), c.est});
+                            cursor, c.idx.size(), c.est, c.kmax});
         std::copy(c.idx.begin(), c.idx.end(), order + ob + cursor);
         cursor += c.idx.size();
       }
@@ -825,6 +867,13 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       else if (L.bs == 18)
         hipLaunchKernelGGL((extz2_wave_kernel<8, true>), dim3((unsigned)L.cnt), dim3(64), L.lds, sdp, lp, lo, d_pool, sk,
                            dir_reg, d_out);
+#define SDF_STRIPE_LAUNCH(N)                                                                                  \
+  else if (L.bs == 200 + N) hipLaunchKernelGGL(extz2_stripe_kernel<N>, dim3((unsigned)L.cnt), dim3(64 * L.kmax), \
+                                               L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);
+      SDF_STRIPE_LAUNCH(1)
+      SDF_STRIPE_LAUNCH(2)
+      SDF_STRIPE_LAUNCH(4)
+#undef SDF_STRIPE_LAUNCH
 #define SDF_PAIR_LAUNCH(N)                                                                                     \
   else if (L.bs == 100 + N) hipLaunchKernelGGL((extz2_pair_kernel<N, false>), dim3((unsigned)(L.cnt / 2)), dim3(64), \
                                                L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);                 \
@@ -876,14 +925,15 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     SDF_HIP(hipEventRecord(ev.tb0, stb));
     if (want_cigar) {
       unsigned layouts = 0;  // direction-flag layouts present in the chunk: one traceback instantiation each
-      for (size_t k = 0; k < cnt; ++k) layouts |= 1u << (cp[k].nreg == 0 ? 0 : cp[k].pad_ == 2 ? 2 : 1);
+      for (size_t k = 0; k < cnt; ++k)
+        layouts |= 1u << (cp[k].nreg == 0 ? 0 : cp[k].pad_ == 2 ? 2 : cp[k].pad_ == 5 ? 3 : 1);
       const dim3 tbg((unsigned)((cnt + 63) / 64));
       // A walk is one step per anti-diagonal, ~1 us each: a launch lasts as long as its longest task.  When a chunk
       // of few tasks mixes layouts, the instantiations run side by side on different streams (each after the
       // chunk's DP, collected again by the chunk's traceback stream) rather than one after the other.
       const bool side_by_side = pipelined && cnt < 32768 && (layouts & (layouts - 1)) != 0;
       int used_tb = 0;
-      hipStream_t tbs[3] = {stb, stb, stb};
+      hipStream_t tbs[3] = {stb, stb, stb};  // (a fourth layout shares the last stream)
       if (side_by_side) {  // (a batch with heavy tasks keeps its stream division: Q[0], Q[1] heavy, Q[2], Q[3] ordinary)
         int j = 1;
         for (int q = 0; q < 4 && j < 3; ++q) {
@@ -898,6 +948,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         ++used_tb;
         return s2;
       };
+      if (layouts & 8u)
+        hipLaunchKernelGGL(traceback_kernel<3>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
       if (layouts & 4u)
         hipLaunchKernelGGL(traceback_kernel<2>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
       if (layouts & 2u)

@@ -2,6 +2,7 @@
 #include "extz2_general.hip"
 #include "extz2_wave.hip"
 #include "extz2_pair.hip"
+#include "extz2_stripe.hip"
 #include "traceback.hip"
 #include "anchors.hip"
 #include "sdf_api.hip"

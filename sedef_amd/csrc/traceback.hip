@@ -19,7 +19,8 @@ __device__ __forceinline__ uint32_t code_at(const uint32_t *codes, const uint32_
   return n ? 4u : c;
 }
 
-// LAYOUT: 0 = byte rows (general kernel), 1 = wave-kernel bit blocks, 2 = pair-kernel bit blocks.  One
+// LAYOUT: 0 = byte rows (general kernel), 1 = wave-kernel bit blocks, 2 = pair-kernel bit blocks, 3 = wave-kernel
+// bit blocks per target stripe (extz2_stripe.hip).  One
 // instantiation per layout: in a common loop every step would wait for all outstanding loads at the point where
 // the three fetch paths meet.  Tasks of another layout leave at once (the host launches only the instantiations
 // a chunk needs).
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const PlanTask tk = plan[k];
-  if ((tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : 1) != LAYOUT) return;
+  if ((tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : 1) != LAYOUT) return;
   sdf_result rr = res[tk.out_idx];
   if (tk.flag & SDF_FLAG_SCORE_ONLY) return;
 
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   const uint4 *dirw = reinterpret_cast<const uint4 *>(dir);
   int64_t cached_line = -1;  // index/4 of the 64-byte line (4 lanes = 8 slots x 16 rows) held below
   uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
-  int blk_rb = -1, blk_base = 0;
+  int blk_rb = -1, blk_sb = -1, blk_base = 0;
   while (i >= 0 && j >= 0) {
     const int r = (int)(i + j);
     Band b;
@@ -126,6 +127,37 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
         const int bit = 15 - (r & 15);
         const uint32_t fa = (wab >> bit) & 1u, fb = (wab >> (bit + 16)) & 1u;
         const uint32_t fx = (wxy >> bit) & 1u, fy = (wxy >> (bit + 16)) & 1u;
+        d = (fb ? 2u : fa) | (fx << 3) | (fy << 4);
+      } else if (LAYOUT == 3) {
+        // stripes of 128 * nreg target positions, each a stand-alone wave-kernel task over its slice in local
+        // coordinates (row r - T0, position t - T0); one flag region per stripe
+        const int sw = 128 * tk.nreg;
+        const int sb = (int)i / sw, t0 = sb * sw;
+        const int rp = r - t0, tp = (int)i - t0;
+        const int rb = rp >> 4;
+        if (rb != blk_rb || sb != blk_sb) {
+          Band b0;
+          band_of(rb << 4, tk.qlen, tk.tlen - t0 < sw ? tk.tlen - t0 : sw, tk.w, b0);
+          blk_rb = rb;
+          blk_sb = sb;
+          blk_base = b0.lo;
+        }
+        const int slot = tp - blk_base;
+        const int64_t per_stripe = (int64_t)((tk.qlen + sw - 1 + 15) / 16) * tk.nreg * 64;  // uint4 records
+        const int64_t idx = sb * per_stripe + ((int64_t)rb * tk.nreg + (slot >> 7)) * 64 + ((slot & 127) >> 1);
+        if ((idx >> 2) != cached_line) {
+          cached_line = idx >> 2;
+          const uint4 *ln = dirw + (cached_line << 2);
+          c0 = ln[0];
+          c1 = ln[1];
+          c2 = ln[2];
+          c3 = ln[3];
+        }
+        const int sel = (int)(idx & 3);
+        const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
+        const int bit = 15 - (rp & 15) + ((slot & 1) << 4);
+        const uint32_t fa = (cached.x >> bit) & 1u, fb = (cached.y >> bit) & 1u;
+        const uint32_t fx = (cached.z >> bit) & 1u, fy = (cached.w >> bit) & 1u;
         d = (fb ? 2u : fa) | (fx << 3) | (fy << 4);
       } else {
         const int rb = r >> 4;
@@ -196,6 +228,8 @@ template __global__ void traceback_kernel<0>(const PlanTask *, int, const uint32
 template __global__ void traceback_kernel<1>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
                                              uint32_t *);
 template __global__ void traceback_kernel<2>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
+                                             uint32_t *);
+template __global__ void traceback_kernel<3>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
                                              uint32_t *);
 
 // Exclusive scan of n_cigar over the result records in record order -> cigar_off, in three small launches:

@@ -569,3 +569,24 @@ def test_wave_kernel_long_sequences_streamed_windows(engine, solo_engine, oracle
             ws.append(w)
     _check_fast(solo_engine, oracle, pairs, ws)
     _check_fast(engine, oracle, pairs, ws)
+
+
+def test_stripe_kernel_wide_full_band(engine, oracle):
+    """Full-band tasks with targets of 1025..8192 positions: a workgroup of wavefronts, one per target stripe
+    (extz2_stripe.hip: 128 / 256 / 512-position stripes), against the oracle -- every stripe count incl. ragged last
+    stripes, short and long queries, N runs, unrelated sequences, big indels."""
+    rng = np.random.default_rng(8181)
+    pairs = []
+    for ql, tl in [(1100, 1100), (1500, 1025), (900, 1300), (2048, 2048), (2100, 2049), (300, 2000), (3000, 3000),
+                   (4000, 4096), (4097, 4100), (6000, 6000), (1200, 8192), (5000, 7000), (40, 1500), (2500, 1026)]:
+        for kind in range(2):
+            q = random_codes(rng, ql, 0.004 if kind else 0.0)
+            if kind and ql > 2000:
+                t = random_codes(rng, tl)
+            else:
+                t = mutate(rng, q, 0.06, 0.02, 0.02)
+                k = int(rng.integers(0, max(1, len(t) - 1)))
+                t = np.concatenate([t[:k], random_codes(rng, int(rng.integers(1, 400))), t[k:]])
+                t = _fit(rng, t, tl)
+            pairs.append((q, t))
+    _check_fast(engine, oracle, pairs, [-1] * len(pairs))
