@@ -578,8 +578,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         // wide full-band task: a workgroup of wavefronts, one per stripe of 128 * nreg target positions
         const int nreg = t.tlen <= 2048 ? 1 : t.tlen <= 4096 ? 2 : 4;
         const int nst = (t.tlen + 128 * nreg - 1) / (128 * nreg);
-        // (a last stripe of one cell would need the H of the cell under the target's end from its neighbour)
-        if (t.tlen % (128 * nreg) != 1 && stripe_lds_bytes(t.qlen, nst, nreg) <= (size_t)ctx->max_dyn_lds) {
+        if (stripe_lds_bytes(t.qlen, nst, nreg) <= (size_t)ctx->max_dyn_lds) {
           p.nreg = nreg;
           p.pad_ = 5;
         }
@@ -602,8 +601,18 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       int snreg = 0;
       for (size_t k = pb; k < np; ++k)
         if (plan[k].pad_ == 5) snreg = std::max(snreg, plan[k].nreg);
-      for (size_t k = pb; k < np; ++k)
-        if (plan[k].pad_ == 5) plan[k].nreg = snreg;
+      for (size_t k = pb; k < np; ++k) {
+        PlanTask &p = plan[k];
+        if (p.pad_ != 5) continue;
+        p.nreg = snreg;
+        // a last stripe of one cell would need the H of the cell under the target's end from its neighbour:
+        // such a task stays on the general kernel
+        if (p.tlen % (128 * snreg) == 1) {
+          p.nreg = 0;
+          const bool hbm = general_lds_bytes(p.qlen, p.tlen) > (size_t)ctx->max_dyn_lds;
+          p.pad_ = hbm ? 4 : 3;
+        }
+      }
     }
     if (cnt == 0) {
       cev[ci] = ChunkEv{};
