@@ -936,7 +936,10 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       unsigned layouts = 0;  // direction-flag layouts present in the chunk: one traceback instantiation each
       for (size_t k = 0; k < cnt; ++k)
         layouts |= 1u << (cp[k].nreg == 0 ? 0 : cp[k].pad_ == 2 ? 2 : cp[k].pad_ == 5 ? 3 : 1);
-      const dim3 tbg((unsigned)((cnt + 63) / 64));
+      // few tasks: a wavefront per walk (see traceback_kernel)
+      const bool tb_solo = cnt <= 8192;
+      const dim3 tbg(tb_solo ? (unsigned)cnt : (unsigned)((cnt + 63) / 64));
+      const int tbn = tb_solo ? -(int)cnt : (int)cnt;
       // A walk is one step per anti-diagonal, ~1 us each: a launch lasts as long as its longest task.  When a chunk
       // of few tasks mixes layouts, the instantiations run side by side on different streams (each after the
       // chunk's DP, collected again by the chunk's traceback stream) rather than one after the other.
@@ -958,13 +961,13 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         return s2;
       };
       if (layouts & 8u)
-        hipLaunchKernelGGL(traceback_kernel<3>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+        hipLaunchKernelGGL(traceback_kernel<3>, tbg, dim3(64), 0, tb_on(), d_plan + pb, tbn, d_pool, dir_reg, d_out, d_stage);
       if (layouts & 4u)
-        hipLaunchKernelGGL(traceback_kernel<2>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+        hipLaunchKernelGGL(traceback_kernel<2>, tbg, dim3(64), 0, tb_on(), d_plan + pb, tbn, d_pool, dir_reg, d_out, d_stage);
       if (layouts & 2u)
-        hipLaunchKernelGGL(traceback_kernel<1>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+        hipLaunchKernelGGL(traceback_kernel<1>, tbg, dim3(64), 0, tb_on(), d_plan + pb, tbn, d_pool, dir_reg, d_out, d_stage);
       if (layouts & 1u)
-        hipLaunchKernelGGL(traceback_kernel<0>, tbg, dim3(64), 0, tb_on(), d_plan + pb, (int)cnt, d_pool, dir_reg, d_out, d_stage);
+        hipLaunchKernelGGL(traceback_kernel<0>, tbg, dim3(64), 0, tb_on(), d_plan + pb, tbn, d_pool, dir_reg, d_out, d_stage);
       if (side_by_side)
         for (int j = 1; j < used_tb && j < 3; ++j) {
           if (tbs[j] == stb) continue;

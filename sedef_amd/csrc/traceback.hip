@@ -30,8 +30,13 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
                                                        const uint8_t *__restrict__ dirbase,
                                                        sdf_result *__restrict__ res,
                                                        uint32_t *__restrict__ stage) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
+  // n < 0: -n tasks, ONE per wavefront (lane 0 walks): the lanes of a wavefront leave their cached lines at
+  // different steps, so with 64 walks per wavefront every step waits for somebody's miss; a chunk of few, long
+  // tasks is walked faster with a wavefront each
+  const bool solo = n < 0;
+  if (solo && threadIdx.x != 0) return;
+  const int k = solo ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= (solo ? -n : n)) return;
   const PlanTask tk = plan[k];
   if ((tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : 1) != LAYOUT) return;
   sdf_result rr = res[tk.out_idx];
