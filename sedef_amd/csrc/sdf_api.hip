@@ -129,6 +129,7 @@ struct sdf_ctx {
   int max_dyn_lds = 64 * 1024;
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
   bool pipeline = true;        // SDF_PIPELINE=0: one chunk on one stream (isolated kernel timing)
+  int stripe_min = 1024;       // SDF_STRIPE_MIN: targets longer than this (and full band) take the stripe kernel
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
 };
@@ -227,6 +228,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   (void)hipGetLastError();
   const char *ns = getenv("SDF_NO_STRIPE");
   ctx->no_stripe = ns && ns[0] == '1';
+  if (const char *sm = getenv("SDF_STRIPE_MIN")) ctx->stripe_min = std::max(128, atoi(sm));
   const char *pl = getenv("SDF_PIPELINE");
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
@@ -574,7 +576,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
       p.cig_slot = stage_words;
       stage_words += p.cig_cap;
-      if (!p.nreg && plain_ok && !ctx->no_stripe && p.w >= std::max(t.qlen, t.tlen) && t.tlen > 1024 && t.tlen <= 8192) {
+      if ((!p.nreg || ctx->stripe_min < 1024) && plain_ok && !ctx->no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
+          t.tlen > ctx->stripe_min && t.tlen <= 8192) {
         // wide full-band task: a workgroup of wavefronts, one per stripe of 128 * nreg target positions
         const int nreg = t.tlen <= 2048 ? 1 : t.tlen <= 4096 ? 2 : 4;
         const int nst = (t.tlen + 128 * nreg - 1) / (128 * nreg);
