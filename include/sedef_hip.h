@@ -178,6 +178,18 @@ typedef struct {
 int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *seq_pool, size_t pool_bytes,
                       int kmer, sdf_anchor *out, size_t out_cap, int64_t *out_off, size_t *out_used);
 
+/* ---- anchor chaining on the GPU ---------------------------------------------------------------
+ * Replaces chain_anchors (reference: src/chain.cc:103-199) for a batch of pairs whose anchors are laid out as
+ * sdf_anchors_batch returns them: anchors[off[i] .. off[i+1]).  The reference returns, per pair, `path` (anchor
+ * indices, best chain first, each chain from its last anchor backwards) and `boundaries` ({end position in path,
+ * any-uppercase flag}, starting with {0, 0}):
+ *   path[off[i] + k]                    k-th path element of pair i (index within the pair), k < off[i+1]-off[i]
+ *   bounds[2 * (off[i] + i + b) + 0/1]  b-th boundary of pair i, b < nbound[i]
+ * path holds off[n] entries, bounds 2 * (off[n] + n), nbound n.  max_chain_gap / match_chain_score are the
+ * reference's MAX_CHAIN_GAP / MATCH_CHAIN_SCORE (src/common.h). */
+int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const int64_t *off, size_t n, int max_chain_gap,
+                    int match_chain_score, int32_t *path, int32_t *bounds, int32_t *nbound);
+
 /* ---- one-task drop-in: same contract as ksw_extz2_sse (extern/ksw2.h:50).  `km` is ignored
  * like in the reference build (no HAVE_KALLOC).  Uses a process-wide context on device 0 (or
  * the device named by SDF_DEVICE).  On a fatal error prints to stderr and exits with 120, the

@@ -1,0 +1,327 @@
+// Anchor chaining on the device: chain_anchors (reference: src/chain.cc:103-199) with the
+// priority search tree of src/segment.tpp, one GPU thread per candidate pair.
+//
+// The sweep over an anchor set is sequential (every anchor's best predecessor depends on the scores of the
+// anchors that ended before it), so the parallelism is across the pairs of a super-batch.  The three orderings
+// the reference obtains with std::sort have no ties (every key carries the anchor index), so any correct sort
+// gives the reference's order; the tree keeps the reference's array layout, split keys and comparison order,
+// which is what makes the answer of a range-maximum query unique among equal scores.  Same results as the
+// host restatement (sedef_amd/csrc/host/chain.cc), compared in tests/test_host_pipeline.py.
+#include <hip/hip_runtime.h>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+
+namespace {
+
+struct P2 {
+  int a, b;
+};
+__device__ __forceinline__ bool lt(const P2 &x, const P2 &y) { return x.a < y.a || (x.a == y.a && x.b < y.b); }
+__device__ __forceinline__ bool le(const P2 &x, const P2 &y) { return !lt(y, x); }
+__device__ __forceinline__ bool eq(const P2 &x, const P2 &y) { return x.a == y.a && x.b == y.b; }
+
+struct Pt {  // Coor of src/chain.cc:106-110
+  P2 x;
+  int score, pos;
+};
+struct Node {  // src/segment.h:21-56
+  int p, a;
+  P2 h;
+};
+
+const int TREE_MIN = (int)0x80000000;
+
+// in-place heap sort; LESS(a, b) is a strict weak order without ties here
+template <typename T, typename LESS>
+__device__ void heap_sort(T *v, int n, LESS less) {
+  auto sift = [&](int root, int end) {
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && less(v[child], v[child + 1])) ++child;
+      if (!less(v[root], v[child])) break;
+      T t = v[root];
+      v[root] = v[child];
+      v[child] = t;
+      root = child;
+    }
+  };
+  for (int i = n / 2 - 1; i >= 0; --i) sift(i, n);
+  for (int end = n - 1; end > 0; --end) {
+    T t = v[0];
+    v[0] = v[end];
+    v[end] = t;
+    sift(0, end);
+  }
+}
+
+struct Tree {
+  Node *tree;
+  Pt *pts;
+  int size;  // number of nodes
+
+  // src/segment.tpp:172-192, recursion unrolled with an explicit stack (depth <= 32)
+  __device__ void build(int npts) {
+    int st_i[40], st_s[40], st_e[40], st_state[40];
+    int sp = 0, tree_i = 0;
+    st_i[0] = 0;
+    st_s[0] = 0;
+    st_e[0] = npts;
+    st_state[0] = 0;
+    while (sp >= 0) {
+      const int i = st_i[sp], s = st_s[sp], e = st_e[sp];
+      if (i >= size) {
+        --sp;
+        continue;
+      }
+      if (st_state[sp] == 0) {
+        if (s + 1 == e) {
+          tree[i].p = -1;
+          tree[i].a = tree_i;
+          tree[i].h = pts[tree_i].x;
+          pts[tree_i].score = TREE_MIN;
+          ++tree_i;
+          --sp;
+          continue;
+        }
+        const int bnd = (s + e + 1) / 2;
+        st_state[sp] = 1;
+        ++sp;
+        st_i[sp] = 2 * i + 1;
+        st_s[sp] = s;
+        st_e[sp] = bnd;
+        st_state[sp] = 0;
+      } else if (st_state[sp] == 1) {
+        const int bnd = (s + e + 1) / 2;
+        st_state[sp] = 2;
+        ++sp;
+        st_i[sp] = 2 * i + 2;
+        st_s[sp] = bnd;
+        st_e[sp] = e;
+        st_state[sp] = 0;
+      } else {
+        tree[i].p = -1;
+        tree[i].a = -1;
+        tree[i].h = tree[2 * i + 1 + (2 * i + 2 < size)].h;
+        --sp;
+      }
+    }
+  }
+
+  // src/segment.tpp:29-66; returns a node index or -1
+  __device__ int rmq(const P2 &p, const P2 &q) const {
+    int st_i[48], st_state[48], st_m1[48];
+    int sp = 0, ret = -1;
+    st_i[0] = 0;
+    st_state[0] = 0;
+    while (sp >= 0) {
+      int i = st_i[sp];
+      if (st_state[sp] == 0) {
+        // descend along single-child cases
+        for (;;) {
+          if (i >= size) {
+            ret = -1;
+            break;
+          }
+          if (tree[i].a != -1) {
+            ret = (le(p, pts[tree[i].a].x) && le(pts[tree[i].a].x, q)) ? i : -1;
+            break;
+          }
+          const int pv = tree[i].p;
+          if (pv == -1) {
+            ret = -1;
+            break;
+          }
+          if (le(p, pts[tree[pv].a].x) && le(pts[tree[pv].a].x, q)) {
+            ret = pv;
+            break;
+          }
+          if (le(q, tree[2 * i + 1].h)) {
+            i = 2 * i + 1;
+            continue;
+          }
+          if (lt(tree[2 * i + 1].h, p)) {
+            i = 2 * i + 2;
+            continue;
+          }
+          // both children: left first
+          st_i[sp] = i;
+          st_state[sp] = 1;
+          ++sp;
+          st_i[sp] = 2 * i + 1;
+          st_state[sp] = 0;
+          ret = -2;  // marker: pushed
+          break;
+        }
+        if (ret != -2) --sp;  // this frame is done, `ret` holds its value
+      } else if (st_state[sp] == 1) {
+        st_m1[sp] = ret;
+        st_state[sp] = 2;
+        ++sp;
+        st_i[sp] = 2 * i + 2;
+        st_state[sp] = 0;
+      } else {
+        const int m1 = st_m1[sp], m2 = ret;
+        if (m1 == -1) ret = m2;
+        else if (m2 == -1) ret = m1;
+        else ret = pts[tree[m1].a].score >= pts[tree[m2].a].score ? m1 : m2;
+        --sp;
+      }
+    }
+    return ret;
+  }
+
+  __device__ int find_leaf(const P2 &q) const {
+    int leaf = 0;
+    while (leaf < size && (tree[leaf].a == -1 || !eq(q, pts[tree[leaf].a].x)))
+      leaf = 2 * leaf + 1 + (lt(tree[2 * leaf + 1].h, q) ? 1 : 0);
+    return leaf;
+  }
+
+  __device__ void activate(const P2 &q, int score) {  // src/segment.tpp:76-103
+    int leaf = find_leaf(q);
+    pts[tree[leaf].a].score = score;
+    for (int i = 0; i < size;) {
+      if (tree[i].p == -1 || pts[tree[leaf].a].score >= pts[tree[tree[i].p].a].score) {
+        const int t = tree[i].p;
+        tree[i].p = leaf;
+        leaf = t;
+      }
+      if (leaf == -1) break;
+      i = 2 * i + 1 + (lt(tree[2 * i + 1].h, pts[tree[leaf].a].x) ? 1 : 0);
+    }
+  }
+
+  __device__ void deactivate(const P2 &q) {  // src/segment.tpp:105-146
+    int leaf = find_leaf(q);
+    pts[tree[leaf].a].score = TREE_MIN;
+    for (int i = 0; i < size;) {
+      if (tree[i].p == -1) break;
+      if (tree[i].p == leaf) {
+        if (tree[i].a != -1) {
+          tree[i].p = -1;
+        } else if (2 * i + 2 < size && tree[2 * i + 2].p != -1 &&
+                   (tree[2 * i + 1].p == -1 ||
+                    pts[tree[tree[2 * i + 2].p].a].score > pts[tree[tree[2 * i + 1].p].a].score)) {
+          tree[i].p = leaf = tree[2 * i + 2].p;
+          i = 2 * i + 2;
+        } else {
+          tree[i].p = leaf = tree[2 * i + 1].p;
+          i = 2 * i + 1;
+        }
+      } else {
+        i = 2 * i + 1 + (lt(tree[2 * i + 1].h, q) ? 1 : 0);
+      }
+    }
+  }
+};
+
+}  // namespace
+
+// One thread per pair.  anchors[off[p] .. off[p+1]) in the order of generate_anchors; work: per-pair scratch at
+// ws_off[p] (in 32-bit words: 12 m + 4 nodes).  Out: path[off[p] + k] = anchor index (within the pair) of the k-th
+// element of the reference's `path`; bounds[2 * (off[p] + p + b)] = {path position, has_u} of the b-th boundary;
+// nbound[p] = number of boundaries (>= 1: the initial {0, 0}).
+__global__ __launch_bounds__(64) void chain_kernel(const sdf_anchor *__restrict__ anchors,
+                                                   const int64_t *__restrict__ off, const int64_t *__restrict__ ws_off,
+                                                   int npairs, int max_chain_gap, int match_chain_score,
+                                                   int32_t *__restrict__ work, int32_t *__restrict__ path,
+                                                   int32_t *__restrict__ bounds, int32_t *__restrict__ nbound) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const sdf_anchor *A = anchors + off[p];
+  const int m = (int)(off[p + 1] - off[p]);
+  int32_t *pth = path + off[p];
+  int32_t *bnd = bounds + 2 * (off[p] + p);
+  bnd[0] = 0;
+  bnd[1] = 0;
+  int nb = 1;
+  if (m == 0) {
+    nbound[p] = nb;
+    return;
+  }
+  int bits = 0;
+  for (unsigned v = (unsigned)m - 1u; v; v >>= 1) ++bits;
+  const int tsize = (1 << bits) << 1;
+  int32_t *w = work + ws_off[p];
+  P2 *xs = reinterpret_cast<P2 *>(w);                      // 2m events (x, anchor)
+  Pt *ys = reinterpret_cast<Pt *>(w + 4 * m);              // m points
+  Node *nodes = reinterpret_cast<Node *>(w + 8 * m);       // tsize nodes
+  int32_t *prev = w + 8 * m + 4 * tsize;                   // m
+  P2 *dp = reinterpret_cast<P2 *>(w + 9 * m + 4 * tsize);  // m (score, anchor)
+  int32_t *used = w + 11 * m + 4 * tsize;                  // m
+
+  int max_q = 0, max_r = 0;
+  for (int i = 0; i < m; ++i) {
+    const sdf_anchor a = A[i];
+    xs[2 * i] = P2{a.q, i};
+    xs[2 * i + 1] = P2{a.q + a.l, i};
+    ys[i] = Pt{P2{a.r + a.l - 1, i}, TREE_MIN, i};
+    max_q = max(max_q, a.q + a.l);
+    max_r = max(max_r, a.r + a.l);
+    prev[i] = -1;
+    dp[i] = P2{0, i};
+    used[i] = 0;
+  }
+  heap_sort(xs, 2 * m, [](const P2 &x, const P2 &y) { return lt(x, y); });
+  heap_sort(ys, m, [](const Pt &x, const Pt &y) { return lt(x.x, y.x); });
+  Tree tr{nodes, ys, tsize};
+  tr.build(m);
+
+  int deactivate_bound = 0;
+  for (int xi = 0; xi < 2 * m; ++xi) {
+    const int i = xs[xi].b;
+    const sdf_anchor a = A[i];
+    if (xs[xi].a == a.q) {  // start point
+      while (deactivate_bound < xi) {
+        const int t = xs[deactivate_bound].b;
+        if (xs[deactivate_bound].a == A[t].q + A[t].l) {  // an end point
+          if (a.q - (A[t].q + A[t].l) <= max_chain_gap) break;
+          tr.deactivate(P2{A[t].r + A[t].l - 1, t});
+        }
+        ++deactivate_bound;
+      }
+      const int wgt = match_chain_score * a.has_u + (match_chain_score / 2) * (a.l - a.has_u);
+      const int node = tr.rmq(P2{a.r - max_chain_gap, 0}, P2{a.r - 1, m});
+      int j = node == -1 ? -1 : nodes[node].a;
+      if (j != -1 && ys[j].score != TREE_MIN) {
+        j = ys[j].pos;
+        const sdf_anchor pa = A[j];
+        const int gap = (a.q - (pa.q + pa.l) + a.r - (pa.r + pa.l));
+        if (wgt + dp[j].a - gap > 0) {
+          dp[i].a = wgt + dp[j].a - gap;
+          prev[i] = j;
+        } else {
+          dp[i].a = wgt;
+        }
+      } else {
+        dp[i].a = wgt;
+      }
+    } else {  // end point: the anchor becomes available as a predecessor
+      const int gap = (max_q + 1 - (a.q + a.l) + max_r + 1 - (a.r + a.l));
+      tr.activate(P2{a.r + a.l - 1, i}, dp[i].a - gap);
+    }
+  }
+  // NB: dp[] is indexed by anchor above and sorted (descending) only now
+  heap_sort(dp, m, [](const P2 &x, const P2 &y) { return lt(y, x); });
+  int np = 0;
+  for (int k = 0; k < m; ++k) {
+    int maxi = dp[k].b;
+    if (used[maxi]) continue;
+    int has_u = 0;
+    while (maxi != -1 && !used[maxi]) {
+      pth[np++] = maxi;
+      has_u += A[maxi].has_u;
+      used[maxi] = 1;
+      maxi = prev[maxi];
+    }
+    bnd[2 * nb] = np;
+    bnd[2 * nb + 1] = has_u != 0;  // int -> bool: "any uppercase anchor"
+    ++nb;
+  }
+  nbound[p] = nb;
+}
+
+}  // namespace sdf

@@ -333,4 +333,26 @@ int sdfh_chains(const char *query, const char *ref, int kmer, char *buf, size_t 
   }
 }
 
+// chain_anchors on a caller-provided anchor list: path (m entries), bounds (2*(m+1)), returns #boundaries
+int sdfh_chain_raw(const int32_t *anchors, int m, int max_chain_gap, int match_chain_score, int32_t *path,
+                   int32_t *bounds) {
+  try {
+    Params p;
+    p.max_chain_gap = max_chain_gap;
+    p.match_chain_score = match_chain_score;
+    std::vector<Anchor> an(m);
+    for (int i = 0; i < m; i++) an[i] = Anchor{anchors[4 * i], anchors[4 * i + 1], anchors[4 * i + 2], anchors[4 * i + 3]};
+    auto ch = chain_anchors(an, p);
+    for (size_t k = 0; k < ch.first.size(); k++) path[k] = ch.first[k];
+    for (size_t b = 0; b < ch.second.size(); b++) {
+      bounds[2 * b] = ch.second[b].first;
+      bounds[2 * b + 1] = ch.second[b].second ? 1 : 0;
+    }
+    return (int)ch.second.size();
+  } catch (std::string &s) {
+    g_err = s;
+    return -1;
+  }
+}
+
 }  // extern "C"

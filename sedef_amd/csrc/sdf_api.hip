@@ -119,6 +119,7 @@ struct sdf_ctx {
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   HostBuf host_plan, host_order;  // pinned staging of the plan
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
+  DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
   std::vector<hipEvent_t> events;
   float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 DP, 1 traceback, 2 compaction, 3 stream total, 4 host planning before the
@@ -250,7 +251,8 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
     if (q) (void)hipStreamSynchronize(q);
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
   for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
-                    &ctx->an_pos, &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff})
+                    &ctx->an_pos, &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff, &ctx->ch_an, &ctx->ch_off,
+                    &ctx->ch_wsoff, &ctx->ch_work, &ctx->ch_path, &ctx->ch_bounds, &ctx->ch_nb})
     b->release();
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
                     &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
@@ -1232,6 +1234,61 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
   SDF_HIP(ctx->an_pool.reserve(pool_bytes + 16));
   SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
   return anchors_range(ctx, pairs, n, (const char *)ctx->an_pool.p, kmer, out, out_cap, out_off, out_used, ctx->stream);
+}
+
+// ---- anchor chaining (reference: src/chain.cc:103-199) ---------------------------------------------------
+extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const int64_t *off, size_t n, int max_chain_gap,
+                               int match_chain_score, int32_t *path, int32_t *bounds, int32_t *nbound) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  if (!off || !bounds || !nbound || n >= (1u << 24)) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  if (n == 0) return SDF_OK;
+  std::vector<int64_t> ws_off(n + 1);
+  int64_t words = 0;
+  for (size_t i = 0; i < n; i++) {
+    const int64_t m = off[i + 1] - off[i];
+    if (off[0] != 0 || m < 0 || m >= (1 << 26)) {
+      ctx->err = "anchor offsets must start at 0, ascend, and hold fewer than 2^26 anchors per pair";
+      return SDF_ERR_INVALID;
+    }
+    ws_off[i] = words;
+    if (m > 0) {
+      int bits = 0;
+      for (unsigned v = (unsigned)m - 1u; v; v >>= 1) ++bits;
+      words += 12 * m + 4 * ((int64_t)2 << bits);
+    }
+  }
+  ws_off[n] = words;
+  const size_t total = (size_t)off[n];
+  if (total && (!anchors || !path)) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  SDF_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  SDF_HIP(ctx->ch_an.reserve(total * sizeof(sdf_anchor) + 16));
+  SDF_HIP(ctx->ch_off.reserve((n + 1) * 8));
+  SDF_HIP(ctx->ch_wsoff.reserve((n + 1) * 8));
+  SDF_HIP(ctx->ch_work.reserve((size_t)words * 4 + 16));
+  SDF_HIP(ctx->ch_path.reserve(total * 4 + 16));
+  SDF_HIP(ctx->ch_bounds.reserve((total + n) * 8));
+  SDF_HIP(ctx->ch_nb.reserve(n * 4));
+  if (total) SDF_HIP(hipMemcpyAsync(ctx->ch_an.p, anchors, total * sizeof(sdf_anchor), hipMemcpyHostToDevice, st));
+  SDF_HIP(hipMemcpyAsync(ctx->ch_off.p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+  SDF_HIP(hipMemcpyAsync(ctx->ch_wsoff.p, ws_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(sdf::chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
+                     (const sdf_anchor *)ctx->ch_an.p, (const int64_t *)ctx->ch_off.p, (const int64_t *)ctx->ch_wsoff.p,
+                     (int)n, max_chain_gap, match_chain_score, (int32_t *)ctx->ch_work.p, (int32_t *)ctx->ch_path.p,
+                     (int32_t *)ctx->ch_bounds.p, (int32_t *)ctx->ch_nb.p);
+  SDF_HIP(hipGetLastError());
+  if (total) SDF_HIP(hipMemcpyAsync(path, ctx->ch_path.p, total * 4, hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipMemcpyAsync(bounds, ctx->ch_bounds.p, (total + n) * 8, hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipMemcpyAsync(nbound, ctx->ch_nb.p, n * 4, hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  return SDF_OK;
 }
 
 // ---- one-task drop-in with the reference's exact signature (extern/ksw2.h:50) -----------------

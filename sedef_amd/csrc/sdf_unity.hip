@@ -5,4 +5,5 @@
 #include "extz2_stripe.hip"
 #include "traceback.hip"
 #include "anchors.hip"
+#include "chain.hip"
 #include "sdf_api.hip"

@@ -74,6 +74,9 @@ def load_library():
     L.sdf_anchors_batch.restype = C.c_int
     L.sdf_anchors_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_void_p,
                                     C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.sdf_chain_batch.restype = C.c_int
+    L.sdf_chain_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
     L.sdf_last_ms.restype = C.c_float
     L.sdf_last_ms.argtypes = [C.c_void_p, C.c_int]
     L.sdf_last_launches.restype = C.c_int
@@ -213,6 +216,26 @@ class Extz2Engine:
             self._check(rc)
             break
         return [[tuple(int(x) for x in a) for a in out[offs[k]:offs[k + 1]]] for k in range(n)]
+
+    def chain_batch(self, anchor_lists, max_chain_gap=210, match_chain_score=4):
+        """GPU chain_anchors.  anchor_lists: one (m, 4) int32 array of (q, r, l, has_u) per pair.  Returns one
+        (path, boundaries) per pair like the reference's chain_anchors (include/sedef_hip.h: sdf_chain_batch)."""
+        n = len(anchor_lists)
+        arrs = [np.ascontiguousarray(a, dtype=np.int32).reshape(-1, 4) for a in anchor_lists]
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum([len(a) for a in arrs])
+        total = int(off[n])
+        flat = np.concatenate(arrs) if total else np.zeros((0, 4), np.int32)
+        path = np.zeros(max(total, 1), np.int32)
+        bounds = np.zeros(2 * (total + n) + 2, np.int32)
+        nb = np.zeros(max(n, 1), np.int32)
+        self._check(self.lib.sdf_chain_batch(self.ctx, flat.ctypes.data, off.ctypes.data, n, max_chain_gap,
+                                             match_chain_score, path.ctypes.data, bounds.ctypes.data, nb.ctypes.data))
+        out = []
+        for i in range(n):
+            b0 = 2 * (int(off[i]) + i)
+            out.append((path[off[i]:off[i + 1]].copy(), bounds[b0:b0 + 2 * int(nb[i])].reshape(-1, 2).copy()))
+        return out
 
     def last_ms(self, which):
         return float(self.lib.sdf_last_ms(self.ctx, which))

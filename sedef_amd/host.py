@@ -96,6 +96,20 @@ def chains(q, r, kmer=11):
     return out
 
 
+def chain_raw(anchors, max_chain_gap=210, match_chain_score=4):
+    """chain_anchors on an (m, 4) int32 array of (q, r, l, has_u): returns (path, boundaries)."""
+    import numpy as np
+    lib = load_host()
+    a = np.ascontiguousarray(anchors, dtype=np.int32).reshape(-1, 4)
+    m = len(a)
+    path = np.zeros(max(m, 1), np.int32)
+    bounds = np.zeros(2 * (m + 1), np.int32)
+    lib.sdfh_chain_raw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    nb = lib.sdfh_chain_raw(a.ctypes.data, m, max_chain_gap, match_chain_score, path.ctypes.data, bounds.ctypes.data)
+    _err(lib, min(nb, 0))
+    return path[:m].copy(), bounds[:2 * nb].reshape(-1, 2).copy()
+
+
 def fasta_get(path, name, start, end):
     lib, buf = load_host(), _buffer()
     e = C.c_int(end)

@@ -270,3 +270,39 @@ def test_gpu_anchors_equal_host_anchors(host):
     for (q, r, same, delta), g in zip(pairs, got):
         exp = host.anchors(q, r, 11, same_chr=same, qstart=0, rstart=delta)
         assert g == exp, (len(q), len(r), same, delta, len(g), len(exp))
+
+
+def _chain_cases(host):
+    rng = np.random.default_rng(23)
+    cases = [np.zeros((0, 4), np.int32), np.array([[5, 9, 11, 1]], np.int32),
+             np.array([[0, 0, 12, 0], [30, 31, 15, 1]], np.int32),
+             np.array([[0, 0, 12, 0], [30, 31, 15, 1], [400, 80, 11, 0]], np.int32)]
+    for it in range(30):  # anchors of mutated copies: real chains, gaps, repeats
+        q = hostgen.rseq(rng, int(rng.integers(50, 6000)), 0.004 if it % 2 else 0.0)
+        r = hostgen.rseq(rng, int(rng.integers(0, 300))) + hostgen.mut(rng, q, rng.random() * 0.15) + \
+            hostgen.rseq(rng, int(rng.integers(0, 300)))
+        if it % 4 == 0:
+            rep = "ACGTTGCAACGT" * 40
+            q, r = q[:200] + rep + q[200:], r[:100] + rep + r[100:]
+        cases.append(np.array(host.anchors(q, r, 11), np.int32).reshape(-1, 4))
+    for it in range(30):  # random anchor sets with many equal scores and coordinates (tie order)
+        m = int(rng.integers(1, 400))
+        span = int(rng.integers(20, 3000))
+        a = np.stack([rng.integers(0, span, m), rng.integers(0, span, m), rng.integers(11, 14, m),
+                      rng.integers(0, 2, m)], 1).astype(np.int32)
+        cases.append(a)
+    return cases
+
+
+@pytest.mark.gpu
+def test_gpu_chains_equal_host_chains(host):
+    """sdf_chain_batch (one GPU thread per pair) returns chain_anchors' path and boundaries exactly."""
+    import sedef_amd
+    eng = sedef_amd.Extz2Engine(0)
+    cases = _chain_cases(host)
+    for gap, score in ((210, 4), (50, 3), (1000, 5)):
+        got = eng.chain_batch(cases, gap, score)
+        for a, (gp, gb) in zip(cases, got):
+            ep, eb = host.chain_raw(a, gap, score)
+            assert np.array_equal(gp, ep) and np.array_equal(gb, eb), (len(a), gap, score)
+    assert eng.chain_batch([]) == []
