@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""One warm-up and one timed call of a mixture batch, for `rocprofv3 --kernel-trace` + profiles/timeline.py.
+usage: mix_probe.py mm8|hg19 [n]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import shapes_bench  # noqa: E402
+from shapes_bench import bench, sedef_amd  # noqa: E402
+
+which = sys.argv[1] if len(sys.argv) > 1 else "mm8"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else (3000 if which == "mm8" else 300000)
+eng = sedef_amd.Extz2Engine(0, 64 << 30)
+dev = torch.device("cuda", 0)
+if which == "mm8":
+    b, w = bench.synth_mm8_mixture(n, seed=505)
+else:
+    b, w = bench.synth_hg19_mixture(n, seed=404, big=6000)
+shapes_bench.run(which, b, w, eng, dev, steps=1)

@@ -80,11 +80,26 @@ class GpuProvider : public DpProvider {
   ~GpuProvider() override { sdf_destroy(ctx_); }
   std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) override {
     std::vector<Cigar> out(reqs.size());
-    if (reqs.empty()) return out;
+    Raw raw;
+    run_raw(reqs, p, raw);
+    const auto tp2 = std::chrono::steady_clock::now();
+    for (size_t r = 0; r < reqs.size(); r++) out[r] = raw.cigar(r);
+    t_unpack += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count();
+    return out;
+  }
+
+  bool run_raw(const std::vector<DpRequest> &reqs, const Params &p, Raw &raw) override {
+    raw.first_task.assign(reqs.size() + 1, 0);
+    raw.off.clear();
+    raw.cnt.clear();
+    if (reqs.empty()) return true;
     std::vector<TaskRef> tr;
     std::vector<uint8_t> pool;
+    const auto tp0 = std::chrono::steady_clock::now();
     expand(reqs, p, tr, pool);
-    if (tr.empty()) return out;
+    for (auto &t : tr) raw.first_task[t.req + 1]++;  // tasks are in request order
+    for (size_t r = 0; r < reqs.size(); r++) raw.first_task[r + 1] += raw.first_task[r];
+    if (tr.empty()) return true;
     std::vector<sdf_task> tasks(tr.size());
     size_t cap = 0;
     for (size_t k = 0; k < tr.size(); k++) {
@@ -109,13 +124,25 @@ class GpuProvider : public DpProvider {
     sc.gapo = (int8_t)(-p.gap_open);
     sc.gape = (int8_t)(-p.gap_extend);
     std::vector<sdf_result> res(tr.size());
-    std::vector<uint32_t> cig(cap);
+    // (not a std::vector: the capacity is the worst case, hundreds of megabytes that would be zero-filled and
+    // paged in although the call writes only the words it reports in `used`)
+    std::unique_ptr<uint32_t[]> cig(new uint32_t[cap]);
     size_t used = 0;
+    const auto tp1 = std::chrono::steady_clock::now();
     const int rc = sdf_extz2_batch(ctx_, &sc, tasks.data(), tasks.size(), pool.data(), pool.size(),
-                                   SDF_WANT_CIGAR | SDF_WANT_SCORE, res.data(), cig.data(), cap, &used);
+                                   SDF_WANT_CIGAR | SDF_WANT_SCORE, res.data(), cig.get(), cap, &used);
     if (rc != SDF_OK) throw std::string("DP batch failed: ") + sdf_last_error(ctx_);
-    for (size_t k = 0; k < tr.size(); k++) append_ops(out[tr[k].req], cig.data() + res[k].cigar_off, res[k].n_cigar);
-    return out;
+    const auto tp2 = std::chrono::steady_clock::now();
+    raw.off.resize(tr.size());
+    raw.cnt.resize(tr.size());
+    for (size_t k = 0; k < tr.size(); k++) {
+      raw.off[k] = res[k].cigar_off;
+      raw.cnt[k] = (int32_t)res[k].n_cigar;
+    }
+    raw.words = std::move(cig);
+    t_pack += std::chrono::duration<double>(tp1 - tp0).count();
+    t_call += std::chrono::duration<double>(tp2 - tp1).count();
+    return true;
   }
 
   // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
@@ -202,6 +229,12 @@ class TestProvider : public DpProvider {
 };
 
 }  // namespace
+
+Cigar DpProvider::Raw::cigar(size_t req) const {
+  Cigar c;
+  for (size_t k = first_task[req]; k < first_task[req + 1]; k++) append_ops(c, words.get() + off[k], cnt[k]);
+  return c;
+}
 
 std::unique_ptr<DpProvider> make_gpu_provider(int device) { return std::unique_ptr<DpProvider>(new GpuProvider(device)); }
 std::unique_ptr<DpProvider> make_test_provider(test_dp_fn fn) { return std::unique_ptr<DpProvider>(new TestProvider(fn)); }
@@ -570,6 +603,11 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   set_alignment_scoring(p);
   GenerateStats st;
   double dp_secs = 0, anchor_secs = 0;
+  double t_fetch = 0, t_adv = 0, t_longest = 0, t_sum = 0, t_collect = 0, t_out = 0;  // wall seconds of the host phases of the driver
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [](std::chrono::steady_clock::time_point a) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+  };
   g_us_chain = 0;
   g_us_rest = 0;
   std::vector<Hit> schedule = read_schedule(bed_path, log);
@@ -597,14 +635,16 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       }
     }
     std::vector<Item> items(n);
-    for (int k = 0; k < n; k++) {  // src/align_main.cc:299-306
+    const auto tf = now();
+    parallel_for(n, [&](int k) {  // src/align_main.cc:299-306
       Item &it = items[k];
       it.h = schedule[base + k];
       it.fa = fr.get_sequence(it.h.query->name, it.h.query_start, &it.h.query_end);
       it.fb = fr.get_sequence(it.h.ref->name, it.h.ref_start, &it.h.ref_end);
       if (it.h.ref->is_rc) it.fb = rc(it.fb);
       it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
-    }
+    });
+    t_fetch += since(tf);
     {  // seed anchors of the whole super-batch in one device pass, when the provider offers it
       std::vector<DpProvider::AnchorJob> aj(n);
       for (int k = 0; k < n; k++) {
@@ -620,18 +660,40 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       }
     }
     // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch
+    // results of the previous round: Cigars per pair (provider without a raw form), or the raw device words
+    // and each pair's first request in them -- then the pair's own thread builds (and later frees) its Cigars
     std::vector<std::vector<Cigar>> results(n);
+    DpProvider::Raw raw;
+    bool have_raw = false;
+    std::vector<size_t> first_req(n, 0), n_req(n, 0);
     for (;;) {
       std::vector<DpRequest> batch;
       std::vector<std::pair<int, size_t>> owners;
       bool any = false;
+      const auto tadv = now();
+      std::atomic<long long> longest_us(0), sum_us(0);
       parallel_for(n, [&](int k) {
         Item &it = items[k];
         it.pending.clear();
         if (it.job->done()) return;
-        it.pending = it.job->advance(results[k]);
-        results[k].clear();
+        const auto tj = std::chrono::steady_clock::now();
+        if (have_raw) {
+          std::vector<Cigar> mine(n_req[k]);
+          for (size_t r = 0; r < n_req[k]; r++) mine[r] = raw.cigar(first_req[k] + r);
+          it.pending = it.job->advance(mine);
+        } else {
+          it.pending = it.job->advance(results[k]);
+          results[k].clear();
+        }
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tj).count();
+        sum_us += us;
+        long long cur = longest_us.load();
+        while (us > cur && !longest_us.compare_exchange_weak(cur, us)) {}
       });
+      t_adv += since(tadv);
+      t_longest += longest_us.load() / 1e6;
+      t_sum += sum_us.load() / 1e6;
+      const auto tc = now();
       for (int k = 0; k < n; k++) {
         Item &it = items[k];
         if (!it.pending.empty()) {
@@ -641,20 +703,35 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
           any = true;
         }
       }
+      t_collect += since(tc);
       if (!any) break;
       st.rounds++;
       const auto td = std::chrono::steady_clock::now();
-      std::vector<Cigar> got = dp.run(batch, p);
+      std::vector<Cigar> got;
+      have_raw = dp.run_raw(batch, p, raw);
+      if (!have_raw) got = dp.run(batch, p);
       dp_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - td).count();
+      const auto tc2 = now();
       size_t cur = 0;
+      std::fill(n_req.begin(), n_req.end(), 0);
       for (auto &o : owners) {
-        results[o.first].assign(got.begin() + cur, got.begin() + cur + o.second);
+        if (have_raw) {
+          first_req[o.first] = cur;
+          n_req[o.first] = o.second;
+        } else {
+          results[o.first].assign(std::make_move_iterator(got.begin() + cur),
+                                  std::make_move_iterator(got.begin() + cur + o.second));
+        }
         cur += o.second;
       }
+      t_collect += since(tc2);
     }
-    for (int k = 0; k < n; k++) {  // src/align_main.cc:314-331
+    const auto tout = now();
+    std::vector<std::string> lines(n);  // formatted on the host threads, written in schedule order
+    std::vector<int> nhits(n, 0);
+    parallel_for(n, [&](int k) {  // src/align_main.cc:314-331
       Item &it = items[k];
-      st.lines++;
+      const std::string tail = "\t" + it.h.to_bed(false) + "\n";
       for (auto &hh : it.job->hits()) {
         hh.query_start += it.h.query_start;
         hh.query_end += it.h.query_start;
@@ -669,10 +746,17 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         }
         hh.query->name = it.h.query->name;
         hh.ref->name = it.h.ref->name;
-        st.total_written++;
-        fprintf(out, "%s\t%s\n", hh.to_bed(false).c_str(), it.h.to_bed(false).c_str());
+        nhits[k]++;
+        lines[k] += hh.to_bed(false);
+        lines[k] += tail;
       }
+    });
+    for (int k = 0; k < n; k++) {
+      st.lines++;
+      st.total_written += nhits[k];
+      if (!lines[k].empty()) fwrite(lines[k].data(), 1, lines[k].size(), out);
     }
+    t_out += since(tout);
     fprintf(log, "\r Processing %d out of %d (%.1f%%)", std::min(base + n, total), total,
             100.0 * std::min(base + n, total) / std::max(total, 1));
   }
@@ -685,6 +769,9 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
                "provider %.2fs wall in %d rounds, %lld tasks, %.3g cells]\n",
           g_us_chain.load() / 1e6, g_us_rest.load() / 1e6, anchor_secs, dp_secs, st.rounds, (long long)dp.tasks,
           (double)dp.cells);
+  fprintf(log, "  [driver wall: sequence fetch %.2fs, job rounds on host threads %.2fs (longest single jobs %.2fs, all jobs %.2fs thread time), request collection %.2fs, output %.2fs; "
+               "DP provider: request packing %.2fs, device call %.2fs, CIGAR unpacking %.2fs]\n",
+          t_fetch, t_adv, t_longest, t_sum, t_collect, t_out, dp.t_pack, dp.t_call, dp.t_unpack);
   return st;
 }
 

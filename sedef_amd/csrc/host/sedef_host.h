@@ -51,6 +51,17 @@ class DpProvider {
  public:
   virtual ~DpProvider() {}
   virtual std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) = 0;
+  // Optional raw form: the device's CIGAR words of every DP task, and the tasks of every request; the caller turns
+  // them into Cigars where it consumes them (the stage driver does that on the thread that owns the pair, so that
+  // the memory of a pair is allocated and freed by one thread).  Returns false if the provider has no raw form.
+  struct Raw {
+    std::unique_ptr<uint32_t[]> words;
+    std::vector<int64_t> off;        // per task: first word
+    std::vector<int32_t> cnt;        // per task: number of words
+    std::vector<size_t> first_task;  // per request (+1): its tasks are [first_task[r], first_task[r+1])
+    Cigar cigar(size_t req) const;
+  };
+  virtual bool run_raw(const std::vector<DpRequest> &, const Params &, Raw &) { return false; }
   // Optional: generate_anchors for a batch of pairs on the device.  Returns false if the provider cannot do it
   // for these inputs (the caller then computes them on the host with generate_anchors()).
   struct AnchorJob {
@@ -62,6 +73,7 @@ class DpProvider {
     return false;
   }
   int64_t tasks = 0, cells = 0;  // statistics
+  double t_pack = 0, t_call = 0, t_unpack = 0;  // wall seconds inside run(): request packing, device call, unpacking
 };
 
 // The product provider: sdf_extz2_batch on a HIP device.  Throws std::string when no device / library.

@@ -3,6 +3,7 @@
 // genome.fa bucket.bed`.  stdout carries only the BEDPE lines; everything else goes to stderr.
 // The DP runs on the GPU; without a HIP device the command fails with exit code 1.
 #include <cstdio>
+#include <malloc.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -65,6 +66,11 @@ int main(int argc, char **argv) {
   // the DP path keeps four streams busy; give the HIP runtime more hardware queues than its default of four so
   // that no two of them share one (has to be in the environment before the runtime initialises)
   setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // the per-pair host work allocates and frees megabytes on every thread: keep freed memory in the arenas instead
+  // of returning it to the kernel each time (munmap / page faults serialise the threads on the address-space lock)
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+  mallopt(M_TOP_PAD, 256 << 20);
   if (argc < 2) {
     fprintf(stderr, "Arguments missing: please run sedef help for more information.\n");
     return 1;

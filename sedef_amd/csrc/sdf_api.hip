@@ -116,6 +116,7 @@ struct sdf_ctx {
   hipStream_t stream = nullptr;
   size_t ws_budget = 0;
   hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr;  // chunk pipeline
+  hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};    // more room for launches that end in a tail
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   HostBuf host_plan, host_order;  // pinned staging of the plan
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
@@ -247,7 +248,8 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
 extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  for (hipStream_t q : {ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream})
+  for (hipStream_t q : {ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
+                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3]})
     if (q) (void)hipStreamSynchronize(q);
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
   for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
@@ -258,7 +260,8 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
                     &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
     b->release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream})
+  for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0], ctx->aux_stream[1],
+                        ctx->aux_stream[2], ctx->aux_stream[3]})
     if (s) (void)hipStreamDestroy(s);
   ctx->host_plan.release();
   ctx->host_order.release();
@@ -514,7 +517,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     int kmax = 0;     // stripe kernel: wavefronts per workgroup (largest stripe count in the class)
   };
   struct ChunkEv {
-    hipEvent_t dp0, dpe[4], tb0, tb1;  // plan uploaded; end of the DP launches per stream; traceback (begin, end)
+    hipEvent_t dp0, dpe[8], tb0, tb1;  // plan uploaded; end of the DP launches per stream; traceback (begin, end)
   };
   std::vector<ChunkEv> cev(chunks.size());
   std::vector<int32_t> win_need, partner;
@@ -524,7 +527,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   size_t nord = 0;         // launch-order entries so far
   int64_t stage_words = 0;
   float plan_first_ms = 0.f;
-  double qload[4] = {0, 0, 0, 0};  // estimated DP work queued on each stream during this call
+  double qload[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // estimated DP work queued on each stream during this call
 
   std::vector<size_t> normal_ids;  // chunk indices of the ordinary chunks, in launch order
   const bool have_heavy = !chunks.empty() && chunks[0].heavy;
@@ -801,8 +804,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     // A heavy chunk uploads and traces back on the caller's stream and uses the workspace slice behind the regions.
     const bool piped = pipelined && !heavy_chunk;
     const size_t nj = normal_ids.size();  // ordinal among the ordinary chunks
-    hipStream_t Q[4] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
-                        pipelined ? ctx->tb_stream : st};
+    if (pipelined && chunks.size() == 1 && !ctx->aux_stream[0])  // created when a one-chunk batch first wants them
+      for (auto &a : ctx->aux_stream)
+        if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) {
+          (void)hipGetLastError();
+          a = nullptr;
+        }
+    hipStream_t Q[8] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
+                        pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
+                        ctx->aux_stream[3]};
+    // Q[4..7]: only the least-loaded-stream assignment below uses them (one-chunk batches without heavy tasks)
     const int ui = piped ? (have_heavy ? 2 : 1 + (int)(nj & 1)) : 0;  // upload stream (and the big launches')
     hipStream_t stb = piped ? Q[3] : st;
     uint8_t *dir_reg = heavy_chunk ? d_dir + nreg_ws * region_need : d_dir + (nj % nreg_ws) * region_need;
@@ -817,14 +828,14 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     ev.tb0 = next_event(ctx, evc);
     ev.tb1 = next_event(ctx, evc);
     SDF_HIP(hipEventRecord(ev.dp0, Q[ui]));
-    bool used[4] = {false, false, false, false};
+    bool used[8] = {false, false, false, false, false, false, false, false};
     size_t gs_off = 0;
     {  // HBM state slabs of the very long tasks of this chunk: one allocation, a slice per launch
       size_t gs_total = 0;
       for (const Launch &L : launches)
         if (L.bs == 1000 || L.bs == 1001 || L.bs == 2001) gs_total += L.lds * L.cnt;
       if (gs_total > ctx->gstate_buf.cap) {  // growing frees the old slabs: nothing may be using them
-        for (hipStream_t q : {st, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream})
+        for (hipStream_t q : Q)
           if (q) SDF_HIP(hipStreamSynchronize(q));
         if (ctx->gstate_buf.reserve(gs_total) != hipSuccess) {
           ctx->err = "cannot allocate the HBM state slabs for very long tasks";
@@ -844,8 +855,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         } else if (have_heavy) {
           qi = heavy_chunk ? (qload[1] < qload[0] ? 1 : 0) : (qload[3] < qload[2] ? 3 : 2);
         } else {
-          for (int q = 1; q < 4; ++q)
-            if (qload[q] < qload[qi]) qi = q;
+          // (a batch of one chunk has nothing else to overlap with: its launches spread over the extra streams too)
+          for (int q = 1; q < (chunks.size() == 1 ? 8 : 4); ++q)
+            if (Q[q] && qload[q] < qload[qi]) qi = q;
         }
       }
       qload[qi] += L.est;
@@ -930,7 +942,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       }
       ++ctx->launches;
     }
-    for (int q = 0; q < 4; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
+    for (int q = 0; q < 8; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
       if (!used[q]) continue;
       ev.dpe[q] = next_event(ctx, evc);
       SDF_HIP(hipEventRecord(ev.dpe[q], Q[q]));
