@@ -8,7 +8,9 @@
 #include <cstring>
 #include <fstream>
 #include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <set>
 #include <thread>
 
@@ -73,11 +75,12 @@ void fill_mat(const Params &p, int8_t mat[25]) {  // src/align.cc:41-44
 
 class GpuProvider : public DpProvider {
  public:
-  explicit GpuProvider(int device) {
+  explicit GpuProvider(int device) : device_(device) {
     ctx_ = sdf_create(device, 0);
     if (!ctx_) throw std::string("GPU DP backend unavailable: ") + sdf_last_error(nullptr);
   }
   ~GpuProvider() override { sdf_destroy(ctx_); }
+  std::unique_ptr<DpProvider> clone() override { return std::unique_ptr<DpProvider>(new GpuProvider(device_)); }
   std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) override {
     std::vector<Cigar> out(reqs.size());
     Raw raw;
@@ -191,6 +194,7 @@ class GpuProvider : public DpProvider {
 
  private:
   sdf_ctx *ctx_;
+  int device_;
   int64_t tasks_ = 0;
 };
 
@@ -596,14 +600,16 @@ static std::vector<Hit> read_schedule(const std::string &bed_path, FILE *log) { 
 }
 
 GenerateStats generate_alignments(const std::string &ref_path, const std::string &bed_path, int kmer_size,
-                                  const Params &p_in, DpProvider &dp, FILE *out, FILE *log, int super_batch) {
+                                  const Params &p_in, DpProvider &dp0, FILE *out, FILE *log, int super_batch) {
   const auto t0 = std::chrono::steady_clock::now();
   Params p = p_in;
   p.kmer = kmer_size;
   set_alignment_scoring(p);
   GenerateStats st;
-  double dp_secs = 0, anchor_secs = 0;
-  double t_fetch = 0, t_adv = 0, t_longest = 0, t_sum = 0, t_collect = 0, t_out = 0;  // wall seconds of the host phases of the driver
+  struct Acc {  // wall seconds of the phases of one lane of the driver
+    double dp_secs = 0, anchor_secs = 0, t_fetch = 0, t_adv = 0, t_longest = 0, t_sum = 0, t_collect = 0, t_out = 0;
+    int rounds = 0;
+  };
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto since = [](std::chrono::steady_clock::time_point a) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
@@ -623,17 +629,28 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   };
   // Pairs per super-batch: every round of a super-batch is one device batch call (planning, launches, one
   // synchronisation), so few large super-batches beat many small ones; bounded by the sequence bytes held at once.
+  // Lanes: super-batches are independent, so two of them are in flight, each on its own device context -- while
+  // one waits for the device, the host threads work on the other.  A second context costs ~0.1 s to set up, so
+  // small inputs stay on one lane; medium ones are cut into at least two super-batches per lane.
+  int nlanes = total >= 4096 ? 2 : 1;
+  if (const char *e = getenv("SDF_LANES")) nlanes = std::max(1, std::min(4, atoi(e)));
+  if (nlanes > 1) super_batch = std::max(1024, std::min(super_batch, (total + 2 * nlanes - 1) / (2 * nlanes)));
   if (const char *sb = getenv("SDF_SUPER_BATCH")) super_batch = std::max(1, atoi(sb));
+  std::vector<std::pair<int, int>> batches;  // (first pair, pairs)
   for (int base = 0, n = 0; base < total; base += n) {
-    {
-      int64_t bytes = 0;
-      n = 0;
-      while (base + n < total && n < super_batch && bytes < ((int64_t)1 << 30)) {
-        const Hit &h = schedule[base + n];
-        bytes += (int64_t)(h.query_end - h.query_start) + (h.ref_end - h.ref_start);
-        ++n;
-      }
+    int64_t bytes = 0;
+    n = 0;
+    while (base + n < total && n < super_batch && bytes < ((int64_t)1 << 30)) {
+      const Hit &h = schedule[base + n];
+      bytes += (int64_t)(h.query_end - h.query_start) + (h.ref_end - h.ref_start);
+      ++n;
     }
+    batches.push_back({base, n});
+  }
+
+  // One super-batch from the sequences to its formatted output lines (one string per pair, schedule order).
+  auto do_batch = [&](int base, int n, DpProvider &dp, Acc &a, std::vector<std::string> &lines,
+                      std::vector<int> &nhits) {
     std::vector<Item> items(n);
     const auto tf = now();
     parallel_for(n, [&](int k) {  // src/align_main.cc:299-306
@@ -644,7 +661,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       if (it.h.ref->is_rc) it.fb = rc(it.fb);
       it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
     });
-    t_fetch += since(tf);
+    a.t_fetch += since(tf);
     {  // seed anchors of the whole super-batch in one device pass, when the provider offers it
       std::vector<DpProvider::AnchorJob> aj(n);
       for (int k = 0; k < n; k++) {
@@ -653,14 +670,14 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
                  h.ref_start - h.query_start};
       }
       std::vector<std::vector<Anchor>> got;
-      const auto ta = std::chrono::steady_clock::now();
+      const auto ta = now();
       if (dp.anchors(aj, p.kmer, got)) {
         for (int k = 0; k < n; k++) items[k].job->set_anchors(std::move(got[k]));
-        anchor_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+        a.anchor_secs += since(ta);
       }
     }
-    // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch
-    // results of the previous round: Cigars per pair (provider without a raw form), or the raw device words
+    // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch.
+    // Results of the previous round: Cigars per pair (provider without a raw form), or the raw device words
     // and each pair's first request in them -- then the pair's own thread builds (and later frees) its Cigars
     std::vector<std::vector<Cigar>> results(n);
     DpProvider::Raw raw;
@@ -685,14 +702,16 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
           it.pending = it.job->advance(results[k]);
           results[k].clear();
         }
-        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tj).count();
+        const long long us =
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tj).count();
         sum_us += us;
         long long cur = longest_us.load();
-        while (us > cur && !longest_us.compare_exchange_weak(cur, us)) {}
+        while (us > cur && !longest_us.compare_exchange_weak(cur, us)) {
+        }
       });
-      t_adv += since(tadv);
-      t_longest += longest_us.load() / 1e6;
-      t_sum += sum_us.load() / 1e6;
+      a.t_adv += since(tadv);
+      a.t_longest += longest_us.load() / 1e6;
+      a.t_sum += sum_us.load() / 1e6;
       const auto tc = now();
       for (int k = 0; k < n; k++) {
         Item &it = items[k];
@@ -703,14 +722,14 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
           any = true;
         }
       }
-      t_collect += since(tc);
+      a.t_collect += since(tc);
       if (!any) break;
-      st.rounds++;
-      const auto td = std::chrono::steady_clock::now();
+      a.rounds++;
+      const auto td = now();
       std::vector<Cigar> got;
       have_raw = dp.run_raw(batch, p, raw);
       if (!have_raw) got = dp.run(batch, p);
-      dp_secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - td).count();
+      a.dp_secs += since(td);
       const auto tc2 = now();
       size_t cur = 0;
       std::fill(n_req.begin(), n_req.end(), 0);
@@ -724,11 +743,11 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         }
         cur += o.second;
       }
-      t_collect += since(tc2);
+      a.t_collect += since(tc2);
     }
     const auto tout = now();
-    std::vector<std::string> lines(n);  // formatted on the host threads, written in schedule order
-    std::vector<int> nhits(n, 0);
+    lines.assign(n, std::string());  // formatted on the host threads, written in schedule order
+    nhits.assign(n, 0);
     parallel_for(n, [&](int k) {  // src/align_main.cc:314-331
       Item &it = items[k];
       const std::string tail = "\t" + it.h.to_bed(false) + "\n";
@@ -751,27 +770,101 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         lines[k] += tail;
       }
     });
+    a.t_out += since(tout);
+  };
+  auto write_batch = [&](int base, int n, const std::vector<std::string> &lines, const std::vector<int> &nhits) {
     for (int k = 0; k < n; k++) {
       st.lines++;
       st.total_written += nhits[k];
       if (!lines[k].empty()) fwrite(lines[k].data(), 1, lines[k].size(), out);
     }
-    t_out += since(tout);
     fprintf(log, "\r Processing %d out of %d (%.1f%%)", std::min(base + n, total), total,
             100.0 * std::min(base + n, total) / std::max(total, 1));
+  };
+
+  // Output is written in schedule order whatever lane produced it.
+  nlanes = std::min<int>(nlanes, (int)batches.size());
+  std::vector<std::unique_ptr<DpProvider>> extra;
+  std::vector<DpProvider *> prov{&dp0};
+  for (int l = 1; l < nlanes; l++) {
+    std::unique_ptr<DpProvider> c = dp0.clone();
+    if (!c) break;
+    prov.push_back(c.get());
+    extra.push_back(std::move(c));
   }
-  st.dp_tasks = dp.tasks;
-  st.dp_cells = dp.cells;
-  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  nlanes = (int)prov.size();
+  std::vector<Acc> acc(std::max(nlanes, 1));
+  if (nlanes <= 1) {
+    std::vector<std::string> lines;
+    std::vector<int> nhits;
+    for (auto &b : batches) {
+      do_batch(b.first, b.second, dp0, acc[0], lines, nhits);
+      write_batch(b.first, b.second, lines, nhits);
+    }
+  } else {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next_write = 0;
+    std::string failure;
+    bool failed = false;
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < nlanes; l++)
+      lanes.emplace_back([&, l] {
+        std::vector<std::string> lines;
+        std::vector<int> nhits;
+        for (size_t bi = (size_t)l; bi < batches.size(); bi += (size_t)nlanes) {
+          try {
+            do_batch(batches[bi].first, batches[bi].second, *prov[l], acc[l], lines, nhits);
+          } catch (std::string &e) {
+            std::lock_guard<std::mutex> g(mu);
+            if (!failed) failure = e.empty() ? std::string("error") : e;
+            failed = true;
+            cv.notify_all();
+            return;
+          }
+          std::unique_lock<std::mutex> g(mu);
+          cv.wait(g, [&] { return failed || next_write == bi; });
+          if (failed) return;
+          write_batch(batches[bi].first, batches[bi].second, lines, nhits);
+          ++next_write;
+          cv.notify_all();
+        }
+      });
+    for (auto &t : lanes) t.join();
+    if (failed) throw failure;
+  }
+  Acc a;
+  for (int l = 0; l < nlanes; l++) {
+    a.dp_secs += acc[l].dp_secs;
+    a.anchor_secs += acc[l].anchor_secs;
+    a.t_fetch += acc[l].t_fetch;
+    a.t_adv += acc[l].t_adv;
+    a.t_longest += acc[l].t_longest;
+    a.t_sum += acc[l].t_sum;
+    a.t_collect += acc[l].t_collect;
+    a.t_out += acc[l].t_out;
+    a.rounds += acc[l].rounds;
+  }
+  st.rounds = a.rounds;
+  double t_pack = 0, t_call = 0, t_unpack = 0;
+  for (DpProvider *d : prov) {
+    st.dp_tasks += d->tasks;
+    st.dp_cells += d->cells;
+    t_pack += d->t_pack;
+    t_call += d->t_call;
+    t_unpack += d->t_unpack;
+  }
+  const double secs = since(t0);
   fprintf(log, "\nFinished BED %s in %.2fs (%d lines, generated %d hits)\n", bed_path.c_str(), secs, st.lines,
           st.total_written);
-  fprintf(log, "  [host CPU: anchors+chaining %.2fs, stitching+refinement %.2fs (summed over threads); device anchors %.2fs wall; DP "
-               "provider %.2fs wall in %d rounds, %lld tasks, %.3g cells]\n",
-          g_us_chain.load() / 1e6, g_us_rest.load() / 1e6, anchor_secs, dp_secs, st.rounds, (long long)dp.tasks,
-          (double)dp.cells);
-  fprintf(log, "  [driver wall: sequence fetch %.2fs, job rounds on host threads %.2fs (longest single jobs %.2fs, all jobs %.2fs thread time), request collection %.2fs, output %.2fs; "
-               "DP provider: request packing %.2fs, device call %.2fs, CIGAR unpacking %.2fs]\n",
-          t_fetch, t_adv, t_longest, t_sum, t_collect, t_out, dp.t_pack, dp.t_call, dp.t_unpack);
+  fprintf(log, "  [%d lane(s); host CPU: anchors+chaining %.2fs, stitching+refinement %.2fs (summed over threads); device "
+               "anchors %.2fs; DP provider %.2fs in %d rounds, %lld tasks, %.3g cells]\n",
+          nlanes, g_us_chain.load() / 1e6, g_us_rest.load() / 1e6, a.anchor_secs, a.dp_secs, st.rounds,
+          (long long)st.dp_tasks, (double)st.dp_cells);
+  fprintf(log, "  [driver (summed over lanes): sequence fetch %.2fs, job rounds on host threads %.2fs (longest single jobs "
+               "%.2fs, all jobs %.2fs thread time), request collection %.2fs, output %.2fs; DP provider: request "
+               "packing %.2fs, device call %.2fs, CIGAR unpacking %.2fs]\n",
+          a.t_fetch, a.t_adv, a.t_longest, a.t_sum, a.t_collect, a.t_out, t_pack, t_call, t_unpack);
   return st;
 }
 

@@ -62,6 +62,8 @@ class DpProvider {
     Cigar cigar(size_t req) const;
   };
   virtual bool run_raw(const std::vector<DpRequest> &, const Params &, Raw &) { return false; }
+  // Optional: another provider of the same kind (own device context) for a second lane of the stage driver.
+  virtual std::unique_ptr<DpProvider> clone() { return nullptr; }
   // Optional: generate_anchors for a batch of pairs on the device.  Returns false if the provider cannot do it
   // for these inputs (the caller then computes them on the host with generate_anchors()).
   struct AnchorJob {
