@@ -20,6 +20,7 @@
 namespace sdfh {
 
 void set_alignment_scoring(const Params &p);
+static void parallel_for(int n, const std::function<void(int)> &body);  // all host cores (defined below)
 
 // ======================================================================================================
 // DP providers: align_helper (src/align.cc:39-68) for a batch of requests
@@ -149,7 +150,7 @@ class GpuProvider : public DpProvider {
   }
 
   // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
-  bool anchors(const std::vector<AnchorJob> &jobs, int kmer, std::vector<std::vector<Anchor>> &out) override {
+  bool anchors(const std::vector<AnchorJob> &jobs, int kmer, AnchorBatch &out) override {
     static const bool enabled = [] {
       const char *e = getenv("SDF_GPU_ANCHORS");
       return !(e && e[0] == '0');
@@ -157,38 +158,37 @@ class GpuProvider : public DpProvider {
     if (!enabled || kmer > 11 || jobs.empty()) return false;
     std::vector<sdf_anchor_pair> pairs(jobs.size());
     size_t total = 0;
-    for (auto &j : jobs) total += j.query->size() + j.ref->size();
-    std::string pool;
-    pool.reserve(total);
     for (size_t k = 0; k < jobs.size(); k++) {
       if (jobs[k].query->size() >= (1u << 22) || jobs[k].ref->size() >= (1u << 22)) return false;
-      pairs[k].q_off = (int64_t)pool.size();
-      pool += *jobs[k].query;
-      pairs[k].r_off = (int64_t)pool.size();
-      pool += *jobs[k].ref;
+      pairs[k].q_off = (int64_t)total;
+      total += jobs[k].query->size();
+      pairs[k].r_off = (int64_t)total;
+      total += jobs[k].ref->size();
       pairs[k].qlen = (int32_t)jobs[k].query->size();
       pairs[k].rlen = (int32_t)jobs[k].ref->size();
       pairs[k].same_chr = jobs[k].same_chr;
       pairs[k].delta = jobs[k].delta;
     }
-    std::vector<int64_t> off(jobs.size() + 1);
-    std::vector<sdf_anchor> buf(std::max<size_t>(total / 8, 4096));
-    size_t used = 0;
-    int rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.data(), pool.size(), kmer, buf.data(), buf.size(),
-                               off.data(), &used);
+    // (plain arrays, not vectors: nothing here needs the zero fill of a hundred megabytes)
+    std::unique_ptr<char[]> pool(new char[total + 1]);
+    parallel_for((int)jobs.size(), [&](int k) {
+      memcpy(pool.get() + pairs[k].q_off, jobs[k].query->data(), jobs[k].query->size());
+      memcpy(pool.get() + pairs[k].r_off, jobs[k].ref->data(), jobs[k].ref->size());
+    });
+    out.off.assign(jobs.size() + 1, 0);
+    size_t cap = std::max<size_t>(total / 8, 4096), used = 0;
+    static_assert(sizeof(sdf_anchor) == sizeof(Anchor), "layouts must agree");
+    out.buf.reset(new Anchor[cap]);
+    int rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.get(), total, kmer, (sdf_anchor *)out.buf.get(), cap,
+                               out.off.data(), &used);
     if (rc == SDF_ERR_CIGAR_OVERFLOW) {
-      buf.resize(used);
-      rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.data(), pool.size(), kmer, buf.data(), buf.size(),
-                             off.data(), &used);
+      cap = used;
+      out.buf.reset(new Anchor[cap]);
+      rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.get(), total, kmer, (sdf_anchor *)out.buf.get(), cap,
+                             out.off.data(), &used);
     }
     if (rc == SDF_ERR_UNSUPPORTED || rc == SDF_ERR_NOMEM) return false;
     if (rc != SDF_OK) throw std::string("GPU anchors failed: ") + sdf_last_error(ctx_);
-    out.resize(jobs.size());
-    static_assert(sizeof(sdf_anchor) == sizeof(Anchor), "layouts must agree");
-    for (size_t k = 0; k < jobs.size(); k++) {
-      out[k].resize((size_t)(off[k + 1] - off[k]));
-      if (!out[k].empty()) memcpy(out[k].data(), buf.data() + off[k], out[k].size() * sizeof(Anchor));
-    }
     return true;
   }
 
@@ -277,6 +277,7 @@ void PairJob::stage_start(std::vector<DpRequest> &out) {  // src/chain.cc:203-25
   query_ptr_ = std::make_shared<Sequence>("QRY", query_);
   ref_ptr_ = std::make_shared<Sequence>("REF", ref_);
   if (!have_anchors_) anchors_ = generate_anchors(query_, ref_, orig_, p_.kmer);
+  else anchors_.assign(ext_anchors_, ext_anchors_ + ext_count_);
   auto chains = chain_anchors(anchors_, p_);
   const auto &chain = chains.first;
   const auto &bounds = chains.second;
@@ -662,6 +663,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
     });
     a.t_fetch += since(tf);
+    DpProvider::AnchorBatch seeds;  // lives until the jobs have taken their copies (first round)
     {  // seed anchors of the whole super-batch in one device pass, when the provider offers it
       std::vector<DpProvider::AnchorJob> aj(n);
       for (int k = 0; k < n; k++) {
@@ -669,10 +671,10 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         aj[k] = {&items[k].fa, &items[k].fb, h.query->name == h.ref->name && h.query->is_rc == h.ref->is_rc,
                  h.ref_start - h.query_start};
       }
-      std::vector<std::vector<Anchor>> got;
       const auto ta = now();
-      if (dp.anchors(aj, p.kmer, got)) {
-        for (int k = 0; k < n; k++) items[k].job->set_anchors(std::move(got[k]));
+      if (dp.anchors(aj, p.kmer, seeds)) {
+        for (int k = 0; k < n; k++)
+          items[k].job->set_anchors(seeds.buf.get() + seeds.off[k], (size_t)(seeds.off[k + 1] - seeds.off[k]));
         a.anchor_secs += since(ta);
       }
     }

@@ -71,9 +71,12 @@ class DpProvider {
     bool same_chr;
     int delta;
   };
-  virtual bool anchors(const std::vector<AnchorJob> &, int /*kmer*/, std::vector<std::vector<Anchor>> &) {
-    return false;
-  }
+  // The anchors of pair k are flat.buf[flat.off[k] .. flat.off[k+1]).
+  struct AnchorBatch {
+    std::unique_ptr<Anchor[]> buf;
+    std::vector<int64_t> off;
+  };
+  virtual bool anchors(const std::vector<AnchorJob> &, int /*kmer*/, AnchorBatch &) { return false; }
   int64_t tasks = 0, cells = 0;  // statistics
   double t_pack = 0, t_call = 0, t_unpack = 0;  // wall seconds inside run(): request packing, device call, unpacking
 };
@@ -205,8 +208,11 @@ class PairJob {
   // Call again with the results of the previous return value, in the same order.
   std::vector<DpRequest> advance(const std::vector<Cigar> &results);
   bool done() const { return stage_ == DONE; }
-  void set_anchors(std::vector<Anchor> a) {  // anchors computed elsewhere (GPU batch)
-    anchors_ = std::move(a);
+  // anchors computed elsewhere (GPU batch): a view that stays valid until the first advance() has returned; the
+  // job copies it on the thread that runs it
+  void set_anchors(const Anchor *a, size_t n) {
+    ext_anchors_ = a;
+    ext_count_ = n;
     have_anchors_ = true;
   }
   std::vector<Hit> &hits() { return final_hits_; }
@@ -226,6 +232,8 @@ class PairJob {
   bool have_anchors_ = false;
   std::shared_ptr<Sequence> query_ptr_, ref_ptr_;
   std::vector<Anchor> anchors_;
+  const Anchor *ext_anchors_ = nullptr;
+  size_t ext_count_ = 0;
   std::vector<std::vector<int>> guides_;
   std::vector<Hit> hits_;
   std::vector<std::shared_ptr<PathState>> paths_;

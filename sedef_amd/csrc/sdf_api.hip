@@ -119,6 +119,7 @@ struct sdf_ctx {
   hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};    // more room for launches that end in a tail
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   HostBuf host_plan, host_order;  // pinned staging of the plan
+  HostBuf host_pool, host_out;    // pinned staging of the host-buffer entry point (packed sequences; results + CIGARs)
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
@@ -265,6 +266,8 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
     if (s) (void)hipStreamDestroy(s);
   ctx->host_plan.release();
   ctx->host_order.release();
+  ctx->host_pool.release();
+  ctx->host_out.release();
   delete ctx;
 }
 
@@ -1087,6 +1090,8 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
   }
   SDF_HIP(hipSetDevice(ctx->device));
   // pack every referenced sequence once (2-bit codes + N mask) and rewrite offsets to words
+  static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
+  const auto dbg0 = std::chrono::steady_clock::now();
   std::vector<sdf_task> t2(tasks, tasks + n);
   size_t words = 0;
   for (size_t k = 0; k < n; ++k) {
@@ -1101,23 +1106,74 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
     t2[k].t_off = (int64_t)words;
     words += sdf_packed_words(t.tlen);
   }
-  std::vector<uint32_t> packed(std::max<size_t>(words, 1));
-  for (size_t k = 0; k < n; ++k) {
-    if (tasks[k].qlen > 0) sdf_pack_codes(seq_pool + tasks[k].q_off, tasks[k].qlen, packed.data() + t2[k].q_off);
-    if (tasks[k].tlen > 0) sdf_pack_codes(seq_pool + tasks[k].t_off, tasks[k].tlen, packed.data() + t2[k].t_off);
+  // packed straight into pinned memory (the upload is then one asynchronous DMA), on a few threads when the batch is
+  // large; results and CIGARs come back through pinned staging too (a pageable hipMemcpy runs at ~2.5 GB/s here)
+  SDF_HIP(ctx->host_pool.reserve(std::max<size_t>(words, 1) * 4));
+  uint32_t *packed = (uint32_t *)ctx->host_pool.p;
+  auto pack_range = [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; ++k) {
+      if (tasks[k].qlen > 0) sdf_pack_codes(seq_pool + tasks[k].q_off, tasks[k].qlen, packed + t2[k].q_off);
+      if (tasks[k].tlen > 0) sdf_pack_codes(seq_pool + tasks[k].t_off, tasks[k].tlen, packed + t2[k].t_off);
+    }
+  };
+  const int nthr = words >= (1u << 18) ? (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  {
+    // equal shares of words, not of tasks
+    std::vector<size_t> cut(nthr + 1, n);
+    cut[0] = 0;
+    for (int q = 1; q < nthr; ++q) {
+      const int64_t target = (int64_t)(words * (size_t)q / (size_t)nthr);
+      size_t lo = cut[q - 1], hi = n;
+      while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (t2[mid].q_off < target) lo = mid + 1; else hi = mid;
+      }
+      cut[q] = lo;
+    }
+    std::vector<std::thread> thr;
+    for (int q = 1; q < nthr; ++q) thr.emplace_back(pack_range, cut[q], cut[q + 1]);
+    pack_range(cut[0], cut[1]);
+    for (auto &th : thr) th.join();
   }
-  SDF_HIP(ctx->h_pool.reserve(packed.size() * 4));
+  const auto dbg1 = std::chrono::steady_clock::now();
+  SDF_HIP(ctx->h_pool.reserve(std::max<size_t>(words, 1) * 4));
   SDF_HIP(ctx->h_out.reserve(n * sizeof(sdf_result)));
   SDF_HIP(ctx->h_cig.reserve(std::max<size_t>(cigar_cap, 1) * 4));
-  SDF_HIP(hipMemcpyAsync(ctx->h_pool.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  SDF_HIP(hipMemcpyAsync(ctx->h_pool.p, packed, std::max<size_t>(words, 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   size_t used = 0;
   int rc = sdf_extz2_batch_device(ctx, sc, t2.data(), n, (const uint32_t *)ctx->h_pool.p, want,
                                   (sdf_result *)ctx->h_out.p, (uint32_t *)ctx->h_cig.p, cigar_cap, &used,
                                   ctx->stream);
   if (cigar_used) *cigar_used = used;
   if (rc != SDF_OK) return rc;
-  SDF_HIP(hipMemcpy(out, ctx->h_out.p, n * sizeof(sdf_result), hipMemcpyDeviceToHost));
-  if (used && cigar_pool) SDF_HIP(hipMemcpy(cigar_pool, ctx->h_cig.p, used * 4, hipMemcpyDeviceToHost));
+  const auto dbg2 = std::chrono::steady_clock::now();
+  const size_t out_bytes = n * sizeof(sdf_result), cig_bytes = (used && cigar_pool) ? used * 4 : 0;
+  SDF_HIP(ctx->host_out.reserve(out_bytes + cig_bytes + 64));
+  uint8_t *stg = (uint8_t *)ctx->host_out.p;
+  SDF_HIP(hipMemcpyAsync(stg, ctx->h_out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (cig_bytes) SDF_HIP(hipMemcpyAsync(stg + out_bytes, ctx->h_cig.p, cig_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SDF_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    auto copy_range = [&](int q, int of) {
+      const size_t a = out_bytes * (size_t)q / (size_t)of, b = out_bytes * (size_t)(q + 1) / (size_t)of;
+      memcpy((uint8_t *)out + a, stg + a, b - a);
+      const size_t c = cig_bytes * (size_t)q / (size_t)of, d = cig_bytes * (size_t)(q + 1) / (size_t)of;
+      if (d > c) memcpy((uint8_t *)cigar_pool + c, stg + out_bytes + c, d - c);
+    };
+    const int nc = out_bytes + cig_bytes >= (8u << 20) ? std::min(nthr > 1 ? nthr : 4, 4) : 1;
+    std::vector<std::thread> thr;
+    for (int q = 1; q < nc; ++q) thr.emplace_back(copy_range, q, nc);
+    copy_range(0, nc);
+    for (auto &th : thr) th.join();
+  }
+  if (dbg_t) {
+    const auto dbg3 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    fprintf(stderr, "[sdf_extz2_batch n=%zu words=%zu cap=%zu used=%zu] pack %.1f ms, h2d+device %.1f ms (plan %.1f, dp %.1f, tb %.1f), d2h %.1f ms\n",
+            n, words, cigar_cap, used, ms(dbg0, dbg1), ms(dbg1, dbg2), ctx->ms[4], ctx->ms[0], ctx->ms[1], ms(dbg2, dbg3));
+  }
   return SDF_OK;
 }
 
@@ -1243,9 +1299,18 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
     out_off[0] = 0;
     return SDF_OK;
   }
+  static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
+  const auto dbg0 = std::chrono::steady_clock::now();
   SDF_HIP(ctx->an_pool.reserve(pool_bytes + 16));
   SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
-  return anchors_range(ctx, pairs, n, (const char *)ctx->an_pool.p, kmer, out, out_cap, out_off, out_used, ctx->stream);
+  if (dbg_t) SDF_HIP(hipStreamSynchronize(ctx->stream));
+  const auto dbg1 = std::chrono::steady_clock::now();
+  const int rc = anchors_range(ctx, pairs, n, (const char *)ctx->an_pool.p, kmer, out, out_cap, out_off, out_used, ctx->stream);
+  if (dbg_t)
+    fprintf(stderr, "[sdf_anchors_batch n=%zu pool=%zu anchors=%zu] upload %.1f ms, rest %.1f ms\n", n, pool_bytes, *out_used,
+            std::chrono::duration<double, std::milli>(dbg1 - dbg0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg1).count());
+  return rc;
 }
 
 // ---- anchor chaining (reference: src/chain.cc:103-199) ---------------------------------------------------
