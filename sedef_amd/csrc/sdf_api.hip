@@ -70,16 +70,24 @@ struct DevBuf {
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t old = cap;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    size_t want = bytes + bytes / 8 + 4096;
+    // growing means a free (which waits for the device) and an allocation, tens to hundreds of milliseconds for
+    // gigabytes: leave half as much again as headroom (at most 8 GiB) so that batches of similar size do not regrow
+    size_t want = bytes + std::min<size_t>(bytes / 2, (size_t)8 << 30) + 4096;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
       want = bytes;
       e = hipMalloc(&p, want);
     }
     if (e == hipSuccess) cap = want;
+    if (dbg_t && want >= (64u << 20))
+      fprintf(stderr, "[DevBuf %zu -> %zu MiB in %.1f ms]\n", old >> 20, want >> 20,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return e;
   }
   void release() {
@@ -479,6 +487,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       heavy_need = std::max(heavy_need, hacc);
     }
   }
+  const float dbg_a = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   region_need = (region_need + 255) & ~(size_t)255;
   heavy_need = (heavy_need + 255) & ~(size_t)255;
   const size_t nreg_ws = std::min(max_regions, chunks.size());
@@ -502,6 +511,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   uint8_t *d_dir = (uint8_t *)ctx->dir_ws.p;
   uint32_t *d_stage = (uint32_t *)ctx->stage_ws.p;
 
+  const float dbg_b = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   size_t evc = 0;
   hipEvent_t ev_begin = next_event(ctx, evc);
   hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out,
@@ -999,6 +1009,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     SDF_HIP(hipEventRecord(ev.tb1, stb));
   }
   ctx->ms[4] = plan_first_ms;
+  if (plan_first_ms > 50.f && getenv("SDF_DEBUG_TIMING"))
+    fprintf(stderr, "[slow plan: n=%zu pre-pass %.1f ms, buffers %.1f ms, first chunk planned %.1f ms; chunks %zu heavy %zu]\n", n,
+            dbg_a, dbg_b, plan_first_ms, chunks.size(), n_heavy);
   if (pipelined)
     for (auto &ev : cev)
       if (ev.tb1) SDF_HIP(hipStreamWaitEvent(st, ev.tb1, 0));
