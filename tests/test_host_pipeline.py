@@ -241,6 +241,22 @@ def test_generate_stage_gpu_equals_cpu_hook(host, oracle_dp, tmp_path):
 
 
 @pytest.mark.gpu
+def test_generate_stage_two_lanes_keep_schedule_order(host, oracle_dp, tmp_path, monkeypatch):
+    """Super-batches on two device contexts at once (SDF_LANES): same bytes, same line order as one lane."""
+    fa = str(tmp_path / "genome.fa")
+    hostgen.make_genome(fa, seed=9, glen=150000, nsd=14)
+    cpu, one, two = (str(tmp_path / n) for n in ("cpu.bed", "one.bed", "two.bed"))
+    host.generate(fa, fa + ".bed", 11, cpu, test_dp=oracle_dp)
+    monkeypatch.setenv("SDF_LANES", "1")
+    host.generate(fa, fa + ".bed", 11, one)
+    monkeypatch.setenv("SDF_LANES", "2")
+    monkeypatch.setenv("SDF_SUPER_BATCH", "3")  # 14 pairs -> 5 super-batches over 2 lanes
+    stats = host.generate(fa, fa + ".bed", 11, two)
+    assert open(two).read() == open(one).read() == open(cpu).read()
+    assert stats[0] == 14 and open(two).read().count("\n") == stats[1]
+
+
+@pytest.mark.gpu
 def test_alignment_golden_on_gpu(host, host_golden):
     for c in host_golden["pairs"]:
         cig, cnt = host.alignment_pair(c["a"], c["b"])
