@@ -630,10 +630,10 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   };
   // Pairs per super-batch: every round of a super-batch is one device batch call (planning, launches, one
   // synchronisation), so few large super-batches beat many small ones; bounded by the sequence bytes held at once.
-  // Lanes: super-batches are independent, so two of them are in flight, each on its own device context -- while
+  // Lanes: super-batches are independent, so two or three of them are in flight, each on its own device context -- while
   // one waits for the device, the host threads work on the other.  A second context costs ~0.1 s to set up, so
   // small inputs stay on one lane; medium ones are cut into at least two super-batches per lane.
-  int nlanes = total >= 4096 ? 2 : 1;
+  int nlanes = total >= 12288 ? 3 : total >= 4096 ? 2 : 1;  // (measured: 40,000 pairs 1.19 / 0.93 / 1.03 s with 2 / 3 / 4 lanes)
   if (const char *e = getenv("SDF_LANES")) nlanes = std::max(1, std::min(4, atoi(e)));
   if (nlanes > 1) super_batch = std::max(1024, std::min(super_batch, (total + 2 * nlanes - 1) / (2 * nlanes)));
   if (const char *sb = getenv("SDF_SUPER_BATCH")) super_batch = std::max(1, atoi(sb));
