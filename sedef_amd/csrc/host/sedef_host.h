@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <deque>
 #include <functional>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <string>
@@ -20,7 +21,54 @@
 
 namespace sdfh {
 
-typedef std::deque<std::pair<char, int>> Cigar;
+// CIGAR runs (op, length).  The reference keeps them in a std::deque; libstdc++'s deque allocates two blocks even
+// when empty and the stage builds millions of short ones, so this is a vector with a movable front instead (the
+// operations the alignment code uses: both ends, range insert at either end, random-access iteration).
+class Cigar {
+ public:
+  typedef std::pair<char, int> value_type;
+  typedef value_type *iterator;
+  typedef const value_type *const_iterator;
+  Cigar() {}
+  Cigar(std::initializer_list<value_type> il) : v_(il) {}
+  iterator begin() { return v_.data() + head_; }
+  iterator end() { return v_.data() + v_.size(); }
+  const_iterator begin() const { return v_.data() + head_; }
+  const_iterator end() const { return v_.data() + v_.size(); }
+  size_t size() const { return v_.size() - head_; }
+  bool empty() const { return v_.size() == head_; }
+  void clear() {
+    v_.clear();
+    head_ = 0;
+  }
+  value_type &operator[](size_t i) { return v_[head_ + i]; }
+  const value_type &operator[](size_t i) const { return v_[head_ + i]; }
+  value_type &front() { return v_[head_]; }
+  const value_type &front() const { return v_[head_]; }
+  value_type &back() { return v_.back(); }
+  const value_type &back() const { return v_.back(); }
+  void push_back(const value_type &x) { v_.push_back(x); }
+  void pop_back() { v_.pop_back(); }
+  void pop_front() { ++head_; }
+  void push_front(const value_type &x) { insert(begin(), &x, &x + 1); }
+  // `at` is begin() or end() (all the alignment code needs)
+  void insert(const_iterator at, const_iterator first, const_iterator last) {
+    const size_t n = (size_t)(last - first);
+    if (n == 0) return;
+    if (at == end() && !(at == begin() && head_ >= n)) {
+      v_.insert(v_.end(), first, last);
+    } else if (head_ >= n) {
+      head_ -= n;
+      std::copy(first, last, v_.data() + head_);
+    } else {
+      v_.insert(v_.begin() + (long)head_, first, last);
+    }
+  }
+
+ private:
+  std::vector<value_type> v_;
+  size_t head_ = 0;
+};
 
 // ---- tunables (reference: src/globals.{h,cc}) ------------------------------------------------
 struct Params {
