@@ -32,10 +32,19 @@ struct DnaTables {
 };
 const DnaTables kDna;
 
+struct UpperTable {  // toupper() of every byte, asked once (ceq runs once per alignment column)
+  unsigned char up[256];
+  UpperTable() {
+    for (int i = 0; i < 256; i++) up[i] = (unsigned char)toupper(i);
+  }
+};
+const UpperTable kUpper;
+
 inline bool ceq(char x, char y) {  // src/align.cc:29-35
   if (x == '-' || y == '-') return false;
-  if (toupper(x) == 'N' || toupper(y) == 'N') return false;
-  return toupper(x) == toupper(y);
+  const unsigned char ux = kUpper.up[(unsigned char)x], uy = kUpper.up[(unsigned char)y];
+  if (ux == 'N' || uy == 'N') return false;
+  return ux == uy;
 }
 inline double pct(double p, double tot) { return 100.0 * p / tot; }  // src/common.h:99
 }  // namespace
@@ -200,27 +209,46 @@ Alignment::Alignment(const std::string &qstr, const std::string &rstr, const std
 
 // ---- column strings and counters (src/align.cc:274-315) -------------------------------------------------
 void Alignment::populate_nice_alignment() {
-  align_a.clear();
-  align_b.clear();
-  alignment.clear();
-  size_t ia = 0, ib = 0;
+  // (one pass over preallocated strings; the reference appends column by column and counts in a second pass --
+  // same strings, same counters)
+  size_t cols = 0;
+  for (auto &c : cigar) cols += c.second > 0 ? (size_t)c.second : 0;
+  align_a.resize(cols);
+  align_b.resize(cols);
+  alignment.resize(cols);
+  char *pa = &align_a[0], *pb = &align_b[0], *pm = &alignment[0];
+  const char *sa = a.data(), *sb = b.data();
+  size_t ia = 0, ib = 0, o = 0;
+  error = AlignmentError{0, 0, 0, 0};
   for (auto &c : cigar) {
-    for (int i = 0; i < c.second; i++) {
-      alignment += (c.first == 'M' && ceq(a[ia], b[ib])) ? '|' : '*';
-      if (c.first != 'D') align_b += b[ib++]; else align_b += '-';
-      if (c.first != 'I') align_a += a[ia++]; else align_a += '-';
+    const int n = c.second;
+    if (c.first == 'M') {
+      for (int i = 0; i < n; i++, o++) {
+        const char ca = sa[ia++], cb = sb[ib++];
+        const bool eq = ceq(ca, cb);
+        pm[o] = eq ? '|' : '*';
+        pa[o] = ca;
+        pb[o] = cb;
+        if (ca != '-' && cb != '-') {
+          if (eq) error.matches++; else error.mismatches++;
+        }
+      }
+    } else {
+      error.gaps++;  // zero-length runs count too
+      error.gap_bases += n;
+      // as in the reference: op D takes a base of a only, op I a base of b only, any other op one of each
+      const bool take_a = c.first != 'I', take_b = c.first != 'D';
+      for (int i = 0; i < n; i++, o++) {
+        const char ca = take_a ? sa[ia++] : '-', cb = take_b ? sb[ib++] : '-';
+        pm[o] = '*';
+        pa[o] = ca;
+        pb[o] = cb;
+        if (ca != '-' && cb != '-') {
+          if (ceq(ca, cb)) error.matches++; else error.mismatches++;
+        }
+      }
     }
   }
-  error = AlignmentError{0, 0, 0, 0};
-  for (auto &c : cigar)
-    if (c.first != 'M') {
-      error.gaps++;  // zero-length runs count too
-      error.gap_bases += c.second;
-    }
-  for (size_t i = 0; i < alignment.size(); i++)
-    if (align_a[i] != '-' && align_b[i] != '-') {
-      if (ceq(align_a[i], align_b[i])) error.matches++; else error.mismatches++;
-    }
 }
 
 double Alignment::gap_error() const { return pct(error.gap_bases, error.matches + error.gap_bases + error.mismatches); }
