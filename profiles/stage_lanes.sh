@@ -1,6 +1,7 @@
-# usage: bash profiles/stage_lanes.sh  -- stage timing for several lane counts
+# usage: bash profiles/stage_lanes.sh [genome_len] [n_dup]  -- stage timing for several lane counts
 cd $GRAFT_REPO_ROOT
-for l in 2 3 4; do
+G=${1:-300000000}; N=${2:-40000}
+for l in 1 2 3 4; do
   echo "== SDF_LANES=$l"
-  SDF_LANES=$l python3 profiles/stage_bench.py 300000000 40000 3 2>&1 | grep -A1 "run [12]" | grep Finished
+  SDF_LANES=$l python3 profiles/stage_bench.py $G $N 4 2>&1 | grep Finished | tail -3 | cut -c1-120
 done
