@@ -789,7 +789,11 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   std::vector<std::unique_ptr<DpProvider>> extra;
   std::vector<DpProvider *> prov{&dp0};
   for (int l = 1; l < nlanes; l++) {
-    std::unique_ptr<DpProvider> c = dp0.clone();
+    std::unique_ptr<DpProvider> c;
+    try {
+      c = dp0.clone();
+    } catch (std::string &) {  // no room for another device context: fewer lanes
+    }
     if (!c) break;
     prov.push_back(c.get());
     extra.push_back(std::move(c));
