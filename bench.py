@@ -359,10 +359,22 @@ def main():
         bytes_per_launch = alg / iso_launches
         achieved = bytes_per_launch / avg_launch_s / 1e9
         traffic = None
+        valu = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp) and n == 100000 and w == 128 and args.qlen == 1000:
             # measured once with rocprofv3 PMC passes on this exact workload and launch (profiles/README.md)
-            traffic = json.load(open(tp)).get("bytes_per_step") / iso_launches
+            pmc = json.load(open(tp))
+            traffic = pmc.get("bytes_per_step") / iso_launches
+            if pmc.get("valu_insts_per_step"):
+                # what actually bounds the launch: VALU issue.  A SIMD issues one wavefront VALU instruction per 4
+                # cycles at best (64 lanes over 16 ALUs); counted instructions / (SIMDs x launch cycles / 4)
+                props = torch.cuda.get_device_properties(local)
+                simds = props.multi_processor_count * 4
+                mhz = (getattr(props, "clock_rate", 0) or 2400000) / 1e3  # (2.4 GHz: MI355X peak engine clock)
+                issue_peak = simds * mhz * 1e6 / 4.0 * avg_launch_s * iso_launches
+                valu = {"insts_per_step": pmc["valu_insts_per_step"], "simds": simds, "clock_mhz": round(mhz, 1),
+                        "frac_of_issue_peak": round(pmc["valu_insts_per_step"] / issue_peak, 4),
+                        "source": pmc.get("valu_source")}
         value = cells_all * args.steps / dt / 1e9
         line = {
             "metric": "aligned DP cells/sec (Gcell/s) on `sedef align` batch",
@@ -383,7 +395,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": "extz2_pair_kernel<3> (extz2 DP)", "measured_on": roof_mode,
                          "launches": iso_launches, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch)},
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "valu_issue": valu},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pool, q_off, qlen, t_off, tlen, cells_task, w)
