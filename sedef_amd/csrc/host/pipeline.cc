@@ -81,7 +81,9 @@ class GpuProvider : public DpProvider {
     if (!ctx_) throw std::string("GPU DP backend unavailable: ") + sdf_last_error(nullptr);
   }
   ~GpuProvider() override { sdf_destroy(ctx_); }
-  std::unique_ptr<DpProvider> clone() override { return std::unique_ptr<DpProvider>(new GpuProvider(device_)); }
+  std::unique_ptr<DpProvider> clone(int device = -1) override {
+    return std::unique_ptr<DpProvider>(new GpuProvider(device < 0 ? device_ : device));
+  }
   std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) override {
     std::vector<Cigar> out(reqs.size());
     Raw raw;
@@ -634,7 +636,20 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   // one waits for the device, the host threads work on the other.  A second context costs ~0.1 s to set up, so
   // small inputs stay on one lane; medium ones are cut into at least two super-batches per lane.
   int nlanes = total >= 12288 ? 3 : total >= 4096 ? 2 : 1;  // (measured: 40,000 pairs 1.19 / 0.93 / 1.03 s with 2 / 3 / 4 lanes)
-  if (const char *e = getenv("SDF_LANES")) nlanes = std::max(1, std::min(4, atoi(e)));
+  // SDF_DEVICES=0,1,...: the lanes after the first go round-robin over these devices (one node, several GPUs; the
+  // first lane stays on the provider's own device, which should be the first of the list); at least one lane each
+  std::vector<int> devices;
+  if (const char *e = getenv("SDF_DEVICES")) {
+    for (const char *c = e; *c;) {
+      char *end = nullptr;
+      const long d = strtol(c, &end, 10);
+      if (end == c) break;
+      devices.push_back((int)d);
+      c = *end == ',' ? end + 1 : end;
+    }
+    if (devices.size() > 1) nlanes = std::max<int>(nlanes, (int)std::min<size_t>(devices.size(), 8));
+  }
+  if (const char *e = getenv("SDF_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
   if (nlanes > 1) super_batch = std::max(1024, std::min(super_batch, (total + 2 * nlanes - 1) / (2 * nlanes)));
   if (const char *sb = getenv("SDF_SUPER_BATCH")) super_batch = std::max(1, atoi(sb));
   std::vector<std::pair<int, int>> batches;  // (first pair, pairs)
@@ -791,7 +806,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   for (int l = 1; l < nlanes; l++) {
     std::unique_ptr<DpProvider> c;
     try {
-      c = dp0.clone();
+      c = dp0.clone(devices.empty() ? -1 : devices[(size_t)l % devices.size()]);
     } catch (std::string &) {  // no room for another device context: fewer lanes
     }
     if (!c) break;

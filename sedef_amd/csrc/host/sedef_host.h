@@ -111,7 +111,8 @@ class DpProvider {
   };
   virtual bool run_raw(const std::vector<DpRequest> &, const Params &, Raw &) { return false; }
   // Optional: another provider of the same kind (own device context) for a second lane of the stage driver.
-  virtual std::unique_ptr<DpProvider> clone() { return nullptr; }
+  // (device < 0: the same device as this one)
+  virtual std::unique_ptr<DpProvider> clone(int /*device*/ = -1) { return nullptr; }
   // Optional: generate_anchors for a batch of pairs on the device.  Returns false if the provider cannot do it
   // for these inputs (the caller then computes them on the host with generate_anchors()).
   struct AnchorJob {

@@ -254,6 +254,11 @@ def test_generate_stage_two_lanes_keep_schedule_order(host, oracle_dp, tmp_path,
     stats = host.generate(fa, fa + ".bed", 11, two)
     assert open(two).read() == open(one).read() == open(cpu).read()
     assert stats[0] == 14 and open(two).read().count("\n") == stats[1]
+    monkeypatch.setenv("SDF_DEVICES", "0,0,0")  # lanes spread over a device list (here the same GPU three times)
+    monkeypatch.delenv("SDF_LANES")
+    three = str(tmp_path / "three.bed")
+    host.generate(fa, fa + ".bed", 11, three)
+    assert open(three).read() == open(cpu).read()
 
 
 @pytest.mark.gpu
