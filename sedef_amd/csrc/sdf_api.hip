@@ -794,6 +794,32 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         }
       }
       cls.erase(std::remove_if(cls.begin(), cls.end(), [](const Cls &c) { return c.idx.empty(); }), cls.end());
+      // inside a launch of few tasks the longest go first too (workgroups are dispatched in order: a long task that
+      // starts last is the tail of the launch); pair-kernel entries move as (task, partner) units
+      for (auto &c : cls) {
+        if (c.idx.size() >= 8192 || c.idx.size() < 3) continue;
+        auto work = [&](int32_t k) { return (int64_t)(cp[k].qlen + cp[k].tlen) * cp[k].ncol16; };
+        int64_t wmin = work(c.idx[0]), wmax = wmin;
+        for (int32_t k : c.idx) {
+          const int64_t wk = work(k);
+          wmin = std::min(wmin, wk);
+          wmax = std::max(wmax, wk);
+        }
+        if (wmax < 2 * wmin) continue;  // tasks of one size: the order does not matter
+        if (c.bs >= 100 && c.bs < 200) {
+          std::vector<std::pair<int32_t, int32_t>> pr(c.idx.size() / 2);
+          for (size_t q = 0; q < pr.size(); ++q) pr[q] = {c.idx[2 * q], c.idx[2 * q + 1]};
+          std::stable_sort(pr.begin(), pr.end(), [&](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) {
+            return work(x.first) > work(y.first);
+          });
+          for (size_t q = 0; q < pr.size(); ++q) {
+            c.idx[2 * q] = pr[q].first;
+            c.idx[2 * q + 1] = pr[q].second;
+          }
+        } else {
+          std::stable_sort(c.idx.begin(), c.idx.end(), [&](int32_t x, int32_t y) { return work(x) > work(y); });
+        }
+      }
       // longest launches first so the long tasks start early
       std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.est > b.est; });
       size_t cursor = 0;
