@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   sdf_result rr = res[tk.out_idx];
   if (tk.flag & SDF_FLAG_SCORE_ONLY) return;
 
-  int64_t i, j;
+  int i, j;  // (sequences are shorter than 2^31)
   if (!rr.zdropped && !(tk.flag & SDF_FLAG_EXTZ_ONLY)) {
     i = tk.tlen - 1;
     j = tk.qlen - 1;
@@ -72,31 +72,27 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     }
   };
 
-  // the two sequences are read backwards one base per M step: keep the current 16-base code word
-  // and 32-base N-mask word of each in registers
-  int qci = -1, tci = -1, qni = -1, tni = -1;
-  uint32_t qcw = 0, tcw = 0, qnw = 0, tnw = 0;
-  auto qcode = [&](int k) -> uint32_t {
-    if ((k >> 4) != qci) { qci = k >> 4; qcw = qw[qci]; }
-    if ((k >> 5) != qni) { qni = k >> 5; qnw = qn[qni]; }
-    return ((qnw >> (k & 31)) & 1u) ? 4u : ((qcw >> ((k & 15) * 2)) & 3u);
-  };
-  auto tcode = [&](int k) -> uint32_t {
-    if ((k >> 4) != tci) { tci = k >> 4; tcw = tw[tci]; }
-    if ((k >> 5) != tni) { tni = k >> 5; tnw = tn[tni]; }
-    return ((tnw >> (k & 31)) & 1u) ? 4u : ((tcw >> ((k & 15) * 2)) & 3u);
-  };
+  // The two sequences are read backwards, one base per step that consumes them: the current 16-base code word and
+  // 32-base N-mask word of each are kept SHIFTED so that the base under the walk is in the top bits -- a step is one
+  // shift, a new word is loaded every 16 steps.
+  uint32_t qsh = 0, qnsh = 0, tsh = 0, tnsh = 0;
+  if (i >= 0 && j >= 0) {
+    qsh = qw[j >> 4] << ((15 - (j & 15)) * 2);
+    qnsh = qn[j >> 5] << (31 - (j & 31));
+    tsh = tw[i >> 4] << ((15 - (i & 15)) * 2);
+    tnsh = tn[i >> 5] << (31 - (i & 31));
+  }
   int state = 0;
   // wave-kernel layout: block rb = r/16 holds, per packed register k and lane, one uint4 of four
   // 32-bit flag words (a>z, b>z', x>0, y>0); bit 15-(r%16) (+16 for the odd slot) is row r;
   // slot = t - (band start of row 16*rb).  The last fetched uint4 is kept: a path stays inside
   // one 16-row x 2-slot tile for several steps.
   const uint4 *dirw = reinterpret_cast<const uint4 *>(dir);
-  int64_t cached_line = -1;  // index/4 of the 64-byte line (4 lanes = 8 slots x 16 rows) held below
+  int cached_line = -1;  // index/4 of the 64-byte line (4 lanes = 8 slots x 16 rows) held below
   uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
   int blk_rb = -1, blk_sb = -1, blk_base = 0;
-  while (i >= 0 && j >= 0) {
-    const int r = (int)(i + j);
+  while ((i | j) >= 0) {
+    const int r = i + j;
     Band b;
     band_of(r, tk.qlen, tk.tlen, tk.w, b);
     int forced = -1;
@@ -116,17 +112,16 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
           blk_rb = rb;
           blk_base = b0.lo;
         }
-        const int slot = (int)i - blk_base;
-        const int64_t idx = ((int64_t)rb * tk.nreg + (slot >> 6)) * 64 + (slot & 63);
+        const int idx = rb * (tk.nreg * 64) + (i - blk_base);  // (register k, lane l) = slot 64k + l
         if ((idx >> 3) != cached_line) {
           cached_line = idx >> 3;
-          const uint4 *ln = dirw + (cached_line << 2);
+          const uint4 *ln = dirw + ((int64_t)cached_line << 2);
           c0 = ln[0];
           c1 = ln[1];
           c2 = ln[2];
           c3 = ln[3];
         }
-        const int sel = (int)(idx & 7) >> 1;
+        const int sel = (idx & 7) >> 1;
         const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
         const uint32_t wab = (idx & 1) ? cached.z : cached.x, wxy = (idx & 1) ? cached.w : cached.y;
         const int bit = 15 - (r & 15);
@@ -137,8 +132,8 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
         // stripes of 128 * nreg target positions, each a stand-alone wave-kernel task over its slice in local
         // coordinates (row r - T0, position t - T0); one flag region per stripe
         const int sw = 128 * tk.nreg;
-        const int sb = (int)i / sw, t0 = sb * sw;
-        const int rp = r - t0, tp = (int)i - t0;
+        const int sb = i / sw, t0 = sb * sw;
+        const int rp = r - t0, tp = i - t0;
         const int rb = rp >> 4;
         if (rb != blk_rb || sb != blk_sb) {
           Band b0;
@@ -148,17 +143,17 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
           blk_base = b0.lo;
         }
         const int slot = tp - blk_base;
-        const int64_t per_stripe = (int64_t)((tk.qlen + sw - 1 + 15) / 16) * tk.nreg * 64;  // uint4 records
-        const int64_t idx = sb * per_stripe + ((int64_t)rb * tk.nreg + (slot >> 7)) * 64 + ((slot & 127) >> 1);
+        const int per_stripe = ((tk.qlen + sw - 1 + 15) / 16) * tk.nreg * 64;  // uint4 records
+        const int idx = sb * per_stripe + rb * (tk.nreg * 64) + (slot >> 1);  // (register k, lane l) = slots 128k + 2l, +1
         if ((idx >> 2) != cached_line) {
           cached_line = idx >> 2;
-          const uint4 *ln = dirw + (cached_line << 2);
+          const uint4 *ln = dirw + ((int64_t)cached_line << 2);
           c0 = ln[0];
           c1 = ln[1];
           c2 = ln[2];
           c3 = ln[3];
         }
-        const int sel = (int)(idx & 3);
+        const int sel = idx & 3;
         const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
         const int bit = 15 - (rp & 15) + ((slot & 1) << 4);
         const uint32_t fa = (cached.x >> bit) & 1u, fb = (cached.y >> bit) & 1u;
@@ -172,17 +167,17 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
           blk_rb = rb;
           blk_base = b0.lo;
         }
-        const int slot = (int)i - blk_base;
-        const int64_t idx = ((int64_t)rb * tk.nreg + (slot >> 7)) * 64 + ((slot & 127) >> 1);
+        const int slot = i - blk_base;
+        const int idx = rb * (tk.nreg * 64) + (slot >> 1);
         if ((idx >> 2) != cached_line) {  // a diagonal run stays inside one line for ~8 steps
           cached_line = idx >> 2;
-          const uint4 *ln = dirw + (cached_line << 2);
+          const uint4 *ln = dirw + ((int64_t)cached_line << 2);
           c0 = ln[0];
           c1 = ln[1];
           c2 = ln[2];
           c3 = ln[3];
         }
-        const int sel = (int)(idx & 3);
+        const int sel = idx & 3;
         const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
         const int bit = 15 - (r & 15) + ((slot & 1) << 4);
         const uint32_t fa = (cached.x >> bit) & 1u, fb = (cached.y >> bit) & 1u;
@@ -194,22 +189,40 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     else if (!((d >> (state + 2)) & 1u)) state = 0;
     if (state == 0) state = (int)(d & 7u);
     if (forced >= 0) state = forced;
+    // one step: state 0 consumes a base of both (M), 1 / 3 of the target (ksw D, op 2), anything else of the query
+    const bool step_i = state == 0 || state == 1 || state == 3, step_j = state == 0 || !step_i;
     if (state == 0) {
-      const uint32_t a = qcode((int)j), c = tcode((int)i);
-      if (a < 4u && a == c) ++matches; else ++mismatches;
-      push(0, 1);
+      // match <=> neither base is N and the 2-bit codes agree (src/align.cc:29-35 on the codes)
+      if ((((qnsh | tnsh) >> 31) | ((qsh ^ tsh) >> 30)) == 0u) ++matches; else ++mismatches;
+    }
+    push(state == 0 ? 0 : step_i ? 2 : 1, 1);
+    if (step_i) {
       --i;
+      if ((i & 15) == 15) {  // (also true for i == -1: the loop ends before the words are used)
+        if (i >= 0) {
+          tsh = tw[i >> 4];
+          tnsh = (i & 31) == 31 ? tn[i >> 5] : tnsh << 1;
+        }
+      } else {
+        tsh <<= 2;
+        tnsh <<= 1;
+      }
+    }
+    if (step_j) {
       --j;
-    } else if (state == 1 || state == 3) {
-      push(2, 1);
-      --i;
-    } else {
-      push(1, 1);
-      --j;
+      if ((j & 15) == 15) {
+        if (j >= 0) {
+          qsh = qw[j >> 4];
+          qnsh = (j & 31) == 31 ? qn[j >> 5] : qnsh << 1;
+        }
+      } else {
+        qsh <<= 2;
+        qnsh <<= 1;
+      }
     }
   }
-  if (i >= 0) push(2, (int)i + 1);
-  if (j >= 0) push(1, (int)j + 1);
+  if (i >= 0) push(2, i + 1);
+  if (j >= 0) push(1, j + 1);
   if (cur_op >= 0) slot[--pos] = ((uint32_t)cur_len << 4) | (uint32_t)cur_op;
 
   const int ncig = tk.cig_cap - pos;
