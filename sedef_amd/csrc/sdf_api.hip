@@ -993,7 +993,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       for (size_t k = 0; k < cnt; ++k)
         layouts |= 1u << (cp[k].nreg == 0 ? 0 : cp[k].pad_ == 2 ? 2 : cp[k].pad_ == 5 ? 3 : 1);
       // few tasks: a wavefront per walk (see traceback_kernel)
-      const bool tb_solo = cnt <= 8192;
+      // (one walk per wavefront costs 64 times the instruction issue of 64 walks per wavefront: only where the
+      // walks have the GPU to themselves, or are few)
+      const bool tb_solo = cnt <= (chunks.size() == 1 ? (size_t)8192 : (size_t)1024);
       const dim3 tbg(tb_solo ? (unsigned)cnt : (unsigned)((cnt + 63) / 64));
       const int tbn = tb_solo ? -(int)cnt : (int)cnt;
       // A walk is one step per anti-diagonal, ~1 us each: a launch lasts as long as its longest task.  When a chunk
