@@ -428,7 +428,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         }
       }
     };
-    const int nthr = n >= 200000 ? 4 : n >= 50000 ? 2 : 1;
+    const int nthr = n >= 200000 ? 4 : 1;
     Part parts[4];
     std::vector<std::thread> thr;
     for (int q = 1; q < nthr; ++q) thr.emplace_back(scan, n * q / nthr, n * (q + 1) / nthr, std::ref(parts[q]));
