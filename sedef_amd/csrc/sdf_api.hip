@@ -843,7 +843,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     // A heavy chunk uploads and traces back on the caller's stream and uses the workspace slice behind the regions.
     const bool piped = pipelined && !heavy_chunk;
     const size_t nj = normal_ids.size();  // ordinal among the ordinary chunks
-    if (pipelined && chunks.size() == 1 && !ctx->aux_stream[0])  // created when a one-chunk batch first wants them
+    if (pipelined && !ctx->aux_stream[0])  // created when a pipelined batch first wants them
       for (auto &a : ctx->aux_stream)
         if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) {
           (void)hipGetLastError();
@@ -854,7 +854,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
                         ctx->aux_stream[3]};
     // Q[4..7]: only the least-loaded-stream assignment below uses them (one-chunk batches without heavy tasks)
     const int ui = piped ? (have_heavy ? 2 : 1 + (int)(nj & 1)) : 0;  // upload stream (and the big launches')
-    hipStream_t stb = piped ? Q[3] : st;
+    // (the tracebacks of consecutive ordinary chunks alternate between two streams: the last one starts when its DP
+    // ends, not when the previous chunk's walk does)
+    hipStream_t stb = piped ? ((nj & 1) && ctx->aux_stream[0] ? ctx->aux_stream[0] : Q[3]) : st;
     uint8_t *dir_reg = heavy_chunk ? d_dir + nreg_ws * region_need : d_dir + (nj % nreg_ws) * region_need;
     hipEvent_t region_ev = nullptr;  // the region's previous user has been traced back
     if (piped && nj >= nreg_ws) region_ev = cev[normal_ids[nj - nreg_ws]].tb1;
