@@ -379,7 +379,12 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // task latency long) go, longest first, to whichever of the four streams has the least work queued, and the
   // traceback of a chunk runs on the fourth stream next to the following chunk's DP.
   // Direction-flag regions rotate over `nreg_ws` slices of the workspace.
-  const bool pipelined = ctx->pipeline && n >= 2048;
+  // (small batches stay on the caller's stream -- unless they hold long tasks: their launch classes, each as long
+  // as its longest task, then run side by side on the other streams like those of a large batch)
+  bool any_long = false;
+  if (n < 2048)
+    for (size_t k = 0; k < n && !any_long; ++k) any_long = tasks[k].qlen + (int64_t)tasks[k].tlen >= 3000;
+  const bool pipelined = ctx->pipeline && (n >= 2048 || any_long);
   size_t nch = 1;
   if (pipelined && n >= 32768) nch = std::min<size_t>(4, n / 16384);  // a traceback launch is ~2 ms of latency
   const size_t max_regions = nch > 1 ? 4 : 1;
