@@ -848,12 +848,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     // A heavy chunk uploads and traces back on the caller's stream and uses the workspace slice behind the regions.
     const bool piped = pipelined && !heavy_chunk;
     const size_t nj = normal_ids.size();  // ordinal among the ordinary chunks
-    if (pipelined && !ctx->aux_stream[0])  // created when a pipelined batch first wants them
-      for (auto &a : ctx->aux_stream)
-        if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) {
+    if (pipelined) {
+      // extra streams, created the first time they are wanted (a stream is a hardware queue: ~7 ms to set up): one
+      // for the alternating tracebacks of a multi-chunk batch, one per launch beyond four for a one-chunk batch
+      const size_t want_aux = chunks.size() == 1 ? (launches.size() > 4 ? std::min<size_t>(launches.size() - 4, 4) : 0) : 1;
+      for (size_t a = 0; a < want_aux; ++a)
+        if (!ctx->aux_stream[a] && hipStreamCreateWithFlags(&ctx->aux_stream[a], hipStreamNonBlocking) != hipSuccess) {
           (void)hipGetLastError();
-          a = nullptr;
+          ctx->aux_stream[a] = nullptr;
         }
+    }
     hipStream_t Q[8] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
                         pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
                         ctx->aux_stream[3]};
