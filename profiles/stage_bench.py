@@ -28,7 +28,7 @@ def main():
         t0 = time.time()
         r = subprocess.run([CLI, "align", "generate", "-k", "11", fa, fa + ".bed"], capture_output=True, text=True)
         dt = time.time() - t0
-        tail = [ln for ln in r.stderr.replace("\r", "\n").splitlines() if "Finished" in ln or "host CPU" in ln or "driver (" in ln or "sdf_extz2_batch" in ln or "sdf_anchors" in ln or "DevBuf" in ln or "slow plan" in ln]
+        tail = [ln for ln in r.stderr.replace("\r", "\n").splitlines() if "Finished" in ln or "host CPU" in ln or "driver (" in ln or "sdf_extz2_batch" in ln or "sdf_anchors" in ln or "DevBuf" in ln or "slow plan" in ln or "process:" in ln]
         print("run %d: rc=%d wall %.2fs, %d output lines\n  %s" % (it, r.returncode, dt, r.stdout.count("\n"),
                                                                   "\n  ".join(tail)), flush=True)
 

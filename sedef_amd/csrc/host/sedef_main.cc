@@ -2,6 +2,7 @@
 // src/align_main.cc:341-373): `sedef align generate -k K [--match N --mismatch N --gap-open N --gap-extend N]
 // genome.fa bucket.bed`.  stdout carries only the BEDPE lines; everything else goes to stderr.
 // The DP runs on the GPU; without a HIP device the command fails with exit code 1.
+#include <chrono>
 #include <cstdio>
 #include <malloc.h>
 #include <cstdlib>
@@ -105,8 +106,16 @@ int main(int argc, char **argv) {
         int k;
         if (!a.get({"k", "kmer"}, k)) throw std::string("Must provide k-mer size (--kmer)");
         const char *dv = getenv("SDF_DEVICE");
+        const auto t0 = std::chrono::steady_clock::now();
         auto dp = make_gpu_provider(dv ? atoi(dv) : 0);
+        const auto t1 = std::chrono::steady_clock::now();
         generate_alignments(a.pos[1], a.pos[2], k, p, *dp, stdout, stderr);
+        const auto t2 = std::chrono::steady_clock::now();
+        dp.reset();
+        if (getenv("SDF_DEBUG_TIMING"))
+          fprintf(stderr, "  [process: device context %.2fs, stage %.2fs, context teardown %.2fs]\n",
+                  std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(),
+                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count());
       } else if (a.pos[0] == "bucket") {
         int nbins;
         if (!a.get({"n", "bins"}, nbins)) throw std::string("Must provide number of bins (--bins)");
