@@ -288,7 +288,27 @@ extern "C" void sdf_pack_codes(const uint8_t *codes, int32_t len, uint32_t *out)
   const size_t nw = sdf_packed_words(len);
   std::memset(out, 0, nw * sizeof(uint32_t));
   uint32_t *cw = out, *nm = out + (len + 15) / 16;
-  for (int32_t k = 0; k < len; ++k) {
+  int32_t k = 0;
+  // eight bases at a time: a code >= 4 is N (mask bit set, code bits 0); codes are 0..4 in the callers, any
+  // byte >= 4 is treated as N like in the byte loop below
+  for (; k + 8 <= len; k += 8) {
+    uint64_t x;
+    std::memcpy(&x, codes + k, 8);
+    // bytes >= 4 have one of bits 2..7 set: fold them onto bit 0 of each byte
+    uint64_t hi = x & 0xFCFCFCFCFCFCFCFCull;
+    hi |= hi >> 4;
+    hi |= hi >> 2;
+    hi |= hi >> 1;
+    const uint64_t nb = hi & 0x0101010101010101ull;
+    const uint32_t nbits = (uint32_t)((nb * 0x0102040810204080ull) >> 56);
+    uint64_t y = x & 0x0303030303030303ull & ~(nb * 0xFFull);
+    y = (y | (y >> 6)) & 0x000F000F000F000Full;
+    y = (y | (y >> 12)) & 0x000000FF000000FFull;
+    y = (y | (y >> 24)) & 0xFFFFull;
+    cw[k >> 4] |= (uint32_t)y << ((k & 15) * 2);
+    nm[k >> 5] |= nbits << (k & 31);
+  }
+  for (; k < len; ++k) {
     const uint8_t c = codes[k];
     if (c >= 4) nm[k >> 5] |= 1u << (k & 31);
     else cw[k >> 4] |= (uint32_t)c << ((k & 15) * 2);
