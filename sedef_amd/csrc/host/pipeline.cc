@@ -565,16 +565,31 @@ static void parallel_for(int n, const std::function<void(int)> &body) {
     for (int i = 0; i < n; i++) body(i);
     return;
   }
+  // The lanes of the stage driver call this concurrently: a process-wide count of running workers keeps the total
+  // at `nthreads` (more runnable threads than the CPU quota get the whole process throttled by the scheduler).
+  static std::mutex slot_mu;
+  static std::condition_variable slot_cv;
+  static int slots_used = 0;
   std::atomic<int> next(0);
   std::vector<std::string> errors(nt);
   std::vector<std::thread> pool;
   for (int t = 0; t < nt; t++)
     pool.emplace_back([&, t] {
+      {
+        std::unique_lock<std::mutex> g(slot_mu);
+        slot_cv.wait(g, [&] { return slots_used < nthreads; });
+        ++slots_used;
+      }
       try {
         for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
       } catch (std::string &s) {
         errors[t] = s.empty() ? std::string("error") : s;
       }
+      {
+        std::lock_guard<std::mutex> g(slot_mu);
+        --slots_used;
+      }
+      slot_cv.notify_one();
     });
   for (auto &th : pool) th.join();
   for (auto &e : errors)
