@@ -575,6 +575,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     const bool heavy_chunk = chunks[ci].heavy;
     // ---- plan the chunk ----
     win_need.clear();
+    int snreg = 0;  // widest stripe any stripe task of the chunk needs
     for (size_t k = chunks[ci].s; k < chunks[ci].e; ++k) {
       const sdf_task &t = tasks[k];
       if (split_heavy && (heavy[k] != 0) != heavy_chunk) continue;
@@ -627,6 +628,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         if (stripe_lds_bytes(t.qlen, nst, nreg) <= (size_t)ctx->max_dyn_lds) {
           p.nreg = nreg;
           p.pad_ = 5;
+          snreg = std::max(snreg, nreg);
         }
       }
       if (!p.nreg) {
@@ -642,11 +644,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       plan[np++] = p;
     }
     const size_t cnt = np - pb;
-    {  // the stripe tasks of a chunk share one stripe width (the widest any of them needs): one launch, all of them
-       // side by side, instead of one launch per width queued behind each other
-      int snreg = 0;
-      for (size_t k = pb; k < np; ++k)
-        if (plan[k].pad_ == 5) snreg = std::max(snreg, plan[k].nreg);
+    if (snreg) {  // the stripe tasks of a chunk share one stripe width (the widest any of them needs): one launch,
+                  // all of them side by side, instead of one launch per width queued behind each other
       for (size_t k = pb; k < np; ++k) {
         PlanTask &p = plan[k];
         if (p.pad_ != 5) continue;
@@ -719,28 +718,6 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         partner[e.second] = e.second;
       }
     }
-    // direction-flag layout inside this chunk's workspace region
-    {
-      size_t acc = 0;
-      for (size_t k = 0; k < cnt; ++k) {
-        PlanTask &p = cp[k];
-        size_t need = 0;
-        if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
-          const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
-          if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
-          else if (p.pad_ == 5)
-            need = (size_t)((p.tlen + 128 * p.nreg - 1) / (128 * p.nreg)) * stripe_dir_bytes(p.qlen, p.nreg);
-          else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
-          else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
-        }
-        p.dir_off = (int64_t)acc;
-        acc += need;
-      }
-      if (acc > (heavy_chunk ? heavy_need : region_need)) {
-        ctx->err = "internal: direction-flag region overflow";
-        return SDF_ERR_INVALID;
-      }
-    }
     // launch classes: (kernel, LDS bytes rounded to a power of two)
     struct Launch {
       int bs;
@@ -752,8 +729,22 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     std::vector<Launch> launches;
     {
       cls.clear();
+      size_t dir_acc = 0;  // direction-flag layout inside this chunk's workspace region, in the same pass
       for (size_t k = 0; k < cnt; ++k) {
-        const PlanTask &p = cp[k];
+        PlanTask &p = cp[k];
+        {
+          size_t need = 0;
+          if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
+            const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
+            if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
+            else if (p.pad_ == 5)
+              need = (size_t)((p.tlen + 128 * p.nreg - 1) / (128 * p.nreg)) * stripe_dir_bytes(p.qlen, p.nreg);
+            else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
+            else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+          }
+          p.dir_off = (int64_t)dir_acc;
+          dir_acc += need;
+        }
         const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
         int bs = width > 1024 ? 1024 : width > 256 ? 256 : 64;  // 4 cells per thread and pass over the row
         size_t lds = 2048, need;
@@ -817,6 +808,10 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
           cls[a].idx.insert(cls[a].idx.end(), cls[b].idx.begin(), cls[b].idx.end());
           cls[b].idx.clear();
         }
+      }
+      if (dir_acc > (heavy_chunk ? heavy_need : region_need)) {
+        ctx->err = "internal: direction-flag region overflow";
+        return SDF_ERR_INVALID;
       }
       cls.erase(std::remove_if(cls.begin(), cls.end(), [](const Cls &c) { return c.idx.empty(); }), cls.end());
       // inside a launch of few tasks the longest go first too (workgroups are dispatched in order: a long task that
