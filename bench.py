@@ -240,7 +240,7 @@ def main():
     import torch.distributed as dist
 
     import sedef_amd
-    from sedef_amd.dist import allgatherv_results
+    from sedef_amd.dist import ResultGather
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,26 +276,41 @@ def main():
 
     eng = sedef_amd.Extz2Engine(local, int(args.workspace_gib * (1 << 30)))
     d_pool = torch.from_numpy(words.view(np.int32)).to(dev)
-    d_out = torch.empty(n * 16, dtype=torch.int32, device=dev)
     cig_cap = int((qlen.astype(np.int64) + tlen + 2).sum())
     cig_cap = min(cig_cap, 256 * n)  # ~50 runs per task at 10 % divergence; overflow is an error
-    d_cig = torch.empty(cig_cap, dtype=torch.int32, device=dev)
+    # N > 1: two sets of output buffers in rotation -- the all-gather of step i's records and CIGAR words (RCCL, on the
+    # communicator's stream) runs under the DP of step i+1, which writes the other set; every gather is waited for
+    # inside the timed region.  The CIGAR words travel with a fixed capacity of 64 per task (~48 are used).
+    nsets = 2 if world > 1 else 1
+    d_outs = [torch.empty(n * 16, dtype=torch.int32, device=dev) for _ in range(nsets)]
+    d_cigs = [torch.empty(cig_cap, dtype=torch.int32, device=dev) for _ in range(nsets)]
+    d_out, d_cig = d_outs[0], d_cigs[0]
     want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
     stream = torch.cuda.current_stream().cuda_stream
 
-    gathered = {}
+    gathers = []
+    if world > 1:
+        gdev = torch.device("cpu") if debug_one_gpu else dev
+        gathers = [ResultGather(n * 16, min(64 * n, cig_cap), gdev, torch.int32) for _ in range(nsets)]
+    step_no = [0]
 
     def step():
-        used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_out.data_ptr(), d_cig.data_ptr(),
+        b = step_no[0] % nsets
+        step_no[0] += 1
+        if gathers:
+            gathers[b].wait()  # the gather that last read this buffer set
+        used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_outs[b].data_ptr(), d_cigs[b].data_ptr(),
                                       cig_cap, want=want, stream=stream)
-        if world > 1:  # all-gatherv of result records + CIGAR words over RCCL
+        if gathers:  # all-gather of result records + CIGAR words over RCCL, asynchronous
             if debug_one_gpu:
-                gathered["recs"], gathered["cig"], gathered["cnts"] = allgatherv_results(d_out.cpu(), d_cig.cpu(), used)
+                gathers[b].start(d_outs[b].cpu(), d_cigs[b].cpu(), used)
             else:
-                gathered["recs"], gathered["cig"], gathered["cnts"] = allgatherv_results(d_out, d_cig, used)
+                gathers[b].start(d_outs[b], d_cigs[b], used)
         return used
 
     def sync():
+        for g in gathers:
+            g.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -328,6 +343,11 @@ def main():
     else:
         cells_all = cells_rank
 
+    if gathers:  # every rank holds every rank's results: check this rank's own slice of the last gather
+        lb = (step_no[0] - 1) % nsets
+        ra, ca, cnts = gathers[lb].result()
+        assert int(cnts[rank, 0]) == n * 16 and int(cnts[rank, 1]) == used
+        assert torch.equal(ra[rank].cpu(), d_outs[lb].cpu()) and torch.equal(ca[rank][:used].cpu(), d_cigs[lb][:used].cpu())
     if rank == 0:
         res = d_out.cpu().numpy().view(sedef_amd.RESULT_DTYPE)
         assert int(res["n_cigar"].astype(np.int64).sum()) == used

@@ -50,3 +50,50 @@ def allgatherv_results(records, cigars, used, group=None):
     dist.all_gather_into_tensor(rec_all, rec_pad.contiguous(), group=group)
     dist.all_gather_into_tensor(cig_all, cig_pad.contiguous(), group=group)
     return rec_all.view(world, n_max), cig_all.view(world, c_max), counts
+
+
+class ResultGather:
+    """All-gather of one step's results into preallocated buffers, asynchronously: `start` enqueues the three
+    collectives (counts, result records, CIGAR words up to a fixed capacity) and returns; the caller computes the
+    next step into ANOTHER set of buffers and calls `wait` before it reuses this set (or reads `result`).  Over nccl
+    (RCCL) the collectives run on the communicator's stream under the next step's kernels; nothing blocks the host.
+
+    Every rank passes the same `rec_words` (records are fixed-size) and `cig_cap` (words gathered per rank: the
+    valid prefix is `counts[r, 1]`, the rest is padding)."""
+
+    def __init__(self, rec_words, cig_cap, device, dtype, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rec_words, self.cig_cap = int(rec_words), int(cig_cap)
+        self.mine = torch.zeros(2, dtype=torch.int64, device=device)
+        self.counts = torch.zeros(self.world * 2, dtype=torch.int64, device=device)
+        self.recs = torch.empty(self.world * self.rec_words, dtype=dtype, device=device)
+        self.cig = torch.empty(self.world * self.cig_cap, dtype=dtype, device=device)
+        self.handles = []
+
+    def start(self, records, cigars, used):
+        import torch.distributed as dist
+        if records.numel() != self.rec_words or int(used) > self.cig_cap or cigars.numel() < self.cig_cap:
+            raise ValueError("ResultGather: %d record words / %d CIGAR words do not fit (%d / %d)" %
+                             (records.numel(), int(used), self.rec_words, self.cig_cap))
+        self.wait()
+        self.mine[0] = records.numel()
+        self.mine[1] = int(used)
+        self.handles = [
+            dist.all_gather_into_tensor(self.counts, self.mine, group=self.group, async_op=True),
+            dist.all_gather_into_tensor(self.recs, records, group=self.group, async_op=True),
+            dist.all_gather_into_tensor(self.cig, cigars[:self.cig_cap], group=self.group, async_op=True),
+        ]
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    def result(self):
+        """(records [world, rec_words], cigars [world, cig_cap], counts [world, 2]) of the last `start`."""
+        self.wait()
+        return (self.recs.view(self.world, self.rec_words), self.cig.view(self.world, self.cig_cap),
+                self.counts.view(self.world, 2))

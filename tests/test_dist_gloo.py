@@ -71,3 +71,53 @@ def test_allgatherv_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert out.get(0) is True and out.get(1) is True
+
+
+def _worker_async(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    from sedef_amd.dist import ResultGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, cap = 50, 400
+        sets = [ResultGather(n * 16, cap, torch.device("cpu"), torch.int32) for _ in range(2)]
+        ok = True
+        expect = {}
+        for step in range(5):  # two buffer sets in rotation: the gather of step i is read after step i+1 started
+            b = step % 2
+            rec = torch.full((n * 16,), 1000 * step + rank, dtype=torch.int32)
+            used = 100 + 7 * rank + step
+            cig = torch.full((cap + 9,), -1, dtype=torch.int32)
+            cig[:used] = 10 * step + rank
+            sets[b].start(rec, cig, used)
+            expect[b] = step
+            if step:
+                pb = (step - 1) % 2
+                ra, ca, counts = sets[pb].result()
+                for r in range(world):
+                    ps = expect[pb]
+                    ok &= bool((ra[r] == 1000 * ps + r).all()) and int(counts[r, 0]) == n * 16
+                    u = int(counts[r, 1])
+                    ok &= u == 100 + 7 * r + ps and bool((ca[r][:u] == 10 * ps + r).all())
+        try:
+            sets[0].start(torch.zeros(n * 16, dtype=torch.int32), torch.zeros(cap, dtype=torch.int32), cap + 1)
+            ok = False
+        except ValueError:
+            pass
+        for s_ in sets:
+            s_.wait()
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_async_result_gather_world2_gloo():
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_async, args=(2, port, out), nprocs=2, join=True)
+    assert out.get(0) is True and out.get(1) is True
