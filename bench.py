@@ -240,7 +240,7 @@ def main():
     import torch.distributed as dist
 
     import sedef_amd
-    from sedef_amd.dist import ResultGather
+    from sedef_amd.dist import ResultGather, allgatherv_results
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,6 +293,7 @@ def main():
         gdev = torch.device("cpu") if debug_one_gpu else dev
         gathers = [ResultGather(n * 16, min(64 * n, cig_cap), gdev, torch.int32) for _ in range(nsets)]
     step_no = [0]
+    sync_gathered = [None, None, None]
 
     def step():
         b = step_no[0] % nsets
@@ -302,10 +303,18 @@ def main():
         used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_outs[b].data_ptr(), d_cigs[b].data_ptr(),
                                       cig_cap, want=want, stream=stream)
         if gathers:  # all-gather of result records + CIGAR words over RCCL, asynchronous
-            if debug_one_gpu:
-                gathers[b].start(d_outs[b].cpu(), d_cigs[b].cpu(), used)
-            else:
-                gathers[b].start(d_outs[b], d_cigs[b], used)
+            try:
+                if debug_one_gpu:
+                    gathers[b].start(d_outs[b].cpu(), d_cigs[b].cpu(), used)
+                else:
+                    gathers[b].start(d_outs[b], d_cigs[b], used)
+            except (RuntimeError, ValueError) as e:  # (same on every rank) -> the synchronous gather from here on
+                if rank == 0:
+                    print("asynchronous gather unavailable (%s): synchronous all-gather" % e, file=sys.stderr)
+                del gathers[:]
+        if world > 1 and not gathers:
+            src = (d_outs[b].cpu(), d_cigs[b].cpu()) if debug_one_gpu else (d_outs[b], d_cigs[b])
+            sync_gathered[:] = allgatherv_results(src[0], src[1], used)
         return used
 
     def sync():
