@@ -266,3 +266,31 @@ class ReferenceAlign:
         rc = self.lib.ref_merge(spec.encode(), merge_dist, self.buf, len(self.buf))
         assert rc == 0
         return self.buf.value.decode()
+
+    def fasta_get(self, fasta_path, name, length, offset, line_blen, line_len, start, end=None):
+        """FastaReference::get_sequence (src/fasta.cc:105-142); `fasta_path` must have no .fai next to it (the one
+        index entry is given here).  Returns (sequence, end after clamping)."""
+        e = C.c_int(0 if end is None else end)
+        f = self.lib.ref_fasta_get
+        f.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int,
+                      C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        rc = f(fasta_path.encode(), name.encode(), length, offset, line_blen, line_len, start, int(end is not None),
+               C.byref(e), self.buf, len(self.buf))
+        assert rc == 0, self.buf.value
+        return self.buf.value.decode(), (None if end is None else e.value)
+
+    def hit_extend(self, qs, qe, rs, re_, factor=5.0, max_extend=15000):
+        io = (C.c_int * 4)(qs, qe, rs, re_)
+        self.lib.ref_hit_extend.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        self.lib.ref_hit_extend(io, factor, max_extend)
+        return list(io)
+
+    def sequence(self, name, seq):
+        rc = self.lib.ref_sequence(name.encode(), seq.encode(), self.buf, len(self.buf))
+        assert rc == 0
+        n, s, r = self.buf.value.decode().split("|")
+        return n, s, r == "1"
+
+    def set_scoring(self, match=5, mismatch=-4, gap_open=-40, gap_extend=-1):
+        """Globals::Align::* as the CLI overrides set them (src/align_main.cc:343-352); process-wide in the reference."""
+        self.lib.ref_set_scoring(match, mismatch, gap_open, gap_extend)

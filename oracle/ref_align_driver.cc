@@ -10,6 +10,9 @@
 #include <vector>
 
 #include "align.h"
+#include "fasta.h"
+#include "globals.h"
+#include "hash.h"
 #include "hit.h"
 #include "merge.h"
 
@@ -113,5 +116,49 @@ int ref_merge(const char *spec, int merge_dist, char *out, size_t cap) {
   for (auto &h : res) os << h.to_bed(false) << "\n";
   return emit(os.str(), out, cap);
 }
+
+// FastaReference::get_sequence (src/fasta.cc:105-142).  The reference parses the .fai with split() (src/util.cc, needs
+// Boost.Math, not compiled): `fasta_path` must have NO .fai next to it, so the constructor leaves the index empty, and
+// the one index entry is inserted here through the public FastaIndex map.  `has_end` = 0 passes end = nullptr.
+int ref_fasta_get(const char *fasta_path, const char *name, int length, long long offset, int line_blen, int line_len,
+                  int start, int has_end, int *end, char *out, size_t cap) {
+  try {
+    FastaReference fr{string(fasta_path)};
+    fr.index.insert(make_pair(string(name), FastaIndexEntry(name, length, offset, line_blen, line_len)));
+    string s = fr.get_sequence(name, start, has_end ? end : nullptr);
+    return emit(s, out, cap);
+  } catch (string &e) {
+    emit(e, out, cap);
+    return -1;
+  }
 }
 
+// Hit::extend (src/hit.cc:200-207): io = {query_start, query_end, ref_start, ref_end}
+int ref_hit_extend(int *io, double factor, int max_extend) {
+  auto q = make_shared<Sequence>("q", "", false);
+  auto r = make_shared<Sequence>("r", "", false);
+  Hit h{q, io[0], io[1], r, io[2], io[3], 0, "", "", {}};
+  h.extend(factor, max_extend);
+  io[0] = h.query_start;
+  io[1] = h.query_end;
+  io[2] = h.ref_start;
+  io[3] = h.ref_end;
+  return 0;
+}
+
+// Sequence ctor (src/hash.cc:104-109) with is_rc = false (is_rc = true calls rc(), src/util.cc, not compiled).
+// Output: "name|seq|is_rc".
+int ref_sequence(const char *name, const char *seq, char *out, size_t cap) {
+  Sequence s{string(name), string(seq), false};
+  return emit(s.name + "|" + s.seq + "|" + (s.is_rc ? "1" : "0"), out, cap);
+}
+
+// CLI scoring overrides (src/align_main.cc:343-352 assign these statics; src/align.cc:84-86,343-456 read them)
+int ref_set_scoring(int match, int mismatch, int gap_open, int gap_extend) {
+  Globals::Align::MATCH = match;
+  Globals::Align::MISMATCH = mismatch;
+  Globals::Align::GAP_OPEN = gap_open;
+  Globals::Align::GAP_EXTEND = gap_extend;
+  return 0;
+}
+}

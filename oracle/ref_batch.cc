@@ -31,3 +31,28 @@ extern "C" int64_t ref_extz2_batch(int64_t n, const uint8_t *pool, const int64_t
   }
   return done;
 }
+
+// Single-task entry with the oracle's signature (oracle/extz2_oracle.h: sdfo_extz2) around the REFERENCE kernel, so
+// that the host pipeline's test hook can run the stage-scale CPU leg on ksw_extz2_sse itself.
+struct hook_result {  // layout of sdfo_result
+  uint32_t max;
+  int32_t zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score;
+  int64_t n_cigar;
+  uint32_t *cigar;
+};
+extern "C" void ref_extz2_hook(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m,
+                               const int8_t *mat, int gapo, int gape, int w, int zdrop, int flag, hook_result *out) {
+  ksw_extz_t ez;
+  ksw_extz2_sse(0, qlen, query, tlen, target, (int8_t)m, mat, (int8_t)gapo, (int8_t)gape, w, zdrop, flag, &ez);
+  out->max = ez.max;
+  out->zdropped = ez.zdropped;
+  out->max_q = ez.max_q;
+  out->max_t = ez.max_t;
+  out->mqe = ez.mqe;
+  out->mqe_t = ez.mqe_t;
+  out->mte = ez.mte;
+  out->mte_q = ez.mte_q;
+  out->score = ez.score;
+  out->n_cigar = ez.n_cigar;
+  out->cigar = ez.cigar;  // malloc'd by the reference, the caller free()s (src/align.cc:65)
+}

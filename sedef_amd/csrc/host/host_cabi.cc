@@ -63,10 +63,27 @@ int sdfh_generate(const char *ref_path, const char *bed_path, int kmer, const ch
 }
 
 // Alignment(fa, fb) (reference: src/align.cc:76-88): CIGAR string + counters {matches, mismatches, gaps, gap_bases, span}
+static int alignment_pair_impl(const Params &p, const char *fa, const char *fb, test_dp_fn test_dp, int device,
+                               char *cigar, size_t cap, int *counts);
 int sdfh_alignment_pair(const char *fa, const char *fb, test_dp_fn test_dp, int device, char *cigar, size_t cap,
                         int *counts) {
+  return alignment_pair_impl(Params(), fa, fb, test_dp, device, cigar, cap, counts);
+}
+// the same with the CLI's scoring overrides (reference: src/align_main.cc:343-352)
+int sdfh_alignment_pair_scored(const char *fa, const char *fb, int match, int mismatch, int gap_open, int gap_extend,
+                               test_dp_fn test_dp, int device, char *cigar, size_t cap, int *counts) {
+  Params p;
+  p.match = match;
+  p.mismatch = mismatch;
+  p.gap_open = gap_open;
+  p.gap_extend = gap_extend;
+  const int rc = alignment_pair_impl(p, fa, fb, test_dp, device, cigar, cap, counts);
+  set_alignment_scoring(Params());
+  return rc;
+}
+static int alignment_pair_impl(const Params &p, const char *fa, const char *fb, test_dp_fn test_dp, int device,
+                               char *cigar, size_t cap, int *counts) {
   try {
-    Params p;
     set_alignment_scoring(p);
     auto dp = provider(test_dp, device);
     std::vector<DpRequest> reqs;
@@ -353,6 +370,27 @@ int sdfh_chain_raw(const int32_t *anchors, int m, int max_chain_gap, int match_c
     g_err = s;
     return -1;
   }
+}
+
+// Hit::extend (reference: src/hit.cc:200-207): io = {query_start, query_end, ref_start, ref_end}
+int sdfh_hit_extend(int *io, double factor, int max_extend) {
+  Hit h;
+  h.query_start = io[0];
+  h.query_end = io[1];
+  h.ref_start = io[2];
+  h.ref_end = io[3];
+  h.extend(factor, max_extend);
+  io[0] = h.query_start;
+  io[1] = h.query_end;
+  io[2] = h.ref_start;
+  io[3] = h.ref_end;
+  return 0;
+}
+
+// Sequence ctor (reference: src/hash.cc:104-109): "name|seq|is_rc"
+int sdfh_sequence(const char *name, const char *seq, int is_rc, char *buf, size_t cap) {
+  Sequence s(name, seq, is_rc != 0);
+  return copy_out(s.name + "|" + s.seq + "|" + (s.is_rc ? "1" : "0"), buf, cap);
 }
 
 }  // extern "C"

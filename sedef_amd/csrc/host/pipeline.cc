@@ -217,15 +217,19 @@ class TestProvider : public DpProvider {
     expand(reqs, p, tr, pool);
     int8_t mat[25];
     fill_mat(p, mat);
-    for (auto &t : tr) {
-      OracleResult r;
-      memset(&r, 0, sizeof(r));
+    // the hook is re-entrant (like ksw_extz2_sse): tasks run on all host threads, CIGARs are appended in task order
+    std::vector<OracleResult> res(tr.size());
+    parallel_for((int)tr.size(), [&](int k) {
+      const TaskRef &t = tr[(size_t)k];
+      memset(&res[(size_t)k], 0, sizeof(OracleResult));
       fn_(t.qlen, pool.data() + t.q_off, t.tlen, pool.data() + t.t_off, 5, mat, -p.gap_open, -p.gap_extend, -1, -1,
-          0, &r);
-      append_ops(out[t.req], r.cigar, r.n_cigar);
-      free(r.cigar);
+          0, &res[(size_t)k]);
+    });
+    for (size_t k = 0; k < tr.size(); k++) {
+      append_ops(out[tr[k].req], res[k].cigar, res[k].n_cigar);
+      free(res[k].cigar);
       tasks++;
-      cells += (int64_t)t.qlen * t.tlen;
+      cells += (int64_t)tr[k].qlen * tr[k].tlen;
     }
     return out;
   }

@@ -72,10 +72,16 @@ def _buffer():
     return _buf
 
 
-def alignment_pair(fa, fb, test_dp=None, device=0):
+def alignment_pair(fa, fb, test_dp=None, device=0, scoring=None):
+    """Alignment(fa, fb) (reference: src/align.cc:76-88) -> (CIGAR string, [matches, mismatches, gaps, gap_bases, span]).
+    scoring = (match, mismatch, gap_open, gap_extend) as the CLI overrides (src/align_main.cc:343-352)."""
     lib, buf = load_host(), _buffer()
     cnt = (C.c_int * 5)()
-    _err(lib, lib.sdfh_alignment_pair(fa.encode(), fb.encode(), test_dp, device, buf, len(buf), cnt))
+    if scoring is None:
+        _err(lib, lib.sdfh_alignment_pair(fa.encode(), fb.encode(), test_dp, device, buf, len(buf), cnt))
+    else:
+        _err(lib, lib.sdfh_alignment_pair_scored(fa.encode(), fb.encode(), *[int(x) for x in scoring], test_dp, device,
+                                                 buf, len(buf), cnt))
     return buf.value.decode(), list(cnt)
 
 
@@ -112,9 +118,10 @@ def chain_raw(anchors, max_chain_gap=210, match_chain_score=4):
 
 def fasta_get(path, name, start, end):
     lib, buf = load_host(), _buffer()
-    e = C.c_int(end)
-    _err(lib, lib.sdfh_fasta_get(path.encode(), name.encode(), start, C.byref(e), buf, len(buf)))
-    return buf.value.decode(), e.value
+    e = C.c_int(0 if end is None else end)
+    _err(lib, lib.sdfh_fasta_get(path.encode(), name.encode(), start, None if end is None else C.byref(e), buf,
+                                 len(buf)))
+    return buf.value.decode(), (None if end is None else e.value)
 
 
 def merge(bed_lines, merge_dist=250):
@@ -134,3 +141,20 @@ def anchors(q, r, kmer=11, same_chr=False, qstart=0, rstart=0):
     lib.sdfh_anchors.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
     _err(lib, lib.sdfh_anchors(q.encode(), r.encode(), kmer, int(same_chr), qstart, rstart, buf, len(buf)))
     return [tuple(int(x) for x in a.split()) for a in buf.value.decode().split(";") if a]
+
+
+def hit_extend(qs, qe, rs, re_, factor=5.0, max_extend=15000):
+    """Hit::extend (reference: src/hit.cc:200-207)."""
+    lib = load_host()
+    io = (C.c_int * 4)(qs, qe, rs, re_)
+    lib.sdfh_hit_extend.argtypes = [C.c_void_p, C.c_double, C.c_int]
+    _err(lib, lib.sdfh_hit_extend(io, factor, max_extend))
+    return list(io)
+
+
+def sequence(name, seq, is_rc=False):
+    """Sequence ctor (reference: src/hash.cc:104-109) -> (name, seq, is_rc)."""
+    lib, buf = load_host(), _buffer()
+    _err(lib, lib.sdfh_sequence(name.encode(), seq.encode(), int(is_rc), buf, len(buf)))
+    n, s, r = buf.value.decode().split("|")
+    return n, s, r == "1"

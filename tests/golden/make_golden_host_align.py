@@ -20,6 +20,60 @@ import hostgen  # noqa: E402
 from sedef_amd import host  # noqa: E402
 
 
+def io_cases(ref):
+    """FastaReference::get_sequence (src/fasta.cc:105-142), Hit::extend (src/hit.cc:200-207), Sequence ctor
+    (src/hash.cc:104-109) of the reference: inputs and what it returned."""
+    import tempfile
+    rng = np.random.default_rng(4242)  # own stream: the sections above stay byte-identical
+    fastas = []
+    for line_blen, nchr in ((60, 2), (7, 3), (70, 1), (1, 2), (50, 2)):
+        text, entries = hostgen.fasta_text(rng, nchr, line_blen)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "g.fa")  # no .fai next to it (see oracle/ref_align_driver.cc: ref_fasta_get)
+            open(path, "w").write(text)
+            queries = []
+            for (name, length, offset, lb, ll) in entries:
+                for (start, end) in hostgen.fasta_queries(rng, length, lb):
+                    seq, e = ref.fasta_get(path, name, length, offset, lb, ll, start, end)
+                    queries.append(dict(name=name, start=start, end=end, seq=seq, end_out=e))
+        fastas.append(dict(text=text, entries=entries, queries=queries))
+    extends = []
+    for _ in range(200):
+        qs, rs = int(rng.integers(0, 40000)), int(rng.integers(0, 40000))
+        io = [qs, qs + int(rng.integers(1, 9000)), rs, rs + int(rng.integers(1, 9000))]
+        factor = float(rng.choice([5.0, 0.5, 1.25, 3.0]))
+        mx = int(rng.choice([15000, 100, 2500]))
+        extends.append(dict(io=io, factor=factor, max_extend=mx, expect=ref.hit_extend(*io, factor, mx)))
+    sequences = []
+    for name, seq in (("chr1", "ACGTNacgtn"), ("", ""), ("a b", "NNNN"), ("chrX_random", hostgen.rseq(rng, 300, 0.05))):
+        sequences.append(dict(name=name, seq=seq, expect=list(ref.sequence(name, seq))))
+    return fastas, extends, sequences
+
+
+def scoring_and_chunk_cases(ref):
+    """Alignment(fa, fb) under the CLI's scoring overrides (src/align_main.cc:343-352) and on sequences beyond
+    Align::MAX_KSW_SEQ_LEN (the 60 kb chunk loop of align_helper, src/align.cc:46-57): what the reference returns."""
+    import hashlib
+    rng = np.random.default_rng(1717)
+    scored = []
+    for sc in ((3, -5, -20, -2), (1, -1, -2, -1), (7, -3, -60, -3)):
+        ref.set_scoring(*sc)
+        for it in range(12):
+            a = hostgen.rseq(rng, int(rng.integers(1, 700)), 0.01 if it % 3 == 0 else 0)
+            b = hostgen.mut(rng, a, rng.random() * 0.2)
+            cig, cnt = ref.alignment_pair(a, b)
+            scored.append(dict(a=a, b=b, scoring=list(sc), cigar=cig, counts=cnt))
+    ref.set_scoring()
+    chunked = []
+    for (seed, n, d) in ((5, 60050, 0.03), (6, 60200, 0.002)):
+        a, b = hostgen.chunk_case(seed, n, d)
+        cig, cnt = ref.alignment_pair(a, b)
+        chunked.append(dict(seed=seed, n=n, d=d, len_a=len(a), len_b=len(b), counts=cnt, cigar_len=len(cig),
+                            cigar_sha256=hashlib.sha256(cig.encode()).hexdigest(), cigar_head=cig[:60],
+                            cigar_tail=cig[-60:]))
+    return scored, chunked
+
+
 def main():
     ref = ReferenceAlign()
     rng = np.random.default_rng(777)
@@ -39,9 +93,12 @@ def main():
     for _ in range(40):
         lines, spec = hostgen.merge_case(rng)
         merges.append(dict(lines=lines, expect=ref.merge(spec, 250)))
+    fastas, extends, sequences = io_cases(ref)
+    scored, chunked = scoring_and_chunk_cases(ref)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_align_kat.json.gz")
     blob = json.dumps(dict(source="reference src/align.cc + src/hit.cc via oracle/_ref/libref_align.so",
-                           pairs=pairs, guides=guides, merges=merges), separators=(",", ":")).encode()
+                           pairs=pairs, guides=guides, merges=merges, fastas=fastas, extends=extends,
+                           sequences=sequences, scored=scored, chunked=chunked), separators=(",", ":")).encode()
     with gzip.GzipFile(out, "wb", mtime=0) as f:
         f.write(blob)
     print("wrote %s: %d pairs, %d guides, %d bytes" % (out, len(pairs), len(guides), os.path.getsize(out)))

@@ -128,3 +128,144 @@ def merge_case(rng):
                                                                        "-" if rcf else "+"))
         spec.append("%s %d %d %s %d %d %d" % (qn, qs, qs + L, rn, rs, rs + L2, rcf))
     return lines, "\n".join(spec)
+
+
+def fasta_text(rng, nchr, line_blen):
+    """A small multi-chromosome FASTA and its .fai entries (name, length, offset, line_blen, line_len)."""
+    text, entries = "", []
+    for c in range(nchr):
+        length = int(rng.integers(1, 6 * line_blen + 40))
+        if c == 0:
+            length = 3 * line_blen  # ends exactly on a line boundary
+        head = ">chr%d some description\n" % (c + 1)
+        text += head
+        entries.append(["chr%d" % (c + 1), length, len(text), line_blen, line_blen + 1])
+        s = rseq(rng, length, 0.02)
+        for i in range(0, length, line_blen):
+            text += s[i:i + line_blen] + "\n"
+    return text, entries
+
+
+def fasta_queries(rng, length, line_blen):
+    """(start, end) pairs incl. negative starts, ends beyond the chromosome (clamped), end=None, line-boundary starts."""
+    qs = [(0, None), (0, length), (-3, length + 10), (0, 1), (length - 1, length), (length - 1, None)]
+    for k in range(1, 4):
+        if k * line_blen < length:
+            qs += [(k * line_blen, None), (k * line_blen, min(length, k * line_blen + 1)), (k * line_blen - 1, length + 5)]
+    for _ in range(12):
+        a = int(rng.integers(-2, length))
+        b = int(rng.integers(max(a, 0) + 1, length + 8))
+        qs.append((a, b))
+    return [(a, b) for (a, b) in qs if max(a, 0) < length]
+
+
+# ---------------------------------------------------------------- stage-scale genome (BASELINE configs[0] / configs[2] shape)
+_CODE2CHR = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _mutate_codes(rng, s, d):
+    """Vectorised form of mut(): 60 % substitution draws, 20 % deletions, 20 % insertions of the events."""
+    r = rng.random(len(s))
+    sub = r < d * 0.6
+    dele = (r >= d * 0.6) & (r < d * 0.8)
+    ins = (r >= d * 0.8) & (r < d)
+    s = s.copy()
+    s[sub] = rng.integers(0, 4, int(sub.sum()), dtype=np.uint8)
+    cnt = np.ones(len(s), np.int64)
+    cnt[dele] = 0
+    cnt[ins] = 2
+    out = np.repeat(s, cnt)
+    pos = np.cumsum(cnt)[ins] - 1
+    out[pos] = rng.integers(0, 4, len(pos), dtype=np.uint8)
+    return out
+
+
+def make_big_genome(path, seed=7, chrom_lens=(25_000_000, 18_000_000, 9_000_000, 500_000), n_pairs=5200,
+                    slot=5000, min_len=1000, max_len=4000):
+    """Multi-chromosome FASTA + .fai + seed BED (as `sedef search` would hand to `align bucket`): `n_pairs` planted
+    duplications (forward and reverse-complement, 1-15 % divergence, some with a large insertion), 40 % soft-masking,
+    N runs, and duplications planted against chromosome ends so that the extended hit is clamped by
+    FastaReference::get_sequence (reference: src/fasta.cc:112-116, src/align_main.cc:303-321).
+    Returns {name: genome string} and the number of seed lines."""
+    rng = np.random.default_rng(seed)
+    names = ["chr%s" % c for c in "ABCDEFGH"[:len(chrom_lens)]]
+    seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in chrom_lens]
+    # destination slots: distinct, `slot` bases each; the last slot of every chromosome is used first (end clamp)
+    slots = [(c, k) for c, L in enumerate(chrom_lens) for k in range(L // slot)]
+    last = [(c, L // slot - 1) for c, L in enumerate(chrom_lens)]
+    first = [(c, 0) for c, L in enumerate(chrom_lens)]
+    forced = last + first + [(c, L // slot - 2) for c, L in enumerate(chrom_lens)]
+    rest = [s for s in slots if s not in set(forced)]
+    pick = rng.permutation(len(rest))[:n_pairs - len(forced)]
+    dests = forced + [rest[i] for i in pick]
+    taken = set(dests)
+    free = [s for s in slots if s not in taken]  # sources come from slots no copy is written to
+    beds = []
+    for k, (dc, ds) in enumerate(dests):
+        L = int(rng.integers(min_len, max_len))
+        sc, ss = free[int(rng.integers(0, len(free)))]
+        sp = ss * slot + int(rng.integers(0, slot - L + 1))
+        out = _mutate_codes(rng, seqs[sc][sp:sp + L], float(rng.uniform(0.01, 0.15)))
+        if rng.random() < 0.3 and len(out) > 300:
+            kk = int(rng.integers(100, len(out) - 100))
+            out = np.concatenate([out[:kk], rng.integers(0, 4, int(rng.integers(50, 400)), dtype=np.uint8), out[kk:]])
+        rcf = bool(rng.random() < 0.45)
+        if k < len(forced):
+            rcf = bool(k % 2)
+        if rcf:
+            out = (3 - out)[::-1]
+        out = out[:slot]
+        if k < len(last):  # flush against the chromosome end
+            dp = chrom_lens[dc] - len(out)
+        elif k < len(last) + len(first):  # flush against the chromosome start
+            dp = 0
+        else:
+            dp = ds * slot + int(rng.integers(0, slot - len(out) + 1))
+        seqs[dc][dp:dp + len(out)] = out
+        j = int(rng.integers(0, 60))  # seeds are never exact
+        beds.append((names[sc], sp + j, sp + L - j, names[dc], dp + j // 2, dp + len(out) - j, rcf))
+    genome = {}
+    with open(path, "wb") as f, open(path + ".fai", "w") as fai:
+        off = 0
+        for name, s, L in zip(names, seqs, chrom_lens):
+            ch = _CODE2CHR[s]
+            # soft-mask ~40 % in runs of 50..400, a few N runs
+            runs = rng.integers(50, 400, L // 100 + 10)
+            ends = np.cumsum(runs)
+            ends = ends[ends < L]
+            masked = rng.random(len(ends) + 1) < 0.4
+            mask = np.repeat(masked, np.diff(np.concatenate(([0], ends, [L]))))
+            ch = np.where(mask, ch + 32, ch).astype(np.uint8)
+            for _ in range(max(2, L // 2_000_000)):
+                p, n = int(rng.integers(0, L - 6000)), int(rng.integers(100, 5000))
+                ch[p:p + n] = ord("N")
+            head = (">%s synthetic\n" % name).encode()
+            f.write(head)
+            off += len(head)
+            fai.write("%s\t%d\t%d\t60\t61\n" % (name, L, off))
+            full = L // 60
+            body = np.empty((full, 61), np.uint8)
+            body[:, :60] = ch[:full * 60].reshape(full, 60)
+            body[:, 60] = 10
+            f.write(body.tobytes())
+            off += full * 61
+            if L % 60:
+                f.write(ch[full * 60:].tobytes() + b"\n")
+                off += L % 60 + 1
+            genome[name] = ch.tobytes().decode()
+    with open(path + ".seeds.bed", "w") as f:
+        for (qn, qs, qe, rn, rs, re_, rcf) in beds:
+            f.write("%s\t%d\t%d\t%s\t%d\t%d\t\t\t+\t%s\t%d\t0\t\tOK\n" % (qn, qs, qe, rn, rs, re_, "-" if rcf else "+",
+                                                                        max(qe - qs, re_ - rs)))
+    return genome, len(beds)
+
+
+def chunk_case(seed=5, n=60050, d=0.03):
+    """Two related sequences longer than Align::MAX_KSW_SEQ_LEN = 60,000 (reference: src/globals.h:54): align_helper
+    cuts them into 60 kb x 60 kb chunks at equal offsets (src/align.cc:46-57)."""
+    rng = np.random.default_rng(seed)
+    a = _mutate_codes(rng, rng.integers(0, 4, n, dtype=np.uint8), 0.0)
+    b = _mutate_codes(rng, a, d)
+    low = rng.random(len(a)) < 0.3
+    sa = np.where(low, _CODE2CHR[a] + 32, _CODE2CHR[a]).astype(np.uint8).tobytes().decode()
+    return sa, _CODE2CHR[b].tobytes().decode()
