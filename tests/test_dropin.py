@@ -139,7 +139,9 @@ def test_sdf_ksw_extz2_fatal_error_exits_120():
     code = ("import ctypes as C, numpy as np, sys; sys.path.insert(0, %r); import sedef_amd; "
             "from oracle.binding import _KswExtz; lib = sedef_amd.load_library(); ez = _KswExtz(); "
             "q = np.zeros(40, np.uint8); mat = np.zeros(36, np.int8); "
-            "lib.sdf_ksw_extz2(None, 40, q.ctypes.data, 40, q.ctypes.data, C.c_int8(6), mat.ctypes.data, C.c_int8(40), "
-            "C.c_int8(1), -1, -1, 0, C.byref(ez))" % ROOT)
+            "lib.sdf_ksw_extz2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int8, C.c_void_p, "
+            "C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int, C.c_void_p]; "
+            "lib.sdf_ksw_extz2(None, 40, q.ctypes.data, 40, q.ctypes.data, 6, mat.ctypes.data, 40, 1, -1, -1, 0, "
+            "C.addressof(ez))" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 120 and "sdf_ksw_extz2" in r.stderr
