@@ -1,0 +1,145 @@
+// Context, device / pinned buffers and kernel declarations shared by the pieces of the C-ABI layer
+// (sdf_plan.hip: batch cutting and chunk planning; sdf_launch.hip: uploads and launches; sdf_api.hip: entry points).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+template <int BS, bool GLOBAL, bool PLAIN>
+__global__ void extz2_general_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                     sdf_result *, uint8_t *, size_t);
+size_t general_lds_bytes(int qlen, int tlen);
+template <int NREG, bool STREAM>
+__global__ void extz2_wave_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                  sdf_result *);
+size_t wave_lds_bytes(int qlen, int tlen, int nreg);
+bool wave_fits_whole(int qlen, int tlen, int nreg);
+template <int NREG, bool STREAM>
+__global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                  sdf_result *);
+size_t pair_lds_bytes(int qlen, int tlen, int nreg);
+bool pair_fits_whole(int qlen, int tlen, int nreg);
+template <int NREG>
+__global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                    sdf_result *);
+size_t stripe_lds_bytes(int qlen, int nstripe, int nreg);
+size_t stripe_dir_bytes(int qlen, int nreg);
+template <int LAYOUT, int G>
+__global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
+__global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
+__global__ void cigar_scan_parts_kernel(unsigned long long *, int, unsigned long long *);
+__global__ void cigar_scan_add_kernel(sdf_result *, int, const unsigned long long *);
+__global__ void cigar_compact_kernel(const PlanTask *, int, const sdf_result *, const uint32_t *,
+                                     uint32_t *, unsigned long long);
+
+__global__ void reset_results_kernel(sdf_result *res, int n);
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t old = cap;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    // growing means a free (which waits for the device) and an allocation, tens to hundreds of milliseconds for
+    // gigabytes: leave half as much again as headroom (at most 8 GiB) so that batches of similar size do not regrow
+    size_t want = bytes + std::min<size_t>(bytes / 2, (size_t)8 << 30) + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipMalloc(&p, want);
+    }
+    if (e == hipSuccess) cap = want;
+    if (dbg_t && want >= (64u << 20))
+      fprintf(stderr, "[DevBuf %zu -> %zu MiB in %.1f ms]\n", old >> 20, want >> 20,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct HostBuf {  // pinned host memory
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace sdf
+
+namespace sdf {
+struct BatchCut;
+}
+using sdf::DevBuf;
+using sdf::HostBuf;
+
+struct sdf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t ws_budget = 0;
+  hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr;  // chunk pipeline
+  hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};    // more room for launches that end in a tail
+  // high-priority streams for the heavy launches of a batch (created on first use): their workgroups -- up to 16
+  // wavefronts that need a CU's wavefront slots together -- are dispatched ahead of the ordinary chunks' queued next to them
+  hipStream_t hi_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool hi_tried = false;
+  bool no_hi_prio = false;  // SDF_NO_HI_PRIO=1
+  DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
+  HostBuf host_plan, host_order;  // pinned staging of the plan
+  HostBuf host_pool, host_out;    // pinned staging of the host-buffer entry point (packed sequences; results + CIGARs)
+  DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
+  DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
+  DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
+  sdf::BatchCut *cut = nullptr;  // chunk list and planning scratch of the last batch call (sdf_plan.hip)
+  std::vector<hipEvent_t> events;
+  float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 DP, 1 traceback, 2 compaction, 3 stream total, 4 host planning before the
+                                           // first launch, 5 host total, 6 sum of the chunks' DP intervals
+  int launches = 0;
+  long long paired = 0;  // tasks of the last batch that ran two per wavefront (extz2_pair.hip)
+  std::string err;
+  int max_dyn_lds = 64 * 1024;
+  bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
+  bool pipeline = true;        // SDF_PIPELINE=0: one chunk on one stream (isolated kernel timing)
+  int stripe_min = 1024;       // SDF_STRIPE_MIN: targets longer than this (and full band) take the stripe kernel
+  bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
+  bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
+};
+
+#define SDF_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      return SDF_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)

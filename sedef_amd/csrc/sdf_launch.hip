@@ -1,0 +1,380 @@
+// Device side of a batch call: uploads a planned chunk, launches its DP kernels and its traceback, and closes the
+// batch (CIGAR scan + compaction, timing).  Planning is in sdf_plan.hip; the entry points are in sdf_api.hip.
+#include "sdf_ctx.h"
+
+namespace sdf {
+
+__global__ __launch_bounds__(256) void reset_results_kernel(sdf_result *res, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  sdf_result o;  // ksw_reset_extz (reference: extern/ksw2.h:153-159)
+  o.score = o.mqe = o.mte = SDF_NEG_INF;
+  o.max = 0;
+  o.max_q = o.max_t = o.mqe_t = o.mte_q = -1;
+  o.zdropped = 0;
+  o.n_cigar = 0;
+  o.cigar_off = 0;
+  o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
+  res[k] = o;
+}
+
+struct ChunkEv {
+  hipEvent_t dp0 = nullptr, dpe[8] = {}, tb0 = nullptr, tb1 = nullptr;  // plan uploaded; end of the DP launches per
+                                                                         // stream; traceback (begin, end)
+};
+
+// Progress of one batch call on the device.
+struct BatchRun {
+  sdf_ctx *ctx = nullptr;
+  hipStream_t st = nullptr;  // the caller's stream
+  ScoreK sk;
+  const uint32_t *d_pool = nullptr;
+  sdf_result *d_out = nullptr;
+  PlanTask *plan = nullptr, *d_plan = nullptr;  // pinned host copy / device copy
+  int32_t *order = nullptr, *d_order = nullptr;
+  uint8_t *d_dir = nullptr;
+  uint32_t *d_stage = nullptr;
+  const BatchCut *cut = nullptr;
+  bool want_cigar = false, have_heavy = false;
+  bool hi_prio = false;  // the heavy launches run on the context's high-priority streams
+  std::vector<ChunkEv> cev;
+  std::vector<size_t> normal_ids;  // chunk indices of the ordinary chunks launched so far
+  double qload[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // estimated DP work queued on each stream during this call
+  size_t evc = 0;
+  hipEvent_t ev_begin = nullptr;
+};
+
+static hipEvent_t next_event(sdf_ctx *ctx, size_t &cursor) {
+  if (cursor == ctx->events.size()) {
+    hipEvent_t ev;
+    (void)hipEventCreate(&ev);
+    ctx->events.push_back(ev);
+  }
+  return ctx->events[cursor++];
+}
+
+// every stream a batch call may have work on
+static void drain_streams(sdf_ctx *ctx, hipStream_t st) {
+  for (hipStream_t q : {st, ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
+                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3], ctx->hi_stream[0],
+                        ctx->hi_stream[1], ctx->hi_stream[2], ctx->hi_stream[3]})
+    if (q) (void)hipStreamSynchronize(q);
+  (void)hipGetLastError();
+}
+
+static bool make_priority_streams(sdf_ctx *ctx) {
+  if (ctx->hi_tried) return ctx->hi_stream[3] != nullptr;
+  ctx->hi_tried = true;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+    (void)hipGetLastError();
+    return false;
+  }
+  for (int q = 0; q < 4; ++q)
+    if (hipStreamCreateWithPriority(&ctx->hi_stream[q], hipStreamNonBlocking, greatest) != hipSuccess) {
+      (void)hipGetLastError();
+      for (int r = 0; r < q; ++r) (void)hipStreamDestroy(ctx->hi_stream[r]);
+      for (auto &ps : ctx->hi_stream) ps = nullptr;
+      return false;
+    }
+  return true;
+}
+
+// One DP launch of a planned class.  slabs: HBM state of the very long tasks (HBM-state classes only).
+static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, const int32_t *lo, const uint32_t *d_pool,
+                      const ScoreK &sk, uint8_t *dir_reg, sdf_result *d_out, uint8_t *slabs) {
+  const dim3 one((unsigned)L.cnt), half((unsigned)(L.cnt / 2));
+#define SDF_WAVE(N, S) \
+  hipLaunchKernelGGL((extz2_wave_kernel<N, S>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
+#define SDF_PAIR(N, S) \
+  hipLaunchKernelGGL((extz2_pair_kernel<N, S>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
+#define SDF_STRIPE(N) \
+  hipLaunchKernelGGL(extz2_stripe_kernel<N>, one, dim3(64 * L.kmax), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
+#define SDF_GENERAL(BS, PLAIN)                                                                                      \
+  hipLaunchKernelGGL((extz2_general_kernel<BS, false, PLAIN>), one, dim3(BS), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, \
+                     d_out, (uint8_t *)nullptr, (size_t)0)
+#define SDF_GENERAL_HBM(BS, PLAIN) /* L.lds = per-workgroup slab bytes in HBM */                                    \
+  hipLaunchKernelGGL((extz2_general_kernel<BS, true, PLAIN>), one, dim3(BS), 512, sdp, lp, lo, d_pool, sk, dir_reg, \
+                     d_out, slabs, L.lds)
+  switch (L.bs) {
+    case 1: SDF_WAVE(1, false); break;
+    case 11: SDF_WAVE(1, true); break;
+    case 2: SDF_WAVE(2, false); break;
+    case 12: SDF_WAVE(2, true); break;
+    case 4: SDF_WAVE(4, false); break;
+    case 14: SDF_WAVE(4, true); break;
+    case 8: SDF_WAVE(8, false); break;
+    case 18: SDF_WAVE(8, true); break;
+    case 101: SDF_PAIR(1, false); break;
+    case 111: SDF_PAIR(1, true); break;
+    case 102: SDF_PAIR(2, false); break;
+    case 112: SDF_PAIR(2, true); break;
+    case 103: SDF_PAIR(3, false); break;
+    case 113: SDF_PAIR(3, true); break;
+    case 104: SDF_PAIR(4, false); break;
+    case 114: SDF_PAIR(4, true); break;
+    case 106: SDF_PAIR(6, false); break;
+    case 116: SDF_PAIR(6, true); break;
+    case 108: SDF_PAIR(8, false); break;
+    case 118: SDF_PAIR(8, true); break;
+    case 201: SDF_STRIPE(1); break;
+    case 202: SDF_STRIPE(2); break;
+    case 204: SDF_STRIPE(4); break;
+    case 64: SDF_GENERAL(64, false); break;
+    case 256: SDF_GENERAL(256, false); break;
+    case 1024: SDF_GENERAL(1024, false); break;
+    case 2256: SDF_GENERAL(256, true); break;
+    case 3024: SDF_GENERAL(1024, true); break;
+    case 2001: SDF_GENERAL_HBM(1024, true); break;
+    case 1001: SDF_GENERAL_HBM(1024, false); break;
+    default: SDF_GENERAL_HBM(256, false); break;  // 1000
+  }
+#undef SDF_WAVE
+#undef SDF_PAIR
+#undef SDF_STRIPE
+#undef SDF_GENERAL
+#undef SDF_GENERAL_HBM
+}
+
+template <int LAYOUT>
+static void launch_traceback(bool solo, size_t cnt, hipStream_t s, const PlanTask *lp, const uint32_t *d_pool,
+                             const uint8_t *dir_reg, sdf_result *d_out, uint32_t *d_stage) {
+  // few tasks: a wavefront per walk (runs of up to 64 cells per round), else four walks per wavefront (16 cells;
+  // 8 and 32 cells per walk were measured within noise of 16 on the headline batch)
+  if (solo)
+    hipLaunchKernelGGL((traceback_kernel<LAYOUT, 64>), dim3((unsigned)cnt), dim3(64), 0, s, lp, (int)cnt, d_pool, dir_reg,
+                       d_out, d_stage);
+  else
+    hipLaunchKernelGGL((traceback_kernel<LAYOUT, 16>), dim3((unsigned)((cnt + 3) / 4)), dim3(64), 0, s, lp, (int)cnt,
+                       d_pool, dir_reg, d_out, d_stage);
+}
+
+// Uploads chunk `ci` of the cut and launches its DP kernels and its traceback.
+// Streams: Q[0] the caller's, Q[1], Q[2] the two DP streams, Q[3] traceback.  The big launches (>= 2048 tasks) of
+// ordinary chunks alternate between the DP streams; every other launch (a class of a few tasks ends in a tail as
+// long as its longest task) goes, longest first, to the stream with the least estimated work queued.  A heavy chunk
+// uploads and traces back on the caller's stream and uses the workspace slice behind the regions.
+static int launch_chunk(BatchRun &run, size_t ci) {
+  sdf_ctx *ctx = run.ctx;
+  const BatchCut &cut = *run.cut;
+  const ChunkPlan &c = cut.chunks[ci];
+  const size_t cnt = c.cnt, pb = c.pb, ob = c.ob;
+  if (cnt == 0) {
+    run.cev[ci] = ChunkEv{};
+    return SDF_OK;
+  }
+  hipStream_t st = run.st;
+  const bool pipelined = cut.pipelined, heavy_chunk = c.heavy;
+  const bool piped = pipelined && !heavy_chunk;
+  const size_t nj = run.normal_ids.size();  // ordinal among the ordinary chunks
+  const size_t nchunks = cut.chunks.size();
+  if (pipelined) {
+    // extra streams, created the first time they are wanted (a stream is a hardware queue: ~7 ms to set up): launches of
+    // few tasks last as long as their longest task whatever else runs, so the more of them run side by side the better
+    const size_t want_aux = nchunks == 1 ? (c.launches.size() > 4 ? std::min<size_t>(c.launches.size() - 4, 4) : 0) : 4;
+    for (size_t a = 0; a < want_aux; ++a)
+      if (!ctx->aux_stream[a] && hipStreamCreateWithFlags(&ctx->aux_stream[a], hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->aux_stream[a] = nullptr;
+      }
+  }
+  hipStream_t Q[8] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
+                      pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
+                      ctx->aux_stream[3]};
+  if (run.hi_prio) {  // the heavy launches' own streams (Q[0], Q[1], Q[4], Q[5] are theirs, see below)
+    Q[0] = ctx->hi_stream[0];
+    Q[1] = ctx->hi_stream[1];
+    Q[4] = ctx->hi_stream[2];
+    Q[5] = ctx->hi_stream[3];
+  }
+  // Q[4..7]: only the least-loaded-stream assignment below uses them (one-chunk batches without heavy tasks)
+  const int ui = piped ? (run.have_heavy ? 2 : 1 + (int)(nj & 1)) : 0;  // upload stream (and the big launches')
+  // (the tracebacks of consecutive ordinary chunks alternate between two streams: the last one starts when its DP
+  // ends, not when the previous chunk's walk does)
+  hipStream_t stb = piped ? ((nj & 1) && ctx->aux_stream[2] ? ctx->aux_stream[2] : Q[3]) : Q[0];
+  uint8_t *dir_reg = heavy_chunk ? run.d_dir + cut.nreg_ws * cut.region_need : run.d_dir + (nj % cut.nreg_ws) * cut.region_need;
+  hipEvent_t region_ev = nullptr;  // the region's previous user has been traced back
+  if (piped && nj >= cut.nreg_ws) region_ev = run.cev[run.normal_ids[nj - cut.nreg_ws]].tb1;
+  if (!heavy_chunk) run.normal_ids.push_back(ci);
+  SDF_HIP(hipMemcpyAsync(run.d_plan + pb, run.plan + pb, cnt * sizeof(PlanTask), hipMemcpyHostToDevice, Q[ui]));
+  SDF_HIP(hipMemcpyAsync(run.d_order + ob, run.order + ob, c.nord * sizeof(int32_t), hipMemcpyHostToDevice, Q[ui]));
+  ChunkEv &ev = run.cev[ci];
+  ev.dp0 = next_event(ctx, run.evc);
+  for (auto &e : ev.dpe) e = nullptr;
+  ev.tb0 = next_event(ctx, run.evc);
+  ev.tb1 = next_event(ctx, run.evc);
+  SDF_HIP(hipEventRecord(ev.dp0, Q[ui]));
+  bool used[8] = {false, false, false, false, false, false, false, false};
+  size_t gs_off = 0;
+  {  // HBM state slabs of the very long tasks of this chunk: one allocation, a slice per launch
+    size_t gs_total = 0;
+    for (const Launch &L : c.launches)
+      if (L.bs == 1000 || L.bs == 1001 || L.bs == 2001) gs_total += L.lds * L.cnt;
+    if (gs_total > ctx->gstate_buf.cap) {  // growing frees the old slabs: nothing may be using them
+      for (hipStream_t q : Q)
+        if (q) SDF_HIP(hipStreamSynchronize(q));
+      if (ctx->gstate_buf.reserve(gs_total) != hipSuccess) {
+        ctx->err = "cannot allocate the HBM state slabs for very long tasks";
+        (void)hipGetLastError();
+        return SDF_ERR_NOMEM;
+      }
+    }
+  }
+  for (const Launch &L : c.launches) {
+    // with heavy tasks in the batch the streams are divided: Q[0], Q[1] for the heavy launches (tens of
+    // milliseconds each), the others for the ordinary chunks, which would otherwise queue behind them
+    int qi = 0;
+    if (pipelined) {
+      if (piped && L.cnt >= 2048) {
+        qi = ui;
+      } else {  // least estimated work queued; with heavy tasks in the batch Q[0], Q[1], Q[4], Q[5] are theirs
+        qi = run.have_heavy ? (heavy_chunk ? 0 : 2) : 1;
+        for (int q = qi + 1; q < 8; ++q) {
+          if (!Q[q] || (run.have_heavy && heavy_chunk != (q == 1 || q == 4 || q == 5))) continue;
+          if (run.qload[q] < run.qload[qi]) qi = q;
+        }
+      }
+    }
+    run.qload[qi] += L.est;
+    hipStream_t sdp = Q[qi];
+    if (!used[qi]) {
+      used[qi] = true;
+      if (pipelined && qi != ui) SDF_HIP(hipStreamWaitEvent(sdp, ev.dp0, 0));  // plan uploaded
+      if (region_ev) SDF_HIP(hipStreamWaitEvent(sdp, region_ev, 0));
+    }
+    uint8_t *slabs = nullptr;
+    if (L.bs == 1000 || L.bs == 1001 || L.bs == 2001) {
+      slabs = (uint8_t *)ctx->gstate_buf.p + gs_off;
+      gs_off += L.lds * L.cnt;
+    }
+    launch_dp(L, sdp, run.d_plan + pb, run.d_order + ob + L.off, run.d_pool, run.sk, dir_reg, run.d_out, slabs);
+    ++ctx->launches;
+  }
+  for (int q = 0; q < 8; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
+    if (!used[q]) continue;
+    ev.dpe[q] = next_event(ctx, run.evc);
+    SDF_HIP(hipEventRecord(ev.dpe[q], Q[q]));
+    if (pipelined && Q[q] != stb) SDF_HIP(hipStreamWaitEvent(stb, ev.dpe[q], 0));
+  }
+  SDF_HIP(hipEventRecord(ev.tb0, stb));
+  if (run.want_cigar) {
+    const unsigned layouts = c.layouts;  // one traceback instantiation per direction-flag layout present
+    const bool tb_solo = cnt <= (nchunks == 1 ? (size_t)8192 : (size_t)1024);
+    // A walk is a few rounds of memory latency per CIGAR run: a launch lasts as long as its longest task.  When a
+    // chunk of few tasks mixes layouts, the instantiations run side by side on different streams (each after the
+    // chunk's DP, collected again by the chunk's traceback stream) rather than one after the other.
+    const bool side_by_side = pipelined && cnt < 32768 && (layouts & (layouts - 1)) != 0;
+    int used_tb = 0;
+    hipStream_t tbs[3] = {stb, stb, stb};  // (a fourth layout shares the last stream)
+    if (side_by_side) {  // (a batch with heavy tasks keeps its stream division: Q[0], Q[1] heavy, Q[2], Q[3] ordinary)
+      int j = 1;
+      for (int q = 0; q < 4 && j < 3; ++q) {
+        if (Q[q] == stb) continue;
+        if (run.have_heavy && (heavy_chunk ? q >= 2 : q < 2)) continue;
+        tbs[j++] = Q[q];
+      }
+    }
+    auto tb_on = [&]() -> hipStream_t {
+      hipStream_t s2 = tbs[used_tb < 3 ? used_tb : 2];
+      if (side_by_side && s2 != stb) (void)hipStreamWaitEvent(s2, ev.tb0, 0);
+      ++used_tb;
+      return s2;
+    };
+    const PlanTask *lp = run.d_plan + pb;
+    if (layouts & 8u) launch_traceback<3>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
+    if (layouts & 4u) launch_traceback<2>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
+    if (layouts & 2u) launch_traceback<1>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
+    if (layouts & 1u) launch_traceback<0>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
+    if (side_by_side)
+      for (int j = 1; j < used_tb && j < 3; ++j) {
+        if (tbs[j] == stb) continue;
+        hipEvent_t e = next_event(ctx, run.evc);
+        SDF_HIP(hipEventRecord(e, tbs[j]));
+        SDF_HIP(hipStreamWaitEvent(stb, e, 0));
+      }
+  }
+  SDF_HIP(hipEventRecord(ev.tb1, stb));
+  return SDF_OK;
+}
+
+// Closes the batch on the caller's stream: waits for every chunk's traceback, scans n_cigar into cigar_off,
+// compacts the CIGARs into the caller's pool and reads the timing events.
+static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_cap, size_t *cigar_used) {
+  sdf_ctx *ctx = run.ctx;
+  hipStream_t st = run.st;
+  if (run.cut->pipelined)
+    for (auto &ev : run.cev)
+      if (ev.tb1) SDF_HIP(hipStreamWaitEvent(st, ev.tb1, 0));
+  unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
+  hipEvent_t ev_c0 = next_event(ctx, run.evc), ev_c1 = next_event(ctx, run.evc), ev_end = next_event(ctx, run.evc);
+  SDF_HIP(hipEventRecord(ev_c0, st));
+  unsigned long long total = 0;
+  const size_t np = run.cut->ntask_total;
+  if (run.want_cigar) {
+    {
+      const int nb = (int)((n + 1023) / 1024);
+      unsigned long long *d_part = d_total + 32;
+      hipLaunchKernelGGL(cigar_scan_blocks_kernel, dim3((unsigned)nb), dim3(1024), 0, st, run.d_out, (int)n, d_part);
+      hipLaunchKernelGGL(cigar_scan_parts_kernel, dim3(1), dim3(1024), 0, st, d_part, nb, d_total);
+      hipLaunchKernelGGL(cigar_scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, run.d_out, (int)n,
+                         (const unsigned long long *)d_part);
+    }
+    SDF_HIP(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, st));
+    SDF_HIP(hipStreamSynchronize(st));
+    if (cigar_used) *cigar_used = (size_t)total;
+    if (total > cigar_cap || (total && !d_cig)) {
+      ctx->err = "CIGAR pool too small";
+      return SDF_ERR_CIGAR_OVERFLOW;
+    }
+    if (np)
+      hipLaunchKernelGGL(cigar_compact_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, st, run.d_plan, (int)np,
+                         run.d_out, run.d_stage, d_cig, (unsigned long long)cigar_cap);
+  }
+  SDF_HIP(hipEventRecord(ev_c1, st));
+  SDF_HIP(hipEventRecord(ev_end, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  SDF_HIP(hipGetLastError());
+  // DP / traceback time = length of the union of the chunks' intervals (chunks overlap when pipelined);
+  // ms[6] = sum of the chunks' DP intervals (what a kernel trace adds up)
+  auto span = [&](bool tb, float &sum) {
+    std::vector<std::pair<float, float>> iv;
+    sum = 0.f;
+    auto add = [&](hipEvent_t e0, hipEvent_t e1) {
+      float a = 0, b = 0;
+      (void)hipEventElapsedTime(&a, run.ev_begin, e0);
+      (void)hipEventElapsedTime(&b, run.ev_begin, e1);
+      iv.push_back({a, b});
+      sum += b - a;
+    };
+    for (auto &ev : run.cev) {
+      if (!ev.dp0) continue;
+      if (tb) {
+        add(ev.tb0, ev.tb1);
+      } else {
+        for (hipEvent_t e : ev.dpe)
+          if (e) add(ev.dp0, e);
+      }
+    }
+    std::sort(iv.begin(), iv.end());
+    float len = 0, end = -1e30f;
+    for (auto &p : iv) {
+      if (p.first > end) {
+        len += p.second - p.first;
+        end = p.second;
+      } else if (p.second > end) {
+        len += p.second - end;
+        end = p.second;
+      }
+    }
+    return len;
+  };
+  float s0 = 0, s1 = 0;
+  ctx->ms[0] = span(false, s0);
+  ctx->ms[1] = span(true, s1);
+  ctx->ms[6] = s0;
+  (void)hipEventElapsedTime(&ctx->ms[2], ev_c0, ev_c1);
+  (void)hipEventElapsedTime(&ctx->ms[3], run.ev_begin, ev_end);
+  return SDF_OK;
+}
+
+}  // namespace sdf

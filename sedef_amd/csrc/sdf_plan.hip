@@ -1,0 +1,579 @@
+// Batch planning for the DP entry points (host code only; no device work happens in this file).
+//
+//   cut_batch()   one pass over the caller's tasks: validation, upper bounds of the direction-flag bytes, the split of
+//                 "heavy" tasks from the chunk rotation, chunk boundaries, and -- so that chunks can be planned
+//                 independently of each other, on several threads -- every chunk's bases into the shared arrays
+//                 (PlanTask index, launch-order index, CIGAR staging word);
+//   plan_chunk()  one chunk: kernel choice per task, pairing of tasks of equal geometry, the direction-flag layout
+//                 inside the chunk's workspace region, launch classes and the launch order.  Pure function of the
+//                 tasks and the PlanEnv: the unit tests of the planner need no GPU.
+//
+// Replaces the per-call set-up of ksw_extz2_sse (reference: extern/ksw2_extz2_sse.cc:57-98: early-outs, band and
+// matrix geometry, allocation) for a batch of tasks.
+#include <thread>
+
+#include "sdf_ctx.h"
+
+namespace sdf {
+
+struct PlanEnv {
+  const sdf_task *tasks = nullptr;
+  size_t n = 0;
+  uint32_t want = 0;
+  bool want_cigar = false;
+  bool degenerate = false;  // scoring for which the reference returns before any work (:81)
+  int gapo = 0;
+  int max_dyn_lds = 64 * 1024;
+  bool force_general = false, no_pair = false, no_stripe = false;
+  int stripe_min = 1024;
+};
+
+struct Launch {
+  int bs;  // 64 / 256 / 1024: general kernel with that many threads (+2000: PLAIN flavour); 1, 2, 4, 8: wave kernel with
+           // NREG (+10: streamed windows); 100 + NREG: pair kernel (+10: streamed); 200 + NREG: stripe kernel;
+           // 1000 / 1001 / 2001: general kernel with its state in HBM
+  size_t lds;  // dynamic LDS bytes of the launch (HBM-state classes: slab bytes per workgroup)
+  size_t off, cnt;  // entries of the chunk's launch order
+  double est;       // duration estimate: the launch's longest task
+  int kmax;         // stripe kernel: wavefronts per workgroup
+};
+
+struct ChunkPlan {
+  size_t s = 0, e = 0;   // ordinary chunk: task range [s, e) of the caller's array, minus the heavy tasks in it;
+  bool heavy = false;    // heavy chunk: range [s, e) of BatchCut::heavy_idx
+  size_t pb = 0;         // first PlanTask of the chunk
+  size_t ob = 0;         // first launch-order entry (room for 2 * ntask: a task paired with itself is listed twice)
+  int64_t stage0 = 0;    // first CIGAR staging word
+  size_t ntask = 0;      // tasks the chunk will plan (known after cut_batch)
+  int64_t stage_words = 0;  // CIGAR staging words of those tasks
+  // filled by plan_chunk
+  size_t cnt = 0, nord = 0;
+  std::vector<Launch> launches;
+  unsigned layouts = 0;  // direction-flag layouts present: bit 0 byte rows, 1 wave blocks, 2 pair blocks, 3 stripes
+  long long paired = 0;
+  size_t dir_bytes = 0;
+  const char *err = nullptr;
+};
+
+struct BatchCut {
+  std::vector<ChunkPlan> chunks;  // heavy chunks first
+  std::vector<uint8_t> heavy;     // per task, when split_heavy
+  std::vector<uint32_t> heavy_idx;  // the heavy tasks, ascending
+  // scratch of cut_batch, kept by the context between calls (fresh vectors of this size cost a millisecond of page faults)
+  std::vector<uint32_t> bound;      // per task: upper bound of its direction flags, in units of 256 bytes
+  std::vector<uint32_t> cap;        // per task: CIGAR staging words | 0x80000000 when the task runs at all
+  std::vector<uint32_t> hparts[8];  // heavy task indices, per scan thread
+  void reset() {
+    chunks.clear();
+    heavy_idx.clear();
+    split_heavy = pipelined = false;
+    nch = max_regions = nreg_ws = 1;
+    n_heavy = 0;
+    region_need = 16;
+    heavy_need = 0;
+    stage_total = 0;
+    ntask_total = 0;
+  }
+  bool split_heavy = false, pipelined = false;
+  size_t nch = 1, max_regions = 1, n_heavy = 0;
+  size_t region_need = 16, heavy_need = 0, nreg_ws = 1;
+  int64_t stage_total = 0;
+  size_t ntask_total = 0;
+};
+
+namespace plan_detail {
+
+inline bool task_runs(const sdf_task &t, bool degenerate) { return t.qlen > 0 && t.tlen > 0 && !degenerate; }
+
+struct Cls {
+  int bs;
+  size_t lds;       // class key (with `sub`)
+  size_t need_max;  // largest real requirement in the class: what the launch asks for
+  std::vector<int32_t> idx;
+  double est = 0;
+  int kmax = 0;
+  int sub = 0;      // stripe kernel: workgroup size bucket (4, 8 or 16 wavefronts), so that tasks of few stripes do not
+                    // occupy the wavefront slots of a 16-stripe workgroup
+};
+
+}  // namespace plan_detail
+
+// Per-thread scratch of plan_chunk (kept between chunks: no allocation in the steady state).
+struct PlanScratch {
+  std::vector<int32_t> win_need, partner;
+  std::vector<std::pair<int32_t, int32_t>> table;
+  std::vector<plan_detail::Cls> cls;
+};
+
+// Returns SDF_OK or an error code with *err set.
+static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget, BatchCut &cut, const char **err) {
+  const sdf_task *tasks = env.tasks;
+  const size_t n = env.n;
+  // The batch is cut into chunks that are planned, uploaded and launched one after the other: while the GPU runs
+  // chunk i the host plans the following ones, the big DP launches of consecutive chunks alternate between two streams
+  // (the next chunk fills the CUs while the previous one drains), launches of a few tasks (each a full task latency
+  // long) go, longest first, to whichever stream has the least work queued, and the traceback of a chunk runs next to
+  // the following chunk's DP.  Direction-flag regions rotate over `nreg_ws` slices of the workspace.
+  // (small batches stay on the caller's stream -- unless they hold long tasks: their launch classes, each as long
+  // as its longest task, then run side by side on the other streams like those of a large batch)
+  bool any_long = false;
+  if (n < 2048)
+    for (size_t k = 0; k < n && !any_long; ++k) any_long = tasks[k].qlen + (int64_t)tasks[k].tlen >= 3000;
+  cut.pipelined = pipeline_enabled && (n >= 2048 || any_long);
+  cut.nch = 1;
+  if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? 8 : 4, n / 16384);
+  cut.max_regions = cut.nch > 4 ? 8 : cut.nch > 1 ? 4 : 1;
+  const size_t nch = cut.nch;
+  // the first chunk is small, so that the GPU starts early, but fills the wavefront slots of the device (4,096 pairs
+  // of tasks of the headline shape) while the next chunks are being planned
+  const size_t first_target = nch > 1 ? std::max<size_t>(8192, n / (16 * nch + 1)) : n;
+  const size_t chunk_target = nch > 1 ? (n - first_target + nch - 1) / nch : n;
+
+  // A task is "heavy" when its wavefront (or workgroup) is busy for about a millisecond or more whatever else runs:
+  // 500 x 500 and up at full band, i.e. from 256 KB of direction flags.
+  static const size_t heavy_min = [] {
+    const char *e = getenv("SDF_HEAVY_BYTES");
+    return e ? (size_t)atoll(e) : (size_t)256 << 10;
+  }();
+  // ---- validation + upper bound of each task's direction flags, whichever kernel takes it ----
+  // (on several threads for batches of hundreds of thousands of tasks: this pass and the loop below are all the
+  // planning the GPU waits for besides the first chunk)
+  std::vector<uint32_t> &bound = cut.bound, &cap = cut.cap;
+  bound.assign(n, 0);
+  cap.assign(n, 0);
+  size_t heavy_bytes = 0;
+  std::vector<uint32_t> (&hparts)[8] = cut.hparts;
+  for (auto &hp : hparts) hp.clear();
+  {
+    struct Part {
+      size_t nh = 0, hb = 0;
+      bool bad = false;
+    };
+    const size_t hv_limit = n / 4 + 1;
+    auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv) {
+      for (size_t k = lo; k < hi; ++k) {
+        const sdf_task &t = tasks[k];
+        if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
+          pt.bad = true;
+          return;
+        }
+        if (!plan_detail::task_runs(t, env.degenerate)) continue;
+        cap[k] = 0x80000000u;
+        if (env.want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
+          cap[k] |= (uint32_t)(t.qlen + t.tlen + 2);
+          const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+          const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
+          const size_t nrow = (size_t)t.qlen + t.tlen - 1;
+          const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
+          size_t bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
+          if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+          bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
+          if (bd >= heavy_min) {
+            ++pt.nh;
+            pt.hb += bd;
+            if (pt.nh <= hv_limit) hv.push_back((uint32_t)k);  // (beyond a quarter of the batch there is no split)
+          }
+        }
+      }
+    };
+    const int nthr = n >= 400000 ? 4 : 1;  // (a thread costs ~0.1 ms to start and join: not worth it below)
+    Part parts[8];
+    std::vector<std::thread> thr;
+    for (int q = 1; q < nthr; ++q)
+      thr.emplace_back(scan, n * q / nthr, n * (q + 1) / nthr, std::ref(parts[q]), std::ref(hparts[q]));
+    scan(0, n / nthr, parts[0], hparts[0]);
+    for (auto &th : thr) th.join();
+    for (int q = 0; q < nthr; ++q) {
+      if (parts[q].bad) {
+        *err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
+        return SDF_ERR_UNSUPPORTED;
+      }
+      cut.n_heavy += parts[q].nh;
+      heavy_bytes += parts[q].hb;
+    }
+  }
+  // Heavy tasks leave the chunk rotation when they are a minority: they are planned and launched FIRST, all together
+  // (a launch of few long tasks lasts as long as its longest task: one such launch per kernel, not one per chunk), with
+  // a workspace slice of their own, and run next to the chunks of ordinary tasks.
+  cut.split_heavy = cut.pipelined && cut.n_heavy * 4 <= n;
+  const size_t heavy_budget = cut.split_heavy && cut.n_heavy ? std::min(heavy_bytes + 256, ws_budget / 2) : 0;
+  const size_t region_budget = (ws_budget - heavy_budget) / cut.max_regions;
+  cut.heavy.assign(cut.split_heavy ? n : 0, 0);
+
+  // ---- chunk boundaries ----
+  std::vector<ChunkPlan> normal, heavy_chunks;
+  if (cut.split_heavy) {  // heavy chunks: ranges of the (ascending) list of heavy tasks
+    for (auto &hp : hparts) cut.heavy_idx.insert(cut.heavy_idx.end(), hp.begin(), hp.end());
+    ChunkPlan hcur;
+    hcur.heavy = true;
+    size_t hacc = 0;
+    for (size_t pos = 0; pos < cut.heavy_idx.size(); ++pos) {
+      const uint32_t k = cut.heavy_idx[pos];
+      const size_t bd = (size_t)bound[k] << 8;
+      cut.heavy[k] = 1;
+      if (pos > hcur.s && hacc + bd > heavy_budget) {
+        hcur.e = pos;
+        heavy_chunks.push_back(hcur);
+        cut.heavy_need = std::max(cut.heavy_need, hacc);
+        hcur = ChunkPlan();
+        hcur.heavy = true;
+        hcur.s = pos;
+        hacc = 0;
+      }
+      hacc += bd;
+      ++hcur.ntask;
+      hcur.stage_words += cap[k] & 0x7fffffffu;
+    }
+    if (!cut.heavy_idx.empty()) {
+      hcur.e = cut.heavy_idx.size();
+      heavy_chunks.push_back(hcur);
+      cut.heavy_need = std::max(cut.heavy_need, hacc);
+    }
+  }
+  {
+    ChunkPlan cur;
+    size_t acc = 0;
+    const uint8_t *hv = cut.split_heavy ? cut.heavy.data() : nullptr;
+    for (size_t k = 0; k < n; ++k) {
+      if (hv && hv[k]) continue;
+      const size_t bd = (size_t)bound[k] << 8;
+      const size_t target = normal.empty() && nch > 1 ? first_target : chunk_target;
+      // (all tasks of the range count towards the target, as they cost planning time whether they run or not)
+      if (k > cur.s && (acc + bd > region_budget || k - cur.s >= target)) {
+        cur.e = k;
+        normal.push_back(cur);
+        cut.region_need = std::max(cut.region_need, acc);
+        cur = ChunkPlan();
+        cur.s = k;
+        acc = 0;
+      }
+      acc += bd;
+      cur.ntask += cap[k] >> 31;
+      cur.stage_words += cap[k] & 0x7fffffffu;
+    }
+    cur.e = n;
+    normal.push_back(cur);
+    cut.region_need = std::max(cut.region_need, acc);
+  }
+  cut.region_need = (cut.region_need + 255) & ~(size_t)255;
+  cut.heavy_need = (cut.heavy_need + 255) & ~(size_t)255;
+  cut.nreg_ws = std::min(cut.max_regions, normal.size());
+  cut.chunks = heavy_chunks;  // heavy first
+  cut.chunks.insert(cut.chunks.end(), normal.begin(), normal.end());
+  // bases: what the chunks before this one (in launch order) occupy
+  size_t pb = 0;
+  int64_t stage = 0;
+  for (ChunkPlan &c : cut.chunks) {
+    c.pb = pb;
+    c.ob = 2 * pb;
+    c.stage0 = stage;
+    pb += c.ntask;
+    stage += c.stage_words;
+  }
+  cut.ntask_total = pb;
+  cut.stage_total = stage;
+  return SDF_OK;
+}
+
+// Plans one chunk into plan[c.pb ...] and order[c.ob ...].
+static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, PlanTask *plan, int32_t *order,
+                       PlanScratch &sx) {
+  using plan_detail::Cls;
+  const sdf_task *tasks = env.tasks;
+  const bool want_cigar = env.want_cigar;
+  std::vector<int32_t> &win_need = sx.win_need, &partner = sx.partner;
+  std::vector<Cls> &cls = sx.cls;
+  win_need.clear();
+  size_t np = c.pb;
+  int64_t stage_words = c.stage0;
+  int snreg = 0;  // widest stripe any stripe task of the chunk needs
+  for (size_t pos = c.s; pos < c.e; ++pos) {
+    const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
+    const sdf_task &t = tasks[k];
+    if (!c.heavy && cut.split_heavy && cut.heavy[k]) continue;
+    if (!plan_detail::task_runs(t, env.degenerate)) continue;  // reference early return (:57,:81)
+    PlanTask p;
+    p.q_word = t.q_off;
+    p.t_word = t.t_off;
+    p.qlen = t.qlen;
+    p.tlen = t.tlen;
+    p.w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+    p.zdrop = t.zdrop;
+    p.flag = t.flag | (want_cigar ? 0 : SDF_FLAG_SCORE_ONLY);
+    int nc = std::min(t.qlen, t.tlen);
+    nc = (std::min(nc, p.w + 1) + 15) / 16 + 1;
+    p.ncol16 = nc * 16;
+    p.out_idx = (int32_t)k;
+    p.pad_ = 0;
+    // register-resident wave kernel when only CIGAR/score/mte are wanted and the shape fits
+    p.nreg = 0;
+    int wneed = 0;
+    bool plain_ok = false;
+    {
+      const int nrow = t.qlen + t.tlen - 1;
+      Band bl;
+      const bool band_whole = (p.w >= 1 || nrow == 1) && band_of(nrow - 1, t.qlen, t.tlen, p.w, bl);
+      const bool plain = !(env.want & SDF_WANT_EXT) && t.zdrop < 0 && !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY)) &&
+                         env.gapo >= 0 && band_whole;
+      plain_ok = plain && !env.force_general;
+      if (plain_ok) {
+        // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
+        // beyond the target's last 16-cell block (cells past it are not part of any window)
+        const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
+        const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : need <= 1024 ? 8 : 0;
+        if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)env.max_dyn_lds) {
+          p.nreg = nreg;
+          wneed = need;
+        }
+      }
+    }
+    win_need.push_back(wneed);
+    p.dir_off = 0;
+    p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
+    p.cig_slot = stage_words;
+    stage_words += p.cig_cap;
+    if ((!p.nreg || env.stripe_min < 1024) && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
+        t.tlen > env.stripe_min && t.tlen <= 8192) {
+      // wide full-band task: a workgroup of wavefronts, one per stripe of 128 * nreg target positions
+      const int nreg = t.tlen <= 2048 ? 1 : t.tlen <= 4096 ? 2 : 4;
+      const int nst = (t.tlen + 128 * nreg - 1) / (128 * nreg);
+      if (stripe_lds_bytes(t.qlen, nst, nreg) <= (size_t)env.max_dyn_lds) {
+        p.nreg = nreg;
+        p.pad_ = 5;
+        snreg = std::max(snreg, nreg);
+      }
+    }
+    if (!p.nreg) {
+      // general kernel: state in LDS, or in an HBM scratch slab when it does not fit; the PLAIN flavour (packed
+      // recurrence, H along the band edge only) when nothing but CIGAR / score / mte is wanted and the window
+      // is wide enough for the 256- or 1024-thread instantiation
+      const bool hbm = general_lds_bytes(t.qlen, t.tlen) > (size_t)env.max_dyn_lds;
+      const int width = std::min(p.ncol16, (t.tlen + 15) / 16 * 16);
+      if (plain_ok && !hbm && width > 256) p.pad_ = 3;
+      else if (plain_ok && hbm && width > 1024) p.pad_ = 4;
+      else p.pad_ = hbm ? 1 : 0;
+    }
+    plan[np++] = p;
+  }
+  const size_t cnt = np - c.pb;
+  c.cnt = cnt;
+  c.nord = 0;
+  c.launches.clear();
+  c.layouts = 0;
+  c.paired = 0;
+  c.dir_bytes = 0;
+  if (cnt == 0) return;
+  PlanTask *cp = plan + c.pb;  // chunk-relative indexing below
+  if (snreg) {  // the stripe tasks of a chunk share one stripe width (the widest any of them needs): one launch,
+                // all of them side by side, instead of one launch per width queued behind each other
+    for (size_t k = 0; k < cnt; ++k) {
+      PlanTask &p = cp[k];
+      if (p.pad_ != 5) continue;
+      const int nr = snreg;  // (one launch per stripe width was measured slower: 35 vs 29 ms on the hg19 mixture)
+      p.nreg = nr;
+      // a last stripe of one cell would need the H of the cell under the target's end from its neighbour, and the
+      // wider stripe may need more LDS than the task's own width did: such a task stays on the general kernel
+      if (p.tlen % (128 * nr) == 1 ||
+          stripe_lds_bytes(p.qlen, (p.tlen + 128 * nr - 1) / (128 * nr), nr) > (size_t)env.max_dyn_lds) {
+        p.nreg = 0;
+        const bool hbm = general_lds_bytes(p.qlen, p.tlen) > (size_t)env.max_dyn_lds;
+        p.pad_ = hbm ? 4 : 3;
+      }
+    }
+  }
+
+  // Pair kernel: two wave-eligible tasks of the chunk with the same (qlen, tlen, w, flag) and a window of at
+  // most 512 slots share a wavefront (extz2_pair.hip).  partner[k] = the other task, or -1.  One pass with an
+  // open-addressing table keyed by the geometry: entry = (first task seen with the key, the task of that key
+  // still waiting for a partner or -1).
+  partner.assign(cnt, -1);
+  if (!env.no_pair && !env.force_general) {
+    auto &table = sx.table;
+    size_t cap = 64;
+    while (cap < 2 * cnt) cap *= 2;
+    table.assign(cap, {-1, -1});
+    for (size_t k = 0; k < cnt; ++k) {
+      PlanTask &y = cp[k];
+      if (!y.nreg || y.pad_ != 0 || win_need[k] > 512) continue;  // wave-kernel tasks only
+      uint64_t h = ((uint64_t)(uint32_t)y.qlen * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)y.tlen * 0xC2B2AE3D27D4EB4Full) ^
+                   ((uint64_t)(uint32_t)y.w * 0x165667B19E3779F9ull) ^ ((uint64_t)(uint32_t)y.flag << 40);
+      h ^= h >> 29;
+      for (size_t slot = (size_t)h & (cap - 1);; slot = (slot + 1) & (cap - 1)) {
+        auto &e = table[slot];
+        if (e.first < 0) {
+          e = {(int32_t)k, (int32_t)k};
+          break;
+        }
+        const PlanTask &x = cp[e.first];
+        if (x.qlen != y.qlen || x.tlen != y.tlen || x.w != y.w || x.flag != y.flag) continue;
+        if (e.second < 0) {
+          e.second = (int32_t)k;
+          break;
+        }
+        PlanTask &z = cp[e.second];
+        const int regs = (win_need[k] + 63) / 64;
+        const int nreg = regs <= 4 ? regs : regs <= 6 ? 6 : 8;
+        if (pair_lds_bytes(y.qlen, y.tlen, nreg) > (size_t)env.max_dyn_lds) break;
+        z.nreg = y.nreg = nreg;
+        z.pad_ = y.pad_ = 2;
+        partner[k] = e.second;
+        partner[e.second] = (int32_t)k;
+        c.paired += 2;
+        e.second = -1;
+        break;
+      }
+    }
+    // a task left without a partner is paired with itself (both halves compute the same task and write the
+    // same bytes) instead of occupying a launch of its own for a whole task latency
+    for (auto &e : table) {
+      if (e.second < 0) continue;
+      PlanTask &y = cp[e.second];
+      const int regs = (win_need[e.second] + 63) / 64;
+      const int nreg = regs <= 4 ? regs : regs <= 6 ? 6 : 8;
+      if (pair_lds_bytes(y.qlen, y.tlen, nreg) > (size_t)env.max_dyn_lds) continue;
+      y.nreg = nreg;
+      y.pad_ = 2;
+      partner[e.second] = e.second;
+    }
+  }
+
+  // launch classes: (kernel, LDS bytes rounded to a power of two); the direction-flag layout inside this chunk's
+  // workspace region is fixed in the same pass
+  cls.clear();
+  size_t dir_acc = 0;
+  for (size_t k = 0; k < cnt; ++k) {
+    PlanTask &p = cp[k];
+    {
+      size_t need = 0;
+      if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
+        const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
+        if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
+        else if (p.pad_ == 5)
+          need = (size_t)((p.tlen + 128 * p.nreg - 1) / (128 * p.nreg)) * stripe_dir_bytes(p.qlen, p.nreg);
+        else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
+        else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
+      }
+      p.dir_off = (int64_t)dir_acc;
+      dir_acc += need;
+    }
+    c.layouts |= 1u << (p.nreg == 0 ? 0 : p.pad_ == 2 ? 2 : p.pad_ == 5 ? 3 : 1);
+    const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
+    int bs = width > 1024 ? 1024 : width > 256 ? 256 : 64;  // 4 cells per thread and pass over the row
+    size_t lds = 2048, need;
+    if (p.pad_ == 2) {
+      if (partner[k] < (int32_t)k) continue;  // placed together with its partner
+      // 100 + NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
+      bs = 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
+      need = pair_lds_bytes(p.qlen, p.tlen, p.nreg);
+      lds = 8192;
+      while (lds < need) lds *= 2;
+    } else if (p.pad_ == 5) {
+      bs = 200 + p.nreg;  // stripe kernel; LDS by the stripe count and the query length
+      need = stripe_lds_bytes(p.qlen, (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg), p.nreg);
+      lds = 32768;
+      while (lds < need) lds *= 2;
+    } else if (p.nreg) {
+      // NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
+      bs = p.nreg + (wave_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
+      // one class for everything up to 6 KiB (>= 6 waves/SIMD either way), powers of two above
+      need = wave_lds_bytes(p.qlen, p.tlen, p.nreg);
+      lds = 6144;
+      while (lds < need) lds *= 2;
+    } else if (p.pad_ == 1 || p.pad_ == 4) {  // HBM-resident state: one class, slab = largest requirement
+      bs = p.pad_ == 4 ? 2001 : width > 1024 ? 1001 : 1000;
+      need = general_lds_bytes(p.qlen, p.tlen);
+      lds = (size_t)1 << 40;
+    } else {
+      if (p.pad_ == 3) bs += 2000;  // PLAIN flavour: 2256 / 3024
+      need = general_lds_bytes(p.qlen, p.tlen);
+      while (lds < need) lds *= 2;
+    }
+    const bool hbm_cls = bs == 1000 || bs == 1001 || bs == 2001;
+    if (!hbm_cls && need > (size_t)env.max_dyn_lds) {  // every kernel choice above checked its LDS need
+      c.err = "internal: launch class needs more LDS than the device offers";
+      return;
+    }
+    if (!hbm_cls && lds > (size_t)env.max_dyn_lds) lds = env.max_dyn_lds;
+    int sub = 0;
+    if (p.pad_ == 5) {
+      const int ns = (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg);
+      sub = ns <= 4 ? 4 : ns <= 8 ? 8 : 16;
+    }
+    Cls *cl = nullptr;
+    for (auto &x : cls)
+      if (x.bs == bs && x.lds == lds && x.sub == sub) cl = &x;
+    if (!cl) {
+      cls.push_back({bs, lds, 0, {}});
+      cl = &cls.back();
+      cl->sub = sub;
+    }
+    cl->need_max = std::max(cl->need_max, need);
+    if (p.pad_ == 5) cl->kmax = std::max(cl->kmax, (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg));
+    {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
+      const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.6 : bs == 2256 ? 0.3 : bs == 3024 ? 0.85
+                          : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..118)
+      cl->est = std::max(cl->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
+    }
+    cl->idx.push_back((int32_t)k);
+    if (p.pad_ == 2) cl->idx.push_back(partner[k]);
+  }
+  c.dir_bytes = dir_acc;
+  if (dir_acc > (c.heavy ? cut.heavy_need : cut.region_need)) {
+    c.err = "internal: direction-flag region overflow";
+    return;
+  }
+  // Small classes of one kernel (< 2048 tasks: occupancy is not what limits them, their longest task is) are
+  // merged into one launch with the largest LDS size among them: fewer launches queued one behind the other.
+  for (size_t a = 0; a < cls.size(); ++a) {
+    if (cls[a].idx.empty() || cls[a].idx.size() >= 2048) continue;
+    for (size_t b = a + 1; b < cls.size(); ++b) {
+      if (cls[b].bs != cls[a].bs || cls[b].sub != cls[a].sub || cls[b].idx.empty() || cls[b].idx.size() >= 2048) continue;
+      cls[a].lds = std::max(cls[a].lds, cls[b].lds);
+      cls[a].need_max = std::max(cls[a].need_max, cls[b].need_max);
+      cls[a].est = std::max(cls[a].est, cls[b].est);
+      cls[a].kmax = std::max(cls[a].kmax, cls[b].kmax);
+      cls[a].idx.insert(cls[a].idx.end(), cls[b].idx.begin(), cls[b].idx.end());
+      cls[b].idx.clear();
+    }
+  }
+  cls.erase(std::remove_if(cls.begin(), cls.end(), [](const Cls &x) { return x.idx.empty(); }), cls.end());
+  // inside a launch of few tasks the longest go first too (workgroups are dispatched in order: a long task that
+  // starts last is the tail of the launch); pair-kernel entries move as (task, partner) units
+  for (auto &x : cls) {
+    if (x.idx.size() >= 8192 || x.idx.size() < 3) continue;
+    auto work = [&](int32_t k) { return (int64_t)(cp[k].qlen + cp[k].tlen) * cp[k].ncol16; };
+    int64_t wmin = work(x.idx[0]), wmax = wmin;
+    for (int32_t k : x.idx) {
+      const int64_t wk = work(k);
+      wmin = std::min(wmin, wk);
+      wmax = std::max(wmax, wk);
+    }
+    if (wmax < 2 * wmin) continue;  // tasks of one size: the order does not matter
+    if (x.bs >= 100 && x.bs < 200) {
+      std::vector<std::pair<int32_t, int32_t>> pr(x.idx.size() / 2);
+      for (size_t q = 0; q < pr.size(); ++q) pr[q] = {x.idx[2 * q], x.idx[2 * q + 1]};
+      std::stable_sort(pr.begin(), pr.end(), [&](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
+        return work(a.first) > work(b.first);
+      });
+      for (size_t q = 0; q < pr.size(); ++q) {
+        x.idx[2 * q] = pr[q].first;
+        x.idx[2 * q + 1] = pr[q].second;
+      }
+    } else {
+      std::stable_sort(x.idx.begin(), x.idx.end(), [&](int32_t a, int32_t b) { return work(a) > work(b); });
+    }
+  }
+  // longest launches first so the long tasks start early
+  std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.est > b.est; });
+  size_t cursor = 0;
+  for (auto &x : cls) {
+    const bool hbm_cls = x.bs == 1000 || x.bs == 1001 || x.bs == 2001;
+    c.launches.push_back({x.bs, hbm_cls ? ((x.need_max + 255) & ~(size_t)255) : std::min(x.lds, (x.need_max + 511) & ~(size_t)511),
+                          cursor, x.idx.size(), x.est, x.kmax});
+    std::copy(x.idx.begin(), x.idx.end(), order + c.ob + cursor);
+    cursor += x.idx.size();
+  }
+  c.nord = cursor;
+}
+
+}  // namespace sdf

@@ -3,10 +3,8 @@
 // Restates ksw_backtrack / ksw_push_cigar (reference: extern/ksw2.h:98-151, rotated layout)
 // and the counters of populate_nice_alignment (reference: src/align.cc:274-315).
 //
-// The walk is inherently serial per task (each step's address depends on the previous
-// direction byte), so it is parallelised across tasks: one lane per task, every lane chasing
-// its own path.  Runs are emitted from the END of the task's staging slot towards its start,
-// which leaves them in forward order without a reversal pass.
+// The reference's walk is serial per task; here a group of lanes walks one task a whole RUN at a time (see
+// traceback_kernel below).
 #include <hip/hip_runtime.h>
 
 #include "sdf_internal.h"
@@ -19,236 +17,217 @@ __device__ __forceinline__ uint32_t code_at(const uint32_t *codes, const uint32_
   return n ? 4u : c;
 }
 
+// ---- one cell of the direction matrix ----------------------------------------------------------------------
 // LAYOUT: 0 = byte rows (general kernel), 1 = wave-kernel bit blocks, 2 = pair-kernel bit blocks, 3 = wave-kernel
-// bit blocks per target stripe (extz2_stripe.hip).  One
-// instantiation per layout: in a common loop every step would wait for all outstanding loads at the point where
-// the three fetch paths meet.  Tasks of another layout leave at once (the host launches only the instantiations
-// a chunk needs).
+// bit blocks per target stripe (extz2_stripe.hip).  A cell outside the block range the reference stored for its
+// anti-diagonal has no flags: the walk is forced there (reference: extern/ksw2.h:128-130) -- state 2 below the
+// range, 1 above it.
+struct TbAddr {
+  int64_t idx;    // record to load (0 when nothing is to be loaded)
+  uint32_t meta;  // bit position of the row inside the record | 0x100 | forced state
+};
+
 template <int LAYOUT>
+__device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
+  const int r = i + j;
+  Band b;
+  band_of(r, tk.qlen, tk.tlen, tk.w, b);
+  TbAddr a;
+  if (i < b.lo || i > b.hi) {
+    a.idx = 0;
+    a.meta = 0x100u | (i < b.lo ? 2u : 1u);
+    return a;
+  }
+  if (LAYOUT == 0) {
+    a.idx = (int64_t)r * tk.ncol16 + (i - b.lo);
+    a.meta = 0;
+  } else if (LAYOUT == 3) {
+    // stripes of 128 * nreg target positions, each a stand-alone wave-kernel task over its slice in local
+    // coordinates (row r - T0, position t - T0); one flag region per stripe
+    const int sw = 128 * tk.nreg;
+    const int sb = i / sw, t0 = sb * sw;
+    const int rp = r - t0, rb = rp >> 4;
+    Band b0;
+    band_of(rb << 4, tk.qlen, tk.tlen - t0 < sw ? tk.tlen - t0 : sw, tk.w, b0);
+    const int slot = i - t0 - b0.lo;
+    const int per_stripe = ((tk.qlen + sw - 1 + 15) / 16) * tk.nreg * 64;  // uint4 records
+    a.idx = (int64_t)sb * per_stripe + rb * (tk.nreg * 64) + (slot >> 1);  // (register k, lane l) = slots 128k + 2l, +1
+    a.meta = (uint32_t)(15 - (rp & 15) + ((slot & 1) << 4));
+  } else {
+    const int rb = r >> 4;
+    Band b0;
+    band_of(rb << 4, tk.qlen, tk.tlen, tk.w, b0);  // window base of the 16-row block
+    const int slot = i - b0.lo;
+    if (LAYOUT == 2) {  // per register k (64 slots) and lane one uint2 (a | b << 16, x | y << 16) of 16-bit row masks
+      a.idx = (int64_t)rb * (tk.nreg * 64) + slot;
+      a.meta = (uint32_t)(15 - (r & 15));
+    } else {  // per register k and lane one uint4 of 32-bit words (a>z, b>z', x>0, y>0); +16 for the odd slot
+      a.idx = (int64_t)rb * (tk.nreg * 64) + (slot >> 1);
+      a.meta = (uint32_t)(15 - (r & 15) + ((slot & 1) << 4));
+    }
+  }
+  return a;
+}
+
+// the reference's direction byte of the cell (bits 0-1: 0 diagonal / 1 E / 2 F won, bit 3: E continues, bit 4: F
+// continues), or 0x100 | forced state
+template <int LAYOUT>
+__device__ __forceinline__ uint32_t tb_load(const uint8_t *dir, const TbAddr a) {
+  if (LAYOUT == 0) {
+    const uint32_t d = dir[a.idx];
+    return (a.meta & 0x100u) ? a.meta : d;
+  } else if (LAYOUT == 2) {
+    const uint2 c = reinterpret_cast<const uint2 *>(dir)[a.idx];
+    const uint32_t bit = a.meta & 31u;
+    const uint32_t fa = (c.x >> bit) & 1u, fb = (c.x >> (bit + 16)) & 1u;
+    const uint32_t fx = (c.y >> bit) & 1u, fy = (c.y >> (bit + 16)) & 1u;
+    return (a.meta & 0x100u) ? a.meta : ((fb ? 2u : fa) | (fx << 3) | (fy << 4));
+  } else {
+    const uint4 c = reinterpret_cast<const uint4 *>(dir)[a.idx];
+    const uint32_t bit = a.meta & 31u;
+    const uint32_t fa = (c.x >> bit) & 1u, fb = (c.y >> bit) & 1u;
+    const uint32_t fx = (c.z >> bit) & 1u, fy = (c.w >> bit) & 1u;
+    return (a.meta & 0x100u) ? a.meta : ((fb ? 2u : fa) | (fx << 3) | (fy << 4));
+  }
+}
+
+// state of the walk at a cell entered in state `s_in` (ksw_backtrack's state machine, extern/ksw2.h:131-137)
+__device__ __forceinline__ int tb_state(int s_in, uint32_t cell) {
+  if (cell & 0x100u) return (int)(cell & 7u);
+  return (s_in != 0 && ((cell >> (s_in + 2)) & 1u)) ? s_in : (int)(cell & 7u);
+}
+
+// ---- the walk ----------------------------------------------------------------------------------------------------
+// ksw_backtrack is serial: the cell a step reads depends on the state the previous cell left.  But a walk is a
+// sequence of RUNS -- diagonal steps while the cells say "diagonal", gap steps while the continuation bit is set --
+// and whether a run goes on through its k-th cell depends on that cell alone.  A group of G lanes walks one task:
+// every lane reads the current cell (-> the state s of the run that starts here), lane k also reads the k-th cell
+// ahead in each of the three directions, one ballot tells how far the run of kind s goes (up to G cells), the
+// match / mismatch columns of a diagonal run are counted with a second ballot, and the whole run is emitted as one
+// CIGAR push.  A 1000 x 1000 task at 10 % divergence is ~60 such rounds (one memory latency each) instead of 2,000
+// dependent steps.  G = 64: one task per wavefront (few or long tasks); G = 16: four tasks per wavefront (bulk).
+// Runs are emitted from the END of the task's staging slot towards its start, which leaves them in forward order.
+template <int LAYOUT, int G>
 __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restrict__ plan, int n,
                                                        const uint32_t *__restrict__ pool,
                                                        const uint8_t *__restrict__ dirbase,
                                                        sdf_result *__restrict__ res,
                                                        uint32_t *__restrict__ stage) {
-  // n < 0: -n tasks, ONE per wavefront (lane 0 walks): the lanes of a wavefront leave their cached lines at
-  // different steps, so with 64 walks per wavefront every step waits for somebody's miss; a chunk of few, long
-  // tasks is walked faster with a wavefront each
-  const bool solo = n < 0;
-  if (solo && threadIdx.x != 0) return;
-  const int k = solo ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (k >= (solo ? -n : n)) return;
-  const PlanTask tk = plan[k];
-  if ((tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : 1) != LAYOUT) return;
+  constexpr int PER = 64 / G;
+  const int lane = threadIdx.x, kk = lane % G, gbase = lane - kk;
+  const int k = (int)blockIdx.x * PER + lane / G;
+  bool active = k < n;
+  PlanTask tk = plan[active ? k : 0];
+  active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : 1) == LAYOUT &&
+           !(tk.flag & SDF_FLAG_SCORE_ONLY);
   sdf_result rr = res[tk.out_idx];
-  if (tk.flag & SDF_FLAG_SCORE_ONLY) return;
-
-  int i, j;  // (sequences are shorter than 2^31)
-  if (!rr.zdropped && !(tk.flag & SDF_FLAG_EXTZ_ONLY)) {
-    i = tk.tlen - 1;
-    j = tk.qlen - 1;
-  } else if (rr.max_t >= 0 && rr.max_q >= 0) {
-    i = rr.max_t;
-    j = rr.max_q;
-  } else {
-    return;  // n_cigar stays 0
+  int i = -1, j = -1;  // (sequences are shorter than 2^31)
+  if (active) {
+    if (!rr.zdropped && !(tk.flag & SDF_FLAG_EXTZ_ONLY)) {
+      i = tk.tlen - 1;
+      j = tk.qlen - 1;
+    } else if (rr.max_t >= 0 && rr.max_q >= 0) {
+      i = rr.max_t;
+      j = rr.max_q;
+    } else {
+      active = false;  // n_cigar stays 0
+    }
   }
-
   const uint8_t *dir = dirbase + tk.dir_off;
-  const int64_t stride = tk.ncol16;
   const uint32_t *tw = pool + tk.t_word, *tn = tw + (tk.tlen + 15) / 16;
   const uint32_t *qw = pool + tk.q_word, *qn = qw + (tk.qlen + 15) / 16;
   uint32_t *slot = stage + tk.cig_slot;
   int pos = tk.cig_cap;
   int cur_op = -1, cur_len = 0;
   int32_t matches = 0, mismatches = 0, gaps = 0, gap_bases = 0;
+  const uint64_t gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
 
+  auto flush = [&]() {
+    if (cur_op >= 0) {
+      --pos;
+      if (kk == 0) slot[pos] = ((uint32_t)cur_len << 4) | (uint32_t)cur_op;
+      if (cur_op != 0) {  // the counters of populate_nice_alignment (src/align.cc:274-315)
+        ++gaps;
+        gap_bases += cur_len;
+      }
+    }
+  };
   auto push = [&](int op, int len) {
     if (op == cur_op) {
       cur_len += len;
     } else {
-      if (cur_op >= 0) slot[--pos] = ((uint32_t)cur_len << 4) | (uint32_t)cur_op;
+      flush();
       cur_op = op;
       cur_len = len;
     }
   };
 
-  // The two sequences are read backwards, one base per step that consumes them: the current 16-base code word and
-  // 32-base N-mask word of each are kept SHIFTED so that the base under the walk is in the top bits -- a step is one
-  // shift, a new word is loaded every 16 steps.
-  uint32_t qsh = 0, qnsh = 0, tsh = 0, tnsh = 0;
-  if (i >= 0 && j >= 0) {
-    qsh = qw[j >> 4] << ((15 - (j & 15)) * 2);
-    qnsh = qn[j >> 5] << (31 - (j & 31));
-    tsh = tw[i >> 4] << ((15 - (i & 15)) * 2);
-    tnsh = tn[i >> 5] << (31 - (i & 31));
-  }
-  int state = 0;
-  // wave-kernel layout: block rb = r/16 holds, per packed register k and lane, one uint4 of four
-  // 32-bit flag words (a>z, b>z', x>0, y>0); bit 15-(r%16) (+16 for the odd slot) is row r;
-  // slot = t - (band start of row 16*rb).  The last fetched uint4 is kept: a path stays inside
-  // one 16-row x 2-slot tile for several steps.
-  const uint4 *dirw = reinterpret_cast<const uint4 *>(dir);
-  int cached_line = -1;  // index/4 of the 64-byte line (4 lanes = 8 slots x 16 rows) held below
-  uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
-  int blk_rb = -1, blk_sb = -1, blk_base = 0;
-  while ((i | j) >= 0) {
-    const int r = i + j;
-    Band b;
-    band_of(r, tk.qlen, tk.tlen, tk.w, b);
-    int forced = -1;
-    uint32_t d = 0;
-    if (i < b.lo) forced = 2;
-    if (i > b.hi) forced = 1;
-    if (forced < 0) {
-      if (LAYOUT == 0) {
-        d = dir[(int64_t)r * stride + (i - b.lo)];
-      } else if (LAYOUT == 2) {
-        // pair-kernel layout: per register k (64 slots) and lane one uint2 (a | b << 16, x | y << 16) of
-        // 16-bit row masks; a 64-byte line holds 8 slots x 16 rows
-        const int rb = r >> 4;
-        if (rb != blk_rb) {
-          Band b0;
-          band_of(rb << 4, tk.qlen, tk.tlen, tk.w, b0);
-          blk_rb = rb;
-          blk_base = b0.lo;
-        }
-        const int idx = rb * (tk.nreg * 64) + (i - blk_base);  // (register k, lane l) = slot 64k + l
-        if ((idx >> 3) != cached_line) {
-          cached_line = idx >> 3;
-          const uint4 *ln = dirw + ((int64_t)cached_line << 2);
-          c0 = ln[0];
-          c1 = ln[1];
-          c2 = ln[2];
-          c3 = ln[3];
-        }
-        const int sel = (idx & 7) >> 1;
-        const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
-        const uint32_t wab = (idx & 1) ? cached.z : cached.x, wxy = (idx & 1) ? cached.w : cached.y;
-        const int bit = 15 - (r & 15);
-        const uint32_t fa = (wab >> bit) & 1u, fb = (wab >> (bit + 16)) & 1u;
-        const uint32_t fx = (wxy >> bit) & 1u, fy = (wxy >> (bit + 16)) & 1u;
-        d = (fb ? 2u : fa) | (fx << 3) | (fy << 4);
-      } else if (LAYOUT == 3) {
-        // stripes of 128 * nreg target positions, each a stand-alone wave-kernel task over its slice in local
-        // coordinates (row r - T0, position t - T0); one flag region per stripe
-        const int sw = 128 * tk.nreg;
-        const int sb = i / sw, t0 = sb * sw;
-        const int rp = r - t0, tp = i - t0;
-        const int rb = rp >> 4;
-        if (rb != blk_rb || sb != blk_sb) {
-          Band b0;
-          band_of(rb << 4, tk.qlen, tk.tlen - t0 < sw ? tk.tlen - t0 : sw, tk.w, b0);
-          blk_rb = rb;
-          blk_sb = sb;
-          blk_base = b0.lo;
-        }
-        const int slot = tp - blk_base;
-        const int per_stripe = ((tk.qlen + sw - 1 + 15) / 16) * tk.nreg * 64;  // uint4 records
-        const int idx = sb * per_stripe + rb * (tk.nreg * 64) + (slot >> 1);  // (register k, lane l) = slots 128k + 2l, +1
-        if ((idx >> 2) != cached_line) {
-          cached_line = idx >> 2;
-          const uint4 *ln = dirw + ((int64_t)cached_line << 2);
-          c0 = ln[0];
-          c1 = ln[1];
-          c2 = ln[2];
-          c3 = ln[3];
-        }
-        const int sel = idx & 3;
-        const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
-        const int bit = 15 - (rp & 15) + ((slot & 1) << 4);
-        const uint32_t fa = (cached.x >> bit) & 1u, fb = (cached.y >> bit) & 1u;
-        const uint32_t fx = (cached.z >> bit) & 1u, fy = (cached.w >> bit) & 1u;
-        d = (fb ? 2u : fa) | (fx << 3) | (fy << 4);
-      } else {
-        const int rb = r >> 4;
-        if (rb != blk_rb) {
-          Band b0;
-          band_of(rb << 4, tk.qlen, tk.tlen, tk.w, b0);
-          blk_rb = rb;
-          blk_base = b0.lo;
-        }
-        const int slot = i - blk_base;
-        const int idx = rb * (tk.nreg * 64) + (slot >> 1);
-        if ((idx >> 2) != cached_line) {  // a diagonal run stays inside one line for ~8 steps
-          cached_line = idx >> 2;
-          const uint4 *ln = dirw + ((int64_t)cached_line << 2);
-          c0 = ln[0];
-          c1 = ln[1];
-          c2 = ln[2];
-          c3 = ln[3];
-        }
-        const int sel = idx & 3;
-        const uint4 cached = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
-        const int bit = 15 - (r & 15) + ((slot & 1) << 4);
-        const uint32_t fa = (cached.x >> bit) & 1u, fb = (cached.y >> bit) & 1u;
-        const uint32_t fx = (cached.z >> bit) & 1u, fy = (cached.w >> bit) & 1u;
-        d = (fb ? 2u : fa) | (fx << 3) | (fy << 4);
+  int s_in = 0;
+  while (__any(active && (i | j) >= 0)) {
+    const bool live = active && (i | j) >= 0;
+    const int ci = live ? i : 0, cj = live ? j : 0;
+    // the k-th cell ahead in each direction (k = 0: the current cell in all three)
+    const int di = ci - kk, dj = cj - kk;
+    const bool vd = di >= 0 && dj >= 0, vu = di >= 0, vl = dj >= 0;
+    const TbAddr a0 = tb_addr<LAYOUT>(tk, ci, cj);
+    const TbAddr ad = tb_addr<LAYOUT>(tk, vd ? di : ci, vd ? dj : cj);
+    const TbAddr au = tb_addr<LAYOUT>(tk, vu ? di : ci, cj);
+    const TbAddr al = tb_addr<LAYOUT>(tk, ci, vl ? dj : cj);
+    const uint32_t c0 = tb_load<LAYOUT>(dir, a0), cd = tb_load<LAYOUT>(dir, ad), cu = tb_load<LAYOUT>(dir, au),
+                   cl = tb_load<LAYOUT>(dir, al);
+    // bases of the diagonal cell (match <=> neither is N and the codes agree, src/align.cc:29-35 on the codes)
+    const uint32_t tb_ = code_at(tw, tn, vd ? di : ci), qb_ = code_at(qw, qn, vd ? dj : cj);
+    const int s = tb_state(s_in, c0);
+    const uint32_t cs = s == 0 ? cd : s == 1 ? cu : cl;
+    const bool vs = s == 0 ? vd : s == 1 ? vu : vl;
+    const bool stay = live && vs && (kk == 0 || tb_state(s, cs) == s);
+    const uint64_t bits = (__ballot(stay) >> gbase) & gmask;
+    const uint64_t stop = ~bits & gmask;
+    const int nrun = stop ? __builtin_ctzll(stop) : G;
+    const uint64_t mb = (__ballot(tb_ == qb_ && tb_ < 4u) >> gbase) & (nrun >= 64 ? ~0ull : ((1ull << nrun) - 1ull));
+    if (live) {
+      if (s == 0) {
+        const int m = __popcll(mb);
+        matches += m;
+        mismatches += nrun - m;
+        i -= nrun;
+        j -= nrun;
+        push(0, nrun);
+      } else if (s == 1) {  // E: consumes the target (ksw op 2, D)
+        i -= nrun;
+        push(2, nrun);
+      } else {  // F: consumes the query (ksw op 1, I)
+        j -= nrun;
+        push(1, nrun);
       }
-    }
-    if (state == 0) state = (int)(d & 7u);
-    else if (!((d >> (state + 2)) & 1u)) state = 0;
-    if (state == 0) state = (int)(d & 7u);
-    if (forced >= 0) state = forced;
-    // one step: state 0 consumes a base of both (M), 1 / 3 of the target (ksw D, op 2), anything else of the query
-    const bool step_i = state == 0 || state == 1 || state == 3, step_j = state == 0 || !step_i;
-    if (state == 0) {
-      // match <=> neither base is N and the 2-bit codes agree (src/align.cc:29-35 on the codes)
-      if ((((qnsh | tnsh) >> 31) | ((qsh ^ tsh) >> 30)) == 0u) ++matches; else ++mismatches;
-    }
-    push(state == 0 ? 0 : step_i ? 2 : 1, 1);
-    if (step_i) {
-      --i;
-      if ((i & 15) == 15) {  // (also true for i == -1: the loop ends before the words are used)
-        if (i >= 0) {
-          tsh = tw[i >> 4];
-          tnsh = (i & 31) == 31 ? tn[i >> 5] : tnsh << 1;
-        }
-      } else {
-        tsh <<= 2;
-        tnsh <<= 1;
-      }
-    }
-    if (step_j) {
-      --j;
-      if ((j & 15) == 15) {
-        if (j >= 0) {
-          qsh = qw[j >> 4];
-          qnsh = (j & 31) == 31 ? qn[j >> 5] : qnsh << 1;
-        }
-      } else {
-        qsh <<= 2;
-        qnsh <<= 1;
-      }
+      s_in = s;
     }
   }
-  if (i >= 0) push(2, i + 1);
-  if (j >= 0) push(1, j + 1);
-  if (cur_op >= 0) slot[--pos] = ((uint32_t)cur_len << 4) | (uint32_t)cur_op;
-
-  const int ncig = tk.cig_cap - pos;
-  for (int c = pos; c < tk.cig_cap; ++c) {
-    const uint32_t wd = slot[c];
-    if (wd & 0xfu) {
-      ++gaps;
-      gap_bases += (int32_t)(wd >> 4);
+  if (active) {
+    if (i >= 0) push(2, i + 1);
+    if (j >= 0) push(1, j + 1);
+    flush();
+    if (kk == 0) {
+      rr.n_cigar = tk.cig_cap - pos;
+      rr.matches = matches;
+      rr.mismatches = mismatches;
+      rr.gaps = gaps;
+      rr.gap_bases = gap_bases;
+      res[tk.out_idx] = rr;
     }
   }
-  rr.n_cigar = ncig;
-  rr.matches = matches;
-  rr.mismatches = mismatches;
-  rr.gaps = gaps;
-  rr.gap_bases = gap_bases;
-  res[tk.out_idx] = rr;
 }
 
-template __global__ void traceback_kernel<0>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
-                                             uint32_t *);
-template __global__ void traceback_kernel<1>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
-                                             uint32_t *);
-template __global__ void traceback_kernel<2>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
-                                             uint32_t *);
-template __global__ void traceback_kernel<3>(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *,
-                                             uint32_t *);
+#define SDF_TB_INST(L)                                                                                              \
+  template __global__ void traceback_kernel<L, 16>(const PlanTask *, int, const uint32_t *, const uint8_t *,      \
+                                                    sdf_result *, uint32_t *);                                     \
+  template __global__ void traceback_kernel<L, 64>(const PlanTask *, int, const uint32_t *, const uint8_t *,      \
+                                                    sdf_result *, uint32_t *);
+SDF_TB_INST(0)
+SDF_TB_INST(1)
+SDF_TB_INST(2)
+SDF_TB_INST(3)
+#undef SDF_TB_INST
 
 // Exclusive scan of n_cigar over the result records in record order -> cigar_off, in three small launches:
 // per 1024-record block a local scan + the block total, a scan of the block totals (one workgroup), and the

@@ -1,0 +1,120 @@
+"""The batch planner (sedef_amd/csrc/sdf_plan.hip) without a GPU: cut_batch + plan_chunk through the library's
+sdf_debug_plan hook.  Invariants of a plan: every runnable task is planned exactly once, direction-flag regions and CIGAR
+staging slots are disjoint and inside the chunk's workspace slice, paired tasks share their geometry, heavy tasks leave
+the chunk rotation, and planning on several threads gives the same plan as planning on one."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _plan(tasks, want=3, ws=64 << 30, lds=160 * 1024, threads=0, mat=None, gapo=40, gape=1):
+    import sedef_amd
+    from sedef_amd import extz2
+    lib = sedef_amd.load_library()
+    sc = extz2._scoring(extz2.sedef_mat() if mat is None else mat, gapo, gape)
+    n = len(tasks)
+    per_task = np.zeros((n, 7), np.int64)
+    per_chunk = np.zeros((64, 5), np.int64)
+    nch = C.c_size_t(0)
+    lib.sdf_debug_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    rc = lib.sdf_debug_plan(C.byref(sc), tasks.ctypes.data, n, want, ws, lds, threads, per_task.ctypes.data,
+                            per_chunk.ctypes.data, 64, C.byref(nch))
+    return rc, per_task, per_chunk[:nch.value]
+
+
+def _tasks(qlen, tlen, w=-1, flag=0, zdrop=-1):
+    from sedef_amd.extz2 import TASK_DTYPE
+    t = np.zeros(len(qlen), TASK_DTYPE)
+    t["qlen"], t["tlen"], t["w"], t["flag"], t["zdrop"] = qlen, tlen, w, flag, zdrop
+    return t
+
+
+def _dir_need(q, t, bs, nreg, pad):
+    nblk = (q + t - 1 + 15) // 16
+    if pad == 2:
+        return nblk * nreg * 512
+    if pad == 5:
+        return None  # stripe layout: checked by disjointness only
+    if nreg:
+        return nblk * nreg * 1024
+    return None
+
+
+def _check(tasks, per_task, per_chunk):
+    runs = (tasks["qlen"] > 0) & (tasks["tlen"] > 0)
+    assert ((per_task[:, 0] >= 0) == runs).all()
+    for ci in range(len(per_chunk)):
+        sel = np.flatnonzero(per_task[:, 0] == ci)
+        assert len(sel) == per_chunk[ci, 1]
+        assert per_chunk[ci, 3] <= per_chunk[ci, 4]
+        offs = np.sort(per_task[sel, 4])
+        assert len(np.unique(offs)) == len(offs) or (tasks["flag"][sel] & 1).any()
+        assert offs.max(initial=0) < max(per_chunk[ci, 3], 1)
+        for k in sel[:2000]:
+            need = _dir_need(int(tasks["qlen"][k]), int(tasks["tlen"][k]), *[int(x) for x in per_task[k, 1:4]])
+            if need is not None:
+                nxt = offs[np.searchsorted(offs, per_task[k, 4], side="right"):]
+                assert len(nxt) == 0 or per_task[k, 4] + need <= nxt[0]
+    slots = per_task[runs, 5]
+    assert len(np.unique(slots)) == len(slots)  # CIGAR staging slots: one per task
+    order = np.argsort(slots)
+    cap = (tasks["qlen"][runs].astype(np.int64) + tasks["tlen"][runs] + 2)[order]
+    assert (slots[order][1:] >= slots[order][:-1] + cap[:-1]).all()
+    part = per_task[:, 6]
+    for k in np.flatnonzero(part >= 0):
+        p = int(part[k])
+        assert part[p] == k and per_task[p, 0] == per_task[k, 0] and per_task[p, 1] == per_task[k, 1]
+        assert (tasks["qlen"][p], tasks["tlen"][p], tasks["w"][p]) == (tasks["qlen"][k], tasks["tlen"][k], tasks["w"][k])
+
+
+def test_headline_batch_is_chunked_paired_and_deterministic():
+    rng = np.random.default_rng(1)
+    n = 100000
+    t = _tasks(np.full(n, 1000), 1000 + rng.integers(-25, 25, n), w=128)
+    rc, pt, pc = _plan(t)
+    assert rc == 0 and len(pc) >= 4 and not pc[:, 0].any()
+    assert (pt[:, 1] == 103).all() and (pt[:, 6] >= 0).all()  # extz2_pair_kernel<3>, every task has a partner
+    assert pc[0, 1] <= 8192 < pc[1, 1]  # a small first chunk: the GPU starts early
+    _check(t, pt, pc)
+    rc2, pt2, pc2 = _plan(t, threads=4)
+    assert rc2 == 0 and (pt2 == pt).all() and (pc2 == pc).all()
+
+
+def test_mixture_with_heavy_tasks_and_empty_tasks():
+    rng = np.random.default_rng(2)
+    n = 80000
+    q = rng.integers(1, 220, n)
+    tl = np.maximum(1, q + rng.integers(-8, 8, n))
+    big = rng.choice(n, 60, replace=False)
+    q[big] = rng.integers(1500, 9000, 60)
+    tl[big] = q[big] + rng.integers(-100, 100, 60)
+    q[rng.choice(n, 50, replace=False)] = 0  # reference early return: no work, reset result
+    t = _tasks(q, tl)
+    rc, pt, pc = _plan(t, threads=3)
+    assert rc == 0
+    heavy = np.flatnonzero(pc[:, 0])
+    assert len(heavy) >= 1 and (heavy == np.arange(len(heavy))).all()  # heavy chunks are launched first
+    hv_tasks = np.isin(pt[:, 0], heavy)
+    assert hv_tasks.sum() >= 40 and (t["qlen"][hv_tasks] >= 700).all()
+    assert set(np.unique(pt[hv_tasks, 1])) <= {201, 202, 204, 2256, 3024, 2001, 104, 114, 106, 116, 108, 118, 8, 18}
+    _check(t, pt, pc)
+    rc1, pt1, pc1 = _plan(t, threads=0)
+    assert (pt1 == pt).all() and (pc1 == pc).all()
+
+
+def test_kernel_choice_by_request():
+    t = _tasks([500, 500, 500, 500, 3000, 70000], [500, 500, 500, 500, 3000, 300], w=[-1, -1, 64, 64, -1, -1],
+               zdrop=[-1, 100, -1, -1, -1, -1], flag=[0, 0, 0, 2, 0, 0])
+    rc, pt, pc = _plan(t)
+    assert rc == 0
+    assert pt[0, 1] in (108, 118) and pt[1, 1] in (64, 256, 1024)  # z-drop needs every ksw_extz_t field: general kernel
+    assert pt[2, 1] in (102, 103) and pt[3, 1] in (64, 256)        # right-aligned gaps: general kernel
+    assert pt[4, 1] in (201, 202, 204)                            # wide full-band: stripe kernel
+    rc, pt, pc = _plan(t, want=7)                                 # every field wanted: no register-resident kernel
+    assert rc == 0 and (pt[:, 1] >= 64).all() and not np.isin(pt[:, 1], (101, 102, 103, 104, 106, 108, 201, 202, 204)).any()
+    rc, _, _ = _plan(_tasks([10], [10], flag=[4]))
+    assert rc == -3  # SDF_ERR_UNSUPPORTED: generic scoring
+    rc, pt, _ = _plan(_tasks([300, 0], [300, 5]), mat=np.array([1] + [-100] * 24, np.int8), gapo=1, gape=1)
+    assert rc == 0 and (pt[:, 0] == -1).all()  # degenerate scoring: the reference returns before any work
