@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- aligned DP cells/s of the `sedef align` DP hot path on MI355X.
 
-One "step" = one pass of the hot path (extz2 DP -> traceback -> CIGAR compaction -> result
-gather) over one batch of synthetic DP tasks whose packed sequences are already resident in HBM.
-Workload at every N: BASELINE.json configs[1] per GPU -- 100,000 tasks, query = 1000 uniform
-ACGT, target = query with 6 % substitution draws / 2 % deletions / 2 % insertions, band w=128,
-scoring 5/-4/40/1, zdrop=-1, flag=0.  N GPUs = N independent shards
-(weak scaling); after the DP every rank all-gathers the per-task result records and CIGARs
-(RCCL over xGMI), as the north star asks.
+One "step" = one pass of the hot path (planning -> extz2 DP -> traceback -> CIGAR compaction -> result D2H, and at
+N > 1 the all-gatherv of the result records and CIGARs over RCCL / xGMI) over one batch of synthetic DP tasks whose
+packed sequences are already resident in HBM.
 
-Prints ONE JSON line (rank 0).  `value` = in-band cells of all ranks / max-over-ranks time.
+Default workload, at every N: BASELINE.json configs[1] per GPU -- 100,000 tasks, query = 1000 uniform ACGT, target =
+query with 6 % substitution draws / 2 % deletions / 2 % insertions, band w=128, scoring 5/-4/40/1, zdrop=-1, flag=0
+(SURVEY.md 8(d), config 2); N GPUs = N independent batches (weak scaling).
+`--workload hg19mix --tasks 1000000 --strong`: the north star's batch -- ONE hg19-shaped mixture of a million tasks
+(BASELINE configs[3]) sharded over the ranks by cells (sedef_amd.dist.shard_tasks), every rank aligns its shard, every
+rank receives every rank's results, and rank 0 checks the union against a single-GPU run of the whole batch.
+
+Prints ONE JSON line (rank 0).  `value` = in-band cells of all ranks / max-over-ranks time; `value_incl_pcie` adds the
+H2D of the packed sequences (untimed extra passes, single GPU).
 """
 import argparse
 import os
@@ -114,6 +118,56 @@ def synth_hg19_mixture(n, seed, big=3000):
     return _mutated_pairs(rng, ql, tlens=tl), -1
 
 
+def synth_ragged(rng, qlens, tlens=None, sub=0.06, dele=0.02, ins=0.02):
+    """Vectorised _mutated_pairs for ragged batches of any size (same mutation model, one pass over all bases):
+    returns (pool, q_off, qlen, t_off, tlen).  With `tlens` every target is cut, or extended with random bases, to the
+    given length."""
+    qlens = np.asarray(qlens, np.int64)
+    n = len(qlens)
+    q_start = np.cumsum(qlens) - qlens
+    total = int(qlens.sum())
+    q = rng.integers(0, 4, size=total, dtype=np.uint8)
+    r = rng.random(total)
+    base = q.copy()
+    m_sub = r < sub
+    base[m_sub] = rng.integers(0, 4, size=int(m_sub.sum()), dtype=np.uint8)
+    cnt = np.ones(total, np.int64)
+    cnt[(r >= sub) & (r < sub + dele)] = 0
+    m_ins = (r >= sub + dele) & (r < sub + dele + ins)
+    cnt[m_ins] = 2
+    t_all = np.repeat(base, cnt)
+    t_all[np.cumsum(cnt)[m_ins] - 1] = rng.integers(0, 4, size=int(m_ins.sum()), dtype=np.uint8)
+    nat = np.add.reduceat(cnt, q_start) if n else np.zeros(0, np.int64)
+    nat_start = np.cumsum(nat) - nat
+    want = np.maximum(nat, 1) if tlens is None else np.asarray(tlens, np.int64)
+    # target k = its first min(nat, want) mutated bases, then random bases up to `want`
+    t_start = np.cumsum(want) - want
+    j = np.arange(int(want.sum())) - np.repeat(t_start, want)
+    src = np.repeat(nat_start, want) + j
+    have = j < np.repeat(nat, want)
+    t = rng.integers(0, 4, size=len(j), dtype=np.uint8)
+    t[have] = t_all[src[have]]
+    pool = np.concatenate([q, t])
+    return pool, q_start, qlens.astype(np.int32), t_start + total, want.astype(np.int32)
+
+
+def synth_hg19_mixture_fast(n, seed, big=6000):
+    """synth_hg19_mixture's size mixture (BASELINE configs[3]: ~59 % of <= 100 cells, ~40 % of <= 1e4, ~1.2 % 500 x 500
+    side extensions, ~0.06 % up to 1000 x 1000, ~0.06 % up to `big` x `big`, all w = -1) drawn and mutated in vectorised
+    form: 1,000,000 tasks in a few seconds.  Returns the batch and w."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    u = rng.random(n)
+    a1, b1 = rng.integers(1, 11, n), rng.integers(1, 11, n)
+    a2 = rng.integers(5, 101, n)
+    b2 = np.clip(a2 + rng.integers(-20, 21, n), 1, 209)
+    b3 = rng.choice(np.array([500, 500, 500, 431, 377]), n)
+    a4, b4 = rng.integers(600, 1001, n), rng.integers(600, 1001, n)
+    a5 = rng.integers(1200, big + 1, n)
+    ql = np.select([u < 0.59, u < 0.99, u < 0.9988, u < 0.9994], [a1, a2, np.full(n, 500), a4], a5)
+    tl = np.select([u < 0.59, u < 0.99, u < 0.9988, u < 0.9994], [b1, b2, b3, b4], a5)
+    return synth_ragged(rng, ql, tlens=tl), -1
+
+
 def synth_mm8_mixture(n, seed, max_len=20000):
     """BASELINE configs[4] shape: lengths log-uniform 200..max_len, one band of
     {64,128,256,512} per task, 5 % of the tasks with a one-sided 1-5 kb indel.  Returns the batch and w[]."""
@@ -140,27 +194,25 @@ def synth_mm8_mixture(n, seed, max_len=20000):
 
 
 def pack_batch(pool, q_off, qlen, t_off, tlen):
-    """Packs every sequence (2-bit codes + N mask) into one uint32 pool; returns (words, q_word, t_word)."""
+    """Packs every sequence (2-bit codes + N mask) into one uint32 pool; returns (words, q_word, t_word)
+    (include/sedef_hip.h: sdf_pack_tasks)."""
+    import ctypes as C
+
     import sedef_amd
     lib = sedef_amd.load_library()
     n = len(qlen)
-    qw = np.array([sedef_amd.packed_words(int(x)) for x in np.unique(qlen)])
-    qmap = dict(zip(np.unique(qlen).tolist(), qw.tolist()))
-    tuniq = np.unique(tlen)
-    tmap = dict(zip(tuniq.tolist(), [sedef_amd.packed_words(int(x)) for x in tuniq]))
-    q_words = np.array([qmap[int(x)] for x in qlen], np.int64)
-    t_words = np.array([tmap[int(x)] for x in tlen], np.int64)
-    offs = np.zeros(2 * n + 1, np.int64)
-    inter = np.empty(2 * n, np.int64)
-    inter[0::2], inter[1::2] = q_words, t_words
-    offs[1:] = np.cumsum(inter)
-    words = np.zeros(int(offs[-1]), np.uint32)
-    base = words.ctypes.data
-    pbase = pool.ctypes.data
-    for k in range(n):
-        lib.sdf_pack_codes(pbase + int(q_off[k]), int(qlen[k]), base + 4 * int(offs[2 * k]))
-        lib.sdf_pack_codes(pbase + int(t_off[k]), int(tlen[k]), base + 4 * int(offs[2 * k + 1]))
-    return words, offs[0:2 * n:2].copy(), offs[1:2 * n:2].copy()
+    pool = np.ascontiguousarray(pool, np.uint8)
+    q_off, t_off = np.ascontiguousarray(q_off, np.int64), np.ascontiguousarray(t_off, np.int64)
+    qlen, tlen = np.ascontiguousarray(qlen, np.int32), np.ascontiguousarray(tlen, np.int32)
+    q_word, t_word = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    lib.sdf_pack_tasks.restype = C.c_size_t
+    lib.sdf_pack_tasks.argtypes = [C.c_void_p] * 5 + [C.c_size_t] + [C.c_void_p] * 3
+    total = lib.sdf_pack_tasks(pool.ctypes.data, q_off.ctypes.data, qlen.ctypes.data, t_off.ctypes.data, tlen.ctypes.data, n,
+                               None, q_word.ctypes.data, t_word.ctypes.data)
+    words = np.zeros(int(total), np.uint32)
+    lib.sdf_pack_tasks(pool.ctypes.data, q_off.ctypes.data, qlen.ctypes.data, t_off.ctypes.data, tlen.ctypes.data, n,
+                       words.ctypes.data, q_word.ctypes.data, t_word.ctypes.data)
+    return words, q_word, t_word
 
 
 def algorithmic_bytes(qlen, tlen, cells, n_cigar):
@@ -224,15 +276,46 @@ def effective_cores():
     return n
 
 
+def batch_cells(qlen, tlen, w):
+    """In-band cells per task (the metric's unit; include/sedef_hip.h: sdf_band_cells)."""
+    import sedef_amd
+    if np.ndim(w) == 0 and int(w) < 0:
+        return qlen.astype(np.int64) * tlen.astype(np.int64)
+    ws = np.broadcast_to(np.asarray(w, np.int64), qlen.shape)
+    key = np.stack([qlen.astype(np.int64), tlen.astype(np.int64), ws])
+    uniq, inv = np.unique(key, axis=1, return_inverse=True)
+    cu = np.array([sedef_amd.band_cells(int(a), int(b), int(c)) for a, b, c in uniq.T], np.int64)
+    return cu[inv.reshape(-1)]
+
+
+def encoding_split():
+    """Per-encoding instruction counts of the steady row of the dominant kernel, from the committed ISA summary
+    (profiles/pair_kernel_isa.json, made by profiles/isa_split.py from the device assembly of the built library)."""
+    p = os.path.join(ROOT, "profiles", "pair_kernel_isa.json")
+    if not os.path.exists(p):
+        return None
+    d = json.load(open(p))
+    row = d.get("steady_row") or {}
+    return {"valu_per_row_of_two_tasks": row.get("valu"), "by_encoding": row.get("by_encoding"),
+            "source": "committed profile: profiles/pair_kernel_isa.json (profiles/isa_split.py on the device assembly)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tasks", type=int, default=100000, help="DP tasks per GPU per step")
+    ap.add_argument("--workload", choices=["configs1", "hg19mix"], default="configs1",
+                    help="configs1: BASELINE configs[1], the metric's headline (default); hg19mix: the hg19-shaped task "
+                         "mixture of BASELINE configs[3]")
+    ap.add_argument("--tasks", type=int, default=None, help="DP tasks per step: per GPU (weak scaling, default) or in the "
+                                                            "whole batch (--strong); default 100000 / 1000000 by workload")
+    ap.add_argument("--strong", action="store_true", help="one batch of --tasks tasks sharded over the ranks by cells "
+                                                          "(shard_tasks) instead of one batch per rank")
     ap.add_argument("--qlen", type=int, default=1000)
     ap.add_argument("--band", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie-pass", action="store_true", help="skip the untimed pass that measures value_incl_pcie")
     ap.add_argument("--workspace-gib", type=float, default=48.0)
     args = ap.parse_args()
 
@@ -240,7 +323,7 @@ def main():
     import torch.distributed as dist
 
     import sedef_amd
-    from sedef_amd.dist import ResultGather, allgatherv_results
+    from sedef_amd.dist import ResultGatherV, shard_tasks, task_checksums
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,60 +344,79 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n, w = args.tasks, args.band
-    pool, q_off, qlen, t_off, tlen = synth_batch(n, args.qlen, seed=42 + rank)
+    # ---- the workload: every rank's shard of the batch ----
+    hg19 = args.workload == "hg19mix"
+    n_arg = args.tasks if args.tasks else (1000000 if hg19 else 100000)
+    n_batch = n_arg if args.strong else n_arg  # tasks generated by this rank
+    seed = (404 if hg19 else 42) + (0 if args.strong else rank)  # --strong: the same batch on every rank
+    if hg19:
+        (pool, q_off, qlen, t_off, tlen), w = synth_hg19_mixture_fast(n_batch, seed)
+    else:
+        (pool, q_off, qlen, t_off, tlen), w = synth_batch(n_batch, args.qlen, seed=seed), args.band
+    cells_task = batch_cells(qlen, tlen, w)
+    whole = None
+    if args.strong and world > 1:  # LPT by cells; every rank computes the same partition
+        whole = (pool, q_off, qlen, t_off, tlen, cells_task)
+        shards = shard_tasks(cells_task, world)
+        mine = shards[rank]
+        q_off, qlen, t_off, tlen, cells_task = q_off[mine], qlen[mine], t_off[mine], tlen[mine], cells_task[mine]
+    n = len(qlen)
     words, q_word, t_word = pack_batch(pool, q_off, qlen, t_off, tlen)
     tasks = np.zeros(n, sedef_amd.TASK_DTYPE)
     tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"] = q_word, t_word, qlen, tlen
     tasks["w"], tasks["zdrop"], tasks["flag"] = w, -1, 0
-    cells = np.array([sedef_amd.band_cells(int(a), int(b), w) for a, b in
-                      zip(*np.unique(np.stack([qlen, tlen]), axis=1))])
-    keys = {(int(a), int(b)): int(c) for (a, b), c in
-            zip(np.unique(np.stack([qlen, tlen]), axis=1).T, cells)}
-    cells_task = np.array([keys[(int(a), int(b))] for a, b in zip(qlen, tlen)], np.int64)
     cells_rank = int(cells_task.sum())
 
     eng = sedef_amd.Extz2Engine(local, int(args.workspace_gib * (1 << 30)))
     d_pool = torch.from_numpy(words.view(np.int32)).to(dev)
     cig_cap = int((qlen.astype(np.int64) + tlen + 2).sum())
-    cig_cap = min(cig_cap, 256 * n)  # ~50 runs per task at 10 % divergence; overflow is an error
-    # N > 1: two sets of output buffers in rotation -- the all-gather of step i's records and CIGAR words (RCCL, on the
-    # communicator's stream) runs under the DP of step i+1, which writes the other set; every gather is waited for
-    # inside the timed region.  The CIGAR words travel with a fixed capacity of 64 per task (~48 are used).
-    nsets = 2 if world > 1 else 1
+    if not hg19:
+        cig_cap = min(cig_cap, 256 * n)  # ~50 runs per task at 10 % divergence; overflow is an error
+    # Two sets of output buffers in rotation: the result D2H of step i (and, at N > 1, the all-gatherv of its records and
+    # CIGAR words: RCCL, on the communicator's stream) runs under the DP of step i+1, which writes the other set; every
+    # copy and every gather is waited for inside the timed region.
+    nsets = 2
     d_outs = [torch.empty(n * 16, dtype=torch.int32, device=dev) for _ in range(nsets)]
     d_cigs = [torch.empty(cig_cap, dtype=torch.int32, device=dev) for _ in range(nsets)]
-    d_out, d_cig = d_outs[0], d_cigs[0]
+    h_outs = [torch.empty(n * 16, dtype=torch.int32).pin_memory() for _ in range(nsets)]
+    h_cigs = [torch.empty(cig_cap, dtype=torch.int32).pin_memory() for _ in range(nsets)]
     want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
-    stream = torch.cuda.current_stream().cuda_stream
+    # The engine works on a torch stream of its own, entered as the current stream: a gather's wait() then orders THIS
+    # stream (and with it everything the engine launches: its internal streams fork from it) behind the collective that
+    # last read the buffer set the step is about to overwrite.
+    estream = torch.cuda.Stream(device=dev)
+    cstream = torch.cuda.Stream(device=dev)  # result D2H
+    copy_done = [None] * nsets
 
     gathers = []
     if world > 1:
         gdev = torch.device("cpu") if debug_one_gpu else dev
-        gathers = [ResultGather(n * 16, min(64 * n, cig_cap), gdev, torch.int32) for _ in range(nsets)]
+        gathers = [ResultGatherV(gdev, torch.int32) for _ in range(nsets)]
     step_no = [0]
-    sync_gathered = [None, None, None]
+    last_used = [0] * nsets
 
     def step():
         b = step_no[0] % nsets
         step_no[0] += 1
-        if gathers:
-            gathers[b].wait()  # the gather that last read this buffer set
-        used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_outs[b].data_ptr(), d_cigs[b].data_ptr(),
-                                      cig_cap, want=want, stream=stream)
-        if gathers:  # all-gather of result records + CIGAR words over RCCL, asynchronous
-            try:
+        with torch.cuda.stream(estream):
+            if gathers:
+                gathers[b].wait()  # the gather that last read this buffer set
+            if copy_done[b] is not None:
+                estream.wait_event(copy_done[b])  # ... and the D2H that did
+            used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_outs[b].data_ptr(), d_cigs[b].data_ptr(),
+                                          cig_cap, want=want, stream=estream.cuda_stream)
+            # (the call returns after its stream has drained: the results are complete here)
+            if gathers:  # all-gatherv of result records + CIGAR words, asynchronous
                 if debug_one_gpu:
-                    gathers[b].start(d_outs[b].cpu(), d_cigs[b].cpu(), used)
+                    gathers[b].start(d_outs[b].cpu(), d_cigs[b][:used].cpu(), used)
                 else:
                     gathers[b].start(d_outs[b], d_cigs[b], used)
-            except (RuntimeError, ValueError) as e:  # (same on every rank) -> the synchronous gather from here on
-                if rank == 0:
-                    print("asynchronous gather unavailable (%s): synchronous all-gather" % e, file=sys.stderr)
-                del gathers[:]
-        if world > 1 and not gathers:
-            src = (d_outs[b].cpu(), d_cigs[b].cpu()) if debug_one_gpu else (d_outs[b], d_cigs[b])
-            sync_gathered[:] = allgatherv_results(src[0], src[1], used)
+        with torch.cuda.stream(cstream):  # result D2H of this rank's shard (pinned), asynchronous
+            h_outs[b].copy_(d_outs[b], non_blocking=True)
+            h_cigs[b][:used].copy_(d_cigs[b][:used], non_blocking=True)
+            copy_done[b] = torch.cuda.Event()
+            copy_done[b].record(cstream)
+        last_used[b] = used
         return used
 
     def sync():
@@ -352,14 +454,33 @@ def main():
     else:
         cells_all = cells_rank
 
-    if gathers:  # every rank holds every rank's results: check this rank's own slice of the last gather
-        lb = (step_no[0] - 1) % nsets
-        ra, ca, cnts = gathers[lb].result()
-        assert int(cnts[rank, 0]) == n * 16 and int(cnts[rank, 1]) == used
-        assert torch.equal(ra[rank].cpu(), d_outs[lb].cpu()) and torch.equal(ca[rank][:used].cpu(), d_cigs[lb][:used].cpu())
+    lb = (step_no[0] - 1) % nsets
+    res = h_outs[lb].numpy().view(sedef_amd.RESULT_DTYPE)
+    assert int(res["n_cigar"].astype(np.int64).sum()) == used  # what came over PCIe is the whole result
+    union_check = None
+    if gathers:  # every rank holds every rank's results: this rank's own part of the last gather is what it computed
+        pr, pc = gathers[lb].part(rank)
+        assert torch.equal(pr.cpu(), h_outs[lb]) and torch.equal(pc.cpu(), h_cigs[lb][:used])
+        if whole is not None and rank == 0:
+            # --strong: the union of the shards against ONE GPU aligning the whole batch (untimed)
+            wpool, wq_off, wqlen, wt_off, wtlen, _ = whole
+            ww, wqw, wtw = pack_batch(wpool, wq_off, wqlen, wt_off, wtlen)
+            wt = np.zeros(len(wqlen), sedef_amd.TASK_DTYPE)
+            wt["q_off"], wt["t_off"], wt["qlen"], wt["tlen"], wt["w"], wt["zdrop"] = wqw, wtw, wqlen, wtlen, w, -1
+            wd_pool = torch.from_numpy(ww.view(np.int32)).to(dev)
+            wcap = int((wqlen.astype(np.int64) + wtlen + 2).sum())
+            wd_out = torch.empty(len(wqlen) * 16, dtype=torch.int32, device=dev)
+            wd_cig = torch.empty(wcap, dtype=torch.int32, device=dev)
+            wused = eng.align_batch_device(wt, wd_pool.data_ptr(), wd_out.data_ptr(), wd_cig.data_ptr(), wcap, want=want)
+            single = task_checksums(wd_out.cpu().numpy(), wd_cig[:wused].cpu().numpy())
+            union = np.zeros(len(wqlen), np.uint64)
+            for r in range(world):
+                pr, pc = gathers[lb].part(r)
+                union[shards[r]] = task_checksums(pr.cpu().numpy(), pc.cpu().numpy())
+            assert np.array_equal(union, single), "union of the shards differs from the single-GPU run"
+            union_check = "CIGAR+score checksum of all %d tasks: union of %d shards == single-GPU run" % (len(wqlen), world)
+            del wd_pool, wd_out, wd_cig
     if rank == 0:
-        res = d_out.cpu().numpy().view(sedef_amd.RESULT_DTYPE)
-        assert int(res["n_cigar"].astype(np.int64).sum()) == used
         alg = algorithmic_bytes(qlen, tlen, cells_task, res["n_cigar"])
         # Roofline of the dominant kernel.  The timed steps above run the batch as a pipeline of chunks whose DP
         # launches overlap each other and the traceback, so a launch's own duration is taken from one extra,
@@ -368,7 +489,8 @@ def main():
         # summary (profiles/) is of `SDF_PIPELINE=0 python bench.py ...`, the same launch.
         iso_ms, iso_launches = dp_ms / max(args.steps, 1), max(launches // max(args.steps, 1), 1)
         roof_mode = "pipelined launches (union of the DP intervals)"
-        if world == 1:
+        headline = world == 1 and not hg19
+        if headline:
             old = os.environ.get("SDF_PIPELINE")
             os.environ["SDF_PIPELINE"] = "0"
             try:
@@ -379,8 +501,8 @@ def main():
                 else:
                     os.environ["SDF_PIPELINE"] = old
             for _ in range(2):  # warm-up + measured
-                iso.align_batch_device(tasks, d_pool.data_ptr(), d_out.data_ptr(), d_cig.data_ptr(), cig_cap,
-                                       want=want, stream=stream)
+                iso.align_batch_device(tasks, d_pool.data_ptr(), d_outs[0].data_ptr(), d_cigs[0].data_ptr(), cig_cap,
+                                       want=want, stream=estream.cuda_stream)
             iso_ms, iso_launches = iso.last_ms(0), max(iso.last_launches(), 1)
             roof_mode = "one isolated DP launch of the whole batch (SDF_PIPELINE=0 pass, untimed)"
             del iso
@@ -390,39 +512,76 @@ def main():
         traffic = None
         valu = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp) and n == 100000 and w == 128 and args.qlen == 1000:
-            # measured once with rocprofv3 PMC passes on this exact workload and launch (profiles/README.md)
+        if os.path.exists(tp) and headline and n == 100000 and w == 128 and args.qlen == 1000:
+            # NOT measured in this run: read from the committed rocprofv3 PMC passes of this exact workload and launch
+            # (profiles/README.md, profiles/collect.sh)
             pmc = json.load(open(tp))
             traffic = pmc.get("bytes_per_step") / iso_launches
             if pmc.get("valu_insts_per_step"):
-                # what actually bounds the launch: VALU issue.  A SIMD issues one wavefront VALU instruction per 4
-                # cycles at best (64 lanes over 16 ALUs); counted instructions / (SIMDs x launch cycles / 4)
+                # What actually bounds the launch: VALU issue.  Counted wavefront VALU instructions over what the SIMDs can
+                # issue in the launch's live-measured duration, against BOTH rates: one per 2 cycles (MI355X_MICROARCH.md:
+                # wave64 on a SIMD-32) and one per 4.2 cycles (the measured rate of the VOP3P / VOP3 / DPP encodings
+                # that make up the row, profiles/r01_ubench_issue_rates.txt; VOP2 issues at 2.5)
                 props = torch.cuda.get_device_properties(local)
                 simds = props.multi_processor_count * 4
                 mhz = (getattr(props, "clock_rate", 0) or 2400000) / 1e3  # (2.4 GHz: MI355X peak engine clock)
-                issue_peak = simds * mhz * 1e6 / 4.0 * avg_launch_s * iso_launches
+                cycles = simds * mhz * 1e6 * avg_launch_s * iso_launches
                 valu = {"insts_per_step": pmc["valu_insts_per_step"], "simds": simds, "clock_mhz": round(mhz, 1),
-                        "frac_of_issue_peak": round(pmc["valu_insts_per_step"] / issue_peak, 4),
-                        "source": pmc.get("valu_source")}
+                        "frac_of_issue_peak_2cyc": round(pmc["valu_insts_per_step"] / (cycles / 2.0), 4),
+                        "frac_of_issue_peak_4p2cyc_measured_vop3p": round(pmc["valu_insts_per_step"] / (cycles / 4.2), 4),
+                        "steady_row_by_encoding": encoding_split(),
+                        "source": "committed profile: " + str(pmc.get("valu_source"))}
         value = cells_all * args.steps / dt / 1e9
+        # End to end over PCIe (never `value`): H2D of the packed sequences, the batch, D2H of the results, back to back
+        # without overlap, untimed extra passes (include/sedef_hip.h: sdf_extz2_batch is this plus packing on the host)
+        incl_pcie = None
+        if world == 1 and not args.no_pcie_pass:
+            h_pool = torch.from_numpy(words.view(np.int32)).pin_memory()
+            d_pool2 = torch.empty_like(d_pool)
+            times = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                tp0 = time.perf_counter()
+                with torch.cuda.stream(estream):
+                    d_pool2.copy_(h_pool, non_blocking=True)
+                    estream.synchronize()
+                    u2 = eng.align_batch_device(tasks, d_pool2.data_ptr(), d_outs[0].data_ptr(), d_cigs[0].data_ptr(),
+                                                cig_cap, want=want, stream=estream.cuda_stream)
+                    h_outs[0].copy_(d_outs[0], non_blocking=True)
+                    h_cigs[0][:u2].copy_(d_cigs[0][:u2], non_blocking=True)
+                    estream.synchronize()
+                times.append(time.perf_counter() - tp0)
+            incl_pcie = round(cells_rank / min(times[1:]) / 1e9, 3)
+        if hg19:
+            wl = ("configs[3]: hg19-shaped task mixture, %d DP tasks %s, all w=-1 (59 %% <=100 cells, 40 %% <=1e4, 1.2 %% "
+                  "500x500, 0.06 %% <=1000^2, 0.06 %% up to 6000^2), affine gap 5/-4/40/1, CIGAR+score+counts"
+                  % (n_arg, "in one batch sharded by cells" if args.strong else "per GPU"))
+        else:
+            wl = ("configs[1]: %d synthetic %dx~%d DP tasks %s, band=%d, affine gap 5/-4/40/1, CIGAR+score+counts"
+                  % (n_arg, args.qlen, args.qlen, "in one batch sharded by cells" if args.strong else "per GPU", w))
         line = {
             "metric": "aligned DP cells/sec (Gcell/s) on `sedef align` batch",
             "value": round(value, 3), "unit": "Gcell/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "i8",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic %dx~%d DP tasks per GPU, band=%d, "
-                                   "affine gap 5/-4/40/1, CIGAR+score+counts" % (n, args.qlen, args.qlen, w),
-                       "tasks_per_gpu": n, "band": w, "cells_per_step_per_gpu": cells_rank,
-                       "parallelism": "task-sharded x%d + all-gatherv of result records" % world},
-            "kernel_ms_per_step": {"pipeline_chunks": launches / args.steps,
+            "value_incl_pcie": incl_pcie,
+            "timed_region": "planning + DP + traceback + CIGAR compaction + result D2H (pinned, double-buffered under the "
+                            "next step)" + (" + all-gatherv of records and CIGARs" if world > 1 else ""),
+            "config": {"workload": wl, "tasks_this_rank": n, "band": int(w) if np.ndim(w) == 0 else "mixed",
+                       "cells_per_step_this_rank": cells_rank, "cells_per_step_all_ranks": cells_all,
+                       "parallelism": "task-sharded x%d + all-gatherv of result records" % world,
+                       "union_check": union_check},
+            "kernel_ms_per_step": {"dp_launches": launches / args.steps,
                                    "dp": round(dp_ms / args.steps, 3), "traceback": round(tb_ms / args.steps, 3),
                                    "compact": round(cp_ms / args.steps, 3),
                                    "host_planning": round(plan_ms / args.steps, 3),
                                    "host_call_total": round(call_ms / args.steps, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "extz2_pair_kernel<3> (extz2 DP)", "measured_on": roof_mode,
+                         "traffic_source": "committed profile (profiles/hbm_traffic.json), not measured in this run" if traffic else None,
+                         "kernel": "extz2_pair_kernel<3> (extz2 DP)" if not hg19 else "all DP launches of the mixture",
+                         "measured_on": roof_mode,
                          "launches": iso_launches, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "valu_issue": valu},
         }
@@ -430,6 +589,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pool, q_off, qlen, t_off, tlen, cells_task, w)
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

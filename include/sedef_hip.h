@@ -122,6 +122,11 @@ const char *sdf_last_error(const sdf_ctx *ctx);
  *   ceil(len/32) words of N mask      (bit b%32 of word b/32 set <=> code >= 4). */
 size_t sdf_packed_words(int32_t len);
 void sdf_pack_codes(const uint8_t *codes, int32_t len, uint32_t *out);
+/* Packs both sequences of n tasks (byte offsets into `codes`, as sdf_extz2_batch takes them) back to back into `out`
+ * and writes each task's word offsets, as sdf_extz2_batch_device takes them.  `out` holds
+ * sum(sdf_packed_words(qlen) + sdf_packed_words(tlen)) words.  Returns that number. */
+size_t sdf_pack_tasks(const uint8_t *codes, const int64_t *q_off, const int32_t *qlen, const int64_t *t_off,
+                      const int32_t *tlen, size_t n, uint32_t *out, int64_t *q_word, int64_t *t_word);
 
 /* ---- batched DP ---------------------------------------------------------------------------
  * Host-buffer form.  seq_pool holds byte codes; out[n]; cigar_pool[cigar_cap] words receives

@@ -183,6 +183,23 @@ extern "C" void sdf_pack_codes(const uint8_t *codes, int32_t len, uint32_t *out)
   }
 }
 
+extern "C" size_t sdf_pack_tasks(const uint8_t *codes, const int64_t *q_off, const int32_t *qlen, const int64_t *t_off,
+                                 const int32_t *tlen, size_t n, uint32_t *out, int64_t *q_word, int64_t *t_word) {
+  size_t words = 0;
+  for (size_t k = 0; k < n; ++k) {
+    q_word[k] = (int64_t)words;
+    words += sdf_packed_words(qlen[k]);
+    t_word[k] = (int64_t)words;
+    words += sdf_packed_words(tlen[k]);
+  }
+  if (out)
+    for (size_t k = 0; k < n; ++k) {
+      if (qlen[k] > 0) sdf_pack_codes(codes + q_off[k], qlen[k], out + q_word[k]);
+      if (tlen[k] > 0) sdf_pack_codes(codes + t_off[k], tlen[k], out + t_word[k]);
+    }
+  return words;
+}
+
 extern "C" int64_t sdf_band_cells(int32_t qlen, int32_t tlen, int32_t w) {
   if (qlen <= 0 || tlen <= 0) return 0;
   if (w < 0) w = tlen > qlen ? tlen : qlen;

@@ -6,94 +6,148 @@ across ranks without any data-path collective.  The one exchange step is the all
 per-task result records and CIGAR words after the DP (RCCL over xGMI when the backend is nccl):
 payload ~0.3 kB per task, latency-bound, one hop on the fully connected mesh.
 """
+import heapq
+
 import numpy as np
 
+REC_WORDS = 16  # int32 words of one sdf_result record (include/sedef_hip.h)
 
-def shard_tasks(cost, world):
-    """Longest-processing-time-first partition of tasks by DP cells.
 
-    cost: per-task cell counts.  Returns a list of `world` index arrays (each sorted ascending)
-    with near-equal total cost; every task appears in exactly one shard."""
+def shard_tasks(cost, world, head=None):
+    """Partition of tasks by DP cells: longest-processing-time-first for the heavy head, then the tail (cheap tasks,
+    the bulk of a batch) is cut into contiguous runs of its cost-sorted order that fill every rank up to the mean.
+
+    cost: per-task cell counts.  Returns a list of `world` index arrays (each sorted ascending) with near-equal total
+    cost -- within the cost of one head task of the mean; every task appears in exactly one shard.  O(n log n) in
+    numpy plus O(head log world) in Python (head = 2048 tasks per rank unless given)."""
     cost = np.asarray(cost, dtype=np.int64)
+    n = len(cost)
+    if world <= 1:
+        return [np.arange(n)]
     order = np.argsort(-cost, kind="stable")
-    load = np.zeros(world, np.int64)
-    owner = np.empty(len(cost), np.int32)
-    # chunked greedy: exact LPT for the heavy head, round-robin by current load for the rest
-    for i in order:
-        r = int(np.argmin(load))
+    nh = min(n, 2048 * world if head is None else int(head))
+    owner = np.empty(n, np.int32)
+    load = [(0, r) for r in range(world)]
+    heapq.heapify(load)
+    for i in order[:nh].tolist():  # exact LPT on the tasks that can unbalance a shard
+        l, r = heapq.heappop(load)
         owner[i] = r
-        load[r] += cost[i]
+        heapq.heappush(load, (l + int(cost[i]), r))
+    loads = np.zeros(world, np.int64)
+    for l, r in load:
+        loads[r] = l
+    tail = order[nh:]
+    if len(tail):
+        # every rank is filled up to the common mean: rank r takes the tail tasks whose running cost falls into its
+        # share [cum_need[r-1], cum_need[r]); ranks already above the mean take none
+        tc = cost[tail]
+        total = loads.sum() + tc.sum()
+        need = np.maximum(total / world - loads, 0.0)
+        need *= tc.sum() / max(need.sum(), 1.0)
+        edges = np.cumsum(need)
+        run = np.cumsum(tc) - tc  # cost of the tail before each task
+        owner[tail] = np.minimum(np.searchsorted(edges, run, side="right"), world - 1).astype(np.int32)
     return [np.flatnonzero(owner == r) for r in range(world)]
 
 
 def allgatherv_results(records, cigars, used, group=None):
-    """All-gather the variable-length results of every rank.
-
-    records: int32 tensor [n*16] (sdf_result records of this rank), cigars: int32 tensor holding
-    `used` CIGAR words (the rest is padding).  Returns (records_all [world, n_max*16],
-    cigars_all [world, c_max], counts [world, 2] = (n_records*16, cigar_words)) on every rank."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    dev = records.device
-    mine = torch.tensor([records.numel(), int(used)], dtype=torch.int64, device=dev)
-    counts = torch.empty(world * 2, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, mine, group=group)
-    counts = counts.view(world, 2)
-    n_max, c_max = int(counts[:, 0].max().item()), max(int(counts[:, 1].max().item()), 1)
-    rec_pad = records if records.numel() == n_max else \
-        torch.cat([records, records.new_zeros(n_max - records.numel())])
-    cig = cigars[:min(int(used), cigars.numel())]
-    cig_pad = cig if cig.numel() == c_max else torch.cat([cig, cig.new_zeros(c_max - cig.numel())])
-    rec_all = torch.empty(world * n_max, dtype=records.dtype, device=dev)
-    cig_all = torch.empty(world * c_max, dtype=cigars.dtype, device=dev)
-    dist.all_gather_into_tensor(rec_all, rec_pad.contiguous(), group=group)
-    dist.all_gather_into_tensor(cig_all, cig_pad.contiguous(), group=group)
-    return rec_all.view(world, n_max), cig_all.view(world, c_max), counts
+    """Blocking all-gatherv of the results of every rank (see ResultGatherV).  Returns (records_all, cigars_all,
+    counts [world, 2] = (record words, CIGAR words) per rank); rank r's part starts at counts[:r].sum(0)."""
+    g = ResultGatherV(records.device, records.dtype, group=group)
+    g.start(records, cigars, used)
+    return g.result()
 
 
-class ResultGather:
-    """All-gather of one step's results into preallocated buffers, asynchronously: `start` enqueues the three
-    collectives (counts, result records, CIGAR words up to a fixed capacity) and returns; the caller computes the
-    next step into ANOTHER set of buffers and calls `wait` before it reuses this set (or reads `result`).  Over nccl
-    (RCCL) the collectives run on the communicator's stream under the next step's kernels; nothing blocks the host.
+class ResultGatherV:
+    """All-gatherv of one step's result records and CIGAR words: every rank ends with every rank's results, back to
+    back in rank order, exactly `counts[r]` words from rank r (no padding travels).
 
-    Every rank passes the same `rec_words` (records are fixed-size) and `cig_cap` (words gathered per rank: the
-    valid prefix is `counts[r, 1]`, the rest is padding)."""
+    `start` exchanges the counts (one small all-gather), then enqueues one broadcast per root and payload on the exact
+    sizes -- RCCL has no native gatherv; on the fully connected xGMI mesh the `world` broadcasts of a group are
+    one-hop transfers running side by side -- and returns; the caller computes the next step into ANOTHER set of
+    buffers and calls `wait` before it reuses this set or reads `result`.  With the nccl backend `wait` makes the
+    CURRENT torch stream wait for the collectives: the caller must launch the work that reuses the buffers on that
+    stream (bench.py runs the engine on a torch stream for this reason).  Buffers grow on demand and are reused."""
 
-    def __init__(self, rec_words, cig_cap, device, dtype, group=None):
+    def __init__(self, device, dtype, group=None):
         import torch
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
-        self.rec_words, self.cig_cap = int(rec_words), int(cig_cap)
+        self.rank = dist.get_rank(group)
+        self.device, self.dtype = device, dtype
         self.mine = torch.zeros(2, dtype=torch.int64, device=device)
-        self.counts = torch.zeros(self.world * 2, dtype=torch.int64, device=device)
-        self.recs = torch.empty(self.world * self.rec_words, dtype=dtype, device=device)
-        self.cig = torch.empty(self.world * self.cig_cap, dtype=dtype, device=device)
+        self.counts_dev = torch.zeros(self.world * 2, dtype=torch.int64, device=device)
+        self.recs = torch.empty(0, dtype=dtype, device=device)
+        self.cig = torch.empty(0, dtype=dtype, device=device)
+        self.counts = None
         self.handles = []
+        self.keep = None
 
     def start(self, records, cigars, used):
+        import torch
         import torch.distributed as dist
-        if records.numel() != self.rec_words or int(used) > self.cig_cap or cigars.numel() < self.cig_cap:
-            raise ValueError("ResultGather: %d record words / %d CIGAR words do not fit (%d / %d)" %
-                             (records.numel(), int(used), self.rec_words, self.cig_cap))
+        used = int(used)
+        if used > cigars.numel():
+            raise ValueError("ResultGatherV: %d CIGAR words used, %d in the buffer" % (used, cigars.numel()))
         self.wait()
         self.mine[0] = records.numel()
-        self.mine[1] = int(used)
-        self.handles = [
-            dist.all_gather_into_tensor(self.counts, self.mine, group=self.group, async_op=True),
-            dist.all_gather_into_tensor(self.recs, records, group=self.group, async_op=True),
-            dist.all_gather_into_tensor(self.cig, cigars[:self.cig_cap], group=self.group, async_op=True),
-        ]
+        self.mine[1] = used
+        dist.all_gather_into_tensor(self.counts_dev, self.mine, group=self.group)
+        counts = self.counts_dev.view(self.world, 2).cpu()
+        self.counts = counts
+        rec_off = np.concatenate([[0], np.cumsum(counts[:, 0].numpy())])
+        cig_off = np.concatenate([[0], np.cumsum(counts[:, 1].numpy())])
+        if self.recs.numel() < rec_off[-1]:
+            self.recs = torch.empty(int(rec_off[-1] * 1.25) + 16, dtype=self.dtype, device=self.device)
+        if self.cig.numel() < cig_off[-1]:
+            self.cig = torch.empty(int(cig_off[-1] * 1.25) + 16, dtype=self.dtype, device=self.device)
+        self.rec_off, self.cig_off = rec_off, cig_off
+        # own part: a local copy; the other parts: broadcasts from their owners into the exact ranges
+        self.recs[rec_off[self.rank]:rec_off[self.rank + 1]].copy_(records)
+        self.cig[cig_off[self.rank]:cig_off[self.rank + 1]].copy_(cigars[:used])
+        self.keep = (records, cigars)  # the sources must stay alive until the collectives are done
+        self.handles = []
+        for r in range(self.world):
+            src = dist.get_global_rank(self.group, r) if self.group is not None else r
+            for buf, off in ((self.recs, rec_off), (self.cig, cig_off)):
+                if off[r + 1] > off[r]:
+                    self.handles.append(dist.broadcast(buf[off[r]:off[r + 1]], src=src, group=self.group, async_op=True))
 
     def wait(self):
         for h in self.handles:
             h.wait()
         self.handles = []
+        self.keep = None
 
     def result(self):
-        """(records [world, rec_words], cigars [world, cig_cap], counts [world, 2]) of the last `start`."""
+        """(records of all ranks back to back, CIGAR words back to back, counts [world, 2]) of the last `start`."""
         self.wait()
-        return (self.recs.view(self.world, self.rec_words), self.cig.view(self.world, self.cig_cap),
-                self.counts.view(self.world, 2))
+        return self.recs[:int(self.rec_off[-1])], self.cig[:int(self.cig_off[-1])], self.counts
+
+    def part(self, r):
+        """Rank r's (records, CIGAR words) of the last `start`."""
+        self.wait()
+        return (self.recs[int(self.rec_off[r]):int(self.rec_off[r + 1])],
+                self.cig[int(self.cig_off[r]):int(self.cig_off[r + 1])])
+
+
+def task_checksums(records, cigars):
+    """One 64-bit checksum per task over (score, n_cigar, CIGAR words): records = int32 array [n, 16] in sdf_result
+    layout (cigar_off = words 10..11, little endian), cigars = the rank's CIGAR pool.  Order independent per task, so
+    the union of the shards can be compared with a single-GPU run of the whole batch."""
+    rec = np.ascontiguousarray(records, dtype=np.int32).reshape(-1, REC_WORDS)
+    cig = np.ascontiguousarray(cigars, dtype=np.int32).view(np.uint32).astype(np.uint64)
+    n = len(rec)
+    ncig = rec[:, 9].astype(np.int64)
+    off = rec[:, 10:12].copy().view(np.int64).reshape(-1)
+    h = (rec[:, 0].astype(np.int64).view(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ ncig.view(np.uint64)
+    if n and ncig.sum():
+        # position-weighted sum of every task's words: word j of the task times an odd multiplier of j + 1
+        idx = np.repeat(off, ncig) + (np.arange(int(ncig.sum())) - np.repeat(np.cumsum(ncig) - ncig, ncig))
+        j = (np.arange(int(ncig.sum())) - np.repeat(np.cumsum(ncig) - ncig, ncig)).astype(np.uint64)
+        w = cig[idx] * (np.uint64(2) * j + np.uint64(0x100000001B3))
+        acc = np.zeros(n, np.uint64)
+        np.add.at(acc, np.repeat(np.arange(n), ncig), w)
+        h ^= acc * np.uint64(0xC2B2AE3D27D4EB4F)
+    return h

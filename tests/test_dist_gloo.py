@@ -1,6 +1,8 @@
-"""CPU, world_size 2 over gloo: task sharding and the all-gatherv of result records."""
+"""CPU, world_size 2 over gloo: task sharding, the all-gatherv of result records, and the strong-scaling flow of
+bench.py (shard -> align -> gatherv -> union check) end to end with a stand-in for the engine."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -14,110 +16,139 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
-    import torch
-    import torch.distributed as dist
+def _spawn(fn, *args):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(fn, args=(2, port, out) + args, nprocs=2, join=True)
+    assert out.get(0) is True and out.get(1) is True, dict(out)
 
-    from sedef_amd.dist import allgatherv_results, shard_tasks
+
+def _init(rank, world, port):
+    import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        rng = np.random.default_rng(5)
-        cost = rng.integers(1, 10 ** 6, size=1001)
-        shards = shard_tasks(cost, world)
-        mine = shards[rank]
-        # fake per-task results: 16 int32 per record, record k tagged with its global task id,
-        # and a CIGAR pool of (task id % 7) words per task
-        rec = np.zeros((len(mine), 16), np.int32)
-        rec[:, 0] = mine
-        ncig = mine % 7
-        rec[:, 9] = ncig
-        cig = np.concatenate([np.full(n, t, np.int32) for t, n in zip(mine, ncig)] + [np.zeros(0, np.int32)])
-        pad = np.concatenate([cig, np.full(13, -1, np.int32)])  # pool larger than `used`
-        ra, ca, counts = allgatherv_results(torch.from_numpy(rec.reshape(-1)), torch.from_numpy(pad), len(cig))
-        ok = True
-        seen = []
-        for r in range(world):
-            n = int(counts[r, 0]) // 16
-            recs = ra[r][: n * 16].view(n, 16).numpy()
-            ok &= np.array_equal(recs[:, 0], shards[r])
-            words = ca[r][: int(counts[r, 1])].numpy()
-            exp = np.concatenate([np.full(t % 7, t, np.int32) for t in shards[r]] + [np.zeros(0, np.int32)])
-            ok &= np.array_equal(words, exp)
-            seen.append(recs[:, 0])
-        ok &= np.array_equal(np.sort(np.concatenate(seen)), np.arange(len(cost)))
-        out[rank] = bool(ok)
-    finally:
-        dist.destroy_process_group()
+    return dist
 
 
-def test_shard_is_a_balanced_partition():
+def _fake_results(ids):
+    """Stand-in for the engine: per task 16 int32 (score = 3 * id, n_cigar = id % 7, cigar_off) + its CIGAR words."""
+    rec = np.zeros((len(ids), 16), np.int32)
+    rec[:, 0] = 3 * ids
+    ncig = (ids % 7).astype(np.int64)
+    rec[:, 9] = ncig
+    off = np.cumsum(ncig) - ncig
+    rec[:, 10:12] = off.astype(np.int64).view(np.int32).reshape(-1, 2)
+    cig = np.concatenate([np.arange(n, dtype=np.int32) + 16 * t for t, n in zip(ids, ncig)] + [np.zeros(0, np.int32)])
+    return rec, cig
+
+
+def test_shard_is_a_balanced_partition_and_fast():
     from sedef_amd.dist import shard_tasks
     rng = np.random.default_rng(1)
     cost = np.concatenate([rng.integers(1, 100, 5000), rng.integers(10 ** 5, 10 ** 8, 20)])
     for world in (1, 2, 4, 8):
         sh = shard_tasks(cost, world)
-        allidx = np.sort(np.concatenate(sh))
-        assert np.array_equal(allidx, np.arange(len(cost)))
+        assert np.array_equal(np.sort(np.concatenate(sh)), np.arange(len(cost)))
         loads = np.array([cost[s].sum() for s in sh], dtype=np.float64)
         assert loads.max() <= loads.mean() + cost.max()
+    # the hg19-shaped mixture at the north star's batch size: 1,000,000 tasks, eight ranks, well under 50 ms each
+    u = rng.random(1000000)
+    cost = np.where(u < 0.59, rng.integers(1, 100, len(u)), np.where(u < 0.99, rng.integers(25, 10000, len(u)),
+                    np.where(u < 0.9994, 250000, rng.integers(1200, 6000, len(u)) ** 2)))
+    t0 = time.perf_counter()
+    sh = shard_tasks(cost, 8)
+    dt = time.perf_counter() - t0
+    loads = np.array([cost[s].sum() for s in sh], dtype=np.float64)
+    assert np.array_equal(np.sort(np.concatenate(sh)), np.arange(len(cost)))
+    assert loads.max() / loads.mean() < 1.02 and dt < 0.5, (loads.max() / loads.mean(), dt)
 
 
-def test_allgatherv_world2_gloo():
-    import torch.multiprocessing as mp
-    port = _free_port()
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    assert out.get(0) is True and out.get(1) is True
-
-
-def _worker_async(rank, world, port, out):
+def _worker_gatherv(rank, world, port, out):
     import torch
-    import torch.distributed as dist
-
-    from sedef_amd.dist import ResultGather
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist = _init(rank, world, port)
+    from sedef_amd.dist import allgatherv_results, shard_tasks
     try:
-        n, cap = 50, 400
-        sets = [ResultGather(n * 16, cap, torch.device("cpu"), torch.int32) for _ in range(2)]
-        ok = True
-        expect = {}
-        for step in range(5):  # two buffer sets in rotation: the gather of step i is read after step i+1 started
-            b = step % 2
-            rec = torch.full((n * 16,), 1000 * step + rank, dtype=torch.int32)
-            used = 100 + 7 * rank + step
-            cig = torch.full((cap + 9,), -1, dtype=torch.int32)
-            cig[:used] = 10 * step + rank
-            sets[b].start(rec, cig, used)
-            expect[b] = step
-            if step:
-                pb = (step - 1) % 2
-                ra, ca, counts = sets[pb].result()
-                for r in range(world):
-                    ps = expect[pb]
-                    ok &= bool((ra[r] == 1000 * ps + r).all()) and int(counts[r, 0]) == n * 16
-                    u = int(counts[r, 1])
-                    ok &= u == 100 + 7 * r + ps and bool((ca[r][:u] == 10 * ps + r).all())
-        try:
-            sets[0].start(torch.zeros(n * 16, dtype=torch.int32), torch.zeros(cap, dtype=torch.int32), cap + 1)
-            ok = False
-        except ValueError:
-            pass
-        for s_ in sets:
-            s_.wait()
+        rng = np.random.default_rng(5)
+        cost = rng.integers(1, 10 ** 6, size=1001)
+        shards = shard_tasks(cost, world)
+        rec, cig = _fake_results(shards[rank])
+        pad = np.concatenate([cig, np.full(13, -1, np.int32)])  # pool larger than `used`
+        ra, ca, counts = allgatherv_results(torch.from_numpy(rec.reshape(-1)), torch.from_numpy(pad), len(cig))
+        ok = ra.numel() == 16 * len(cost) and int(counts[:, 1].sum()) == ca.numel()  # exact sizes, no padding
+        ro = co = 0
+        for r in range(world):
+            er, ec = _fake_results(shards[r])
+            ok &= int(counts[r, 0]) == er.size and int(counts[r, 1]) == len(ec)
+            ok &= np.array_equal(ra[ro:ro + er.size].numpy(), er.reshape(-1)) and np.array_equal(ca[co:co + len(ec)].numpy(), ec)
+            ro, co = ro + er.size, co + len(ec)
         out[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
 
 
-def test_async_result_gather_world2_gloo():
-    import torch.multiprocessing as mp
-    port = _free_port()
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_worker_async, args=(2, port, out), nprocs=2, join=True)
-    assert out.get(0) is True and out.get(1) is True
+def test_allgatherv_world2_gloo():
+    _spawn(_worker_gatherv)
+
+
+def _worker_strong(rank, world, port, out):
+    """bench.py --strong in miniature: every rank aligns its shard step after step into two buffer sets in rotation, the
+    gatherv of step i runs while step i+1 'computes', and the union of the shards equals the whole batch."""
+    import torch
+    dist = _init(rank, world, port)
+    from sedef_amd.dist import ResultGatherV, shard_tasks, task_checksums
+    try:
+        rng = np.random.default_rng(9)
+        n = 3000
+        cost = np.where(rng.random(n) < 0.99, rng.integers(1, 5000, n), rng.integers(10 ** 6, 10 ** 7, n))
+        shards = shard_tasks(cost, world)
+        mine = shards[rank]
+        whole_rec, whole_cig = _fake_results(np.arange(n))
+        whole = task_checksums(whole_rec, whole_cig)
+        sets = [ResultGatherV(torch.device("cpu"), torch.int32) for _ in range(2)]
+        ok = True
+        for step in range(4):
+            b = step % 2
+            sets[b].wait()  # the gather that last read this buffer set
+            rec, cig = _fake_results(mine)
+            sets[b].start(torch.from_numpy(rec.reshape(-1)), torch.from_numpy(cig), len(cig))
+        for g in sets:
+            g.wait()
+        union = np.zeros(n, np.uint64)
+        seen = np.zeros(n, np.int32)
+        for r in range(world):
+            pr, pc = sets[1].part(r)
+            union[shards[r]] = task_checksums(pr.numpy(), pc.numpy())
+            seen[shards[r]] += 1
+        ok &= bool((seen == 1).all()) and np.array_equal(union, whole)
+        try:
+            sets[0].start(torch.zeros(16, dtype=torch.int32), torch.zeros(4, dtype=torch.int32), 5)
+            ok = False
+        except ValueError:
+            pass
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strong_scaling_flow_world2_gloo():
+    _spawn(_worker_strong)
+
+
+def test_task_checksums_see_every_word():
+    from sedef_amd.dist import task_checksums
+    rec, cig = _fake_results(np.arange(50))
+    base = task_checksums(rec, cig)
+    assert len(np.unique(base)) == 50
+    c2 = cig.copy()
+    c2[len(c2) // 2] ^= 1
+    assert (task_checksums(rec, c2) != base).sum() == 1
+    r2 = rec.copy()
+    r2[7, 0] += 1
+    assert (task_checksums(r2, cig) != base).sum() == 1
+    # a task's checksum does not depend on where its words sit in the pool
+    perm = np.arange(50)[::-1]
+    rec_p, cig_p = _fake_results(perm)
+    assert np.array_equal(task_checksums(rec_p, cig_p)[::-1], base)
