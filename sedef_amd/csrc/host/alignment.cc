@@ -1,7 +1,11 @@
-// Alignment object of the `sedef align` stage (restates reference src/align.cc, src/align.h).
-// The DP itself is never run here: every place the reference calls align_helper
-// (src/align.cc:39-68) goes through DpSession::align, which records or replays.
-#include <algorithm>
+// Alignment of one candidate pair as a run-length CIGAR with a match counter (see sedef_host.h).
+//
+// Behaviour pinned against the reference's own class (src/align.cc, src/align.h) through oracle/_ref and the golden
+// vectors in tests/golden/host_align_kat.json.gz: CIGAR strings, the four counters of populate_nice_alignment
+// (src/align.cc:274-315), coordinates after trims and merges, including the reference's quirks (zero-length runs that
+// count as gaps and block run merging, the dead second DP of the far-gap branch, the "\0" run of an alignment that lost
+// all its columns).  The DP itself is never run here: every place the reference calls align_helper
+// (src/align.cc:39-68) goes through DpSession, which records the request or replays its result.
 #include <cassert>
 #include <cctype>
 #include <cstdio>
@@ -11,15 +15,16 @@
 
 namespace sdfh {
 
-// ---- small utilities -------------------------------------------------------------------------------
+// ---- character tables --------------------------------------------------------------------------------
 namespace {
 struct DnaTables {
   char align[128], hash[128], rev[128];
+  unsigned char up[256];
   DnaTables() {
     for (int i = 0; i < 128; i++) {
-      align[i] = 4;   // src/common.h:70
-      hash[i] = 0;    // src/common.h:69
-      rev[i] = 'N';   // src/common.h:75-77
+      align[i] = 4;  // src/common.h:70
+      hash[i] = 0;   // src/common.h:69
+      rev[i] = 'N';  // src/common.h:75-77
     }
     const char *fw = "ACGT", *bw = "TGCA";
     for (int k = 0; k < 4; k++) {
@@ -28,27 +33,37 @@ struct DnaTables {
       rev[(int)fw[k]] = bw[k];
       rev[tolower(fw[k])] = (char)tolower(bw[k]);
     }
+    for (int i = 0; i < 256; i++) up[i] = (unsigned char)toupper(i);
   }
 };
 const DnaTables kDna;
 
-struct UpperTable {  // toupper() of every byte, asked once (ceq runs once per alignment column)
-  unsigned char up[256];
-  UpperTable() {
-    for (int i = 0; i < 256; i++) up[i] = (unsigned char)toupper(i);
-  }
-};
-const UpperTable kUpper;
-
-inline bool ceq(char x, char y) {  // src/align.cc:29-35
-  if (x == '-' || y == '-') return false;
-  const unsigned char ux = kUpper.up[(unsigned char)x], uy = kUpper.up[(unsigned char)y];
-  if (ux == 'N' || uy == 'N') return false;
-  return ux == uy;
+// a match column: equal ignoring case, and not N (src/align.cc:29-35; '-' never reaches here)
+inline bool same_base(char x, char y) {
+  const unsigned char ux = kDna.up[(unsigned char)x], uy = kDna.up[(unsigned char)y];
+  return ux == uy && ux != 'N';
 }
 inline double pct(double p, double tot) { return 100.0 * p / tot; }  // src/common.h:99
+
+// which sequences a run consumes (populate_nice_alignment: D a base of a only, I a base of b only, anything else both)
+inline bool takes_a(char op) { return op != 'I'; }
+inline bool takes_b(char op) { return op != 'D'; }
+
+int count_matches(const char *a, const char *b, const Cigar &cg) {
+  int m = 0;
+  for (auto &run : cg) {
+    if (run.first == 'M')
+      for (int i = 0; i < run.second; i++) m += same_base(a[i], b[i]);
+    if (takes_a(run.first)) a += run.second;
+    if (takes_b(run.first)) b += run.second;
+  }
+  return m;
+}
+
+Params g_score_params;  // Align::MATCH etc. are process-wide in the reference (src/globals.cc:25-28)
 }  // namespace
 
+void set_alignment_scoring(const Params &p) { g_score_params = p; }
 char align_dna(char c) { return kDna.align[(unsigned char)c & 127]; }
 char hash_dna(char c) { return kDna.hash[(unsigned char)c & 127]; }
 
@@ -70,6 +85,7 @@ Sequence::Sequence(const std::string &n, const std::string &s, bool is_rc_) : na
   if (is_rc) seq = rc(s);
 }
 
+// ---- DP access ---------------------------------------------------------------------------------------
 Cigar DpSession::align(const std::string &q_codes, const std::string &t_codes) {
   if (recording) {
     requests->push_back({q_codes, t_codes});
@@ -79,20 +95,115 @@ Cigar DpSession::align(const std::string &q_codes, const std::string &t_codes) {
   return (*results)[cursor++];
 }
 
-// ---- constructors ------------------------------------------------------------------------------------
-Alignment::Alignment() {}
-
-Alignment::Alignment(const std::string &fa, const std::string &fb, DpSession &dp)  // src/align.cc:76-88
-    : chr_a("A"), start_a(0), end_a((int)fa.size()), chr_b("B"), start_b(0), end_b((int)fb.size()), a(fa), b(fb) {
-  std::string xa = fa, xb = fb;
-  for (auto &c : xa) c = align_dna(c);
-  for (auto &c : xb) c = align_dna(c);
-  cigar = dp.align(xa, xb);
-  populate_nice_alignment();
+Cigar DpSession::align_ranges(const char *q, int qlen, const char *t, int tlen) {
+  if (recording) {
+    DpRequest rq;
+    rq.q.resize((size_t)qlen);
+    rq.t.resize((size_t)tlen);
+    for (int i = 0; i < qlen; i++) rq.q[(size_t)i] = kDna.align[(unsigned char)q[i] & 127];
+    for (int i = 0; i < tlen; i++) rq.t[(size_t)i] = kDna.align[(unsigned char)t[i] & 127];
+    requests->push_back(std::move(rq));
+    return Cigar();
+  }
+  assert(cursor < results->size());
+  Cigar cg = (*results)[cursor++];
+  // the device counts matches on the codes (ACGT + wildcard); for IUPAC letters other than N the reference's
+  // comparison of the characters differs, and providers without counters leave -1: count here then
+  if (cg.matches < 0 || !codes_are_exact) cg.matches = count_matches(q, t, cg);
+  return cg;
 }
 
-Alignment::Alignment(const std::string &fa, const std::string &fb, const std::string &cigar_str)  // :90-105
-    : chr_a("A"), start_a(0), end_a((int)fa.size()), chr_b("B"), start_b(0), end_b((int)fb.size()), a(fa), b(fb) {
+// ---- counters ----------------------------------------------------------------------------------------
+Alignment::Alignment() {}
+
+void Alignment::recount(int matches) {  // what populate_nice_alignment derives (src/align.cc:274-315)
+  matches_ = matches;
+  int mcols = 0;
+  error = AlignmentError{0, 0, 0, 0};
+  columns_ = 0;
+  for (auto &run : cigar) {
+    columns_ += run.second;
+    if (run.first == 'M') {
+      mcols += run.second;
+    } else {
+      error.gaps++;  // zero-length runs count too
+      error.gap_bases += run.second;
+    }
+  }
+  error.matches = matches;
+  error.mismatches = mcols - matches;
+}
+
+double Alignment::gap_error() const { return pct(error.gap_bases, error.matches + error.gap_bases + error.mismatches); }
+double Alignment::mismatch_error() const {
+  return pct(error.mismatches, error.matches + error.gap_bases + error.mismatches);
+}
+
+std::string Alignment::cigar_string() const {  // src/align.cc:614-621: zero-length runs are not printed
+  std::string res;
+  char buf[32];
+  for (auto &run : cigar)
+    if (run.second) {
+      snprintf(buf, sizeof buf, "%d%c", run.second, run.first);
+      res += buf;
+    }
+  return res;
+}
+
+// ---- concatenation -------------------------------------------------------------------------------------
+void Alignment::append(const Cigar &piece) {  // src/align.cc:469-478
+  if (piece.matches > 0) matches_ += piece.matches;
+  if (piece.empty()) return;
+  if (!cigar.empty() && cigar.back().first == piece.front().first) {
+    cigar.back().second += piece.front().second;
+    cigar.insert(cigar.end(), std::next(piece.begin()), piece.end());
+  } else {
+    cigar.insert(cigar.end(), piece.begin(), piece.end());
+  }
+}
+
+void Alignment::prepend(const Cigar &piece) {  // src/align.cc:458-467
+  if (piece.matches > 0) matches_ += piece.matches;
+  if (piece.empty()) return;
+  if (!cigar.empty() && cigar.front().first == piece.back().first) {
+    cigar.front().second += piece.back().second;
+    cigar.insert(cigar.begin(), piece.begin(), piece.begin() + (piece.size() - 1));
+  } else {
+    cigar.insert(cigar.begin(), piece.begin(), piece.end());
+  }
+}
+
+// The stretch between two consecutive pieces (the reference has this block three times: src/align.cc:126-144,
+// :233-249, :579-600).  Both sides non-empty and at most 1000 long: one DP over the stretch.  Longer: a DP over the
+// first min(qgap, rgap) bases of each side and one gap run for the rest -- the reference also aligns the LAST
+// min(...) bases and then compares that result's error with itself, which is never smaller, so the first variant is
+// always taken and the second DP is not requested here.  When both sides are equally long that gap run has length
+// zero; it stays in the run list (it counts as a gap and keeps its neighbours from merging).
+void Alignment::fill_gap(int qfrom, int qgap, int rfrom, int rgap, DpSession &dp) {
+  if (qgap && rgap) {
+    const bool close = qgap <= 1000 && rgap <= 1000;
+    const int mi = std::min(qgap, rgap);
+    Cigar piece = dp.align_ranges(seq_a + qfrom, close ? qgap : mi, seq_b + rfrom, close ? rgap : mi);
+    if (!close) piece.push_back({qgap == mi ? 'I' : 'D', std::max(qgap, rgap) - mi});  // (length 0 when qgap == rgap)
+    append(piece);
+  } else if (qgap) {
+    append(Cigar{{'D', qgap}});
+  } else if (rgap) {
+    append(Cigar{{'I', rgap}});
+  }
+}
+
+// ---- constructors ------------------------------------------------------------------------------------
+Alignment::Alignment(const std::string &fa, const std::string &fb, DpSession &dp)
+    : end_a((int)fa.size()), end_b((int)fb.size()), seq_a(fa.data()), seq_b(fb.data()), len_a((int)fa.size()),
+      len_b((int)fb.size()) {
+  cigar = dp.align_ranges(seq_a, end_a, seq_b, end_b);
+  recount(std::max(cigar.matches, 0));
+}
+
+Alignment::Alignment(const std::string &fa, const std::string &fb, const std::string &cigar_str)
+    : end_a((int)fa.size()), end_b((int)fb.size()), seq_a(fa.data()), seq_b(fb.data()), len_a((int)fa.size()),
+      len_b((int)fb.size()) {
   int num = 0;
   for (char ch : cigar_str) {
     if (isdigit((unsigned char)ch)) num = 10 * num + (ch - '0');
@@ -102,384 +213,288 @@ Alignment::Alignment(const std::string &fa, const std::string &fb, const std::st
       num = 0;
     }
   }
-  populate_nice_alignment();
-}
-
-namespace {
-// the gap between two consecutive pieces (identical in the three places the reference has it:
-// src/align.cc:126-144, :233-249, :579-600)
-void fill_gap(Alignment &self, const std::string &qstr, const std::string &rstr, int qfrom, int qgap, int rfrom,
-              int rgap, int q_next, int r_next, DpSession &dp) {
-  if (qgap && rgap) {
-    if (qgap <= 1000 && rgap <= 1000) {  // "close" pieces: one DP over the whole gap
-      Alignment gap(qstr.substr(qfrom, qgap), rstr.substr(rfrom, rgap), dp);
-      self.append_cigar(gap.cigar);
-    } else {  // far: DP over the first min(qgap,rgap) bases, the rest is one gap run
-      const int ma = std::max(qgap, rgap), mi = std::min(qgap, rgap);
-      Alignment ma1(qstr.substr(qfrom, mi), rstr.substr(rfrom, mi), dp);
-      ma1.cigar.push_back({qgap == mi ? 'I' : 'D', ma - mi});
-      // The reference also aligns the LAST mi bases (ma2) and then compares
-      // ma2.total_error() < ma2.total_error(), which is never true: ma1 is always taken and ma2's DP
-      // has no observable effect, so it is not requested.
-      (void)q_next;
-      (void)r_next;
-      self.append_cigar(ma1.cigar);
-    }
-  } else if (qgap) {
-    self.append_cigar({{'D', qgap}});
-  } else if (rgap) {
-    self.append_cigar({{'I', rgap}});
-  }
-}
-}  // namespace
-
-Alignment::Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Hit> &guide, int side,
-                     DpSession &dp) {  // src/align.cc:107-197
-  auto prev = guide.begin();
-  *this = prev->aln;
-  for (auto cur = std::next(prev); cur != guide.end(); ++cur) {
-    const int qs = cur->query_start, qe = cur->query_end, qpe = prev->query_end;
-    const int rs = cur->ref_start, re = cur->ref_end, rpe = prev->ref_end;
-    end_a = qe;
-    end_b = re;
-    a += qstr.substr(qpe, qe - qpe);
-    b += rstr.substr(rpe, re - rpe);
-    fill_gap(*this, qstr, rstr, qpe, qs - qpe, rpe, rs - rpe, qs, rs, dp);
-    append_cigar(cur->aln.cigar);
-    prev = cur;
-  }
-  int qlo = start_a, qhi = end_a, rlo = start_b, rhi = end_b;
-  if (side) {
-    int qlo_n = std::max(0, qlo - side), rlo_n = std::max(0, rlo - side);
-    if (qlo - qlo_n && rlo - rlo_n) {
-      Alignment gap(qstr.substr(qlo_n, qlo - qlo_n), rstr.substr(rlo_n, rlo - rlo_n), dp);
-      gap.trim_front();
-      qlo_n = qlo - (gap.end_a - gap.start_a);
-      rlo_n = rlo - (gap.end_b - gap.start_b);
-      prepend_cigar(gap.cigar);
-      a = qstr.substr(qlo_n, qlo - qlo_n) + a;
-      b = rstr.substr(rlo_n, rlo - rlo_n) + b;
-      start_a = qlo = qlo_n;
-      start_b = rlo = rlo_n;
-    }
-    int qhi_n = std::min(qhi + side, (int)qstr.size()), rhi_n = std::min(rhi + side, (int)rstr.size());
-    if (qhi_n - qhi && rhi_n - rhi) {
-      Alignment gap(qstr.substr(qhi, qhi_n - qhi), rstr.substr(rhi, rhi_n - rhi), dp);
-      gap.trim_back();
-      qhi_n = qhi + gap.end_a;
-      rhi_n = rhi + gap.end_b;
-      append_cigar(gap.cigar);
-      a += qstr.substr(qhi, qhi_n - qhi);
-      b += rstr.substr(rhi, rhi_n - rhi);
-      end_a = qhi = qhi_n;
-      end_b = rhi = rhi_n;
-    }
-  }
-  populate_nice_alignment();
+  recount(count_matches(seq_a, seq_b, cigar));
 }
 
 Alignment::Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Anchor> &guide,
-                     const std::vector<int> &guide_idx, DpSession &dp)  // src/align.cc:199-270
-    : chr_a("A"), chr_b("B") {
-  if (guide_idx.empty()) {
-    *this = Alignment();
-    return;
+                     const std::vector<int> &guide_idx, DpSession &dp)
+    : seq_a(qstr.data()), seq_b(rstr.data()), len_a((int)qstr.size()), len_b((int)rstr.size()) {
+  if (guide_idx.empty()) return;
+  // anchors are exact matches (case-insensitive, no N): every column of their M runs is a match column
+  const Anchor &first = guide[guide_idx[0]];
+  start_a = first.q;
+  start_b = first.r;
+  end_a = first.q + first.l;
+  end_b = first.r + first.l;
+  cigar = {{'M', first.l}};
+  matches_ = first.l;
+  for (size_t g = 1; g < guide_idx.size(); g++) {
+    const Anchor &an = guide[guide_idx[g]];
+    fill_gap(end_a, an.q - end_a, end_b, an.r - end_b, dp);
+    Cigar piece{{'M', an.l}};
+    piece.matches = an.l;
+    append(piece);
+    end_a = an.q + an.l;
+    end_b = an.r + an.l;
   }
-  auto prev = guide_idx.begin();
-  start_a = guide[*prev].q;
-  end_a = guide[*prev].q + guide[*prev].l;
-  start_b = guide[*prev].r;
-  end_b = guide[*prev].r + guide[*prev].l;
-  a = qstr.substr(start_a, end_a - start_a);
-  b = rstr.substr(start_b, end_b - start_b);
-  cigar = {{'M', end_a - start_a}};
-  for (auto cur = std::next(prev); cur != guide_idx.end(); ++cur) {
-    const int qs = guide[*cur].q, qe = qs + guide[*cur].l, qpe = guide[*prev].q + guide[*prev].l;
-    const int rs = guide[*cur].r, re = rs + guide[*cur].l, rpe = guide[*prev].r + guide[*prev].l;
-    end_a = qe;
-    end_b = re;
-    a += qstr.substr(qpe, qe - qpe);
-    b += rstr.substr(rpe, re - rpe);
-    fill_gap(*this, qstr, rstr, qpe, qs - qpe, rpe, rs - rpe, qs, rs, dp);
-    append_cigar({{'M', qe - qs}});
-    prev = cur;
-  }
-  populate_nice_alignment();
+  recount(matches_);
 }
 
-// ---- column strings and counters (src/align.cc:274-315) -------------------------------------------------
-void Alignment::populate_nice_alignment() {
-  // (one pass over preallocated strings; the reference appends column by column and counts in a second pass --
-  // same strings, same counters)
-  size_t cols = 0;
-  for (auto &c : cigar) cols += c.second > 0 ? (size_t)c.second : 0;
-  align_a.resize(cols);
-  align_b.resize(cols);
-  alignment.resize(cols);
-  char *pa = &align_a[0], *pb = &align_b[0], *pm = &alignment[0];
-  const char *sa = a.data(), *sb = b.data();
-  size_t ia = 0, ib = 0, o = 0;
-  error = AlignmentError{0, 0, 0, 0};
-  for (auto &c : cigar) {
-    const int n = c.second;
-    if (c.first == 'M') {
-      for (int i = 0; i < n; i++, o++) {
-        const char ca = sa[ia++], cb = sb[ib++];
-        const bool eq = ceq(ca, cb);
-        pm[o] = eq ? '|' : '*';
-        pa[o] = ca;
-        pb[o] = cb;
-        if (ca != '-' && cb != '-') {
-          if (eq) error.matches++; else error.mismatches++;
-        }
-      }
-    } else {
-      error.gaps++;  // zero-length runs count too
-      error.gap_bases += n;
-      // as in the reference: op D takes a base of a only, op I a base of b only, any other op one of each
-      const bool take_a = c.first != 'I', take_b = c.first != 'D';
-      for (int i = 0; i < n; i++, o++) {
-        const char ca = take_a ? sa[ia++] : '-', cb = take_b ? sb[ib++] : '-';
-        pm[o] = '*';
-        pa[o] = ca;
-        pb[o] = cb;
-        if (ca != '-' && cb != '-') {
-          if (ceq(ca, cb)) error.matches++; else error.mismatches++;
-        }
-      }
+Alignment::Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Hit> &guide, int side,
+                     DpSession &dp) {
+  *this = guide.front().aln;
+  seq_a = qstr.data();
+  seq_b = rstr.data();
+  len_a = (int)qstr.size();
+  len_b = (int)rstr.size();
+  for (size_t g = 1; g < guide.size(); g++) {
+    const Hit &cur = guide[g];
+    fill_gap(end_a, cur.query_start - end_a, end_b, cur.ref_start - end_b, dp);
+    Cigar piece = cur.aln.cigar;
+    piece.matches = cur.aln.matches_;
+    append(piece);
+    end_a = cur.query_end;
+    end_b = cur.ref_end;
+  }
+  if (side) {
+    // up to `side` bases on both flanks are aligned and only the best-scoring part next to the alignment is kept
+    const int qlo = std::max(0, start_a - side), rlo = std::max(0, start_b - side);
+    if (start_a - qlo && start_b - rlo) {
+      Alignment flank;
+      flank.seq_a = seq_a + qlo;
+      flank.seq_b = seq_b + rlo;
+      flank.end_a = start_a - qlo;
+      flank.end_b = start_b - rlo;
+      flank.cigar = dp.align_ranges(flank.seq_a, flank.end_a, flank.seq_b, flank.end_b);
+      flank.recount(std::max(flank.cigar.matches, 0));
+      flank.trim_front();
+      flank.cigar.matches = flank.matches_;
+      prepend(flank.cigar);
+      start_a -= flank.end_a - flank.start_a;
+      start_b -= flank.end_b - flank.start_b;
+    }
+    const int qhi = std::min(end_a + side, len_a), rhi = std::min(end_b + side, len_b);
+    if (qhi - end_a && rhi - end_b) {
+      Alignment flank;
+      flank.seq_a = seq_a + end_a;
+      flank.seq_b = seq_b + end_b;
+      flank.end_a = qhi - end_a;
+      flank.end_b = rhi - end_b;
+      flank.cigar = dp.align_ranges(flank.seq_a, flank.end_a, flank.seq_b, flank.end_b);
+      flank.recount(std::max(flank.cigar.matches, 0));
+      flank.trim_back();
+      flank.cigar.matches = flank.matches_;
+      append(flank.cigar);
+      end_a += flank.end_a;
+      end_b += flank.end_b;
     }
   }
+  recount(matches_);
 }
 
-double Alignment::gap_error() const { return pct(error.gap_bases, error.matches + error.gap_bases + error.mismatches); }
-double Alignment::mismatch_error() const {
-  return pct(error.mismatches, error.matches + error.gap_bases + error.mismatches);
-}
-
-void Alignment::trim() {  // src/align.cc:317-341
-  while (!cigar.empty()) {
-    if (cigar[0].first == 'D') {
-      a = a.substr(cigar[0].second);
-      start_a += cigar[0].second;
-      cigar.pop_front();
-    } else if (cigar[0].first == 'I') {
-      b = b.substr(cigar[0].second);
-      start_b += cigar[0].second;
-      cigar.pop_front();
-    } else if (cigar.back().first == 'D') {
-      end_a -= cigar.back().second;
-      a = a.substr(0, a.size() - cigar.back().second);
-      cigar.pop_back();
-    } else if (cigar.back().first == 'I') {
-      end_b -= cigar.back().second;
-      b = b.substr(0, b.size() - cigar.back().second);
-      cigar.pop_back();
-    } else {
-      break;
-    }
-  }
-  populate_nice_alignment();
-}
-
+// ---- trims -------------------------------------------------------------------------------------------
 namespace {
-// score contribution of alignment column i given its neighbour towards the scan origin
-inline int column_score(const Alignment &al, int i, bool first, int nb, const Params &p) {
-  if (al.alignment[i] == '|') return p.match;
-  if (al.align_a[i] != '-' && al.align_b[i] != '-') return p.mismatch;
-  int s = 0;
-  if (first || (al.align_a[i] == '-' && al.align_a[nb] != '-') || (al.align_b[i] == '-' && al.align_b[nb] != '-'))
-    s += p.gap_open;
-  return s + p.gap_extend;
-}
-Params g_score_params;  // Align::MATCH etc. are process-wide in the reference (src/globals.cc:25-28)
+// Walks the columns of a run list in either direction and scores them like the reference's trim scans: a match
+// column scores `match`, a mismatch column `mismatch`, a gap column `gap_extend`, plus `gap_open` when it is the first
+// column of the scan or its neighbour towards the scan's origin is not a gap in the same sequence
+// (src/align.cc:347-362, :404-418).
+struct ColumnScan {
+  const Params &p;
+  int prev_kind = -1;  // 0: both bases, 1: gap in a, 2: gap in b
+  explicit ColumnScan(const Params &pp) : p(pp) {}
+  int gap(int kind) {
+    const int s = (prev_kind != kind ? p.gap_open : 0) + p.gap_extend;
+    prev_kind = kind;
+    return s;
+  }
+  int pair(bool match) {
+    prev_kind = 0;
+    return match ? p.match : p.mismatch;
+  }
+};
 }  // namespace
 
-void set_alignment_scoring(const Params &p) { g_score_params = p; }
-
-void Alignment::trim_front() {  // ABCD -> --CD  (src/align.cc:343-398)
+void Alignment::trim_front() {
   const Params &p = g_score_params;
-  int max_score = 0, max_i = (int)a.size(), score = 0;
-  const int n = (int)alignment.size();
-  for (int i = n - 1; i >= 0; i--) {
-    score += column_score(*this, i, i == n - 1, i + 1 < n ? i + 1 : i, p);
-    if (score >= max_score) max_score = score, max_i = i;
+  ColumnScan scan(p);
+  // best suffix: scan from the last column; ties go to the longer suffix (>=)
+  const int none = end_a - start_a;  // the reference's "nothing found" marker is the LENGTH OF a, not of the columns
+  int best = 0, best_col = none, best_matches = 0, score = 0, seen = 0;
+  int ia = end_a, ib = end_b, col = columns_;
+  for (size_t k = cigar.size(); k-- > 0;) {
+    const char op = cigar[k].first;
+    for (int i = 0; i < cigar[k].second; i++) {
+      --col;
+      if (op == 'M') {
+        const bool m = same_base(seq_a[--ia], seq_b[--ib]);
+        seen += m;
+        score += scan.pair(m);
+      } else if (!takes_a(op)) {
+        --ib;
+        score += scan.gap(1);
+      } else if (!takes_b(op)) {
+        --ia;
+        score += scan.gap(2);
+      } else {  // (a run that consumes both and is not M: scored as a mismatch column, like the reference)
+        --ia;
+        --ib;
+        score += scan.pair(false);
+      }
+      if (score >= best) best = score, best_col = col, best_matches = seen;
+    }
   }
-  if (max_i == (int)a.size()) {
-    a = "";
-    b = "";
+  if (best_col == none) {
     start_a = end_a;
     start_b = end_b;
     cigar.clear();
+    recount(0);
     return;
   }
-  for (int ci = 0, cur_len = 0; ci < (int)cigar.size(); ci++) {
-    if (cigar[ci].second + cur_len > max_i) {
-      const int need = max_i - cur_len;
-      cigar[ci].second -= need;
-      for (int cj = 0; cj < ci; cj++) cigar.pop_front();
+  // drop the first best_col columns (the cut lands inside an M run: a best suffix starts with a match)
+  int done = 0;
+  for (size_t k = 0; k < cigar.size(); k++) {
+    const int len = cigar[k].second;
+    if (done + len > best_col) {
+      const int need = best_col - done;
+      cigar[k].second -= need;
+      for (size_t j = 0; j < k; j++) cigar.pop_front();
       start_a += need;
       start_b += need;
       break;
     }
-    cur_len += cigar[ci].second;
-    if (cigar[ci].first == 'M') {
-      start_a += cigar[ci].second;
-      start_b += cigar[ci].second;
-    } else if (cigar[ci].first == 'I') {
-      start_b += cigar[ci].second;
-    } else {
-      start_a += cigar[ci].second;
-    }
+    done += len;
+    if (takes_a(cigar[k].first)) start_a += len;
+    if (takes_b(cigar[k].first)) start_b += len;
   }
-  a = a.substr(start_a, end_a - start_a);
-  b = b.substr(start_b, end_b - start_b);
-  populate_nice_alignment();
+  recount(best_matches);
 }
 
-void Alignment::trim_back() {  // ABCD -> AB--  (src/align.cc:400-456)
+void Alignment::trim_back() {
   const Params &p = g_score_params;
-  int max_score = 0, max_i = -1, score = 0;
-  const int n = (int)alignment.size();
-  for (int i = 0; i < n; i++) {
-    score += column_score(*this, i, i == 0, i > 0 ? i - 1 : i, p);
-    if (score >= max_score) max_score = score, max_i = i;
+  ColumnScan scan(p);
+  int best = 0, best_col = -1, best_matches = 0, score = 0, seen = 0;
+  int ia = start_a, ib = start_b, col = 0;
+  for (size_t k = 0; k < cigar.size(); k++) {
+    const char op = cigar[k].first;
+    for (int i = 0; i < cigar[k].second; i++, col++) {
+      if (op == 'M') {
+        const bool m = same_base(seq_a[ia++], seq_b[ib++]);
+        seen += m;
+        score += scan.pair(m);
+      } else if (!takes_a(op)) {
+        ++ib;
+        score += scan.gap(1);
+      } else if (!takes_b(op)) {
+        ++ia;
+        score += scan.gap(2);
+      } else {
+        ++ia;
+        ++ib;
+        score += scan.pair(false);
+      }
+      if (score >= best) best = score, best_col = col, best_matches = seen;
+    }
   }
-  if (max_i == -1) {
-    a = "";
-    b = "";
+  if (best_col == -1) {
     end_a = start_a;
     end_b = start_b;
     cigar.clear();
+    recount(0);
     return;
   }
-  max_i++;
-  end_a = start_a, end_b = start_b;
-  for (int ci = 0, cur_len = 0; ci < (int)cigar.size(); ci++) {
-    if (cigar[ci].second + cur_len >= max_i) {
-      const int need = max_i - cur_len;
-      cigar[ci].second = need;
-      while ((int)cigar.size() - 1 > ci) cigar.pop_back();
+  const int keep = best_col + 1;  // columns kept
+  end_a = start_a;
+  end_b = start_b;
+  int done = 0;
+  for (size_t k = 0; k < cigar.size(); k++) {
+    const int len = cigar[k].second;
+    if (done + len >= keep) {
+      const int need = keep - done;
+      cigar[k].second = need;
+      while (cigar.size() - 1 > k) cigar.pop_back();
       end_a += need;
       end_b += need;
       break;
     }
-    cur_len += cigar[ci].second;
-    if (cigar[ci].first == 'M') {
-      end_a += cigar[ci].second;
-      end_b += cigar[ci].second;
-    } else if (cigar[ci].first == 'I') {
-      end_b += cigar[ci].second;
-    } else {
-      end_a += cigar[ci].second;
-    }
+    done += len;
+    if (takes_a(cigar[k].first)) end_a += len;
+    if (takes_b(cigar[k].first)) end_b += len;
   }
-  a = a.substr(start_a, end_a - start_a);
-  b = b.substr(start_b, end_b - start_b);
-  populate_nice_alignment();
+  recount(best_matches);
 }
 
-void Alignment::prepend_cigar(const Cigar &app) {  // src/align.cc:458-467
-  if (app.empty()) return;
-  if (!cigar.empty() && cigar.front().first == app.back().first) {
-    cigar.front().second += app.back().second;
-    cigar.insert(cigar.begin(), app.begin(), app.begin() + (app.size() - 1));
-  } else {
-    cigar.insert(cigar.begin(), app.begin(), app.end());
+// ---- merge -------------------------------------------------------------------------------------------
+// Columns leave from the end until `trim` bases of the query (or of the reference) have gone with them; a column that
+// does not consume that sequence leaves too while the count is still short (src/align.cc:511-517, :543-549).
+// Returns nothing; coordinates and the match counter follow the columns.
+int Alignment::cut_tail(int trim, bool by_query) {
+  int gone = 0;
+  while (gone < trim && !cigar.empty()) {
+    auto &run = cigar.back();
+    const bool counts = by_query ? takes_a(run.first) : takes_b(run.first);
+    const int take = counts ? std::min(run.second, trim - gone) : run.second;
+    if (run.first == 'M')
+      for (int i = 1; i <= take; i++) matches_ -= same_base(seq_a[end_a - i], seq_b[end_b - i]);
+    if (takes_a(run.first)) end_a -= take;
+    if (takes_b(run.first)) end_b -= take;
+    if (counts) gone += take;
+    run.second -= take;
+    if (run.second == 0) cigar.pop_back();
   }
+  return gone;
 }
 
-void Alignment::append_cigar(const Cigar &app) {  // src/align.cc:469-478
-  if (app.empty()) return;
-  if (!cigar.empty() && cigar.back().first == app.front().first) {
-    cigar.back().second += app.front().second;
-    cigar.insert(cigar.end(), std::next(app.begin()), app.end());
-  } else {
-    cigar.insert(cigar.end(), app.begin(), app.end());
+int Alignment::cut_head(int trim, bool by_query) {  // (src/align.cc:524-534, :556-566)
+  int gone = 0;
+  while (gone < trim && !cigar.empty()) {
+    auto &run = cigar.front();
+    const bool counts = by_query ? takes_a(run.first) : takes_b(run.first);
+    const int take = counts ? std::min(run.second, trim - gone) : run.second;
+    if (run.first == 'M')
+      for (int i = 0; i < take; i++) matches_ -= same_base(seq_a[start_a + i], seq_b[start_b + i]);
+    if (takes_a(run.first)) start_a += take;
+    if (takes_b(run.first)) start_b += take;
+    if (counts) gone += take;
+    run.second -= take;
+    if (run.second == 0) cigar.pop_front();
   }
+  return gone;
 }
 
-void Alignment::cigar_from_alignment() {  // src/align.cc:480-501
-  cigar.clear();
-  int sz = 0;
-  char op = 0, top;
-  for (size_t i = 0; i < alignment.size(); i++) {
-    if (align_a[i] == '-') top = 'I';
-    else if (align_b[i] == '-') top = 'D';
-    else top = 'M';
-    if (op != top) {
-      if (op) cigar.push_back({op, sz});
-      op = top, sz = 0;
-    }
-    sz++;
+// The reference rebuilds the CIGAR from the remaining columns (cigar_from_alignment, src/align.cc:480-501): runs of
+// length zero disappear, neighbours of one kind fuse, and an alignment without columns gets one run {'\0', 0}.
+void Alignment::normalise() {
+  Cigar out;
+  for (auto &run : cigar) {
+    if (run.second == 0) continue;
+    if (!out.empty() && out.back().first == run.first) out.back().second += run.second;
+    else out.push_back(run);
   }
-  cigar.push_back({op, sz});
+  if (out.empty()) out.push_back({'\0', 0});
+  cigar = out;
 }
 
 void Alignment::merge(Alignment &cur, const std::string &qstr, const std::string &rstr, DpSession &dp) {
-  // src/align.cc:505-610: cut the overlapping columns off both alignments, first by query then by reference
+  seq_a = cur.seq_a = qstr.data();
+  seq_b = cur.seq_b = rstr.data();
+  len_a = cur.len_a = (int)qstr.size();
+  len_b = cur.len_b = (int)rstr.size();
+  // the overlap goes from BOTH alignments: first what overlaps in the query, then what still overlaps in the reference
   for (int pass = 0; pass < 2; pass++) {
-    const int trim = pass == 0 ? end_a - cur.start_a : end_b - cur.start_b;
-    int q = 0, r = 0, i;
-    for (i = (int)alignment.size() - 1; i >= 0 && (pass == 0 ? q : r) < trim; i--) {
-      if (align_a[i] != '-') q++;
-      if (align_b[i] != '-') r++;
-    }
-    align_a = align_a.substr(0, i + 1);
-    alignment = alignment.substr(0, i + 1);
-    align_b = align_b.substr(0, i + 1);
-    end_a = start_a + (int)a.size() - q;
-    end_b = start_b + (int)b.size() - r;
-    a = a.substr(0, a.size() - q);
-    b = b.substr(0, b.size() - r);
-
-    q = 0, r = 0;
-    for (i = 0; i < (int)cur.alignment.size() && (pass == 0 ? q : r) < trim; i++) {
-      if (cur.align_a[i] != '-') q++;
-      if (cur.align_b[i] != '-') r++;
-    }
-    cur.align_a = cur.align_a.substr(i);
-    cur.alignment = cur.alignment.substr(i);
-    cur.align_b = cur.align_b.substr(i);
-    cur.start_a += q;
-    cur.start_b += r;
-    cur.a = cur.a.substr(q);
-    cur.b = cur.b.substr(r);
+    const bool by_query = pass == 0;
+    const int trim = by_query ? end_a - cur.start_a : end_b - cur.start_b;
+    cut_tail(trim, by_query);
+    cur.cut_head(trim, by_query);
   }
-  cigar_from_alignment();
-  cur.cigar_from_alignment();
-
-  const int qgap = cur.start_a - end_a, rgap = cur.start_b - end_b;
-  fill_gap(*this, qstr, rstr, end_a, qgap, end_b, rgap, cur.start_a, cur.start_b, dp);
-  a += qstr.substr(end_a, qgap) + cur.a;
-  b += rstr.substr(end_b, rgap) + cur.b;
+  normalise();
+  cur.normalise();
+  fill_gap(end_a, cur.start_a - end_a, end_b, cur.start_b - end_b, dp);
+  Cigar piece = cur.cigar;
+  piece.matches = cur.matches_;
+  append(piece);
   end_a = cur.end_a;
   end_b = cur.end_b;
-  append_cigar(cur.cigar);
-  populate_nice_alignment();
-}
-
-std::string Alignment::cigar_string() const {  // src/align.cc:614-621
-  std::string res;
-  char buf[32];
-  for (auto &p : cigar)
-    if (p.second) {
-      snprintf(buf, sizeof buf, "%d%c", p.second, p.first);
-      res += buf;
-    }
-  return res;
-}
-
-void Alignment::swap() {  // src/align.cc:623-636
-  std::swap(a, b);
-  std::swap(chr_a, chr_b);
-  std::swap(start_a, start_b);
-  std::swap(end_a, end_b);
-  for (auto &p : cigar)
-    if (p.second) {
-      if (p.first == 'I') p.first = 'D';
-      else if (p.first == 'D') p.first = 'I';
-    }
-  populate_nice_alignment();
+  recount(matches_);
 }
 
 }  // namespace sdfh

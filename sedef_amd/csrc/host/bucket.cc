@@ -1,10 +1,15 @@
-// `sedef align bucket` (restates reference src/align_main.cc:38-198, src/merge.cc:35-109,
-// src/search_main.cc:93-120): extend the seed hits, canonicalise, spill per chromosome-group pair, merge
-// nearby hits, and deal them round-robin per complexity class into N bucket files.
-#include <dirent.h>
+// `sedef align bucket`: seed hits -> N bucket files for `align generate` (what bucket_alignments_extern of the reference
+// produces, src/align_main.cc:38-198, with merge() of src/merge.cc:35-109 and the chromosome grouping of
+// src/search_main.cc:93-120).
+//
+// The reference spills the extended seeds into one temporary file per pair of chromosome groups, re-reads each file to
+// merge it, writes it back, and re-reads everything a third time to deal the hits into the buckets.  Here the seeds
+// stream through memory once: they are grouped under the temporary file's NAME (its lexicographic order is the order the
+// reference processes the groups in), every group is merged in place, and the hits are dealt straight into the bucket
+// files.  A hit still passes through its BED text between the steps, exactly where the reference writes and re-reads it
+// (the round trip drops fields: a seed's 14th column becomes the jaccard count, the CIGAR column is ignored).
 #include <glob.h>
 #include <sys/stat.h>
-#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -17,209 +22,202 @@
 
 namespace sdfh {
 
-std::vector<Hit> merge_hits(std::vector<Hit> &hits, int merge_dist) {  // src/merge.cc:35-109
-  std::vector<Hit> results;
-  for (auto &h : hits) {
-    if (std::tie(h.query->name, h.query_start, h.query_end) > std::tie(h.ref->name, h.ref_start, h.ref_end)) {
-      std::swap(h.query->name, h.ref->name);
-      std::swap(h.query_start, h.ref_start);
-      std::swap(h.query_end, h.ref_end);
-    }
+namespace {
+// a hit is kept with the pair ordered by (chromosome, start, end) of its two sides (src/merge.cc:38-46,
+// src/align_main.cc:79-84); only the names, not the Sequence objects, change sides
+void order_sides(Hit &h) {
+  if (std::tie(h.query->name, h.query_start, h.query_end) > std::tie(h.ref->name, h.ref_start, h.ref_end)) {
+    std::swap(h.query->name, h.ref->name);
+    std::swap(h.query_start, h.ref_start);
+    std::swap(h.query_end, h.ref_end);
   }
-  // same library sort, same comparator, same input order => same permutation among equal keys
+}
+
+int complexity_class(const Hit &h) {  // src/align_main.cc:128-130, :172-174
+  return (int)std::sqrt(double(h.query_end - h.query_start) * double(h.ref_end - h.ref_start)) / 1000;
+}
+int complexity_of(const Hit &h) {
+  return (int)std::sqrt(double(h.query_end - h.query_start) * double(h.ref_end - h.ref_start));
+}
+}  // namespace
+
+// Sweep over the hits in (strand, query chromosome, reference chromosome, query start, reference start) order.  The
+// hits of the current run of nearby query intervals are kept as "windows" keyed by their reference end; a new hit
+// swallows every window it comes within `merge_dist` of (in both sequences), repeatedly, as its own extent grows.
+std::vector<Hit> merge_hits(std::vector<Hit> &hits, int merge_dist) {
+  for (auto &h : hits) order_sides(h);
+  // (std::sort, this comparator, this input order: equal keys end up where the reference's sort leaves them)
   std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) {
     return std::tie(a.ref->is_rc, a.query->name, a.ref->name, a.query_start, a.ref_start) <
            std::tie(b.ref->is_rc, b.query->name, b.ref->name, b.query_start, b.ref_start);
   });
-  Hit prev;
-  std::multimap<int, Hit> windows;
-  for (auto &rec : hits) {
-    if (rec.query->name == rec.ref->name && rec.query_start == rec.ref_start && rec.query_end == rec.ref_end &&
-        rec.query->is_rc == rec.ref->is_rc)
-      continue;
-    if ((&rec - &hits[0]) == 0) {
-      windows.emplace(rec.ref_end, rec);
-      prev = rec;
-    } else if (prev.query_end + merge_dist < rec.query_start || prev.query->name != rec.query->name ||
-               prev.ref->name != rec.ref->name || prev.ref->is_rc != rec.ref->is_rc) {
-      for (auto &it : windows) results.push_back(it.second);
-      windows.clear();
-      windows.emplace(rec.ref_end, rec);
-      prev = rec;
+  std::vector<Hit> merged;
+  std::multimap<int, Hit> windows;  // by reference end
+  auto flush = [&] {
+    for (auto &w : windows) merged.push_back(w.second);
+    windows.clear();
+  };
+  auto apart = [&](const Hit &w, const Hit &h) {
+    return w.query_end + merge_dist < h.query_start || w.ref_end < h.ref_start - merge_dist ||
+           w.ref_start > h.ref_end + merge_dist;
+  };
+  Hit last;  // the previous hit, its query end raised to that of everything before it in the run (src/merge.cc:101-102)
+  bool have_last = false;
+  for (Hit &h : hits) {
+    const bool self = h.query->name == h.ref->name && h.query_start == h.ref_start && h.query_end == h.ref_end &&
+                      h.query->is_rc == h.ref->is_rc;
+    if (self) continue;  // a region against itself
+    const bool new_run = !have_last || last.query_end + merge_dist < h.query_start ||
+                         last.query->name != h.query->name || last.ref->name != h.ref->name ||
+                         last.ref->is_rc != h.ref->is_rc;
+    if (new_run) {
+      flush();
     } else {
-      bool need_update = true;
-      while (need_update) {
-        auto loc = windows.lower_bound(rec.ref_start - merge_dist);
-        need_update = false;
-        while (loc != windows.end()) {
-          if (loc->second.query_end + merge_dist < rec.query_start || loc->second.ref_end < rec.ref_start - merge_dist ||
-              loc->second.ref_start > rec.ref_end + merge_dist) {
-            ++loc;
+      for (bool grew = true; grew;) {
+        grew = false;
+        for (auto w = windows.lower_bound(h.ref_start - merge_dist); w != windows.end();) {
+          if (apart(w->second, h)) {
+            ++w;
             continue;
           }
-          need_update = true;
-          rec.query_end = std::max(rec.query_end, loc->second.query_end);
-          rec.ref_end = std::max(rec.ref_end, loc->second.ref_end);
-          rec.query_start = std::min(rec.query_start, loc->second.query_start);
-          rec.ref_start = std::min(rec.ref_start, loc->second.ref_start);
-          windows.erase(loc++);
+          h.query_start = std::min(h.query_start, w->second.query_start);
+          h.query_end = std::max(h.query_end, w->second.query_end);
+          h.ref_start = std::min(h.ref_start, w->second.ref_start);
+          h.ref_end = std::max(h.ref_end, w->second.ref_end);
+          w = windows.erase(w);
+          grew = true;
         }
       }
-      windows.emplace(rec.ref_end, rec);
     }
-    rec.query_end = std::max(rec.query_end, prev.query_end);
-    prev = rec;
+    windows.emplace(h.ref_end, h);
+    if (!new_run) h.query_end = std::max(h.query_end, last.query_end);
+    last = h;
+    have_last = true;
   }
-  for (auto &it : windows) results.push_back(it.second);
-  return results;
+  flush();
+  return merged;
 }
 
-// chromosomes sorted by (length, name) descending, grouped greedily into <= 100 MB groups
+// chromosomes by (length, name) descending, packed greedily into groups of at most 100 MB
 std::vector<std::vector<std::string>> generate_translation(const std::string &ref_path) {  // src/search_main.cc:93-120
-  std::ifstream fin((ref_path + ".fai").c_str());
-  if (!fin.is_open()) throw "Index file " + ref_path + ".fai does not exist";
-  std::map<std::string, std::pair<size_t, std::string>> index;  // keyed by first token, like FastaIndex
-  std::string line;
-  while (std::getline(fin, line)) {
-    auto f = split(line, '\t');
+  std::ifstream fai((ref_path + ".fai").c_str());
+  if (!fai.is_open()) throw "Index file " + ref_path + ".fai does not exist";
+  std::map<std::string, std::pair<size_t, std::string>> by_key;  // first token of the name -> (length, full name)
+  for (std::string line; std::getline(fai, line);) {
+    const auto f = split(line, '\t');
     if (f.size() != 5) throw "Index file " + ref_path + ".fai is malformed";
-    index.insert({split(f[0], ' ').at(0), {(size_t)atoi(f[1].c_str()), f[0]}});
+    by_key.insert({split(f[0], ' ').at(0), {(size_t)atoi(f[1].c_str()), f[0]}});
   }
-  std::vector<std::pair<size_t, std::string>> vv;
-  for (auto &e : index) vv.push_back(e.second);
-  std::sort(vv.begin(), vv.end(), std::greater<std::pair<size_t, std::string>>());
-  std::vector<std::vector<std::string>> ref;
-  int cur_size = 0;
-  const int MAX_SIZE = 100 * 1000 * 1000;
-  for (auto &v : vv) {
-    if (ref.empty() || cur_size + v.first > (size_t)MAX_SIZE) {
-      ref.push_back({v.second});
-      cur_size = (int)v.first;
+  std::vector<std::pair<size_t, std::string>> chroms;
+  for (auto &e : by_key) chroms.push_back(e.second);
+  std::sort(chroms.begin(), chroms.end(), std::greater<std::pair<size_t, std::string>>());
+  std::vector<std::vector<std::string>> groups;
+  int filled = 0;  // (an int in the reference as well)
+  for (auto &c : chroms) {
+    if (groups.empty() || filled + c.first > (size_t)(100 * 1000 * 1000)) {
+      groups.push_back({c.second});
+      filled = (int)c.first;
     } else {
-      ref.back().push_back(v.second);
-      cur_size += (int)v.first;
+      groups.back().push_back(c.second);
+      filled += (int)c.first;
     }
   }
-  return ref;
+  return groups;
 }
 
-static std::vector<std::string> list_beds(const std::string &bed_path) {
+static std::vector<std::string> seed_files(const std::string &path) {  // src/align_main.cc:44-62
   struct stat st;
-  if (stat(bed_path.c_str(), &st) != 0) throw "Path " + bed_path + " is neither file nor directory";
+  if (stat(path.c_str(), &st) != 0) throw "Path " + path + " is neither file nor directory";
   std::vector<std::string> files;
   if (S_ISREG(st.st_mode)) {
-    files.push_back(bed_path);
+    files.push_back(path);
   } else if (S_ISDIR(st.st_mode)) {
     glob_t g;
-    glob((bed_path + "/*.bed").c_str(), GLOB_TILDE, nullptr, &g);
+    glob((path + "/*.bed").c_str(), GLOB_TILDE, nullptr, &g);
     for (size_t i = 0; i < g.gl_pathc; i++) {
       struct stat s2;
       if (stat(g.gl_pathv[i], &s2) == 0 && S_ISREG(s2.st_mode)) files.push_back(g.gl_pathv[i]);
     }
     globfree(&g);
   } else {
-    throw "Path " + bed_path + " is neither file nor directory";
+    throw "Path " + path + " is neither file nor directory";
   }
   return files;
 }
 
 void bucket_alignments_extern(const std::string &bed_path, int nbins, const std::string &output_dir, bool extend,
                               const std::string &reference, const BucketParams &bp, FILE *log) {
-  auto ref = generate_translation(reference);
-  std::map<std::string, int> lookup;
-  for (int i = 0; i < (int)ref.size(); i++)
-    for (auto &j : ref[i]) lookup[j] = i;
-
-  std::map<std::string, FILE *> tmp_bins;
-  std::map<std::string, int> lens;
-  int total_nhits = 0;
-  for (auto &file : list_beds(bed_path)) {
+  std::map<std::string, int> group_of;
+  {
+    const auto groups = generate_translation(reference);
+    for (int g = 0; g < (int)groups.size(); g++)
+      for (auto &name : groups[(size_t)g]) group_of[name] = g;
+  }
+  // 1. seeds -> extended, side-ordered hits, grouped by the pair of chromosome groups.  The key is the reference's
+  //    temporary file name: groups are processed in the order of these strings.
+  std::map<std::string, std::vector<std::string>> group_lines;
+  int total = 0;
+  for (auto &file : seed_files(bed_path)) {
     std::ifstream fin(file.c_str());
     if (!fin.is_open()) throw "BED file " + bed_path + " does not exist";
-    std::string s;
-    int nhits = 0;
-    while (std::getline(fin, s)) {
-      Hit h = Hit::from_bed(s);
+    int count = 0;
+    for (std::string line; std::getline(fin, line); count++) {
+      Hit h = Hit::from_bed(line);
       if (extend) h.extend(bp.extend_ratio, bp.max_extend);
-      if (std::tie(h.query->name, h.query_start, h.query_end) > std::tie(h.ref->name, h.ref_start, h.ref_end)) {
-        std::swap(h.query->name, h.ref->name);
-        std::swap(h.query_start, h.ref_start);
-        std::swap(h.query_end, h.ref_end);
-      }
-      const std::string fno = output_dir + "/tmp_" + std::to_string(lookup[h.query->name]) + "_" +
-                              std::to_string(lookup[h.ref->name]) + ".tmp";
-      auto it = tmp_bins.find(fno);
-      if (it == tmp_bins.end()) {
-        FILE *f = fopen(fno.c_str(), "w");
-        if (!f) throw "Cannot open file " + fno + " for writing";
-        it = tmp_bins.emplace(fno, f).first;
-      }
-      fputs(h.to_bed(false).c_str(), it->second);
-      fputs("\n", it->second);
-      lens[fno]++;
-      nhits++;
-      total_nhits++;
+      order_sides(h);
+      const std::string key = output_dir + "/tmp_" + std::to_string(group_of[h.query->name]) + "_" +
+                              std::to_string(group_of[h.ref->name]) + ".tmp";
+      group_lines[key].push_back(h.to_bed(false));
     }
-    fprintf(log, "\rRead %10d alignments in %s         ", nhits, file.c_str());
+    total += count;
+    fprintf(log, "\rRead %10d alignments in %s         ", count, file.c_str());
   }
-  fprintf(log, "\nRead total %d alignments\n", total_nhits);
+  fprintf(log, "\nRead total %d alignments\n", total);
 
+  // 2. merge every group; count the hits per complexity class (sqrt of the area, in thousands)
   int max_complexity = 0;
-  std::map<int, int> complexity;
-  for (auto &bin : tmp_bins) {
-    fclose(bin.second);
-    std::ifstream fin(bin.first.c_str());
+  std::map<int, int> per_class;
+  for (auto &g : group_lines) {
     std::vector<Hit> hits;
-    hits.reserve(lens[bin.first]);
-    std::string s;
-    while (std::getline(fin, s)) hits.push_back(Hit::from_bed(s));
-    fin.close();
+    hits.reserve(g.second.size());
+    for (auto &line : g.second) hits.push_back(Hit::from_bed(line));
     if (extend) hits = merge_hits(hits, bp.merge_dist);
+    g.second.clear();
     for (auto &h : hits) {
-      const int c = (int)std::sqrt(double(h.query_end - h.query_start) * double(h.ref_end - h.ref_start));
-      max_complexity = std::max(max_complexity, c);
-      complexity[c / 1000]++;
+      max_complexity = std::max(max_complexity, complexity_of(h));
+      per_class[complexity_class(h)]++;
+      g.second.push_back(h.to_bed(false));
     }
-    FILE *fo = fopen(bin.first.c_str(), "w");
-    for (auto &h : hits) {
-      fputs(h.to_bed(false).c_str(), fo);
-      fputs("\n", fo);
-    }
-    fclose(fo);
   }
   fprintf(log, "\nFinished with sorting\n");
 
-  std::vector<int> next_bin(1, 0);
-  for (int c = 1; c <= max_complexity / 1000; c++) next_bin.push_back((next_bin[c - 1] + complexity[c - 1]) % nbins);
-
-  std::vector<FILE *> fout;
+  // 3. deal: every complexity class goes round the buckets on its own, starting where the class below it stopped
+  //    (src/align_main.cc:147-175), so that each bucket gets its share of cheap and of expensive pairs
+  std::vector<int> next_bucket(1, 0);
+  for (int c = 1; c <= max_complexity / 1000; c++) next_bucket.push_back((next_bucket[(size_t)c - 1] + per_class[c - 1]) % nbins);
+  std::vector<FILE *> out;
   for (int b = 0; b < nbins; b++) {
     char name[64];
     snprintf(name, sizeof name, "/bucket_%04d", b);
     FILE *f = fopen((output_dir + name).c_str(), "w");
     if (!f) throw "Cannot open file " + output_dir + name + " for writing";
-    fout.push_back(f);
+    out.push_back(f);
   }
-  for (auto &bin : tmp_bins) {
-    std::ifstream fin(bin.first.c_str());
-    std::string s;
-    while (std::getline(fin, s)) {
-      Hit h = Hit::from_bed(s);
-      int cx = (int)std::sqrt(double(h.query_end - h.query_start) * double(h.ref_end - h.ref_start));
-      cx /= 1000;
-      const int b = next_bin[cx];
-      next_bin[cx] = (next_bin[cx] + 1) % nbins;
-      if (h.query->is_rc) {
+  for (auto &g : group_lines)
+    for (auto &line : g.second) {
+      Hit h = Hit::from_bed(line);
+      int &turn = next_bucket[(size_t)complexity_class(h)];
+      FILE *f = out[(size_t)turn];
+      turn = (turn + 1) % nbins;
+      if (h.query->is_rc) {  // the reverse strand belongs on the reference side
         std::swap(h.query, h.ref);
         std::swap(h.query_start, h.ref_start);
         std::swap(h.query_end, h.ref_end);
       }
-      fputs(h.to_bed(false).c_str(), fout[b]);  // buffered in blocks of 1000 in the reference: same file content
-      fputs("\n", fout[b]);
+      fputs(h.to_bed(false).c_str(), f);
+      fputs("\n", f);
     }
-  }
-  for (auto f : fout) fclose(f);
-  for (auto &s : tmp_bins) unlink(s.first.c_str());
+  for (auto f : out) fclose(f);
 }
 
 }  // namespace sdfh

@@ -1,253 +1,271 @@
-// Seed anchors and sparse chaining (restates reference src/chain.cc:24-199 and the priority-search
-// "segment tree" of src/segment.{h,tpp}, whose tie-breaking decides which predecessor a chain takes).
+// Seed anchors and sparse chaining on the host (what generate_anchors and chain_anchors of the reference compute,
+// src/chain.cc:24-199, with the range-maximum structure of src/segment.{h,tpp}).
+//
+// The stage driver takes its anchors from the GPU (anchors.hip); this file is the host path for what the device
+// kernels do not cover (k > 11, sequences of 4 Mb and more) and for chaining.  Both are checked against the
+// brute-force definitions in tests/bruteforce.py; the reference's own code cannot be compiled here (Boost).
+//
+//   anchors   sort-merge join of the two k-mer lists instead of a hash map of position lists: the reference
+//             k-mers are packed with their positions into 64-bit keys and sorted once; every query k-mer finds its
+//             positions with one binary search, in ascending order, which is the order the reference visits them in.
+//   chaining  a sweep over the anchors' start and end points in query order with a range-maximum structure over the
+//             reference end points.  WHICH of several equally good predecessors an anchor gets is decided by that
+//             structure's shape and update rules (src/segment.tpp:62,89,128), so the structure here is the same
+//             priority search tree -- flat arrays, no recursion -- and its choices are the reference's.
 #include <algorithm>
-#include <cassert>
-#include <cctype>
 #include <climits>
 #include <cstdlib>
-#include <list>
-#include <unordered_map>
 
 #include "sedef_host.h"
 
 namespace sdfh {
 
-std::vector<Anchor> generate_anchors(const std::string &query, const std::string &ref, const Hit &orig,
-                                     int kmer_size) {  // src/chain.cc:24-101
-  const uint32_t MASK = (1u << (2 * kmer_size)) - 1;
-  std::unordered_map<uint32_t, std::vector<int>> ref_hashes;  // positions in ascending order
-  int last_n = -kmer_size;
-  uint32_t h = 0;
-  for (int i = 0; i < (int)ref.size(); i++) {
-    if (toupper(ref[i]) == 'N') last_n = i;
-    h = ((h << 2) | (uint32_t)hash_dna(ref[i])) & MASK;
-    if (i < kmer_size - 1) continue;
-    if (last_n >= (i - kmer_size + 1)) continue;
-    ref_hashes[h].push_back(i - kmer_size + 1);
-  }
-
-  std::vector<int> slide(query.size() + ref.size(), -1);
-  std::vector<Anchor> anchors;
-  const bool same_chr = orig.query->name == orig.ref->name && orig.query->is_rc == orig.ref->is_rc;
-
-  last_n = -kmer_size, h = 0;
-  for (int i = 0; i < (int)query.size(); i++) {
-    if (toupper(query[i]) == 'N') last_n = i;
-    h = ((h << 2) | (uint32_t)hash_dna(query[i])) & MASK;
-    if (i < kmer_size - 1) continue;
-    if (last_n >= (i - kmer_size + 1)) continue;
-    auto it = ref_hashes.find(h);
-    if (it == ref_hashes.end() || it->second.size() >= 1000) continue;
-    const int q = i - kmer_size + 1;
-    const int off = (int)query.size();
-    for (int r : it->second) {
-      if (same_chr && abs(orig.ref_start + r - (orig.query_start + q)) <= kmer_size) continue;
-      const int d = off + r - q;
-      if (q >= slide[d]) {
-        bool has_u = false;  // "any uppercase base": the reference accumulates into a bool
-        int len;
-        for (len = 0; q + len < (int)query.size() && r + len < (int)ref.size(); len++) {
-          if (toupper(query[q + len]) == 'N' || toupper(ref[r + len]) == 'N') break;
-          if (toupper(query[q + len]) != toupper(ref[r + len])) break;
-          has_u = has_u || isupper((unsigned char)query[q + len]) || isupper((unsigned char)ref[r + len]);
-        }
-        if (len >= kmer_size) {
-          anchors.push_back(Anchor{q, r, len, has_u ? 1 : 0});
-          slide[d] = q + len;
-        }
-      }
+// ---- anchors ---------------------------------------------------------------------------------------------
+namespace {
+// the sequence in upper case and the running count of upper-case input letters
+struct ScannedSeq {
+  std::string up;
+  std::vector<int> upper_before;  // upper_before[i] = upper-case letters among the first i bases
+  explicit ScannedSeq(const std::string &s) : up(s.size(), ' '), upper_before(s.size() + 1, 0) {
+    for (size_t i = 0; i < s.size(); i++) {
+      const unsigned char c = (unsigned char)s[i];
+      up[i] = (char)toupper(c);
+      upper_before[i + 1] = upper_before[i] + (c >= 'A' && c <= 'Z');
     }
   }
-  return anchors;
-}
-
-namespace {
-const int TREE_MIN = INT_MIN;
-
-struct Coor {  // src/chain.cc:106-110
-  std::pair<int, int> x;
-  int score, pos;
-  bool operator<(const Coor &o) const { return x < o.x; }
 };
 
-// Priority search tree over the anchors' reference end points (src/segment.tpp).  The array layout
-// (heap indices), the split keys `h`, the "best active point" slot `p` of every node and the order of
-// the comparisons are what make rmq's answer unique among equal scores, so they are kept as they are.
-struct PrioTree {
-  struct Node {
-    int p = -1, a = -1;
-    std::pair<int, int> h;
-  };
-  std::vector<Node> tree;
-  std::vector<Coor> &pts;
+// calls f(position, kmer) for every k-mer window without an N, in ascending position: the rolling 2-bit hash and the
+// position of the last N (src/chain.cc:29-39, :49-58)
+template <typename F>
+void for_each_kmer(const std::string &s, int k, F f) {
+  const uint32_t mask = (uint32_t)((1ull << (2 * k)) - 1);
+  uint32_t h = 0;
+  int last_n = -k;
+  for (int i = 0; i < (int)s.size(); i++) {
+    if (toupper((unsigned char)s[i]) == 'N') last_n = i;
+    h = ((h << 2) | (uint32_t)hash_dna(s[i])) & mask;
+    if (i >= k - 1 && last_n < i - k + 1) f(i - k + 1, h);
+  }
+}
+}  // namespace
 
-  explicit PrioTree(std::vector<Coor> &a) : pts(a) {
-    std::sort(pts.begin(), pts.end());
-    const unsigned n1 = (unsigned)pts.size() - 1u;
-    // 1 << (32 - clz(n-1)); clz(0) is taken as 32 (lzcnt), i.e. one point -> size 1
+std::vector<Anchor> generate_anchors(const std::string &query, const std::string &ref, const Hit &orig, int kmer_size) {
+  std::vector<uint64_t> rk;  // (k-mer << 32) | position
+  rk.reserve(ref.size());
+  for_each_kmer(ref, kmer_size, [&](int pos, uint32_t h) { rk.push_back(((uint64_t)h << 32) | (uint32_t)pos); });
+  std::sort(rk.begin(), rk.end());
+
+  const ScannedSeq Q(query), R(ref);
+  const int qn = (int)query.size(), rn = (int)ref.size();
+  // covered[d]: first query position of diagonal d (= qn + r - q) not yet inside an anchor (src/chain.cc:42,70-72)
+  std::vector<int> covered((size_t)qn + rn, -1);
+  const bool same_chr = orig.query->name == orig.ref->name && orig.query->is_rc == orig.ref->is_rc;
+  const int self_shift = orig.ref_start - orig.query_start;  // diagonal of "the same genome position" (:67-69)
+  std::vector<Anchor> out;
+  for_each_kmer(query, kmer_size, [&](int q, uint32_t h) {
+    auto lo = std::lower_bound(rk.begin(), rk.end(), (uint64_t)h << 32);
+    auto hi = lo;
+    while (hi != rk.end() && (*hi >> 32) == h) ++hi;
+    if (lo == hi || hi - lo >= 1000) return;  // frequent k-mers are not seeds (:61)
+    for (auto it = lo; it != hi; ++it) {
+      const int r = (int)(uint32_t)*it;
+      if (same_chr && abs(self_shift + r - q) <= kmer_size) continue;
+      int &cov = covered[(size_t)(qn + r - q)];
+      if (q < cov) continue;
+      int len = 0;  // maximal exact match, case-insensitive, stopping at an N (:76-85)
+      while (q + len < qn && r + len < rn && Q.up[q + len] == R.up[r + len] && Q.up[q + len] != 'N') ++len;
+      if (len < kmer_size) continue;
+      const bool any_upper = Q.upper_before[q + len] - Q.upper_before[q] + R.upper_before[r + len] - R.upper_before[r] > 0;
+      out.push_back(Anchor{q, r, len, any_upper ? 1 : 0});  // (the reference adds flags into a bool: 0 or 1, :74,84)
+      cov = q + len;
+    }
+  });
+  return out;
+}
+
+// ---- chaining --------------------------------------------------------------------------------------------
+namespace {
+const int kInactive = INT_MIN;
+
+inline int64_t key_of(int coord, int idx) { return (int64_t)coord * ((int64_t)1 << 32) + idx; }
+
+// Priority search tree over points sorted by key: node i covers a range of points, `reach[i]` is the largest key of
+// that range, leaves hold one point, and `top[i]` names the leaf of the best active point below i that no ancestor
+// has claimed.  Heap layout, split rule and the three tie rules are those of src/segment.tpp.
+class RangeMax {
+ public:
+  std::vector<int64_t> key;  // per point, ascending
+  std::vector<int> score;    // per point; kInactive while not active
+  explicit RangeMax(std::vector<int64_t> sorted_keys) : key(std::move(sorted_keys)), score(key.size(), kInactive) {
+    const int n = (int)key.size();
     int bits = 0;
-    for (unsigned v = n1; v; v >>= 1) bits++;
-    const int size = pts.empty() ? 1 : (1 << bits);
-    tree.resize((size_t)size << 1);
-    int tree_i = 0;
-    build(0, 0, (int)pts.size(), tree_i);
-  }
-
-  int build(int i, int s, int e, int &tree_i) {  // src/segment.tpp:172-192
-    if (i >= (int)tree.size()) return -1;
-    if (s + 1 == e) {
-      tree[i].p = -1;
-      tree[i].a = tree_i;
-      tree[i].h = pts[tree_i].x;
-      pts[tree_i].score = TREE_MIN;
-      tree_i++;
-      return i;
-    }
-    const int bnd = (s + e + 1) / 2;
-    const int a = build(2 * i + 1, s, bnd, tree_i);
-    const int b = build(2 * i + 2, bnd, e, tree_i);
-    tree[i].p = -1;
-    tree[i].a = -1;
-    tree[i].h = tree[2 * i + 1 + (2 * i + 2 < (int)tree.size())].h;
-    return std::max(a, std::max(i, b));
-  }
-
-  int rmq(const std::pair<int, int> &p, const std::pair<int, int> &q, int i) const {  // :29-66
-    if (i >= (int)tree.size()) return -1;
-    if (tree[i].a != -1) {
-      return (p <= pts[tree[i].a].x && pts[tree[i].a].x <= q) ? i : -1;
-    }
-    const int pv = tree[i].p;
-    if (pv == -1) return -1;
-    if (p <= pts[tree[pv].a].x && pts[tree[pv].a].x <= q) return pv;
-    if (q <= tree[2 * i + 1].h) return rmq(p, q, 2 * i + 1);
-    if (p > tree[2 * i + 1].h) return rmq(p, q, 2 * i + 2);
-    const int m1 = rmq(p, q, 2 * i + 1);
-    const int m2 = rmq(p, q, 2 * i + 2);
-    if (m1 == -1) return m2;
-    if (m2 == -1) return m1;
-    return pts[tree[m1].a].score >= pts[tree[m2].a].score ? m1 : m2;
-  }
-  int rmq(const std::pair<int, int> &p, const std::pair<int, int> &q) const {
-    const int i = rmq(p, q, 0);
-    return i == -1 ? -1 : tree[i].a;
-  }
-
-  int find_leaf(const std::pair<int, int> &q) const {
-    int leaf = 0;
-    while (leaf < (int)tree.size() && (tree[leaf].a == -1 || q != pts[tree[leaf].a].x))
-      leaf = 2 * leaf + 1 + (q > tree[2 * leaf + 1].h);
-    return leaf;
-  }
-
-  void activate(const std::pair<int, int> &q, int score) {  // :76-103
-    int leaf = find_leaf(q);
-    pts[tree[leaf].a].score = score;
-    for (int i = 0; i < (int)tree.size();) {
-      if (tree[i].p == -1 || pts[tree[leaf].a].score >= pts[tree[tree[i].p].a].score) std::swap(tree[i].p, leaf);
-      if (leaf == -1) break;
-      i = 2 * i + 1 + (pts[tree[leaf].a].x > tree[2 * i + 1].h);
+    for (unsigned v = (unsigned)n - 1u; n > 0 && v; v >>= 1) bits++;
+    const int size = 2 << (n > 0 ? bits : 0);  // twice the next power of two (src/segment.tpp:18-19)
+    reach.assign((size_t)size, 0);
+    point.assign((size_t)size, -1);
+    top.assign((size_t)size, -1);
+    // node i covers [lo, hi); children split at (lo + hi + 1) / 2 (src/segment.tpp:184)
+    std::vector<int> lo((size_t)size, 0), hi((size_t)size, 0);
+    if (n > 0) hi[0] = n;
+    for (int i = 0; i < size; i++) {
+      if (hi[i] <= lo[i]) continue;
+      reach[i] = key[(size_t)hi[i] - 1];
+      if (hi[i] - lo[i] == 1) {
+        point[i] = lo[i];
+        continue;
+      }
+      const int mid = (lo[i] + hi[i] + 1) / 2;
+      lo[2 * i + 1] = lo[i];
+      hi[2 * i + 1] = mid;
+      lo[2 * i + 2] = mid;
+      hi[2 * i + 2] = hi[i];
     }
   }
 
-  void deactivate(const std::pair<int, int> &q) {  // :105-146
-    int leaf = find_leaf(q);
-    pts[tree[leaf].a].score = TREE_MIN;
-    for (int i = 0; i < (int)tree.size();) {
-      if (tree[i].p == -1) break;
-      if (tree[i].p == leaf) {
-        if (tree[i].a != -1) {
-          tree[i].p = -1;
-        } else if (2 * i + 2 < (int)tree.size() && tree[2 * i + 2].p != -1 &&
-                   (tree[2 * i + 1].p == -1 ||
-                    pts[tree[tree[2 * i + 2].p].a].score > pts[tree[tree[2 * i + 1].p].a].score)) {
-          tree[i].p = leaf = tree[2 * i + 2].p;
-          i = 2 * i + 2;
+  // point with the largest score among the active points with lo <= key <= hi, or -1.  Among equal scores: a
+  // subtree's own top before anything below it, the left subtree before the right one (src/segment.tpp:29-66).
+  int best_in(int64_t lo, int64_t hi) const {
+    int best_leaf = -1;
+    stack_.clear();
+    stack_.push_back(0);
+    while (!stack_.empty()) {
+      const int i = stack_.back();
+      stack_.pop_back();
+      int cand = -1;
+      if (point[i] != -1) {
+        if (lo <= key[point[i]] && key[point[i]] <= hi) cand = i;
+      } else if (top[i] != -1) {
+        const int64_t tk = key[point[top[i]]];
+        if (lo <= tk && tk <= hi) {
+          cand = top[i];
+        } else if (hi <= reach[2 * i + 1]) {
+          stack_.push_back(2 * i + 1);
+        } else if (lo > reach[2 * i + 1]) {
+          stack_.push_back(2 * i + 2);
         } else {
-          tree[i].p = leaf = tree[2 * i + 1].p;
-          i = 2 * i + 1;
+          stack_.push_back(2 * i + 2);  // (popped after the left one: candidates arrive left to right)
+          stack_.push_back(2 * i + 1);
         }
+      }
+      if (cand != -1 && (best_leaf == -1 || score[point[cand]] > score[point[best_leaf]])) best_leaf = cand;
+    }
+    return best_leaf == -1 ? -1 : point[best_leaf];
+  }
+
+  void activate(int64_t k, int s) {  // src/segment.tpp:76-103: a newcomer takes the place of an equal score
+    int leaf = leaf_of(k);
+    score[point[leaf]] = s;
+    for (int i = 0; i < (int)top.size() && leaf != -1;) {
+      if (top[i] == -1 || score[point[leaf]] >= score[point[top[i]]]) std::swap(top[i], leaf);
+      if (leaf == -1) break;
+      i = 2 * i + 1 + (key[point[leaf]] > reach[2 * i + 1]);
+    }
+  }
+
+  void deactivate(int64_t k) {  // src/segment.tpp:105-146: the hole is filled from below, left child on equal scores
+    int leaf = leaf_of(k);
+    score[point[leaf]] = kInactive;
+    for (int i = 0; i < (int)top.size() && top[i] != -1;) {
+      if (top[i] != leaf) {
+        i = 2 * i + 1 + (k > reach[2 * i + 1]);
+      } else if (point[i] != -1) {
+        top[i] = -1;
       } else {
-        i = 2 * i + 1 + (q > tree[2 * i + 1].h);
+        const int l = 2 * i + 1, r = 2 * i + 2;
+        const bool right = r < (int)top.size() && top[r] != -1 &&
+                           (top[l] == -1 || score[point[top[r]]] > score[point[top[l]]]);
+        top[i] = leaf = top[right ? r : l];
+        i = right ? r : l;
       }
     }
   }
+
+ private:
+  int leaf_of(int64_t k) const {
+    int i = 0;
+    while (point[i] == -1 || key[point[i]] != k) i = 2 * i + 1 + (k > reach[2 * i + 1]);
+    return i;
+  }
+  std::vector<int64_t> reach;
+  std::vector<int> point, top;
+  mutable std::vector<int> stack_;
 };
 }  // namespace
 
 std::pair<std::vector<int>, std::vector<std::pair<int, bool>>> chain_anchors(std::vector<Anchor> &anchors,
                                                                             const Params &P) {
-  // src/chain.cc:103-199
-  std::vector<Coor> xs, ys;
-  xs.reserve(2 * anchors.size());
-  ys.reserve(anchors.size());
-  int max_q = 0, max_r = 0;
-  for (int i = 0; i < (int)anchors.size(); i++) {
-    const Anchor &a = anchors[i];
-    xs.push_back({{a.q, i}, TREE_MIN, i});
-    xs.push_back({{a.q + a.l, i}, TREE_MIN, i});
-    ys.push_back({{a.r + a.l - 1, i}, TREE_MIN, i});
-    max_q = std::max(max_q, a.q + a.l);
-    max_r = std::max(max_r, a.r + a.l);
-  }
+  const int n = (int)anchors.size();
   std::vector<int> path;
-  std::vector<std::pair<int, bool>> boundaries{{0, 0}};
-  if (anchors.empty()) return {path, boundaries};
+  std::vector<std::pair<int, bool>> boundaries{{0, false}};
+  if (n == 0) return {path, boundaries};
 
-  std::sort(xs.begin(), xs.end());
-  PrioTree tree(ys);
-
-  std::vector<int> prev(anchors.size(), -1);
-  std::vector<std::pair<int, int>> dp(anchors.size());
-  for (int i = 0; i < (int)dp.size(); i++) dp[i] = {0, i};
-  int deactivate_bound = 0;
-  for (int xi = 0; xi < (int)xs.size(); xi++) {
-    const int i = xs[xi].x.second;
+  // sweep events in (query coordinate, anchor) order: an anchor's start looks for a predecessor, its end makes it
+  // available as one (src/chain.cc:112-135)
+  std::vector<int64_t> events, ends_r((size_t)n);
+  events.reserve(2 * (size_t)n);
+  int far_q = 0, far_r = 0;
+  for (int i = 0; i < n; i++) {
     const Anchor &a = anchors[i];
-    if (xs[xi].x.first == a.q) {  // start point
-      while (deactivate_bound < xi) {
-        const int t = xs[deactivate_bound].x.second;
-        if (xs[deactivate_bound].x.first == anchors[t].q + anchors[t].l) {  // an end point
-          if (a.q - (anchors[t].q + anchors[t].l) <= P.max_chain_gap) break;
-          tree.deactivate({anchors[t].r + anchors[t].l - 1, t});
-        }
-        deactivate_bound++;
+    events.push_back(key_of(a.q, i));
+    events.push_back(key_of(a.q + a.l, i));
+    ends_r[(size_t)i] = key_of(a.r + a.l - 1, i);
+    far_q = std::max(far_q, a.q + a.l);
+    far_r = std::max(far_r, a.r + a.l);
+  }
+  std::sort(events.begin(), events.end());
+  std::vector<int64_t> sorted_r = ends_r;
+  std::sort(sorted_r.begin(), sorted_r.end());
+  RangeMax tree(sorted_r);
+  // (point of the tree -> anchor: the low half of its key)
+
+  std::vector<int> best(n, 0), pred(n, -1);
+  size_t expire = 0;  // events before this one have been checked for expiry
+  for (size_t e = 0; e < events.size(); e++) {
+    const int i = (int)(uint32_t)events[e];
+    const int coord = (int)(events[e] >> 32);
+    const Anchor &a = anchors[i];
+    if (coord != a.q) {  // end point; stored score = chain score minus the way to the far corner (:175-176)
+      tree.activate(ends_r[(size_t)i], best[i] - ((far_q + 1 - (a.q + a.l)) + (far_r + 1 - (a.r + a.l))));
+      continue;
+    }
+    // anchors that ended more than max_chain_gap before this start are no predecessors any more (:142-152)
+    for (; expire < e; expire++) {
+      const int t = (int)(uint32_t)events[expire];
+      const int tend = anchors[t].q + anchors[t].l;
+      if ((int)(events[expire] >> 32) != tend) continue;  // a start point
+      if (a.q - tend <= P.max_chain_gap) break;
+      tree.deactivate(ends_r[(size_t)t]);
+    }
+    const int w = P.match_chain_score * a.has_u + (P.match_chain_score / 2) * (a.l - a.has_u);
+    best[i] = w;
+    const int pt = tree.best_in(key_of(a.r - P.max_chain_gap, 0), key_of(a.r - 1, n));
+    if (pt != -1 && tree.score[(size_t)pt] != kInactive) {
+      const int j = (int)(uint32_t)tree.key[(size_t)pt];
+      const Anchor &p = anchors[j];
+      const int with = w + best[j] - ((a.q - (p.q + p.l)) + (a.r - (p.r + p.l)));
+      if (with > 0) {
+        best[i] = with;
+        pred[i] = j;
       }
-      const int w = P.match_chain_score * a.has_u + (P.match_chain_score / 2) * (a.l - a.has_u);
-      int j = tree.rmq({a.r - P.max_chain_gap, 0}, {a.r - 1, (int)anchors.size()});
-      if (j != -1 && ys[j].score != TREE_MIN) {
-        j = ys[j].pos;
-        const Anchor &p = anchors[j];
-        const int gap = (a.q - (p.q + p.l) + a.r - (p.r + p.l));
-        if (w + dp[j].first - gap > 0) {
-          dp[i].first = w + dp[j].first - gap;
-          prev[i] = j;
-        } else {
-          dp[i].first = w;
-        }
-      } else {
-        dp[i].first = w;
-      }
-    } else {  // end point: the anchor becomes available as a predecessor
-      const int gap = (max_q + 1 - (a.q + a.l) + max_r + 1 - (a.r + a.l));
-      tree.activate({a.r + a.l - 1, i}, dp[i].first - gap);
     }
   }
-  std::sort(dp.begin(), dp.end(), std::greater<std::pair<int, int>>());
-
-  path.reserve(anchors.size());
-  std::vector<char> used(anchors.size(), 0);
-  for (auto &m : dp) {
-    int maxi = m.second;
-    if (used[maxi]) continue;
-    int has_u = 0;
-    while (maxi != -1 && !used[maxi]) {
-      path.push_back(maxi);
-      has_u += anchors[maxi].has_u;
-      used[maxi] = true;
-      maxi = prev[maxi];
+  // chains, best first (ties: the later anchor first), each from its last anchor backwards until it meets an anchor
+  // an earlier chain took (src/chain.cc:179-197)
+  std::vector<int> order(n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int x, int y) { return best[x] != best[y] ? best[x] > best[y] : x > y; });
+  path.reserve((size_t)n);
+  std::vector<char> taken(n, 0);
+  for (int head : order) {
+    if (taken[head]) continue;
+    int upper = 0;
+    for (int i = head; i != -1 && !taken[i]; i = pred[i]) {
+      path.push_back(i);
+      upper += anchors[i].has_u;
+      taken[i] = 1;
     }
-    boundaries.push_back({(int)path.size(), has_u});  // int -> bool: "any uppercase anchor"
+    boundaries.push_back({(int)path.size(), upper != 0});
   }
   return {path, boundaries};
 }

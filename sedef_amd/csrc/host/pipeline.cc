@@ -98,6 +98,7 @@ class GpuProvider : public DpProvider {
     raw.first_task.assign(reqs.size() + 1, 0);
     raw.off.clear();
     raw.cnt.clear();
+    raw.match.clear();
     if (reqs.empty()) return true;
     std::vector<TaskRef> tr;
     std::vector<uint8_t> pool;
@@ -141,9 +142,11 @@ class GpuProvider : public DpProvider {
     const auto tp2 = std::chrono::steady_clock::now();
     raw.off.resize(tr.size());
     raw.cnt.resize(tr.size());
+    raw.match.resize(tr.size());
     for (size_t k = 0; k < tr.size(); k++) {
       raw.off[k] = res[k].cigar_off;
       raw.cnt[k] = (int32_t)res[k].n_cigar;
+      raw.match[k] = res[k].matches;
     }
     raw.words = std::move(cig);
     t_pack += std::chrono::duration<double>(tp1 - tp0).count();
@@ -242,7 +245,11 @@ class TestProvider : public DpProvider {
 
 Cigar DpProvider::Raw::cigar(size_t req) const {
   Cigar c;
-  for (size_t k = first_task[req]; k < first_task[req + 1]; k++) append_ops(c, words.get() + off[k], cnt[k]);
+  c.matches = 0;
+  for (size_t k = first_task[req]; k < first_task[req + 1]; k++) {
+    append_ops(c, words.get() + off[k], cnt[k]);
+    c.matches += match[k];
+  }
   return c;
 }
 
@@ -277,7 +284,21 @@ struct PairJob::PathState {
 };
 
 PairJob::PairJob(const std::string &query, const std::string &ref, const Hit &orig, const Params &p)
-    : query_(query), ref_(ref), orig_(orig), p_(p) {}
+    : query_(query), ref_(ref), orig_(orig), p_(p) {
+  auto plain = [](const std::string &s) {
+    static const struct Tab {
+      bool ok[256];
+      Tab() {
+        for (auto &b : ok) b = false;
+        for (const char *c = "ACGTNacgtn"; *c; ++c) ok[(unsigned char)*c] = true;
+      }
+    } tab;
+    for (unsigned char c : s)
+      if (!tab.ok[c]) return false;
+    return true;
+  };
+  exact_ = plain(query) && plain(ref);
+}
 
 void PairJob::stage_start(std::vector<DpRequest> &out) {  // src/chain.cc:203-258
   query_ptr_ = std::make_shared<Sequence>("QRY", query_);
@@ -318,6 +339,7 @@ void PairJob::stage_chain_finish(const std::vector<Cigar> &results) {
   DpSession rep;
   rep.recording = false;
   rep.results = &results;
+  rep.codes_are_exact = exact_;
   for (size_t k = 0; k < hits_.size(); k++) {
     hits_[k].aln = Alignment(query_, ref_, anchors_, guides_[k], rep);
     update_from_alignment(hits_[k]);
@@ -439,6 +461,7 @@ std::vector<DpRequest> PairJob::advance(const std::vector<Cigar> &results) {
         DpSession rep;
         rep.recording = false;
         rep.results = &have;
+        rep.codes_are_exact = exact_;
         ps.result.aln = Alignment(qseq, rseq, ps.guide, p_.refine_side_align, rep);
         update_from_alignment(ps.result);
         ps.finished = true;
@@ -450,6 +473,7 @@ std::vector<DpRequest> PairJob::advance(const std::vector<Cigar> &results) {
         DpSession rep;
         rep.recording = false;
         rep.results = &have;
+        rep.codes_are_exact = exact_;
         prev.aln.merge(cur.aln, qseq, rseq, rep);
         update_from_alignment(prev);
         ps.merging = false;
@@ -475,6 +499,7 @@ std::vector<DpRequest> PairJob::advance(const std::vector<Cigar> &results) {
             DpSession rep;
             rep.recording = false;
             rep.results = &none;
+            rep.codes_are_exact = exact_;
             prev.aln.merge(cur.aln, qseq, rseq, rep);
             update_from_alignment(prev);
             ps.pi++;

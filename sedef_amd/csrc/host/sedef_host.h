@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <deque>
 #include <functional>
+#include <algorithm>
 #include <initializer_list>
 #include <map>
 #include <memory>
@@ -29,6 +30,9 @@ class Cigar {
   typedef std::pair<char, int> value_type;
   typedef value_type *iterator;
   typedef const value_type *const_iterator;
+  // number of match columns ('|' of the reference's alignment string) among the M runs, when the producer knows it
+  // (the device's per-task counter, summed over a request's tasks); -1: unknown, counted on the host when needed
+  int matches = -1;
   Cigar() {}
   Cigar(std::initializer_list<value_type> il) : v_(il) {}
   iterator begin() { return v_.data() + head_; }
@@ -106,6 +110,7 @@ class DpProvider {
     std::unique_ptr<uint32_t[]> words;
     std::vector<int64_t> off;        // per task: first word
     std::vector<int32_t> cnt;        // per task: number of words
+    std::vector<int32_t> match;      // per task: match columns (sdf_result.matches)
     std::vector<size_t> first_task;  // per request (+1): its tasks are [first_task[r], first_task[r+1])
     Cigar cigar(size_t req) const;
   };
@@ -145,7 +150,12 @@ struct DpSession {
   std::vector<DpRequest> *requests = nullptr;  // recording: appended to
   const std::vector<Cigar> *results = nullptr; // replay: consumed in order
   size_t cursor = 0;
+  // true: both sequences of the pair hold nothing but ACGTN (either case), so a match on the DP's codes is a match of
+  // the reference's character comparison (src/align.cc:29-35) and the device's match counter can be taken as it is
+  bool codes_are_exact = false;
   Cigar align(const std::string &q_codes, const std::string &t_codes);
+  // align_helper on two ranges of raw FASTA characters (mapped through align_dna here)
+  Cigar align_ranges(const char *q, int qlen, const char *t, int tlen);
 };
 
 // ---- sequences / hits ----------------------------------------------------------------------------
@@ -157,39 +167,43 @@ struct Sequence {  // reference: src/hash.h:51-57, src/hash.cc:104-109
 
 struct Hit;
 
-class Alignment {  // reference: src/align.h:32-103
+// The alignment of a query range [start_a, end_a) with a reference range [start_b, end_b) of one candidate pair
+// (reference: class Alignment, src/align.h:32-103, src/align.cc).
+//
+// The reference object owns copies of both substrings and three per-column strings (align_a / align_b / alignment) that
+// every operation rebuilds.  Here an alignment is its run-length CIGAR plus ONE counter -- the match columns -- over
+// sequences it only points to: the other counters of populate_nice_alignment (src/align.cc:274-315) follow from the
+// runs (M columns - matches = mismatches; non-M runs = gaps, zero-length ones included; their lengths = gap bases), the
+// match counter arrives with the CIGAR from the device (sdf_result.matches) and is corrected by comparing bases only
+// where an operation cuts through columns (trims, merges).  Coordinates index the sequences `seq_a` / `seq_b` point to.
+class Alignment {
  public:
-  std::string chr_a;
   int start_a = 0, end_a = 0;
-  std::string chr_b;
   int start_b = 0, end_b = 0;
-  std::string a, b;
-  std::string align_a, align_b, alignment;
   Cigar cigar;
   struct AlignmentError {
     int gaps, gap_bases, mismatches, matches;
   } error = {0, 0, 0, 0};
 
   Alignment();
+  // Alignment(fa, fb): one DP over two whole strings (src/align.cc:76-88)
   Alignment(const std::string &fa, const std::string &fb, DpSession &dp);
+  // a given CIGAR string over two whole strings (src/align.cc:90-105)
   Alignment(const std::string &fa, const std::string &fb, const std::string &cigar);
+  // guide of refined chains + side extension (src/align.cc:107-197)
   Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Hit> &guide, int side,
             DpSession &dp);
+  // chain of seed anchors (src/align.cc:199-270)
   Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Anchor> &guide,
             const std::vector<int> &guide_idx, DpSession &dp);
 
-  void populate_nice_alignment();
-  void trim();
-  void trim_front();
-  void trim_back();
-  void prepend_cigar(const Cigar &app);
-  void append_cigar(const Cigar &app);
-  void cigar_from_alignment();
-  void swap();
+  // joins `cur`, which starts before this alignment ends, to this one (src/align.cc:505-610)
   void merge(Alignment &cur, const std::string &qstr, const std::string &rstr, DpSession &dp);
+  void trim_front();  // keep the best-scoring suffix of the columns (src/align.cc:343-398)
+  void trim_back();   // keep the best-scoring prefix (src/align.cc:400-456)
 
   std::string cigar_string() const;
-  int span() const { return (int)alignment.size(); }
+  int span() const { return columns_; }  // alignment columns
   int matches() const { return error.matches; }
   int mismatches() const { return error.mismatches; }
   int gap_bases() const { return error.gap_bases; }
@@ -197,6 +211,19 @@ class Alignment {  // reference: src/align.h:32-103
   double gap_error() const;
   double mismatch_error() const;
   double total_error() const { return mismatch_error() + gap_error(); }
+
+ private:
+  void recount(int matches);  // counters and column count from the runs + the match counter
+  void append(const Cigar &piece);   // run-merging concatenation (src/align.cc:469-478); adds piece.matches
+  void prepend(const Cigar &piece);  // (src/align.cc:458-467)
+  void fill_gap(int qfrom, int qgap, int rfrom, int rgap, DpSession &dp);
+  int cut_tail(int trim, bool by_query);  // drop columns from the end until `trim` bases of one sequence are gone
+  int cut_head(int trim, bool by_query);
+  void normalise();                       // what rebuilding the CIGAR from columns does (src/align.cc:480-501)
+  const char *seq_a = nullptr, *seq_b = nullptr;  // base x of the query / reference is seq_a[x] / seq_b[x]
+  int len_a = 0, len_b = 0;                       // their lengths (side extension is clipped to them)
+  int columns_ = 0;
+  int matches_ = 0;
 };
 
 struct Hit {  // reference: src/hit.h:23-51
@@ -289,6 +316,7 @@ class PairJob {
   std::vector<size_t> wait_counts_;  // requests issued per waiting path, in order
   std::vector<int> wait_paths_;
   std::vector<Hit> final_hits_;
+  bool exact_ = false;  // the pair's sequences are plain ACGTN: device match counters are exact (DpSession)
 };
 
 // ---- `align bucket` (reference: src/align_main.cc:38-198, src/merge.cc, src/search_main.cc:93-120) -----------

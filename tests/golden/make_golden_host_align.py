@@ -64,6 +64,10 @@ def scoring_and_chunk_cases(ref):
             cig, cnt = ref.alignment_pair(a, b)
             scored.append(dict(a=a, b=b, scoring=list(sc), cigar=cig, counts=cnt))
     ref.set_scoring()
+    far_equal = []
+    for gap in (1001, 1200, 2500, 1000):
+        q, r, spec, side = hostgen.far_equal_case(rng, gap)
+        far_equal.append(dict(q=q, r=r, spec=spec, side=side, expect=ref.guide_from_chains(q, r, spec, side)))
     chunked = []
     for (seed, n, d) in ((5, 60050, 0.03), (6, 60200, 0.002)):
         a, b = hostgen.chunk_case(seed, n, d)
@@ -71,7 +75,7 @@ def scoring_and_chunk_cases(ref):
         chunked.append(dict(seed=seed, n=n, d=d, len_a=len(a), len_b=len(b), counts=cnt, cigar_len=len(cig),
                             cigar_sha256=hashlib.sha256(cig.encode()).hexdigest(), cigar_head=cig[:60],
                             cigar_tail=cig[-60:]))
-    return scored, chunked
+    return scored, chunked, far_equal
 
 
 def main():
@@ -94,11 +98,11 @@ def main():
         lines, spec = hostgen.merge_case(rng)
         merges.append(dict(lines=lines, expect=ref.merge(spec, 250)))
     fastas, extends, sequences = io_cases(ref)
-    scored, chunked = scoring_and_chunk_cases(ref)
+    scored, chunked, far_equal = scoring_and_chunk_cases(ref)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_align_kat.json.gz")
     blob = json.dumps(dict(source="reference src/align.cc + src/hit.cc via oracle/_ref/libref_align.so",
                            pairs=pairs, guides=guides, merges=merges, fastas=fastas, extends=extends,
-                           sequences=sequences, scored=scored, chunked=chunked), separators=(",", ":")).encode()
+                           sequences=sequences, scored=scored, chunked=chunked, far_equal=far_equal), separators=(",", ":")).encode()
     with gzip.GzipFile(out, "wb", mtime=0) as f:
         f.write(blob)
     print("wrote %s: %d pairs, %d guides, %d bytes" % (out, len(pairs), len(guides), os.path.getsize(out)))

@@ -269,3 +269,15 @@ def chunk_case(seed=5, n=60050, d=0.03):
     low = rng.random(len(a)) < 0.3
     sa = np.where(low, _CODE2CHR[a] + 32, _CODE2CHR[a]).astype(np.uint8).tobytes().decode()
     return sa, _CODE2CHR[b].tobytes().decode()
+
+
+def far_equal_case(rng, gap):
+    """Two chains separated by unrelated stretches of EQUAL length > 1000 in both sequences: the far-gap branch of the
+    reference (src/align.cc:131-139) then pushes a run of length zero, which stays in the CIGAR's run list."""
+    a = rseq(rng, int(rng.integers(300, 600)))
+    b = rseq(rng, int(rng.integers(300, 600)))
+    q = a + rseq(rng, gap) + b
+    r = mut(rng, a, 0.0) + rseq(rng, gap) + mut(rng, b, 0.0)
+    la, lb = len(a), len(b)
+    spec = "0,0,%d|%d,%d,%d" % (la, la + gap, la + gap, lb)
+    return q, r, spec, int(rng.choice([0, 500]))

@@ -50,6 +50,18 @@ def test_chain_merge_guide_to_bed_match_reference_golden(host, oracle_dp, host_g
         assert host.guide_from_chains(c["q"], c["r"], c["spec"], c["side"], test_dp=oracle_dp) == c["expect"]
 
 
+def test_far_gap_of_equal_sides_keeps_its_zero_length_run(host, oracle_dp, host_golden):
+    """qgap == rgap > 1000: the reference's far branch appends a run of length 0 (src/align.cc:135); invisible in a
+    CIGAR string, but it counts as a gap and keeps the M runs on either side from merging ("...300M450M...")."""
+    seen = 0
+    for c in host_golden["far_equal"]:
+        got = host.guide_from_chains(c["q"], c["r"], c["spec"], c["side"], test_dp=oracle_dp)
+        assert got == c["expect"]
+        import re as _re
+        seen += bool(_re.search(r"\d+M\d+M", got))
+    assert seen >= 2
+
+
 def test_alignment_live_vs_reference_classes(host, oracle_dp):
     from oracle.binding import ReferenceAlign
     try:
