@@ -843,22 +843,14 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
             100.0 * std::min(base + n, total) / std::max(total, 1));
   };
 
-  // Output is written in schedule order whatever lane produced it.
+  // Output is written in schedule order whatever lane produced it.  Every lane but the first creates its own device
+  // context (~0.1 s) on its own thread while the first one is already working; the super-batches are handed out as the
+  // lanes ask for them, so a lane that starts late, or cannot get a context at all, just takes fewer.
   nlanes = std::min<int>(nlanes, (int)batches.size());
-  std::vector<std::unique_ptr<DpProvider>> extra;
-  std::vector<DpProvider *> prov{&dp0};
-  for (int l = 1; l < nlanes; l++) {
-    std::unique_ptr<DpProvider> c;
-    try {
-      c = dp0.clone(devices.empty() ? -1 : devices[(size_t)l % devices.size()]);
-    } catch (std::string &) {  // no room for another device context: fewer lanes
-    }
-    if (!c) break;
-    prov.push_back(c.get());
-    extra.push_back(std::move(c));
-  }
-  nlanes = (int)prov.size();
-  std::vector<Acc> acc(std::max(nlanes, 1));
+  std::vector<std::unique_ptr<DpProvider>> extra((size_t)std::max(nlanes, 1));
+  std::vector<DpProvider *> prov((size_t)std::max(nlanes, 1), nullptr);
+  prov[0] = &dp0;
+  std::vector<Acc> acc((size_t)std::max(nlanes, 1));
   if (nlanes <= 1) {
     std::vector<std::string> lines;
     std::vector<int> nhits;
@@ -870,16 +862,27 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     std::mutex mu;
     std::condition_variable cv;
     size_t next_write = 0;
+    std::atomic<size_t> next_batch(0);
     std::string failure;
     bool failed = false;
     std::vector<std::thread> lanes;
     for (int l = 0; l < nlanes; l++)
       lanes.emplace_back([&, l] {
+        if (l > 0) {
+          try {
+            extra[(size_t)l] = dp0.clone(devices.empty() ? -1 : devices[(size_t)l % devices.size()]);
+          } catch (std::string &) {  // no room for another device context: one lane fewer
+          }
+          prov[(size_t)l] = extra[(size_t)l].get();
+          if (!prov[(size_t)l]) return;
+        }
         std::vector<std::string> lines;
         std::vector<int> nhits;
-        for (size_t bi = (size_t)l; bi < batches.size(); bi += (size_t)nlanes) {
+        for (;;) {
+          const size_t bi = next_batch.fetch_add(1);
+          if (bi >= batches.size()) return;
           try {
-            do_batch(batches[bi].first, batches[bi].second, *prov[l], acc[l], lines, nhits);
+            do_batch(batches[bi].first, batches[bi].second, *prov[(size_t)l], acc[(size_t)l], lines, nhits);
           } catch (std::string &e) {
             std::lock_guard<std::mutex> g(mu);
             if (!failed) failure = e.empty() ? std::string("error") : e;
@@ -913,6 +916,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   st.rounds = a.rounds;
   double t_pack = 0, t_call = 0, t_unpack = 0;
   for (DpProvider *d : prov) {
+    if (!d) continue;
     st.dp_tasks += d->tasks;
     st.dp_cells += d->cells;
     t_pack += d->t_pack;

@@ -104,7 +104,6 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   const char *ns = getenv("SDF_NO_STRIPE");
   ctx->no_stripe = ns && ns[0] == '1';
   if (const char *sm = getenv("SDF_STRIPE_MIN")) ctx->stripe_min = std::max(128, atoi(sm));
-  if (const char *hp = getenv("SDF_NO_HI_PRIO")) ctx->no_hi_prio = hp[0] == '1';
   const char *pl = getenv("SDF_PIPELINE");
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
@@ -123,8 +122,7 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (hipStream_t q : {ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
-                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3], ctx->hi_stream[0],
-                        ctx->hi_stream[1], ctx->hi_stream[2], ctx->hi_stream[3]})
+                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3]})
     if (q) (void)hipStreamSynchronize(q);
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
   for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
@@ -136,9 +134,9 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
     b->release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0], ctx->aux_stream[1],
-                        ctx->aux_stream[2], ctx->aux_stream[3], ctx->hi_stream[0], ctx->hi_stream[1],
-                        ctx->hi_stream[2], ctx->hi_stream[3]})
+                        ctx->aux_stream[2], ctx->aux_stream[3]})
     if (s) (void)hipStreamDestroy(s);
+  delete ctx->pool;
   delete ctx->cut;
   ctx->host_plan.release();
   ctx->host_order.release();
@@ -247,17 +245,20 @@ int make_scorek(sdf_ctx *ctx, const sdf_scoring *sc, ScoreK &k, bool &degenerate
 // With nthreads == 0 wait(ci) plans the chunk itself (small batches: nothing to overlap with).
 class ChunkPlanner {
  public:
-  ChunkPlanner(const PlanEnv &env, BatchCut &cut, PlanTask *plan, int32_t *order, int nthreads)
-      : env_(env), cut_(cut), plan_(plan), order_(order), ready_(cut.chunks.size(), 0) {
-    if (nthreads > 0) next_.store(1);  // chunk 0 is planned by the caller of wait(0): no hand-over in front of the GPU's start
-    for (int t = 0; t < nthreads; ++t) workers_.emplace_back([this] { work(); });
+  // nworkers jobs on `pool` (may be null when nworkers == 0)
+  ChunkPlanner(const PlanEnv &env, BatchCut &cut, PlanTask *plan, int32_t *order, WorkerPool *pool, int nworkers)
+      : env_(env), cut_(cut), plan_(plan), order_(order), pool_(nworkers > 0 ? pool : nullptr),
+        ready_(cut.chunks.size(), 0) {
+    if (!pool_) return;
+    next_.store(1);  // chunk 0 is planned by the caller of wait(0): no hand-over in front of the GPU's start
+    for (int t = 0; t < nworkers; ++t) pool_->submit([this] { work(); });
   }
   ~ChunkPlanner() {
     stop_.store(true);
-    for (auto &w : workers_) w.join();
+    if (pool_) pool_->wait_idle();
   }
   void wait(size_t ci) {
-    if (workers_.empty() || ci == 0) {
+    if (!pool_ || ci == 0) {
       plan_chunk(env_, cut_, cut_.chunks[ci], plan_, order_, own_);
       return;
     }
@@ -283,8 +284,8 @@ class ChunkPlanner {
   BatchCut &cut_;
   PlanTask *plan_;
   int32_t *order_;
+  WorkerPool *pool_;
   std::vector<char> ready_;
-  std::vector<std::thread> workers_;
   std::atomic<size_t> next_{0};
   std::atomic<bool> stop_{false};
   std::mutex mu_;
@@ -338,7 +339,14 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   cut.reset();
   {
     const char *msg = nullptr;
-    if (int rc = cut_batch(env, ctx->pipeline, ctx->ws_budget, cut, &msg)) {
+    static const int max_planners = [] {
+      const char *e = getenv("SDF_PLAN_THREADS");
+      return e ? std::max(0, std::min(7, atoi(e))) : 3;
+    }();
+    // (parked threads pay from a few hundred thousand tasks: below, waking them costs more than they save -- measured
+    // on the 100,000-task headline batch: 0.9 ms of planning alone, 2.4 ms with three helpers)
+    if (!ctx->pool && n >= 400000 && max_planners > 0) ctx->pool = new WorkerPool(max_planners);
+    if (int rc = cut_batch(env, ctx->pipeline, ctx->ws_budget, cut, &msg, ctx->pool)) {
       ctx->err = msg ? msg : "invalid batch";
       return rc;
     }
@@ -372,26 +380,19 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   run.ev_begin = next_event(ctx, run.evc);
   hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n);
   SDF_HIP(hipEventRecord(run.ev_begin, st));
-  run.hi_prio = cut.pipelined && run.have_heavy && cut.chunks.size() > 1 && !ctx->no_hi_prio && make_priority_streams(ctx);
   if (cut.pipelined)
     for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream}) SDF_HIP(hipStreamWaitEvent(s, run.ev_begin, 0));
-  if (run.hi_prio)
-    for (hipStream_t s : ctx->hi_stream) SDF_HIP(hipStreamWaitEvent(s, run.ev_begin, 0));
 
   // ---- plan (worker threads, chunk order) and launch (this thread, chunk order) ----
   int rc = SDF_OK;
   float dbg_c = 0.f;
   {
-    static const int max_planners = [] {
-      const char *e = getenv("SDF_PLAN_THREADS");
-      return e ? std::max(0, std::min(16, atoi(e))) : 4;
-    }();
-    // (one worker keeps ahead of the GPU on batches of ordinary size: a chunk of 25,000 tasks is planned in under a
-    // millisecond and runs for five; batches of many small tasks are planned on several)
-    const int nthr = cut.chunks.size() >= 3 && n >= 65536
-                         ? (int)std::min<size_t>(n >= 400000 ? max_planners : std::min(max_planners, 1), cut.chunks.size())
+    // (batches of ordinary size are planned by this thread, a chunk ahead of the GPU: 25,000 tasks take under a
+    // millisecond to plan and five to run; batches of many small tasks are planned on the context's parked threads)
+    const int nthr = ctx->pool && cut.chunks.size() >= 3 && n >= 400000
+                         ? (int)std::min<size_t>(ctx->pool->size(), cut.chunks.size())
                          : 0;
-    ChunkPlanner planner(env, cut, run.plan, run.order, nthr);
+    ChunkPlanner planner(env, cut, run.plan, run.order, ctx->pool, nthr);
     dbg_c = host_ms();
     for (size_t ci = 0; ci < cut.chunks.size() && rc == SDF_OK; ++ci) {
       planner.wait(ci);
@@ -463,7 +464,8 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
       if (tasks[k].tlen > 0) sdf_pack_codes(seq_pool + tasks[k].t_off, tasks[k].tlen, packed + t2[k].t_off);
     }
   };
-  const int nthr = words >= (1u << 18) ? (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  // (at most four: the stage driver runs up to three of these calls at once next to its own worker threads)
+  const int nthr = words >= (1u << 18) ? (int)std::min<unsigned>(4, std::max(1u, std::thread::hardware_concurrency())) : 1;
   {
     // equal shares of words, not of tasks
     std::vector<size_t> cut(nthr + 1, n);
@@ -814,7 +816,8 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   std::vector<PlanTask> plan(np);
   std::vector<int32_t> order(2 * np);
   {
-    ChunkPlanner planner(env, cut, plan.data(), order.data(), nthreads);
+    WorkerPool pool(std::max(nthreads, 1));
+    ChunkPlanner planner(env, cut, plan.data(), order.data(), &pool, nthreads);
     for (size_t ci = 0; ci < cut.chunks.size(); ++ci) planner.wait(ci);
   }
   for (size_t k = 0; k < n * 7; ++k) per_task[k] = -1;

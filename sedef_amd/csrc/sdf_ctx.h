@@ -8,7 +8,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sdf_internal.h"
@@ -83,7 +88,9 @@ struct HostBuf {  // pinned host memory
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
-    const size_t want = bytes + bytes / 8 + 4096;
+    // (pinning is slow -- about a millisecond per 4 MB -- and a stage run sees its batches grow: half as much again as
+    // headroom, so that a context re-pins a few times, not for every batch)
+    const size_t want = bytes + bytes / 2 + 4096;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
     return e;
@@ -99,6 +106,61 @@ struct HostBuf {  // pinned host memory
 
 namespace sdf {
 struct BatchCut;
+
+// A few parked host threads for the planning of a batch (a thread costs ~0.1 ms to start and join, a planning pass over
+// a hundred thousand tasks less than a millisecond: the threads are started once per context).
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n) {
+    for (int t = 0; t < n; ++t) threads_.emplace_back([this] { loop(); });
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      quit_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  int size() const { return (int)threads_.size(); }
+  void submit(std::function<void()> job) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      jobs_.push_back(std::move(job));
+      ++pending_;
+    }
+    cv_.notify_one();
+  }
+  void wait_idle() {  // every submitted job has finished
+    std::unique_lock<std::mutex> g(mu_);
+    idle_.wait(g, [&] { return pending_ == 0; });
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      std::function<void()> job;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return quit_ || !jobs_.empty(); });
+        if (jobs_.empty()) return;
+        job = std::move(jobs_.front());
+        jobs_.pop_front();
+      }
+      job();
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (--pending_ == 0) idle_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::deque<std::function<void()>> jobs_;
+  std::mutex mu_;
+  std::condition_variable cv_, idle_;
+  int pending_ = 0;
+  bool quit_ = false;
+};
 }
 using sdf::DevBuf;
 using sdf::HostBuf;
@@ -109,17 +171,13 @@ struct sdf_ctx {
   size_t ws_budget = 0;
   hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr;  // chunk pipeline
   hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};    // more room for launches that end in a tail
-  // high-priority streams for the heavy launches of a batch (created on first use): their workgroups -- up to 16
-  // wavefronts that need a CU's wavefront slots together -- are dispatched ahead of the ordinary chunks' queued next to them
-  hipStream_t hi_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool hi_tried = false;
-  bool no_hi_prio = false;  // SDF_NO_HI_PRIO=1
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   HostBuf host_plan, host_order;  // pinned staging of the plan
   HostBuf host_pool, host_out;    // pinned staging of the host-buffer entry point (packed sequences; results + CIGARs)
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
+  sdf::WorkerPool *pool = nullptr;  // planning threads, started with the first batch large enough to use them
   sdf::BatchCut *cut = nullptr;  // chunk list and planning scratch of the last batch call (sdf_plan.hip)
   std::vector<hipEvent_t> events;
   float ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 DP, 1 traceback, 2 compaction, 3 stream total, 4 host planning before the

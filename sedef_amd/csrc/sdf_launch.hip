@@ -36,7 +36,6 @@ struct BatchRun {
   uint32_t *d_stage = nullptr;
   const BatchCut *cut = nullptr;
   bool want_cigar = false, have_heavy = false;
-  bool hi_prio = false;  // the heavy launches run on the context's high-priority streams
   std::vector<ChunkEv> cev;
   std::vector<size_t> normal_ids;  // chunk indices of the ordinary chunks launched so far
   double qload[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // estimated DP work queued on each stream during this call
@@ -56,28 +55,9 @@ static hipEvent_t next_event(sdf_ctx *ctx, size_t &cursor) {
 // every stream a batch call may have work on
 static void drain_streams(sdf_ctx *ctx, hipStream_t st) {
   for (hipStream_t q : {st, ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
-                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3], ctx->hi_stream[0],
-                        ctx->hi_stream[1], ctx->hi_stream[2], ctx->hi_stream[3]})
+                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3]})
     if (q) (void)hipStreamSynchronize(q);
   (void)hipGetLastError();
-}
-
-static bool make_priority_streams(sdf_ctx *ctx) {
-  if (ctx->hi_tried) return ctx->hi_stream[3] != nullptr;
-  ctx->hi_tried = true;
-  int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
-    (void)hipGetLastError();
-    return false;
-  }
-  for (int q = 0; q < 4; ++q)
-    if (hipStreamCreateWithPriority(&ctx->hi_stream[q], hipStreamNonBlocking, greatest) != hipSuccess) {
-      (void)hipGetLastError();
-      for (int r = 0; r < q; ++r) (void)hipStreamDestroy(ctx->hi_stream[r]);
-      for (auto &ps : ctx->hi_stream) ps = nullptr;
-      return false;
-    }
-  return true;
 }
 
 // One DP launch of a planned class.  slabs: HBM state of the very long tasks (HBM-state classes only).
@@ -171,7 +151,9 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   if (pipelined) {
     // extra streams, created the first time they are wanted (a stream is a hardware queue: ~7 ms to set up): launches of
     // few tasks last as long as their longest task whatever else runs, so the more of them run side by side the better
-    const size_t want_aux = nchunks == 1 ? (c.launches.size() > 4 ? std::min<size_t>(c.launches.size() - 4, 4) : 0) : 4;
+    // (batches of a few ten thousand tasks, the stage driver's rounds, get by with two: 7 ms per stream is their budget)
+    const size_t want_aux = nchunks == 1 ? (c.launches.size() > 4 ? std::min<size_t>(c.launches.size() - 4, 4) : 0)
+                                         : (cut.ntask_total >= 200000 ? 4 : 2);
     for (size_t a = 0; a < want_aux; ++a)
       if (!ctx->aux_stream[a] && hipStreamCreateWithFlags(&ctx->aux_stream[a], hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
@@ -181,12 +163,6 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   hipStream_t Q[8] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
                       pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
                       ctx->aux_stream[3]};
-  if (run.hi_prio) {  // the heavy launches' own streams (Q[0], Q[1], Q[4], Q[5] are theirs, see below)
-    Q[0] = ctx->hi_stream[0];
-    Q[1] = ctx->hi_stream[1];
-    Q[4] = ctx->hi_stream[2];
-    Q[5] = ctx->hi_stream[3];
-  }
   // Q[4..7]: only the least-loaded-stream assignment below uses them (one-chunk batches without heavy tasks)
   const int ui = piped ? (run.have_heavy ? 2 : 1 + (int)(nj & 1)) : 0;  // upload stream (and the big launches')
   // (the tracebacks of consecutive ordinary chunks alternate between two streams: the last one starts when its DP

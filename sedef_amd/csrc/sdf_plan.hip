@@ -10,8 +10,6 @@
 //
 // Replaces the per-call set-up of ksw_extz2_sse (reference: extern/ksw2_extz2_sse.cc:57-98: early-outs, band and
 // matrix geometry, allocation) for a batch of tasks.
-#include <thread>
-
 #include "sdf_ctx.h"
 
 namespace sdf {
@@ -106,7 +104,8 @@ struct PlanScratch {
 };
 
 // Returns SDF_OK or an error code with *err set.
-static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget, BatchCut &cut, const char **err) {
+static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget, BatchCut &cut, const char **err,
+                     WorkerPool *pool = nullptr) {
   const sdf_task *tasks = env.tasks;
   const size_t n = env.n;
   // The batch is cut into chunks that are planned, uploaded and launched one after the other: while the GPU runs
@@ -176,13 +175,13 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         }
       }
     };
-    const int nthr = n >= 400000 ? 4 : 1;  // (a thread costs ~0.1 ms to start and join: not worth it below)
+    // (on the context's parked planning threads when there are any; this thread takes a share too)
+    const int nthr = pool && n >= 400000 ? std::min(8, pool->size() + 1) : 1;
     Part parts[8];
-    std::vector<std::thread> thr;
     for (int q = 1; q < nthr; ++q)
-      thr.emplace_back(scan, n * q / nthr, n * (q + 1) / nthr, std::ref(parts[q]), std::ref(hparts[q]));
+      pool->submit([&, q] { scan(n * q / nthr, n * (q + 1) / nthr, parts[q], hparts[q]); });
     scan(0, n / nthr, parts[0], hparts[0]);
-    for (auto &th : thr) th.join();
+    if (nthr > 1) pool->wait_idle();
     for (int q = 0; q < nthr; ++q) {
       if (parts[q].bad) {
         *err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
