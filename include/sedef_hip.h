@@ -35,9 +35,9 @@ extern "C" {
 /* task flag bits: numerically the reference's KSW_EZ_* (extern/ksw2.h:8-16) */
 #define SDF_FLAG_SCORE_ONLY 0x01 /* no direction matrix, no CIGAR */
 #define SDF_FLAG_RIGHT 0x02      /* right-align gaps */
-#define SDF_FLAG_GENERIC_SC 0x04 /* NOT supported on the GPU path (SEDEF never sets it) */
-#define SDF_FLAG_APPROX_MAX 0x08 /* NOT supported */
-#define SDF_FLAG_APPROX_DROP 0x10 /* NOT supported */
+#define SDF_FLAG_GENERIC_SC 0x04 /* scores from the whole m x m matrix (general kernel; SEDEF never sets it) */
+#define SDF_FLAG_APPROX_MAX 0x08 /* approximate max: score only along one followed path (general kernel) */
+#define SDF_FLAG_APPROX_DROP 0x10 /* with APPROX_MAX: z-drop test on the followed value */
 #define SDF_FLAG_EXTZ_ONLY 0x40  /* traceback from the best extension cell */
 #define SDF_FLAG_REV_CIGAR 0x80  /* leave the CIGAR reversed */
 
@@ -45,7 +45,7 @@ extern "C" {
 #define SDF_OK 0
 #define SDF_ERR_NO_DEVICE (-1)
 #define SDF_ERR_HIP (-2)
-#define SDF_ERR_UNSUPPORTED (-3) /* flag / alphabet the GPU path does not implement */
+#define SDF_ERR_UNSUPPORTED (-3) /* alphabet (m != 5) or flag bits the GPU path does not implement */
 #define SDF_ERR_INVALID (-4)
 #define SDF_ERR_CIGAR_OVERFLOW (-5) /* cigar_cap too small; *cigar_used holds the need */
 #define SDF_ERR_NOMEM (-6)
@@ -166,7 +166,8 @@ long long sdf_last_paired(const sdf_ctx *ctx);
 /* ---- seed anchors on the GPU (next row of the scope table) -----------------------------------
  * Replaces generate_anchors (reference: src/chain.cc:24-101) for a batch of candidate pairs: maximal exact
  * k-mer matches, in the reference's order (query position, then reference position).  Sequences are the raw
- * FASTA characters (case = soft-masking, N = unknown).  kmer <= 11, sequences shorter than 4 Mb. */
+ * FASTA characters (case = soft-masking, N = unknown).  kmer <= 11, sequences shorter than 4 Mb (SDF_ERR_UNSUPPORTED
+ * otherwise), at most 65,535 pairs per call. */
 typedef struct {
   int64_t q_off, r_off; /* byte offsets of query / reference characters in seq_pool */
   int32_t qlen, rlen;

@@ -110,7 +110,13 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
   const int flag = tk.flag;
   const bool with_dir = !(flag & SDF_FLAG_SCORE_ONLY);
   const bool right = (flag & SDF_FLAG_RIGHT) != 0;
-  const bool zd_mode = tk.zdrop >= 0;
+  // KSW_EZ_GENERIC_SC: scores from the whole matrix; KSW_EZ_APPROX_MAX: no H[] at all, one H value followed from cell to
+  // cell (reference :268-283), with KSW_EZ_APPROX_DROP the z-drop test on it
+  const bool generic_sc = !PLAIN && (flag & SDF_FLAG_GENERIC_SC) != 0;
+  const bool approx = !PLAIN && (flag & SDF_FLAG_APPROX_MAX) != 0;
+  const bool zd_mode = tk.zdrop >= 0 && !approx;
+  int32_t H0 = 0;
+  int last_H0_t = 0;
   const int64_t stride = tk.ncol16;
   uint8_t *dir = dirbase + tk.dir_off;
   const int nrow = qlen + tlen - 1;
@@ -150,13 +156,16 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
     }
     int32_t h_diag_prev = 0;
     if (tid == 0) {
-      if (!PLAIN) h_diag_prev = b.hi0 > 0 ? H[b.hi0 - 1] : H[b.hi0];
+      if (!PLAIN && !approx) h_diag_prev = b.hi0 > 0 ? H[b.hi0 - 1] : H[b.hi0];
       if (b.hi >= r) {
         Y[r] = 0;
         U[r] = r ? sc.q_b : 0;
       }
     }
-    {
+    if (generic_sc) {  // exactly [st0, en0], no 16-cell rounding (reference :139-141)
+      const uint8_t *qrow = QR + (qlen - 1 - r);
+      for (int t = b.lo0 + tid; t <= b.hi0; t += BS) S[t] = (uint8_t)sc.mat[SF[t] * 5 + qrow[t]];
+    } else {
       const int top = b.lo0 + ((b.hi0 - b.lo0) / 16 + 1) * 16;
       const uint8_t *qrow = QR + (qlen - 1 - r);
       for (int t = b.lo0 + tid; t < top; t += BS) {
@@ -324,6 +333,27 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
           if (r == nrow - 1) ez_score = h_top;
         }
       }
+    } else if (approx) {
+      if (tid == 0) {
+        const bool in0 = last_H0_t >= b.lo0 && last_H0_t <= b.hi0, in1 = last_H0_t + 1 >= b.lo0 && last_H0_t + 1 <= b.hi0;
+        if (r == 0) {
+          H0 = (int32_t)V[0] - 2 * sc.qe;
+          last_H0_t = 0;
+        } else if (in0 && in1) {
+          const int32_t d0 = (int32_t)V[last_H0_t] - sc.qe, d1 = (int32_t)U[last_H0_t + 1] - sc.qe;
+          if (d0 > d1) {
+            H0 += d0;
+          } else {
+            H0 += d1;
+            ++last_H0_t;
+          }
+        } else if (in0) {
+          H0 += (int32_t)V[last_H0_t] - sc.qe;
+        } else {
+          ++last_H0_t;
+          H0 += (int32_t)U[last_H0_t] - sc.qe;
+        }
+      }
     } else if (r > 0) {
       const int vec_end = b.lo0 + (b.hi0 - b.lo0) / 4 * 4;
       for (int t = b.lo0 + tid; t < b.hi0; t += BS) {
@@ -350,7 +380,32 @@ __global__ __launch_bounds__(BS) void extz2_general_kernel(
 
     // ---- ksw_extz_t bookkeeping (reference :259-267) ----
     if (zd_mode) rowbest = block_best<BS>(rowbest, red);
-    if (!PLAIN && tid == 0) {
+    if (!PLAIN && approx) {  // (mte / mqe are not produced in this mode; max only through the z-drop test, r > 0)
+      if (tid == 0) {
+        bool stop = false;
+        if (r > 0 && (flag & SDF_FLAG_APPROX_DROP)) {  // ksw_apply_zdrop on the followed value
+          const int tt = last_H0_t;
+          if (H0 > ez_max) {
+            ez_max = H0;
+            ez_max_t = tt;
+            ez_max_q = r - tt;
+          } else if (tt >= ez_max_t && r - tt >= ez_max_q) {
+            const int tl = tt - ez_max_t, ql = (r - tt) - ez_max_q;
+            const int l = tl > ql ? tl - ql : ql - tl;
+            if (tk.zdrop >= 0 && ez_max - H0 > tk.zdrop + l * sc.e) {
+              ez_zdropped = 1;
+              stop = true;
+            }
+          }
+          if (stop) *stop_flag = 1;
+        }
+        if (!stop && r == nrow - 1 && b.hi0 == tlen - 1) ez_score = H0;
+      }
+      if (flag & SDF_FLAG_APPROX_DROP) {
+        __syncthreads();
+        if (*stop_flag) break;
+      }
+    } else if (!PLAIN && tid == 0) {
       if (b.hi0 == tlen - 1 && H[b.hi0] > ez_mte) {
         ez_mte = H[b.hi0];
         ez_mte_q = r - b.hi;

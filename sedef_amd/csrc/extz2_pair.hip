@@ -73,7 +73,13 @@ __host__ __device__ inline int pair_qcap(int qlen, int nreg) {
   }
 
 // STREAM: the sequences do not fit the LDS windows whole (long tasks); without it the window code compiles out.
-template <int NREG, bool STREAM>
+// TRACK: for banded tasks whose band cannot reach the end of both sequences (|qlen - tlen| > w): the reference runs out
+// of band, sets zdropped and backtracks from the best cell seen (extern/ksw2_extz2_sse.cc:116, :292-295), so the exact H
+// of EVERY in-band cell is needed, not only along the band's upper edge.  Each lane keeps the H of its cell of task A in
+// a 32-bit register (H[t] += v[t] - (q+e); the top cell from its lower neighbour's old H and u, :226-258) and a running
+// (best H, row); one reduction at the end applies the reference's tie order (earliest row, then its 4-lane scan order).
+// Such a task is launched paired with itself: both halves compute it, half B is ignored.
+template <int NREG, bool STREAM, bool TRACK>
 __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 4 ? 3 : 2) void extz2_pair_kernel(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
@@ -155,6 +161,14 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
     Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
     Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[64 * k + lane], 0x0c010c00u);
   }
+  // TRACK: exact H of the lane's cell of task A per register, and the best (H, row) the lane has seen
+  int32_t Hc[TRACK ? NREG : 1], bestH[TRACK ? NREG : 1], bestR[TRACK ? NREG : 1];
+#pragma unroll
+  for (int k = 0; k < (TRACK ? NREG : 1); ++k) {
+    Hc[k] = SDF_NEG_INF;
+    bestH[k] = 0;  // ksw_reset_extz: max = 0, so only H > 0 is ever recorded (extern/ksw2.h:155,:165)
+    bestR[k] = -1;
+  }
 
   const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
   uint2 *dir_a = reinterpret_cast<uint2 *>(dirbase + tk.dir_off);
@@ -218,6 +232,34 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
         }
         if (r == nrow - 1) ez_score[t] = h_top[t];
       }
+    }
+  };
+
+  int32_t carry_h = SDF_NEG_INF;  // TRACK: H of target position base - 1 (left the window at the last re-base)
+  // TRACK: H of every in-band cell after row r's recurrence (reference :222-258), and the running best per lane
+  auto track_row = [&](const int r, const int lo0, const int hi0) {
+    if (!TRACK) return;
+    const int st = hi0 - base;  // slot of the top cell
+    // H of the cell under it BEFORE this row's update; under slot 0 lies the cell the last re-base pushed out
+    int32_t h_below = st == 0 ? carry_h : 0;
+#pragma unroll
+    for (int k = 0; k < (TRACK ? NREG : 0); ++k)
+      if (st > 0 && ((st - 1) >> 6) == k) h_below = __builtin_amdgcn_readlane(Hc[k], (st - 1) & 63);
+#pragma unroll
+    for (int k = 0; k < (TRACK ? NREG : 0); ++k) {
+      const int t = base + 64 * k + lane;
+      if (base + 64 * k > hi0 || base + 64 * k + 63 < lo0) continue;  // (wave-uniform) no in-band cell in this register
+      const int32_t vA = (int32_t)((V[k] >> 8) & 0xffu), uA = (int32_t)((U[k] >> 8) & 0xffu);
+      const bool mid = (unsigned)(t - lo0) < (unsigned)(hi0 - lo0);  // lo0 <= t < hi0
+      const bool top = t == hi0;
+      int32_t h = Hc[k];
+      h = mid ? h + vA - sc.qe : h;
+      const int32_t htop = r == 0 ? vA - 2 * sc.qe : (hi0 > 0 ? h_below + uA : h + vA) - sc.qe;
+      h = top ? htop : h;
+      Hc[k] = h;
+      const bool better = (mid || top) && h > bestH[k];
+      bestH[k] = better ? h : bestH[k];
+      bestR[k] = better ? r : bestR[k];
     }
   };
 
@@ -334,6 +376,7 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
       }
       h_row(r, hi0, lo0, hi, r == 0, want_top, hi0 > 0, up, uh, vu);
     }
+    track_row(r, lo0, hi0);
     prev_lo = lo;
     return true;
   };
@@ -489,6 +532,7 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
           if (!STEADY) ++hcnt;
         }
       }
+      track_row(r, lo0, hi0);
     }
   };
   auto lean_rows = [&](auto low16_c, auto scalarh_c, auto steady_c, const int rb, const int re) {
@@ -528,6 +572,7 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
           carry_x = (unsigned)__builtin_amdgcn_readlane((int)X[0], 15);  // (r-1) value of the cell just
           carry_v = (unsigned)__builtin_amdgcn_readlane((int)V[0], 15);  // below the new window
         }
+        if (TRACK) carry_h = __builtin_amdgcn_readlane(Hc[0], 15);
 #pragma unroll
         for (int k = 0; k < NREG; ++k) {
           const bool from_next = lane >= 48;
@@ -541,6 +586,11 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
           SDF_SHIFT16(X, 0u)
           SDF_SHIFT16(Y, 0u)
           SDF_SHIFT16(S, z_wild)
+          if (TRACK) {
+            const int h0 = __builtin_amdgcn_ds_bpermute(bperm_idx, Hc[TRACK ? k : 0]);
+            const int h1 = (k + 1 < NREG) ? __builtin_amdgcn_ds_bpermute(bperm_idx, Hc[TRACK && k + 1 < NREG ? k + 1 : 0]) : SDF_NEG_INF;
+            Hc[TRACK ? k : 0] = from_next ? h1 : h0;
+          }
 #undef SDF_SHIFT16
         }
         base = b0.lo;
@@ -646,6 +696,10 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
           int rt = 2 * (tlen - 1) - w;
           rt = rt < tlen - 1 ? tlen - 1 : rt;
           if (rt > r && rt < stop) stop = rt;
+          if (TRACK) {  // the row at which the band runs out (lo0 > hi0) ends a segment too: the check above sees it
+            const int rx = 2 * (tlen < qlen ? tlen : qlen) + w - 1;
+            if (rx > r && rx < stop) stop = rx;
+          }
         }
         const bool scalarh = hi0 == tlen - 1;
         if (scalarh) {
@@ -702,12 +756,36 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
   }
 
   fold_h();
+  int32_t ez_max = 0, ez_max_t = -1, ez_max_q = -1;
+  if (TRACK) {
+    BestCell best = {0, -1, 0, -1};
+#pragma unroll
+    for (int k = 0; k < (TRACK ? NREG : 0); ++k) {
+      const int rr = bestR[k];
+      if (rr < 0) continue;
+      Band bb, br;
+      band_of((rr >> 4) << 4, qlen, tlen, w, bb);  // window base of the row's block
+      band_of(rr, qlen, tlen, w, br);
+      const int t = bb.lo + 64 * k + lane;
+      const int vec_end = br.lo0 + (br.hi0 - br.lo0) / 4 * 4;  // the reference's scan order inside a row (:226-258)
+      const int key = t == br.hi0 ? 0 : t < vec_end ? 1 + (((t - br.lo0) & 3) << 20) + t : 1 + (4 << 20) + t;
+      const BestCell cand = {bestH[k], rr, key, t};
+      if (beats(cand, best)) best = cand;
+    }
+    best = wave_best(best);
+    if (best.r >= 0) {
+      ez_max = best.H;
+      ez_max_t = best.t;
+      ez_max_q = best.r - best.t;
+    }
+  }
   if (lane < 2) {
     const bool second = lane == 1;
     sdf_result o;
     o.score = second ? ez_score[1] : ez_score[0];
-    o.max = 0;
-    o.max_q = o.max_t = -1;
+    o.max = ez_max;
+    o.max_q = ez_max_q;
+    o.max_t = ez_max_t;
     o.mqe = SDF_NEG_INF;
     o.mqe_t = -1;
     o.mte = second ? ez_mte[1] : ez_mte[0];
@@ -723,11 +801,11 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
 #undef tt0
 #undef we0
 
-#define SDF_PAIR_INST(N)                                                                                        \
-  template __global__ void extz2_pair_kernel<N, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, \
-                                                       uint8_t *, sdf_result *);                               \
-  template __global__ void extz2_pair_kernel<N, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,  \
-                                                      uint8_t *, sdf_result *);
+#define SDF_PAIR_INST(N)                                                                                               \
+  template __global__ void extz2_pair_kernel<N, false, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, \
+                                                              uint8_t *, sdf_result *);                               \
+  template __global__ void extz2_pair_kernel<N, true, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,  \
+                                                             uint8_t *, sdf_result *);
 SDF_PAIR_INST(1)
 SDF_PAIR_INST(2)
 SDF_PAIR_INST(3)
@@ -735,6 +813,11 @@ SDF_PAIR_INST(4)
 SDF_PAIR_INST(6)
 SDF_PAIR_INST(8)
 #undef SDF_PAIR_INST
+// TRACK flavour (band-exhausting tasks; windows streamed): windows of up to 192 / 384 slots
+template __global__ void extz2_pair_kernel<3, true, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                          uint8_t *, sdf_result *);
+template __global__ void extz2_pair_kernel<6, true, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                          uint8_t *, sdf_result *);
 
 // the windows hold the sequences whole?
 bool pair_fits_whole(int qlen, int tlen, int nreg) {

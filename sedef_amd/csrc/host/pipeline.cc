@@ -160,11 +160,19 @@ class GpuProvider : public DpProvider {
       const char *e = getenv("SDF_GPU_ANCHORS");
       return !(e && e[0] == '0');
     }();
-    if (!enabled || kmer > 11 || jobs.empty()) return false;
+    if (!enabled || jobs.empty()) return false;
+    // what the device kernels do not cover goes to the host's generate_anchors -- said once, not silently
+    auto host_instead = [](const char *why) {
+      static std::atomic<bool> said(false);
+      if (!said.exchange(true)) fprintf(stderr, "\n[sedef_amd] seed anchors on the host for this input: %s\n", why);
+      return false;
+    };
+    if (kmer > 11) return host_instead("GPU anchors implement k-mer sizes up to 11");
     std::vector<sdf_anchor_pair> pairs(jobs.size());
     size_t total = 0;
     for (size_t k = 0; k < jobs.size(); k++) {
-      if (jobs[k].query->size() >= (1u << 22) || jobs[k].ref->size() >= (1u << 22)) return false;
+      if (jobs[k].query->size() >= (1u << 22) || jobs[k].ref->size() >= (1u << 22))
+        return host_instead("GPU anchors implement sequences shorter than 4 Mb");
       pairs[k].q_off = (int64_t)total;
       total += jobs[k].query->size();
       pairs[k].r_off = (int64_t)total;
@@ -192,7 +200,7 @@ class GpuProvider : public DpProvider {
       rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.get(), total, kmer, (sdf_anchor *)out.buf.get(), cap,
                              out.off.data(), &used);
     }
-    if (rc == SDF_ERR_UNSUPPORTED || rc == SDF_ERR_NOMEM) return false;
+    if (rc == SDF_ERR_UNSUPPORTED || rc == SDF_ERR_NOMEM) return host_instead(sdf_last_error(ctx_));
     if (rc != SDF_OK) throw std::string("GPU anchors failed: ") + sdf_last_error(ctx_);
     return true;
   }

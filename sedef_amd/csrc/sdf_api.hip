@@ -85,12 +85,15 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<8, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
 #define SDF_PAIR_ATTR(N)                                                                   \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N, false>),  \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N, false, false>),  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);         \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N, true>),   \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_pair_kernel<N, true, false>),   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   SDF_PAIR_ATTR(1) SDF_PAIR_ATTR(2) SDF_PAIR_ATTR(3) SDF_PAIR_ATTR(4) SDF_PAIR_ATTR(6) SDF_PAIR_ATTR(8)
 #undef SDF_PAIR_ATTR
+  for (const void *f : {reinterpret_cast<const void *>(&extz2_pair_kernel<3, true, true>),
+                        reinterpret_cast<const void *>(&extz2_pair_kernel<6, true, true>)})
+    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipGetLastError();
   const char *fg = getenv("SDF_FORCE_GENERAL");
   ctx->force_general = fg && fg[0] == '1';
@@ -235,6 +238,7 @@ int make_scorek(sdf_ctx *ctx, const sdf_scoring *sc, ScoreK &k, bool &degenerate
   k.sc_match = (uint8_t)sc->mat[0];
   k.sc_mis = (uint8_t)sc->mat[1];
   k.wild = (uint8_t)(sc->m - 1);
+  memcpy(k.mat, sc->mat, 25);
   int min_sc = sc->mat[1];
   for (int t = 1; t < sc->m * sc->m; ++t) min_sc = std::min<int>(min_sc, sc->mat[t]);
   degenerate = -min_sc > 2 * (q + e);  // reference returns before any work (:81)
@@ -624,8 +628,12 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
   if (!ctx) return SDF_ERR_INVALID;
   ctx->err.clear();
   if (out_used) *out_used = 0;
-  if (!pairs || !out_off || !out_used || (!seq_pool && pool_bytes) || n >= (1u << 20)) {
+  if (!pairs || !out_off || !out_used || (!seq_pool && pool_bytes)) {
     ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  if (n > 65535) {  // one grid row of workgroups per pair (gridDim.y)
+    ctx->err = "at most 65,535 pairs per sdf_anchors_batch call";
     return SDF_ERR_INVALID;
   }
   if (kmer < 1 || kmer > 11) {

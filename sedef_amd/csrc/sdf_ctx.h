@@ -28,7 +28,7 @@ __global__ void extz2_wave_kernel(const PlanTask *, const int32_t *, const uint3
                                   sdf_result *);
 size_t wave_lds_bytes(int qlen, int tlen, int nreg);
 bool wave_fits_whole(int qlen, int tlen, int nreg);
-template <int NREG, bool STREAM>
+template <int NREG, bool STREAM, bool TRACK>
 __global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                   sdf_result *);
 size_t pair_lds_bytes(int qlen, int tlen, int nreg);

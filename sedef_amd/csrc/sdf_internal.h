@@ -17,6 +17,8 @@ struct ScoreK {
   uint8_t sc_mis;      // (uint8)mat[1]
   uint8_t wild;        // m-1
   uint8_t pad_[2];
+  int8_t mat[25];      // the whole 5x5 matrix: KSW_EZ_GENERIC_SC scores by mat[target * m + query] (reference :139-141)
+  int8_t pad2_[3];
 };
 
 // One planned task as the kernels see it.

@@ -67,7 +67,9 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
 #define SDF_WAVE(N, S) \
   hipLaunchKernelGGL((extz2_wave_kernel<N, S>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
 #define SDF_PAIR(N, S) \
-  hipLaunchKernelGGL((extz2_pair_kernel<N, S>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
+  hipLaunchKernelGGL((extz2_pair_kernel<N, S, false>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
+#define SDF_PAIR_TRACK(N) \
+  hipLaunchKernelGGL((extz2_pair_kernel<N, true, true>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
 #define SDF_STRIPE(N) \
   hipLaunchKernelGGL(extz2_stripe_kernel<N>, one, dim3(64 * L.kmax), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
 #define SDF_GENERAL(BS, PLAIN)                                                                                      \
@@ -97,6 +99,8 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 116: SDF_PAIR(6, true); break;
     case 108: SDF_PAIR(8, false); break;
     case 118: SDF_PAIR(8, true); break;
+    case 123: SDF_PAIR_TRACK(3); break;
+    case 126: SDF_PAIR_TRACK(6); break;
     case 201: SDF_STRIPE(1); break;
     case 202: SDF_STRIPE(2); break;
     case 204: SDF_STRIPE(4); break;
@@ -111,6 +115,7 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
   }
 #undef SDF_WAVE
 #undef SDF_PAIR
+#undef SDF_PAIR_TRACK
 #undef SDF_STRIPE
 #undef SDF_GENERAL
 #undef SDF_GENERAL_HBM

@@ -28,7 +28,8 @@ struct PlanEnv {
 
 struct Launch {
   int bs;  // 64 / 256 / 1024: general kernel with that many threads (+2000: PLAIN flavour); 1, 2, 4, 8: wave kernel with
-           // NREG (+10: streamed windows); 100 + NREG: pair kernel (+10: streamed); 200 + NREG: stripe kernel;
+           // NREG (+10: streamed windows); 100 + NREG: pair kernel (+10: streamed; 120 + NREG: TRACK flavour);
+           // 200 + NREG: stripe kernel;
            // 1000 / 1001 / 2001: general kernel with its state in HBM
   size_t lds;  // dynamic LDS bytes of the launch (HBM-state classes: slab bytes per workgroup)
   size_t off, cnt;  // entries of the chunk's launch order
@@ -101,6 +102,7 @@ struct PlanScratch {
   std::vector<int32_t> win_need, partner;
   std::vector<std::pair<int32_t, int32_t>> table;
   std::vector<plan_detail::Cls> cls;
+  std::vector<char> tracked;
 };
 
 // Returns SDF_OK or an error code with *err set.
@@ -152,7 +154,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv) {
       for (size_t k = lo; k < hi; ++k) {
         const sdf_task &t = tasks[k];
-        if (t.flag & (SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP | 0x300)) {
+        if (t.flag & 0x300) {  // (not KSW_EZ_* bits of the extz2 kernel)
           pt.bad = true;
           return;
         }
@@ -166,6 +168,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
           size_t bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
           if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+          // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
+          if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
           bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
           if (bd >= heavy_min) {
             ++pt.nh;
@@ -184,7 +188,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     if (nthr > 1) pool->wait_idle();
     for (int q = 0; q < nthr; ++q) {
       if (parts[q].bad) {
-        *err = "task flag not implemented on the GPU path (generic scoring / approximate max)";
+        *err = "unknown task flag";
         return SDF_ERR_UNSUPPORTED;
       }
       cut.n_heavy += parts[q].nh;
@@ -312,9 +316,24 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       const int nrow = t.qlen + t.tlen - 1;
       Band bl;
       const bool band_whole = (p.w >= 1 || nrow == 1) && band_of(nrow - 1, t.qlen, t.tlen, p.w, bl);
-      const bool plain = !(env.want & SDF_WANT_EXT) && t.zdrop < 0 && !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY)) &&
-                         env.gapo >= 0 && band_whole;
+      // (generic scoring and the approximate-max modes exist in the general kernel only)
+      const int general_only = SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY | SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP;
+      const bool plain = !(env.want & SDF_WANT_EXT) && t.zdrop < 0 && !(t.flag & general_only) && env.gapo >= 0 && band_whole;
       plain_ok = plain && !env.force_general;
+      // the same request on a band that runs out before the end of both sequences: the pair kernel's TRACK flavour
+      // (exact H of every cell, best cell for the traceback), the task paired with itself; windows up to 384 slots
+      const bool runs_out = !band_whole && p.w >= 1 && nrow > 1;
+      if (runs_out && !env.force_general && !env.no_pair && !(env.want & SDF_WANT_EXT) && t.zdrop < 0 &&
+          !(t.flag & general_only) && env.gapo >= 0) {
+        const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
+        // (wider windows stay on the general kernel: ten registers on one wavefront were measured no faster per row
+        // than its 1024-thread workgroup, 2.0 vs 1.75 us on 20 kb tasks at w = 512)
+        const int nreg = need <= 192 ? 3 : need <= 384 ? 6 : 0;
+        if (nreg && pair_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)env.max_dyn_lds) {
+          p.nreg = nreg;
+          p.pad_ = 6;  // (becomes layout 2 below; 6 marks the TRACK launch class until then)
+        }
+      }
       if (plain_ok) {
         // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
         // beyond the target's last 16-cell block (cells past it are not part of any window)
@@ -386,6 +405,14 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   // open-addressing table keyed by the geometry: entry = (first task seen with the key, the task of that key
   // still waiting for a partner or -1).
   partner.assign(cnt, -1);
+  std::vector<char> &tracked = sx.tracked;
+  tracked.assign(cnt, 0);
+  for (size_t k = 0; k < cnt; ++k)
+    if (cp[k].pad_ == 6) {
+      cp[k].pad_ = 2;
+      partner[k] = (int32_t)k;
+      tracked[k] = 1;
+    }
   if (!env.no_pair && !env.force_general) {
     auto &table = sx.table;
     size_t cap = 64;
@@ -462,7 +489,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     if (p.pad_ == 2) {
       if (partner[k] < (int32_t)k) continue;  // placed together with its partner
       // 100 + NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
-      bs = 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
+      bs = tracked[k] ? 120 + p.nreg : 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
       need = pair_lds_bytes(p.qlen, p.tlen, p.nreg);
       lds = 8192;
       while (lds < need) lds *= 2;

@@ -79,7 +79,7 @@ def test_chunk_loop_matches_reference_golden_gpu(host, host_golden):
 
 
 # ---------------------------------------------------------------- (b) boundary: sdf_ksw_extz2 itself
-UNSUPPORTED = 0x04 | 0x08 | 0x10  # KSW_EZ_GENERIC_SC / APPROX_MAX / APPROX_DROP (SEDEF passes flag = 0, src/align.cc:56)
+UNSUPPORTED = 0  # (every KSW_EZ_* flag of the extz2 kernel is served)
 
 def _call_dropin(lib, libc, q, t, mat, gapo, gape, w, zdrop, flag):
     ez = _KswExtz()
@@ -124,7 +124,7 @@ def test_sdf_ksw_extz2_dropin_on_golden_vectors(golden_cases):
         assert got["n_cigar"] == len(got["cigar"]) and got["m_cigar"] >= got["n_cigar"]
         assert got["cigar_ptr"] == (got["n_cigar"] > 0)  # ez->cigar = 0 in the reset (extern/ksw2.h:158)
         n += 1
-    assert n >= 278
+    assert n == len(golden_cases) >= 284
     # empty inputs: the reset result, no CIGAR (extern/ksw2_extz2_sse.cc:57)
     for (q, t) in ((np.zeros(0, np.uint8), codes("ACGT")), (codes("ACGT"), np.zeros(0, np.uint8))):
         got = _call_dropin(lib, libc, q, t, sedef_mat(), 40, 1, -1, -1, 0)

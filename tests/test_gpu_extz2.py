@@ -36,7 +36,7 @@ def _rec_to_dict(r, cig):
     return d
 
 
-GPU_FLAGS_OK = lambda f: not (f & (0x04 | 0x08 | 0x10))  # noqa: E731
+GPU_FLAGS_OK = lambda f: True  # noqa: E731  (generic scoring and the approximate modes run on the general kernel)
 
 
 def test_golden_vectors_single_calls(engine, golden_cases):
@@ -49,7 +49,7 @@ def test_golden_vectors_single_calls(engine, golden_cases):
                                   c["gapo"], c["gape"], c["w"], c["zdrop"], c["flag"], engine=engine)
         check_case(got, c)
         n += 1
-    assert n > 200
+    assert n == len(golden_cases) >= 284
 
 
 def test_golden_vectors_one_batch(engine, golden_cases):
@@ -64,7 +64,7 @@ def test_golden_vectors_one_batch(engine, golden_cases):
 def test_unsupported_flags_are_rejected(engine):
     import sedef_amd
     q = np.zeros(10, np.uint8)
-    for f in (0x04, 0x08):
+    for f in (0x100, 0x200):  # not KSW_EZ_* bits of this kernel
         with pytest.raises(sedef_amd.SdfError):
             engine.align_pairs([(q, q)], flag=f)
 
@@ -590,3 +590,74 @@ def test_stripe_kernel_wide_full_band(engine, oracle):
                 t = _fit(rng, t, tl)
             pairs.append((q, t))
     _check_fast(engine, oracle, pairs, [-1] * len(pairs))
+
+
+def test_pair_kernel_track_band_runs_out(engine, oracle):
+    """Banded tasks whose band cannot reach the end of both sequences (|qlen - tlen| > w): the reference stops when
+    the band is exhausted and backtracks from the best cell (extern/ksw2_extz2_sse.cc:116, :292-295).  The pair kernel's
+    TRACK flavour follows the exact H of every cell for that: zdropped, max / max_t / max_q and the CIGAR against the
+    oracle, for windows of 192 / 384 slots (wider ones: the general kernel), short and streamed sequences, ties
+    (repeats), N runs."""
+    import sedef_amd
+    rng = np.random.default_rng(4711)
+    pairs, ws = [], []
+    for w in (1, 2, 7, 16, 33, 64, 128, 200, 256, 400, 512):
+        for it in range(6):
+            ql = int(rng.integers(w + 40, 900)) if it < 4 else int(rng.integers(2500, 7000))
+            q = random_codes(rng, ql, 0.01 if it % 3 == 0 else 0.0)
+            if it == 1:  # low complexity: many equal scores
+                q = np.tile(random_codes(rng, 5), ql // 5 + 1)[:ql]
+            t = mutate(rng, q, 0.05, 0.015, 0.015)
+            cut = w + int(rng.integers(5, 300))
+            if it % 2 == 0 and len(t) > cut + 20:  # target shorter: the band leaves through the target's end
+                at = int(rng.integers(0, len(t) - cut))
+                t = np.concatenate([t[:at], t[at + cut:]])
+            else:  # target longer
+                at = int(rng.integers(0, len(t)))
+                t = np.concatenate([t[:at], random_codes(rng, cut), t[at:]])
+            pairs.append((q, t))
+            ws.append(w)
+    res, cig = engine.align_pairs(pairs, w=ws, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    dropped = 0
+    for (q, t), w, r in zip(pairs, ws, res):
+        exp = oracle.extz2(q, t, w=w)
+        got = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+        for fld in ("score", "mte", "mte_q", "zdropped"):
+            assert int(r[fld]) == exp[fld], (fld, w, len(q), len(t), int(r[fld]), exp[fld])
+        if exp["zdropped"]:
+            dropped += 1
+            for fld in ("max", "max_t", "max_q"):
+                assert int(r[fld]) == exp[fld], (fld, w, len(q), len(t), int(r[fld]), exp[fld])
+        assert cigar_to_str(got) == cigar_to_str(exp["cigar"]), (w, len(q), len(t))
+    assert dropped >= 50
+
+
+def test_generic_scoring_and_approximate_modes_fuzz(engine, oracle):
+    """KSW_EZ_GENERIC_SC (scores from the whole matrix, also for the wildcard row), KSW_EZ_APPROX_MAX (one followed H
+    value instead of H[]) and KSW_EZ_APPROX_DROP (z-drop on it): every ksw_extz_t field and the CIGAR against the
+    oracle (pinned against the reference kernel for the same flags, tests/test_oracle_vs_ref.py)."""
+    rng = np.random.default_rng(808)
+    mat = np.array([6, -3, -5, -3, -1, -3, 6, -3, -5, -1, -5, -3, 6, -3, -1, -3, -5, -3, 6, -1, -1, -1, -1, -1, 1], np.int8)
+    n = 0
+    for flag in (0x04, 0x08, 0x18, 0x0c, 0x1c, 0x48, 0x09, 0x05):
+        pairs, kws = [], []
+        for _ in range(40):
+            q = random_codes(rng, int(rng.integers(1, 500)), 0.03)
+            d = rng.random() * 0.2
+            t = mutate(rng, q, d, d / 3, d / 3)
+            if rng.random() < 0.3:
+                k = int(rng.integers(0, len(t)))
+                t = np.concatenate([t[:k], random_codes(rng, int(rng.integers(1, 120))), t[k:]])
+            pairs.append((q, t))
+            kws.append(dict(w=int(rng.choice([-1, -1, 3, 17, 64])), zdrop=int(rng.choice([-1, 40, 300]))))
+        m = mat if flag & 0x04 else sedef_mat()
+        res, cig = engine.align_pairs(pairs, w=[k["w"] for k in kws], zdrop=[k["zdrop"] for k in kws], flag=flag, mat=m,
+                                      gapo=12, gape=2)
+        for (q, t), kw, r in zip(pairs, kws, res):
+            exp = oracle.extz2(q, t, mat=m, gapo=12, gape=2, flag=flag, **kw)
+            got = _rec_to_dict(r, cig)
+            for f in FIELDS:
+                assert got[f] == exp[f], (hex(flag), f, kw, len(q), len(t), got[f], exp[f])
+            assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"]), (hex(flag), kw, len(q), len(t))
+            n += 1
+    assert n == 320

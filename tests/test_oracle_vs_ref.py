@@ -46,3 +46,17 @@ def test_fuzz_wrapping_scorings(oracle, ref):
                   gapo=int(rng.integers(0, 70)), gape=int(rng.integers(0, 6)),
                   flag=int(rng.choice([0, 0, 2, 0x40])))
         assert _same(oracle.extz2(q, t, **kw), ref.extz2(q, t, **kw)), kw
+
+
+def test_fuzz_generic_matrix_and_approximate_modes(oracle, ref):
+    """KSW_EZ_GENERIC_SC with a matrix whose wildcard row / column is not zero, KSW_EZ_APPROX_MAX / APPROX_DROP."""
+    rng = np.random.default_rng(13)
+    mat = np.array([6, -3, -5, -3, -1, -3, 6, -3, -5, -1, -5, -3, 6, -3, -1, -3, -5, -3, 6, -1, -1, -1, -1, -1, 1], np.int8)
+    for _ in range(2000):
+        q = random_codes(rng, int(rng.integers(1, 300)), 0.04)
+        d = rng.random() * 0.2
+        t = mutate(rng, q, d, d / 3, d / 3)
+        flag = int(rng.choice([0x04, 0x08, 0x18, 0x0c, 0x1c, 0x48, 0x09, 0x05]))
+        kw = dict(w=int(rng.choice([-1, -1, 3, 17, 64])), zdrop=int(rng.choice([-1, 40, 300])), flag=flag,
+                  mat=mat if flag & 4 else sedef_mat(), gapo=12, gape=2)
+        assert _same(oracle.extz2(q, t, **kw), ref.extz2(q, t, **kw)), kw

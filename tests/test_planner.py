@@ -114,7 +114,9 @@ def test_kernel_choice_by_request():
     assert pt[4, 1] in (201, 202, 204)                            # wide full-band: stripe kernel
     rc, pt, pc = _plan(t, want=7)                                 # every field wanted: no register-resident kernel
     assert rc == 0 and (pt[:, 1] >= 64).all() and not np.isin(pt[:, 1], (101, 102, 103, 104, 106, 108, 201, 202, 204)).any()
-    rc, _, _ = _plan(_tasks([10], [10], flag=[4]))
-    assert rc == -3  # SDF_ERR_UNSUPPORTED: generic scoring
+    rc, pt, _ = _plan(_tasks([300, 300], [300, 300], flag=[4, 8]))
+    assert rc == 0 and (pt[:, 1] == 256).all()  # generic scoring / approximate max: the general kernel
+    rc, _, _ = _plan(_tasks([10], [10], flag=[0x100]))
+    assert rc == -3  # SDF_ERR_UNSUPPORTED: not a flag of this kernel
     rc, pt, _ = _plan(_tasks([300, 0], [300, 5]), mat=np.array([1] + [-100] * 24, np.int8), gapo=1, gape=1)
     assert rc == 0 and (pt[:, 0] == -1).all()  # degenerate scoring: the reference returns before any work
