@@ -1,23 +1,33 @@
-// Register-resident extz2 DP for targets wider than one wavefront's window: a workgroup of up to 16 wavefronts
-// works on ONE full-band task as a systolic array.
+// Register-resident extz2 DP for FULL-BAND tasks whose target is wider than one wavefront's window: the target is cut
+// into stripes of NSLOT = 128 * NREG positions and every stripe is ONE wavefront (a one-wavefront workgroup) that runs
+// down its anti-diagonals r' = r - T0 with its NSLOT cells in registers -- a systolic array over the stripes.
 //
-// The target is cut into stripes of NSLOT = 128*NREG positions, one wavefront each.  In stripe-local
-// coordinates (t' = t - T0, r' = r - T0) the reference's band of a full-band task (lo = max(0, r-qlen+1),
-// hi = min(r, tlen-1), extern/ksw2_extz2_sse.cc:101-115) has the same form as that of a stand-alone task over
-// the target slice -- so each wavefront runs the one-task kernel of extz2_wave.hip on its slice, with three
-// differences at the stripe's left edge:
-//   * the (r-1, t-1) neighbour of its first column is the left stripe's last column of the previous global row
-//     (x, v), not the reference's start-of-target constants: stripes export that column row by row into an LDS
-//     ring and publish their progress once per 16-row block; a stripe waits for its left neighbour's block
-//     before its own (and a producer never runs more than a ring ahead of its consumer);
-//   * "first row" rules (r == 0) apply to the global row; the exact H of the top cell, which moves up one
-//     column per row until it reaches the end of the target, is handed from stripe to stripe;
-//   * only the last stripe owns the target's end: score / mte come from it.
-// Wavefront s starts NSLOT rows after wavefront s-1 and all of them advance together afterwards: a 6000 x 6000
-// task keeps 12 wavefronts of a CU busy instead of one workgroup stepping through LDS-resident state.
-// Direction flags: the wave-kernel bit blocks, one region per stripe (traceback layout 3).
+// A full-band task (w >= max(qlen, tlen); reference band lo = max(0, r - qlen + 1), hi = min(r, tlen - 1),
+// extern/ksw2_extz2_sse.cc:101-115) has no cell whose neighbours lie outside the band except at the matrix borders:
+// cell (r, t) reads x, v of (r-1, t-1) and u, y of (r-1, t), both inside the band of row r-1 unless t = 0 (the
+// reference's start-of-target constants), or the cell is on the first query row (t = r: u = gap open, y = 0,
+// reference :122).  So, unlike the banded kernels, nothing of the reference's 16-cell block rounding, re-basing or
+// carry-in artefacts can reach a cell that is ever read: the stripe keeps its window at its first column for all rows,
+// computes whole registers (what lies above the diagonal t = r or below the band start is scratch nobody reads) and
+// spends its instructions on the recurrence:
+//   * rows r' < tlen' ("head"): the top cell moves up one column per row along the first query row; the registers
+//     up to its own are computed, the cell gets its border values before the row, and its u is added (inside the
+//     owning lane) to the H of the top cell, which is handed from stripe to stripe;
+//   * then all registers, every row the same instructions; the (r-1, t-1) neighbour of the stripe's first column is
+//     the left stripe's last column of the previous global row, its own last column leaves for the right stripe;
+//   * rows r' >= qlen ("tail"): registers wholly below the band start drop out;
+//   * the last stripe owns the target's end: H of its last column is followed down the rows (inside the owning lane)
+//     for mte / score.
+// The stripes of a task talk through HBM (they share an XCD, so its L2): per stripe a progress word ("first query row
+// done, H handed over") and, per stripe boundary, the FULL edge column, one x | v << 16 word per global row.  A stripe
+// stores the 16 edge words of a 16-row block with one instruction, bit 0 of a word set (the state values are
+// multiples of 256: the bit is free; the columns are zeroed before the launch); its right neighbour fetches the 16
+// words a block needs with one load -- issued one block ahead -- and looks at the tag bits.  A stripe only ever waits
+// for its left neighbour, which has the smaller workgroup index on the same XCD: resident or finished.
+// Launch-order entries are (stripe << 24) | task; stripe index 127 marks an entry that does nothing.
+// Direction flags: the wave-kernel bit blocks, one region per stripe, slot = t - T0 (traceback layout 3).
 //
-// Compiled inside sdf_unity.hip after extz2_wave.hip (helpers, SDF_CORE, SDF_FRESH, slot_half, sel*).
+// Compiled inside sdf_unity.hip after extz2_wave.hip (helpers, SDF_CORE, pool_code16).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -26,73 +36,80 @@
 
 namespace sdf {
 
-#define SDF_RING 256  // rows of edge values a stripe may run ahead of its right neighbour
+// bytes of LDS of one stripe's wavefront (the reversed query, byte pairs, NSLOT entries of margin either side)
+__host__ __device__ inline size_t stripe_lds_bytes(int qlen, int nreg) {
+  return ((size_t)2 * (size_t)(qlen + 256 * nreg) + 15) & ~(size_t)15;
+}
+// bytes of a task's direction flags (one region per stripe) / of its sync words and edge columns behind them
+__host__ __device__ inline size_t stripe_dir_bytes(int qlen, int tlen, int nreg) {
+  const int nslot = 128 * nreg, nst = (tlen + nslot - 1) / nslot;
+  return (size_t)nst * ((size_t)((qlen + nslot - 1 + 15) / 16) * nreg * 1024);
+}
+__host__ __device__ inline size_t stripe_sync_bytes(int qlen, int tlen, int nreg) {
+  const int nslot = 128 * nreg, nst = (tlen + nslot - 1) / nslot;
+  return (((size_t)nst * 8 + 255) & ~(size_t)255) + (size_t)(nst > 1 ? nst - 1 : 0) * (size_t)(qlen + tlen) * 4;
+}
+
+#define SDF_STRIPE_SPIN_CAP (1 << 24)  // polls before a wait gives up (a wrong result instead of a hung queue)
 
 template <int NREG>
-__global__ __launch_bounds__(1024) void extz2_stripe_kernel(const PlanTask *__restrict__ plan,
-                                                                              const int32_t *__restrict__ order,
-                                                                              const uint32_t *__restrict__ pool, ScoreK sc,
-                                                                              uint8_t *__restrict__ dirbase,
-                                                                              sdf_result *__restrict__ res) {
+__global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__restrict__ plan,
+                                                             const int32_t *__restrict__ order,
+                                                             const uint32_t *__restrict__ pool, ScoreK sc,
+                                                             uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
   extern __shared__ __align__(16) uint8_t lds[];
-  constexpr int NSLOT = 128 * NREG;  // window slots = stripe width
-  const PlanTask tk = plan[order[blockIdx.x]];
-  const int lane = threadIdx.x & 63;
-  const int sb = threadIdx.x >> 6;  // stripe of this wavefront
+  constexpr int NSLOT = 128 * NREG;  // stripe width
+  constexpr int KT = NREG - 1;
+  const int32_t entry = order[blockIdx.x];
+  const PlanTask tk = plan[entry & 0xffffff];
+  const int lane = threadIdx.x;
+  const int sb = entry >> 24;  // stripe of this wavefront
   const int tlen_all = tk.tlen;
   const int nstripe = (tlen_all + NSLOT - 1) / NSLOT;
-  const int qlen = tk.qlen, w = tk.w;
-  const int T0 = sb * NSLOT;                                           // first target position of the stripe
-  const int tlen = tlen_all - T0 < NSLOT ? tlen_all - T0 : NSLOT;      // its slice (<= 0: no such stripe)
-  // LDS: sync words | rings | reversed query (shared) | target slices (one per stripe)
-  volatile int *prog_prod = reinterpret_cast<volatile int *>(lds);       // [16] last global row stripe s has completed
-  volatile int *prog_cons = prog_prod + 16;  // [16] last global row whose edge (of stripe s) stripe s+1 is done with
-  volatile int *hand_val = prog_prod + 32;   // [16] H of the top cell after stripe s's row NSLOT-1
-  volatile uint32_t *rings = reinterpret_cast<volatile uint32_t *>(lds + 256);  // [16][SDF_RING] x | v << 16
-  const int qcap = qlen + NSLOT + 36, tcap = 2 * NSLOT + 32;
-  const int wofs = 256 + 16 * SDF_RING * 4;  // byte offset of the shared reversed query
-  uint16_t *W = reinterpret_cast<uint16_t *>(lds + wofs);
-  uint16_t *Tb = reinterpret_cast<uint16_t *>(lds + wofs + ((2 * qcap + 15) & ~15)) + sb * tcap;
-  const int64_t tw_off = tk.t_word, qw_off = tk.q_word;
-#define tt0 0
-#define we0 0
+  if (sb >= nstripe) return;  // (a padding entry of the launch order)
+  const int qlen = tk.qlen;
+  const int T0 = sb * NSLOT;                                       // first target position of the stripe
+  const int tlen = tlen_all - T0 < NSLOT ? tlen_all - T0 : NSLOT;  // its slice
+  const int nrow = qlen + tlen - 1;                                // its anti-diagonals
+  const int nrow_all = qlen + tlen_all;                            // entries of an edge column (global rows, + 1)
+  const bool has_left = sb > 0, has_right = sb + 1 < nstripe;
+  uint8_t *gsync = dirbase + tk.dir_off + (int64_t)stripe_dir_bytes(qlen, tlen_all, NREG);
+  volatile int *prog = reinterpret_cast<volatile int *>(gsync);  // [nstripe] T0 + NSLOT - 1 once stripe s has handed over
+  volatile int *hand_val = prog + nstripe;                       // [nstripe] H of its top cell after its row NSLOT - 1
+  volatile uint32_t *rings = reinterpret_cast<volatile uint32_t *>(gsync + (((size_t)nstripe * 8 + 255) & ~(size_t)255));
+  volatile uint32_t *ring_out = rings + (size_t)sb * nrow_all;
+  volatile uint32_t *ring_in = rings + (size_t)(has_left ? sb - 1 : 0) * nrow_all;
 
-  // ---- unpack: the query once for the workgroup, each wavefront its slice of the target ----
+  // ---- unpack: the reversed query as byte pairs; W[i] = (QR[i - NSLOT], QR[i - NSLOT + 1]), QR[e] = query[qlen-1-e]
+  // (0 outside): lane l of register k reads entry qlen - 1 - r + NSLOT + 128 k + 2 l on row r ----
+  uint16_t *W = reinterpret_cast<uint16_t *>(lds);
   bool has_n;
+  unsigned Tc[NREG];
   {
-    const uint32_t *tw = pool + tw_off, *tn = tw + (tlen_all + 15) / 16;
-    const uint32_t *qw = pool + qw_off, *qn = qw + (qlen + 15) / 16;
+    const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen_all + 15) / 16;
+    const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
     uint32_t n_seen = 0;
     for (int k = lane; k < (tlen_all + 31) / 32; k += 64) n_seen |= tn[k];
     for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qn[k];
     has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0)) != 0;  // wave-uniform
-    if (threadIdx.x < 16) {
-      prog_prod[threadIdx.x] = -1;
-      // nothing of an edge is needed before the next stripe's first row; no next stripe: never wait
-      prog_cons[threadIdx.x] = (int)threadIdx.x + 1 < nstripe ? ((int)threadIdx.x + 1) * NSLOT - 1 : 0x7fffffff;
-      hand_val[threadIdx.x] = 0;
-    }
-    if (sb < nstripe)  // (wavefronts beyond the task's last stripe have no slice, nor LDS for one)
-      for (int i = lane; i < tcap; i += 64) Tb[i] = i < tlen ? (uint16_t)pool_code16(tw, tn, T0 + i, sc.wild) : 0;
-    for (int i = threadIdx.x; i < qcap; i += blockDim.x) {
-      const int e0 = i - 32, e1 = e0 + 1;  // QR indices; QR[e] = query[qlen-1-e], 0 outside
+    const int qcap = qlen + 2 * NSLOT;
+    for (int i = lane; i < qcap; i += 64) {
+      const int e0 = i - NSLOT, e1 = e0 + 1;
       uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
       uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
       v0 = (v0 & 0x7fu) | ((v0 >> 8) & 0x80u);
       v1 = (v1 & 0x7fu) | ((v1 >> 8) & 0x80u);
       W[i] = (uint16_t)(v0 | (v1 << 8));
     }
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int t = 128 * k + 2 * lane;
+      const uint32_t c0 = t < tlen ? pool_code16(tw, tn, T0 + t, sc.wild) : 0u;
+      const uint32_t c1 = t + 1 < tlen ? pool_code16(tw, tn, T0 + t + 1, sc.wild) : 0u;
+      Tc[k] = c0 | (c1 << 16);
+    }
   }
   __syncthreads();
-  if (sb >= nstripe) return;
-  const bool has_left = sb > 0, has_right = sb + 1 < nstripe;
-  // the right neighbour reads this stripe's edge while its own window starts at its first column
-  const int export_until = has_right ? qlen + NSLOT + 32 : 0;
-  volatile uint32_t *ring_out = rings + sb * SDF_RING, *ring_in = rings + (sb > 0 ? sb - 1 : 0) * SDF_RING;
-  auto wait_ge = [&](volatile int *p, const int need) {
-    while (*p < need) __builtin_amdgcn_s_sleep(2);
-    __threadfence_block();
-  };
 
   // ---- constants of the <<8 difference domain ----
   const unsigned qv = ((unsigned)sc.q_b << 8) * 0x00010001u;
@@ -100,296 +117,106 @@ __global__ __launch_bounds__(1024) void extz2_stripe_kernel(const PlanTask *__re
   const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
   const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
   const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
-  const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
+  const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0
   unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16
   SDF_OPQ(one2);
   unsigned z_match_v = z_match;  // kept in a VGPR: v_pk_mad_u16 takes one scalar operand only
   SDF_OPQ(z_match_v);
 
-  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], Tc[NREG];
+  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG];
   unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
 #pragma unroll
   for (int k = 0; k < NREG; ++k) {
     U[k] = V[k] = X[k] = Y[k] = 0u;
     S[k] = z_wild;
     Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
-    Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + 128 * k + 2 * lane);
   }
-
   const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
-  // flags: one region per stripe, sized for a full stripe
-  uint4 *dir = reinterpret_cast<uint4 *>(dirbase + tk.dir_off + (int64_t)sb * ((int64_t)((qlen + NSLOT - 1 + 15) / 16) * NREG * 1024));
-  const int nrow = qlen + tlen - 1;
-  const int bperm_idx = ((lane + 8) & 63) * 4;
+  uint4 *dir = reinterpret_cast<uint4 *>(dirbase + tk.dir_off +
+                                         (int64_t)sb * ((int64_t)((qlen + NSLOT - 1 + 15) / 16) * NREG * 1024));
 
-  int base = 0;
-  int prev_lo = -1;
-  unsigned carry_x = 0u, carry_v = 0u;  // halves shifted into slot 0 on the first row of a block
-  bool zero_low = false;  // slots below the reference window still hold x,v that must read as 0
-  int32_t h_top = 0, h_under = 0;  // H of the top cell / of the cell the next top cell will read
-  bool track_h = true;  // (a stripe hands the top cell's H to the next one after its row NSLOT-1)
-  if (has_left) {  // the left stripe has finished global row T0-1: its edge values and the H of the top cell are there
-    wait_ge(prog_prod + sb - 1, T0 - 1);
-    h_top = h_under = hand_val[sb - 1];
+  // H of the top cell: along the first query row it is the left stripe's (or the matrix corner's) value plus the u of
+  // every border cell passed, added up inside the lanes and folded at the end of the head
+  int32_t h_head = -sc.qe;  // (global row 0: H = u' - 2 (q + e), the same form with this start value)
+  if (has_left) {           // the left stripe has finished global row T0 - 1: the H of its top cell is there
+    int spins = 0;
+    // (readfirstlane: the compiler cannot see that a volatile load of one address is wave-uniform, and a divergent
+    // loop here would make every value that lives across it -- the row counters -- a vector value)
+    while (__builtin_amdgcn_readfirstlane(prog[sb - 1]) < T0 - 1 && ++spins < SDF_STRIPE_SPIN_CAP) __builtin_amdgcn_s_sleep(8);
+    h_head = __builtin_amdgcn_readfirstlane(hand_val[sb - 1]);
   }
-  int32_t ez_score = SDF_NEG_INF, ez_mte = SDF_NEG_INF, ez_mte_q = -1, ez_zdropped = 0;
-  int drop_row = -1;  // row of the current block at which the reference window left slots 0..15
-  int r0 = 0;
-  unsigned qaddr = 0u, qnext[NREG];  // LDS address / prefetched query codes of row `qrow` (lean rows)
-  int qrow = -1;
+  unsigned hacc = 0u;
+  // the last stripe: H of the last column (target end), row by row from the end of the head on, inside lane LT
+  const int shT = (((tlen - 1) & 1) << 4) + 8;
+  int32_t ht = 0, best = SDF_NEG_INF, best_r = -1;
+
+  // edge words: this stripe's of the current block (export side); the left neighbour's of the current block and,
+  // fetched ahead, of the next one
+  uint32_t edge16 = 0u, feed16 = 0u, feed_next = 0u;
+  int feed_g0 = -0x40000000;
+  auto feed_load = [&](const int rfirst) -> uint32_t {  // words of the global rows T0 + rfirst - 1 + (0 .. 15)
+    // row r of this stripe reads global row T0 + r - 1 of the column, and only while its first column is in the band
+    // (r <= qlen - 1): what lies beyond is never written by the neighbour and never used here -- "tagged", value 0
+    const int i = lane & 15, r = rfirst + i;
+    return (r <= qlen - 1) ? ring_in[T0 + r - 1] : 1u;
+  };
+
+  unsigned qaddr = 0u, qnext[NREG];
 #pragma unroll
   for (int k = 0; k < NREG; ++k) qnext[k] = 0u;
-  unsigned hacc = 0u;  // lane-distributed part of the H path sum (lean rows), folded lazily
-  int hcnt = 0;        // number of path steps in hacc (each subtracts q+e)
-  auto fold_h = [&]() {  // bring the scalar path value up to date
-    if (hcnt) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
-      h_under += (int32_t)hacc - hcnt * sc.qe;
-      h_top = h_under;
-      hacc = 0u;
-      hcnt = 0;
-    }
-  };
-
-  // the stripe's last column (x, v of target position T0 + NSLOT - 1 after row r) for the right neighbour
-  auto export_edge = [&](const int r) {
-    const int s = NSLOT - 1 - base;  // its slot
-    unsigned xe = 0u, ve = 0u;
-#pragma unroll
-    for (int k = 0; k < NREG; ++k)
-      if ((s >> 7) == k) {
-        xe = slot_half(X[k], s & 127);
-        ve = slot_half(V[k], s & 127);
-      }
-    if (lane == 0) ring_out[(r + T0) & (SDF_RING - 1)] = xe | (ve << 16);
-  };
 
   // ------------------------------------------------------------------------------------------
-  // General row: every special case of the reference (first/last rows, boundary cell t = r,
-  // clipping by the sequence ends, carry-in artefacts).  Returns false when the band is exhausted.
+  // Rows [rb, re) of one 16-row block with the registers KLO .. KHI active.
+  //   head: these are rows of the first query row's passage (r <= tlen - 1): border values for the cell t = r
+  //         (register KHI) before the row, its u into the H sum after it;
+  //   exp:  the last slot's x, v leave as this stripe's edge word (rows >= NSLOT - 1 of a stripe with a right
+  //         neighbour; KHI == KT then);
+  //   trk:  the last stripe after its head: H of the last column (register KHI).
+  // The flags are constant over the call (the caller cuts the block at r = tlen and r = NSLOT - 1).
   // ------------------------------------------------------------------------------------------
-  auto slow_row = [&](const int r) -> bool {
-    fold_h();
-    // band of this row (reference :101-115); eligibility guarantees it is never empty
-    int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
-    lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
-    lo0 = lo0 < 0 ? 0 : lo0;
-    hi0 = hi0 > r ? r : hi0;
-    hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
-    if (lo0 > hi0) return false;
-    const int lo = lo0 & ~15, hi = hi0 | 15;
-    const int off_lo = lo - base;  // 0 or 16
-    const int off_hi = hi - base;  // last enabled slot
-    // the reference rebased at this row: slot off_lo's (r-1,t-1) neighbour is slot 15 (natural);
-    // on later rows that neighbour reads as 0
-    const bool ref_rebased = lo != prev_lo && prev_lo >= 0;
-    if (ref_rebased && off_lo == 16) drop_row = r;
-    if (off_lo == 16 && !ref_rebased && !zero_low) {
-      if (lane < 8) {
-        X[0] = 0u;
-        V[0] = 0u;
-      }
-      zero_low = true;
-    }
-    // ---- boundary cell t = r: y = 0, u = gap open (reference :122) ----
-    if (hi >= r) {
-      const int sr = r - base;
-      const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
-      const unsigned uval = (r + T0) ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
+  auto rows = [&](auto klo_c, auto khi_c, const bool head, const bool exp, const bool trk, const int rb, const int re) {
+    constexpr int KLO = decltype(klo_c)::value, KHI = decltype(khi_c)::value;
+    qaddr = (unsigned)(2 * (qlen - 1 - rb + NSLOT + 2 * lane));
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) {  // selects on every register: conditional stores into the arrays would be
-        const bool mine = (sr >> 7) == k && lane == ((sr & 127) >> 1);  // merged into a dynamically indexed store
-        U[k] = mine ? ((U[k] & keep) | uval) : U[k];
-        Y[k] = mine ? (Y[k] & keep) : Y[k];
-      }
-    }
-    // ---- (r-1, t-1) neighbours: shift x and v up by one slot ----
-    unsigned xt1[NREG], vt1[NREG];
-    {
-      // carry into slot 0: x = 0, v = gap open when the window starts at t = 0 (r > 0); the
-      // captured (r-1) values when the reference re-bases exactly at a block start
-      // (a stripe with a left neighbour: the neighbour's edge values of the previous global row instead)
-      const bool feed = has_left && base == 0;
-      const uint32_t fe = feed ? ring_in[(r + T0 - 1) & (SDF_RING - 1)] : 0u;
-      const unsigned vcarry = feed ? (fe & 0xffff0000u)
-                              : (base == 0 && r > 0) ? ((unsigned)sc.q_b << 24) : (r == r0 ? carry_v << 16 : 0u);
-      const unsigned xcarry = feed ? fe << 16 : (base != 0 && r == r0) ? carry_x << 16 : 0u;
-#pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        unsigned xs, vs;
-        if (k == 0) {
-          xs = (unsigned)__builtin_amdgcn_update_dpp((int)xcarry, (int)X[0], 0x138, 0xf, 0xf, false);
-          vs = (unsigned)__builtin_amdgcn_update_dpp((int)vcarry, (int)V[0], 0x138, 0xf, 0xf, false);
-        } else {
-          int ux, uv;
-          asm("" : "=v"(ux));
-          asm("" : "=v"(uv));
-          const int x0 = __builtin_amdgcn_update_dpp(ux, (int)X[k - 1], 0x13C, 0x1, 0x1, false);
-          xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-          const int v0 = __builtin_amdgcn_update_dpp(uv, (int)V[k - 1], 0x13C, 0x1, 0x1, false);
-          vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
-        }
-        xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
-        vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
-      }
-      // sign-extension artefact of the reference's carry-in (:145-146): a negative v carry also
-      // sets lanes 1..3 of the first block.  Only possible on the reference's rebase rows.
-      if (ref_rebased) {
-        if (off_lo == 16) {
-          const unsigned cvh = slot_half(V[0], 15);
-          if (cvh & 0x8000u) {
-            if (lane == 8) vt1[0] |= 0xff000000u;
-            if (lane == 9) vt1[0] |= 0xff00ff00u;
-          }
-        } else if (r == r0 && (carry_v & 0x8000u)) {
-          if (lane == 0) vt1[0] |= 0xff000000u;
-          if (lane == 1) vt1[0] |= 0xff00ff00u;
-        }
-      }
-    }
-    // ---- scores: refresh [lo0, lo0 + 16*n), keep the old value elsewhere ----
-    {
-      const int ra = lo0 - base;
-      const int rb = ra + ((hi0 - lo0) & ~15) + 16;
-      const int cq = qlen - 1 - r + base + 32;
-#pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        const int a_ = ra - 128 * k, b_ = rb - 128 * k;
-        if (b_ > 0 && a_ < 128) {
-          const unsigned qc = W[cq - we0 + 128 * k + 2 * lane];  // zero-extended byte pair
-          unsigned z;
-          SDF_FRESH(z, Tc[k], qc)
-          if (a_ <= 0 && b_ >= 128) {
-            S[k] = z;
-          } else {
-            sel_lo_rng(S[k], z, (a_ + 1) >> 1, (b_ + 1) >> 1, lane);
-            sel_hi_rng(S[k], z, a_ >> 1, b_ >> 1, lane);
-          }
-        }
-      }
-    }
-    // ---- the recurrence on the reference's widened range [lo, hi] ----
-#pragma unroll
-    for (int k = 0; k < NREG; ++k) {
-      const int l0 = off_lo - 128 * k <= 0 ? 0 : (off_lo - 128 * k) >> 1;
-      const int l1 = (off_hi - 128 * k) >> 1;  // off_hi is odd
-      if (l1 >= l0 && l0 < 64) {
-        if ((unsigned)(lane - l0) <= (unsigned)(l1 - l0)) SDF_CORE(k)
-      }
-    }
-    // ---- exact H of the top cell and of the cell under the band edge (score, mte) ----
-    {
-      const int st = hi0 - base;  // slot of the top cell
-      unsigned uh = 0, vu = 0;
-      // next row's top cell: does it move up?
-      int hin = (r + 1 + w) >> 1;
-      hin = hin > r + 1 ? r + 1 : hin;
-      hin = hin > tlen - 1 ? tlen - 1 : hin;
-      const bool up = hin == hi0 + 1 || hin == 0;
-      const bool want_top = up || hi0 == tlen - 1 || hi0 == 0;
-#pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        if (want_top && (st >> 7) == k) uh = hi0 > 0 ? slot_half(U[k], st & 127) : slot_half(V[k], st & 127);
-        if (!up && st > 0 && ((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
-      }
-      if (want_top) {
-        if (r + T0 == 0) h_top = (int32_t)(uh >> 8) - 2 * sc.qe;
-        else h_top = (hi0 > 0 ? h_under : h_top) + (int32_t)(uh >> 8) - sc.qe;
-      }
-      if (up || r + T0 == 0) {
-        h_under = h_top;
-      } else if (hi0 - 1 >= lo0) {
-        h_under += (int32_t)(vu >> 8) - sc.qe;
-      }
-      if (hi0 == tlen - 1) {
-        if (h_top > ez_mte) {
-          ez_mte = h_top;
-          ez_mte_q = r - hi;
-        }
-        if (r == nrow - 1) ez_score = h_top;
-      }
-    }
-    if (r >= NSLOT - 1 && r < export_until) export_edge(r);
-    prev_lo = lo;
-    return true;
-  };
-
-  // ------------------------------------------------------------------------------------------
-  // Lean rows [rb, re) of one block (rb >= 1): the same recurrence as the general row with the
-  // rare cases taken out (row 0, captured carries, the sign-extension artefact -- the caller
-  // routes those rows to slow_row) and everything that is constant over the segment hoisted:
-  //   LOW16   the reference window starts at base+16 (lanes 0..7 of register 0 are out of it);
-  //   SCALARH hi0 == tlen-1: the top cell's H is needed every row (mte / score) -> scalar path;
-  //           otherwise the H path sum is accumulated inside the owning lane, reduced at the end;
-  //   STEADY  pure band regime lo0 = (r-w+1)>>1, hi0 = (r+w)>>1, no boundary cell t = r, refresh
-  //           range from register 0 to register KT: no per-register case analysis at all.
-  // Lanes above the window top are NOT masked: they compute values nobody reads (the neighbour
-  // dependency only runs upwards); the caller zeroes them when the window grows over them.
-  // Lane predicates are VALU compares: the scalar unit is shared by the CU's four SIMDs and was
-  // the bottleneck of the general row.
-  // ------------------------------------------------------------------------------------------
-  auto lean_rows = [&](auto low16_c, auto scalarh_c, auto steady_c, const int rb, const int re) {
-    constexpr bool LOW16 = decltype(low16_c)::value;
-    constexpr bool SCALARH = decltype(scalarh_c)::value;
-    constexpr bool STEADY = decltype(steady_c)::value;
-    constexpr int KT = NREG - 1;
-    if (SCALARH) fold_h();
-    if (qrow != rb) {  // (re)start the one-row-ahead query fetch at this row
-      qaddr = (unsigned)(wofs + 2 * (qlen - 1 - rb + base + 32 + 2 * lane));
-#pragma unroll
-      for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
-    }
-    qrow = re;
-    if (STEADY && !SCALARH) hcnt += re - rb;  // every steady row takes one path step
-    const unsigned vcar = base == 0 ? ((unsigned)sc.q_b << 24) : 0u;  // v carry into slot 0 (r > 0)
-    const bool feed = has_left && base == 0;  // ... or the left stripe's edge values of the previous global row
+    for (int k = KLO; k <= KHI; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+    const bool feed = KLO == 0 && has_left;
+    int fidx = rb + T0 - 1 - feed_g0;  // lane of feed16 with the left edge word of the previous global row
+    int eidx = rb & 15;                // lane of edge16 this row's edge word goes to
 #pragma unroll 1
-    for (int r = rb; r < re; ++r) {
-      int hi0 = (r + w) >> 1, lo0 = (r - w + 1) >> 1;
-      if (!STEADY) {
-        lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
-        lo0 = lo0 < 0 ? 0 : lo0;
-        hi0 = hi0 > r ? r : hi0;
-        hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
-      }
-      const int off_hi = (hi0 | 15) - base;
+    for (int r = rb; r < re; ++r, ++fidx, ++eidx) {
       unsigned qcur[NREG];
       qaddr -= 2;
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) {
+      for (int k = KLO; k <= KHI; ++k) {
         qcur[k] = qnext[k];
         qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
       }
-      // boundary cell t = r: y = 0, u = gap open (reference :122)
-      if (!STEADY && off_hi + base >= r) {
-        const int sr = r - base;
+      const int sr = r - 128 * KHI;  // slot of the cell t = r inside register KHI (head rows)
+      const bool mine = lane == (sr >> 1);
+      if (head) {  // border cell t = r: y = 0, u = gap open (reference :122; 0 on global row 0)
         const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
-        const unsigned uval = ((unsigned)sc.q_b << 8) << ((sr & 1) * 16);
-#pragma unroll
-        for (int k = 0; k < NREG; ++k) {  // selects on every register (see slow_row)
-          const bool mine = (sr >> 7) == k && lane == ((sr & 127) >> 1);
-          U[k] = mine ? ((U[k] & keep) | uval) : U[k];
-          Y[k] = mine ? (Y[k] & keep) : Y[k];
-        }
+        const unsigned uval = (r + T0) ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
+        U[KHI] = mine ? ((U[KHI] & keep) | uval) : U[KHI];
+        Y[KHI] = mine ? (Y[KHI] & keep) : Y[KHI];
       }
+      // (r-1, t-1) neighbours: x and v one slot up; into slot 0 the left stripe's edge word of the previous global
+      // row, or the start-of-target constants (x = 0, v = gap open; 0 on row 0)
       unsigned xt1[NREG], vt1[NREG];
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) {
+      for (int k = KLO; k <= KHI; ++k) {
         unsigned xs, vs;
         if (k == 0) {
-          if (STEADY) {
-            xs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X[0], 0x138, 0xf, 0xf, true);
-            vs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)V[0], 0x138, 0xf, 0xf, true);
-          } else if (feed) {
-            const uint32_t fe = ring_in[(r + T0 - 1) & (SDF_RING - 1)];
-            xs = (unsigned)__builtin_amdgcn_update_dpp((int)(fe << 16), (int)X[0], 0x138, 0xf, 0xf, false);
-            vs = (unsigned)__builtin_amdgcn_update_dpp((int)(fe & 0xffff0000u), (int)V[0], 0x138, 0xf, 0xf, false);
-          } else {
-            xs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X[0], 0x138, 0xf, 0xf, true);
-            vs = (unsigned)__builtin_amdgcn_update_dpp((int)vcar, (int)V[0], 0x138, 0xf, 0xf, false);
+          unsigned xc = 0u, vc = r ? ((unsigned)sc.q_b << 24) : 0u;
+          if (feed) {
+            const uint32_t fe = (uint32_t)__builtin_amdgcn_readlane((int)feed16, fidx);
+            xc = (fe & 0xfffeu) << 16;
+            vc = fe & 0xffff0000u;
           }
+          xs = (unsigned)__builtin_amdgcn_update_dpp((int)xc, (int)X[0], 0x138, 0xf, 0xf, false);
+          vs = (unsigned)__builtin_amdgcn_update_dpp((int)vc, (int)V[0], 0x138, 0xf, 0xf, false);
         } else {
+          // (register k - 1 may have dropped out of the band: its last values are those of the row before it did,
+          // which is the only row on which slot 128 k still reads them)
           int ux, uv;  // lanes 1..63 are overwritten by the second move: no initial value needed
           asm("" : "=v"(ux));
           asm("" : "=v"(uv));
@@ -401,345 +228,148 @@ __global__ __launch_bounds__(1024) void extz2_stripe_kernel(const PlanTask *__re
         xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
         vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
       }
-      // scores: refreshed slots are [ra, rbe)
-      const int ra = lo0 - base;
-      const int rbe = ra + ((hi0 - lo0) & ~15) + 16;
+      // scores of the row's cells
+      unsigned qc[NREG];
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        const int b_ = rbe - 128 * k;
-        if (STEADY) {
-          unsigned z;
-          SDF_FRESH(z, Tc[k], qcur[k])
-          if (NREG == 1) {
-            sel_lo_rng(S[0], z, (ra + 1) >> 1, (b_ + 1) >> 1, lane);
-            sel_hi_rng(S[0], z, ra >> 1, b_ >> 1, lane);
-          } else if (k == 0) {
-            sel2_ge(S[0], z, (ra + 1) >> 1, ra >> 1, lane);
-          } else if (k == KT) {
-            sel2_lt(S[k], z, (b_ + 1) >> 1, b_ >> 1, lane);
-          } else {
-            S[k] = z;
-          }
-        } else if (b_ > 0) {
-          unsigned z;
-          SDF_FRESH(z, Tc[k], qcur[k])
-          if (k == 0) {
-            if (b_ >= 128) {
-              sel2_ge(S[0], z, (ra + 1) >> 1, ra >> 1, lane);
-            } else {
-              sel_lo_rng(S[0], z, (ra + 1) >> 1, (b_ + 1) >> 1, lane);
-              sel_hi_rng(S[0], z, ra >> 1, b_ >> 1, lane);
-            }
-          } else if (b_ >= 128) {
-            S[k] = z;
-          } else {
-            sel2_lt(S[k], z, (b_ + 1) >> 1, b_ >> 1, lane);
-          }
+      for (int k = KLO; k <= KHI; ++k) {
+        qc[k] = __builtin_amdgcn_perm(0u, qcur[k], 0x0c010c00u);  // bytes -> halves
+        S[k] = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+      }
+      if (has_n) {
+#pragma unroll
+        for (int k = KLO; k <= KHI; ++k) {
+          unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
+          SDF_OPQ(nn);
+          S[k] = (z_wild & nn) | (S[k] & ~nn);
         }
       }
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) {
-        if (STEADY || off_hi >= 128 * k) {
-          if (k == 0 && LOW16) {
-            if (lane >= 8) SDF_CORE(0)
-          } else {
-            SDF_CORE(k)
-          }
-        }
+      for (int k = KLO; k <= KHI; ++k) SDF_CORE(k)
+      if (head) hacc += mine ? ((U[KHI] >> (((sr & 1) << 4) + 8)) & 0xffu) : 0u;
+      if (exp) {
+        // x | v << 16 of the last slot (high halves of lane 63), tagged, into its lane of the block's edge words
+        const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
+        const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;  // (outside the select: all lanes)
+        edge16 = lane == eidx ? es : edge16;
       }
-      if (SCALARH) {
-        // top cell H every row: h_top = H(cell under the edge, previous row) + u(top) - (q+e)
-        const int st = hi0 - base;
-        unsigned uh = 0u, vu = 0u;
-#pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          if ((st >> 7) == k) uh = slot_half(U[k], st & 127);
-          if (((st - 1) >> 7) == k) vu = slot_half(V[k], (st - 1) & 127);
-        }
-        h_top = h_under + (int32_t)(uh >> 8) - sc.qe;
-        if (hi0 - 1 >= lo0) h_under += (int32_t)(vu >> 8) - sc.qe;
-        if (h_top > ez_mte) {
-          ez_mte = h_top;
-          ez_mte_q = r - (hi0 | 15);
-        }
-        if (r == nrow - 1) ez_score = h_top;
-      } else {
-        // H path: rows whose successor moves the top cell up read u of the top cell, the others
-        // read v of the cell under it.  Added up inside the owning lane, reduced once at the end.
-        int up;
-        if (STEADY) {
-          up = (r + w) & 1;
-        } else {
-          int hin = (r + 1 + w) >> 1;
-          hin = hin > r + 1 ? r + 1 : hin;
-          hin = hin > tlen - 1 ? tlen - 1 : hin;
-          up = hin == hi0 + 1;
-        }
-        if (STEADY || up || hi0 - 1 >= lo0) {
-          const int sl = hi0 - base - 1 + up;
-          const int sh = ((sl & 1) << 4) + 8;
-          unsigned val = 0u;
-          if (STEADY) {
-            const int slt = sl - 128 * KT;
-            if (NREG > 1 && slt < 0) {
-              if (up) val = U[KT > 0 ? KT - 1 : 0]; else val = V[KT > 0 ? KT - 1 : 0];
-            } else {
-              if (up) val = U[KT]; else val = V[KT];
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < NREG; ++k)
-              if ((sl >> 7) == k) {
-                if (up) val = U[k]; else val = V[k];
-              }
-          }
-          if (lane == ((sl & 127) >> 1)) hacc += (val >> sh) & 0xffu;
-          if (!STEADY) ++hcnt;
-        }
-      }
-      if (r >= NSLOT - 1 && r < export_until) export_edge(r);
-    }
-  };
-  // U,V,X,Y of the cells t in [t_from, t_to] back to "never computed" (both bounds block aligned)
-  auto zero_cells = [&](const int t_from, const int t_to) {
-#pragma unroll
-    for (int k = 0; k < NREG; ++k) {
-      const int a_ = t_from - base - 128 * k, b_ = t_to - base - 128 * k;
-      if (b_ >= 0 && a_ < 128) {
-        const int la = a_ <= 0 ? 0 : a_ >> 1, lb = b_ >> 1;
-        if ((unsigned)(lane - la) <= (unsigned)(lb - la)) {
-          U[k] = 0u;
-          V[k] = 0u;
-          X[k] = 0u;
-          Y[k] = 0u;
-        }
+      if (trk) {  // H(r, T) = H(r-1, T) + v(r, T), T = tlen - 1
+        ht += (int32_t)((V[KHI] >> shT) & 0xffu) - sc.qe;
+        const bool gt = ht > best;
+        best = gt ? ht : best;
+        best_r = gt ? r : best_r;
       }
     }
   };
-  int win_hi = -1;    // last cell of the reference window so far (cells above it were never computed)
-  int dirty_hi = -1;  // cells in (win_hi, dirty_hi] may hold scratch values left by lean rows
+  auto run_rows = [&](const int klo, const int khi, const bool head, const bool exp, const bool trk, const int rb,
+                      const int re) {
+#define SDF_ROWS(A, B)                                                                                               \
+  case (A) * 4 + (B):                                                                                                 \
+    if constexpr ((B) < NREG && (A) <= (B))                                                                           \
+      rows(std::integral_constant<int, (A)>{}, std::integral_constant<int, (B)>{}, head, exp, trk, rb, re);           \
+    break;
+    switch (klo * 4 + khi) {
+      SDF_ROWS(0, 0) SDF_ROWS(0, 1) SDF_ROWS(0, 2) SDF_ROWS(0, 3) SDF_ROWS(1, 1) SDF_ROWS(1, 2) SDF_ROWS(1, 3)
+      SDF_ROWS(2, 2) SDF_ROWS(2, 3) SDF_ROWS(3, 3)
+      default: break;
+    }
+#undef SDF_ROWS
+  };
 
-  for (r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
-    // ---- block start: re-base the window to the reference's band start of this row ----
-    {
-      Band b0;
-      if (!band_of(r0, qlen, tlen, w, b0)) {
-        ez_zdropped = 1;
-        break;
-      }
-      carry_x = carry_v = 0u;
-      if (b0.lo != base) {  // always +16: shift everything down by 8 lanes
-        if (prev_lo == base) {  // the reference re-bases at this very row: its carry-in is the
-          carry_x = slot_half(X[0], 15);  // (r-1) value of the cell just below the new window
-          carry_v = slot_half(V[0], 15);
-        }
-#pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          const bool from_next = lane >= 56;
-          unsigned a0, a1;
-#define SDF_SHIFT8(A, INIT)                                                              \
-  a0 = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_idx, (int)A[k]);                     \
-  a1 = (k + 1 < NREG) ? (unsigned)__builtin_amdgcn_ds_bpermute(bperm_idx, (int)A[k + 1 < NREG ? k + 1 : k]) : (INIT); \
-  A[k] = from_next ? a1 : a0;
-          SDF_SHIFT8(U, 0u)
-          SDF_SHIFT8(V, 0u)
-          SDF_SHIFT8(X, 0u)
-          SDF_SHIFT8(Y, 0u)
-          SDF_SHIFT8(S, z_wild)
-#undef SDF_SHIFT8
-        }
-        base = b0.lo;
-        qrow = -1;  // the window moved: query addresses change
-#pragma unroll
-        for (int k = 0; k < NREG; ++k)
-          Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + (base - tt0) + 128 * k + 2 * lane);
-        zero_low = false;
-      }
-    }
-    // ---- systolic hand-shake with the neighbour stripes (whole blocks: 16 rows of slack either way) ----
-    {
-      const int g_end = T0 + (r0 + 15 < nrow - 1 ? r0 + 15 : nrow - 1);  // last global row of this block
-      if (has_left) {
-        if (base == 0) wait_ge(prog_prod + sb - 1, g_end - 1);  // the left stripe's edge of the rows before ours
-      }
-      if (has_right && r0 < export_until) wait_ge(prog_cons + sb, g_end - SDF_RING + 1);  // ring not overrun
-    }
+  for (int r0 = 0; r0 < nrow; r0 += 16) {
+    r0 = __builtin_amdgcn_readfirstlane(r0);  // (wave-uniform; stated, so that the row loops stay scalar branches)
     const int rend = r0 + 16 < nrow ? r0 + 16 : nrow;
-    drop_row = -1;
-    int r = r0;
-    // rows of this block: lean segments between the rows at which the reference window changes
-    {
-      constexpr int KT = NREG - 1;
-      const int rl = r0 + 15;
-      // pure band regime on all 16 rows, no boundary cell, refresh range spanning registers 0..KT
-      bool steady = w >= 2 && r0 + 16 <= nrow && base >= 16 && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
-                    ((rl + w) >> 1) < tlen - 1 && ((r0 + w) >> 1) + 15 < r0;
-      if (steady) {
-        const int lo0a = (r0 - w + 1) >> 1, hi0a = (r0 + w) >> 1;
-        steady = lo0a + ((w - 1) & ~15) + 16 - base >= 128 * KT && (hi0a | 15) - base >= 128 * KT &&
-                 hi0a - 1 - base >= 128 * KT - 128;
+    // registers with a cell of the band on some row of the block
+    const int lo_first = r0 - qlen + 1 > 0 ? r0 - qlen + 1 : 0;
+    const int hi_last = rend - 1 < tlen - 1 ? rend - 1 : tlen - 1;
+    const int klo = lo_first >> 7, khi = hi_last >> 7;
+    if (has_left && klo == 0) {
+      // the sixteen edge words of the block: fetched during the previous block; all tagged, or fetched again
+      uint32_t got = (feed_g0 + 16 == T0 + r0 - 1) ? feed_next : feed_load(r0);
+      int spins = 0;
+      while (__builtin_amdgcn_readfirstlane((int)__any((got & 1u) == 0u)) && ++spins < SDF_STRIPE_SPIN_CAP) {
+        __builtin_amdgcn_s_sleep(2);
+        got = feed_load(r0);
       }
-      const bool lean_ok = tlen >= 2 && w >= 1;
-      bool low16 = false;
-      while (r < rend) {
-        int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
-        lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
-        lo0 = lo0 < 0 ? 0 : lo0;
-        hi0 = hi0 > r ? r : hi0;
-        hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
-        if (lo0 > hi0) {
-          ez_zdropped = 1;
-          break;
-        }
-        const int lo = lo0 & ~15, hi = hi0 | 15;
-        if (hi > win_hi) {  // the window grows over cells that must read as "never computed"
-          if (dirty_hi > win_hi) zero_cells(win_hi + 1, hi < dirty_hi ? hi : dirty_hi);
-          win_hi = hi;
-          if (dirty_hi < win_hi) dirty_hi = win_hi;
-        }
-        const bool rebase_row = lo != prev_lo && prev_lo >= 0;
-        bool special = !lean_ok || r + T0 == 0 || (r == r0 && (carry_x | carry_v) != 0u);
-        if (rebase_row && !special) {
-          // natural neighbour, but mind the sign-extension artefact of a negative carry
-          const unsigned cvh = lo - base == 16 ? slot_half(V[0], 15) : carry_v;
-          special = (cvh & 0x8000u) != 0u;
-        }
-        if (special) {
-          if (dirty_hi > win_hi) zero_cells(win_hi + 1, dirty_hi);
-          dirty_hi = win_hi;
-          if (!slow_row(r)) {
-            ez_zdropped = 1;
-            break;
-          }
-          low16 = prev_lo - base == 16;
-          if (has_right && track_h && r >= tlen - 1) {
-            fold_h();
-            hand_val[sb] = h_top;
-            track_h = false;
-          }
-          ++r;
-          continue;
-        }
-        if (rebase_row) {
-          if (lo - base == 16) {
-            drop_row = r;
-            low16 = true;
-          }
-        } else if (low16 && !zero_low) {
-          if (lane < 8) {
-            X[0] = 0u;
-            V[0] = 0u;
-          }
-          zero_low = true;
-        }
-        // rows until the reference window changes again (closed forms of the band geometry)
-        int stop = rend;
-        if (rebase_row) {
-          stop = r + 1;  // the re-base row runs alone: slots 0..15 are zeroed right after it
-        } else {
-          int rr = lo + 15 + qlen;
-          const int rr2 = 2 * (lo + 16) + w - 1;
-          rr = rr2 < rr ? rr2 : rr;
-          if (rr > r && rr < stop) stop = rr;
-          const int h1 = hi + 1;
-          if (h1 <= tlen - 1) {
-            int rh = 2 * h1 - w;
-            rh = rh < h1 ? h1 : rh;
-            if (rh > r && rh < stop) stop = rh;
-          }
-          int rt = 2 * (tlen - 1) - w;
-          rt = rt < tlen - 1 ? tlen - 1 : rt;
-          if (rt > r && rt < stop) stop = rt;
-        }
-        if (has_right && track_h && r == tlen - 1 && stop > r + 1) stop = r + 1;  // that row alone: its H is handed on
-        const bool scalarh = track_h && hi0 == tlen - 1;
-        if (scalarh) {
-          if (low16) lean_rows(std::true_type{}, std::true_type{}, std::false_type{}, r, stop);
-          else lean_rows(std::false_type{}, std::true_type{}, std::false_type{}, r, stop);
-        } else if (steady) {
-          if (low16) lean_rows(std::true_type{}, std::false_type{}, std::true_type{}, r, stop);
-          else lean_rows(std::false_type{}, std::false_type{}, std::true_type{}, r, stop);
-        } else {
-          if (low16) lean_rows(std::true_type{}, std::false_type{}, std::false_type{}, r, stop);
-          else lean_rows(std::false_type{}, std::false_type{}, std::false_type{}, r, stop);
-        }
-        if (has_right && track_h && stop > tlen - 1) {  // row NSLOT-1 done: the next stripe takes over the top cell
-          fold_h();
-          hand_val[sb] = h_top;
-          track_h = false;
-        }
-        {  // the top register of the window now holds scratch values above the window
-          const int top = base + 128 * (((win_hi - base) >> 7) + 1) - 1;
-          if (top > dirty_hi) dirty_hi = top;
-        }
-        prev_lo = lo;
-        r = stop;
-      }
-      if (dirty_hi > win_hi) zero_cells(win_hi + 1, dirty_hi);  // clean lanes for the re-base shift
-      dirty_hi = win_hi;
+      feed16 = got;
+      feed_g0 = T0 + r0 - 1;
+      feed_next = feed_load(r0 + 16);  // for the next block; checked there
     }
-    // ---- block end: direction flags of these (<=16) rows leave for HBM ----
-    if (with_dir) {
-      const int done = r - r0;
-      const int rbk = r0 >> 4;
-      if (drop_row >= 0 && lane < 8) {  // lanes that stopped shifting when their slots were dropped
-        const unsigned sh = (unsigned)(r - drop_row);
-        Fa[0] = pk_shl(Fa[0], sh);
-        Fb[0] = pk_shl(Fb[0], sh);
-        Fx[0] = pk_shl(Fx[0], sh);
-        Fy[0] = pk_shl(Fy[0], sh);
-      }
-      if (done > 0) {
+    // cut at the end of the head (r = tlen) and where the edge export starts (r = NSLOT - 1)
+    int r = r0;
+    while (r < rend) {
+      r = __builtin_amdgcn_readfirstlane(r);
+      const bool head = r < tlen;
+      const bool exp = has_right && r >= NSLOT - 1;
+      int stop = rend;
+      if (head && tlen < stop) stop = tlen;
+      if (has_right && r < NSLOT - 1 && NSLOT - 1 < stop) stop = NSLOT - 1;
+      run_rows(klo, khi, head, exp, !has_right && !head, r, stop);
+      r = stop;
+      if (r == tlen) {  // the first query row has reached the end of the slice: fold the H sum
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          unsigned fa = Fa[k], fb = Fb[k], fx = Fx[k], fy = Fy[k];
-          if (done < 16) {
-            const unsigned sh = 16 - done;
-            fa = pk_shl(fa, sh);
-            fb = pk_shl(fb, sh);
-            fx = pk_shl(fx, sh);
-            fy = pk_shl(fy, sh);
-          }
-          dir[((int64_t)rbk * NREG + k) * 64 + lane] = make_uint4(fa, fb, fx, fy);
+        for (int off = 32; off >= 1; off >>= 1) hacc += (unsigned)__shfl_xor((int)hacc, off);
+        h_head += (int32_t)hacc - tlen * sc.qe;
+        ht = best = h_head;  // (the last stripe: H(tlen - 1, tlen - 1), the first candidate for mte)
+        best_r = tlen - 1;
+      }
+    }
+    // ---- block end: direction flags of these (<= 16) rows leave for HBM ----
+    if (with_dir) {
+      const int done = rend - r0;
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        if (k < klo || k > khi) continue;
+        unsigned fa = Fa[k], fb = Fb[k], fx = Fx[k], fy = Fy[k];
+        if (done < 16) {
+          const unsigned sh = 16 - done;
+          fa = pk_shl(fa, sh);
+          fb = pk_shl(fb, sh);
+          fx = pk_shl(fx, sh);
+          fy = pk_shl(fy, sh);
         }
+        dir[((int64_t)(r0 >> 4) * NREG + k) * 64 + lane] = make_uint4(fa, fb, fx, fy);
       }
     }
 #pragma unroll
     for (int k = 0; k < NREG; ++k) Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
-    // publish: rows done (edge values and hand-off written before), edge rows consumed
-    __threadfence_block();
-    if (lane == 0) {
-      if (has_right) prog_prod[sb] = T0 + r - 1;
-      if (has_left) prog_cons[sb - 1] = (base == 0 && r < nrow) ? T0 + r - 2 : 0x7fffffff;
+    if (has_right) {
+      if (rend > NSLOT - 1) {  // this block's edge words (the tagged ones: rows >= NSLOT - 1)
+        const int g = T0 + r0 + lane;
+        if (lane < 16 && (edge16 & 1u) && g < nrow_all) ring_out[g] = edge16;
+      }
+      edge16 = 0u;
+      if (rend == NSLOT) {  // first query row done, its edge word stored: the right neighbour may start
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) {
+          hand_val[sb] = h_head;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          prog[sb] = T0 + NSLOT - 1;
+        }
+      }
     }
-  }
-  __threadfence_block();
-  if (lane == 0) {  // (a stripe that ends early must not hold its neighbours up)
-    if (has_right) prog_prod[sb] = 0x7fffffff;
-    if (has_left) prog_cons[sb - 1] = 0x7fffffff;
   }
   if (has_right) return;  // the last stripe owns the end of the target: score, mte
 
-  fold_h();
+  const int lt = ((tlen - 1) & 127) >> 1;
+  const int32_t score = __builtin_amdgcn_readlane(ht, lt);
+  const int32_t mte = __builtin_amdgcn_readlane(best, lt);
+  const int32_t mte_r = __builtin_amdgcn_readlane(best_r, lt);
   if (lane == 0) {
     sdf_result o;
-    o.score = ez_score;
+    o.score = score;
     o.max = 0;
     o.max_q = o.max_t = -1;
     o.mqe = SDF_NEG_INF;
     o.mqe_t = -1;
-    o.mte = ez_mte;
-    o.mte_q = ez_mte_q;
-    o.zdropped = ez_zdropped;
+    o.mte = mte;
+    o.mte_q = mte_r - ((tlen - 1) | 15);  // (the reference's en is block-rounded, :209)
+    o.zdropped = 0;
     o.n_cigar = 0;
     o.cigar_off = 0;
     o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
     res[tk.out_idx] = o;
   }
 }
-
-#undef tt0
-#undef we0
 
 template __global__ void extz2_stripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                                 sdf_result *);
@@ -748,15 +378,27 @@ template __global__ void extz2_stripe_kernel<2>(const PlanTask *, const int32_t 
 template __global__ void extz2_stripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                                 sdf_result *);
 
-// dynamic LDS of a launch with `nstripe` wavefronts per workgroup
-size_t stripe_lds_bytes(int qlen, int nstripe, int nreg) {
-  const size_t nslot = 128 * (size_t)nreg;
-  return 256 + 16 * SDF_RING * 4 + ((2 * ((size_t)qlen + nslot + 36) + 15) & ~(size_t)15) + (size_t)nstripe * 2 * (2 * nslot + 32);
-}
-
-// flag bytes of one stripe's region (sized for a full stripe)
-size_t stripe_dir_bytes(int qlen, int nreg) {
-  return (size_t)((qlen + 128 * nreg - 1 + 15) / 16) * (size_t)nreg * 1024;
+// Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's progress and hand-over words to
+// "nothing done" and the edge column of its right boundary to zero (no word tagged as written)
+__global__ __launch_bounds__(64) void stripe_sync_init_kernel(const PlanTask *__restrict__ plan,
+                                                              const int32_t *__restrict__ order, int nreg,
+                                                              uint8_t *__restrict__ dirbase) {
+  const int32_t entry = order[blockIdx.x];
+  const PlanTask tk = plan[entry & 0xffffff];
+  const int sb = entry >> 24;
+  const int nslot = 128 * nreg, nst = (tk.tlen + nslot - 1) / nslot;
+  if (sb >= nst) return;
+  uint8_t *gsync = dirbase + tk.dir_off + (int64_t)stripe_dir_bytes(tk.qlen, tk.tlen, nreg);
+  int *prog = reinterpret_cast<int *>(gsync);
+  if (threadIdx.x == 0) {
+    prog[sb] = -1;
+    prog[nst + sb] = 0;
+  }
+  if (sb + 1 < nst) {
+    const int nrow_all = tk.qlen + tk.tlen;
+    uint32_t *col = reinterpret_cast<uint32_t *>(gsync + (((size_t)nst * 8 + 255) & ~(size_t)255)) + (size_t)sb * nrow_all;
+    for (int g = threadIdx.x; g < nrow_all; g += 64) col[g] = 0u;
+  }
 }
 
 }  // namespace sdf

@@ -368,10 +368,11 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   const size_t np = std::max<size_t>(cut.ntask_total, 1);
   SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(cut.stage_total, 4) * 4));
   SDF_HIP(ctx->plan_buf.reserve(np * sizeof(PlanTask)));
-  SDF_HIP(ctx->order_buf.reserve(2 * np * sizeof(int32_t)));  // a task paired with itself is listed twice
+  const size_t nord = std::max<size_t>(cut.order_total, 2);
+  SDF_HIP(ctx->order_buf.reserve(nord * sizeof(int32_t)));
   SDF_HIP(ctx->misc_buf.reserve(256 + ((n + 1023) / 1024 + 1) * 8));
   SDF_HIP(ctx->host_plan.reserve(np * sizeof(PlanTask)));
-  SDF_HIP(ctx->host_order.reserve(2 * np * sizeof(int32_t)));
+  SDF_HIP(ctx->host_order.reserve(nord * sizeof(int32_t)));
   run.plan = (PlanTask *)ctx->host_plan.p;  // pinned: the uploads are asynchronous
   run.order = (int32_t *)ctx->host_order.p;
   run.d_plan = (PlanTask *)ctx->plan_buf.p;
@@ -822,7 +823,7 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   if (int rc = cut_batch(env, true, ws_budget, cut, &msg)) return rc;
   const size_t np = std::max<size_t>(cut.ntask_total, 1);
   std::vector<PlanTask> plan(np);
-  std::vector<int32_t> order(2 * np);
+  std::vector<int32_t> order(std::max<size_t>(cut.order_total, 2));
   {
     WorkerPool pool(std::max(nthreads, 1));
     ChunkPlanner planner(env, cut, plan.data(), order.data(), &pool, nthreads);
@@ -843,8 +844,13 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
     }
     for (const Launch &L : c.launches) {
       const bool pair = L.bs >= 100 && L.bs < 200;
+      const bool stripes = L.bs >= 300 && L.bs < 400;
       for (size_t e = 0; e < L.cnt; ++e) {
-        const int32_t rel = order[c.ob + L.off + e];
+        int32_t rel = order[c.ob + L.off + e];
+        if (stripes) {  // one entry per stripe: the task is reported at its stripe 0
+          if (rel >> 24) continue;
+          rel &= 0xffffff;
+        }
         const PlanTask &p = plan[c.pb + rel];
         int64_t *o = per_task + 7 * (size_t)p.out_idx;
         if (o[0] >= 0 && !(pair && o[6] == p.out_idx)) return SDF_ERR_INVALID;  // listed twice (only a self-pair may be)

@@ -36,8 +36,7 @@ bool pair_fits_whole(int qlen, int tlen, int nreg);
 template <int NREG>
 __global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                     sdf_result *);
-size_t stripe_lds_bytes(int qlen, int nstripe, int nreg);
-size_t stripe_dir_bytes(int qlen, int nreg);
+__global__ void stripe_sync_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 template <int LAYOUT, int G>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
 __global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);

@@ -70,8 +70,11 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
   hipLaunchKernelGGL((extz2_pair_kernel<N, S, false>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
 #define SDF_PAIR_TRACK(N) \
   hipLaunchKernelGGL((extz2_pair_kernel<N, true, true>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
-#define SDF_STRIPE(N) \
-  hipLaunchKernelGGL(extz2_stripe_kernel<N>, one, dim3(64 * L.kmax), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
+#define SDF_STRIPE(N) /* one workgroup of one wavefront per stripe; progress words and edge columns reset first */ \
+  {                                                                                                              \
+    hipLaunchKernelGGL(stripe_sync_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                      \
+    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out); \
+  }
 #define SDF_GENERAL(BS, PLAIN)                                                                                      \
   hipLaunchKernelGGL((extz2_general_kernel<BS, false, PLAIN>), one, dim3(BS), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, \
                      d_out, (uint8_t *)nullptr, (size_t)0)
@@ -101,9 +104,9 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 118: SDF_PAIR(8, true); break;
     case 123: SDF_PAIR_TRACK(3); break;
     case 126: SDF_PAIR_TRACK(6); break;
-    case 201: SDF_STRIPE(1); break;
-    case 202: SDF_STRIPE(2); break;
-    case 204: SDF_STRIPE(4); break;
+    case 301: SDF_STRIPE(1) break;
+    case 302: SDF_STRIPE(2) break;
+    case 304: SDF_STRIPE(4) break;
     case 64: SDF_GENERAL(64, false); break;
     case 256: SDF_GENERAL(256, false); break;
     case 1024: SDF_GENERAL(1024, false); break;

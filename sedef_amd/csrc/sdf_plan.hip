@@ -29,19 +29,20 @@ struct PlanEnv {
 struct Launch {
   int bs;  // 64 / 256 / 1024: general kernel with that many threads (+2000: PLAIN flavour); 1, 2, 4, 8: wave kernel with
            // NREG (+10: streamed windows); 100 + NREG: pair kernel (+10: streamed; 120 + NREG: TRACK flavour);
-           // 200 + NREG: stripe kernel;
+           // 300 + NREG: stripe kernel (one launch-order entry per stripe);
            // 1000 / 1001 / 2001: general kernel with its state in HBM
   size_t lds;  // dynamic LDS bytes of the launch (HBM-state classes: slab bytes per workgroup)
   size_t off, cnt;  // entries of the chunk's launch order
   double est;       // duration estimate: the launch's longest task
-  int kmax;         // stripe kernel: wavefronts per workgroup
 };
 
 struct ChunkPlan {
   size_t s = 0, e = 0;   // ordinary chunk: task range [s, e) of the caller's array, minus the heavy tasks in it;
   bool heavy = false;    // heavy chunk: range [s, e) of BatchCut::heavy_idx
   size_t pb = 0;         // first PlanTask of the chunk
-  size_t ob = 0;         // first launch-order entry (room for 2 * ntask: a task paired with itself is listed twice)
+  size_t ob = 0;         // first launch-order entry (room for `order_cap`: a task paired with itself is listed twice,
+                         // a stripe task once per stripe)
+  size_t order_cap = 0;
   int64_t stage0 = 0;    // first CIGAR staging word
   size_t ntask = 0;      // tasks the chunk will plan (known after cut_batch)
   int64_t stage_words = 0;  // CIGAR staging words of those tasks
@@ -72,12 +73,14 @@ struct BatchCut {
     heavy_need = 0;
     stage_total = 0;
     ntask_total = 0;
+    order_total = 0;
   }
   bool split_heavy = false, pipelined = false;
   size_t nch = 1, max_regions = 1, n_heavy = 0;
   size_t region_need = 16, heavy_need = 0, nreg_ws = 1;
   int64_t stage_total = 0;
   size_t ntask_total = 0;
+  size_t order_total = 0;
 };
 
 namespace plan_detail {
@@ -86,13 +89,10 @@ inline bool task_runs(const sdf_task &t, bool degenerate) { return t.qlen > 0 &&
 
 struct Cls {
   int bs;
-  size_t lds;       // class key (with `sub`)
+  size_t lds;       // class key
   size_t need_max;  // largest real requirement in the class: what the launch asks for
   std::vector<int32_t> idx;
   double est = 0;
-  int kmax = 0;
-  int sub = 0;      // stripe kernel: workgroup size bucket (4, 8 or 16 wavefronts), so that tasks of few stripes do not
-                    // occupy the wavefront slots of a 16-stripe workgroup
 };
 
 }  // namespace plan_detail
@@ -226,6 +226,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       hacc += bd;
       ++hcur.ntask;
       hcur.stage_words += cap[k] & 0x7fffffffu;
+      hcur.order_cap += 2 + (tasks[k].tlen > 1024 && tasks[k].tlen <= 8192 ? 128 : 0);  // (a stripe task: 8 x 16 entries at most)
     }
     if (!cut.heavy_idx.empty()) {
       hcur.e = cut.heavy_idx.size();
@@ -253,6 +254,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       acc += bd;
       cur.ntask += cap[k] >> 31;
       cur.stage_words += cap[k] & 0x7fffffffu;
+      cur.order_cap += (cap[k] >> 31) * (2 + (tasks[k].tlen > 1024 && tasks[k].tlen <= 8192 ? 128 : 0));
     }
     cur.e = n;
     normal.push_back(cur);
@@ -264,16 +266,18 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   cut.chunks = heavy_chunks;  // heavy first
   cut.chunks.insert(cut.chunks.end(), normal.begin(), normal.end());
   // bases: what the chunks before this one (in launch order) occupy
-  size_t pb = 0;
+  size_t pb = 0, ob = 0;
   int64_t stage = 0;
   for (ChunkPlan &c : cut.chunks) {
     c.pb = pb;
-    c.ob = 2 * pb;
+    c.ob = ob;
     c.stage0 = stage;
     pb += c.ntask;
+    ob += c.order_cap;
     stage += c.stage_words;
   }
   cut.ntask_total = pb;
+  cut.order_total = ob;
   cut.stage_total = stage;
   return SDF_OK;
 }
@@ -352,10 +356,9 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     stage_words += p.cig_cap;
     if ((!p.nreg || env.stripe_min < 1024) && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
         t.tlen > env.stripe_min && t.tlen <= 8192) {
-      // wide full-band task: a workgroup of wavefronts, one per stripe of 128 * nreg target positions
+      // wide full-band task: one wavefront per stripe of 128 * nreg target positions
       const int nreg = t.tlen <= 2048 ? 1 : t.tlen <= 4096 ? 2 : 4;
-      const int nst = (t.tlen + 128 * nreg - 1) / (128 * nreg);
-      if (stripe_lds_bytes(t.qlen, nst, nreg) <= (size_t)env.max_dyn_lds) {
+      if (stripe_lds_bytes(t.qlen, nreg) <= (size_t)env.max_dyn_lds) {
         p.nreg = nreg;
         p.pad_ = 5;
         snreg = std::max(snreg, nreg);
@@ -389,10 +392,8 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       if (p.pad_ != 5) continue;
       const int nr = snreg;  // (one launch per stripe width was measured slower: 35 vs 29 ms on the hg19 mixture)
       p.nreg = nr;
-      // a last stripe of one cell would need the H of the cell under the target's end from its neighbour, and the
-      // wider stripe may need more LDS than the task's own width did: such a task stays on the general kernel
-      if (p.tlen % (128 * nr) == 1 ||
-          stripe_lds_bytes(p.qlen, (p.tlen + 128 * nr - 1) / (128 * nr), nr) > (size_t)env.max_dyn_lds) {
+      // the wider stripe may need more LDS than the task's own width did: such a task stays on the general kernel
+      if (stripe_lds_bytes(p.qlen, nr) > (size_t)env.max_dyn_lds) {
         p.nreg = 0;
         const bool hbm = general_lds_bytes(p.qlen, p.tlen) > (size_t)env.max_dyn_lds;
         p.pad_ = hbm ? 4 : 3;
@@ -475,7 +476,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
         if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
         else if (p.pad_ == 5)
-          need = (size_t)((p.tlen + 128 * p.nreg - 1) / (128 * p.nreg)) * stripe_dir_bytes(p.qlen, p.nreg);
+          need = stripe_dir_bytes(p.qlen, p.tlen, p.nreg) + stripe_sync_bytes(p.qlen, p.tlen, p.nreg);
         else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
         else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
       }
@@ -494,9 +495,9 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       lds = 8192;
       while (lds < need) lds *= 2;
     } else if (p.pad_ == 5) {
-      bs = 200 + p.nreg;  // stripe kernel; LDS by the stripe count and the query length
-      need = stripe_lds_bytes(p.qlen, (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg), p.nreg);
-      lds = 32768;
+      bs = 300 + p.nreg;  // stripe kernel, one wavefront (workgroup) per stripe
+      need = stripe_lds_bytes(p.qlen, p.nreg);
+      lds = 8192;
       while (lds < need) lds *= 2;
     } else if (p.nreg) {
       // NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
@@ -520,24 +521,17 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       return;
     }
     if (!hbm_cls && lds > (size_t)env.max_dyn_lds) lds = env.max_dyn_lds;
-    int sub = 0;
-    if (p.pad_ == 5) {
-      const int ns = (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg);
-      sub = ns <= 4 ? 4 : ns <= 8 ? 8 : 16;
-    }
     Cls *cl = nullptr;
     for (auto &x : cls)
-      if (x.bs == bs && x.lds == lds && x.sub == sub) cl = &x;
+      if (x.bs == bs && x.lds == lds) cl = &x;
     if (!cl) {
       cls.push_back({bs, lds, 0, {}});
       cl = &cls.back();
-      cl->sub = sub;
     }
     cl->need_max = std::max(cl->need_max, need);
-    if (p.pad_ == 5) cl->kmax = std::max(cl->kmax, (p.tlen + 128 * p.nreg - 1) / (128 * p.nreg));
     {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
       const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.6 : bs == 2256 ? 0.3 : bs == 3024 ? 0.85
-                          : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..118)
+                          : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 300 ? 1.0 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..126)
       cl->est = std::max(cl->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
     }
     cl->idx.push_back((int32_t)k);
@@ -553,11 +547,10 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   for (size_t a = 0; a < cls.size(); ++a) {
     if (cls[a].idx.empty() || cls[a].idx.size() >= 2048) continue;
     for (size_t b = a + 1; b < cls.size(); ++b) {
-      if (cls[b].bs != cls[a].bs || cls[b].sub != cls[a].sub || cls[b].idx.empty() || cls[b].idx.size() >= 2048) continue;
+      if (cls[b].bs != cls[a].bs || cls[b].idx.empty() || cls[b].idx.size() >= 2048) continue;
       cls[a].lds = std::max(cls[a].lds, cls[b].lds);
       cls[a].need_max = std::max(cls[a].need_max, cls[b].need_max);
       cls[a].est = std::max(cls[a].est, cls[b].est);
-      cls[a].kmax = std::max(cls[a].kmax, cls[b].kmax);
       cls[a].idx.insert(cls[a].idx.end(), cls[b].idx.begin(), cls[b].idx.end());
       cls[b].idx.clear();
     }
@@ -594,12 +587,56 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   size_t cursor = 0;
   for (auto &x : cls) {
     const bool hbm_cls = x.bs == 1000 || x.bs == 1001 || x.bs == 2001;
-    c.launches.push_back({x.bs, hbm_cls ? ((x.need_max + 255) & ~(size_t)255) : std::min(x.lds, (x.need_max + 511) & ~(size_t)511),
-                          cursor, x.idx.size(), x.est, x.kmax});
+    const size_t lds_bytes = hbm_cls ? ((x.need_max + 255) & ~(size_t)255) : std::min(x.lds, (x.need_max + 511) & ~(size_t)511);
+    if (x.bs >= 300 && x.bs < 400) {
+      // SOLO stripes: one entry per stripe, (stripe << 24) | task.  Workgroup i runs on XCD i mod 8 and workgroups are
+      // dispatched in index order.  The tasks are dealt to the eight residues (most stripes first, to the residue
+      // with the fewest so far), and every residue lists its entries STRIPE-major: stripe 0 of all its tasks, then
+      // stripe 1, ...  A stripe waits for its left neighbour only -- a smaller index on the same XCD, so resident or
+      // finished -- and by the time the dispatcher reaches stripe s of a task its stripe s - 1 is well under way:
+      // task-major order kept as many wavefronts waiting for their turn in the systolic pipeline as working.
+      // (Entries with stripe index 127 do nothing: they keep the residues aligned where the lists differ in length.)
+      const int nreg = x.bs - 300;
+      const size_t first = cursor;
+      auto stripes_of = [&](int32_t rel) { return (cp[rel].tlen + 128 * nreg - 1) / (128 * nreg); };
+      std::vector<int32_t> by_n(x.idx);
+      std::stable_sort(by_n.begin(), by_n.end(), [&](int32_t a, int32_t b) { return stripes_of(a) > stripes_of(b); });
+      std::vector<int32_t> lane_tasks[8];
+      int lane_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int32_t rel : by_n) {
+        int to = 0;
+        for (int q = 1; q < 8; ++q)
+          if (lane_sum[q] < lane_sum[to]) to = q;
+        lane_tasks[to].push_back(rel);
+        lane_sum[to] += stripes_of(rel);
+      }
+      const int longest = *std::max_element(lane_sum, lane_sum + 8);
+      {
+        size_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // next task of the residue's current stripe round
+        int round[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int pos = 0; pos < longest; ++pos)
+          for (int q = 0; q < 8; ++q) {
+            int32_t e = (int32_t)((127 << 24) | x.idx[0]);
+            // (the residue's tasks are in descending stripe count: those with a stripe `round` are a prefix)
+            if (pos < lane_sum[q]) {
+              if (at[q] >= lane_tasks[q].size() || stripes_of(lane_tasks[q][at[q]]) <= round[q]) {
+                at[q] = 0;
+                ++round[q];
+              }
+              e = (int32_t)((round[q] << 24) | lane_tasks[q][at[q]++]);
+            }
+            order[c.ob + cursor++] = e;
+          }
+      }
+      c.launches.push_back({x.bs, lds_bytes, first, cursor - first, x.est});
+      continue;
+    }
+    c.launches.push_back({x.bs, lds_bytes, cursor, x.idx.size(), x.est});
     std::copy(x.idx.begin(), x.idx.end(), order + c.ob + cursor);
     cursor += x.idx.size();
   }
   c.nord = cursor;
+  if (c.nord > c.order_cap) c.err = "internal: launch-order segment overflow";
 }
 
 }  // namespace sdf

@@ -42,14 +42,12 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
     a.idx = (int64_t)r * tk.ncol16 + (i - b.lo);
     a.meta = 0;
   } else if (LAYOUT == 3) {
-    // stripes of 128 * nreg target positions, each a stand-alone wave-kernel task over its slice in local
-    // coordinates (row r - T0, position t - T0); one flag region per stripe
+    // stripes of 128 * nreg target positions, each with its own flag region in local coordinates (row r - T0,
+    // slot t - T0: a stripe's window stays at its first column, extz2_stripe.hip)
     const int sw = 128 * tk.nreg;
     const int sb = i / sw, t0 = sb * sw;
     const int rp = r - t0, rb = rp >> 4;
-    Band b0;
-    band_of(rb << 4, tk.qlen, tk.tlen - t0 < sw ? tk.tlen - t0 : sw, tk.w, b0);
-    const int slot = i - t0 - b0.lo;
+    const int slot = i - t0;
     const int per_stripe = ((tk.qlen + sw - 1 + 15) / 16) * tk.nreg * 64;  // uint4 records
     a.idx = (int64_t)sb * per_stripe + rb * (tk.nreg * 64) + (slot >> 1);  // (register k, lane l) = slots 128k + 2l, +1
     a.meta = (uint32_t)(15 - (rp & 15) + ((slot & 1) << 4));

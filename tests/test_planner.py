@@ -98,7 +98,7 @@ def test_mixture_with_heavy_tasks_and_empty_tasks():
     assert len(heavy) >= 1 and (heavy == np.arange(len(heavy))).all()  # heavy chunks are launched first
     hv_tasks = np.isin(pt[:, 0], heavy)
     assert hv_tasks.sum() >= 40 and (t["qlen"][hv_tasks] >= 700).all()
-    assert set(np.unique(pt[hv_tasks, 1])) <= {201, 202, 204, 2256, 3024, 2001, 104, 114, 106, 116, 108, 118, 8, 18}
+    assert set(np.unique(pt[hv_tasks, 1])) <= {301, 302, 304, 2256, 3024, 2001, 104, 114, 106, 116, 108, 118, 8, 18}
     _check(t, pt, pc)
     rc1, pt1, pc1 = _plan(t, threads=0)
     assert (pt1 == pt).all() and (pc1 == pc).all()
@@ -111,9 +111,9 @@ def test_kernel_choice_by_request():
     assert rc == 0
     assert pt[0, 1] in (108, 118) and pt[1, 1] in (64, 256, 1024)  # z-drop needs every ksw_extz_t field: general kernel
     assert pt[2, 1] in (102, 103) and pt[3, 1] in (64, 256)        # right-aligned gaps: general kernel
-    assert pt[4, 1] in (201, 202, 204)                            # wide full-band: stripe kernel
+    assert pt[4, 1] in (301, 302, 304)                            # wide full-band: stripe kernel (one wavefront per stripe)
     rc, pt, pc = _plan(t, want=7)                                 # every field wanted: no register-resident kernel
-    assert rc == 0 and (pt[:, 1] >= 64).all() and not np.isin(pt[:, 1], (101, 102, 103, 104, 106, 108, 201, 202, 204)).any()
+    assert rc == 0 and (pt[:, 1] >= 64).all() and not np.isin(pt[:, 1], (101, 102, 103, 104, 106, 108, 201, 202, 204, 301, 302, 304)).any()
     rc, pt, _ = _plan(_tasks([300, 300], [300, 300], flag=[4, 8]))
     assert rc == 0 and (pt[:, 1] == 256).all()  # generic scoring / approximate max: the general kernel
     rc, _, _ = _plan(_tasks([10], [10], flag=[0x100]))
