@@ -19,7 +19,8 @@
 //   * the last stripe owns the target's end: H of its last column is followed down the rows (inside the owning lane)
 //     for mte / score.
 // The stripes of a task talk through HBM (they share an XCD, so its L2): per stripe a progress word ("first query row
-// done, H handed over") and, per stripe boundary, the FULL edge column, one x | v << 16 word per global row.  A stripe
+// done, H handed over") and, per stripe boundary, the FULL edge column: one x | v << 16 word per row of the right
+// stripe that reads it (its rows 0 .. qlen - 1; row r reads what the left stripe left after its row r + NSLOT - 1).  A stripe
 // stores the 16 edge words of a 16-row block with one instruction, bit 0 of a word set (the state values are
 // multiples of 256: the bit is free; the columns are zeroed before the launch); its right neighbour fetches the 16
 // words a block needs with one load -- issued one block ahead -- and looks at the tag bits.  A stripe only ever waits
@@ -47,7 +48,7 @@ __host__ __device__ inline size_t stripe_dir_bytes(int qlen, int tlen, int nreg)
 }
 __host__ __device__ inline size_t stripe_sync_bytes(int qlen, int tlen, int nreg) {
   const int nslot = 128 * nreg, nst = (tlen + nslot - 1) / nslot;
-  return (((size_t)nst * 8 + 255) & ~(size_t)255) + (size_t)(nst > 1 ? nst - 1 : 0) * (size_t)(qlen + tlen) * 4;
+  return (((size_t)nst * 8 + 255) & ~(size_t)255) + (size_t)(nst > 1 ? nst - 1 : 0) * (size_t)(qlen + 16) * 4;
 }
 
 #define SDF_STRIPE_SPIN_CAP (1 << 24)  // polls before a wait gives up (a wrong result instead of a hung queue)
@@ -56,7 +57,8 @@ template <int NREG>
 __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__restrict__ plan,
                                                              const int32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ pool, ScoreK sc,
-                                                             uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
+                                                             uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res,
+                                                             const int rmax) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;  // stripe width
   constexpr int KT = NREG - 1;
@@ -69,16 +71,26 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   if (sb >= nstripe) return;  // (a padding entry of the launch order)
   const int qlen = tk.qlen;
   const int T0 = sb * NSLOT;                                       // first target position of the stripe
+                                     // first target position of the stripe
   const int tlen = tlen_all - T0 < NSLOT ? tlen_all - T0 : NSLOT;  // its slice
   const int nrow = qlen + tlen - 1;                                // its anti-diagonals
-  const int nrow_all = qlen + tlen_all;                            // entries of an edge column (global rows, + 1)
+  const int ncol = qlen + 16;                                      // entries of an edge column
   const bool has_left = sb > 0, has_right = sb + 1 < nstripe;
+  // A launch ends with its longest task, whose stripes form ONE chain of qlen + tlen dependent rows: the wavefronts of
+  // the long tasks get the SIMD first (issue priority by the task's share of the launch's longest chain), the short
+  // tasks fill the gaps.
+  {
+    const int share = 4 * (qlen + tlen_all) / (rmax > 0 ? rmax + 1 : 1);
+    if (share >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (share == 2) __builtin_amdgcn_s_setprio(2);
+    else if (share == 1) __builtin_amdgcn_s_setprio(1);
+  }
   uint8_t *gsync = dirbase + tk.dir_off + (int64_t)stripe_dir_bytes(qlen, tlen_all, NREG);
   volatile int *prog = reinterpret_cast<volatile int *>(gsync);  // [nstripe] T0 + NSLOT - 1 once stripe s has handed over
   volatile int *hand_val = prog + nstripe;                       // [nstripe] H of its top cell after its row NSLOT - 1
   volatile uint32_t *rings = reinterpret_cast<volatile uint32_t *>(gsync + (((size_t)nstripe * 8 + 255) & ~(size_t)255));
-  volatile uint32_t *ring_out = rings + (size_t)sb * nrow_all;
-  volatile uint32_t *ring_in = rings + (size_t)(has_left ? sb - 1 : 0) * nrow_all;
+  volatile uint32_t *ring_out = rings + (size_t)sb * ncol;                         // [r - (NSLOT - 1)], r: my row
+  volatile uint32_t *ring_in = rings + (size_t)(has_left ? sb - 1 : 0) * ncol;  // [r], r: my row
 
   // ---- unpack: the reversed query as byte pairs; W[i] = (QR[i - NSLOT], QR[i - NSLOT + 1]), QR[e] = query[qlen-1-e]
   // (0 outside): lane l of register k reads entry qlen - 1 - r + NSLOT + 128 k + 2 l on row r ----
@@ -145,6 +157,9 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     while (__builtin_amdgcn_readfirstlane(prog[sb - 1]) < T0 - 1 && ++spins < SDF_STRIPE_SPIN_CAP) __builtin_amdgcn_s_sleep(8);
     h_head = __builtin_amdgcn_readfirstlane(hand_val[sb - 1]);
   }
+#ifdef SDF_STRIPE_TIMING
+  unsigned long long tm_start = __builtin_amdgcn_s_memrealtime(), tm_head = 0, tm_tail = 0, tm_wait = 0;
+#endif
   unsigned hacc = 0u;
   // the last stripe: H of the last column (target end), row by row from the end of the head on, inside lane LT
   const int shT = (((tlen - 1) & 1) << 4) + 8;
@@ -154,11 +169,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   // fetched ahead, of the next one
   uint32_t edge16 = 0u, feed16 = 0u, feed_next = 0u;
   int feed_g0 = -0x40000000;
-  auto feed_load = [&](const int rfirst) -> uint32_t {  // words of the global rows T0 + rfirst - 1 + (0 .. 15)
-    // row r of this stripe reads global row T0 + r - 1 of the column, and only while its first column is in the band
-    // (r <= qlen - 1): what lies beyond is never written by the neighbour and never used here -- "tagged", value 0
+  auto feed_load = [&](const int rfirst) -> uint32_t {  // the edge words rows rfirst + (0 .. 15) read
+    // a row reads the column only while its first cell is in the band (r <= qlen - 1): what lies beyond is never
+    // written by the neighbour and never used here -- "tagged", value 0
     const int i = lane & 15, r = rfirst + i;
-    return (r <= qlen - 1) ? ring_in[T0 + r - 1] : 1u;
+    return (r <= qlen - 1) ? ring_in[r] : 1u;
   };
 
   unsigned qaddr = 0u, qnext[NREG];
@@ -184,13 +199,16 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     int eidx = rb & 15;                // lane of edge16 this row's edge word goes to
 #pragma unroll 1
     for (int r = rb; r < re; ++r, ++fidx, ++eidx) {
-      unsigned qcur[NREG];
-      qaddr -= 2;
+      // query codes of this row (fetched during the previous one), bytes -> halves; the next row's fetch is issued
+      // only now -- behind the use of the last one, so that the wait for LDS above finds it long complete instead of
+      // covering a fetch issued just before it (the empty asm ties the address to the consumed values)
+      unsigned qc[NREG];
 #pragma unroll
-      for (int k = KLO; k <= KHI; ++k) {
-        qcur[k] = qnext[k];
-        qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
-      }
+      for (int k = KLO; k <= KHI; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+      qaddr -= 2;
+      asm volatile("" : "+v"(qaddr) : "v"(qc[KLO]), "v"(qc[KHI]));
+#pragma unroll
+      for (int k = KLO; k <= KHI; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
       const int sr = r - 128 * KHI;  // slot of the cell t = r inside register KHI (head rows)
       const bool mine = lane == (sr >> 1);
       if (head) {  // border cell t = r: y = 0, u = gap open (reference :122; 0 on global row 0)
@@ -229,12 +247,8 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
         vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
       }
       // scores of the row's cells
-      unsigned qc[NREG];
 #pragma unroll
-      for (int k = KLO; k <= KHI; ++k) {
-        qc[k] = __builtin_amdgcn_perm(0u, qcur[k], 0x0c010c00u);  // bytes -> halves
-        S[k] = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
-      }
+      for (int k = KLO; k <= KHI; ++k) S[k] = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
       if (has_n) {
 #pragma unroll
         for (int k = KLO; k <= KHI; ++k) {
@@ -286,10 +300,16 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
       // the sixteen edge words of the block: fetched during the previous block; all tagged, or fetched again
       uint32_t got = (feed_g0 + 16 == T0 + r0 - 1) ? feed_next : feed_load(r0);
       int spins = 0;
+#ifdef SDF_STRIPE_TIMING
+      const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
       while (__builtin_amdgcn_readfirstlane((int)__any((got & 1u) == 0u)) && ++spins < SDF_STRIPE_SPIN_CAP) {
         __builtin_amdgcn_s_sleep(2);
         got = feed_load(r0);
       }
+#ifdef SDF_STRIPE_TIMING
+      if (spins) tm_wait += __builtin_amdgcn_s_memrealtime() - tw0;
+#endif
       feed16 = got;
       feed_g0 = T0 + r0 - 1;
       feed_next = feed_load(r0 + 16);  // for the next block; checked there
@@ -311,7 +331,13 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
         h_head += (int32_t)hacc - tlen * sc.qe;
         ht = best = h_head;  // (the last stripe: H(tlen - 1, tlen - 1), the first candidate for mte)
         best_r = tlen - 1;
+#ifdef SDF_STRIPE_TIMING
+        tm_head = __builtin_amdgcn_s_memrealtime();
+#endif
       }
+#ifdef SDF_STRIPE_TIMING
+      if (!tm_tail && r >= qlen) tm_tail = __builtin_amdgcn_s_memrealtime();
+#endif
     }
     // ---- block end: direction flags of these (<= 16) rows leave for HBM ----
     if (with_dir) {
@@ -334,8 +360,8 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     for (int k = 0; k < NREG; ++k) Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
     if (has_right) {
       if (rend > NSLOT - 1) {  // this block's edge words (the tagged ones: rows >= NSLOT - 1)
-        const int g = T0 + r0 + lane;
-        if (lane < 16 && (edge16 & 1u) && g < nrow_all) ring_out[g] = edge16;
+        const int g = r0 + lane - (NSLOT - 1);
+        if (lane < 16 && (edge16 & 1u) && g < ncol) ring_out[g] = edge16;
       }
       edge16 = 0u;
       if (rend == NSLOT) {  // first query row done, its edge word stored: the right neighbour may start
@@ -348,6 +374,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
       }
     }
   }
+#ifdef SDF_STRIPE_TIMING
+  if (lane == 0)
+    printf("stripe %d start %llu head %llu tail %llu end %llu wait %llu\n", sb, tm_start, tm_head, tm_tail,
+           (unsigned long long)__builtin_amdgcn_s_memrealtime(), tm_wait);
+#endif
   if (has_right) return;  // the last stripe owns the end of the target: score, mte
 
   const int lt = ((tlen - 1) & 127) >> 1;
@@ -372,11 +403,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
 }
 
 template __global__ void extz2_stripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *);
+                                                sdf_result *, int);
 template __global__ void extz2_stripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *);
+                                                sdf_result *, int);
 template __global__ void extz2_stripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *);
+                                                sdf_result *, int);
 
 // Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's progress and hand-over words to
 // "nothing done" and the edge column of its right boundary to zero (no word tagged as written)
@@ -395,9 +426,9 @@ __global__ __launch_bounds__(64) void stripe_sync_init_kernel(const PlanTask *__
     prog[nst + sb] = 0;
   }
   if (sb + 1 < nst) {
-    const int nrow_all = tk.qlen + tk.tlen;
-    uint32_t *col = reinterpret_cast<uint32_t *>(gsync + (((size_t)nst * 8 + 255) & ~(size_t)255)) + (size_t)sb * nrow_all;
-    for (int g = threadIdx.x; g < nrow_all; g += 64) col[g] = 0u;
+    const int ncol = tk.qlen + 16;
+    uint32_t *col = reinterpret_cast<uint32_t *>(gsync + (((size_t)nst * 8 + 255) & ~(size_t)255)) + (size_t)sb * ncol;
+    for (int g = threadIdx.x; g < ncol; g += 64) col[g] = 0u;
   }
 }
 

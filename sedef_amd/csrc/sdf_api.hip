@@ -345,7 +345,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     const char *msg = nullptr;
     static const int max_planners = [] {
       const char *e = getenv("SDF_PLAN_THREADS");
-      return e ? std::max(0, std::min(7, atoi(e))) : 3;
+      return e ? std::max(0, std::min(15, atoi(e))) : 3;
     }();
     // (parked threads pay from a few hundred thousand tasks: below, waking them costs more than they save -- measured
     // on the 100,000-task headline batch: 0.9 ms of planning alone, 2.4 ms with three helpers)
@@ -389,6 +389,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream}) SDF_HIP(hipStreamWaitEvent(s, run.ev_begin, 0));
 
   // ---- plan (worker threads, chunk order) and launch (this thread, chunk order) ----
+  static const bool dbg_plan_chunks = getenv("SDF_DEBUG_PLAN") != nullptr;
   int rc = SDF_OK;
   float dbg_c = 0.f;
   {
@@ -409,7 +410,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         break;
       }
       ctx->paired += c.paired;
+      const float tw = host_ms();
       rc = launch_chunk(run, ci);
+      if (dbg_plan_chunks) fprintf(stderr, "[chunk %zu: %zu tasks%s planned by %.2f ms, launched by %.2f ms]\n", ci, c.cnt, c.heavy ? " (heavy)" : "", tw, host_ms());
     }
   }
   if (rc != SDF_OK) {  // earlier chunks are in flight and reference the context's buffers: let them finish
@@ -426,6 +429,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     return rc;
   }
   ctx->ms[5] = host_ms();
+  if (dbg_plan_chunks) fprintf(stderr, "[batch finished by %.2f ms]\n", ctx->ms[5]);
   return SDF_OK;
 }
 
@@ -820,7 +824,14 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   env.max_dyn_lds = max_dyn_lds;
   BatchCut cut;
   const char *msg = nullptr;
-  if (int rc = cut_batch(env, true, ws_budget, cut, &msg)) return rc;
+  const auto tc0 = std::chrono::steady_clock::now();
+  {
+    WorkerPool cut_pool(std::max(nthreads, 1));
+    if (int rc = cut_batch(env, true, ws_budget, cut, &msg, nthreads > 0 ? &cut_pool : nullptr)) return rc;
+  }
+  if (getenv("SDF_DEBUG_PLAN"))
+    fprintf(stderr, "[sdf] debug plan: cut %.2f ms (%zu tasks, %d threads)\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(), n, nthreads);
   const size_t np = std::max<size_t>(cut.ntask_total, 1);
   std::vector<PlanTask> plan(np);
   std::vector<int32_t> order(std::max<size_t>(cut.order_total, 2));

@@ -35,7 +35,7 @@ size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 bool pair_fits_whole(int qlen, int tlen, int nreg);
 template <int NREG>
 __global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                    sdf_result *);
+                                    sdf_result *, int);
 __global__ void stripe_sync_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 template <int LAYOUT, int G>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
@@ -187,7 +187,7 @@ struct sdf_ctx {
   int max_dyn_lds = 64 * 1024;
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
   bool pipeline = true;        // SDF_PIPELINE=0: one chunk on one stream (isolated kernel timing)
-  int stripe_min = 1024;       // SDF_STRIPE_MIN: targets longer than this (and full band) take the stripe kernel
+  int stripe_min = 400;       // SDF_STRIPE_MIN: targets longer than this (and full band) take the stripe kernel
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
 };

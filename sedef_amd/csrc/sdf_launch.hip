@@ -73,7 +73,7 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
 #define SDF_STRIPE(N) /* one workgroup of one wavefront per stripe; progress words and edge columns reset first */ \
   {                                                                                                              \
     hipLaunchKernelGGL(stripe_sync_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                      \
-    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out); \
+    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax); \
   }
 #define SDF_GENERAL(BS, PLAIN)                                                                                      \
   hipLaunchKernelGGL((extz2_general_kernel<BS, false, PLAIN>), one, dim3(BS), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, \
@@ -172,7 +172,9 @@ static int launch_chunk(BatchRun &run, size_t ci) {
                       pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
                       ctx->aux_stream[3]};
   // Q[4..7]: only the least-loaded-stream assignment below uses them (one-chunk batches without heavy tasks)
-  const int ui = piped ? (run.have_heavy ? 2 : 1 + (int)(nj & 1)) : 0;  // upload stream (and the big launches')
+  // upload stream (and the big launches'): consecutive ordinary chunks alternate between two, so that a chunk's upload
+  // and DP do not queue behind the previous chunk's (with heavy tasks in the batch Q[0], Q[1], Q[4], Q[5] are theirs)
+  const int ui = piped ? (run.have_heavy ? ((nj & 1) && Q[7] ? 7 : 2) : 1 + (int)(nj & 1)) : 0;
   // (the tracebacks of consecutive ordinary chunks alternate between two streams: the last one starts when its DP
   // ends, not when the previous chunk's walk does)
   hipStream_t stb = piped ? ((nj & 1) && ctx->aux_stream[2] ? ctx->aux_stream[2] : Q[3]) : Q[0];

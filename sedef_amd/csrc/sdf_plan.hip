@@ -23,7 +23,7 @@ struct PlanEnv {
   int gapo = 0;
   int max_dyn_lds = 64 * 1024;
   bool force_general = false, no_pair = false, no_stripe = false;
-  int stripe_min = 1024;
+  int stripe_min = 400;
 };
 
 struct Launch {
@@ -34,6 +34,7 @@ struct Launch {
   size_t lds;  // dynamic LDS bytes of the launch (HBM-state classes: slab bytes per workgroup)
   size_t off, cnt;  // entries of the chunk's launch order
   double est;       // duration estimate: the launch's longest task
+  int rmax = 0;     // stripe kernel: anti-diagonals (qlen + tlen) of the launch's longest task
 };
 
 struct ChunkPlan {
@@ -42,7 +43,7 @@ struct ChunkPlan {
   size_t pb = 0;         // first PlanTask of the chunk
   size_t ob = 0;         // first launch-order entry (room for `order_cap`: a task paired with itself is listed twice,
                          // a stripe task once per stripe)
-  size_t order_cap = 0;
+  size_t order_cap = 1024;  // (a stripe launch: up to 8 x 127 idle entries)
   int64_t stage0 = 0;    // first CIGAR staging word
   size_t ntask = 0;      // tasks the chunk will plan (known after cut_batch)
   int64_t stage_words = 0;  // CIGAR staging words of those tasks
@@ -103,6 +104,7 @@ struct PlanScratch {
   std::vector<std::pair<int32_t, int32_t>> table;
   std::vector<plan_detail::Cls> cls;
   std::vector<char> tracked;
+  std::vector<int32_t> stripe_lane, stripe_fill;
 };
 
 // Returns SDF_OK or an error code with *err set.
@@ -122,7 +124,11 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     for (size_t k = 0; k < n && !any_long; ++k) any_long = tasks[k].qlen + (int64_t)tasks[k].tlen >= 3000;
   cut.pipelined = pipeline_enabled && (n >= 2048 || any_long);
   cut.nch = 1;
-  if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? 8 : 4, n / 16384);
+  static const size_t nch_big = [] {
+    const char *e = getenv("SDF_NCH");
+    return e ? (size_t)atoll(e) : (size_t)8;
+  }();
+  if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? nch_big : 4, n / 16384);
   cut.max_regions = cut.nch > 4 ? 8 : cut.nch > 1 ? 4 : 1;
   const size_t nch = cut.nch;
   // the first chunk is small, so that the GPU starts early, but fills the wavefront slots of the device (4,096 pairs
@@ -170,6 +176,9 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
           // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
           if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
+          if (t.tlen > env.stripe_min && t.tlen <= 8192 && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
+            for (int nr = 1; nr <= 4; nr *= 2)
+              bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
           bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
           if (bd >= heavy_min) {
             ++pt.nh;
@@ -226,7 +235,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       hacc += bd;
       ++hcur.ntask;
       hcur.stage_words += cap[k] & 0x7fffffffu;
-      hcur.order_cap += 2 + (tasks[k].tlen > 1024 && tasks[k].tlen <= 8192 ? 128 : 0);  // (a stripe task: 8 x 16 entries at most)
+      hcur.order_cap += 2 + (tasks[k].tlen > env.stripe_min && tasks[k].tlen <= 8192 ? (tasks[k].tlen + 127) / 128 : 0);  // (a stripe task: an entry per stripe)
     }
     if (!cut.heavy_idx.empty()) {
       hcur.e = cut.heavy_idx.size();
@@ -254,7 +263,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       acc += bd;
       cur.ntask += cap[k] >> 31;
       cur.stage_words += cap[k] & 0x7fffffffu;
-      cur.order_cap += (cap[k] >> 31) * (2 + (tasks[k].tlen > 1024 && tasks[k].tlen <= 8192 ? 128 : 0));
+      cur.order_cap += (cap[k] >> 31) * (2 + (tasks[k].tlen > env.stripe_min && tasks[k].tlen <= 8192 ? (tasks[k].tlen + 127) / 128 : 0));
     }
     cur.e = n;
     normal.push_back(cur);
@@ -293,7 +302,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   win_need.clear();
   size_t np = c.pb;
   int64_t stage_words = c.stage0;
-  int snreg = 0;  // widest stripe any stripe task of the chunk needs
+  size_t n_stripe_tasks = 0, stripes4 = 0;  // stripe tasks of the chunk; their stripes at 512 positions each
   for (size_t pos = c.s; pos < c.e; ++pos) {
     const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
     const sdf_task &t = tasks[k];
@@ -354,14 +363,14 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
     p.cig_slot = stage_words;
     stage_words += p.cig_cap;
-    if ((!p.nreg || env.stripe_min < 1024) && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
+    if (plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
         t.tlen > env.stripe_min && t.tlen <= 8192) {
-      // wide full-band task: one wavefront per stripe of 128 * nreg target positions
-      const int nreg = t.tlen <= 2048 ? 1 : t.tlen <= 4096 ? 2 : 4;
-      if (stripe_lds_bytes(t.qlen, nreg) <= (size_t)env.max_dyn_lds) {
-        p.nreg = nreg;
+      // wide full-band task: one wavefront per stripe of 128 * nreg target positions (nreg: after this pass)
+      if (stripe_lds_bytes(t.qlen, 4) <= (size_t)env.max_dyn_lds) {
+        p.nreg = 4;
         p.pad_ = 5;
-        snreg = std::max(snreg, nreg);
+        ++n_stripe_tasks;
+        stripes4 += (size_t)(t.tlen + 511) / 512;
       }
     }
     if (!p.nreg) {
@@ -385,15 +394,23 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   c.dir_bytes = 0;
   if (cnt == 0) return;
   PlanTask *cp = plan + c.pb;  // chunk-relative indexing below
-  if (snreg) {  // the stripe tasks of a chunk share one stripe width (the widest any of them needs): one launch,
-                // all of them side by side, instead of one launch per width queued behind each other
+  if (n_stripe_tasks) {
+    // One stripe width per chunk (one launch, all its tasks side by side).  A wavefront alone on its SIMD issues an
+    // instruction every ~5 cycles whatever its width, so a row of a 128-position stripe takes a quarter of the time of
+    // a row of a 512-position one, and a task is a chain of qlen + tlen dependent rows: few tasks want narrow stripes
+    // (a 6000 x 6000 task alone: 6.1 ms at 512 positions per stripe).  Many tasks want wide ones: per cell a wide stripe
+    // spends fewer instructions on the edges and the loop (1k x 1k tasks by the thousand: 1180 Gcell/s at 512, 800 at
+    // 128), and with a wavefront or more per SIMD the chains overlap anyway.
+    static const int force_nreg = [] {
+      const char *e = getenv("SDF_STRIPE_NREG");
+      return e ? atoi(e) : 0;
+    }();
+    const int nr = force_nreg ? force_nreg : stripes4 >= 1536 ? 4 : stripes4 >= 384 ? 2 : 1;
     for (size_t k = 0; k < cnt; ++k) {
       PlanTask &p = cp[k];
       if (p.pad_ != 5) continue;
-      const int nr = snreg;  // (one launch per stripe width was measured slower: 35 vs 29 ms on the hg19 mixture)
       p.nreg = nr;
-      // the wider stripe may need more LDS than the task's own width did: such a task stays on the general kernel
-      if (stripe_lds_bytes(p.qlen, nr) > (size_t)env.max_dyn_lds) {
+      if ((p.tlen + 128 * nr - 1) / (128 * nr) > 126) {  // (entry encoding: 7 bits of stripe index, 127 = idle)
         p.nreg = 0;
         const bool hbm = general_lds_bytes(p.qlen, p.tlen) > (size_t)env.max_dyn_lds;
         p.pad_ = hbm ? 4 : 3;
@@ -476,7 +493,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
         if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
         else if (p.pad_ == 5)
-          need = stripe_dir_bytes(p.qlen, p.tlen, p.nreg) + stripe_sync_bytes(p.qlen, p.tlen, p.nreg);
+          need = (stripe_dir_bytes(p.qlen, p.tlen, p.nreg) + stripe_sync_bytes(p.qlen, p.tlen, p.nreg) + 255) & ~(size_t)255;
         else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
         else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
       }
@@ -589,46 +606,65 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     const bool hbm_cls = x.bs == 1000 || x.bs == 1001 || x.bs == 2001;
     const size_t lds_bytes = hbm_cls ? ((x.need_max + 255) & ~(size_t)255) : std::min(x.lds, (x.need_max + 511) & ~(size_t)511);
     if (x.bs >= 300 && x.bs < 400) {
-      // SOLO stripes: one entry per stripe, (stripe << 24) | task.  Workgroup i runs on XCD i mod 8 and workgroups are
-      // dispatched in index order.  The tasks are dealt to the eight residues (most stripes first, to the residue
-      // with the fewest so far), and every residue lists its entries STRIPE-major: stripe 0 of all its tasks, then
-      // stripe 1, ...  A stripe waits for its left neighbour only -- a smaller index on the same XCD, so resident or
-      // finished -- and by the time the dispatcher reaches stripe s of a task its stripe s - 1 is well under way:
-      // task-major order kept as many wavefronts waiting for their turn in the systolic pipeline as working.
+      // Stripe kernel: one entry per stripe, (stripe << 24) | task.  Workgroup i runs on XCD i mod 8 and workgroups
+      // are dispatched in index order.  The tasks are dealt to the eight residues (most stripes first, to the residue
+      // with the fewest so far): a task's stripes share an XCD (its L2 carries their edge words).  A task is a chain:
+      // stripe s starts 128 * nreg rows after stripe s - 1 and the last one ends qlen + tlen rows after the first
+      // began, and the launch ends with its longest chain.  Every residue lists its entries by the row at which they
+      // would have to start for all chains to END together -- s * 128 * nreg - (qlen + tlen) -- earliest first: the
+      // long tasks get their wavefront slots first (those of their later stripes sleep until their turn), the short
+      // ones fill in behind.  The key grows with s, so a stripe's left neighbour -- the only wavefront it ever waits
+      // for -- has a smaller index on the same XCD: resident or finished.
       // (Entries with stripe index 127 do nothing: they keep the residues aligned where the lists differ in length.)
       const int nreg = x.bs - 300;
       const size_t first = cursor;
-      auto stripes_of = [&](int32_t rel) { return (cp[rel].tlen + 128 * nreg - 1) / (128 * nreg); };
-      std::vector<int32_t> by_n(x.idx);
-      std::stable_sort(by_n.begin(), by_n.end(), [&](int32_t a, int32_t b) { return stripes_of(a) > stripes_of(b); });
-      std::vector<int32_t> lane_tasks[8];
-      int lane_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int32_t rel : by_n) {
+      const int nslot = 128 * nreg;
+      auto stripes_of = [&](int32_t rel) { return (cp[rel].tlen + nslot - 1) / nslot; };
+      // (the start keys are taken in units of one stripe's head, 128 * nreg rows: a counting sort per residue)
+      int rq_max = 0, lane_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int32_t rel : x.idx) rq_max = std::max(rq_max, (cp[rel].qlen + cp[rel].tlen) / nslot);
+      const int nbucket = rq_max + 130;  // key of (task, s): s - (qlen + tlen) / nslot + rq_max, 0 <= s < 127
+      std::vector<int32_t> &lane_of = sx.stripe_lane, &fill = sx.stripe_fill;
+      lane_of.resize(x.idx.size());
+      fill.assign((size_t)8 * nbucket + 1, 0);
+      for (size_t j = 0; j < x.idx.size(); ++j) {
+        const int32_t rel = x.idx[j];
         int to = 0;
         for (int q = 1; q < 8; ++q)
           if (lane_sum[q] < lane_sum[to]) to = q;
-        lane_tasks[to].push_back(rel);
-        lane_sum[to] += stripes_of(rel);
+        const int nst = stripes_of(rel), key0 = rq_max - (cp[rel].qlen + cp[rel].tlen) / nslot;
+        lane_of[j] = to;
+        lane_sum[to] += nst;
+        for (int sidx = 0; sidx < nst; ++sidx) ++fill[(size_t)to * nbucket + key0 + sidx + 1];
       }
       const int longest = *std::max_element(lane_sum, lane_sum + 8);
+      if (cursor + (size_t)longest * 8 > c.order_cap) {
+        c.err = "internal: launch-order segment overflow";
+        return;
+      }
+      for (size_t q = 0; q < (size_t)8 * nbucket; ++q) fill[q + 1] += fill[q];  // -> first position of (residue, key)
       {
-        size_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // next task of the residue's current stripe round
-        int round[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int base[8], acc = 0;  // positions are residue-relative
+        for (int q = 0; q < 8; ++q) {
+          base[q] = acc;
+          acc += lane_sum[q];
+        }
+        const int32_t idle = (int32_t)((127 << 24) | x.idx[0]);
         for (int pos = 0; pos < longest; ++pos)
-          for (int q = 0; q < 8; ++q) {
-            int32_t e = (int32_t)((127 << 24) | x.idx[0]);
-            // (the residue's tasks are in descending stripe count: those with a stripe `round` are a prefix)
-            if (pos < lane_sum[q]) {
-              if (at[q] >= lane_tasks[q].size() || stripes_of(lane_tasks[q][at[q]]) <= round[q]) {
-                at[q] = 0;
-                ++round[q];
-              }
-              e = (int32_t)((round[q] << 24) | lane_tasks[q][at[q]++]);
-            }
-            order[c.ob + cursor++] = e;
+          for (int q = 0; q < 8; ++q)
+            if (pos >= lane_sum[q]) order[c.ob + first + (size_t)pos * 8 + q] = idle;
+        for (size_t j = 0; j < x.idx.size(); ++j) {
+          const int32_t rel = x.idx[j];
+          const int to = lane_of[j], nst = stripes_of(rel), key0 = rq_max - (cp[rel].qlen + cp[rel].tlen) / nslot;
+          for (int sidx = 0; sidx < nst; ++sidx) {
+            const int pos = fill[(size_t)to * nbucket + key0 + sidx]++ - base[to];
+            order[c.ob + first + (size_t)pos * 8 + to] = (int32_t)((sidx << 24) | rel);
           }
+        }
+        cursor = first + (size_t)longest * 8;
       }
       c.launches.push_back({x.bs, lds_bytes, first, cursor - first, x.est});
+      for (int32_t rel : x.idx) c.launches.back().rmax = std::max(c.launches.back().rmax, cp[rel].qlen + cp[rel].tlen);
       continue;
     }
     c.launches.push_back({x.bs, lds_bytes, cursor, x.idx.size(), x.est});

@@ -377,11 +377,12 @@ def test_pair_kernel_fuzz_banded(engine, oracle):
 
 def test_pair_kernel_all_register_counts(engine, oracle):
     """Windows of 16..512 slots -> 1, 2, 3, 4, 6, 8 registers; full band and banded; wider windows and odd
-    tasks out stay on the one-task wave kernel inside the same batch."""
+    tasks out stay on the one-task wave kernel inside the same batch (full-band tasks of more than 400 target
+    bases: the stripe kernel)."""
     rng = np.random.default_rng(778)
     pairs, ws = [], []
     for ql, tl, w in [(8, 8, -1), (30, 30, -1), (60, 50, -1), (100, 120, -1), (150, 150, -1), (210, 209, -1),
-                      (300, 280, -1), (400, 410, -1), (500, 500, -1), (480, 500, -1), (500, 431, -1),
+                      (300, 280, -1), (390, 395, -1), (400, 399, -1), (400, 410, -1), (500, 500, -1), (480, 500, -1), (500, 431, -1),
                       (1000, 1000, 20), (1000, 990, 60), (1000, 1010, 100), (1000, 1003, 128), (990, 1000, 128),
                       (1000, 1000, 160), (1000, 980, 200), (1000, 1000, 260), (1000, 1000, 350), (900, 1000, 440),
                       (1000, 1000, 470), (1000, 1000, 500), (700, 700, -1), (1, 1, -1), (1, 40, -1), (40, 1, -1),
@@ -390,7 +391,7 @@ def test_pair_kernel_all_register_counts(engine, oracle):
         pairs += _same_geometry_tasks(rng, ql, tl, copies, 0.01)
         ws += [w] * copies
     _check_fast(engine, oracle, pairs, ws)
-    assert engine.last_paired() >= 50
+    assert engine.last_paired() >= 44
 
 
 def test_pair_kernel_other_scorings(engine, oracle):

@@ -109,9 +109,12 @@ def test_kernel_choice_by_request():
                zdrop=[-1, 100, -1, -1, -1, -1], flag=[0, 0, 0, 2, 0, 0])
     rc, pt, pc = _plan(t)
     assert rc == 0
-    assert pt[0, 1] in (108, 118) and pt[1, 1] in (64, 256, 1024)  # z-drop needs every ksw_extz_t field: general kernel
+    assert pt[0, 1] in (301, 302, 304) and pt[1, 1] in (64, 256, 1024)  # full band from 400 target bases up: stripe kernel;
+    #                                                                    z-drop needs every ksw_extz_t field: general kernel
     assert pt[2, 1] in (102, 103) and pt[3, 1] in (64, 256)        # right-aligned gaps: general kernel
-    assert pt[4, 1] in (301, 302, 304)                            # wide full-band: stripe kernel (one wavefront per stripe)
+    assert pt[4, 1] in (301, 302, 304) and pt[4, 1] == pt[0, 1]   # wide full-band: stripe kernel, one width per chunk
+    rc, pt, pc = _plan(_tasks([300, 390], [300, 390]))
+    assert rc == 0 and (pt[:, 1] // 10 == 10).all()               # short full-band tasks: two to a wavefront (pair kernel)
     rc, pt, pc = _plan(t, want=7)                                 # every field wanted: no register-resident kernel
     assert rc == 0 and (pt[:, 1] >= 64).all() and not np.isin(pt[:, 1], (101, 102, 103, 104, 106, 108, 201, 202, 204, 301, 302, 304)).any()
     rc, pt, _ = _plan(_tasks([300, 300], [300, 300], flag=[4, 8]))
