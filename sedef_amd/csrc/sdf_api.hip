@@ -345,7 +345,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     const char *msg = nullptr;
     static const int max_planners = [] {
       const char *e = getenv("SDF_PLAN_THREADS");
-      return e ? std::max(0, std::min(15, atoi(e))) : 3;
+      return e ? std::max(0, std::min(15, atoi(e))) : 7;
     }();
     // (parked threads pay from a few hundred thousand tasks: below, waking them costs more than they save -- measured
     // on the 100,000-task headline batch: 0.9 ms of planning alone, 2.4 ms with three helpers)

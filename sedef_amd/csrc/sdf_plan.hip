@@ -56,6 +56,8 @@ struct ChunkPlan {
   const char *err = nullptr;
 };
 
+#define SDF_CUT_BLOCK 4096
+
 struct BatchCut {
   std::vector<ChunkPlan> chunks;  // heavy chunks first
   std::vector<uint8_t> heavy;     // per task, when split_heavy
@@ -63,7 +65,12 @@ struct BatchCut {
   // scratch of cut_batch, kept by the context between calls (fresh vectors of this size cost a millisecond of page faults)
   std::vector<uint32_t> bound;      // per task: upper bound of its direction flags, in units of 256 bytes
   std::vector<uint32_t> cap;        // per task: CIGAR staging words | 0x80000000 when the task runs at all
-  std::vector<uint32_t> hparts[8];  // heavy task indices, per scan thread
+  std::vector<uint32_t> hparts[16];  // heavy task indices, per scan thread
+  struct Block {  // sums over SDF_CUT_BLOCK consecutive tasks: all runnable ones / the heavy ones among them
+    uint64_t bd = 0, hbd = 0;  // direction-flag bounds, bytes
+    uint32_t nt = 0, hnt = 0, sw = 0, hsw = 0, oc = 0, hoc = 0;  // tasks, CIGAR staging words, launch-order entries
+  };
+  std::vector<Block> blocks;
   void reset() {
     chunks.clear();
     heavy_idx.clear();
@@ -149,15 +156,20 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   bound.assign(n, 0);
   cap.assign(n, 0);
   size_t heavy_bytes = 0;
-  std::vector<uint32_t> (&hparts)[8] = cut.hparts;
+  std::vector<uint32_t> (&hparts)[16] = cut.hparts;
   for (auto &hp : hparts) hp.clear();
+  const size_t nblk = (n + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK;
+  cut.blocks.assign(nblk, BatchCut::Block());
+  auto order_entries = [&](const sdf_task &t) -> uint32_t {  // a task paired with itself is listed twice, a stripe task
+    return 2 + (t.tlen > env.stripe_min && t.tlen <= 8192 ? (uint32_t)(t.tlen + 127) / 128 : 0u);  // once per stripe
+  };
   {
     struct Part {
       size_t nh = 0, hb = 0;
       bool bad = false;
     };
     const size_t hv_limit = n / 4 + 1;
-    auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv) {
+    auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv) {  // (lo: a multiple of the block size)
       for (size_t k = lo; k < hi; ++k) {
         const sdf_task &t = tasks[k];
         if (t.flag & 0x300) {  // (not KSW_EZ_* bits of the extz2 kernel)
@@ -165,9 +177,15 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           return;
         }
         if (!plan_detail::task_runs(t, env.degenerate)) continue;
+        BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
         cap[k] = 0x80000000u;
+        const uint32_t oc = order_entries(t);
+        ++blk.nt;
+        blk.oc += oc;
         if (env.want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
-          cap[k] |= (uint32_t)(t.qlen + t.tlen + 2);
+          const uint32_t words = (uint32_t)(t.qlen + t.tlen + 2);
+          cap[k] |= words;
+          blk.sw += words;
           const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
           const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
           const size_t nrow = (size_t)t.qlen + t.tlen - 1;
@@ -180,20 +198,25 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
             for (int nr = 1; nr <= 4; nr *= 2)
               bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
           bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
+          blk.bd += (uint64_t)bound[k] << 8;
           if (bd >= heavy_min) {
             ++pt.nh;
             pt.hb += bd;
+            ++blk.hnt;
+            blk.hbd += (uint64_t)bound[k] << 8;
+            blk.hsw += words;
+            blk.hoc += oc;
             if (pt.nh <= hv_limit) hv.push_back((uint32_t)k);  // (beyond a quarter of the batch there is no split)
           }
         }
       }
     };
     // (on the context's parked planning threads when there are any; this thread takes a share too)
-    const int nthr = pool && n >= 400000 ? std::min(8, pool->size() + 1) : 1;
-    Part parts[8];
-    for (int q = 1; q < nthr; ++q)
-      pool->submit([&, q] { scan(n * q / nthr, n * (q + 1) / nthr, parts[q], hparts[q]); });
-    scan(0, n / nthr, parts[0], hparts[0]);
+    const int nthr = pool && n >= 400000 ? std::min(16, pool->size() + 1) : 1;
+    Part parts[16];
+    auto edge = [&](int q) { return q >= nthr ? n : std::min(n, (nblk * (size_t)q / (size_t)nthr) * SDF_CUT_BLOCK); };
+    for (int q = 1; q < nthr; ++q) pool->submit([&, q] { scan(edge(q), edge(q + 1), parts[q], hparts[q]); });
+    scan(0, edge(1), parts[0], hparts[0]);
     if (nthr > 1) pool->wait_idle();
     for (int q = 0; q < nthr; ++q) {
       if (parts[q].bad) {
@@ -235,7 +258,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       hacc += bd;
       ++hcur.ntask;
       hcur.stage_words += cap[k] & 0x7fffffffu;
-      hcur.order_cap += 2 + (tasks[k].tlen > env.stripe_min && tasks[k].tlen <= 8192 ? (tasks[k].tlen + 127) / 128 : 0);  // (a stripe task: an entry per stripe)
+      hcur.order_cap += order_entries(tasks[k]);
     }
     if (!cut.heavy_idx.empty()) {
       hcur.e = cut.heavy_idx.size();
@@ -244,26 +267,42 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     }
   }
   {
+    // whole blocks of tasks at a time (their sums come from the scan above); task by task only inside a block that
+    // does not fit the region as a whole
     ChunkPlan cur;
     size_t acc = 0;
     const uint8_t *hv = cut.split_heavy ? cut.heavy.data() : nullptr;
-    for (size_t k = 0; k < n; ++k) {
-      if (hv && hv[k]) continue;
-      const size_t bd = (size_t)bound[k] << 8;
+    auto close_at = [&](size_t k) {
+      cur.e = k;
+      normal.push_back(cur);
+      cut.region_need = std::max(cut.region_need, acc);
+      cur = ChunkPlan();
+      cur.s = k;
+      acc = 0;
+    };
+    for (size_t b = 0; b < nblk; ++b) {
+      const size_t k0 = b * SDF_CUT_BLOCK, k1 = std::min(n, k0 + SDF_CUT_BLOCK);
+      const BatchCut::Block &blk = cut.blocks[b];
       const size_t target = normal.empty() && nch > 1 ? first_target : chunk_target;
       // (all tasks of the range count towards the target, as they cost planning time whether they run or not)
-      if (k > cur.s && (acc + bd > region_budget || k - cur.s >= target)) {
-        cur.e = k;
-        normal.push_back(cur);
-        cut.region_need = std::max(cut.region_need, acc);
-        cur = ChunkPlan();
-        cur.s = k;
-        acc = 0;
+      if (k0 > cur.s && k0 - cur.s >= target) close_at(k0);
+      const uint64_t bbd = blk.bd - (hv ? blk.hbd : 0);
+      if (acc + bbd <= region_budget) {
+        acc += bbd;
+        cur.ntask += blk.nt - (hv ? blk.hnt : 0);
+        cur.stage_words += blk.sw - (hv ? blk.hsw : 0);
+        cur.order_cap += blk.oc - (hv ? blk.hoc : 0);
+        continue;
       }
-      acc += bd;
-      cur.ntask += cap[k] >> 31;
-      cur.stage_words += cap[k] & 0x7fffffffu;
-      cur.order_cap += (cap[k] >> 31) * (2 + (tasks[k].tlen > env.stripe_min && tasks[k].tlen <= 8192 ? (tasks[k].tlen + 127) / 128 : 0));
+      for (size_t k = k0; k < k1; ++k) {
+        if (hv && hv[k]) continue;
+        const size_t bd = (size_t)bound[k] << 8;
+        if (k > cur.s && acc + bd > region_budget) close_at(k);
+        acc += bd;
+        cur.ntask += cap[k] >> 31;
+        cur.stage_words += cap[k] & 0x7fffffffu;
+        cur.order_cap += (cap[k] >> 31) * order_entries(tasks[k]);
+      }
     }
     cur.e = n;
     normal.push_back(cur);
