@@ -1,0 +1,741 @@
+// Register-resident extz2 DP for LONG BANDED tasks: the target is cut into stripes of NSLOT = 128 * NREG positions and
+// every stripe is one wavefront (a one-wavefront workgroup, as in extz2_stripe.hip) that owns the reference's state
+// arrays u, v, x, y, s, H (extern/ksw2_extz2_sse.cc:83-85: indexed by TARGET position) for its columns, in registers.
+//
+// A banded task is a chain of qlen + tlen dependent anti-diagonals; a wavefront alone on its SIMD issues an
+// instruction every ~5 cycles, so the time of a row is the number of instructions it takes.  The one-task kernels hold
+// the whole band window (up to 1024 cells) in one wavefront or walk it with a 1024-thread workgroup through LDS:
+// 1 - 2 us per row, 40 - 80 ms for a 20 kb task.  Here the band (2 w + 1 cells) lies over (2 w + 1) / NSLOT + 1
+// stripes at a time, each wavefront computes its 128 * NREG columns of the row -- about a hundred instructions at
+// NREG = 1 -- and the stripes follow each other one 16-row block apart.
+//
+// Because a stripe's lanes ARE the reference's array slots, its artefacts need no emulation of a moving window: a row
+// computes the cells of the 16-cell blocks [lo, hi] the reference computes (:115), from whatever the slots hold;
+// the scores are refreshed in 16-cell strides from the band start (:124-138); the (r-1, t-1) neighbour of a cell is
+// the slot to its left as the previous row left it, except for the first computed cell (:140-146: the start-of-target
+// constants, 0 when the window did not move, the slot to its left with the sign-extension smear when it did), and the
+// slot left of the stripe's first one is the left stripe's last, handed over through HBM with the H of that column:
+// one (x | v << 16 | tag, H) pair per row, stored sixteen at a time per 16-row block and fetched one block ahead, as
+// in extz2_stripe.hip.  H of every band cell is kept (:222-258), with the best cell per column; a finishing kernel
+// merges the stripes' bests in the reference's order and writes the result record.
+// Rows of a stripe: hi(r) >= T0 and lo(r) < T1, i.e. r in [max(T0, 2 T0 - w), min(T1 + qlen, 2 T1 + w) - 2] (cut at
+// the end of the matrix or where the band runs out).  Direction flags: bit blocks per stripe, block index relative to
+// the stripe's first row block, slot = t - T0 (traceback layout 4).
+//
+// Compiled inside sdf_unity.hip after extz2_wave.hip and extz2_general.hip (helpers, BestCell).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "sdf_internal.h"
+
+namespace sdf {
+
+struct BStripeGeom {
+  int nslot, nst, blocks_cap, col_len;
+  size_t flag_bytes;  // per stripe
+};
+__host__ __device__ inline BStripeGeom bstripe_geom(int qlen, int tlen, int w, int nreg) {
+  BStripeGeom g;
+  g.nslot = 128 * nreg;
+  const int t16 = (tlen + 15) / 16 * 16;
+  g.nst = (t16 + g.nslot - 1) / g.nslot;
+  const int rows = 2 * g.nslot + 2 * w < g.nslot + qlen ? 2 * g.nslot + 2 * w : g.nslot + qlen;
+  g.blocks_cap = (rows + 15) / 16 + 2;
+  g.col_len = g.blocks_cap * 16 + 64;
+  g.flag_bytes = (size_t)g.blocks_cap * nreg * 1024;
+  return g;
+}
+// first / last anti-diagonal on which the stripe [T0, T1) has a computed cell (band not cut by its end)
+__host__ __device__ inline int bstripe_first_row(int T0, int w) { return T0 > 2 * T0 - w ? T0 : 2 * T0 - w; }
+__host__ __device__ inline int bstripe_last_row(int T1, int qlen, int tlen, int w) {
+  int z = qlen + tlen - 2;
+  if (z > T1 + qlen - 2) z = T1 + qlen - 2;
+  if (z > 2 * T1 + w - 2) z = 2 * T1 + w - 2;
+  return z;
+}
+// bytes of a task's direction flags / of what lies behind them: a 64-byte record per stripe, then the edge columns
+__host__ __device__ inline size_t bstripe_dir_bytes(int qlen, int tlen, int w, int nreg) {
+  const BStripeGeom g = bstripe_geom(qlen, tlen, w, nreg);
+  return (size_t)g.nst * g.flag_bytes;
+}
+__host__ __device__ inline size_t bstripe_sync_bytes(int qlen, int tlen, int w, int nreg) {
+  const BStripeGeom g = bstripe_geom(qlen, tlen, w, nreg);
+  return (size_t)g.nst * 64 + (size_t)(g.nst > 1 ? g.nst - 1 : 0) * (size_t)g.col_len * 8;
+}
+__host__ __device__ inline size_t bstripe_lds_bytes(int w, int nreg) {
+  return ((size_t)2 * (size_t)(6 * 128 * nreg + 2 * w + 256) + 15) & ~(size_t)15;  // reversed-query window, byte pairs
+}
+
+struct BStripeRec {  // what a stripe leaves for the finishing kernel
+  int32_t bestH, bestR, bestKey, bestT;
+  int32_t score, mte, mte_q, flags;  // flags: 1 score set, 2 record written
+  int32_t pad[8];
+};
+
+template <int NREG>
+__global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__restrict__ plan,
+                                                              const int32_t *__restrict__ order,
+                                                              const uint32_t *__restrict__ pool, ScoreK sc,
+                                                              uint8_t *__restrict__ dirbase) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr int NSLOT = 128 * NREG;
+  constexpr int KT = NREG - 1;
+  const int32_t entry = order[blockIdx.x];
+  const PlanTask tk = plan[entry & 0xffffff];
+  const int lane = threadIdx.x;
+  const int sb = entry >> 24;
+  const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
+  const BStripeGeom g = bstripe_geom(qlen, tlen, w, NREG);
+  if (sb >= g.nst) return;  // (a padding entry of the launch order)
+  const int T0 = sb * NSLOT, T1 = T0 + NSLOT;
+  const bool has_left = sb > 0, has_right = sb + 1 < g.nst;
+  const int nrow = qlen + tlen - 1;
+  uint8_t *gsync = dirbase + tk.dir_off + (int64_t)g.nst * (int64_t)g.flag_bytes;
+  BStripeRec *recs = reinterpret_cast<BStripeRec *>(gsync);
+  // (64-bit words: x | v << 16 | tag in the low half, H in the high half -- one store, one load)
+  volatile unsigned long long *cols = reinterpret_cast<volatile unsigned long long *>(gsync + (size_t)g.nst * 64);
+  volatile unsigned long long *col_out = cols + (size_t)sb * g.col_len;  // [row - (first row of the right stripe - 1)]
+  volatile unsigned long long *col_in = cols + (size_t)(has_left ? sb - 1 : 0) * g.col_len;  // [row - (my first row - 1)]: state AFTER that row
+  const int r_a = bstripe_first_row(T0, w);
+  int r_z = bstripe_last_row(T1, qlen, tlen, w);
+  const int next_a = bstripe_first_row(T1, w);  // the right stripe's first row: it reads my state from row next_a - 1 on
+  // rows on which the left stripe's last column is read: while my first 16-cell block is computed
+  const int r_need = bstripe_last_row(T0 + 16, qlen, tlen, w);
+  const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
+  uint4 *dir = reinterpret_cast<uint4 *>(dirbase + tk.dir_off + (int64_t)sb * (int64_t)g.flag_bytes);
+
+  // ---- the stripe's target codes; the reversed query of its rows: W[i] = (QR[i + q0], QR[i + q0 + 1]),
+  // QR[e] = query[qlen - 1 - e] (0 outside) -- row r, lane l, register k read e = qlen - 1 - r + T0 + 128 k + 2 l ----
+  const int q0 = qlen - 1 - r_z + T0 - 2;  // first entry any row of the stripe reads (minus the fetch-ahead)
+  uint16_t *W = reinterpret_cast<uint16_t *>(lds);
+  bool has_n;
+  unsigned Tc[NREG];
+  {
+    const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen + 15) / 16;
+    const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
+    const int wcap = (r_z - r_a) + NSLOT + 8;
+    uint32_t n_seen = 0;
+    for (int i = lane; i < wcap; i += 64) {
+      const int e0 = i + q0, e1 = e0 + 1;
+      uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
+      uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
+      n_seen |= (v0 | v1) >> 8;
+      v0 = (v0 & 0x7fu) | ((v0 >> 8) & 0x80u);
+      v1 = (v1 & 0x7fu) | ((v1 >> 8) & 0x80u);
+      W[i] = (uint16_t)(v0 | (v1 << 8));
+    }
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+      const int t = T0 + 128 * k + 2 * lane;
+      const uint32_t c0 = t < tlen ? pool_code16(tw, tn, t, sc.wild) : 0u;
+      const uint32_t c1 = t + 1 < tlen ? pool_code16(tw, tn, t + 1, sc.wild) : 0u;
+      n_seen |= (c0 | c1) >> 8;
+      Tc[k] = c0 | (c1 << 16);
+    }
+    has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0)) != 0;  // wave-uniform
+  }
+  __syncthreads();
+
+  // ---- constants of the <<8 difference domain ----
+  const unsigned qv = ((unsigned)sc.q_b << 8) * 0x00010001u;
+  const unsigned capv = ((unsigned)sc.cap_b << 8) * 0x00010001u;
+  const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
+  const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
+  const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
+  const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0
+  unsigned one2 = 0x00010001u;
+  SDF_OPQ(one2);
+  unsigned z_match_v = z_match;
+  SDF_OPQ(z_match_v);
+
+  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG];
+  unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
+  int32_t He[NREG], Ho[NREG];                          // H of the even / odd column of the lane
+  int32_t bHe[NREG], bRe[NREG], bHo[NREG], bRo[NREG];  // best H of the column so far, and its row
+#pragma unroll
+  for (int k = 0; k < NREG; ++k) {
+    U[k] = V[k] = X[k] = Y[k] = 0u;
+    S[k] = z_wild;  // (the reference's s array is zero: z = 0 + 2 (q + e))
+    Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
+    He[k] = Ho[k] = SDF_NEG_INF;
+    bHe[k] = bHo[k] = 0;  // (ez->max starts at 0: only a positive H can become the maximum, :41)
+    bRe[k] = bRo[k] = -1;
+  }
+  int32_t ez_score = SDF_NEG_INF, ez_mte = SDF_NEG_INF, ez_mte_q = -1;
+  bool have_score = false;
+
+  uint32_t feed_xv = 0u, feed_h = 0u, next_xv = 0u, next_h = 0u;  // the left column's words of the block / the next one
+  int feed_r0 = -0x40000000;
+  uint32_t out_xv = 0u, out_h = 0u;  // my last column's words of the block (lane = row & 15)
+  auto feed_load = [&](const int rfirst, uint32_t &xv, uint32_t &hh) {  // states after rows rfirst - 1 + (0 .. 15)
+    const int r = rfirst + (lane & 15);
+    xv = 1u;
+    hh = 0u;
+    if (r >= r_a && r <= r_need) {
+      const unsigned long long wv = col_in[r - r_a];
+      xv = (uint32_t)wv;
+      hh = (uint32_t)(wv >> 32);
+    }
+  };
+
+#ifdef SDF_STRIPE_TIMING
+  const unsigned long long tm_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tm_first = 0, tm_wait = 0;
+  int n_full = 0, n_lean = 0, n_slow = 0;
+#endif
+  int r_stop = r_z + 1;  // (lowered when the band runs out)
+  for (int r0 = r_a & ~15; r0 < r_stop; r0 += 16) {
+    r0 = __builtin_amdgcn_readfirstlane(r0);
+    const int rb = r0 > r_a ? r0 : r_a, re = r0 + 16 < r_stop ? r0 + 16 : r_stop;
+    if (has_left && rb <= r_need) {
+      uint32_t gx, gh;
+      if (feed_r0 + 16 == r0) {
+        gx = next_xv;
+        gh = next_h;
+      } else {
+        feed_load(r0, gx, gh);
+      }
+      int spins = 0;
+#ifdef SDF_STRIPE_TIMING
+      const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
+#endif
+      while (__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u)) && ++spins < (1 << 24)) {
+        __builtin_amdgcn_s_sleep(2);
+        feed_load(r0, gx, gh);
+      }
+#ifdef SDF_STRIPE_TIMING
+      if (!tm_first) tm_first = __builtin_amdgcn_s_memrealtime();
+      else if (spins) tm_wait += __builtin_amdgcn_s_memrealtime() - tw0;
+#endif
+      feed_xv = gx;
+      feed_h = gh;
+      feed_r0 = r0;
+      feed_load(r0 + 16, next_xv, next_h);
+    } else {
+      feed_xv = 1u;
+      feed_h = 0u;
+    }
+    unsigned qaddr = (unsigned)(2 * (qlen - 1 - rb + T0 + 2 * lane - q0));
+    unsigned qnext[NREG];
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+    int r = rb;
+    // ---- a block on whose rows the band covers the whole stripe with room to spare (its start left of the stripe,
+    // its top cell right of it: most rows of a wide band): every cell is computed, refreshed and an inner cell of the
+    // band -- no border cell, no first-cell rule, no masks ----
+    {
+      Band b_first, b_last;
+      const bool ok_first = band_of(rb, qlen, tlen, w, b_first), ok_last = band_of(re - 1, qlen, tlen, w, b_last);
+      if (has_left && re > rb && ok_first && ok_last && b_last.lo0 < T0 && b_first.hi0 >= T1 && rb >= next_a - 1) {
+#pragma unroll 1
+        for (; r < re; ++r) {
+          unsigned qc[NREG];
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+          qaddr -= 2;
+          asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+          const uint32_t fxv = (uint32_t)__builtin_amdgcn_readlane((int)feed_xv, r - r0);
+          const int32_t fh = __builtin_amdgcn_readlane((int)feed_h, r - r0);
+          (void)fh;
+          unsigned xt1[NREG], vt1[NREG];
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) {
+            unsigned xs, vs;
+            if (k == 0) {
+              xs = (unsigned)__builtin_amdgcn_update_dpp((int)((fxv & 0xfffeu) << 16), (int)X[0], 0x138, 0xf, 0xf, false);
+              vs = (unsigned)__builtin_amdgcn_update_dpp((int)(fxv & 0xffff0000u), (int)V[0], 0x138, 0xf, 0xf, false);
+            } else {
+              int ux, uv;
+              asm("" : "=v"(ux));
+              asm("" : "=v"(uv));
+              const int x0 = __builtin_amdgcn_update_dpp(ux, (int)X[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+              xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+              const int v0 = __builtin_amdgcn_update_dpp(uv, (int)V[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+              vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+            }
+            xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
+            vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
+          }
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) S[k] = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+          if (has_n) {
+#pragma unroll
+            for (int k = 0; k < NREG; ++k) {
+              unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
+              SDF_OPQ(nn);
+              S[k] = (z_wild & nn) | (S[k] & ~nn);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) SDF_CORE(k)
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) {
+            const int32_t nE = He[k] + (int32_t)((V[k] >> 8) & 0xffu) - sc.qe;
+            const int32_t nO = Ho[k] + (int32_t)(V[k] >> 24) - sc.qe;
+            He[k] = nE;
+            Ho[k] = nO;
+            const bool gE = nE > bHe[k], gO = nO > bHo[k];
+            bHe[k] = gE ? nE : bHe[k];
+            bRe[k] = gE ? r : bRe[k];
+            bHo[k] = gO ? nO : bHo[k];
+            bRo[k] = gO ? r : bRo[k];
+          }
+          if (has_right) {
+            const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
+            const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;
+            const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
+            out_xv = lane == (r & 15) ? es : out_xv;
+            out_h = lane == (r & 15) ? eh : out_h;
+          }
+        }
+      }
+    }
+#pragma unroll 1
+    for (; r < re; ++r) {
+      // ---- ordinary rows, as long as they last: no border cell (hi < r), the end of the target not reached, the
+      // first computed cell not in this stripe or its window not moved (then its left neighbour reads as 0): nothing
+      // but lane predicates against the row's band, no branch ----
+      // (PURE: on every row of the block the band is [(r - w + 1) >> 1, (r + w) >> 1], clear of the matrix borders)
+      auto lean_rows = [&](auto pure_c) {
+      constexpr bool PURE = decltype(pure_c)::value;
+#pragma unroll 1
+      for (; r < re; ++r) {
+        r = __builtin_amdgcn_readfirstlane(r);
+        int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
+        int plo = (r - w) >> 1;  // the previous row's band start
+        if (!PURE) {
+          lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
+          lo0 = lo0 < 0 ? 0 : lo0;
+          hi0 = hi0 > r ? r : hi0;
+          hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
+          plo = plo < r - qlen ? r - qlen : plo;
+          plo = plo < 0 ? 0 : plo;
+        }
+        const int lo = lo0 & ~15, hi = hi0 | 15, prev_lo = plo & ~15;
+        const bool moved_here = lo != prev_lo && lo >= T0 && lo < T1;
+        if (PURE) {
+          if (moved_here) break;
+        } else if (lo0 > hi0 || r == 0 || hi >= r || hi0 == tlen - 1 || moved_here || (lo == 0 && T0 == 0)) {
+          break;
+        }
+        unsigned qc[NREG];
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+        qaddr -= 2;
+        asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+        const uint32_t fxv = (uint32_t)__builtin_amdgcn_readlane((int)feed_xv, r - r0);
+        const int32_t fh = __builtin_amdgcn_readlane((int)feed_h, r - r0);
+        unsigned xt1[NREG], vt1[NREG];
+        int32_t hleft[NREG];  // H (before this row) of the column to the left of the lane's even one
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          unsigned xs, vs;
+          if (k == 0) {
+            xs = (unsigned)__builtin_amdgcn_update_dpp((int)((fxv & 0xfffeu) << 16), (int)X[0], 0x138, 0xf, 0xf, false);
+            vs = (unsigned)__builtin_amdgcn_update_dpp((int)(fxv & 0xffff0000u), (int)V[0], 0x138, 0xf, 0xf, false);
+            hleft[0] = __builtin_amdgcn_update_dpp(fh, Ho[0], 0x138, 0xf, 0xf, false);
+          } else {
+            int ux, uv, uh;
+            asm("" : "=v"(ux));
+            asm("" : "=v"(uv));
+            asm("" : "=v"(uh));
+            const int x0 = __builtin_amdgcn_update_dpp(ux, (int)X[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+            xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+            const int v0 = __builtin_amdgcn_update_dpp(uv, (int)V[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+            vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+            const int h0 = __builtin_amdgcn_update_dpp(uh, Ho[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+            hleft[k] = __builtin_amdgcn_update_dpp(h0, Ho[k], 0x138, 0xf, 0xf, false);
+          }
+          xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
+          vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
+        }
+        // the first computed cell, its window not moved: its left neighbour reads as 0 (lo: an even column)
+        const int lo_fix = lo > 0 ? lo : -2;
+        const int ra = lo0 - T0, rbe = ra + ((hi0 - lo0) & ~15) + 16;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          const int te = T0 + 128 * k + 2 * lane;
+          const bool first = te == lo_fix;
+          xt1[k] = first ? (xt1[k] & 0xffff0000u) : xt1[k];
+          vt1[k] = first ? (vt1[k] & 0xffff0000u) : vt1[k];
+          unsigned z = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+          if (has_n) {
+            unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
+            SDF_OPQ(nn);
+            z = (z_wild & nn) | (z & ~nn);
+          }
+          sel_lo_rng(S[k], z, (ra - 128 * k + 1) >> 1, (rbe - 128 * k + 1) >> 1, lane);
+          sel_hi_rng(S[k], z, (ra - 128 * k) >> 1, (rbe - 128 * k) >> 1, lane);
+          const bool act = (unsigned)(te - lo) <= (unsigned)(hi - lo);
+          const unsigned a_ = pk_add(xt1[k], vt1[k]);
+          const unsigned bb_ = pk_add(Y[k], U[k]);
+          const unsigned z0_ = S[k];
+          const unsigned z1_ = pk_maxi(z0_, a_);
+          const unsigned fa_ = pk_sub(z1_, z0_);
+          const unsigned zb_ = pk_maxi(z1_, bb_);
+          const unsigned fb_ = pk_sub(zb_, z1_);
+          const unsigned z2_ = pk_maxu(z1_, bb_);
+          const unsigned z3_ = pk_minu(z2_, capv);
+          const unsigned un_ = pk_sub(z3_, vt1[k]);
+          const unsigned vn_ = pk_sub(z3_, U[k]);
+          const unsigned zq_ = pk_sub(z3_, qv);
+          const unsigned xn_ = pk_maxi(pk_sub(a_, zq_), 0u);
+          const unsigned yn_ = pk_maxi(pk_sub(bb_, zq_), 0u);
+          U[k] = act ? un_ : U[k];
+          V[k] = act ? vn_ : V[k];
+          X[k] = act ? xn_ : X[k];
+          Y[k] = act ? yn_ : Y[k];
+          Fa[k] = shl1_or(Fa[k], pk_nonzero(fa_));
+          Fb[k] = shl1_or(Fb[k], pk_nonzero(fb_));
+          Fx[k] = shl1_or(Fx[k], pk_nonzero(xn_));
+          Fy[k] = shl1_or(Fy[k], pk_nonzero(yn_));
+          // H: the top cell (hi0 > 0 here) from the column to its left before this row, the cells below it from
+          // themselves
+          const int32_t vE = (int32_t)((V[k] >> 8) & 0xffu), vO = (int32_t)(V[k] >> 24);
+          const int32_t uE = (int32_t)((U[k] >> 8) & 0xffu), uO = (int32_t)(U[k] >> 24);
+          const unsigned dE = (unsigned)(te - lo0), dO = dE + 1u, span = (unsigned)(hi0 - lo0);
+          const int32_t tE = hleft[k] + uE - sc.qe, tO = He[k] + uO - sc.qe;
+          const int32_t mE = He[k] + vE - sc.qe, mO = Ho[k] + vO - sc.qe;
+          const int32_t nE = dE < span ? mE : dE == span ? tE : He[k];
+          const int32_t nO = dO < span ? mO : dO == span ? tO : Ho[k];
+          const bool gE = dE <= span && nE > bHe[k], gO = dO <= span && nO > bHo[k];
+          He[k] = nE;
+          Ho[k] = nO;
+          bHe[k] = gE ? nE : bHe[k];
+          bRe[k] = gE ? r : bRe[k];
+          bHo[k] = gO ? nO : bHo[k];
+          bRo[k] = gO ? r : bRo[k];
+        }
+        if (has_right && r >= next_a - 1) {
+          const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
+          const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;
+          const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
+          out_xv = lane == (r & 15) ? es : out_xv;
+          out_h = lane == (r & 15) ? eh : out_h;
+        }
+      }
+      };
+      {
+        // PURE for the rows left in the block?  (all bounds grow with r: the ends of the range decide)
+        const int rl = re - 1;
+        const bool pure = has_left && r >= w && ((r + w) >> 1 | 15) < r && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
+                          ((rl + w) >> 1) < tlen - 1 && ((r - w) >> 1) >= 0 && ((rl - w) >> 1) >= rl - qlen;
+        if (pure) lean_rows(std::true_type{});
+        else lean_rows(std::false_type{});
+      }
+      if (r >= re) break;
+      Band bd, bp;
+      if (!band_of(r, qlen, tlen, w, bd)) {  // the band has run out (every stripe sees it on the same row)
+        r_stop = r;
+        break;
+      }
+      band_of(r - 1, qlen, tlen, w, bp);
+      const int lo0 = bd.lo0, hi0 = bd.hi0, lo = bd.lo, hi = bd.hi;
+      const int prev_lo = r > 0 ? bp.lo : -1;
+      unsigned qc[NREG];
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+      qaddr -= 2;
+      asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+      // the left column after row r - 1
+      const uint32_t fxv = (uint32_t)__builtin_amdgcn_readlane((int)feed_xv, r - r0) & ~1u;
+      const int32_t fh = __builtin_amdgcn_readlane((int)feed_h, r - r0);
+      // ---- border cell t = r (:122), inside the computed blocks only ----
+      if (hi >= r && r >= T0 && r < T1) {
+        const int sr = r - T0;
+        const unsigned keep = (sr & 1) ? 0x0000ffffu : 0xffff0000u;
+        const unsigned uval = r ? (((unsigned)sc.q_b << 8) << ((sr & 1) * 16)) : 0u;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          const bool mine = (sr >> 7) == k && lane == ((sr & 127) >> 1);
+          U[k] = mine ? ((U[k] & keep) | uval) : U[k];
+          Y[k] = mine ? (Y[k] & keep) : Y[k];
+        }
+      }
+      // ---- per register: neighbours, scores, recurrence on the computed blocks, H ----
+      int32_t h_left = fh;          // H (before this row) of the column left of the register's first one
+      unsigned xprev = 0u, vprev = 0u;  // x, v of the register to the left as the previous row left them
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) {
+        const int tb = T0 + 128 * k;  // first column of the register
+        const int32_t h_left_k = h_left;
+        const unsigned xleft = xprev, vleft = vprev;
+        h_left = __builtin_amdgcn_readlane(Ho[k], 63);
+        xprev = X[k];
+        vprev = V[k];
+        if (hi < tb || lo > tb + 127) {  // (wave-uniform) no computed cell in this register: its flag rows move on
+          Fa[k] <<= 1;
+          Fb[k] <<= 1;
+          Fx[k] <<= 1;
+          Fy[k] <<= 1;
+          continue;
+        }
+        const int te = tb + 2 * lane;
+        // (r-1, t-1) neighbours
+        unsigned xs, vs;
+        if (k == 0) {
+          unsigned xc = fxv << 16, vc = fxv & 0xffff0000u;
+          if (!has_left) {
+            xc = 0u;
+            vc = r ? ((unsigned)sc.q_b << 24) : 0u;
+          }
+          xs = (unsigned)__builtin_amdgcn_update_dpp((int)xc, (int)X[0], 0x138, 0xf, 0xf, false);
+          vs = (unsigned)__builtin_amdgcn_update_dpp((int)vc, (int)V[0], 0x138, 0xf, 0xf, false);
+        } else {
+          int ux, uv;
+          asm("" : "=v"(ux));
+          asm("" : "=v"(uv));
+          const int x0 = __builtin_amdgcn_update_dpp(ux, (int)xleft, 0x13C, 0x1, 0x1, false);
+          xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
+          const int v0 = __builtin_amdgcn_update_dpp(uv, (int)vleft, 0x13C, 0x1, 0x1, false);
+          vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+        }
+        unsigned xt1 = __builtin_amdgcn_alignbit(X[k], xs, 16);
+        unsigned vt1 = __builtin_amdgcn_alignbit(V[k], vs, 16);
+        // the first computed cell (:140-146)
+        if (lo >= tb && lo <= tb + 127 && lo > 0) {
+          const int ll = (lo - tb) >> 1;  // its lane (lo is even: the low half)
+          if (lo == prev_lo) {            // the window did not move: that neighbour reads as 0
+            if (lane == ll) {
+              xt1 &= 0xffff0000u;
+              vt1 &= 0xffff0000u;
+            }
+          } else {  // it moved: the slot to the left, and a negative byte also sets the next three cells (sign extension)
+            const unsigned cx = (unsigned)__builtin_amdgcn_readlane((int)xt1, ll) & 0xffffu;
+            const unsigned cv = (unsigned)__builtin_amdgcn_readlane((int)vt1, ll) & 0xffffu;
+            const unsigned sx = (cx & 0x8000u) ? 0xff00u : 0u, sv = (cv & 0x8000u) ? 0xff00u : 0u;
+            if (lane == ll) {
+              xt1 |= sx << 16;
+              vt1 |= sv << 16;
+            }
+            if (lane == ll + 1) {
+              xt1 |= sx * 0x00010001u;
+              vt1 |= sv * 0x00010001u;
+            }
+          }
+        }
+        // scores: refreshed in 16-cell strides from lo0 (:124-138)
+        {
+          unsigned z = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+          if (has_n) {
+            unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
+            SDF_OPQ(nn);
+            z = (z_wild & nn) | (z & ~nn);
+          }
+          const int ra = lo0 - tb, rbe = ra + ((hi0 - lo0) & ~15) + 16;
+          sel_lo_rng(S[k], z, (ra + 1) >> 1, (rbe + 1) >> 1, lane);
+          sel_hi_rng(S[k], z, ra >> 1, rbe >> 1, lane);
+        }
+        // recurrence; written back in the computed blocks [lo, hi] only
+        const bool act = (unsigned)(te - lo) <= (unsigned)(hi - lo);
+        {
+          const unsigned a_ = pk_add(xt1, vt1);
+          const unsigned bb_ = pk_add(Y[k], U[k]);
+          const unsigned z0_ = S[k];
+          const unsigned z1_ = pk_maxi(z0_, a_);
+          const unsigned fa_ = pk_sub(z1_, z0_);
+          const unsigned zb_ = pk_maxi(z1_, bb_);
+          const unsigned fb_ = pk_sub(zb_, z1_);
+          const unsigned z2_ = pk_maxu(z1_, bb_);
+          const unsigned z3_ = pk_minu(z2_, capv);
+          const unsigned un_ = pk_sub(z3_, vt1);
+          const unsigned vn_ = pk_sub(z3_, U[k]);
+          const unsigned zq_ = pk_sub(z3_, qv);
+          const unsigned xn_ = pk_maxi(pk_sub(a_, zq_), 0u);
+          const unsigned yn_ = pk_maxi(pk_sub(bb_, zq_), 0u);
+          U[k] = act ? un_ : U[k];
+          V[k] = act ? vn_ : V[k];
+          X[k] = act ? xn_ : X[k];
+          Y[k] = act ? yn_ : Y[k];
+          Fa[k] = shl1_or(Fa[k], pk_nonzero(fa_));
+          Fb[k] = shl1_or(Fb[k], pk_nonzero(fb_));
+          Fx[k] = shl1_or(Fx[k], pk_nonzero(xn_));
+          Fy[k] = shl1_or(Fy[k], pk_nonzero(yn_));
+        }
+        // H of the band cells (:222-258): the top cell from the column to its left (before this row), the others
+        // from themselves
+        {
+          const int32_t vE = (int32_t)((V[k] >> 8) & 0xffu), vO = (int32_t)(V[k] >> 24);
+          const int32_t uE = (int32_t)((U[k] >> 8) & 0xffu), uO = (int32_t)(U[k] >> 24);
+          const int32_t ho_left = __builtin_amdgcn_update_dpp(h_left_k, Ho[k], 0x138, 0xf, 0xf, false);  // H of te - 1
+          const bool midE = (unsigned)(te - lo0) < (unsigned)(hi0 - lo0);
+          const bool midO = (unsigned)(te + 1 - lo0) < (unsigned)(hi0 - lo0);
+          const bool topE = te == hi0, topO = te + 1 == hi0;
+          const int32_t tE = r == 0 ? vE - 2 * sc.qe : (hi0 > 0 ? ho_left + uE : He[k] + vE) - sc.qe;
+          const int32_t tO = He[k] + uO - sc.qe;  // (hi0 odd: > 0)
+          const int32_t nE = topE ? tE : midE ? He[k] + vE - sc.qe : He[k];
+          const int32_t nO = topO ? tO : midO ? Ho[k] + vO - sc.qe : Ho[k];
+          He[k] = nE;
+          Ho[k] = nO;
+          const bool gE = (midE || topE) && nE > bHe[k], gO = (midO || topO) && nO > bHo[k];
+          bHe[k] = gE ? nE : bHe[k];
+          bRe[k] = gE ? r : bRe[k];
+          bHo[k] = gO ? nO : bHo[k];
+          bRo[k] = gO ? r : bRo[k];
+        }
+      }
+      // ---- the end of the target: mte, score (:259-262) ----
+      if (hi0 == tlen - 1 && hi0 >= T0 && hi0 < T1) {
+        const int st = hi0 - T0;
+        int32_t hv = 0;
+#pragma unroll
+        for (int k = 0; k < NREG; ++k)
+          if ((st >> 7) == k) hv = (st & 1) ? __builtin_amdgcn_readlane(Ho[k], (st & 127) >> 1) : __builtin_amdgcn_readlane(He[k], (st & 127) >> 1);
+        if (hv > ez_mte) {
+          ez_mte = hv;
+          ez_mte_q = r - hi;
+        }
+        if (r == nrow - 1) {
+          ez_score = hv;
+          have_score = true;
+        }
+      }
+      // ---- my last column after this row, for the right stripe ----
+      if (has_right && r >= next_a - 1) {
+        const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
+        const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;
+        const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
+        out_xv = lane == (r & 15) ? es : out_xv;
+        out_h = lane == (r & 15) ? eh : out_h;
+      }
+    }
+    // ---- block end: direction flags and edge words of these rows leave for HBM ----
+    const int done_hi = r - 1;  // last row done in this block
+    if (with_dir && r > rb) {
+      const unsigned sh = 15 - (done_hi & 15);
+      const int blk = (r0 >> 4) - (r_a >> 4);
+#pragma unroll
+      for (int k = 0; k < NREG; ++k)
+        dir[((int64_t)blk * NREG + k) * 64 + lane] = make_uint4(pk_shl(Fa[k], sh), pk_shl(Fb[k], sh), pk_shl(Fx[k], sh), pk_shl(Fy[k], sh));
+    }
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
+    if (has_right) {
+      const int row = r0 + lane;  // state after `row` -> entry row - (next_a - 1)
+      if (lane < 16 && (out_xv & 1u) && row >= next_a - 1 && row - (next_a - 1) < g.col_len)
+        col_out[row - (next_a - 1)] = (unsigned long long)out_xv | ((unsigned long long)out_h << 32);
+      out_xv = 0u;
+    }
+  }
+#ifdef SDF_STRIPE_TIMING
+  if (lane == 0 && (sb % 8 == 0 || sb == g.nst - 1))
+    printf("bstripe %d rows %d..%d start %llu first %llu end %llu wait %llu\n", sb, r_a, r_stop - 1, tm_start, tm_first,
+           (unsigned long long)__builtin_amdgcn_s_memrealtime(), tm_wait);
+#endif
+  // the right stripe may read my last column for a few rows after my last one: the final state, repeated
+  if (has_right) {
+    const int last = r_stop - 1;  // my last row
+    const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
+    const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;
+    const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
+    const int from = last + 1 > next_a - 1 ? last + 1 : next_a - 1;
+    const int e = from + lane - (next_a - 1);
+    if (e >= 0 && e < g.col_len) col_out[e] = (unsigned long long)es | ((unsigned long long)eh << 32);
+  }
+  // ---- the stripe's record: best cell in the reference's order (:226-258 inside a row, :41 across rows) ----
+  BestCell best = {0, -1, 0, -1};
+#pragma unroll
+  for (int k = 0; k < NREG; ++k) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int rr = half ? bRo[k] : bRe[k];
+      if (rr < 0) continue;
+      Band br;
+      band_of(rr, qlen, tlen, w, br);
+      const int t = T0 + 128 * k + 2 * lane + half;
+      const int vec_end = br.lo0 + (br.hi0 - br.lo0) / 4 * 4;
+      const int key = t == br.hi0 ? 0 : t < vec_end ? 1 + (((t - br.lo0) & 3) << 20) + t : 1 + (4 << 20) + t;
+      const BestCell cand = {half ? bHo[k] : bHe[k], rr, key, t};
+      if (beats(cand, best)) best = cand;
+    }
+  }
+  best = wave_best(best);
+  if (lane == 0) {
+    BStripeRec rec;
+    rec.bestH = best.H;
+    rec.bestR = best.r;
+    rec.bestKey = best.key;
+    rec.bestT = best.t;
+    rec.score = ez_score;
+    rec.mte = ez_mte;
+    rec.mte_q = ez_mte_q;
+    rec.flags = 2 | (have_score ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rec.pad[i] = 0;
+    recs[sb] = rec;
+  }
+}
+
+template __global__ void extz2_bstripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
+template __global__ void extz2_bstripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
+template __global__ void extz2_bstripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
+
+// Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's record and the edge column of its
+// right boundary to zero (no word tagged as written)
+__global__ __launch_bounds__(64) void bstripe_init_kernel(const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
+                                                          int nreg, uint8_t *__restrict__ dirbase) {
+  const int32_t entry = order[blockIdx.x];
+  const PlanTask tk = plan[entry & 0xffffff];
+  const int sb = entry >> 24;
+  const BStripeGeom g = bstripe_geom(tk.qlen, tk.tlen, tk.w, nreg);
+  if (sb >= g.nst) return;
+  uint8_t *gsync = dirbase + tk.dir_off + (int64_t)g.nst * (int64_t)g.flag_bytes;
+  if (threadIdx.x < 16) reinterpret_cast<int32_t *>(gsync)[sb * 16 + threadIdx.x] = 0;
+  if (sb + 1 < g.nst) {
+    unsigned long long *col = reinterpret_cast<unsigned long long *>(gsync + (size_t)g.nst * 64) + (size_t)sb * g.col_len;
+    for (int i = threadIdx.x; i < g.col_len; i += 64) col[i] = 0ull;
+  }
+}
+
+// After the launch, one thread per launch-order entry; the thread of a task's stripe 0 merges the stripes' records
+__global__ __launch_bounds__(64) void bstripe_finish_kernel(const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
+                                                            int n, int nreg, const uint8_t *__restrict__ dirbase,
+                                                            sdf_result *__restrict__ res) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= n) return;
+  const int32_t entry = order[e];
+  if (entry >> 24) return;
+  const PlanTask tk = plan[entry & 0xffffff];
+  const BStripeGeom g = bstripe_geom(tk.qlen, tk.tlen, tk.w, nreg);
+  const BStripeRec *recs = reinterpret_cast<const BStripeRec *>(dirbase + tk.dir_off + (int64_t)g.nst * (int64_t)g.flag_bytes);
+  // did the band run out before the last anti-diagonal?  (its lower bound grows faster than the upper one once they
+  // have crossed: empty on some row <=> empty on the last one)
+  Band bl;
+  const bool dropped = !band_of(tk.qlen + tk.tlen - 2, tk.qlen, tk.tlen, tk.w, bl);
+  BestCell best = {0, -1, 0, -1};
+  sdf_result o;
+  o.score = SDF_NEG_INF;
+  o.mte = SDF_NEG_INF;
+  o.mte_q = -1;
+  for (int s = 0; s < g.nst; ++s) {
+    const BStripeRec rc = recs[s];
+    if (!(rc.flags & 2)) continue;  // (a stripe the band never reached)
+    const BestCell cand = {rc.bestH, rc.bestR, rc.bestKey, rc.bestT};
+    if (rc.bestR >= 0 && beats(cand, best)) best = cand;
+    if (rc.flags & 1) o.score = rc.score;
+    if (rc.mte > o.mte) {
+      o.mte = rc.mte;
+      o.mte_q = rc.mte_q;
+    }
+  }
+  // (the one-task kernels report the best cell only when the traceback needs it: the band ran out)
+  o.max = dropped && best.r >= 0 ? best.H : 0;
+  o.max_t = dropped && best.r >= 0 ? best.t : -1;
+  o.max_q = dropped && best.r >= 0 ? best.r - best.t : -1;
+  o.mqe = SDF_NEG_INF;
+  o.mqe_t = -1;
+  o.zdropped = dropped ? 1 : 0;
+  o.n_cigar = 0;
+  o.cigar_off = 0;
+  o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
+  res[tk.out_idx] = o;
+}
+
+}  // namespace sdf

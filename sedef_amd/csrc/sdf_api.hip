@@ -101,12 +101,16 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->no_pair = np && np[0] == '1';
   for (const void *f : {reinterpret_cast<const void *>(&extz2_stripe_kernel<1>),
                         reinterpret_cast<const void *>(&extz2_stripe_kernel<2>),
-                        reinterpret_cast<const void *>(&extz2_stripe_kernel<4>)})
+                        reinterpret_cast<const void *>(&extz2_stripe_kernel<4>),
+                        reinterpret_cast<const void *>(&extz2_bstripe_kernel<1>),
+                        reinterpret_cast<const void *>(&extz2_bstripe_kernel<2>),
+                        reinterpret_cast<const void *>(&extz2_bstripe_kernel<4>)})
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipGetLastError();
   const char *ns = getenv("SDF_NO_STRIPE");
   ctx->no_stripe = ns && ns[0] == '1';
   if (const char *sm = getenv("SDF_STRIPE_MIN")) ctx->stripe_min = std::max(128, atoi(sm));
+  if (const char *bm = getenv("SDF_BSTRIPE_MIN_ROWS")) ctx->bstripe_min_rows = std::max(0, atoi(bm));
   const char *pl = getenv("SDF_PIPELINE");
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
@@ -337,6 +341,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   env.no_pair = ctx->no_pair;
   env.no_stripe = ctx->no_stripe;
   env.stripe_min = ctx->stripe_min;
+  env.bstripe_min_rows = ctx->bstripe_min_rows;
   run.want_cigar = env.want_cigar;
   if (!ctx->cut) ctx->cut = new BatchCut();
   BatchCut &cut = *ctx->cut;
@@ -855,7 +860,7 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
     }
     for (const Launch &L : c.launches) {
       const bool pair = L.bs >= 100 && L.bs < 200;
-      const bool stripes = L.bs >= 300 && L.bs < 400;
+      const bool stripes = L.bs >= 300 && L.bs < 500;
       for (size_t e = 0; e < L.cnt; ++e) {
         int32_t rel = order[c.ob + L.off + e];
         if (stripes) {  // one entry per stripe: the task is reported at its stripe 0

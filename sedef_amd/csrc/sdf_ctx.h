@@ -37,6 +37,10 @@ template <int NREG>
 __global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                     sdf_result *, int);
 __global__ void stripe_sync_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
+template <int NREG>
+__global__ void extz2_bstripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
+__global__ void bstripe_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
+__global__ void bstripe_finish_kernel(const PlanTask *, const int32_t *, int, int, const uint8_t *, sdf_result *);
 template <int LAYOUT, int G>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
 __global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
@@ -188,6 +192,8 @@ struct sdf_ctx {
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
   bool pipeline = true;        // SDF_PIPELINE=0: one chunk on one stream (isolated kernel timing)
   int stripe_min = 400;       // SDF_STRIPE_MIN: targets longer than this (and full band) take the stripe kernel
+  int bstripe_min_rows = 6000;  // SDF_BSTRIPE_MIN_ROWS: banded tasks of this many anti-diagonals or more take the banded
+                               // stripe kernel (extz2_bstripe.hip); 0: never
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
 };

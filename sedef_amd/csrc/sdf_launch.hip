@@ -75,6 +75,13 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     hipLaunchKernelGGL(stripe_sync_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                      \
     hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax); \
   }
+#define SDF_BSTRIPE(N) /* banded stripes: records and edge columns reset first, the records merged afterwards */    \
+  {                                                                                                               \
+    hipLaunchKernelGGL(bstripe_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                           \
+    hipLaunchKernelGGL((extz2_bstripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg);        \
+    hipLaunchKernelGGL(bstripe_finish_kernel, dim3((unsigned)((L.cnt + 63) / 64)), dim3(64), 0, sdp, lp, lo,     \
+                       (int)L.cnt, N, dir_reg, d_out);                                                            \
+  }
 #define SDF_GENERAL(BS, PLAIN)                                                                                      \
   hipLaunchKernelGGL((extz2_general_kernel<BS, false, PLAIN>), one, dim3(BS), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, \
                      d_out, (uint8_t *)nullptr, (size_t)0)
@@ -107,6 +114,9 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 301: SDF_STRIPE(1) break;
     case 302: SDF_STRIPE(2) break;
     case 304: SDF_STRIPE(4) break;
+    case 401: SDF_BSTRIPE(1) break;
+    case 402: SDF_BSTRIPE(2) break;
+    case 404: SDF_BSTRIPE(4) break;
     case 64: SDF_GENERAL(64, false); break;
     case 256: SDF_GENERAL(256, false); break;
     case 1024: SDF_GENERAL(1024, false); break;
@@ -120,6 +130,7 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
 #undef SDF_PAIR
 #undef SDF_PAIR_TRACK
 #undef SDF_STRIPE
+#undef SDF_BSTRIPE
 #undef SDF_GENERAL
 #undef SDF_GENERAL_HBM
 }
@@ -267,6 +278,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       return s2;
     };
     const PlanTask *lp = run.d_plan + pb;
+    if (layouts & 16u) launch_traceback<4>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
     if (layouts & 8u) launch_traceback<3>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
     if (layouts & 4u) launch_traceback<2>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
     if (layouts & 2u) launch_traceback<1>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);

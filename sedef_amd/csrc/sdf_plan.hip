@@ -24,12 +24,13 @@ struct PlanEnv {
   int max_dyn_lds = 64 * 1024;
   bool force_general = false, no_pair = false, no_stripe = false;
   int stripe_min = 400;
+  int bstripe_min_rows = 6000;  // banded tasks with at least this many anti-diagonals: banded stripe kernel (0: off)
 };
 
 struct Launch {
   int bs;  // 64 / 256 / 1024: general kernel with that many threads (+2000: PLAIN flavour); 1, 2, 4, 8: wave kernel with
            // NREG (+10: streamed windows); 100 + NREG: pair kernel (+10: streamed; 120 + NREG: TRACK flavour);
-           // 300 + NREG: stripe kernel (one launch-order entry per stripe);
+           // 300 + NREG: stripe kernel, 400 + NREG: banded stripe kernel (one launch-order entry per stripe);
            // 1000 / 1001 / 2001: general kernel with its state in HBM
   size_t lds;  // dynamic LDS bytes of the launch (HBM-state classes: slab bytes per workgroup)
   size_t off, cnt;  // entries of the chunk's launch order
@@ -92,6 +93,17 @@ struct BatchCut {
 };
 
 namespace plan_detail {
+
+// stripe width of the banded stripe kernel: the narrowest with at most 126 stripes (0: target too long)
+inline int bstripe_nreg(int tlen) {
+  static const int forced = [] {
+    const char *e = getenv("SDF_BSTRIPE_NREG");  // (tests: wider stripes than the target needs)
+    return e ? atoi(e) : 0;
+  }();
+  const int t16 = (tlen + 15) / 16 * 16;
+  if ((forced == 2 || forced == 4) && t16 <= 126 * 128 * forced) return forced;
+  return t16 <= 126 * 128 ? 1 : t16 <= 126 * 256 ? 2 : t16 <= 126 * 512 ? 4 : 0;
+}
 
 inline bool task_runs(const sdf_task &t, bool degenerate) { return t.qlen > 0 && t.tlen > 0 && !degenerate; }
 
@@ -160,8 +172,12 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   for (auto &hp : hparts) hp.clear();
   const size_t nblk = (n + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK;
   cut.blocks.assign(nblk, BatchCut::Block());
+  auto banded_long = [&](const sdf_task &t) {  // (a superset of what plan_chunk gives to the banded stripe kernel)
+    return env.bstripe_min_rows > 0 && t.w >= 1 && t.qlen + t.tlen - 1 >= env.bstripe_min_rows && plan_detail::bstripe_nreg(t.tlen) > 0;
+  };
   auto order_entries = [&](const sdf_task &t) -> uint32_t {  // a task paired with itself is listed twice, a stripe task
-    return 2 + (t.tlen > env.stripe_min && t.tlen <= 8192 ? (uint32_t)(t.tlen + 127) / 128 : 0u);  // once per stripe
+    return 2 + (t.tlen > env.stripe_min && t.tlen <= 8192 ? (uint32_t)(t.tlen + 127) / 128 : 0u) +  // once per stripe
+           (banded_long(t) ? (uint32_t)(t.tlen + 15 + 127) / 128 : 0u);
   };
   {
     struct Part {
@@ -197,6 +213,10 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           if (t.tlen > env.stripe_min && t.tlen <= 8192 && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
             for (int nr = 1; nr <= 4; nr *= 2)
               bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
+          if (banded_long(t)) {
+            const int nr = plan_detail::bstripe_nreg(t.tlen);
+            bd = std::max(bd, (bstripe_dir_bytes(t.qlen, t.tlen, w, nr) + bstripe_sync_bytes(t.qlen, t.tlen, w, nr) + 255) & ~(size_t)255);
+          }
           bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
           blk.bd += (uint64_t)bound[k] << 8;
           if (bd >= heavy_min) {
@@ -370,12 +390,31 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       const bool band_whole = (p.w >= 1 || nrow == 1) && band_of(nrow - 1, t.qlen, t.tlen, p.w, bl);
       // (generic scoring and the approximate-max modes exist in the general kernel only)
       const int general_only = SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY | SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP;
-      const bool plain = !(env.want & SDF_WANT_EXT) && t.zdrop < 0 && !(t.flag & general_only) && env.gapo >= 0 && band_whole;
+      const bool simple = !(env.want & SDF_WANT_EXT) && t.zdrop < 0 && !(t.flag & general_only) && env.gapo >= 0;
+      const bool plain = simple && band_whole;
       plain_ok = plain && !env.force_general;
+      // a long banded task, whether its band reaches the end or runs out: the banded stripe kernel (a chain of
+      // qlen + tlen rows at a hundred instructions each instead of several hundred)
+      // -- where the one-task kernels are slower per row: windows of more than 384 slots (eight registers on one
+      // wavefront, or the general kernel: 1.1 - 1.9 us per row against 0.7), and bands that run out from 192 slots up
+      // (the TRACK flavour with six registers: 1.35 us)
+      static const int bstripe_all = [] {
+        const char *e = getenv("SDF_BSTRIPE_ALL");  // (tests: every long banded task)
+        return e ? atoi(e) : 0;
+      }();
+      const int bneed = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
+      if (simple && !env.force_general && env.bstripe_min_rows > 0 && nrow >= env.bstripe_min_rows && p.w >= 1 &&
+          p.w < std::max(t.qlen, t.tlen) && (bstripe_all || bneed > 384 || (!band_whole && bneed > 192))) {
+        const int nr = plan_detail::bstripe_nreg(t.tlen);
+        if (nr && bstripe_lds_bytes(p.w, nr) <= (size_t)env.max_dyn_lds) {
+          p.nreg = nr;
+          p.pad_ = 7;
+        }
+      }
       // the same request on a band that runs out before the end of both sequences: the pair kernel's TRACK flavour
       // (exact H of every cell, best cell for the traceback), the task paired with itself; windows up to 384 slots
       const bool runs_out = !band_whole && p.w >= 1 && nrow > 1;
-      if (runs_out && !env.force_general && !env.no_pair && !(env.want & SDF_WANT_EXT) && t.zdrop < 0 &&
+      if (p.pad_ != 7 && runs_out && !env.force_general && !env.no_pair && !(env.want & SDF_WANT_EXT) && t.zdrop < 0 &&
           !(t.flag & general_only) && env.gapo >= 0) {
         const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
         // (wider windows stay on the general kernel: ten registers on one wavefront were measured no faster per row
@@ -386,7 +425,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
           p.pad_ = 6;  // (becomes layout 2 below; 6 marks the TRACK launch class until then)
         }
       }
-      if (plain_ok) {
+      if (plain_ok && p.pad_ != 7) {
         // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
         // beyond the target's last 16-cell block (cells past it are not part of any window)
         const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
@@ -402,7 +441,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
     p.cig_slot = stage_words;
     stage_words += p.cig_cap;
-    if (plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
+    if (p.pad_ != 7 && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
         t.tlen > env.stripe_min && t.tlen <= 8192) {
       // wide full-band task: one wavefront per stripe of 128 * nreg target positions (nreg: after this pass)
       if (stripe_lds_bytes(t.qlen, 4) <= (size_t)env.max_dyn_lds) {
@@ -533,13 +572,15 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
         else if (p.pad_ == 5)
           need = (stripe_dir_bytes(p.qlen, p.tlen, p.nreg) + stripe_sync_bytes(p.qlen, p.tlen, p.nreg) + 255) & ~(size_t)255;
+        else if (p.pad_ == 7)
+          need = (bstripe_dir_bytes(p.qlen, p.tlen, p.w, p.nreg) + bstripe_sync_bytes(p.qlen, p.tlen, p.w, p.nreg) + 255) & ~(size_t)255;
         else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
         else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
       }
       p.dir_off = (int64_t)dir_acc;
       dir_acc += need;
     }
-    c.layouts |= 1u << (p.nreg == 0 ? 0 : p.pad_ == 2 ? 2 : p.pad_ == 5 ? 3 : 1);
+    c.layouts |= 1u << (p.nreg == 0 ? 0 : p.pad_ == 2 ? 2 : p.pad_ == 5 ? 3 : p.pad_ == 7 ? 4 : 1);
     const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
     int bs = width > 1024 ? 1024 : width > 256 ? 256 : 64;  // 4 cells per thread and pass over the row
     size_t lds = 2048, need;
@@ -553,6 +594,11 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     } else if (p.pad_ == 5) {
       bs = 300 + p.nreg;  // stripe kernel, one wavefront (workgroup) per stripe
       need = stripe_lds_bytes(p.qlen, p.nreg);
+      lds = 8192;
+      while (lds < need) lds *= 2;
+    } else if (p.pad_ == 7) {
+      bs = 400 + p.nreg;  // banded stripe kernel, one wavefront (workgroup) per stripe
+      need = bstripe_lds_bytes(p.w, p.nreg);
       lds = 8192;
       while (lds < need) lds *= 2;
     } else if (p.nreg) {
@@ -587,7 +633,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     cl->need_max = std::max(cl->need_max, need);
     {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
       const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.6 : bs == 2256 ? 0.3 : bs == 3024 ? 0.85
-                          : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 300 ? 1.0 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..126)
+                          : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 400 ? 0.3 : bs >= 300 ? 1.0 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..126)
       cl->est = std::max(cl->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
     }
     cl->idx.push_back((int32_t)k);
@@ -644,7 +690,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   for (auto &x : cls) {
     const bool hbm_cls = x.bs == 1000 || x.bs == 1001 || x.bs == 2001;
     const size_t lds_bytes = hbm_cls ? ((x.need_max + 255) & ~(size_t)255) : std::min(x.lds, (x.need_max + 511) & ~(size_t)511);
-    if (x.bs >= 300 && x.bs < 400) {
+    if (x.bs >= 300 && x.bs < 500) {
       // Stripe kernel: one entry per stripe, (stripe << 24) | task.  Workgroup i runs on XCD i mod 8 and workgroups
       // are dispatched in index order.  The tasks are dealt to the eight residues (most stripes first, to the residue
       // with the fewest so far): a task's stripes share an XCD (its L2 carries their edge words).  A task is a chain:
@@ -655,11 +701,14 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // ones fill in behind.  The key grows with s, so a stripe's left neighbour -- the only wavefront it ever waits
       // for -- has a smaller index on the same XCD: resident or finished.
       // (Entries with stripe index 127 do nothing: they keep the residues aligned where the lists differ in length.)
-      const int nreg = x.bs - 300;
+      const bool banded = x.bs >= 400;  // (banded stripe kernel: stripes over the padded target, 2 * 128 * nreg rows apart)
+      const int nreg = x.bs - (banded ? 400 : 300);
       const size_t first = cursor;
-      const int nslot = 128 * nreg;
-      auto stripes_of = [&](int32_t rel) { return (cp[rel].tlen + nslot - 1) / nslot; };
-      // (the start keys are taken in units of one stripe's head, 128 * nreg rows: a counting sort per residue)
+      const int nslot = banded ? 256 * nreg : 128 * nreg;  // rows between the starts of consecutive stripes
+      auto stripes_of = [&](int32_t rel) {
+        return banded ? bstripe_geom(cp[rel].qlen, cp[rel].tlen, cp[rel].w, nreg).nst : (cp[rel].tlen + 128 * nreg - 1) / (128 * nreg);
+      };
+      // (the start keys are taken in units of the rows between two stripes' starts: a counting sort per residue)
       int rq_max = 0, lane_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int32_t rel : x.idx) rq_max = std::max(rq_max, (cp[rel].qlen + cp[rel].tlen) / nslot);
       const int nbucket = rq_max + 130;  // key of (task, s): s - (qlen + tlen) / nslot + rq_max, 0 <= s < 127

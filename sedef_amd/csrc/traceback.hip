@@ -41,6 +41,15 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
   if (LAYOUT == 0) {
     a.idx = (int64_t)r * tk.ncol16 + (i - b.lo);
     a.meta = 0;
+  } else if (LAYOUT == 4) {
+    // banded stripes (extz2_bstripe.hip): a flag region per stripe of 128 * nreg target positions, 16-row blocks counted
+    // from the block of the stripe's first row, slot t - T0
+    const BStripeGeom g = bstripe_geom(tk.qlen, tk.tlen, tk.w, tk.nreg);
+    const int sb = i / g.nslot, t0 = sb * g.nslot;
+    const int rb = (r >> 4) - (bstripe_first_row(t0, tk.w) >> 4);
+    const int slot = i - t0;
+    a.idx = (int64_t)sb * (int64_t)(g.flag_bytes / 16) + (int64_t)rb * (tk.nreg * 64) + (slot >> 1);
+    a.meta = (uint32_t)(15 - (r & 15) + ((slot & 1) << 4));
   } else if (LAYOUT == 3) {
     // stripes of 128 * nreg target positions, each with its own flag region in local coordinates (row r - T0,
     // slot t - T0: a stripe's window stays at its first column, extz2_stripe.hip)
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   const int k = (int)blockIdx.x * PER + lane / G;
   bool active = k < n;
   PlanTask tk = plan[active ? k : 0];
-  active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : 1) == LAYOUT &&
+  active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : tk.pad_ == 7 ? 4 : 1) == LAYOUT &&
            !(tk.flag & SDF_FLAG_SCORE_ONLY);
   sdf_result rr = res[tk.out_idx];
   int i = -1, j = -1;  // (sequences are shorter than 2^31)
@@ -225,6 +234,7 @@ SDF_TB_INST(0)
 SDF_TB_INST(1)
 SDF_TB_INST(2)
 SDF_TB_INST(3)
+SDF_TB_INST(4)
 #undef SDF_TB_INST
 
 // Exclusive scan of n_cigar over the result records in record order -> cigar_off, in three small launches:
