@@ -84,10 +84,13 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   const int32_t entry = order[blockIdx.x];
   const PlanTask tk = plan[entry & 0xffffff];
   const int lane = threadIdx.x;
-  const int sb = entry >> 24;
+  const int sb = (int)((uint32_t)entry >> 24);
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
   const BStripeGeom g = bstripe_geom(qlen, tlen, w, NREG);
   if (sb >= g.nst) return;  // (a padding entry of the launch order)
+  const bool very_long = qlen + tlen >= 16384;
+  if (very_long) __builtin_amdgcn_s_setprio(3);  // (as the one-task kernels: long chains first)
+  else __builtin_amdgcn_s_setprio(2);
   const int T0 = sb * NSLOT, T1 = T0 + NSLOT;
   const bool has_left = sb > 0, has_right = sb + 1 < g.nst;
   const int nrow = qlen + tlen - 1;
@@ -200,9 +203,18 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
 #ifdef SDF_STRIPE_TIMING
       const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      while (__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u)) && ++spins < (1 << 24)) {
-        __builtin_amdgcn_s_sleep(2);
-        feed_load(r0, gx, gh);
+      // (before its first block a stripe may wait for most of the task: it looks every few microseconds, so that the
+      // hundred waiting stripes of a long task leave the L2 to the ten working ones; between blocks it looks at once)
+      const bool first_wait = feed_r0 < 0;
+      if (__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u))) {
+        __builtin_amdgcn_s_setprio(0);  // (a waiting wavefront must not take issue slots from the one it waits for)
+        do {
+          if (first_wait) __builtin_amdgcn_s_sleep(100);
+          else __builtin_amdgcn_s_sleep(2);
+          feed_load(r0, gx, gh);
+        } while (__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u)) && ++spins < (1 << 24));
+        if (very_long) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(2);
       }
 #ifdef SDF_STRIPE_TIMING
       if (!tm_first) tm_first = __builtin_amdgcn_s_memrealtime();
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(64) void bstripe_init_kernel(const PlanTask *__rest
                                                           int nreg, uint8_t *__restrict__ dirbase) {
   const int32_t entry = order[blockIdx.x];
   const PlanTask tk = plan[entry & 0xffffff];
-  const int sb = entry >> 24;
+  const int sb = (int)((uint32_t)entry >> 24);
   const BStripeGeom g = bstripe_geom(tk.qlen, tk.tlen, tk.w, nreg);
   if (sb >= g.nst) return;
   uint8_t *gsync = dirbase + tk.dir_off + (int64_t)g.nst * (int64_t)g.flag_bytes;
@@ -701,7 +713,7 @@ __global__ __launch_bounds__(64) void bstripe_finish_kernel(const PlanTask *__re
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= n) return;
   const int32_t entry = order[e];
-  if (entry >> 24) return;
+  if ((uint32_t)entry >> 24) return;
   const PlanTask tk = plan[entry & 0xffffff];
   const BStripeGeom g = bstripe_geom(tk.qlen, tk.tlen, tk.w, nreg);
   const BStripeRec *recs = reinterpret_cast<const BStripeRec *>(dirbase + tk.dir_off + (int64_t)g.nst * (int64_t)g.flag_bytes);

@@ -86,6 +86,10 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 64 * NREG;
   const PlanTask tk = plan[order[2 * blockIdx.x]];       // task A (low halves)
+  // (a long task is a chain of dependent rows that ends the launch: its wavefront gets the SIMD before those of short
+  // tasks sharing it)
+  if (tk.qlen + tk.tlen >= 16384) __builtin_amdgcn_s_setprio(3);
+  else if (tk.qlen + tk.tlen >= 6144) __builtin_amdgcn_s_setprio(2);
   const PlanTask tkb = plan[order[2 * blockIdx.x + 1]];  // task B (high halves): same qlen, tlen, w, flag
   const int lane = threadIdx.x;
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;

@@ -25,7 +25,7 @@
 // multiples of 256: the bit is free; the columns are zeroed before the launch); its right neighbour fetches the 16
 // words a block needs with one load -- issued one block ahead -- and looks at the tag bits.  A stripe only ever waits
 // for its left neighbour, which has the smaller workgroup index on the same XCD: resident or finished.
-// Launch-order entries are (stripe << 24) | task; stripe index 127 marks an entry that does nothing.
+// Launch-order entries are (stripe << 24) | task; stripe index 255 marks an entry that does nothing.
 // Direction flags: the wave-kernel bit blocks, one region per stripe, slot = t - T0 (traceback layout 3).
 //
 // Compiled inside sdf_unity.hip after extz2_wave.hip (helpers, SDF_CORE, pool_code16).
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   const int32_t entry = order[blockIdx.x];
   const PlanTask tk = plan[entry & 0xffffff];
   const int lane = threadIdx.x;
-  const int sb = entry >> 24;  // stripe of this wavefront
+  const int sb = (int)((uint32_t)entry >> 24);  // stripe of this wavefront
   const int tlen_all = tk.tlen;
   const int nstripe = (tlen_all + NSLOT - 1) / NSLOT;
   if (sb >= nstripe) return;  // (a padding entry of the launch order)
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(64) void stripe_sync_init_kernel(const PlanTask *__
                                                               uint8_t *__restrict__ dirbase) {
   const int32_t entry = order[blockIdx.x];
   const PlanTask tk = plan[entry & 0xffffff];
-  const int sb = entry >> 24;
+  const int sb = (int)((uint32_t)entry >> 24);
   const int nslot = 128 * nreg, nst = (tk.tlen + nslot - 1) / nslot;
   if (sb >= nst) return;
   uint8_t *gsync = dirbase + tk.dir_off + (int64_t)stripe_dir_bytes(tk.qlen, tk.tlen, nreg);

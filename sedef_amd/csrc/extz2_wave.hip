@@ -217,6 +217,10 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_w
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;
   const PlanTask tk = plan[order[blockIdx.x]];
+  // (a long task is a chain of dependent rows that ends the launch: its wavefront gets the SIMD before those of short
+  // tasks sharing it)
+  if (tk.qlen + tk.tlen >= 16384) __builtin_amdgcn_s_setprio(3);
+  else if (tk.qlen + tk.tlen >= 6144) __builtin_amdgcn_s_setprio(2);
   const int lane = threadIdx.x;
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
   // Sequence windows in LDS.  Tb[i] = target position tt0 + i (16-bit codes, zero beyond the ends); W[i] = entry

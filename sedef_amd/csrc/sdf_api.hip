@@ -864,7 +864,7 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
       for (size_t e = 0; e < L.cnt; ++e) {
         int32_t rel = order[c.ob + L.off + e];
         if (stripes) {  // one entry per stripe: the task is reported at its stripe 0
-          if (rel >> 24) continue;
+          if ((uint32_t)rel >> 24) continue;
           rel &= 0xffffff;
         }
         const PlanTask &p = plan[c.pb + rel];

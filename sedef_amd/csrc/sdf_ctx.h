@@ -192,7 +192,7 @@ struct sdf_ctx {
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel
   bool pipeline = true;        // SDF_PIPELINE=0: one chunk on one stream (isolated kernel timing)
   int stripe_min = 400;       // SDF_STRIPE_MIN: targets longer than this (and full band) take the stripe kernel
-  int bstripe_min_rows = 6000;  // SDF_BSTRIPE_MIN_ROWS: banded tasks of this many anti-diagonals or more take the banded
+  int bstripe_min_rows = 4000;  // SDF_BSTRIPE_MIN_ROWS: banded tasks of this many anti-diagonals or more take the banded
                                // stripe kernel (extz2_bstripe.hip); 0: never
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)

@@ -222,7 +222,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
     // milliseconds each), the others for the ordinary chunks, which would otherwise queue behind them
     int qi = 0;
     if (pipelined) {
-      if (piped && L.cnt >= 2048) {
+      if (piped && L.cnt >= 2048 && L.bs < 300) {  // (a stripe class counts stripes, and lasts as long as its longest task)
         qi = ui;
       } else {  // least estimated work queued; with heavy tasks in the batch Q[0], Q[1], Q[4], Q[5] are theirs
         qi = run.have_heavy ? (heavy_chunk ? 0 : 2) : 1;

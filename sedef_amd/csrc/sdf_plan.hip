@@ -24,7 +24,7 @@ struct PlanEnv {
   int max_dyn_lds = 64 * 1024;
   bool force_general = false, no_pair = false, no_stripe = false;
   int stripe_min = 400;
-  int bstripe_min_rows = 6000;  // banded tasks with at least this many anti-diagonals: banded stripe kernel (0: off)
+  int bstripe_min_rows = 4000;  // banded tasks with at least this many anti-diagonals: banded stripe kernel (0: off)
 };
 
 struct Launch {
@@ -44,7 +44,7 @@ struct ChunkPlan {
   size_t pb = 0;         // first PlanTask of the chunk
   size_t ob = 0;         // first launch-order entry (room for `order_cap`: a task paired with itself is listed twice,
                          // a stripe task once per stripe)
-  size_t order_cap = 1024;  // (a stripe launch: up to 8 x 127 idle entries)
+  size_t order_cap = 4096;  // (stripe launches: up to 8 x 255 idle entries each)
   int64_t stage0 = 0;    // first CIGAR staging word
   size_t ntask = 0;      // tasks the chunk will plan (known after cut_batch)
   int64_t stage_words = 0;  // CIGAR staging words of those tasks
@@ -94,15 +94,15 @@ struct BatchCut {
 
 namespace plan_detail {
 
-// stripe width of the banded stripe kernel: the narrowest with at most 126 stripes (0: target too long)
+// stripe width of the banded stripe kernel: the narrowest with at most 254 stripes (0: target too long)
 inline int bstripe_nreg(int tlen) {
   static const int forced = [] {
     const char *e = getenv("SDF_BSTRIPE_NREG");  // (tests: wider stripes than the target needs)
     return e ? atoi(e) : 0;
   }();
   const int t16 = (tlen + 15) / 16 * 16;
-  if ((forced == 2 || forced == 4) && t16 <= 126 * 128 * forced) return forced;
-  return t16 <= 126 * 128 ? 1 : t16 <= 126 * 256 ? 2 : t16 <= 126 * 512 ? 4 : 0;
+  if ((forced == 2 || forced == 4) && t16 <= 254 * 128 * forced) return forced;
+  return t16 <= 254 * 128 ? 1 : t16 <= 254 * 256 ? 2 : t16 <= 254 * 512 ? 4 : 0;
 }
 
 inline bool task_runs(const sdf_task &t, bool degenerate) { return t.qlen > 0 && t.tlen > 0 && !degenerate; }
@@ -402,9 +402,13 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         const char *e = getenv("SDF_BSTRIPE_ALL");  // (tests: every long banded task)
         return e ? atoi(e) : 0;
       }();
+      static const int bstripe_plain_min = [] {
+        const char *e = getenv("SDF_BSTRIPE_PLAIN_MIN");
+        return e ? atoi(e) : 192;
+      }();
       const int bneed = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
       if (simple && !env.force_general && env.bstripe_min_rows > 0 && nrow >= env.bstripe_min_rows && p.w >= 1 &&
-          p.w < std::max(t.qlen, t.tlen) && (bstripe_all || bneed > 384 || (!band_whole && bneed > 192))) {
+          p.w < std::max(t.qlen, t.tlen) && (bstripe_all || bneed > bstripe_plain_min || (!band_whole && bneed > 192))) {
         const int nr = plan_detail::bstripe_nreg(t.tlen);
         if (nr && bstripe_lds_bytes(p.w, nr) <= (size_t)env.max_dyn_lds) {
           p.nreg = nr;
@@ -488,7 +492,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       PlanTask &p = cp[k];
       if (p.pad_ != 5) continue;
       p.nreg = nr;
-      if ((p.tlen + 128 * nr - 1) / (128 * nr) > 126) {  // (entry encoding: 7 bits of stripe index, 127 = idle)
+      if ((p.tlen + 128 * nr - 1) / (128 * nr) > 254) {  // (entry encoding: 8 bits of stripe index, 255 = idle)
         p.nreg = 0;
         const bool hbm = general_lds_bytes(p.qlen, p.tlen) > (size_t)env.max_dyn_lds;
         p.pad_ = hbm ? 4 : 3;
@@ -700,7 +704,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // long tasks get their wavefront slots first (those of their later stripes sleep until their turn), the short
       // ones fill in behind.  The key grows with s, so a stripe's left neighbour -- the only wavefront it ever waits
       // for -- has a smaller index on the same XCD: resident or finished.
-      // (Entries with stripe index 127 do nothing: they keep the residues aligned where the lists differ in length.)
+      // (Entries with stripe index 255 do nothing: they keep the residues aligned where the lists differ in length.)
       const bool banded = x.bs >= 400;  // (banded stripe kernel: stripes over the padded target, 2 * 128 * nreg rows apart)
       const int nreg = x.bs - (banded ? 400 : 300);
       const size_t first = cursor;
@@ -711,7 +715,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // (the start keys are taken in units of the rows between two stripes' starts: a counting sort per residue)
       int rq_max = 0, lane_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int32_t rel : x.idx) rq_max = std::max(rq_max, (cp[rel].qlen + cp[rel].tlen) / nslot);
-      const int nbucket = rq_max + 130;  // key of (task, s): s - (qlen + tlen) / nslot + rq_max, 0 <= s < 127
+      const int nbucket = rq_max + 258;  // key of (task, s): s - (qlen + tlen) / nslot + rq_max, 0 <= s < 255
       std::vector<int32_t> &lane_of = sx.stripe_lane, &fill = sx.stripe_fill;
       lane_of.resize(x.idx.size());
       fill.assign((size_t)8 * nbucket + 1, 0);
@@ -737,7 +741,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
           base[q] = acc;
           acc += lane_sum[q];
         }
-        const int32_t idle = (int32_t)((127 << 24) | x.idx[0]);
+        const int32_t idle = (int32_t)((255u << 24) | (uint32_t)x.idx[0]);
         for (int pos = 0; pos < longest; ++pos)
           for (int q = 0; q < 8; ++q)
             if (pos >= lane_sum[q]) order[c.ob + first + (size_t)pos * 8 + q] = idle;
@@ -746,7 +750,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
           const int to = lane_of[j], nst = stripes_of(rel), key0 = rq_max - (cp[rel].qlen + cp[rel].tlen) / nslot;
           for (int sidx = 0; sidx < nst; ++sidx) {
             const int pos = fill[(size_t)to * nbucket + key0 + sidx]++ - base[to];
-            order[c.ob + first + (size_t)pos * 8 + to] = (int32_t)((sidx << 24) | rel);
+            order[c.ob + first + (size_t)pos * 8 + to] = (int32_t)(((uint32_t)sidx << 24) | (uint32_t)rel);
           }
         }
         cursor = first + (size_t)longest * 8;

@@ -30,6 +30,32 @@ def solo_engine():
             os.environ["SDF_NO_PAIR"] = old
 
 
+def _engine_with_env(**env):
+    import os
+    import sedef_amd
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return sedef_amd.Extz2Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def onetask_engine():
+    """Context with the banded stripe kernel off: long banded tasks stay on the one-task kernels (pair / wave / general)."""
+    return _engine_with_env(SDF_BSTRIPE_MIN_ROWS=0)
+
+
+@pytest.fixture(scope="module")
+def onetask_solo_engine():
+    return _engine_with_env(SDF_BSTRIPE_MIN_ROWS=0, SDF_NO_PAIR=1)
+
+
 def _rec_to_dict(r, cig):
     d = {k: int(r[k]) for k in FIELDS}
     d["cigar"] = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
@@ -529,7 +555,8 @@ def test_plain_general_kernel_wide_windows(engine, oracle):
     _check_fast(engine, oracle, [(q, t), (q[:15000], t[:15100])], [-1, 1400])
 
 
-def test_pair_kernel_long_sequences_streamed_windows(engine, oracle):
+def test_pair_kernel_long_sequences_streamed_windows(onetask_engine, oracle):
+    engine = onetask_engine
     """Sequences far longer than the LDS windows of the pair kernel (window slots + 1024 entries): the target and
     reversed-query windows are re-filled from the packed pool as the band moves; N runs and indels near the band
     edge included; several same-geometry tasks per shape so that pairs form."""
@@ -551,7 +578,8 @@ def test_pair_kernel_long_sequences_streamed_windows(engine, oracle):
     assert engine.last_paired() >= 14
 
 
-def test_wave_kernel_long_sequences_streamed_windows(engine, solo_engine, oracle):
+def test_wave_kernel_long_sequences_streamed_windows(onetask_engine, onetask_solo_engine, oracle):
+    engine, solo_engine = onetask_engine, onetask_solo_engine
     """Long sequences through the one-task-per-wavefront kernel: its LDS sequence windows are re-filled as the band
     moves (bands of 513..1000 cells take this kernel in the default context too; narrower ones with SDF_NO_PAIR)."""
     rng = np.random.default_rng(7070)
@@ -591,6 +619,66 @@ def test_stripe_kernel_wide_full_band(engine, oracle):
                 t = _fit(rng, t, tl)
             pairs.append((q, t))
     _check_fast(engine, oracle, pairs, [-1] * len(pairs))
+
+
+def _check_dropped_max(engine, oracle, pairs, ws):
+    """_check_fast, plus the best cell (max, max_t, max_q) of the tasks whose band runs out: the traceback starts there."""
+    import sedef_amd
+    _check_fast(engine, oracle, pairs, ws)
+    res, _ = engine.align_pairs(pairs, w=ws, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    ndrop = 0
+    for (q, t), w, r in zip(pairs, ws, res):
+        exp = oracle.extz2(q, t, w=w)
+        if exp["zdropped"]:
+            ndrop += 1
+            assert (int(r["max"]), int(r["max_t"]), int(r["max_q"])) == (exp["max"], exp["max_t"], exp["max_q"]), (w, len(q), len(t))
+    return ndrop
+
+
+@pytest.mark.parametrize("nreg", [1, 2, 4])
+def test_stripe_kernels_every_width_fuzz(oracle, nreg):
+    """Both stripe kernels with the stripe width forced (128 / 256 / 512 positions) and every banded / full-band task
+    of 100+ anti-diagonals routed to them: full band (extz2_stripe.hip) from 130 target bases, bands of 1..300 that
+    reach the corner or run out (extz2_bstripe.hip), N bases, indels longer than the band, one-base sequences."""
+    eng = _engine_with_env(SDF_STRIPE_NREG=nreg, SDF_BSTRIPE_NREG=nreg if nreg > 1 else 0, SDF_STRIPE_MIN=130,
+                           SDF_BSTRIPE_MIN_ROWS=100, SDF_BSTRIPE_ALL=1)
+    rng = np.random.default_rng(9900 + nreg)
+    pairs, ws = [], []
+    for _ in range(260):
+        ql = int(rng.integers(60, 1500))
+        tl = max(1, ql + int(rng.integers(-250, 250)))
+        w = int(rng.choice([-1, -1, 1, 2, 7, 15, 16, 17, 31, 33, 64, 100, 128, 200, 300]))
+        q = random_codes(rng, ql, 0.004 if rng.random() < 0.3 else 0.0)
+        t = mutate(rng, q, 0.05, 0.01, 0.01)
+        if rng.random() < 0.4 and len(t) > 300:
+            k, L = int(rng.integers(0, len(t) - 100)), int(rng.integers(1, 400))
+            t = np.concatenate([t[:k], random_codes(rng, L), t[k:]]) if rng.random() < 0.5 else np.concatenate([t[:k], t[k + L:]])
+        pairs.append((q, _fit(rng, t, tl)))
+        ws.append(w)
+    for ql, tl, w in [(1, 700, 5), (700, 1, 5), (2, 900, -1), (900, 2, -1), (129, 129, 64), (128, 2000, 100), (2000, 128, 100)]:
+        q = random_codes(rng, ql)
+        pairs.append((q, _fit(rng, mutate(rng, q, 0.05, 0.01, 0.01), tl)))
+        ws.append(w)
+    assert _check_dropped_max(eng, oracle, pairs, ws) >= 20
+
+
+def test_banded_stripe_kernel_long_tasks(engine, oracle):
+    """Long banded tasks as the default context routes them (4000+ anti-diagonals, windows of more than 192 slots, or
+    bands that run out): 128-position stripes up to 32 kb targets, one row block apart; bands that reach the corner, run
+    out after a long indel, or never reach it at all."""
+    rng = np.random.default_rng(9911)
+    pairs, ws = [], []
+    for ql, tl, w, indel in [(7000, 7000, 128, 0), (6500, 6400, 256, 0), (8000, 8000, 512, 300), (12000, 11000, 300, 0),
+                             (7000, 9000, 512, 0), (20000, 20000, 200, 150), (3000, 3100, 100, 0), (9000, 9000, 300, 700),
+                             (16200, 16300, 128, 0), (17000, 16500, 256, 0), (2100, 2000, 400, 0), (25000, 25010, 96, 40)]:
+        q = random_codes(rng, ql, 0.002 if rng.random() < 0.5 else 0.0)
+        t = mutate(rng, q, 0.05, 0.01, 0.01)
+        if indel:
+            k = int(rng.integers(0, len(t) - indel))
+            t = np.concatenate([t[:k], t[k + indel:]])
+        pairs.append((q, _fit(rng, t, tl)))
+        ws.append(w)
+    assert _check_dropped_max(engine, oracle, pairs, ws) >= 3
 
 
 def test_pair_kernel_track_band_runs_out(engine, oracle):
