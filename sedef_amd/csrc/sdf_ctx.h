@@ -59,16 +59,24 @@ struct DevBuf {
     static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     const size_t old = cap;
-    if (p) (void)hipFree(p);
+    // hipFree waits for the whole DEVICE -- the other lanes' batches included: 100-170 ms measured in a stage run, where
+    // the allocation itself takes 0.2 ms -- so an outgrown buffer is only retired here and freed with the context
+    // (sizes grow by half each time: the retired ones add up to less than twice the last)
+    if (p) retired.push_back(p);
     p = nullptr;
     cap = 0;
-    // growing means a free (which waits for the device) and an allocation, tens to hundreds of milliseconds for
-    // gigabytes: leave half as much again as headroom (at most 8 GiB) so that batches of similar size do not regrow
     size_t want = bytes + std::min<size_t>(bytes / 2, (size_t)8 << 30) + 4096;
     hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {
-      want = bytes;
+    if (e != hipSuccess) {  // short of memory: give the retired buffers back first, then without headroom
+      (void)hipGetLastError();
+      for (void *q : retired) (void)hipFree(q);
+      retired.clear();
       e = hipMalloc(&p, want);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes;
+        e = hipMalloc(&p, want);
+      }
     }
     if (e == hipSuccess) cap = want;
     if (dbg_t && want >= (64u << 20))
@@ -78,9 +86,12 @@ struct DevBuf {
   }
   void release() {
     if (p) (void)hipFree(p);
+    for (void *q : retired) (void)hipFree(q);
+    retired.clear();
     p = nullptr;
     cap = 0;
   }
+  std::vector<void *> retired;
 };
 
 struct HostBuf {  // pinned host memory
@@ -88,7 +99,7 @@ struct HostBuf {  // pinned host memory
   size_t cap = 0;
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
+    if (p) retired.push_back(p);  // (hipHostFree waits for the device like hipFree: freed with the context)
     p = nullptr;
     cap = 0;
     // (pinning is slow -- about a millisecond per 4 MB -- and a stage run sees its batches grow: half as much again as
@@ -100,9 +111,12 @@ struct HostBuf {  // pinned host memory
   }
   void release() {
     if (p) (void)hipHostFree(p);
+    for (void *q : retired) (void)hipHostFree(q);
+    retired.clear();
     p = nullptr;
     cap = 0;
   }
+  std::vector<void *> retired;
 };
 
 }  // namespace sdf

@@ -143,11 +143,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     for (size_t k = 0; k < n && !any_long; ++k) any_long = tasks[k].qlen + (int64_t)tasks[k].tlen >= 3000;
   cut.pipelined = pipeline_enabled && (n >= 2048 || any_long);
   cut.nch = 1;
-  static const size_t nch_big = [] {
-    const char *e = getenv("SDF_NCH");
-    return e ? (size_t)atoll(e) : (size_t)8;
-  }();
-  if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? nch_big : 4, n / 16384);
+  // (sixteen or twenty-four chunks for a million tasks were measured no better than eight)
+  if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? 8 : 4, n / 16384);
   cut.max_regions = cut.nch > 4 ? 8 : cut.nch > 1 ? 4 : 1;
   const size_t nch = cut.nch;
   // the first chunk is small, so that the GPU starts early, but fills the wavefront slots of the device (4,096 pairs
@@ -395,17 +392,14 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       plain_ok = plain && !env.force_general;
       // a long banded task, whether its band reaches the end or runs out: the banded stripe kernel (a chain of
       // qlen + tlen rows at a hundred instructions each instead of several hundred)
-      // -- where the one-task kernels are slower per row: windows of more than 384 slots (eight registers on one
-      // wavefront, or the general kernel: 1.1 - 1.9 us per row against 0.7), and bands that run out from 192 slots up
-      // (the TRACK flavour with six registers: 1.35 us)
+      // -- where the one-task kernels are slower per row: windows of more than 192 slots (six or eight registers on
+      // one wavefront, or the general kernel: 0.9 - 1.9 us per row in a mixed batch against 0.2 - 0.5), and bands that
+      // run out from 192 slots up (the TRACK flavour with six registers: 1.35 us)
       static const int bstripe_all = [] {
         const char *e = getenv("SDF_BSTRIPE_ALL");  // (tests: every long banded task)
         return e ? atoi(e) : 0;
       }();
-      static const int bstripe_plain_min = [] {
-        const char *e = getenv("SDF_BSTRIPE_PLAIN_MIN");
-        return e ? atoi(e) : 192;
-      }();
+      constexpr int bstripe_plain_min = 192;  // (measured on the mm8-like mixture: 384 -> 47 ms, 192 -> 29-34 ms, 128 -> 36-39 ms)
       const int bneed = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
       if (simple && !env.force_general && env.bstripe_min_rows > 0 && nrow >= env.bstripe_min_rows && p.w >= 1 &&
           p.w < std::max(t.qlen, t.tlen) && (bstripe_all || bneed > bstripe_plain_min || (!band_whole && bneed > 192))) {
