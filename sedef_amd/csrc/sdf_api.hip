@@ -352,9 +352,14 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       const char *e = getenv("SDF_PLAN_THREADS");
       return e ? std::max(0, std::min(15, atoi(e))) : 7;
     }();
-    // (parked threads pay from a few hundred thousand tasks: below, waking them costs more than they save -- measured
-    // on the 100,000-task headline batch: 0.9 ms of planning alone, 2.4 ms with three helpers)
-    if (!ctx->pool && n >= 400000 && max_planners > 0) ctx->pool = new WorkerPool(max_planners);
+    // (parked threads plan the chunks of batches of 100,000 tasks and more -- 250,000 tasks of the hg19 mixture:
+    // 14.5 -> 10.1 ms, the headline batch unchanged -- and from 400,000 tasks the scan of the cut as well: there, below,
+    // waking them cost more than they saved)
+    static const size_t pool_from = [] {
+      const char *e = getenv("SDF_PLAN_POOL_FROM");
+      return e ? (size_t)atoll(e) : (size_t)100000;
+    }();
+    if (!ctx->pool && n >= pool_from && max_planners > 0) ctx->pool = new WorkerPool(max_planners);
     if (int rc = cut_batch(env, ctx->pipeline, ctx->ws_budget, cut, &msg, ctx->pool)) {
       ctx->err = msg ? msg : "invalid batch";
       return rc;
@@ -400,7 +405,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   {
     // (batches of ordinary size are planned by this thread, a chunk ahead of the GPU: 25,000 tasks take under a
     // millisecond to plan and five to run; batches of many small tasks are planned on the context's parked threads)
-    const int nthr = ctx->pool && cut.chunks.size() >= 3 && n >= 400000
+    const int nthr = ctx->pool && cut.chunks.size() >= 3
                          ? (int)std::min<size_t>(ctx->pool->size(), cut.chunks.size())
                          : 0;
     ChunkPlanner planner(env, cut, run.plan, run.order, ctx->pool, nthr);
