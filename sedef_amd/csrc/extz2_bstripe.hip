@@ -97,9 +97,9 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   uint8_t *gsync = dirbase + tk.dir_off + (int64_t)g.nst * (int64_t)g.flag_bytes;
   BStripeRec *recs = reinterpret_cast<BStripeRec *>(gsync);
   // (64-bit words: x | v << 16 | tag in the low half, H in the high half -- one store, one load)
-  volatile unsigned long long *cols = reinterpret_cast<volatile unsigned long long *>(gsync + (size_t)g.nst * 64);
-  volatile unsigned long long *col_out = cols + (size_t)sb * g.col_len;  // [row - (first row of the right stripe - 1)]
-  volatile unsigned long long *col_in = cols + (size_t)(has_left ? sb - 1 : 0) * g.col_len;  // [row - (my first row - 1)]: state AFTER that row
+  unsigned long long *cols = reinterpret_cast<unsigned long long *>(gsync + (size_t)g.nst * 64);
+  unsigned long long *col_out = cols + (size_t)sb * g.col_len;  // [row - (first row of the right stripe - 1)]
+  unsigned long long *col_in = cols + (size_t)(has_left ? sb - 1 : 0) * g.col_len;  // [row - (my first row - 1)]: state AFTER that row
   const int r_a = bstripe_first_row(T0, w);
   int r_z = bstripe_last_row(T1, qlen, tlen, w);
   const int next_a = bstripe_first_row(T1, w);  // the right stripe's first row: it reads my state from row next_a - 1 on
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     xv = 1u;
     hh = 0u;
     if (r >= r_a && r <= r_need) {
-      const unsigned long long wv = col_in[r - r_a];
+      const unsigned long long wv = ld_agent(col_in + (r - r_a));
       xv = (uint32_t)wv;
       hh = (uint32_t)(wv >> 32);
     }
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     if (has_right) {
       const int row = r0 + lane;  // state after `row` -> entry row - (next_a - 1)
       if (lane < 16 && (out_xv & 1u) && row >= next_a - 1 && row - (next_a - 1) < g.col_len)
-        col_out[row - (next_a - 1)] = (unsigned long long)out_xv | ((unsigned long long)out_h << 32);
+        st_agent(col_out + (row - (next_a - 1)), (unsigned long long)out_xv | ((unsigned long long)out_h << 32));
       out_xv = 0u;
     }
   }
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
     const int from = last + 1 > next_a - 1 ? last + 1 : next_a - 1;
     const int e = from + lane - (next_a - 1);
-    if (e >= 0 && e < g.col_len) col_out[e] = (unsigned long long)es | ((unsigned long long)eh << 32);
+    if (e >= 0 && e < g.col_len) st_agent(col_out + e, (unsigned long long)es | ((unsigned long long)eh << 32));
   }
   // ---- the stripe's record: best cell in the reference's order (:226-258 inside a row, :41 across rows) ----
   BestCell best = {0, -1, 0, -1};

@@ -51,6 +51,17 @@ __host__ __device__ inline size_t stripe_sync_bytes(int qlen, int tlen, int nreg
   return (((size_t)nst * 8 + 255) & ~(size_t)255) + (size_t)(nst > 1 ? nst - 1 : 0) * (size_t)(qlen + 16) * 4;
 }
 
+// The words stripes exchange: relaxed atomics of agent scope -- coherent across the XCDs' L2 caches, so that the protocol
+// does not depend on a task's stripes sharing an XCD (that is a matter of speed: then the words stay in its L2).
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void st_agent(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define SDF_STRIPE_SPIN_CAP (1 << 24)  // polls before a wait gives up (a wrong result instead of a hung queue)
 
 template <int NREG>
@@ -86,11 +97,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     else if (share == 1) __builtin_amdgcn_s_setprio(1);
   }
   uint8_t *gsync = dirbase + tk.dir_off + (int64_t)stripe_dir_bytes(qlen, tlen_all, NREG);
-  volatile int *prog = reinterpret_cast<volatile int *>(gsync);  // [nstripe] T0 + NSLOT - 1 once stripe s has handed over
-  volatile int *hand_val = prog + nstripe;                       // [nstripe] H of its top cell after its row NSLOT - 1
-  volatile uint32_t *rings = reinterpret_cast<volatile uint32_t *>(gsync + (((size_t)nstripe * 8 + 255) & ~(size_t)255));
-  volatile uint32_t *ring_out = rings + (size_t)sb * ncol;                         // [r - (NSLOT - 1)], r: my row
-  volatile uint32_t *ring_in = rings + (size_t)(has_left ? sb - 1 : 0) * ncol;  // [r], r: my row
+  int *prog = reinterpret_cast<int *>(gsync);  // [nstripe] T0 + NSLOT - 1 once stripe s has handed over
+  int *hand_val = prog + nstripe;                       // [nstripe] H of its top cell after its row NSLOT - 1
+  uint32_t *rings = reinterpret_cast<uint32_t *>(gsync + (((size_t)nstripe * 8 + 255) & ~(size_t)255));
+  uint32_t *ring_out = rings + (size_t)sb * ncol;                         // [r - (NSLOT - 1)], r: my row
+  uint32_t *ring_in = rings + (size_t)(has_left ? sb - 1 : 0) * ncol;  // [r], r: my row
 
   // ---- unpack: the reversed query as byte pairs; W[i] = (QR[i - NSLOT], QR[i - NSLOT + 1]), QR[e] = query[qlen-1-e]
   // (0 outside): lane l of register k reads entry qlen - 1 - r + NSLOT + 128 k + 2 l on row r ----
@@ -154,8 +165,8 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     int spins = 0;
     // (readfirstlane: the compiler cannot see that a volatile load of one address is wave-uniform, and a divergent
     // loop here would make every value that lives across it -- the row counters -- a vector value)
-    while (__builtin_amdgcn_readfirstlane(prog[sb - 1]) < T0 - 1 && ++spins < SDF_STRIPE_SPIN_CAP) __builtin_amdgcn_s_sleep(8);
-    h_head = __builtin_amdgcn_readfirstlane(hand_val[sb - 1]);
+    while (__builtin_amdgcn_readfirstlane(ld_agent(prog + sb - 1)) < T0 - 1 && ++spins < SDF_STRIPE_SPIN_CAP) __builtin_amdgcn_s_sleep(8);
+    h_head = __builtin_amdgcn_readfirstlane(ld_agent(hand_val + sb - 1));
   }
 #ifdef SDF_STRIPE_TIMING
   unsigned long long tm_start = __builtin_amdgcn_s_memrealtime(), tm_head = 0, tm_tail = 0, tm_wait = 0;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     // a row reads the column only while its first cell is in the band (r <= qlen - 1): what lies beyond is never
     // written by the neighbour and never used here -- "tagged", value 0
     const int i = lane & 15, r = rfirst + i;
-    return (r <= qlen - 1) ? ring_in[r] : 1u;
+    return (r <= qlen - 1) ? ld_agent(ring_in + r) : 1u;
   };
 
   unsigned qaddr = 0u, qnext[NREG];
@@ -361,15 +372,15 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     if (has_right) {
       if (rend > NSLOT - 1) {  // this block's edge words (the tagged ones: rows >= NSLOT - 1)
         const int g = r0 + lane - (NSLOT - 1);
-        if (lane < 16 && (edge16 & 1u) && g < ncol) ring_out[g] = edge16;
+        if (lane < 16 && (edge16 & 1u) && g < ncol) st_agent(ring_out + g, edge16);
       }
       edge16 = 0u;
       if (rend == NSLOT) {  // first query row done, its edge word stored: the right neighbour may start
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) {
-          hand_val[sb] = h_head;
+          st_agent(hand_val + sb, h_head);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          prog[sb] = T0 + NSLOT - 1;
+          st_agent(prog + sb, T0 + NSLOT - 1);
         }
       }
     }
