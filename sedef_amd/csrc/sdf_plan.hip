@@ -229,6 +229,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       }
     };
     // (on the context's parked planning threads when there are any; this thread takes a share too)
+    // (from 400,000 tasks: on the 100,000-task headline batch four scan threads were measured at 5.2 ms of planning
+    // before the first launch against 1.2 ms on this thread alone -- the wake-up of parked threads, not the scan)
     const int nthr = pool && n >= 400000 ? std::min(16, pool->size() + 1) : 1;
     Part parts[16];
     auto edge = [&](int q) { return q >= nthr ? n : std::min(n, (nblk * (size_t)q / (size_t)nthr) * SDF_CUT_BLOCK); };
