@@ -12,6 +12,10 @@
 // matrix geometry, allocation) for a batch of tasks.
 #include "sdf_ctx.h"
 
+#include <atomic>
+#include <memory>
+#include <thread>
+
 namespace sdf {
 
 struct PlanEnv {
@@ -161,6 +165,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   // ---- validation + upper bound of each task's direction flags, whichever kernel takes it ----
   // (on several threads for batches of hundreds of thousands of tasks: this pass and the loop below are all the
   // planning the GPU waits for besides the first chunk)
+  static const bool dbg_cut = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const auto tc0 = std::chrono::steady_clock::now();
   std::vector<uint32_t> &bound = cut.bound, &cap = cut.cap;
   bound.assign(n, 0);
   cap.assign(n, 0);
@@ -233,10 +239,24 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     // before the first launch against 1.2 ms on this thread alone -- the wake-up of parked threads, not the scan)
     const int nthr = pool && n >= 400000 ? std::min(16, pool->size() + 1) : 1;
     Part parts[16];
-    auto edge = [&](int q) { return q >= nthr ? n : std::min(n, (nblk * (size_t)q / (size_t)nthr) * SDF_CUT_BLOCK); };
-    for (int q = 1; q < nthr; ++q) pool->submit([&, q] { scan(edge(q), edge(q + 1), parts[q], hparts[q]); });
-    scan(0, edge(1), parts[0], hparts[0]);
-    if (nthr > 1) pool->wait_idle();
+    // Runs of 16 blocks are handed out through a counter: this thread starts at once, a parked helper joins when it
+    // has woken up (which takes up to milliseconds on a box with a CPU quota) and takes what is left -- nobody waits
+    // for a share that was dealt to a thread still asleep.
+    struct Share {
+      std::atomic<size_t> next{0}, done{0};
+    };
+    auto share = std::make_shared<Share>();  // (outlives this call: a helper may wake up after everything is done)
+    const size_t run_blocks = 16, nrun = (nblk + run_blocks - 1) / run_blocks;
+    auto work = [&, share, nrun](int q) {  // (touches nothing of this frame once the runs are handed out)
+      for (size_t ru = share->next.fetch_add(1); ru < nrun; ru = share->next.fetch_add(1)) {
+        if (!parts[q].bad)
+          scan(ru * run_blocks * SDF_CUT_BLOCK, std::min(n, (ru + 1) * run_blocks * SDF_CUT_BLOCK), parts[q], hparts[q]);
+        share->done.fetch_add(1);
+      }
+    };
+    for (int q = 1; q < nthr; ++q) pool->submit([work, q] { work(q); });
+    work(0);
+    while (share->done.load() < nrun) std::this_thread::yield();  // (a helper still inside its last run)
     for (int q = 0; q < nthr; ++q) {
       if (parts[q].bad) {
         *err = "unknown task flag";
@@ -246,6 +266,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       heavy_bytes += parts[q].hb;
     }
   }
+  const auto tc1 = std::chrono::steady_clock::now();
   // Heavy tasks leave the chunk rotation when they are a minority: they are planned and launched FIRST, all together
   // (a launch of few long tasks lasts as long as its longest task: one such launch per kernel, not one per chunk), with
   // a workspace slice of their own, and run next to the chunks of ordinary tasks.
@@ -258,10 +279,17 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   std::vector<ChunkPlan> normal, heavy_chunks;
   if (cut.split_heavy) {  // heavy chunks: ranges of the (ascending) list of heavy tasks
     for (auto &hp : hparts) cut.heavy_idx.insert(cut.heavy_idx.end(), hp.begin(), hp.end());
+    std::sort(cut.heavy_idx.begin(), cut.heavy_idx.end());  // (the scan threads took their runs of blocks in any order)
     ChunkPlan hcur;
     hcur.heavy = true;
     size_t hacc = 0;
     for (size_t pos = 0; pos < cut.heavy_idx.size(); ++pos) {
+      if (pos + 16 < cut.heavy_idx.size()) {  // (the heavy tasks lie scattered over the batch: a cache miss each)
+        const uint32_t kn = cut.heavy_idx[pos + 16];
+        __builtin_prefetch(&tasks[kn]);
+        __builtin_prefetch(&bound[kn]);
+        __builtin_prefetch(&cap[kn]);
+      }
       const uint32_t k = cut.heavy_idx[pos];
       const size_t bd = (size_t)bound[k] << 8;
       cut.heavy[k] = 1;
@@ -346,6 +374,9 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   cut.ntask_total = pb;
   cut.order_total = ob;
   cut.stage_total = stage;
+  if (dbg_cut && n >= 100000)
+    fprintf(stderr, "[cut: clear + scan %.2f ms, boundaries %.2f ms]\n", std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
   return SDF_OK;
 }
 
@@ -355,6 +386,9 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   using plan_detail::Cls;
   const sdf_task *tasks = env.tasks;
   const bool want_cigar = env.want_cigar;
+  static const bool dbg_pc = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto tp1 = tp0, tp2 = tp0, tp3 = tp0;
   std::vector<int32_t> &win_need = sx.win_need, &partner = sx.partner;
   std::vector<Cls> &cls = sx.cls;
   win_need.clear();
@@ -362,6 +396,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   int64_t stage_words = c.stage0;
   size_t n_stripe_tasks = 0, stripes4 = 0;  // stripe tasks of the chunk; their stripes at 512 positions each
   for (size_t pos = c.s; pos < c.e; ++pos) {
+    if (c.heavy && pos + 16 < c.e) __builtin_prefetch(&tasks[cut.heavy_idx[pos + 16]]);
     const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
     const sdf_task &t = tasks[k];
     if (!c.heavy && cut.split_heavy && cut.heavy[k]) continue;
@@ -463,6 +498,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     }
     plan[np++] = p;
   }
+  tp1 = std::chrono::steady_clock::now();
   const size_t cnt = np - c.pb;
   c.cnt = cnt;
   c.nord = 0;
@@ -559,6 +595,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     }
   }
 
+  tp2 = std::chrono::steady_clock::now();
   // launch classes: (kernel, LDS bytes rounded to a power of two); the direction-flag layout inside this chunk's
   // workspace region is fixed in the same pass
   cls.clear();
@@ -684,6 +721,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       std::stable_sort(x.idx.begin(), x.idx.end(), [&](int32_t a, int32_t b) { return work(a) > work(b); });
     }
   }
+  tp3 = std::chrono::steady_clock::now();
   // longest launches first so the long tasks start early
   std::sort(cls.begin(), cls.end(), [](const Cls &a, const Cls &b) { return a.est > b.est; });
   size_t cursor = 0;
@@ -761,6 +799,10 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   }
   c.nord = cursor;
   if (c.nord > c.order_cap) c.err = "internal: launch-order segment overflow";
+  if (dbg_pc && c.heavy) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[plan_chunk heavy: tasks %.2f ms, pairing %.2f ms, classes %.2f ms, order %.2f ms]\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()));
+  }
 }
 
 }  // namespace sdf
