@@ -108,10 +108,12 @@ __device__ __forceinline__ int tb_state(int s_in, uint32_t cell) {
 // ksw_backtrack is serial: the cell a step reads depends on the state the previous cell left.  But a walk is a
 // sequence of RUNS -- diagonal steps while the cells say "diagonal", gap steps while the continuation bit is set --
 // and whether a run goes on through its k-th cell depends on that cell alone.  A group of G lanes walks one task:
-// every lane reads the current cell (-> the state s of the run that starts here), lane k also reads the k-th cell
-// ahead in each of the three directions, one ballot tells how far the run of kind s goes (up to G cells), the
-// match / mismatch columns of a diagonal run are counted with a second ballot, and the whole run is emitted as one
-// CIGAR push.  A 1000 x 1000 task at 10 % divergence is ~60 such rounds (one memory latency each) instead of 2,000
+// the flags of the current cell are in hand (they give the state s of the run that starts here), lane k reads the
+// (k+1)-th cell ahead in THAT direction -- one address, one load per lane and round --, one ballot tells how far the
+// run goes (up to G cells), the match / mismatch columns of a diagonal run are counted with a second ballot, the whole
+// run is emitted as one CIGAR push, and the flags of the cell the run stopped at -- some lane has just read them --
+// become the current ones.  A 1000 x 1000 task at 10 % divergence is ~60 such rounds (one memory latency each) instead
+// of 2,000
 // dependent steps.  G = 64: one task per wavefront (few or long tasks); G = 16: four tasks per wavefront (bulk).
 // Runs are emitted from the END of the task's staging slot towards its start, which leaves them in forward order.
 template <int LAYOUT, int G>
@@ -169,29 +171,38 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
     }
   };
 
+  // The flags of the CURRENT cell are always in hand: loaded before the first round, afterwards they are those of the
+  // cell the last run stopped at, which one of the lanes had read.  So a round knows the state s of the run that starts
+  // here before it loads anything, and every lane reads ONE cell: the (k+1)-th ahead in that run's direction.
   int s_in = 0;
+  uint32_t c0 = 0;
+  {
+    const bool live0 = active && (i | j) >= 0;
+    c0 = tb_load<LAYOUT>(dir, tb_addr<LAYOUT>(tk, live0 ? i : 0, live0 ? j : 0));
+  }
   while (__any(active && (i | j) >= 0)) {
     const bool live = active && (i | j) >= 0;
     const int ci = live ? i : 0, cj = live ? j : 0;
-    // the k-th cell ahead in each direction (k = 0: the current cell in all three)
-    const int di = ci - kk, dj = cj - kk;
-    const bool vd = di >= 0 && dj >= 0, vu = di >= 0, vl = dj >= 0;
-    const TbAddr a0 = tb_addr<LAYOUT>(tk, ci, cj);
-    const TbAddr ad = tb_addr<LAYOUT>(tk, vd ? di : ci, vd ? dj : cj);
-    const TbAddr au = tb_addr<LAYOUT>(tk, vu ? di : ci, cj);
-    const TbAddr al = tb_addr<LAYOUT>(tk, ci, vl ? dj : cj);
-    const uint32_t c0 = tb_load<LAYOUT>(dir, a0), cd = tb_load<LAYOUT>(dir, ad), cu = tb_load<LAYOUT>(dir, au),
-                   cl = tb_load<LAYOUT>(dir, al);
-    // bases of the diagonal cell (match <=> neither is N and the codes agree, src/align.cc:29-35 on the codes)
-    const uint32_t tb_ = code_at(tw, tn, vd ? di : ci), qb_ = code_at(qw, qn, vd ? dj : cj);
     const int s = tb_state(s_in, c0);
-    const uint32_t cs = s == 0 ? cd : s == 1 ? cu : cl;
-    const bool vs = s == 0 ? vd : s == 1 ? vu : vl;
-    const bool stay = live && vs && (kk == 0 || tb_state(s, cs) == s);
+    // the cell kk + 1 steps ahead
+    const int di = ci - (s != 2 ? kk + 1 : 0), dj = cj - (s != 1 ? kk + 1 : 0);
+    const bool valid = di >= 0 && dj >= 0;
+    const uint32_t cs = tb_load<LAYOUT>(dir, tb_addr<LAYOUT>(tk, valid ? di : ci, valid ? dj : cj));
+    // bases of the run's own cells (kk steps ahead), diagonal runs only: match <=> neither is N and the codes agree
+    // (src/align.cc:29-35 on the codes)
+    const bool vb = s == 0 && ci - kk >= 0 && cj - kk >= 0;
+    const uint32_t tb_ = vb ? code_at(tw, tn, ci - kk) : 4u, qb_ = vb ? code_at(qw, qn, cj - kk) : 5u;
+    const bool stay = live && valid && tb_state(s, cs) == s;
     const uint64_t bits = (__ballot(stay) >> gbase) & gmask;
     const uint64_t stop = ~bits & gmask;
-    const int nrun = stop ? __builtin_ctzll(stop) : G;
+    // cells of the run: the current one and the leading ones that go on with it -- at most G, so that the cell the run
+    // stops at (or pauses at: then the next round continues it) is one a lane has read
+    const int ahead = stop ? __builtin_ctzll(stop) : G - 1;
+    const int nrun = ahead + 1;
     const uint64_t mb = (__ballot(tb_ == qb_ && tb_ < 4u) >> gbase) & (nrun >= 64 ? ~0ull : ((1ull << nrun) - 1ull));
+    // the flags of the cell after the run: read by lane `ahead` of the group (if it lies outside the matrix the walk
+    // ends and they are not used)
+    const uint32_t c_next = (uint32_t)__shfl((int)cs, gbase + ahead);
     if (live) {
       if (s == 0) {
         const int m = __popcll(mb);
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
         push(1, nrun);
       }
       s_in = s;
+      c0 = c_next;
     }
   }
   if (active) {
