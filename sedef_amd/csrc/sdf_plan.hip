@@ -430,8 +430,9 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // a long banded task, whether its band reaches the end or runs out: the banded stripe kernel (a chain of
       // qlen + tlen rows at a hundred instructions each instead of several hundred)
       // -- where the one-task kernels are slower per row: windows of more than 192 slots (six or eight registers on
-      // one wavefront, or the general kernel: 0.9 - 1.9 us per row in a mixed batch against 0.2 - 0.5), and bands that
-      // run out from 192 slots up (the TRACK flavour with six registers: 1.35 us)
+      // one wavefront, or the general kernel: 0.9 - 1.9 us per row in a mixed batch against 0.2 - 0.5), and every band
+      // that runs out (the TRACK flavour: 0.6 us per row with three registers, 1.35 with six; mm8-like mixture with
+      // those of up to 192 slots left on it 27.5 ms, without 24.1)
       static const int bstripe_all = [] {
         const char *e = getenv("SDF_BSTRIPE_ALL");  // (tests: every long banded task)
         return e ? atoi(e) : 0;
@@ -439,7 +440,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       constexpr int bstripe_plain_min = 192;  // (measured on the mm8-like mixture: 384 -> 47 ms, 192 -> 29-34 ms, 128 -> 36-39 ms)
       const int bneed = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
       if (simple && !env.force_general && env.bstripe_min_rows > 0 && nrow >= env.bstripe_min_rows && p.w >= 1 &&
-          p.w < std::max(t.qlen, t.tlen) && (bstripe_all || bneed > bstripe_plain_min || (!band_whole && bneed > 192))) {
+          p.w < std::max(t.qlen, t.tlen) && (bstripe_all || bneed > bstripe_plain_min || !band_whole)) {
         const int nr = plan_detail::bstripe_nreg(t.tlen);
         if (nr && bstripe_lds_bytes(p.w, nr) <= (size_t)env.max_dyn_lds) {
           p.nreg = nr;
