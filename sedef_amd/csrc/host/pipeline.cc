@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <fstream>
 #include <atomic>
 #include <condition_variable>
@@ -602,35 +604,84 @@ static void parallel_for(int n, const std::function<void(int)> &body) {
     for (int i = 0; i < n; i++) body(i);
     return;
   }
-  // The lanes of the stage driver call this concurrently: a process-wide count of running workers keeps the total
-  // at `nthreads` (more runnable threads than the CPU quota get the whole process throttled by the scheduler).
-  static std::mutex slot_mu;
-  static std::condition_variable slot_cv;
-  static int slots_used = 0;
-  std::atomic<int> next(0);
-  std::vector<std::string> errors(nt);
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nt; t++)
-    pool.emplace_back([&, t] {
+  // The lanes of the stage driver call this concurrently, a few hundred times per run.  One set of worker threads for
+  // the whole process (as many as the CPU quota: more runnable threads get the process throttled) serves all callers:
+  // a call is a REGION -- a counter over its items -- queued for the workers; the caller works on its own region too,
+  // so it never waits for a parked thread to wake up, and returns when all its items are done.  (Threads created and
+  // joined per call cost 0.1 ms each, milliseconds under a CPU quota.)
+  struct Region {
+    const std::function<void(int)> *body;
+    int n;
+    std::atomic<int> next{0}, done{0};
+    std::mutex err_mu;
+    std::string error;
+    void run() {
+      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+        try {
+          (*body)(i);
+        } catch (std::string &s) {
+          std::lock_guard<std::mutex> g(err_mu);
+          if (error.empty()) error = s.empty() ? std::string("error") : s;
+        }
+        if (done.fetch_add(1) + 1 == n) {  // the last item: wake the caller if it is waiting
+          std::lock_guard<std::mutex> g(fin_mu);
+          fin_cv.notify_all();
+        }
+      }
+    }
+    std::mutex fin_mu;
+    std::condition_variable fin_cv;
+  };
+  struct Pool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<Region>> open;  // regions that may still have items to hand out
+    std::vector<std::thread> workers;
+    bool quit = false;
+    explicit Pool(int nw) {
+      for (int t = 0; t < nw; t++)
+        workers.emplace_back([this] {
+          for (;;) {
+            std::shared_ptr<Region> r;
+            {
+              std::unique_lock<std::mutex> g(mu);
+              cv.wait(g, [&] {
+                while (!open.empty() && open.front()->next.load() >= open.front()->n) open.pop_front();
+                return quit || !open.empty();
+              });
+              if (open.empty()) return;
+              r = open.front();  // (to the back: the next worker takes another caller's region -- the lanes share the
+              open.pop_front();  // workers instead of queueing behind each other)
+              open.push_back(r);
+            }
+            r->run();
+          }
+        });
+    }
+    ~Pool() {
       {
-        std::unique_lock<std::mutex> g(slot_mu);
-        slot_cv.wait(g, [&] { return slots_used < nthreads; });
-        ++slots_used;
+        std::lock_guard<std::mutex> g(mu);
+        quit = true;
       }
-      try {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
-      } catch (std::string &s) {
-        errors[t] = s.empty() ? std::string("error") : s;
-      }
-      {
-        std::lock_guard<std::mutex> g(slot_mu);
-        --slots_used;
-      }
-      slot_cv.notify_one();
-    });
-  for (auto &th : pool) th.join();
-  for (auto &e : errors)
-    if (!e.empty()) throw e;
+      cv.notify_all();
+      for (auto &t : workers) t.join();
+    }
+  };
+  static Pool pool(nthreads);
+  auto region = std::make_shared<Region>();
+  region->body = &body;
+  region->n = n;
+  {
+    std::lock_guard<std::mutex> g(pool.mu);
+    pool.open.push_back(region);
+  }
+  pool.cv.notify_all();
+  region->run();
+  if (region->done.load() < n) {  // (workers still inside their last items: sleep, a spinning caller eats CPU quota)
+    std::unique_lock<std::mutex> g(region->fin_mu);
+    region->fin_cv.wait(g, [&] { return region->done.load() >= n; });
+  }
+  if (!region->error.empty()) throw region->error;
 }
 
 static std::vector<Hit> read_schedule(const std::string &bed_path, FILE *log) {  // src/align_main.cc:200-283, nbins=1
