@@ -48,7 +48,8 @@ struct ChunkPlan {
   size_t pb = 0;         // first PlanTask of the chunk
   size_t ob = 0;         // first launch-order entry (room for `order_cap`: a task paired with itself is listed twice,
                          // a stripe task once per stripe)
-  size_t order_cap = 4096;  // (stripe launches: up to 8 x 255 idle entries each)
+  size_t order_cap = 12288;  // (up to five stripe launches -- one width of the full-band kernel, three of the banded one -- of up
+                             // to 8 x 254 idle entries each)
   int64_t stage0 = 0;    // first CIGAR staging word
   size_t ntask = 0;      // tasks the chunk will plan (known after cut_batch)
   int64_t stage_words = 0;  // CIGAR staging words of those tasks
