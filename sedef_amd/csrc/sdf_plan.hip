@@ -169,8 +169,10 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   static const bool dbg_cut = getenv("SDF_DEBUG_PLAN") != nullptr;
   const auto tc0 = std::chrono::steady_clock::now();
   std::vector<uint32_t> &bound = cut.bound, &cap = cut.cap;
-  bound.assign(n, 0);
-  cap.assign(n, 0);
+  // (not cleared: 8 MB of memset per million tasks, on this thread, before anything else can start -- the scan below
+  // writes both words of every task, runnable or not)
+  if (bound.size() < n) bound.resize(n);
+  if (cap.size() < n) cap.resize(n);
   size_t heavy_bytes = 0;
   std::vector<uint32_t> (&hparts)[16] = cut.hparts;
   for (auto &hp : hparts) hp.clear();
@@ -196,6 +198,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           pt.bad = true;
           return;
         }
+        bound[k] = 0;
+        cap[k] = 0;
         if (!plan_detail::task_runs(t, env.degenerate)) continue;
         BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
         cap[k] = 0x80000000u;
@@ -240,14 +244,15 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     // before the first launch against 1.2 ms on this thread alone -- the wake-up of parked threads, not the scan)
     const int nthr = pool && n >= 400000 ? std::min(16, pool->size() + 1) : 1;
     Part parts[16];
-    // Runs of 16 blocks are handed out through a counter: this thread starts at once, a parked helper joins when it
+    // Runs of sixteen blocks are handed out through a counter: this thread starts at once, a parked helper joins when it
     // has woken up (which takes up to milliseconds on a box with a CPU quota) and takes what is left -- nobody waits
     // for a share that was dealt to a thread still asleep.
     struct Share {
       std::atomic<size_t> next{0}, done{0};
     };
     auto share = std::make_shared<Share>();  // (outlives this call: a helper may wake up after everything is done)
-    const size_t run_blocks = 16, nrun = (nblk + run_blocks - 1) / run_blocks;
+    const size_t run_blocks = 16, nrun = (nblk + run_blocks - 1) / run_blocks;  // (runs of 1 / 2 / 4 blocks: 3.3-4.0 / 2.0-2.7 / 1.8-2.5 ms
+                                                                                // per million tasks against 1.3-2.1)
     auto work = [&, share, nrun](int q) {  // (touches nothing of this frame once the runs are handed out)
       for (size_t ru = share->next.fetch_add(1); ru < nrun; ru = share->next.fetch_add(1)) {
         if (!parts[q].bad)
