@@ -107,6 +107,11 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   const int r_need = bstripe_last_row(T0 + 16, qlen, tlen, w);
   const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
   uint4 *dir = reinterpret_cast<uint4 *>(dirbase + tk.dir_off + (int64_t)sb * (int64_t)g.flag_bytes);
+  // H of every band cell and the best cell are what a band that runs out needs (the traceback starts at the best
+  // cell).  A band that reaches the corner needs score and mte only: H of the top cell and of the one under it, i.e. of
+  // this stripe's columns while the top cell is in them or has just left for the right neighbour's first column.
+  Band b_end;
+  const bool can_drop = !band_of(nrow - 1, qlen, tlen, w, b_end);
 
   // ---- the stripe's target codes; the reversed query of its rows: W[i] = (QR[i + q0], QR[i + q0 + 1]),
   // QR[e] = query[qlen - 1 - e] (0 outside) -- row r, lane l, register k read e = qlen - 1 - r + T0 + 128 k + 2 l ----
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
       Band b_first, b_last;
       const bool ok_first = band_of(rb, qlen, tlen, w, b_first), ok_last = band_of(re - 1, qlen, tlen, w, b_last);
       if (has_left && re > rb && ok_first && ok_last && b_last.lo0 < T0 && b_first.hi0 >= T1 && rb >= next_a - 1) {
+        const bool full_h = can_drop || b_first.hi0 <= T1 + 1;  // (see can_drop)
 #pragma unroll 1
         for (; r < re; ++r) {
           unsigned qc[NREG];
@@ -283,17 +289,21 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           }
 #pragma unroll
           for (int k = 0; k < NREG; ++k) SDF_CORE(k)
+          if (full_h) {
 #pragma unroll
-          for (int k = 0; k < NREG; ++k) {
-            const int32_t nE = He[k] + (int32_t)((V[k] >> 8) & 0xffu) - sc.qe;
-            const int32_t nO = Ho[k] + (int32_t)(V[k] >> 24) - sc.qe;
-            He[k] = nE;
-            Ho[k] = nO;
-            const bool gE = nE > bHe[k], gO = nO > bHo[k];
-            bHe[k] = gE ? nE : bHe[k];
-            bRe[k] = gE ? r : bRe[k];
-            bHo[k] = gO ? nO : bHo[k];
-            bRo[k] = gO ? r : bRo[k];
+            for (int k = 0; k < NREG; ++k) {
+              const int32_t nE = He[k] + (int32_t)((V[k] >> 8) & 0xffu) - sc.qe;
+              const int32_t nO = Ho[k] + (int32_t)(V[k] >> 24) - sc.qe;
+              He[k] = nE;
+              Ho[k] = nO;
+              if (can_drop) {
+                const bool gE = nE > bHe[k], gO = nO > bHo[k];
+                bHe[k] = gE ? nE : bHe[k];
+                bRe[k] = gE ? r : bRe[k];
+                bHo[k] = gO ? nO : bHo[k];
+                bRo[k] = gO ? r : bRo[k];
+              }
+            }
           }
           if (has_right) {
             const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
@@ -408,6 +418,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           Fy[k] = shl1_or(Fy[k], pk_nonzero(yn_));
           // H: the top cell (hi0 > 0 here) from the column to its left before this row, the cells below it from
           // themselves
+          if (!(can_drop || hi0 <= T1 + 1)) continue;  // (wave-uniform; see can_drop)
           const int32_t vE = (int32_t)((V[k] >> 8) & 0xffu), vO = (int32_t)(V[k] >> 24);
           const int32_t uE = (int32_t)((U[k] >> 8) & 0xffu), uO = (int32_t)(U[k] >> 24);
           const unsigned dE = (unsigned)(te - lo0), dO = dE + 1u, span = (unsigned)(hi0 - lo0);
@@ -415,13 +426,15 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           const int32_t mE = He[k] + vE - sc.qe, mO = Ho[k] + vO - sc.qe;
           const int32_t nE = dE < span ? mE : dE == span ? tE : He[k];
           const int32_t nO = dO < span ? mO : dO == span ? tO : Ho[k];
-          const bool gE = dE <= span && nE > bHe[k], gO = dO <= span && nO > bHo[k];
           He[k] = nE;
           Ho[k] = nO;
-          bHe[k] = gE ? nE : bHe[k];
-          bRe[k] = gE ? r : bRe[k];
-          bHo[k] = gO ? nO : bHo[k];
-          bRo[k] = gO ? r : bRo[k];
+          if (can_drop) {
+            const bool gE = dE <= span && nE > bHe[k], gO = dO <= span && nO > bHo[k];
+            bHe[k] = gE ? nE : bHe[k];
+            bRe[k] = gE ? r : bRe[k];
+            bHo[k] = gO ? nO : bHo[k];
+            bRo[k] = gO ? r : bRo[k];
+          }
         }
         if (has_right && r >= next_a - 1) {
           const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);

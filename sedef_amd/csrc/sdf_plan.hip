@@ -149,6 +149,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   cut.pipelined = pipeline_enabled && (n >= 2048 || any_long);
   cut.nch = 1;
   // (sixteen or twenty-four chunks for a million tasks were measured no better than eight)
+  // (two, three or six chunks for the 100,000-task headline batch: within noise of four)
   if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? 8 : 4, n / 16384);
   cut.max_regions = cut.nch > 4 ? 8 : cut.nch > 1 ? 4 : 1;
   const size_t nch = cut.nch;
