@@ -401,7 +401,9 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   win_need.clear();
   size_t np = c.pb;
   int64_t stage_words = c.stage0;
-  size_t n_stripe_tasks = 0, stripes4 = 0;  // stripe tasks of the chunk; their stripes at 512 positions each
+  size_t n_stripe_tasks = 0;   // stripe tasks of the chunk,
+  double stripe_cells = 0;     // their cells,
+  int stripe_rows = 0;         // the anti-diagonals of the longest of them
   for (size_t pos = c.s; pos < c.e; ++pos) {
     if (c.heavy && pos + 16 < c.e) __builtin_prefetch(&tasks[cut.heavy_idx[pos + 16]]);
     const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
@@ -491,7 +493,8 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         p.nreg = 4;
         p.pad_ = 5;
         ++n_stripe_tasks;
-        stripes4 += (size_t)(t.tlen + 511) / 512;
+        stripe_cells += (double)t.qlen * (double)t.tlen;
+        stripe_rows = std::max(stripe_rows, t.qlen + t.tlen);
       }
     }
     if (!p.nreg) {
@@ -527,7 +530,21 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       const char *e = getenv("SDF_STRIPE_NREG");
       return e ? atoi(e) : 0;
     }();
-    const int nr = force_nreg ? force_nreg : stripes4 >= 1536 ? 4 : stripes4 >= 384 ? 2 : 1;
+    // -> the width with the smaller of: the launch's cells at the width's throughput (800 / 1100 / 1300 Gcell/s measured
+    // on batches of equal tasks), its longest chain at the width's row time alone on a SIMD (0.29 / 0.31 / 0.50 us)
+    int nr = 1;
+    {
+      const double rate[3] = {800e3, 1100e3, 1300e3}, row_us[3] = {0.29, 0.31, 0.50};  // cells per us; us per row
+      double best = 1e300;
+      for (int q = 0; q < 3; ++q) {
+        const double t_us = std::max(stripe_cells / rate[q], (double)stripe_rows * row_us[q]);
+        if (t_us < best) {
+          best = t_us;
+          nr = 1 << q;
+        }
+      }
+      if (force_nreg) nr = force_nreg;
+    }
     for (size_t k = 0; k < cnt; ++k) {
       PlanTask &p = cp[k];
       if (p.pad_ != 5) continue;
