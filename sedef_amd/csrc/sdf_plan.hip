@@ -824,9 +824,10 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   }
   c.nord = cursor;
   if (c.nord > c.order_cap) c.err = "internal: launch-order segment overflow";
-  if (dbg_pc && c.heavy) {
+  static const bool dbg_pc_all = getenv("SDF_DEBUG_PLAN") && getenv("SDF_DEBUG_PLAN")[0] == '2';
+  if (dbg_pc && (c.heavy || dbg_pc_all)) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    fprintf(stderr, "[plan_chunk heavy: tasks %.2f ms, pairing %.2f ms, classes %.2f ms, order %.2f ms]\n", ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()));
+    fprintf(stderr, "[plan_chunk %s %zu tasks: tasks %.2f ms, pairing %.2f ms, classes %.2f ms, order %.2f ms]\n", c.heavy ? "heavy" : "ordinary", c.cnt, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()));
   }
 }
 
