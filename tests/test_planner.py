@@ -123,3 +123,22 @@ def test_kernel_choice_by_request():
     assert rc == -3  # SDF_ERR_UNSUPPORTED: not a flag of this kernel
     rc, pt, _ = _plan(_tasks([300, 0], [300, 5]), mat=np.array([1] + [-100] * 24, np.int8), gapo=1, gape=1)
     assert rc == 0 and (pt[:, 0] == -1).all()  # degenerate scoring: the reference returns before any work
+
+
+def test_stripe_kernel_routing_and_widths():
+    """Full-band tasks from 400 target bases up and long banded tasks take the stripe kernels; the stripe width of a chunk
+    follows its work (one long task: 128 positions, thousands of tasks: 512), the banded kernel's the target length."""
+    rc, pt, _ = _plan(_tasks([6000], [6000]))
+    assert rc == 0 and pt[0, 1] == 301                        # one long chain: the narrowest stripes
+    rc, pt, _ = _plan(_tasks([1000] * 4000, [1000] * 4000))
+    assert rc == 0 and (pt[:, 1] == 304).all()                # many tasks: throughput decides
+    t = _tasks([7000, 7000, 3000, 20000, 33000, 1000, 2500, 12000], [7000, 7100, 3100, 20000, 33000, 1000, 2700, 11000],
+               w=[64, 128, 16, 200, 200, 128, 100, 300])
+    rc, pt, pc = _plan(t)
+    assert rc == 0
+    assert pt[3, 1] == 401                                    # windows of more than 192 slots, 4000+ anti-diagonals
+    assert pt[4, 1] == 402                                    # more than 254 stripes of 128 positions: 256
+    assert pt[0, 1] // 10 in (10, 11) and pt[1, 1] // 10 in (10, 11)  # windows of up to 192 slots that reach the corner: pair kernel
+    assert pt[2, 1] == 401 and pt[7, 1] == 401                # bands that run out: banded stripes whatever their width
+    assert pt[5, 1] // 10 in (10, 11) and pt[6, 1] == 401     # too short / just long enough (and its band runs out)
+    _check(t, pt, pc)
