@@ -18,8 +18,9 @@
 // one (x | v << 16 | tag, H) pair per row, stored sixteen at a time per 16-row block and fetched one block ahead, as
 // in extz2_stripe.hip.  H of every band cell is kept (:222-258), with the best cell per column; a finishing kernel
 // merges the stripes' bests in the reference's order and writes the result record.
-// Rows of a stripe: hi(r) >= T0 and lo(r) < T1, i.e. r in [max(T0, 2 T0 - w), min(T1 + qlen, 2 T1 + w) - 2] (cut at
-// the end of the matrix or where the band runs out).  Direction flags: bit blocks per stripe, block index relative to
+// Rows of a stripe: from sixteen columns before hi(r) >= T0 (the score refresh reaches that far ahead) to the last row
+// with lo(r) < T1, i.e. r in [max(T0 - 16, 2 (T0 - 16) - w), min(T1 + qlen, 2 T1 + w) - 2] (cut at the end of the matrix
+// or where the band runs out).  Direction flags: bit blocks per stripe, block index relative to
 // the stripe's first row block, slot = t - T0 (traceback layout 4).
 //
 // Compiled inside sdf_unity.hip after extz2_wave.hip and extz2_general.hip (helpers, BestCell).
@@ -41,13 +42,19 @@ __host__ __device__ inline BStripeGeom bstripe_geom(int qlen, int tlen, int w, i
   const int t16 = (tlen + 15) / 16 * 16;
   g.nst = (t16 + g.nslot - 1) / g.nslot;
   const int rows = 2 * g.nslot + 2 * w < g.nslot + qlen ? 2 * g.nslot + 2 * w : g.nslot + qlen;
-  g.blocks_cap = (rows + 15) / 16 + 2;
+  g.blocks_cap = (rows + 32 + 15) / 16 + 2;
   g.col_len = g.blocks_cap * 16 + 64;
   g.flag_bytes = (size_t)g.blocks_cap * nreg * 1024;
   return g;
 }
-// first / last anti-diagonal on which the stripe [T0, T1) has a computed cell (band not cut by its end)
-__host__ __device__ inline int bstripe_first_row(int T0, int w) { return T0 > 2 * T0 - w ? T0 : 2 * T0 - w; }
+// First / last anti-diagonal of the stripe [T0, T1) (band not cut by its end).  The last one is the last on which it
+// has a computed cell; the first one is sixteen columns early: the score refresh runs in 16-cell strides from the band
+// START (:124-138), so it reaches up to fifteen cells past the last computed block -- into the first columns of a
+// stripe that computes nothing yet, and a cell computed later as part of a widened block may still hold that score.
+__host__ __device__ inline int bstripe_first_row(int T0, int w) {
+  const int t = T0 >= 16 ? T0 - 16 : 0;
+  return t > 2 * t - w ? t : 2 * t - w;
+}
 __host__ __device__ inline int bstripe_last_row(int T1, int qlen, int tlen, int w) {
   int z = qlen + tlen - 2;
   if (z > T1 + qlen - 2) z = T1 + qlen - 2;
@@ -244,7 +251,11 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     {
       Band b_first, b_last;
       const bool ok_first = band_of(rb, qlen, tlen, w, b_first), ok_last = band_of(re - 1, qlen, tlen, w, b_last);
+#ifdef SDF_BS_NO_FULL
+      if (false) {
+#else
       if (has_left && re > rb && ok_first && ok_last && b_last.lo0 < T0 && b_first.hi0 >= T1 && rb >= next_a - 1) {
+#endif
         const bool full_h = can_drop || b_first.hi0 <= T1 + 1;  // (see can_drop)
 #pragma unroll 1
         for (; r < re; ++r) {
@@ -450,8 +461,14 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         const int rl = re - 1;
         const bool pure = has_left && r >= w && ((r + w) >> 1 | 15) < r && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
                           ((rl + w) >> 1) < tlen - 1 && ((r - w) >> 1) >= 0 && ((rl - w) >> 1) >= rl - qlen;
+#ifdef SDF_BS_NO_LEAN
+        (void)pure;
+#elif defined(SDF_BS_NO_PURE)
+        lean_rows(std::false_type{});
+#else
         if (pure) lean_rows(std::true_type{});
         else lean_rows(std::false_type{});
+#endif
       }
       if (r >= re) break;
       Band bd, bp;

@@ -662,6 +662,29 @@ def test_stripe_kernels_every_width_fuzz(oracle, nreg):
     assert _check_dropped_max(eng, oracle, pairs, ws) >= 20
 
 
+def test_banded_stripe_kernel_score_refresh_reaches_the_next_stripe(oracle):
+    """The reference refreshes scores in 16-cell strides from the band START, up to fifteen cells past its last computed
+    block -- into the first columns of the next target stripe before that stripe computes anything; a cell computed later
+    as part of a widened block still holds that score.  Found by fuzzing (279 x 460, w = 200: score -373 instead of -377):
+    the committed pair, its prefixes (the alignment of the band start with the 16-cell blocks decides) and random pairs of
+    that geometry."""
+    import os
+    eng = _engine_with_env(SDF_BSTRIPE_MIN_ROWS=200, SDF_BSTRIPE_ALL=1)
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "bstripe_refresh_spill.npz"))
+    q, t, w = d["q"], d["t"], int(d["w"])
+    pairs = [(q[:n], t) for n in range(255, 280)] + [(q, t[:n]) for n in range(441, 461)]
+    ws = [w] * len(pairs)
+    rng = np.random.default_rng(9922)
+    for _ in range(300):
+        ww = int(rng.choice([100, 150, 176, 200, 232, 300]))
+        ql = int(rng.integers(130, 700))
+        tl = ql + ww - int(rng.integers(0, 40))
+        qq = random_codes(rng, ql)
+        pairs.append((qq, _fit(rng, mutate(rng, qq, 0.05, 0.01, 0.01), tl)))
+        ws.append(ww)
+    _check_fast(eng, oracle, pairs, ws)
+
+
 def test_banded_stripe_kernel_long_tasks(engine, oracle):
     """Long banded tasks as the default context routes them (4000+ anti-diagonals, windows of more than 192 slots, or
     bands that run out): 128-position stripes up to 32 kb targets, one row block apart; bands that reach the corner, run
