@@ -662,6 +662,24 @@ def test_stripe_kernels_every_width_fuzz(oracle, nreg):
     assert _check_dropped_max(eng, oracle, pairs, ws) >= 20
 
 
+def test_stripe_kernels_other_scorings(oracle):
+    """Both stripe kernels under other match / mismatch / gap scores (the CLI's --match ... overrides, src/align_main.cc:
+    343-352): saturation of the difference bytes, gap-open 0, scores the reference clamps."""
+    eng = _engine_with_env(SDF_STRIPE_MIN=130, SDF_BSTRIPE_MIN_ROWS=150, SDF_BSTRIPE_ALL=1)
+    rng = np.random.default_rng(9933)
+    for _ in range(36):
+        ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
+        go, ge = int(rng.integers(0, 70)), int(rng.integers(0, 6))
+        pairs, ws = [], []
+        for _ in range(10):
+            ql = int(rng.integers(80, 900))
+            tl = max(1, ql + int(rng.integers(-150, 150)))
+            q = random_codes(rng, ql, 0.003 if rng.random() < 0.3 else 0.0)
+            pairs.append((q, _fit(rng, mutate(rng, q, 0.06, 0.015, 0.015), tl)))
+            ws.append(int(rng.choice([-1, -1, 3, 16, 40, 100, 200])))
+        _check_fast(eng, oracle, pairs, ws, mat=sedef_mat(ma, mi), gapo=go, gape=ge)
+
+
 def test_banded_stripe_kernel_score_refresh_reaches_the_next_stripe(oracle):
     """The reference refreshes scores in 16-cell strides from the band START, up to fifteen cells past its last computed
     block -- into the first columns of the next target stripe before that stripe computes anything; a cell computed later
