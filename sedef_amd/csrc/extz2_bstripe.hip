@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     }
 #pragma unroll 1
     for (; r < re; ++r) {
-      // ---- ordinary rows, as long as they last: no border cell (hi < r), the end of the target not reached, the
+      // ---- ordinary rows, as long as they last: no border cell (hi < r), the
       // first computed cell not in this stripe or its window not moved (then its left neighbour reads as 0): nothing
       // but lane predicates against the row's band, no branch ----
       // (PURE: on every row of the block the band is [(r - w + 1) >> 1, (r + w) >> 1], clear of the matrix borders)
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         const bool moved_here = lo != prev_lo && lo >= T0 && lo < T1;
         if (PURE) {
           if (moved_here) break;
-        } else if (lo0 > hi0 || r == 0 || hi >= r || hi0 == tlen - 1 || moved_here || (lo == 0 && T0 == 0)) {
+        } else if (lo0 > hi0 || r == 0 || hi >= r || moved_here || (lo == 0 && T0 == 0)) {
           break;
         }
         unsigned qc[NREG];
@@ -445,6 +445,21 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
             bRe[k] = gE ? r : bRe[k];
             bHo[k] = gO ? nO : bHo[k];
             bRo[k] = gO ? r : bRo[k];
+          }
+        }
+        if (!PURE && hi0 == tlen - 1 && hi0 >= T0 && hi0 < T1) {  // the end of the target: mte, score (:259-262)
+          const int st = hi0 - T0;
+          int32_t hv = 0;
+#pragma unroll
+          for (int k = 0; k < NREG; ++k)
+            if ((st >> 7) == k) hv = (st & 1) ? __builtin_amdgcn_readlane(Ho[k], (st & 127) >> 1) : __builtin_amdgcn_readlane(He[k], (st & 127) >> 1);
+          if (hv > ez_mte) {
+            ez_mte = hv;
+            ez_mte_q = r - hi;
+          }
+          if (r == nrow - 1) {
+            ez_score = hv;
+            have_score = true;
           }
         }
         if (has_right && r >= next_a - 1) {
