@@ -352,12 +352,12 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       const char *e = getenv("SDF_PLAN_THREADS");
       return e ? std::max(0, std::min(15, atoi(e))) : 7;
     }();
-    // (parked threads plan the chunks of batches of 100,000 tasks and more -- 250,000 tasks of the hg19 mixture:
+    // (parked threads plan the chunks of batches of 120,000 tasks and more -- 250,000 tasks of the hg19 mixture:
     // 14.5 -> 10.1 ms, the headline batch unchanged -- and from 400,000 tasks the scan of the cut as well: there, below,
     // waking them cost more than they saved)
     static const size_t pool_from = [] {
       const char *e = getenv("SDF_PLAN_POOL_FROM");
-      return e ? (size_t)atoll(e) : (size_t)100000;
+      return e ? (size_t)atoll(e) : (size_t)120000;
     }();
     if (!ctx->pool && n >= pool_from && max_planners > 0) ctx->pool = new WorkerPool(max_planners);
     if (int rc = cut_batch(env, ctx->pipeline, ctx->ws_budget, cut, &msg, ctx->pool)) {
