@@ -84,7 +84,8 @@ template <int NREG>
 __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__restrict__ plan,
                                                               const int32_t *__restrict__ order,
                                                               const uint32_t *__restrict__ pool, ScoreK sc,
-                                                              uint8_t *__restrict__ dirbase) {
+                                                              uint8_t *__restrict__ dirbase,
+                                                              unsigned long long *__restrict__ gave_up) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;
   constexpr int KT = NREG - 1;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           else __builtin_amdgcn_s_sleep(2);
           feed_load(r0, gx, gh);
         } while (__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u)) && ++spins < (1 << 24));
+        if (spins >= (1 << 24) && lane == 0) atomicAdd(gave_up, 1ull);  // (the batch call reports it as an error)
         if (very_long) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(2);
       }
@@ -730,9 +732,12 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   }
 }
 
-template __global__ void extz2_bstripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
-template __global__ void extz2_bstripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
-template __global__ void extz2_bstripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
+template __global__ void extz2_bstripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                                 unsigned long long *);
+template __global__ void extz2_bstripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                                 unsigned long long *);
+template __global__ void extz2_bstripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                                 unsigned long long *);
 
 // Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's record and the edge column of its
 // right boundary to zero (no word tagged as written)

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
                                                              const int32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ pool, ScoreK sc,
                                                              uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res,
-                                                             const int rmax) {
+                                                             const int rmax, unsigned long long *__restrict__ gave_up) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;  // stripe width
   constexpr int KT = NREG - 1;
@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     // (readfirstlane: the compiler cannot see that a volatile load of one address is wave-uniform, and a divergent
     // loop here would make every value that lives across it -- the row counters -- a vector value)
     while (__builtin_amdgcn_readfirstlane(ld_agent(prog + sb - 1)) < T0 - 1 && ++spins < SDF_STRIPE_SPIN_CAP) __builtin_amdgcn_s_sleep(8);
+    if (spins >= SDF_STRIPE_SPIN_CAP && lane == 0) atomicAdd(gave_up, 1ull);  // (the batch call reports it as an error)
     h_head = __builtin_amdgcn_readfirstlane(ld_agent(hand_val + sb - 1));
   }
 #ifdef SDF_STRIPE_TIMING
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
         __builtin_amdgcn_s_sleep(2);
         got = feed_load(r0);
       }
+      if (spins >= SDF_STRIPE_SPIN_CAP && lane == 0) atomicAdd(gave_up, 1ull);
 #ifdef SDF_STRIPE_TIMING
       if (spins) tm_wait += __builtin_amdgcn_s_memrealtime() - tw0;
 #endif
@@ -414,11 +416,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
 }
 
 template __global__ void extz2_stripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int);
+                                                sdf_result *, int, unsigned long long *);
 template __global__ void extz2_stripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int);
+                                                sdf_result *, int, unsigned long long *);
 template __global__ void extz2_stripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int);
+                                                sdf_result *, int, unsigned long long *);
 
 // Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's progress and hand-over words to
 // "nothing done" and the edge column of its right boundary to zero (no word tagged as written)

@@ -392,6 +392,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   run.cev.assign(cut.chunks.size(), ChunkEv{});
   const float dbg_b = host_ms();
 
+  SDF_HIP(hipMemsetAsync((unsigned long long *)ctx->misc_buf.p + 1, 0, sizeof(unsigned long long), st));
   run.ev_begin = next_event(ctx, run.evc);
   hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n);
   SDF_HIP(hipEventRecord(run.ev_begin, st));

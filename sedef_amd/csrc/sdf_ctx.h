@@ -35,10 +35,10 @@ size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 bool pair_fits_whole(int qlen, int tlen, int nreg);
 template <int NREG>
 __global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                    sdf_result *, int);
+                                    sdf_result *, int, unsigned long long *);
 __global__ void stripe_sync_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 template <int NREG>
-__global__ void extz2_bstripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *);
+__global__ void extz2_bstripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, unsigned long long *);
 __global__ void bstripe_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 __global__ void bstripe_finish_kernel(const PlanTask *, const int32_t *, int, int, const uint8_t *, sdf_result *);
 template <int LAYOUT, int G>

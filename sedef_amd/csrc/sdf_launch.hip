@@ -62,7 +62,7 @@ static void drain_streams(sdf_ctx *ctx, hipStream_t st) {
 
 // One DP launch of a planned class.  slabs: HBM state of the very long tasks (HBM-state classes only).
 static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, const int32_t *lo, const uint32_t *d_pool,
-                      const ScoreK &sk, uint8_t *dir_reg, sdf_result *d_out, uint8_t *slabs) {
+                      const ScoreK &sk, uint8_t *dir_reg, sdf_result *d_out, uint8_t *slabs, unsigned long long *gave_up) {
   const dim3 one((unsigned)L.cnt), half((unsigned)(L.cnt / 2));
 #define SDF_WAVE(N, S) \
   hipLaunchKernelGGL((extz2_wave_kernel<N, S>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
@@ -73,12 +73,12 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
 #define SDF_STRIPE(N) /* one workgroup of one wavefront per stripe; progress words and edge columns reset first */ \
   {                                                                                                              \
     hipLaunchKernelGGL(stripe_sync_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                      \
-    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax); \
+    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax, gave_up); \
   }
 #define SDF_BSTRIPE(N) /* banded stripes: records and edge columns reset first, the records merged afterwards */    \
   {                                                                                                               \
     hipLaunchKernelGGL(bstripe_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                           \
-    hipLaunchKernelGGL((extz2_bstripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg);        \
+    hipLaunchKernelGGL((extz2_bstripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, gave_up); \
     hipLaunchKernelGGL(bstripe_finish_kernel, dim3((unsigned)((L.cnt + 63) / 64)), dim3(64), 0, sdp, lp, lo,     \
                        (int)L.cnt, N, dir_reg, d_out);                                                            \
   }
@@ -244,7 +244,8 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       slabs = (uint8_t *)ctx->gstate_buf.p + gs_off;
       gs_off += L.lds * L.cnt;
     }
-    launch_dp(L, sdp, run.d_plan + pb, run.d_order + ob + L.off, run.d_pool, run.sk, dir_reg, run.d_out, slabs);
+    launch_dp(L, sdp, run.d_plan + pb, run.d_order + ob + L.off, run.d_pool, run.sk, dir_reg, run.d_out, slabs,
+              (unsigned long long *)ctx->misc_buf.p + 1);
     ++ctx->launches;
   }
   for (int q = 0; q < 8; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
@@ -306,7 +307,7 @@ static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_c
   unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
   hipEvent_t ev_c0 = next_event(ctx, run.evc), ev_c1 = next_event(ctx, run.evc), ev_end = next_event(ctx, run.evc);
   SDF_HIP(hipEventRecord(ev_c0, st));
-  unsigned long long total = 0;
+  unsigned long long total = 0, gave_up = 0;  // (misc word 1: stripe wavefronts that gave up waiting for a neighbour)
   const size_t np = run.cut->ntask_total;
   if (run.want_cigar) {
     {
@@ -330,8 +331,13 @@ static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_c
   }
   SDF_HIP(hipEventRecord(ev_c1, st));
   SDF_HIP(hipEventRecord(ev_end, st));
+  SDF_HIP(hipMemcpyAsync(&gave_up, d_total + 1, sizeof(gave_up), hipMemcpyDeviceToHost, st));
   SDF_HIP(hipStreamSynchronize(st));
   SDF_HIP(hipGetLastError());
+  if (gave_up) {
+    ctx->err = "internal: a stripe wavefront gave up waiting for its neighbour";
+    return SDF_ERR_INVALID;
+  }
   // DP / traceback time = length of the union of the chunks' intervals (chunks overlap when pipelined);
   // ms[6] = sum of the chunks' DP intervals (what a kernel trace adds up)
   auto span = [&](bool tb, float &sum) {
