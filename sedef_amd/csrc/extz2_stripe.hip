@@ -62,7 +62,7 @@ __device__ __forceinline__ void st_agent(T *p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#define SDF_STRIPE_SPIN_CAP (1 << 24)  // polls before a wait gives up (a wrong result instead of a hung queue)
+#define SDF_STRIPE_SPIN_CAP (1 << 24)  // polls before a wait gives up (an error from the batch call instead of a hung queue)
 
 template <int NREG>
 __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__restrict__ plan,
