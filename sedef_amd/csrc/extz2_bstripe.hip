@@ -269,8 +269,6 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
 #pragma unroll
           for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
           const uint32_t fxv = (uint32_t)__builtin_amdgcn_readlane((int)feed_xv, r - r0);
-          const int32_t fh = __builtin_amdgcn_readlane((int)feed_h, r - r0);
-          (void)fh;
           unsigned xt1[NREG], vt1[NREG];
 #pragma unroll
           for (int k = 0; k < NREG; ++k) {
