@@ -328,9 +328,8 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     }
 #pragma unroll 1
     for (; r < re; ++r) {
-      // ---- ordinary rows, as long as they last: no border cell (hi < r), the
-      // first computed cell not in this stripe or its window not moved (then its left neighbour reads as 0): nothing
-      // but lane predicates against the row's band, no branch ----
+      // ---- ordinary rows, as long as they last (no border cell: hi < r): lane predicates against the row's band; the
+      // row on which the first computed cell's window moves (one in 32) takes the one branch ----
       // (PURE: on every row of the block the band is [(r - w + 1) >> 1, (r + w) >> 1], clear of the matrix borders)
       auto lean_rows = [&](auto pure_c) {
       constexpr bool PURE = decltype(pure_c)::value;
@@ -349,11 +348,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         }
         const int lo = lo0 & ~15, hi = hi0 | 15, prev_lo = plo & ~15;
         const bool moved_here = lo != prev_lo && lo >= T0 && lo < T1;
-        if (PURE) {
-          if (moved_here) break;
-        } else if (lo0 > hi0 || r == 0 || hi >= r || moved_here || (lo == 0 && T0 == 0)) {
-          break;
-        }
+        if (!PURE && (lo0 > hi0 || r == 0 || hi >= r || (lo == 0 && T0 == 0))) break;
         unsigned qc[NREG];
 #pragma unroll
         for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
@@ -387,8 +382,24 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
           vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
         }
-        // the first computed cell, its window not moved: its left neighbour reads as 0 (lo: an even column)
-        const int lo_fix = lo > 0 ? lo : -2;
+        // the first computed cell (lo: an even column), its window not moved: its left neighbour reads as 0
+        const int lo_fix = lo > 0 && !moved_here ? lo : -2;
+        if (moved_here) {  // moved (one row in 32): the slot to the left as it is, and a negative byte there also sets
+                           // the next three cells (the reference's sign extension, :145-146)
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) {
+            const int tb = T0 + 128 * k;
+            if (lo < tb || lo > tb + 127) continue;
+            const int ll = (lo - tb) >> 1;
+            const unsigned cx = (unsigned)__builtin_amdgcn_readlane((int)xt1[k], ll) & 0xffffu;
+            const unsigned cv = (unsigned)__builtin_amdgcn_readlane((int)vt1[k], ll) & 0xffffu;
+            const unsigned sx = (cx & 0x8000u) ? 0xff00u : 0u, sv = (cv & 0x8000u) ? 0xff00u : 0u;
+            const unsigned mx = lane == ll ? sx << 16 : lane == ll + 1 ? sx * 0x00010001u : 0u;
+            const unsigned mv = lane == ll ? sv << 16 : lane == ll + 1 ? sv * 0x00010001u : 0u;
+            xt1[k] |= mx;
+            vt1[k] |= mv;
+          }
+        }
         const int ra = lo0 - T0, rbe = ra + ((hi0 - lo0) & ~15) + 16;
 #pragma unroll
         for (int k = 0; k < NREG; ++k) {
