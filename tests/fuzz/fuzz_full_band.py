@@ -1,7 +1,7 @@
 """GPU fuzz campaign against the oracle (not collected by pytest: run by hand on a GPU box, e.g.
     SEED=1 ROUNDS=60 SDF_BSTRIPE_MIN_ROWS=100 SDF_BSTRIPE_ALL=1 [SDF_BSTRIPE_NREG=2] python tests/fuzz/fuzz_full_band.py
 Every task's score, mte, mte_q, zdropped, CIGAR (and the best cell of a band that runs out) must equal the oracle's; the
-first ten mismatching shapes are printed.  Round 2 ran about 300,000 tasks through these three scripts with the stripe
+first ten mismatching shapes are printed.  Round 2 ran about 800,000 tasks through these three scripts with the stripe
 kernels forced to every width; one parity bug came out of it (tests/golden/bstripe_refresh_spill.npz)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
