@@ -201,8 +201,15 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   //   trk:  the last stripe after its head: H of the last column (register KHI).
   // The flags are constant over the call (the caller cuts the block at r = tlen and r = NSLOT - 1).
   // ------------------------------------------------------------------------------------------
-  auto rows = [&](auto klo_c, auto khi_c, const bool head, const bool exp, const bool trk, const int rb, const int re) {
-    constexpr int KLO = decltype(klo_c)::value, KHI = decltype(khi_c)::value;
+  // (FLAGS: the three flags as constants -- head | exp << 1 | trk << 2 -- for the narrower stripe widths, whose rows
+  // are short enough for the flag branches to show; -1: read at run time, as the 512-position width does to keep its
+  // ten register ranges from growing into sixty row loops)
+  auto rows = [&](auto klo_c, auto khi_c, auto flags_c, const bool head_rt, const bool exp_rt, const bool trk_rt, const int rb,
+                  const int re) {
+    constexpr int KLO = decltype(klo_c)::value, KHI = decltype(khi_c)::value, FLAGS = decltype(flags_c)::value;
+    const bool head = FLAGS < 0 ? head_rt : (FLAGS & 1) != 0;
+    const bool exp = FLAGS < 0 ? exp_rt : (FLAGS & 2) != 0;
+    const bool trk = FLAGS < 0 ? trk_rt : (FLAGS & 4) != 0;
     qaddr = (unsigned)(2 * (qlen - 1 - rb + NSLOT + 2 * lane));
 #pragma unroll
     for (int k = KLO; k <= KHI; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
@@ -288,10 +295,24 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   };
   auto run_rows = [&](const int klo, const int khi, const bool head, const bool exp, const bool trk, const int rb,
                       const int re) {
+#define SDF_ROWS_F(A, B, F) \
+  rows(std::integral_constant<int, (A)>{}, std::integral_constant<int, (B)>{}, std::integral_constant<int, (F)>{}, head, exp, trk, rb, re)
 #define SDF_ROWS(A, B)                                                                                               \
   case (A) * 4 + (B):                                                                                                 \
-    if constexpr ((B) < NREG && (A) <= (B))                                                                           \
-      rows(std::integral_constant<int, (A)>{}, std::integral_constant<int, (B)>{}, head, exp, trk, rb, re);           \
+    if constexpr ((B) < NREG && (A) <= (B)) {                                                                         \
+      if constexpr (NREG >= 4) {                                                                                      \
+        SDF_ROWS_F(A, B, -1);                                                                                         \
+      } else {                                                                                                        \
+        switch ((head ? 1 : 0) | (exp ? 2 : 0) | (trk ? 4 : 0)) { /* (exp and trk exclude each other) */             \
+          case 0: SDF_ROWS_F(A, B, 0); break;                                                                         \
+          case 1: SDF_ROWS_F(A, B, 1); break;                                                                         \
+          case 2: SDF_ROWS_F(A, B, 2); break;                                                                         \
+          case 3: SDF_ROWS_F(A, B, 3); break;                                                                         \
+          case 4: SDF_ROWS_F(A, B, 4); break;                                                                         \
+          default: SDF_ROWS_F(A, B, -1); break;                                                                       \
+        }                                                                                                             \
+      }                                                                                                               \
+    }                                                                                                                 \
     break;
     switch (klo * 4 + khi) {
       SDF_ROWS(0, 0) SDF_ROWS(0, 1) SDF_ROWS(0, 2) SDF_ROWS(0, 3) SDF_ROWS(1, 1) SDF_ROWS(1, 2) SDF_ROWS(1, 3)
@@ -299,6 +320,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
       default: break;
     }
 #undef SDF_ROWS
+#undef SDF_ROWS_F
   };
 
   for (int r0 = 0; r0 < nrow; r0 += 16) {

@@ -531,10 +531,10 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       return e ? atoi(e) : 0;
     }();
     // -> the width with the smaller of: the launch's cells at the width's throughput (800 / 1100 / 1300 Gcell/s measured
-    // on batches of equal tasks), its longest chain at the width's row time alone on a SIMD (0.29 / 0.31 / 0.50 us)
+    // on batches of equal tasks), its longest chain at the width's row time alone on a SIMD (0.24 / 0.27 / 0.50 us)
     int nr = 1;
     {
-      const double rate[3] = {800e3, 1100e3, 1300e3}, row_us[3] = {0.29, 0.31, 0.50};  // cells per us; us per row
+      const double rate[3] = {800e3, 1100e3, 1300e3}, row_us[3] = {0.24, 0.27, 0.50};  // cells per us; us per row
       double best = 1e300;
       for (int q = 0; q < 3; ++q) {
         const double t_us = std::max(stripe_cells / rate[q], (double)stripe_rows * row_us[q]);
