@@ -202,8 +202,8 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   // The flags are constant over the call (the caller cuts the block at r = tlen and r = NSLOT - 1).
   // ------------------------------------------------------------------------------------------
   // (FLAGS: the three flags as constants -- head | exp << 1 | trk << 2 -- for the narrower stripe widths, whose rows
-  // are short enough for the flag branches to show; -1: read at run time, as the 512-position width does to keep its
-  // ten register ranges from growing into sixty row loops)
+  // are short enough for the flag branches to show; -1: read at run time, as the 512-position width does for all but its
+  // all-register rows, to keep its ten register ranges from growing into sixty row loops)
   auto rows = [&](auto klo_c, auto khi_c, auto flags_c, const bool head_rt, const bool exp_rt, const bool trk_rt, const int rb,
                   const int re) {
     constexpr int KLO = decltype(klo_c)::value, KHI = decltype(khi_c)::value, FLAGS = decltype(flags_c)::value;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
 #define SDF_ROWS(A, B)                                                                                               \
   case (A) * 4 + (B):                                                                                                 \
     if constexpr ((B) < NREG && (A) <= (B)) {                                                                         \
-      if constexpr (NREG >= 4) {                                                                                      \
+      if constexpr (NREG >= 4 && !((A) == 0 && (B) == NREG - 1)) { /* (512 positions: the all-register rows only) */ \
         SDF_ROWS_F(A, B, -1);                                                                                         \
       } else {                                                                                                        \
         switch ((head ? 1 : 0) | (exp ? 2 : 0) | (trk ? 4 : 0)) { /* (exp and trk exclude each other) */             \
