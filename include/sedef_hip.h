@@ -196,6 +196,37 @@ int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, cons
 int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const int64_t *off, size_t n, int max_chain_gap,
                     int match_chain_score, int32_t *path, int32_t *bounds, int32_t *nbound);
 
+/* ---- per-alignment columns of `stats generate` on the GPU (scope row f4) -------------------------
+ * Replaces the column walk of process() (reference: src/stats_main.cc:228-270) and the AlignmentError counters of
+ * populate_nice_alignment (src/align.cc:300-314) for a batch of finished alignments.  An alignment is the two
+ * sequences as FASTA characters (case = soft-masking) and its CIGAR as runs `len << 4 | op` with op 0 = 'M',
+ * 1 = 'D' (consumes a only), 2 = 'I' (consumes b only) -- the reference's letters (src/align.cc:59-63), numerically
+ * the words sdf_extz2_batch returns.  Nothing is expanded into column strings.  Sequences up to 16 Mb
+ * (SDF_ERR_UNSUPPORTED beyond); a CIGAR that consumes more than its sequences, where the reference would read past
+ * its strings, sets `flags` to 1 and makes the host-buffer call return SDF_ERR_INVALID. */
+typedef struct {
+  uint64_t a_off, b_off;   /* byte offsets of the two sequences in seq_pool */
+  uint32_t a_len, b_len;
+  uint64_t cigar_off;      /* first run of the alignment in cigar_pool (in words) */
+  uint32_t n_cigar, reserved;
+} sdf_stats_task;
+
+typedef struct {
+  /* src/stats_main.cc:231-270, in the order of the output columns 15-21 and 27-29 */
+  int32_t indel_a, indel_b, aln_b, match_b, mismatch_b, transitions_b, transversions_b;
+  int32_t uppercase_a, uppercase_b, uppercase_matches;
+  /* Alignment::matches() / mismatches() / gaps() / gap_bases() / span() (src/align.h:79-83) */
+  int32_t matches, mismatches, gaps, gap_bases, span;
+  int32_t flags;           /* 1: the CIGAR does not fit the sequences (counters undefined) */
+} sdf_stats_cols;
+
+int sdf_stats_columns_batch(sdf_ctx *ctx, const sdf_stats_task *tasks, size_t n, const char *seq_pool, size_t pool_bytes,
+                            const uint32_t *cigar_pool, size_t cigar_words, sdf_stats_cols *out);
+/* The same with tasks, pools and results resident in HBM; asynchronous on `stream` (a hipStream_t; NULL = the
+ * context's own stream, synchronised before returning).  Offsets are not checked against the pools here. */
+int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_tasks, size_t n, const char *d_seq_pool,
+                             const uint32_t *d_cigar_pool, sdf_stats_cols *d_out, void *stream);
+
 /* ---- one-task drop-in: same contract as ksw_extz2_sse (extern/ksw2.h:50).  `km` is ignored
  * like in the reference build (no HAVE_KALLOC).  Uses a process-wide context on device 0 (or
  * the device named by SDF_DEVICE).  On a fatal error prints to stderr and exits with 120, the

@@ -48,8 +48,8 @@ def _u8(a):
 
 def build_oracle(force=False):
     so = os.path.join(_HERE, "liboracle_extz2.so")
-    src = os.path.join(_HERE, "extz2_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("extz2_oracle.c", "stats_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle_extz2.so"],
                               stdout=subprocess.DEVNULL)
     return so
@@ -91,6 +91,23 @@ class Oracle:
         L.sdfo_cigar_counts.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+
+    def stats_columns(self, a, b, cigar, want_columns=False):
+        """stats_oracle.c: a, b FASTA characters (str / bytes), cigar uint32 runs len << 4 | op (0 M, 1 D, 2 I).
+        Returns the 16 counters (dict order of STATS_FIELDS) [, align_a, align_b]."""
+        a = a.encode() if isinstance(a, str) else bytes(a)
+        b = b.encode() if isinstance(b, str) else bytes(b)
+        cg = np.ascontiguousarray(cigar, dtype=np.uint32)
+        out = np.zeros(16, np.int32)
+        ca = C.create_string_buffer(len(a) + len(b) + 1) if want_columns else None
+        cb = C.create_string_buffer(len(a) + len(b) + 1) if want_columns else None
+        self.lib.sdfo_stats_columns.restype = C.c_int
+        self.lib.sdfo_stats_columns.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_char_p, C.c_char_p]
+        self.lib.sdfo_stats_columns(a, len(a), b, len(b), cg.ctypes.data, len(cg), out.ctypes.data, ca, cb)
+        if want_columns:
+            return out, ca.value.decode("latin1"), cb.value.decode("latin1")
+        return out
 
     def extz2(self, query, target, mat=None, m=5, gapo=40, gape=1, w=-1, zdrop=-1, flag=0):
         mat = sedef_mat() if mat is None else np.ascontiguousarray(mat, dtype=np.int8)
@@ -191,6 +208,11 @@ class Reference:
         return d
 
 
+STATS_FIELDS = ("indel_a", "indel_b", "aln_b", "match_b", "mismatch_b", "transitions_b", "transversions_b",
+                "uppercase_a", "uppercase_b", "uppercase_matches", "matches", "mismatches", "gaps", "gap_bases", "span",
+                "flags")
+
+
 def cigar_to_str(cigar):
     return "".join("%d%s" % (c >> 4, "MID"[c & 0xf]) for c in np.asarray(cigar).tolist())
 
@@ -226,9 +248,11 @@ def mutate(rng, s, sub=0.06, dele=0.02, ins=0.02):
 # ---- reference Alignment / Hit classes (oracle/_ref/libref_align.so; built by `make -C oracle refalign`) ----
 def build_reference_align():
     so = os.path.join(_HERE, "_ref", "libref_align.so")
-    if os.path.exists(so):
+    have_ref = os.path.exists("/root/reference/src/align.cc")
+    drv = os.path.join(_HERE, "ref_align_driver.cc")
+    if os.path.exists(so) and not (have_ref and os.path.getmtime(so) < os.path.getmtime(drv)):
         return so
-    if os.path.exists("/root/reference/src/align.cc"):
+    if have_ref:
         subprocess.check_call(["make", "-C", _HERE, "refalign"], stdout=subprocess.DEVNULL)
         return so
     return None
@@ -256,6 +280,14 @@ class ReferenceAlign:
         rc = self.lib.ref_alignment_pair(fa.encode(), fb.encode(), self.buf, len(self.buf), cnt)
         assert rc == 0
         return self.buf.value.decode(), list(cnt)
+
+    def alignment_from_cigar(self, fa, fb, cigar):
+        """Reference Alignment(fa, fb, cigar string): (align_a, align_b, [matches, mismatches, gaps, gap_bases, span])."""
+        cnt = (C.c_int * 5)()
+        rc = self.lib.ref_alignment_from_cigar(fa.encode(), fb.encode(), cigar.encode(), self.buf, len(self.buf), cnt)
+        assert rc == 0
+        aa, _, ab = self.buf.value.decode().split("\n")[:3]
+        return aa, ab, list(cnt)
 
     def guide_from_chains(self, q, r, spec, side):
         rc = self.lib.ref_guide_from_chains(q.encode(), r.encode(), spec.encode(), side, self.buf, len(self.buf))

@@ -153,6 +153,19 @@ int ref_sequence(const char *name, const char *seq, char *out, size_t cap) {
   return emit(s.name + "|" + s.seq + "|" + (s.is_rc ? "1" : "0"), out, cap);
 }
 
+// Alignment(fa, fb, cigar) (src/align.cc:90-106): the column strings populate_nice_alignment expands and its
+// AlignmentError counters -- what `stats generate` walks (src/stats_main.cc:222-270).  The strings are private; the
+// reference's own Alignment::print(-1, true) returns them (src/align.cc:658-661).  out: "align_a\nalignment\nalign_b\n\n".
+int ref_alignment_from_cigar(const char *fa, const char *fb, const char *cigar, char *out, size_t cap, int *counts) {
+  Alignment al{string(fa), string(fb), string(cigar)};
+  counts[0] = al.matches();
+  counts[1] = al.mismatches();
+  counts[2] = al.gaps();
+  counts[3] = al.gap_bases();
+  counts[4] = al.span();
+  return emit(al.span() ? al.print(-1, true) : string("\n\n\n\n"), out, cap);
+}
+
 // CLI scoring overrides (src/align_main.cc:343-352 assign these statics; src/align.cc:84-86,343-456 read them)
 int ref_set_scoring(int match, int mismatch, int gap_open, int gap_extend) {
   Globals::Align::MATCH = match;

@@ -134,7 +134,8 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
   for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
                     &ctx->an_pos, &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff, &ctx->ch_an, &ctx->ch_off,
-                    &ctx->ch_wsoff, &ctx->ch_work, &ctx->ch_path, &ctx->ch_bounds, &ctx->ch_nb})
+                    &ctx->ch_wsoff, &ctx->ch_work, &ctx->ch_path, &ctx->ch_bounds, &ctx->ch_nb, &ctx->st_tasks, &ctx->st_pool,
+                    &ctx->st_cig, &ctx->st_out})
     b->release();
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
                     &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
@@ -738,6 +739,69 @@ extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const in
   SDF_HIP(hipMemcpyAsync(bounds, ctx->ch_bounds.p, (total + n) * 8, hipMemcpyDeviceToHost, st));
   SDF_HIP(hipMemcpyAsync(nbound, ctx->ch_nb.p, n * 4, hipMemcpyDeviceToHost, st));
   SDF_HIP(hipStreamSynchronize(st));
+  return SDF_OK;
+}
+
+// ---- per-alignment columns of `stats generate` (reference: src/stats_main.cc:228-270) -------------------
+extern "C" int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_tasks, size_t n, const char *d_seq_pool,
+                                        const uint32_t *d_cigar_pool, sdf_stats_cols *d_out, void *stream) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  if (n >= ((size_t)1 << 31) || (n && (!d_tasks || !d_out))) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  if (n == 0) return SDF_OK;
+  SDF_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  hipLaunchKernelGGL(sdf::stats_columns_kernel, dim3((unsigned)((n + sdf::STATS_WAVES - 1) / sdf::STATS_WAVES)),
+                     dim3(64 * sdf::STATS_WAVES), 0, st, d_tasks, (int)n, d_seq_pool, d_cigar_pool, d_out);
+  SDF_HIP(hipGetLastError());
+  if (!stream) SDF_HIP(hipStreamSynchronize(st));
+  return SDF_OK;
+}
+
+extern "C" int sdf_stats_columns_batch(sdf_ctx *ctx, const sdf_stats_task *tasks, size_t n, const char *seq_pool,
+                                       size_t pool_bytes, const uint32_t *cigar_pool, size_t cigar_words,
+                                       sdf_stats_cols *out) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  if (n >= ((size_t)1 << 31) || (n && (!tasks || !out)) || (!seq_pool && pool_bytes) || (!cigar_pool && cigar_words)) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  for (size_t i = 0; i < n; i++) {
+    const sdf_stats_task &t = tasks[i];
+    if (t.a_len > (1u << 24) || t.b_len > (1u << 24)) {
+      ctx->err = "stats columns implement sequences up to 16 Mb";
+      return SDF_ERR_UNSUPPORTED;
+    }
+    if (t.a_off > pool_bytes || t.a_len > pool_bytes - t.a_off || t.b_off > pool_bytes || t.b_len > pool_bytes - t.b_off ||
+        t.cigar_off > cigar_words || t.n_cigar > cigar_words - t.cigar_off || t.n_cigar >= (1u << 31)) {
+      ctx->err = "alignment " + std::to_string(i) + ": sequence or CIGAR range outside its pool";
+      return SDF_ERR_INVALID;
+    }
+  }
+  if (n == 0) return SDF_OK;
+  SDF_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  SDF_HIP(ctx->st_tasks.reserve(n * sizeof(sdf_stats_task)));
+  SDF_HIP(ctx->st_pool.reserve(pool_bytes + 16));
+  SDF_HIP(ctx->st_cig.reserve(cigar_words * 4 + 16));
+  SDF_HIP(ctx->st_out.reserve(n * sizeof(sdf_stats_cols)));
+  SDF_HIP(hipMemcpyAsync(ctx->st_tasks.p, tasks, n * sizeof(sdf_stats_task), hipMemcpyHostToDevice, st));
+  if (pool_bytes) SDF_HIP(hipMemcpyAsync(ctx->st_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, st));
+  if (cigar_words) SDF_HIP(hipMemcpyAsync(ctx->st_cig.p, cigar_pool, cigar_words * 4, hipMemcpyHostToDevice, st));
+  const int rc = sdf_stats_columns_device(ctx, (const sdf_stats_task *)ctx->st_tasks.p, n, (const char *)ctx->st_pool.p,
+                                          (const uint32_t *)ctx->st_cig.p, (sdf_stats_cols *)ctx->st_out.p, st);
+  if (rc != SDF_OK) return rc;
+  SDF_HIP(hipMemcpyAsync(out, ctx->st_out.p, n * sizeof(sdf_stats_cols), hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  for (size_t i = 0; i < n; i++)
+    if (out[i].flags) {
+      ctx->err = "alignment " + std::to_string(i) + ": the CIGAR does not fit its sequences";
+      return SDF_ERR_INVALID;
+    }
   return SDF_OK;
 }
 

@@ -193,6 +193,7 @@ struct sdf_ctx {
   HostBuf host_pool, host_out;    // pinned staging of the host-buffer entry point (packed sequences; results + CIGARs)
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
+  DevBuf st_tasks, st_pool, st_cig, st_out;  // sdf_stats_columns_batch
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
   sdf::WorkerPool *pool = nullptr;  // planning threads, started with the first batch large enough to use them
   sdf::BatchCut *cut = nullptr;  // chunk list and planning scratch of the last batch call (sdf_plan.hip)

@@ -1,0 +1,170 @@
+// Per-alignment columns of `sedef stats generate` (scope row f4) for a batch of finished alignments.
+//
+// Reference: process() walks the three column strings that populate_nice_alignment expanded from the CIGAR
+// (src/align.cc:274-315) and counts, per column, indels, matches, mismatches split into transitions and
+// transversions, and upper-case (not soft-masked) bases (src/stats_main.cc:228-270); the AlignmentError counters
+// {gaps, gap_bases, mismatches, matches} come from populate_nice_alignment itself (src/align.cc:300-314, ceq :29-35).
+// Here nothing is expanded: one wavefront takes one alignment, 64 CIGAR runs at a time.  The runs' column / a / b
+// offsets are a wave scan; the chunk is cut into units of up to eight consecutive columns of one run, every lane takes
+// every 64th unit (two per round, so that four loads are in flight), finds its run by a six-step search of the chunk's
+// unit offsets in LDS and reads its characters with one unaligned 8-byte load per sequence.
+// HBM-bound byte pass: a_len + b_len + 4 n_cigar + 64 bytes per alignment.
+#pragma once
+#include "sdf_internal.h"
+
+namespace sdf {
+
+constexpr int STATS_WAVES = 4;  // alignments per workgroup
+
+__device__ __forceinline__ int stats_wave_sum(int v) {
+#pragma unroll
+  for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// Eight consecutive characters of a sequence, as many of them as the sequence still holds (the rest unspecified):
+// one unaligned 8-byte load, taken from the last eight bytes of the sequence when fewer remain.
+__device__ __forceinline__ uint64_t stats_ld8(const char *p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__device__ __forceinline__ uint64_t stats_fetch8(const char *s, int pos, int slen, bool wide) {
+  const int avail = slen - pos;
+  if (wide) {  // wave-uniform: the sequence holds eight bytes
+    const bool whole = avail >= 8;
+    const uint64_t v = stats_ld8(s + (whole ? pos : slen - 8));
+    return whole ? v : v >> (8 * (8 - avail));
+  }
+  uint64_t v = 0;
+  for (int i = 0; i < avail && i < 8; i++) v |= (uint64_t)(unsigned char)s[pos + i] << (8 * i);
+  return v;
+}
+
+constexpr uint64_t STATS_DASHES = 0x2D2D2D2D2D2D2D2DULL;
+
+__global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(const sdf_stats_task *__restrict__ tasks, int n,
+                                                                         const char *__restrict__ pool,
+                                                                         const uint32_t *__restrict__ cigars,
+                                                                         sdf_stats_cols *__restrict__ out) {
+  __shared__ int s_unit[STATS_WAVES][64], s_a[STATS_WAVES][64], s_b[STATS_WAVES][64], s_len[STATS_WAVES][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int task = blockIdx.x * STATS_WAVES + wv;
+  if (task >= n) return;  // whole wavefronts leave; the kernel has no workgroup barrier
+  const sdf_stats_task T = tasks[task];
+  const char *a = pool + T.a_off, *b = pool + T.b_off;
+  const uint32_t *cg = cigars + T.cigar_off;
+  const int n_cigar = (int)T.n_cigar, a_len = (int)T.a_len, b_len = (int)T.b_len;
+  const bool wide_a = a_len >= 8, wide_b = b_len >= 8;
+  int *unit = s_unit[wv], *sa = s_a[wv], *sb = s_b[wv], *sl = s_len[wv];
+
+  // mismatchB = alnB - matchB, transversionsB = mismatchB - transitionsB, mismatches = alnB - matches: derived at the end
+  int indel_a = 0, indel_b = 0, aln_b = 0, match_b = 0, ts = 0, up_a = 0, up_b = 0, up_m = 0;
+  int matches = 0, gaps = 0, gap_bases = 0;
+  int ia = 0, ib = 0, span = 0, bad = 0;  // wave-uniform
+
+  // a unit: up to eight consecutive columns of one run.  fetch() finds unit u's run by a six-step search of the
+  // chunk's unit offsets and loads its characters; lanes past the last unit get eight ('-', '-') columns.
+  auto fetch = [&](int u, int total, uint64_t &wa, uint64_t &wb, int &cnt) {
+    const bool valid = u < total;
+    u = valid ? u : total - 1;
+    int j = 0;
+#pragma unroll
+    for (int step = 32; step; step >>= 1)
+      if (unit[j + step] <= u) j += step;  // last run that starts at or before unit u: the one that holds it
+    const int d = 8 * (u - unit[j]), pa = sa[j], pb = sb[j];
+    const int left = sl[j] - d;
+    cnt = valid ? (left < 8 ? left : 8) : 0;
+    wa = pa >= 0 ? stats_fetch8(a, pa + d, a_len, wide_a) : STATS_DASHES;
+    wb = pb >= 0 ? stats_fetch8(b, pb + d, b_len, wide_b) : STATS_DASHES;
+    const uint64_t keep = cnt >= 8 ? ~0ULL : (1ULL << (8 * cnt)) - 1ULL;
+    wa = (wa & keep) | (STATS_DASHES & ~keep);
+    wb = (wb & keep) | (STATS_DASHES & ~keep);
+  };
+  // ('-', '-') columns count one indel on each side and nothing else: taken back per unit
+  auto count = [&](uint64_t wa, uint64_t wb, int cnt) {
+    indel_a -= 8 - cnt;
+    indel_b -= 8 - cnt;
+#pragma unroll 2  // a rolled loop: sixteen columns' predicates side by side cost 180 registers and the occupancy with them
+    for (int i = 0; i < 8; i++) {
+      const int ca = (int)(wa & 255u), cb = (int)(wb & 255u);
+      wa >>= 8, wb >>= 8;
+      // branch-free: every counter adds a 0 / 1 predicate of the column (src/stats_main.cc:239-269)
+      const int isup_a = (unsigned)(ca - 'A') < 26u, isup_b = (unsigned)(cb - 'A') < 26u;
+      const int ua = (unsigned)(ca - 'a') < 26u ? ca - 32 : ca, ub = (unsigned)(cb - 'a') < 26u ? cb - 32 : cb;
+      const int gap_a = ca == '-', gap_b = cb == '-', eq = ua == ub;
+      const int both = (gap_a | gap_b) ^ 1, beq = both & eq;
+      const int pur_a = (ua == 'A') | (ua == 'G'), pur_b = (ub == 'A') | (ub == 'G'), pyr_b = (ub == 'C') | (ub == 'T');
+      const int same = pur_a ? pur_b : pyr_b;
+      indel_a += gap_a;
+      indel_b += gap_b;
+      up_a += (gap_a ^ 1) & (ua != 'N') & isup_a;
+      up_b += (gap_b ^ 1) & (ub != 'N') & isup_b;
+      aln_b += both;
+      match_b += beq;  // a != '-' && a == b: b is not '-' either
+      ts += (both ^ beq) & same;
+      up_m += beq & isup_a & isup_b;
+      matches += beq & (ua != 'N');  // ceq (src/align.cc:29-35)
+    }
+  };
+
+  uint32_t w_next = lane < n_cigar ? cg[lane] : 0u;
+  for (int base = 0; base < n_cigar; base += 64) {
+    const int k = base + lane;
+    const uint32_t w = w_next;
+    w_next = k + 64 < n_cigar ? cg[k + 64] : 0u;  // the next chunk's runs travel while this chunk's columns are counted
+    const int op = (int)(w & 15u);
+    const int len = k < n_cigar ? (int)(w >> 4) : 0;
+    // op 0 = 'M', 1 = 'D' (consumes a only), 2 = 'I' (consumes b only); anything else is refused
+    const int bad_l = op > 2 || len > (a_len > b_len ? a_len : b_len);
+    if (__any(bad_l)) {
+      bad = 1;
+      break;
+    }
+    const int adv_a = op != 2 ? len : 0, adv_b = op != 1 ? len : 0, nunit = (len + 7) >> 3;
+    gaps += k < n_cigar && op != 0;  // zero-length runs count (src/align.cc:301-306)
+    gap_bases += op != 0 ? len : 0;
+    int in_u = nunit, in_c = len, in_a = adv_a, in_b = adv_b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u1 = __shfl_up(in_u, d), c1 = __shfl_up(in_c, d), a1 = __shfl_up(in_a, d), b1 = __shfl_up(in_b, d);
+      if (lane >= d) in_u += u1, in_c += c1, in_a += a1, in_b += b1;
+    }
+    const int total = __shfl(in_u, 63), tot_c = __shfl(in_c, 63), tot_a = __shfl(in_a, 63), tot_b = __shfl(in_b, 63);
+    if (ia + tot_a > a_len || ib + tot_b > b_len) {  // the reference would read past its strings
+      bad = 1;
+      break;
+    }
+    unit[lane] = in_u - nunit;
+    sl[lane] = len;
+    // a run that does not consume a sequence keeps no offset; the sign bit says so
+    sa[lane] = op != 2 ? ia + in_a - adv_a : -1;
+    sb[lane] = op != 1 ? ib + in_b - adv_b : -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int u0 = 0; u0 < total; u0 += 128) {  // uniform trip count: lanes past the last unit are masked inside fetch()
+      uint64_t wa0, wb0, wa1, wb1;
+      int c0, c1;
+      fetch(u0 + lane, total, wa0, wb0, c0);
+      fetch(u0 + 64 + lane, total, wa1, wb1, c1);
+      count(wa0, wb0, c0);
+      count(wa1, wb1, c1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ia += tot_a, ib += tot_b, span += tot_c;
+  }
+  int v[11] = {indel_a, indel_b, aln_b, match_b, ts, up_a, up_b, up_m, matches, gaps, gap_bases};
+#pragma unroll
+  for (int i = 0; i < 11; i++) v[i] = stats_wave_sum(v[i]);
+  if (lane == 0) {
+    sdf_stats_cols R;
+    R.indel_a = v[0], R.indel_b = v[1], R.aln_b = v[2], R.match_b = v[3], R.mismatch_b = v[2] - v[3];
+    R.transitions_b = v[4], R.transversions_b = v[2] - v[3] - v[4], R.uppercase_a = v[5], R.uppercase_b = v[6];
+    R.uppercase_matches = v[7], R.matches = v[8], R.mismatches = v[2] - v[8], R.gaps = v[9], R.gap_bases = v[10];
+    R.span = span, R.flags = bad;
+    out[task] = R;
+  }
+}
+
+}  // namespace sdf

@@ -25,6 +25,13 @@ ANCHOR_PAIR_DTYPE = np.dtype([("q_off", "<i8"), ("r_off", "<i8"), ("qlen", "<i4"
                               ("same_chr", "<i4"), ("delta", "<i4")])
 ANCHOR_DTYPE = np.dtype([("q", "<i4"), ("r", "<i4"), ("l", "<i4"), ("has_u", "<i4")])
 assert TASK_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 64 and ANCHOR_PAIR_DTYPE.itemsize == 32
+# include/sedef_hip.h: sdf_stats_task / sdf_stats_cols
+STATS_TASK_DTYPE = np.dtype([("a_off", "<u8"), ("b_off", "<u8"), ("a_len", "<u4"), ("b_len", "<u4"),
+                             ("cigar_off", "<u8"), ("n_cigar", "<u4"), ("reserved", "<u4")])
+STATS_COLS_DTYPE = np.dtype([(f, "<i4") for f in (
+    "indel_a", "indel_b", "aln_b", "match_b", "mismatch_b", "transitions_b", "transversions_b", "uppercase_a",
+    "uppercase_b", "uppercase_matches", "matches", "mismatches", "gaps", "gap_bases", "span", "flags")])
+assert STATS_TASK_DTYPE.itemsize == 40 and STATS_COLS_DTYPE.itemsize == 64
 
 
 class SdfError(RuntimeError):
@@ -77,6 +84,12 @@ def load_library():
     L.sdf_chain_batch.restype = C.c_int
     L.sdf_chain_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
+    L.sdf_stats_columns_batch.restype = C.c_int
+    L.sdf_stats_columns_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]
+    L.sdf_stats_columns_device.restype = C.c_int
+    L.sdf_stats_columns_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
     L.sdf_last_ms.restype = C.c_float
     L.sdf_last_ms.argtypes = [C.c_void_p, C.c_int]
     L.sdf_last_launches.restype = C.c_int
@@ -236,6 +249,33 @@ class Extz2Engine:
             b0 = 2 * (int(off[i]) + i)
             out.append((path[off[i]:off[i + 1]].copy(), bounds[b0:b0 + 2 * int(nb[i])].reshape(-1, 2).copy()))
         return out
+
+    def stats_columns_batch(self, alignments):
+        """Per-alignment columns of `stats generate`.  alignments: list of (a, b, cigar) with a, b the FASTA characters
+        (str / bytes) and cigar uint32 runs len << 4 | op (0 'M', 1 'D', 2 'I').  Returns a STATS_COLS_DTYPE array
+        (include/sedef_hip.h: sdf_stats_columns_batch)."""
+        n = len(alignments)
+        tasks = np.zeros(n, STATS_TASK_DTYPE)
+        chunks, cigs, off, coff = [], [], 0, 0
+        for k, (a, b, cg) in enumerate(alignments):
+            a = a.encode() if isinstance(a, str) else bytes(a)
+            b = b.encode() if isinstance(b, str) else bytes(b)
+            cg = np.ascontiguousarray(cg, dtype=np.uint32)
+            tasks[k] = (off, off + len(a), len(a), len(b), coff, len(cg), 0)
+            off += len(a) + len(b)
+            coff += len(cg)
+            chunks += [a, b]
+            cigs.append(cg)
+        pool = b"".join(chunks)
+        cig = np.concatenate(cigs) if cigs else np.zeros(0, np.uint32)
+        out = np.zeros(n, STATS_COLS_DTYPE)
+        self._check(self.lib.sdf_stats_columns_batch(self.ctx, tasks.ctypes.data, n, pool, len(pool), cig.ctypes.data,
+                                                     len(cig), out.ctypes.data))
+        return out
+
+    def stats_columns_device(self, d_tasks, n, d_pool, d_cigar, d_out, stream=None):
+        """The same over device pointers (ints); asynchronous on `stream` when one is given."""
+        self._check(self.lib.sdf_stats_columns_device(self.ctx, d_tasks, n, d_pool, d_cigar, d_out, stream))
 
     def last_ms(self, which):
         return float(self.lib.sdf_last_ms(self.ctx, which))
