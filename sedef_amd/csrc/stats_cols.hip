@@ -81,10 +81,9 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
     wa = (wa & keep) | (STATS_DASHES & ~keep);
     wb = (wb & keep) | (STATS_DASHES & ~keep);
   };
-  // ('-', '-') columns count one indel on each side and nothing else: taken back per unit
-  auto count = [&](uint64_t wa, uint64_t wb, int cnt) {
-    indel_a -= 8 - cnt;
-    indel_b -= 8 - cnt;
+  // One column at a time: the statement of the counters (src/stats_main.cc:239-269), used for units that hold bytes
+  // outside ASCII; everything else goes through count() below.
+  auto count_scalar = [&](uint64_t wa, uint64_t wb) {
 #pragma unroll 2  // a rolled loop: sixteen columns' predicates side by side cost 180 registers and the occupancy with them
     for (int i = 0; i < 8; i++) {
       const int ca = (int)(wa & 255u), cb = (int)(wb & 255u);
@@ -105,6 +104,42 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
       ts += (both ^ beq) & same;
       up_m += beq & isup_a & isup_b;
       matches += beq & (ua != 'N');  // ceq (src/align.cc:29-35)
+    }
+  };
+
+  // Four columns per 32-bit word, flags in bit 7 of every byte (all bytes below 0x80, so no sum carries into the next
+  // byte), one v_bcnt per counter and word.  ge(v, c): byte >= c;  ne(v, c): byte != c.
+  auto count_word = [&](uint32_t x, uint32_t y) {
+    constexpr uint32_t O = 0x01010101u, H = 0x80808080u;
+    auto ge = [](uint32_t v, uint32_t c) { return v + (0x80u - c) * O; };
+    auto ne = [](uint32_t v, uint32_t c) { return (v ^ (c * O)) + 0x7Fu * O; };
+    const uint32_t ux = x ^ ((ge(x, 'a') & ~ge(x, '{') & H) >> 2), uy = y ^ ((ge(y, 'a') & ~ge(y, '{') & H) >> 2);
+    const uint32_t isup_x = ge(x, 'A') & ~ge(x, '['), isup_y = ge(y, 'A') & ~ge(y, '[');
+    const uint32_t nd_x = ne(x, '-'), nd_y = ne(y, '-'), nN_x = ne(ux, 'N'), nN_y = ne(uy, 'N');
+    const uint32_t neq = (ux ^ uy) + 0x7Fu * O;
+    const uint32_t both = nd_x & nd_y, beq = both & ~neq;
+    const uint32_t pur_x = ~(ne(ux, 'A') & ne(ux, 'G')), pur_y = ~(ne(uy, 'A') & ne(uy, 'G'));
+    const uint32_t pyr_y = ~(ne(uy, 'C') & ne(uy, 'T'));
+    const uint32_t same = (pur_x & pur_y) | (~pur_x & pyr_y);
+    indel_a += __popc(~nd_x & H);
+    indel_b += __popc(~nd_y & H);
+    up_a += __popc(isup_x & nN_x & H);  // an upper-case letter is not '-'
+    up_b += __popc(isup_y & nN_y & H);
+    aln_b += __popc(both & H);
+    match_b += __popc(beq & H);
+    ts += __popc(both & neq & same & H);
+    up_m += __popc(beq & isup_x & isup_y & H);
+    matches += __popc(beq & nN_x & H);
+  };
+  // ('-', '-') columns count one indel on each side and nothing else: taken back per unit
+  auto count = [&](uint64_t wa, uint64_t wb, int cnt) {
+    indel_a -= 8 - cnt;
+    indel_b -= 8 - cnt;
+    if (((wa | wb) & 0x8080808080808080ULL) == 0) {
+      count_word((uint32_t)wa, (uint32_t)wb);
+      count_word((uint32_t)(wa >> 32), (uint32_t)(wb >> 32));
+    } else {
+      count_scalar(wa, wb);
     }
   };
 
@@ -145,10 +180,11 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
     for (int u0 = 0; u0 < total; u0 += 128) {  // uniform trip count: lanes past the last unit are masked inside fetch()
       uint64_t wa0, wb0, wa1, wb1;
       int c0, c1;
+      const bool two = u0 + 64 < total;  // uniform
       fetch(u0 + lane, total, wa0, wb0, c0);
-      fetch(u0 + 64 + lane, total, wa1, wb1, c1);
+      if (two) fetch(u0 + 64 + lane, total, wa1, wb1, c1);
       count(wa0, wb0, c0);
-      count(wa1, wb1, c1);
+      if (two) count(wa1, wb1, c1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -131,7 +131,13 @@ def test_gpu_stats_columns_fuzz_and_edges(oracle):
               ("AC", "AC", [(1, 0), (2, 0), (0, 0)]), ("NNNN", "nnnn", [(0, 4)]),
               ("ACGT" * 16, "ACGA" * 16, [(0, 1)] * 64), ("ACGT" * 32, "ACGA" * 32, [(0, 1)] * 128),
               ("ACGT" * 25000, "ACGT" * 25000, [(0, 100000)]), ("acgt" * 50, "acga" * 50, [(0, 200)]),
-              ("AC-T*R", "AC-T*Y", [(0, 6)])]
+              ("AC-T*R", "AC-T*Y", [(0, 6)]),
+              # bytes outside ASCII (the per-column path of the kernel), next to units that take the packed path
+              (b"AC\xc3\x80GTacgtNNAC\xffTACGTACGTAC", b"AC\xc3\x81GTacgaNnAC\xffTACGAACGTAC", [(0, 12), (1, 2), (0, 12)]),
+              (bytes(range(1, 256)), bytes(range(1, 256)), [(0, 255)]),
+              (bytes(range(1, 256)), bytes(reversed(range(1, 256))), [(0, 100), (2, 55), (1, 55), (0, 100)]),
+              (bytes(range(33, 128)) * 3, (bytes(range(33, 128)) * 3).swapcase(), [(0, 285)]),
+              ("@[`{AZaz" * 9, "@[`{azAZ" * 9, [(0, 72)])]
     _check_batch(eng, oracle, cases)
     assert len(eng.stats_columns_batch([])) == 0
 
