@@ -785,18 +785,71 @@ extern "C" int sdf_stats_columns_batch(sdf_ctx *ctx, const sdf_stats_task *tasks
   if (n == 0) return SDF_OK;
   SDF_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  SDF_HIP(ctx->st_tasks.reserve(n * sizeof(sdf_stats_task)));
+  // The kernel gives an alignment to one wavefront.  A long alignment is cut here at every STATS_SEG runs into pieces
+  // that run side by side -- a piece is an alignment of its own: the sequences' ranges its runs consume -- and the
+  // pieces' counters are added up afterwards (every counter is a sum over columns or runs).
+  constexpr uint32_t STATS_SEG = 512, STATS_LONG = 1024;
+  std::vector<sdf_stats_task> pieces;
+  std::vector<size_t> first;
+  bool any_long = false;
+  for (size_t i = 0; i < n && !any_long; i++) any_long = tasks[i].n_cigar > STATS_LONG;
+  if (any_long) {
+    first.resize(n + 1);
+    for (size_t i = 0; i < n; i++) {
+      const sdf_stats_task &t = tasks[i];
+      first[i] = pieces.size();
+      if (t.n_cigar <= STATS_LONG) {
+        pieces.push_back(t);
+        continue;
+      }
+      uint64_t ia = 0, ib = 0;
+      for (uint32_t k0 = 0; k0 < t.n_cigar; k0 += STATS_SEG) {
+        const uint32_t nk = std::min(STATS_SEG, t.n_cigar - k0);
+        uint64_t da = 0, db = 0;
+        bool ok = true;
+        for (uint32_t k = 0; k < nk; k++) {
+          const uint32_t w = cigar_pool[t.cigar_off + k0 + k], op = w & 15u;
+          ok &= op <= 2;
+          if (op != 2) da += w >> 4;
+          if (op != 1) db += w >> 4;
+        }
+        if (!ok || ia + da > t.a_len || ib + db > t.b_len) {
+          ctx->err = "alignment " + std::to_string(i) + ": the CIGAR does not fit its sequences";
+          return SDF_ERR_INVALID;
+        }
+        pieces.push_back({t.a_off + ia, t.b_off + ib, (uint32_t)da, (uint32_t)db, t.cigar_off + k0, nk, 0});
+        ia += da, ib += db;
+      }
+    }
+    first[n] = pieces.size();
+  }
+  const sdf_stats_task *up = any_long ? pieces.data() : tasks;
+  const size_t nup = any_long ? pieces.size() : n;
+  std::vector<sdf_stats_cols> piece_out(any_long ? nup : 0);
+  sdf_stats_cols *down = any_long ? piece_out.data() : out;
+  SDF_HIP(ctx->st_tasks.reserve(nup * sizeof(sdf_stats_task)));
   SDF_HIP(ctx->st_pool.reserve(pool_bytes + 16));
   SDF_HIP(ctx->st_cig.reserve(cigar_words * 4 + 16));
-  SDF_HIP(ctx->st_out.reserve(n * sizeof(sdf_stats_cols)));
-  SDF_HIP(hipMemcpyAsync(ctx->st_tasks.p, tasks, n * sizeof(sdf_stats_task), hipMemcpyHostToDevice, st));
+  SDF_HIP(ctx->st_out.reserve(nup * sizeof(sdf_stats_cols)));
+  SDF_HIP(hipMemcpyAsync(ctx->st_tasks.p, up, nup * sizeof(sdf_stats_task), hipMemcpyHostToDevice, st));
   if (pool_bytes) SDF_HIP(hipMemcpyAsync(ctx->st_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, st));
   if (cigar_words) SDF_HIP(hipMemcpyAsync(ctx->st_cig.p, cigar_pool, cigar_words * 4, hipMemcpyHostToDevice, st));
-  const int rc = sdf_stats_columns_device(ctx, (const sdf_stats_task *)ctx->st_tasks.p, n, (const char *)ctx->st_pool.p,
+  const int rc = sdf_stats_columns_device(ctx, (const sdf_stats_task *)ctx->st_tasks.p, nup, (const char *)ctx->st_pool.p,
                                           (const uint32_t *)ctx->st_cig.p, (sdf_stats_cols *)ctx->st_out.p, st);
   if (rc != SDF_OK) return rc;
-  SDF_HIP(hipMemcpyAsync(out, ctx->st_out.p, n * sizeof(sdf_stats_cols), hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipMemcpyAsync(down, ctx->st_out.p, nup * sizeof(sdf_stats_cols), hipMemcpyDeviceToHost, st));
   SDF_HIP(hipStreamSynchronize(st));
+  if (any_long)
+    for (size_t i = 0; i < n; i++) {
+      static_assert(sizeof(sdf_stats_cols) == 16 * sizeof(int32_t), "sdf_stats_cols is sixteen counters");
+      int32_t acc[16] = {0};
+      for (size_t k = first[i]; k < first[i + 1]; k++) {
+        const int32_t *v = reinterpret_cast<const int32_t *>(&piece_out[k]);
+        for (int f = 0; f < 15; f++) acc[f] += v[f];
+        acc[15] |= v[15];
+      }
+      memcpy(&out[i], acc, sizeof(acc));
+    }
   for (size_t i = 0; i < n; i++)
     if (out[i].flags) {
       ctx->err = "alignment " + std::to_string(i) + ": the CIGAR does not fit its sequences";

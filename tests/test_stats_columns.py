@@ -165,6 +165,36 @@ def test_gpu_stats_columns_long_alignment_and_many(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_stats_columns_long_and_short_in_one_call(oracle):
+    """Alignments of more than 1,024 runs are cut into pieces of 512 runs by the host-buffer call: next to short ones, with
+    zero-length runs at the cuts, a CIGAR that stops short of the sequences, and gap-only pieces."""
+    import sedef_amd
+    eng = sedef_amd.Extz2Engine(0)
+    rng = np.random.default_rng(8)
+    cases = []
+    for n_runs in (1024, 1025, 1536, 1537, 5000, 3000):
+        runs = []
+        for k in range(n_runs):
+            op = int(rng.choice([0, 0, 1, 2]))
+            runs.append((op, 0 if k % 512 in (0, 511) and rng.random() < 0.5 else int(rng.integers(0, 30))))
+        if n_runs == 3000:  # 600 gap runs in a row: a piece that consumes nothing of b, then one that consumes nothing of a
+            runs[1000:1300] = [(1, 3)] * 300
+            runs[1300:1600] = [(2, 2)] * 300
+        na = sum(l for op, l in runs if op != 2) + 17
+        nb = sum(l for op, l in runs if op != 1) + 5
+        a = rng.choice(list(b"ACGTacgtNn-"), na).astype(np.uint8).tobytes()
+        b = rng.choice(list(b"ACGTacgtNn"), nb).astype(np.uint8).tobytes()
+        cases.append((a, b, runs))
+        cases.append(random_stats_case(rng, n_runs))
+    _check_batch(eng, oracle, cases)
+    a, b, runs = cases[8]
+    with pytest.raises(sedef_amd.SdfError, match="alignment 1: the CIGAR does not fit"):
+        eng.stats_columns_batch([("ACGT", "ACGT", _words([(0, 4)])), (a, b[:len(b) - 200], _words(runs))])
+    with pytest.raises(sedef_amd.SdfError, match="alignment 0: the CIGAR does not fit"):
+        eng.stats_columns_batch([(a, b, np.concatenate([_words(runs[:2000]), np.array([(1 << 4) | 7], np.uint32)]))])
+
+
+@pytest.mark.gpu
 def test_gpu_stats_columns_errors():
     import sedef_amd
     eng = sedef_amd.Extz2Engine(0)
