@@ -791,3 +791,90 @@ def test_generic_scoring_and_approximate_modes_fuzz(engine, oracle):
             assert cigar_to_str(got["cigar"]) == cigar_to_str(exp["cigar"]), (hex(flag), kw, len(q), len(t))
             n += 1
     assert n == 320
+
+
+def _full_size_properties(engine, batch, w, cpu_sample, oracle):
+    """Size-independent checks on EVERY task of a batch (vectorised over the CIGAR pool) + an exact comparison with the
+    CPU path on a sample: the CIGAR consumes both sequences, is a canonical run-length code, its counters add up, and --
+    the sequences hold no N, full band -- the path it describes scores exactly the DP score: 5 per match, -4 per mismatch,
+    -(40 + length) per gap (checked to hold for the oracle's own results)."""
+    import sedef_amd
+    from oracle.binding import Reference
+    pool, q_off, qlen, t_off, tlen = batch
+    n = len(qlen)
+    tasks = np.zeros(n, sedef_amd.TASK_DTYPE)
+    tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"] = q_off, t_off, qlen, tlen
+    tasks["w"], tasks["zdrop"] = w, -1
+    res, cig = engine.align_batch(tasks, pool, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    nc = res["n_cigar"].astype(np.int64)
+    off = res["cigar_off"].astype(np.int64)
+    start = np.cumsum(nc) - nc
+    ids = np.repeat(np.arange(n), nc)
+    words = cig[np.repeat(off - start, nc) + np.arange(int(nc.sum()))]
+    ops, lens = (words & 15).astype(np.int64), (words >> 4).astype(np.int64)
+    assert ops.max() <= 2 and lens.min() >= 1
+    same_task = ids[1:] == ids[:-1]
+    assert not np.any(same_task & (ops[1:] == ops[:-1]))  # ksw_push_cigar merges equal neighbours (extern/ksw2.h:98-111)
+
+    def per_task(x):
+        return np.bincount(ids, weights=x, minlength=n).astype(np.int64)
+
+    # a band that cannot reach the corner: no score, and the CIGAR -- if any -- ends at the best cell (extern/ksw2_extz2_sse.cc:286-296;
+    # compared with the CPU path on the sample)
+    done = (nc > 0) & (res["zdropped"] == 0) & (res["score"] > -0x40000000)
+    assert np.array_equal(per_task(lens * (ops != 2))[done], np.asarray(qlen, np.int64)[done])
+    assert np.array_equal(per_task(lens * (ops != 1))[done], np.asarray(tlen, np.int64)[done])
+    assert np.array_equal(per_task(lens * (ops == 0)), res["matches"].astype(np.int64) + res["mismatches"])
+    assert np.array_equal(per_task(lens * (ops != 0)), res["gap_bases"].astype(np.int64))
+    assert np.array_equal(per_task((ops != 0).astype(np.int64)), res["gaps"].astype(np.int64))
+    path_score = 5 * res["matches"].astype(np.int64) - 4 * res["mismatches"] - (40 * res["gaps"].astype(np.int64)
+                                                                               + res["gap_bases"])
+    # full band only: under a band the reference's score can exceed its own path's (cells outside the band keep stale
+    # values, extern/ksw2_extz2_sse.cc:115-138; one such task in configs[4]'s 3,000, identical on the GPU)
+    full = done & (np.broadcast_to(np.asarray(w, np.int32), (n,)) < 0)
+    assert np.array_equal(path_score[full], res["score"].astype(np.int64)[full])
+    try:
+        cpu = Reference()
+    except Exception:
+        cpu = oracle
+    ws = np.broadcast_to(np.asarray(w, np.int32), (n,))
+    for wv in np.unique(ws[cpu_sample]):
+        sel = cpu_sample[ws[cpu_sample] == wv]
+        score, h = cpu.batch(pool, q_off[sel], qlen[sel], t_off[sel], tlen[sel], w=int(wv))
+        assert np.array_equal(res["score"][sel], score), int(wv)
+        for k, hk in zip(sel, h):
+            assert _fnv(cig[off[k]:off[k] + nc[k]]) == int(hk), (int(k), int(qlen[k]), int(tlen[k]), int(wv))
+    return res, done
+
+
+def test_config4_full_size_one_million_tasks(engine, oracle):
+    """configs[3] at the size bench.py --workload hg19mix runs: 1,000,000 tasks, the heavy ones up to 6000 x 6000."""
+    import bench
+    batch, w = bench.synth_hg19_mixture_fast(1000000, seed=7, big=6000)
+    qlen = batch[1 + 1]
+    rng = np.random.default_rng(1)
+    heavy = np.nonzero(qlen >= 1200)[0]
+    sample = np.unique(np.r_[rng.choice(len(qlen), 4000, replace=False), heavy[np.argsort(qlen[heavy])[:40]], heavy[-8:]])
+    res, done = _full_size_properties(engine, batch, w, sample, oracle)
+    assert done.all() and len(heavy) > 300 and len(qlen) == 1000000 and int(res["n_cigar"].astype(np.int64).sum()) > 2000000
+
+
+def test_config5_full_size_mixed_bands(engine, oracle):
+    """configs[4] at the size profiles/mix_probe.py mm8 runs: 3,000 tasks up to 20 kb, bands 64..512 in one batch."""
+    import bench
+    batch, w = bench.synth_mm8_mixture(3000, seed=8, max_len=20000)
+    sample = np.arange(0, 3000, 10)
+    res, done = _full_size_properties(engine, batch, w, sample, oracle)
+    assert 2500 < int(done.sum()) < 3000  # the one-sided kb-scale indels leave their bands
+
+
+def test_config2_full_size_banded_and_full_band(engine, oracle):
+    """configs[1] at the size bench.py times: the 100,000 seed-42 tasks at w = 128, and the same inputs in SEDEF's real
+    mode (w = -1), every task through the size-independent checks, a sample against the CPU path."""
+    import bench
+    batch = bench.synth_batch(100000, 1000, seed=42)
+    rng = np.random.default_rng(2)
+    res, done = _full_size_properties(engine, batch, 128, np.sort(rng.choice(100000, 2000, replace=False)), oracle)
+    assert done.all() and int(res["n_cigar"].astype(np.int64).sum()) > 3000000
+    res, done = _full_size_properties(engine, batch, -1, np.sort(rng.choice(100000, 500, replace=False)), oracle)
+    assert done.all()
