@@ -16,10 +16,17 @@ namespace sdf {
 
 constexpr int STATS_WAVES = 4;  // alignments per workgroup
 
+// Sum over the wavefront (all 64 lanes active), in every lane: an inclusive scan inside each row of sixteen lanes
+// (row_shr 1, 2, 4, 8), the rows' totals passed on (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3) --
+// six DPP adds, no LDS -- and lane 63 read back.
 __device__ __forceinline__ int stats_wave_sum(int v) {
-#pragma unroll
-  for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
-  return v;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Eight consecutive characters of a sequence, as many of them as the sequence still holds (the rest unspecified):
