@@ -16,18 +16,19 @@ namespace sdf {
 
 constexpr int STATS_WAVES = 4;  // alignments per workgroup
 
-// Sum over the wavefront (all 64 lanes active), in every lane: an inclusive scan inside each row of sixteen lanes
+// Prefix sums and sums over the wavefront (all 64 lanes active): an inclusive scan inside each row of sixteen lanes
 // (row_shr 1, 2, 4, 8), the rows' totals passed on (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3) --
 // six DPP adds, no LDS -- and lane 63 read back.
-__device__ __forceinline__ int stats_wave_sum(int v) {
+__device__ __forceinline__ int stats_wave_scan(int v) {  // inclusive prefix sum over the lanes
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-  return __builtin_amdgcn_readlane(v, 63);
+  return v;
 }
+__device__ __forceinline__ int stats_wave_sum(int v) { return __builtin_amdgcn_readlane(stats_wave_scan(v), 63); }
 
 // Eight consecutive characters of a sequence, as many of them as the sequence still holds (the rest unspecified):
 // one unaligned 8-byte load, taken from the last eight bytes of the sequence when fewer remain.
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
   // mismatchB = alnB - matchB, transversionsB = mismatchB - transitionsB, mismatches = alnB - matches: derived at the end
   int indel_a = 0, indel_b = 0, aln_b = 0, match_b = 0, ts = 0, up_a = 0, up_b = 0, up_m = 0;
   int matches = 0, gaps = 0, gap_bases = 0;
-  int ia = 0, ib = 0, span = 0, bad = 0;  // wave-uniform
+  int ia = 0, ib = 0, bad = 0;  // wave-uniform
+  int span_l = 0;
 
   // a unit: up to eight consecutive columns of one run.  fetch() finds unit u's run by a six-step search of the
   // chunk's unit offsets and loads its characters; lanes past the last unit get eight ('-', '-') columns.
@@ -166,13 +168,10 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
     const int adv_a = op != 2 ? len : 0, adv_b = op != 1 ? len : 0, nunit = (len + 7) >> 3;
     gaps += k < n_cigar && op != 0;  // zero-length runs count (src/align.cc:301-306)
     gap_bases += op != 0 ? len : 0;
-    int in_u = nunit, in_c = len, in_a = adv_a, in_b = adv_b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int u1 = __shfl_up(in_u, d), c1 = __shfl_up(in_c, d), a1 = __shfl_up(in_a, d), b1 = __shfl_up(in_b, d);
-      if (lane >= d) in_u += u1, in_c += c1, in_a += a1, in_b += b1;
-    }
-    const int total = __shfl(in_u, 63), tot_c = __shfl(in_c, 63), tot_a = __shfl(in_a, 63), tot_b = __shfl(in_b, 63);
+    const int in_u = stats_wave_scan(nunit), in_a = stats_wave_scan(adv_a), in_b = stats_wave_scan(adv_b);
+    const int total = __builtin_amdgcn_readlane(in_u, 63), tot_a = __builtin_amdgcn_readlane(in_a, 63),
+              tot_b = __builtin_amdgcn_readlane(in_b, 63);
+    span_l += len;  // summed over the lanes at the end
     if (ia + tot_a > a_len || ib + tot_b > b_len) {  // the reference would read past its strings
       bad = 1;
       break;
@@ -195,17 +194,17 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    ia += tot_a, ib += tot_b, span += tot_c;
+    ia += tot_a, ib += tot_b;
   }
-  int v[11] = {indel_a, indel_b, aln_b, match_b, ts, up_a, up_b, up_m, matches, gaps, gap_bases};
+  int v[12] = {indel_a, indel_b, aln_b, match_b, ts, up_a, up_b, up_m, matches, gaps, gap_bases, span_l};
 #pragma unroll
-  for (int i = 0; i < 11; i++) v[i] = stats_wave_sum(v[i]);
+  for (int i = 0; i < 12; i++) v[i] = stats_wave_sum(v[i]);
   if (lane == 0) {
     sdf_stats_cols R;
     R.indel_a = v[0], R.indel_b = v[1], R.aln_b = v[2], R.match_b = v[3], R.mismatch_b = v[2] - v[3];
     R.transitions_b = v[4], R.transversions_b = v[2] - v[3] - v[4], R.uppercase_a = v[5], R.uppercase_b = v[6];
     R.uppercase_matches = v[7], R.matches = v[8], R.mismatches = v[2] - v[8], R.gaps = v[9], R.gap_bases = v[10];
-    R.span = span, R.flags = bad;
+    R.span = v[11], R.flags = bad;
     out[task] = R;
   }
 }
