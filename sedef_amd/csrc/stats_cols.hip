@@ -4,10 +4,10 @@
 // (src/align.cc:274-315) and counts, per column, indels, matches, mismatches split into transitions and
 // transversions, and upper-case (not soft-masked) bases (src/stats_main.cc:228-270); the AlignmentError counters
 // {gaps, gap_bases, mismatches, matches} come from populate_nice_alignment itself (src/align.cc:300-314, ceq :29-35).
-// Here nothing is expanded: one wavefront takes one alignment, 64 CIGAR runs at a time.  The runs' column / a / b
-// offsets are a wave scan; the chunk is cut into units of up to eight consecutive columns of one run, every lane takes
-// every 64th unit (two per round, so that four loads are in flight), finds its run by a six-step search of the chunk's
-// unit offsets in LDS and reads its characters with one unaligned 8-byte load per sequence.
+// Here nothing is expanded: one wavefront takes one alignment, 64 CIGAR runs at a time.  The runs' unit / a / b offsets
+// are wave scans; the chunk is cut into units of up to eight consecutive columns of one run, every lane takes every 64th
+// unit (two per round, so that four loads are in flight), finds its run by a six-step search of the chunk's unit offsets
+// in LDS, reads its characters with one unaligned 8-byte load per sequence and counts them four columns per 32-bit word.
 // HBM-bound byte pass: a_len + b_len + 4 n_cigar + 64 bytes per alignment.
 #pragma once
 #include "sdf_internal.h"
@@ -18,7 +18,7 @@ constexpr int STATS_WAVES = 4;  // alignments per workgroup
 
 // Prefix sums and sums over the wavefront (all 64 lanes active): an inclusive scan inside each row of sixteen lanes
 // (row_shr 1, 2, 4, 8), the rows' totals passed on (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3) --
-// six DPP adds, no LDS -- and lane 63 read back.
+// six DPP adds, no LDS; the sum is lane 63's prefix.
 __device__ __forceinline__ int stats_wave_scan(int v) {  // inclusive prefix sum over the lanes
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
