@@ -162,6 +162,10 @@ int sdf_last_launches(const sdf_ctx *ctx);
 /* Number of tasks of the last batch call that ran two per wavefront: tasks with the same (qlen, tlen, w, flag)
  * share the reference's band schedule (extern/ksw2_extz2_sse.cc:101-115) and are packed side by side. */
 long long sdf_last_paired(const sdf_ctx *ctx);
+/* Number of tasks of the last batch call that were run a second time, inside the call, on the one-wavefront / one-workgroup
+ * kernels because a stripe kernel's wavefront gave up waiting for its neighbour (SDF_STRIPE_SPIN_CAP polls; the stripe
+ * protocol's forward progress rests on the dispatch order).  0 in normal operation. */
+long long sdf_last_reran(const sdf_ctx *ctx);
 
 /* ---- seed anchors on the GPU (next row of the scope table) -----------------------------------
  * Replaces generate_anchors (reference: src/chain.cc:24-101) for a batch of candidate pairs: maximal exact

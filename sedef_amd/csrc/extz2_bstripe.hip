@@ -85,7 +85,9 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
                                                               const int32_t *__restrict__ order,
                                                               const uint32_t *__restrict__ pool, ScoreK sc,
                                                               uint8_t *__restrict__ dirbase,
-                                                              unsigned long long *__restrict__ gave_up) {
+                                                              sdf_result *__restrict__ res,
+                                                              unsigned long long *__restrict__ gave_up,
+                                                              const int spin_cap) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;
   constexpr int KT = NREG - 1;
@@ -225,8 +227,13 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           if (first_wait) __builtin_amdgcn_s_sleep(100);
           else __builtin_amdgcn_s_sleep(2);
           feed_load(r0, gx, gh);
-        } while (__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u)) && ++spins < (1 << 24));
-        if (spins >= (1 << 24) && lane == 0) atomicAdd(gave_up, 1ull);  // (the batch call reports it as an error)
+          if (!__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u))) break;
+          // (gives up like the full-band stripe kernel: extz2_stripe.hip, stripe_abandon)
+          if (++spins >= spin_cap || ((spins & 63) == 63 && stripe_abandoned(res + tk.out_idx))) {
+            stripe_abandon(gave_up, res + tk.out_idx, tk.out_idx, lane);
+            return;
+          }
+        } while (true);
         if (very_long) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(2);
       }
@@ -742,11 +749,11 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
 }
 
 template __global__ void extz2_bstripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                 unsigned long long *);
+                                                 sdf_result *, unsigned long long *, int);
 template __global__ void extz2_bstripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                 unsigned long long *);
+                                                 sdf_result *, unsigned long long *, int);
 template __global__ void extz2_bstripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                 unsigned long long *);
+                                                 sdf_result *, unsigned long long *, int);
 
 // Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's record and the edge column of its
 // right boundary to zero (no word tagged as written)
@@ -803,7 +810,7 @@ __global__ __launch_bounds__(64) void bstripe_finish_kernel(const PlanTask *__re
   o.mqe = SDF_NEG_INF;
   o.mqe_t = -1;
   o.zdropped = dropped ? 1 : 0;
-  o.n_cigar = 0;
+  o.n_cigar = res[tk.out_idx].n_cigar == -1 ? -1 : 0;  // (-1: a stripe gave the task up; it is run again, sdf_launch.hip)
   o.cigar_off = 0;
   o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
   res[tk.out_idx] = o;

@@ -62,14 +62,34 @@ __device__ __forceinline__ void st_agent(T *p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#define SDF_STRIPE_SPIN_CAP (1 << 24)  // polls before a wait gives up (an error from the batch call instead of a hung queue)
+// A wait gives up after `spin_cap` polls (context field, SDF_STRIPE_SPIN_CAP in the environment of sdf_create; 2^24 by
+// default: seconds) -- the protocol's forward progress rests on the dispatch order (a stripe's left neighbour is resident or
+// finished), which a part with another XCD count, or other launches holding the wavefront slots, may not honour.  The
+// wavefront then marks its TASK as abandoned (n_cigar = -1 in the task's result record, which nothing else touches before
+// the traceback; the task's index is appended to the list behind the give-up counter, once per task) and ends; the other
+// stripes of the task see the mark within 64 polls and end too.  The batch call re-runs abandoned tasks on the
+// one-wavefront / one-workgroup kernels (sdf_launch.hip: rerun_abandoned).
+#define SDF_GAVEUP_LIST 32   // (in 64-bit words behind the counter: the list of abandoned tasks, 32-bit entries)
+#define SDF_GAVEUP_CAP 1024  // entries of the list
+#define SDF_MISC_PARTS (1 + SDF_GAVEUP_LIST + SDF_GAVEUP_CAP / 2)  // (64-bit words of the context's misc buffer before the scan's partial sums)
+__device__ __forceinline__ void stripe_abandon(unsigned long long *gave_up, sdf_result *rec, int out_idx, int lane) {
+  if (lane != 0) return;
+  const int old = __hip_atomic_exchange(&rec->n_cigar, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old == -1) return;
+  const unsigned long long slot = atomicAdd(gave_up, 1ull);
+  if (slot < SDF_GAVEUP_CAP) reinterpret_cast<uint32_t *>(gave_up + SDF_GAVEUP_LIST)[slot] = (uint32_t)out_idx;
+}
+__device__ __forceinline__ bool stripe_abandoned(const sdf_result *rec) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&rec->n_cigar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1;
+}
 
 template <int NREG>
 __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__restrict__ plan,
                                                              const int32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ pool, ScoreK sc,
                                                              uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res,
-                                                             const int rmax, unsigned long long *__restrict__ gave_up) {
+                                                             const int rmax, unsigned long long *__restrict__ gave_up,
+                                                             const int spin_cap) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;  // stripe width
   constexpr int KT = NREG - 1;
@@ -165,8 +185,20 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
     int spins = 0;
     // (readfirstlane: the compiler cannot see that a volatile load of one address is wave-uniform, and a divergent
     // loop here would make every value that lives across it -- the row counters -- a vector value)
-    while (__builtin_amdgcn_readfirstlane(ld_agent(prog + sb - 1)) < T0 - 1 && ++spins < SDF_STRIPE_SPIN_CAP) __builtin_amdgcn_s_sleep(8);
-    if (spins >= SDF_STRIPE_SPIN_CAP && lane == 0) atomicAdd(gave_up, 1ull);  // (the batch call reports it as an error)
+    bool lost = false;
+    while (__builtin_amdgcn_readfirstlane(ld_agent(prog + sb - 1)) < T0 - 1) {
+      if (++spins >= spin_cap || ((spins & 63) == 63 && stripe_abandoned(res + tk.out_idx))) {
+        lost = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (lost) {  // (the batch call re-runs the task on another kernel)
+      stripe_abandon(gave_up, res + tk.out_idx, tk.out_idx, lane);
+      return;
+    }
+    // (the hand-over value was stored before the progress word, release fence in between: acquire on this side)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     h_head = __builtin_amdgcn_readfirstlane(ld_agent(hand_val + sb - 1));
   }
 #ifdef SDF_STRIPE_TIMING
@@ -337,11 +369,14 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
 #ifdef SDF_STRIPE_TIMING
       const unsigned long long tw0 = __builtin_amdgcn_s_memrealtime();
 #endif
-      while (__builtin_amdgcn_readfirstlane((int)__any((got & 1u) == 0u)) && ++spins < SDF_STRIPE_SPIN_CAP) {
+      while (__builtin_amdgcn_readfirstlane((int)__any((got & 1u) == 0u))) {
+        if (++spins >= spin_cap || ((spins & 63) == 63 && stripe_abandoned(res + tk.out_idx))) {
+          stripe_abandon(gave_up, res + tk.out_idx, tk.out_idx, lane);
+          return;
+        }
         __builtin_amdgcn_s_sleep(2);
         got = feed_load(r0);
       }
-      if (spins >= SDF_STRIPE_SPIN_CAP && lane == 0) atomicAdd(gave_up, 1ull);
 #ifdef SDF_STRIPE_TIMING
       if (spins) tm_wait += __builtin_amdgcn_s_memrealtime() - tw0;
 #endif
@@ -438,11 +473,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
 }
 
 template __global__ void extz2_stripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int, unsigned long long *);
+                                                sdf_result *, int, unsigned long long *, int);
 template __global__ void extz2_stripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int, unsigned long long *);
+                                                sdf_result *, int, unsigned long long *, int);
 template __global__ void extz2_stripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int, unsigned long long *);
+                                                sdf_result *, int, unsigned long long *, int);
 
 // Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's progress and hand-over words to
 // "nothing done" and the edge column of its right boundary to zero (no word tagged as written)

@@ -111,6 +111,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->no_stripe = ns && ns[0] == '1';
   if (const char *sm = getenv("SDF_STRIPE_MIN")) ctx->stripe_min = std::max(128, atoi(sm));
   if (const char *bm = getenv("SDF_BSTRIPE_MIN_ROWS")) ctx->bstripe_min_rows = std::max(0, atoi(bm));
+  if (const char *cp = getenv("SDF_STRIPE_SPIN_CAP")) ctx->stripe_spin_cap = std::max(1, atoi(cp));
   const char *pl = getenv("SDF_PIPELINE");
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
@@ -138,8 +139,9 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
                     &ctx->st_cig, &ctx->st_out})
     b->release();
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
-                    &ctx->h_pool, &ctx->h_out, &ctx->h_cig})
+                    &ctx->h_pool, &ctx->h_out, &ctx->h_cig, &ctx->rr_out, &ctx->rr_cig, &ctx->rr_map})
     b->release();
+  if (ctx->rerun_ctx) sdf_destroy(ctx->rerun_ctx);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0], ctx->aux_stream[1],
                         ctx->aux_stream[2], ctx->aux_stream[3]})
@@ -225,6 +227,7 @@ extern "C" float sdf_last_ms(const sdf_ctx *ctx, int which) {
 
 extern "C" int sdf_last_launches(const sdf_ctx *ctx) { return ctx ? ctx->launches : 0; }
 extern "C" long long sdf_last_paired(const sdf_ctx *ctx) { return ctx ? ctx->paired : 0; }
+extern "C" long long sdf_last_reran(const sdf_ctx *ctx) { return ctx ? ctx->reran : 0; }
 
 namespace {
 
@@ -344,6 +347,10 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   env.stripe_min = ctx->stripe_min;
   env.bstripe_min_rows = ctx->bstripe_min_rows;
   run.want_cigar = env.want_cigar;
+  run.scoring = sc;
+  run.tasks = tasks;
+  run.want = want;
+  ctx->reran = 0;
   if (!ctx->cut) ctx->cut = new BatchCut();
   BatchCut &cut = *ctx->cut;
   cut.reset();
@@ -381,7 +388,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   SDF_HIP(ctx->plan_buf.reserve(np * sizeof(PlanTask)));
   const size_t nord = std::max<size_t>(cut.order_total, 2);
   SDF_HIP(ctx->order_buf.reserve(nord * sizeof(int32_t)));
-  SDF_HIP(ctx->misc_buf.reserve(256 + ((n + 1023) / 1024 + 1) * 8));
+  SDF_HIP(ctx->misc_buf.reserve(SDF_MISC_PARTS * 8 + ((n + 1023) / 1024 + 1) * 8));
   SDF_HIP(ctx->host_plan.reserve(np * sizeof(PlanTask)));
   SDF_HIP(ctx->host_order.reserve(nord * sizeof(int32_t)));
   run.plan = (PlanTask *)ctx->host_plan.p;  // pinned: the uploads are asynchronous
@@ -397,8 +404,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   run.ev_begin = next_event(ctx, run.evc);
   hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n);
   SDF_HIP(hipEventRecord(run.ev_begin, st));
-  if (cut.pipelined)
-    for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream}) SDF_HIP(hipStreamWaitEvent(s, run.ev_begin, 0));
+  // (the internal streams are ordered behind ev_begin by launch_chunk, each before its first use in this call)
 
   // ---- plan (worker threads, chunk order) and launch (this thread, chunk order) ----
   static const bool dbg_plan_chunks = getenv("SDF_DEBUG_PLAN") != nullptr;

@@ -35,10 +35,11 @@ size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 bool pair_fits_whole(int qlen, int tlen, int nreg);
 template <int NREG>
 __global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                    sdf_result *, int, unsigned long long *);
+                                    sdf_result *, int, unsigned long long *, int);
 __global__ void stripe_sync_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 template <int NREG>
-__global__ void extz2_bstripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, unsigned long long *);
+__global__ void extz2_bstripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *,
+                                     unsigned long long *, int);
 __global__ void bstripe_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 __global__ void bstripe_finish_kernel(const PlanTask *, const int32_t *, int, int, const uint8_t *, sdf_result *);
 template <int LAYOUT, int G>
@@ -211,6 +212,10 @@ struct sdf_ctx {
                                // stripe kernel (extz2_bstripe.hip); 0: never
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
+  int stripe_spin_cap = 1 << 24;  // SDF_STRIPE_SPIN_CAP: polls before a stripe's wait gives its task up (extz2_stripe.hip)
+  sdf_ctx *rerun_ctx = nullptr;   // context without stripe kernels for the tasks they gave up (created when first needed)
+  DevBuf rr_out, rr_cig, rr_map;  // its outputs, and the (record, staging slot) map of the merge
+  long long reran = 0;            // tasks of the last batch call that were re-run after a stripe gave up
 };
 
 #define SDF_HIP(call)                                                                          \

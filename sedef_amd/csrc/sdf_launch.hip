@@ -41,6 +41,12 @@ struct BatchRun {
   double qload[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // estimated DP work queued on each stream during this call
   size_t evc = 0;
   hipEvent_t ev_begin = nullptr;
+  bool any_stripe = false;  // a stripe kernel was launched: its give-up list is looked at before the batch closes
+  const sdf_scoring *scoring = nullptr;  // what the caller passed (a re-run of abandoned tasks passes them on)
+  const sdf_task *tasks = nullptr;
+  uint32_t want = 0;
+  hipStream_t began[12] = {};  // internal streams already ordered behind ev_begin in this call
+  size_t nbegan = 0;
 };
 
 static hipEvent_t next_event(sdf_ctx *ctx, size_t &cursor) {
@@ -62,7 +68,8 @@ static void drain_streams(sdf_ctx *ctx, hipStream_t st) {
 
 // One DP launch of a planned class.  slabs: HBM state of the very long tasks (HBM-state classes only).
 static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, const int32_t *lo, const uint32_t *d_pool,
-                      const ScoreK &sk, uint8_t *dir_reg, sdf_result *d_out, uint8_t *slabs, unsigned long long *gave_up) {
+                      const ScoreK &sk, uint8_t *dir_reg, sdf_result *d_out, uint8_t *slabs, unsigned long long *gave_up,
+                      int spin_cap) {
   const dim3 one((unsigned)L.cnt), half((unsigned)(L.cnt / 2));
 #define SDF_WAVE(N, S) \
   hipLaunchKernelGGL((extz2_wave_kernel<N, S>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
@@ -73,12 +80,12 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
 #define SDF_STRIPE(N) /* one workgroup of one wavefront per stripe; progress words and edge columns reset first */ \
   {                                                                                                              \
     hipLaunchKernelGGL(stripe_sync_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                      \
-    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax, gave_up); \
+    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax, gave_up, spin_cap); \
   }
 #define SDF_BSTRIPE(N) /* banded stripes: records and edge columns reset first, the records merged afterwards */    \
   {                                                                                                               \
     hipLaunchKernelGGL(bstripe_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                           \
-    hipLaunchKernelGGL((extz2_bstripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, gave_up); \
+    hipLaunchKernelGGL((extz2_bstripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap); \
     hipLaunchKernelGGL(bstripe_finish_kernel, dim3((unsigned)((L.cnt + 63) / 64)), dim3(64), 0, sdp, lp, lo,     \
                        (int)L.cnt, N, dir_reg, d_out);                                                            \
   }
@@ -182,6 +189,18 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   hipStream_t Q[8] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
                       pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
                       ctx->aux_stream[3]};
+  // Every internal stream waits for the start of the call before its first use in it -- whatever it is used for (plan
+  // upload, DP, traceback): the packed pool's upload, the reset of the result records, the give-up word and whatever the
+  // caller ordered on its stream all lie before ev_begin.  (The extra streams are created lazily, above: a fixed list
+  // at the start of the call would miss them.)
+  for (int q = 1; q < 8; ++q) {
+    if (!Q[q] || Q[q] == st) continue;
+    bool seen = false;
+    for (size_t b = 0; b < run.nbegan; ++b) seen = seen || run.began[b] == Q[q];
+    if (seen) continue;
+    SDF_HIP(hipStreamWaitEvent(Q[q], run.ev_begin, 0));
+    if (run.nbegan < 12) run.began[run.nbegan++] = Q[q];
+  }
   // Q[4..7]: only the least-loaded-stream assignment below uses them (one-chunk batches without heavy tasks)
   // upload stream (and the big launches'): consecutive ordinary chunks alternate between two, so that a chunk's upload
   // and DP do not queue behind the previous chunk's (with heavy tasks in the batch Q[0], Q[1], Q[4], Q[5] are theirs)
@@ -245,7 +264,8 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       gs_off += L.lds * L.cnt;
     }
     launch_dp(L, sdp, run.d_plan + pb, run.d_order + ob + L.off, run.d_pool, run.sk, dir_reg, run.d_out, slabs,
-              (unsigned long long *)ctx->misc_buf.p + 1);
+              (unsigned long long *)ctx->misc_buf.p + 1, ctx->stripe_spin_cap);
+    if (L.bs >= 300 && L.bs < 500) run.any_stripe = true;
     ++ctx->launches;
   }
   for (int q = 0; q < 8; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
@@ -296,6 +316,93 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   return SDF_OK;
 }
 
+// One workgroup per re-run task: its record over the one the stripe kernel left (n_cigar = -1), its CIGAR runs to the end
+// of the task's staging slot, where the compaction looks for them (in walk order: a reversed CIGAR is turned back, the
+// compaction reverses it again).
+struct RerunMap {
+  int32_t out_idx, cig_cap, flag, pad;
+  int64_t cig_slot;
+};
+__global__ __launch_bounds__(64) void rerun_merge_kernel(const RerunMap *__restrict__ map, const sdf_result *__restrict__ rr_out,
+                                                         const uint32_t *__restrict__ rr_cig, sdf_result *__restrict__ res,
+                                                         uint32_t *__restrict__ stage) {
+  const RerunMap m = map[blockIdx.x];
+  const sdf_result r = rr_out[blockIdx.x];
+  const int nc = r.n_cigar;
+  if (nc > 0 && nc <= m.cig_cap) {
+    const uint32_t *src = rr_cig + r.cigar_off;
+    uint32_t *dst = stage + m.cig_slot + (m.cig_cap - nc);
+    const bool rev = (m.flag & SDF_FLAG_REV_CIGAR) != 0;
+    for (int c = threadIdx.x; c < nc; c += 64) dst[c] = src[rev ? nc - 1 - c : c];
+  }
+  if (threadIdx.x == 0) {
+    sdf_result o = r;
+    o.cigar_off = 0;
+    res[m.out_idx] = o;
+  }
+}
+
+// Tasks a stripe kernel gave up (extz2_stripe.hip: stripe_abandon) run again, in this call, on the kernels that keep a
+// task inside one wavefront or workgroup: a second context of this device without the stripe kernels aligns them into
+// buffers of their own, and their records and CIGAR runs are merged into this batch before its CIGARs are scanned.
+static int rerun_abandoned(BatchRun &run, unsigned long long count) {
+  sdf_ctx *ctx = run.ctx;
+  hipStream_t st = run.st;
+  unsigned long long *d_gave = (unsigned long long *)ctx->misc_buf.p + 1;
+  if (count > SDF_GAVEUP_CAP) {
+    ctx->err = "internal: stripe wavefronts gave up waiting for their neighbours on more tasks than can be re-run";
+    return SDF_ERR_INVALID;
+  }
+  std::vector<uint32_t> idx(count);
+  SDF_HIP(hipMemcpyAsync(idx.data(), d_gave + SDF_GAVEUP_LIST, count * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  std::sort(idx.begin(), idx.end());
+  // their plan entries (staging slots): one pass over the batch's plan
+  std::vector<RerunMap> map(count);
+  std::vector<sdf_task> sub(count);
+  size_t found = 0, cig_cap = 4;
+  for (size_t k = 0; k < run.cut->ntask_total; ++k) {
+    const PlanTask &p = run.plan[k];
+    const auto it = std::lower_bound(idx.begin(), idx.end(), (uint32_t)p.out_idx);
+    if (it == idx.end() || *it != (uint32_t)p.out_idx) continue;
+    const size_t j = (size_t)(it - idx.begin());
+    map[j] = {p.out_idx, p.cig_cap, p.flag, 0, p.cig_slot};
+    sub[j] = run.tasks[p.out_idx];
+    cig_cap += (size_t)p.cig_cap;
+    ++found;
+  }
+  if (found != count) {
+    ctx->err = "internal: give-up list names a task that is not in the plan";
+    return SDF_ERR_INVALID;
+  }
+  if (!ctx->rerun_ctx) {
+    ctx->rerun_ctx = sdf_create(ctx->device, ctx->ws_budget / 4);
+    if (!ctx->rerun_ctx) {
+      ctx->err = "cannot create the context that re-runs the tasks a stripe kernel gave up";
+      return SDF_ERR_NOMEM;
+    }
+    ctx->rerun_ctx->no_stripe = true;
+    ctx->rerun_ctx->bstripe_min_rows = 0;
+  }
+  SDF_HIP(ctx->rr_out.reserve(count * sizeof(sdf_result)));
+  SDF_HIP(ctx->rr_cig.reserve(cig_cap * 4));
+  SDF_HIP(ctx->rr_map.reserve(count * sizeof(RerunMap)));
+  size_t used = 0;
+  const int rc = sdf_extz2_batch_device(ctx->rerun_ctx, run.scoring, sub.data(), count, run.d_pool, run.want,
+                                        (sdf_result *)ctx->rr_out.p, (uint32_t *)ctx->rr_cig.p, cig_cap, &used, st);
+  if (rc != SDF_OK) {
+    ctx->err = std::string("re-run of abandoned stripe tasks: ") + sdf_last_error(ctx->rerun_ctx);
+    return rc;
+  }
+  SDF_HIP(hipMemcpyAsync(ctx->rr_map.p, map.data(), count * sizeof(RerunMap), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(rerun_merge_kernel, dim3((unsigned)count), dim3(64), 0, st, (const RerunMap *)ctx->rr_map.p,
+                     (const sdf_result *)ctx->rr_out.p, (const uint32_t *)ctx->rr_cig.p, run.d_out, run.d_stage);
+  SDF_HIP(hipMemsetAsync(d_gave, 0, sizeof(unsigned long long), st));
+  SDF_HIP(hipStreamSynchronize(st));  // (`map` is pageable host memory)
+  ctx->reran = (long long)count;
+  return SDF_OK;
+}
+
 // Closes the batch on the caller's stream: waits for every chunk's traceback, scans n_cigar into cigar_off,
 // compacts the CIGARs into the caller's pool and reads the timing events.
 static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_cap, size_t *cigar_used) {
@@ -307,12 +414,19 @@ static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_c
   unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
   hipEvent_t ev_c0 = next_event(ctx, run.evc), ev_c1 = next_event(ctx, run.evc), ev_end = next_event(ctx, run.evc);
   SDF_HIP(hipEventRecord(ev_c0, st));
-  unsigned long long total = 0, gave_up = 0;  // (misc word 1: stripe wavefronts that gave up waiting for a neighbour)
+  unsigned long long total = 0, gave_up = 0;  // (misc word 1: tasks whose stripe wavefronts gave up waiting for a neighbour)
   const size_t np = run.cut->ntask_total;
+  if (run.any_stripe) {  // (one more round trip, for batches with stripe launches only)
+    SDF_HIP(hipMemcpyAsync(&gave_up, d_total + 1, sizeof(gave_up), hipMemcpyDeviceToHost, st));
+    SDF_HIP(hipStreamSynchronize(st));
+    if (gave_up)
+      if (int rc = rerun_abandoned(run, gave_up)) return rc;
+    gave_up = 0;
+  }
   if (run.want_cigar) {
     {
       const int nb = (int)((n + 1023) / 1024);
-      unsigned long long *d_part = d_total + 32;
+      unsigned long long *d_part = d_total + SDF_MISC_PARTS;
       hipLaunchKernelGGL(cigar_scan_blocks_kernel, dim3((unsigned)nb), dim3(1024), 0, st, run.d_out, (int)n, d_part);
       hipLaunchKernelGGL(cigar_scan_parts_kernel, dim3(1), dim3(1024), 0, st, d_part, nb, d_total);
       hipLaunchKernelGGL(cigar_scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, run.d_out, (int)n,

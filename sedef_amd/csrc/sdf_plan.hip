@@ -207,18 +207,25 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         const uint32_t oc = order_entries(t);
         ++blk.nt;
         blk.oc += oc;
-        if (env.want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY)) {
-          const uint32_t words = (uint32_t)(t.qlen + t.tlen + 2);
+        {
+          // A task that wants no CIGAR needs no direction flags -- except on the stripe kernels, whose progress words,
+          // hand-over values and edge columns live in HBM right behind the task's flag blocks: those tasks reserve the
+          // whole layout whatever they want.
+          const bool with_dir = env.want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY);
+          const uint32_t words = with_dir ? (uint32_t)(t.qlen + t.tlen + 2) : 0u;
           cap[k] |= words;
           blk.sw += words;
           const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
           const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
           const size_t nrow = (size_t)t.qlen + t.tlen - 1;
           const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
-          size_t bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
-          if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
-          // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
-          if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
+          size_t bd = 0;
+          if (with_dir) {
+            bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
+            if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+            // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
+            if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
+          }
           if (t.tlen > env.stripe_min && t.tlen <= 8192 && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
             for (int nr = 1; nr <= 4; nr *= 2)
               bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
@@ -629,13 +636,14 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     PlanTask &p = cp[k];
     {
       size_t need = 0;
-      if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
+      // (the stripe kernels keep their inter-stripe words behind the flag blocks: reserved for score-only tasks as well)
+      if (p.pad_ == 5)
+        need = (stripe_dir_bytes(p.qlen, p.tlen, p.nreg) + stripe_sync_bytes(p.qlen, p.tlen, p.nreg) + 255) & ~(size_t)255;
+      else if (p.pad_ == 7)
+        need = (bstripe_dir_bytes(p.qlen, p.tlen, p.w, p.nreg) + bstripe_sync_bytes(p.qlen, p.tlen, p.w, p.nreg) + 255) & ~(size_t)255;
+      else if (!(p.flag & SDF_FLAG_SCORE_ONLY)) {
         const size_t nblk = (size_t)((p.qlen + p.tlen - 1 + 15) / 16);
         if (p.pad_ == 2) need = nblk * (size_t)p.nreg * 512;
-        else if (p.pad_ == 5)
-          need = (stripe_dir_bytes(p.qlen, p.tlen, p.nreg) + stripe_sync_bytes(p.qlen, p.tlen, p.nreg) + 255) & ~(size_t)255;
-        else if (p.pad_ == 7)
-          need = (bstripe_dir_bytes(p.qlen, p.tlen, p.w, p.nreg) + bstripe_sync_bytes(p.qlen, p.tlen, p.w, p.nreg) + 255) & ~(size_t)255;
         else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
         else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
       }

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : tk.pad_ == 7 ? 4 : 1) == LAYOUT &&
            !(tk.flag & SDF_FLAG_SCORE_ONLY);
   sdf_result rr = res[tk.out_idx];
+  active = active && rr.n_cigar != -1;  // (-1: a stripe kernel gave the task up -- nothing to walk; it is run again)
   int i = -1, j = -1;  // (sequences are shorter than 2^31)
   if (active) {
     if (!rr.zdropped && !(tk.flag & SDF_FLAG_EXTZ_ONLY)) {

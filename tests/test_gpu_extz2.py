@@ -722,6 +722,80 @@ def test_banded_stripe_kernel_long_tasks(engine, oracle):
     assert _check_dropped_max(engine, oracle, pairs, ws) >= 3
 
 
+def _stripe_mix(rng):
+    """Tasks of both stripe kernels (wide full band; long banded, some whose band runs out) between ordinary ones."""
+    pairs, ws = [], []
+    for ql, tl, w, indel in [(1500, 1400, -1, 0), (700, 700, 64, 0), (7000, 7000, 128, 0), (2500, 3000, -1, 0),
+                             (300, 310, -1, 0), (8000, 8000, 512, 300), (900, 2000, -1, 0), (6500, 6400, 256, 0),
+                             (1000, 1000, 128, 0), (4100, 4000, -1, 0), (9000, 9000, 300, 700), (50, 60, -1, 0)]:
+        q = random_codes(rng, ql, 0.002 if rng.random() < 0.5 else 0.0)
+        t = mutate(rng, q, 0.05, 0.01, 0.01)
+        if indel:
+            k = int(rng.integers(0, len(t) - indel))
+            t = np.concatenate([t[:k], t[k + indel:]])
+        pairs.append((q, _fit(rng, t, tl)))
+        ws.append(w)
+    return pairs, ws
+
+
+def test_stripe_kernels_score_only(engine, oracle):
+    """The stripe kernels keep their progress words, hand-over values and edge columns in HBM behind a task's direction
+    flags: a task that wants no CIGAR still needs that room.  (a) a whole batch with want = SCORE, (b) SDF_FLAG_SCORE_ONLY
+    on every other task of a CIGAR batch -- the neighbours' CIGARs must not be touched -- on both layouts."""
+    import sedef_amd
+    rng = np.random.default_rng(4242)
+    pairs, ws = _stripe_mix(rng)
+    pairs, ws = pairs * 3, ws * 3  # (several stripe tasks per launch: their sync regions must be disjoint)
+    exp = [oracle.extz2(q, t, w=w) for (q, t), w in zip(pairs, ws)]
+    res, cig = engine.align_pairs(pairs, w=ws, want=sedef_amd.extz2.WANT_SCORE)
+    assert len(cig) == 0 and engine.last_reran() == 0
+    for r, e, w in zip(res, exp, ws):
+        assert (int(r["score"]), int(r["mte"]), int(r["zdropped"]), int(r["n_cigar"])) == (e["score"], e["mte"], e["zdropped"], 0), w
+    SCORE_ONLY = 0x01  # KSW_EZ_SCORE_ONLY (extern/ksw2.h:10)
+    flags = [SCORE_ONLY if k % 2 else 0 for k in range(len(pairs))]
+    for shift in (0, 1):
+        fl = flags[shift:] + flags[:shift]
+        res, cig = engine.align_pairs(pairs, w=ws, flag=fl, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+        for r, e, w, f, (q, t) in zip(res, exp, ws, fl, pairs):
+            assert (int(r["score"]), int(r["mte"]), int(r["zdropped"])) == (e["score"], e["mte"], e["zdropped"]), (w, f)
+            got = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+            if f:
+                assert len(got) == 0
+            else:
+                assert cigar_to_str(got) == cigar_to_str(e["cigar"]), (w, len(q), len(t))
+
+
+def test_stripe_wait_gives_up_and_tasks_run_again(oracle):
+    """A stripe that stops waiting for its left neighbour (SDF_STRIPE_SPIN_CAP polls; the protocol's progress rests on
+    the dispatch order) abandons its TASK; the batch call runs abandoned tasks again on the one-wavefront / one-workgroup
+    kernels inside the same call.  Forced here with a cap of one poll: parity of the merged batch, CIGARs included, with
+    reversed CIGARs and score-only tasks among the abandoned ones, next to tasks that never waited."""
+    import sedef_amd
+    eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1)
+    rng = np.random.default_rng(4343)
+    pairs, ws = _stripe_mix(rng)
+    pairs, ws = pairs * 2, ws * 2
+    REV = 0x80  # KSW_EZ_REV_CIGAR
+    flags = [(REV if k % 3 == 1 else 0) | (0x01 if k % 7 == 5 else 0) for k in range(len(pairs))]
+    want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
+    res, cig = eng.align_pairs(pairs, w=ws, flag=flags, want=want)
+    assert eng.last_reran() >= 6
+    for (q, t), w, f, r in zip(pairs, ws, flags, res):
+        e = oracle.extz2(q, t, w=w, flag=f)
+        assert (int(r["score"]), int(r["mte"]), int(r["zdropped"])) == (e["score"], e["mte"], e["zdropped"]), (w, f)
+        got = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+        assert cigar_to_str(got) == cigar_to_str(e["cigar"]), (w, f, len(q), len(t))
+    # the same context again, a larger batch (heavy split, several chunks): the counters of a call start at zero
+    pairs2, ws2 = pairs * 90, ws * 90
+    res2, cig2 = eng.align_pairs(pairs2, w=ws2, want=want)
+    assert eng.last_reran() >= 100
+    exp = [oracle.extz2(q, t, w=w) for (q, t), w in zip(pairs, ws)]
+    for k, r in enumerate(res2):
+        e = exp[k % len(pairs)]
+        got = cig2[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]
+        assert int(r["score"]) == e["score"] and cigar_to_str(got) == cigar_to_str(e["cigar"]), k
+
+
 def test_pair_kernel_track_band_runs_out(engine, oracle):
     """Banded tasks whose band cannot reach the end of both sequences (|qlen - tlen| > w): the reference stops when
     the band is exhausted and backtracks from the best cell (extern/ksw2_extz2_sse.cc:116, :292-295).  The pair kernel's
