@@ -300,6 +300,67 @@ def encoding_split():
             "source": "committed profile: profiles/pair_kernel_isa.json (profiles/isa_split.py on the device assembly)"}
 
 
+def visible_devices():
+    """HIP devices this process would see, counted WITHOUT initialising the GPU runtime (the launcher below must stay
+    clean of it): the KFD topology's GPU nodes, filtered like the runtime filters them."""
+    nodes = []
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30):
+            try:
+                props = dict(l.split(None, 1) for l in open(os.path.join(base, d, "properties")).read().splitlines() if " " in l)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:  # (CPU nodes have none)
+                nodes.append(d)
+    except OSError:
+        return None
+    n = len(nodes)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(n):
+    """Starts `n` ranks of this script (one per GPU, LOCAL_RANK = device) on this node and waits for them: the
+    rendezvous variables are what `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` would set."""
+    import socket
+    import subprocess
+    have = visible_devices()
+    if os.environ.get("BENCH_DEBUG_ONE_GPU") != "1" and have is not None and have < n:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (n, have), file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = str(so.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if bad and not rc:  # a rank failed: the others would wait for it in a collective forever
+                rc = bad[0]
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()
+        rc = rc or max(abs(p.returncode) for p in procs)
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        rc = 130
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +379,13 @@ def main():
     ap.add_argument("--no-pcie-pass", action="store_true", help="skip the untimed pass that measures value_incl_pcie")
     ap.add_argument("--workspace-gib", type=float, default=48.0)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: this process starts the N ranks itself -- before anything here
+        # has touched the GPU (no torch import, no HIP call so far: a process that has initialised the GPU must not
+        # spawn-and-replace) -- and exits with their worst return code.  Rank 0 prints the JSON line.
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -328,6 +396,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (start it as `python bench.py --gpus N`, or under "
+                         "torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
     # BENCH_DEBUG_ONE_GPU=1: dry-run of the multi-rank path on a single-GPU box (all ranks on
@@ -335,6 +406,8 @@ def main():
     debug_one_gpu = os.environ.get("BENCH_DEBUG_ONE_GPU") == "1"
     if debug_one_gpu:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants device %d, %d visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -343,6 +416,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
     # ---- the workload: every rank's shard of the batch ----
     hg19 = args.workload == "hg19mix"

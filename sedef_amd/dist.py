@@ -62,9 +62,9 @@ class ResultGatherV:
     """All-gatherv of one step's result records and CIGAR words: every rank ends with every rank's results, back to
     back in rank order, exactly `counts[r]` words from rank r (no padding travels).
 
-    `start` exchanges the counts (one small all-gather), then enqueues one broadcast per root and payload on the exact
-    sizes -- RCCL has no native gatherv; on the fully connected xGMI mesh the `world` broadcasts of a group are
-    one-hop transfers running side by side -- and returns; the caller computes the next step into ANOTHER set of
+    `start` exchanges the counts (one small all-gather and a host read of its 2 * world words: the exact ranges size the
+    receive buffers), then enqueues ONE group of point-to-point transfers on the exact sizes -- RCCL has no native
+    gatherv; two collectives per step whatever the world size -- and returns; the caller computes the next step into ANOTHER set of
     buffers and calls `wait` before it reuses this set or reads `result`.  With the nccl backend `wait` makes the
     CURRENT torch stream wait for the collectives: the caller must launch the work that reuses the buffers on that
     stream (bench.py runs the engine on a torch stream for this reason).  Buffers grow on demand and are reused."""
@@ -106,13 +106,23 @@ class ResultGatherV:
         # own part: a local copy; the other parts: broadcasts from their owners into the exact ranges
         self.recs[rec_off[self.rank]:rec_off[self.rank + 1]].copy_(records)
         self.cig[cig_off[self.rank]:cig_off[self.rank + 1]].copy_(cigars[:used])
-        self.keep = (records, cigars)  # the sources must stay alive until the collectives are done
-        self.handles = []
+        self.keep = (records, cigars)  # the sources must stay alive until the transfers are done
+        # ONE group of point-to-point transfers (batch_isend_irecv: ncclGroupStart ... ncclGroupEnd on RCCL): this rank's
+        # two ranges to every peer, every peer's two ranges into their places here.  Every rank derives the same list
+        # from the same counts table, so sends and receives of a pair match in order; empty ranges are skipped on both
+        # sides.  On the fully connected xGMI mesh the world - 1 transfers of a rank run side by side, one hop each.
+        ops = []
+        me = self.rank
         for r in range(self.world):
-            src = dist.get_global_rank(self.group, r) if self.group is not None else r
+            if r == me:
+                continue
+            peer = dist.get_global_rank(self.group, r) if self.group is not None else r
             for buf, off in ((self.recs, rec_off), (self.cig, cig_off)):
+                if off[me + 1] > off[me]:
+                    ops.append(dist.P2POp(dist.isend, buf[off[me]:off[me + 1]], peer, self.group))
                 if off[r + 1] > off[r]:
-                    self.handles.append(dist.broadcast(buf[off[r]:off[r + 1]], src=src, group=self.group, async_op=True))
+                    ops.append(dist.P2POp(dist.irecv, buf[off[r]:off[r + 1]], peer, self.group))
+        self.handles = dist.batch_isend_irecv(ops) if ops else []
 
     def wait(self):
         for h in self.handles:

@@ -16,13 +16,13 @@ def _free_port():
     return p
 
 
-def _spawn(fn, *args):
+def _spawn(fn, *args, world=2):
     import torch.multiprocessing as mp
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(fn, args=(2, port, out) + args, nprocs=2, join=True)
-    assert out.get(0) is True and out.get(1) is True, dict(out)
+    mp.spawn(fn, args=(world, port, out) + args, nprocs=world, join=True)
+    assert all(out.get(r) is True for r in range(world)), dict(out)
 
 
 def _init(rank, world, port):
@@ -91,6 +91,55 @@ def _worker_gatherv(rank, world, port, out):
 
 def test_allgatherv_world2_gloo():
     _spawn(_worker_gatherv)
+
+
+def _worker_gatherv_ragged(rank, world, port, out):
+    """Three ranks, one with records but no CIGAR words, one with nothing at all: the grouped point-to-point transfers
+    skip the empty ranges on both sides and still match."""
+    import torch
+    dist = _init(rank, world, port)
+    from sedef_amd.dist import ResultGatherV
+    try:
+        ids = [np.arange(0, 700, 7), np.arange(1, 400), np.zeros(0, np.int64)]  # rank 0: n_cigar = id % 7 = 0 everywhere
+        g = ResultGatherV(torch.device("cpu"), torch.int32)
+        ok = True
+        for step in range(3):  # (buffers are reused: same group of transfers again)
+            rec, cig = _fake_results(ids[rank])
+            g.start(torch.from_numpy(rec.reshape(-1)), torch.from_numpy(cig), len(cig))
+            ra, ca, counts = g.result()
+            for r in range(world):
+                er, ec = _fake_results(ids[r])
+                pr, pc = g.part(r)
+                ok &= np.array_equal(pr.numpy(), er.reshape(-1)) and np.array_equal(pc.numpy(), ec)
+            ok &= counts[:, 0].tolist() == [1600, 399 * 16, 0] and int(counts[0, 1]) == 0 and int(counts[2, 1]) == 0
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgatherv_world3_empty_ranges_gloo():
+    _spawn(_worker_gatherv_ragged, world=3)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher typed by the caller: the script starts N ranks itself, before it
+    touches the GPU.  Without a GPU (this test runs in the build container) every rank must refuse to run -- the product
+    path has no CPU fallback -- and the launcher must hand the failure on; under a launcher whose world size differs from
+    --gpus it refuses as well."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form of this test is tests/test_bench_launch.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert p.stderr.count("bench.py needs a HIP device") == 2, p.stderr  # one refusal per rank
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE is 2" in p.stderr
 
 
 def _worker_strong(rank, world, port, out):
