@@ -73,6 +73,19 @@ def _as_dict(max_, zd, r, n_cigar, cigar_ptr):
                 mqe_t=r.mqe_t, mte=r.mte, mte_q=r.mte_q, score=r.score, cigar=cig)
 
 
+def _segtree_script(fn, pts, ops):
+    pts = np.ascontiguousarray(pts, dtype=np.int32).reshape(-1, 2)
+    ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 5)
+    out = np.zeros((max(len(ops), 1), 2), np.int32)
+    cap = 4 << max(1, int(len(pts) - 1).bit_length())
+    state = np.zeros(cap, np.int32)
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    size = fn(pts.ctypes.data, len(pts), ops.ctypes.data, len(ops), out.ctypes.data, state.ctypes.data, cap)
+    assert 0 < size <= cap, size
+    return out[:len(ops)].copy(), state[:size].copy()
+
+
 class Oracle:
     def __init__(self):
         self.lib = C.CDLL(build_oracle())
@@ -91,6 +104,34 @@ class Oracle:
         L.sdfo_cigar_counts.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+
+    def segtree_script(self, pts, ops):
+        """chain_oracle.c: replays activate / deactivate / rmq calls on the restated SegmentTree.  pts: n x 2 keys;
+        ops: k x 5 (see oracle/ref_align_driver.cc: ref_segtree_script).  Returns (out [k, 2], p pointers of all nodes)."""
+        return _segtree_script(self.lib.sdfo_segtree_script, pts, ops)
+
+    def chain_anchors(self, anchors, max_chain_gap=210, match_chain_score=4, want_ops=False):
+        """chain_oracle.c: chain_anchors (src/chain.cc:103-199).  anchors: n x (q, r, l, has_u).  Returns a dict with
+        path, bounds [(pos, any_upper)], dp, prev [, ops: the tree calls of the sweep]."""
+        a = np.ascontiguousarray(anchors, dtype=np.int32).reshape(-1, 4)
+        n = len(a)
+        path = np.zeros(max(n, 1), np.int32)
+        bounds = np.zeros(2 * (n + 1), np.int32)
+        nb, nops = C.c_int(0), C.c_int(0)
+        dp, prev = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        ops = np.zeros((4 * n + 1, 5), np.int32) if want_ops else None
+        f = self.lib.sdfo_chain_anchors
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        rc = f(a.ctypes.data, n, max_chain_gap, match_chain_score, path.ctypes.data, bounds.ctypes.data, C.byref(nb),
+               dp.ctypes.data, prev.ctypes.data, ops.ctypes.data if want_ops else None, C.byref(nops))
+        assert rc == 0
+        d = dict(path=path[:n].copy(), bounds=bounds[:2 * nb.value].reshape(-1, 2).copy(), dp=dp[:n].copy(),
+                 prev=prev[:n].copy())
+        if want_ops:
+            d["ops"] = ops[:nops.value].copy()
+        return d
 
     def stats_columns(self, a, b, cigar, want_columns=False):
         """stats_oracle.c: a, b FASTA characters (str / bytes), cigar uint32 runs len << 4 | op (0 M, 1 D, 2 I).
@@ -322,6 +363,11 @@ class ReferenceAlign:
         assert rc == 0
         n, s, r = self.buf.value.decode().split("|")
         return n, s, r == "1"
+
+    def segtree_script(self, pts, ops):
+        """The reference's own SegmentTree<T> (src/segment.h, src/segment.tpp) driven by a script of activate /
+        deactivate / rmq calls (oracle/ref_align_driver.cc: ref_segtree_script).  At least two points."""
+        return _segtree_script(self.lib.ref_segtree_script, pts, ops)
 
     def set_scoring(self, match=5, mismatch=-4, gap_open=-40, gap_extend=-1):
         """Globals::Align::* as the CLI overrides set them (src/align_main.cc:343-352); process-wide in the reference."""

@@ -3,8 +3,11 @@
 // without Boost (see Makefile `refalign`).  It only constructs objects through the reference's public
 // interface and prints what it returns; the refinement loop below calls the reference's merge() and
 // guide constructor in the order refine_chains does (src/refine.cc:163-183).
+#include <algorithm>
+#include <cassert>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -15,6 +18,7 @@
 #include "hash.h"
 #include "hit.h"
 #include "merge.h"
+#include "segment.h"
 
 using namespace std;
 
@@ -164,6 +168,47 @@ int ref_alignment_from_cigar(const char *fa, const char *fb, const char *cigar, 
   counts[3] = al.gap_bases();
   counts[4] = al.span();
   return emit(al.span() ? al.print(-1, true) : string("\n\n\n\n"), out, cap);
+}
+
+// SegmentTree<T> (src/segment.h:21-56, src/segment.tpp:12-172), the priority search tree chain_anchors keeps its
+// candidate predecessors in, instantiated on a point type shaped like chain_anchors' own (`Coor`, src/chain.cc:106-110:
+// that struct is local to a function of a file that cannot be compiled here) and driven through its public interface
+// by a script: which of several equally good points a range query returns is decided by the tree's shape and history
+// (the `>=` / `>` of segment.tpp:62,89,128), and this is where that rule is pinned.
+//   pts[2 i], pts[2 i + 1]: x of point i (pos = i); the constructor sorts them (n >= 2: it takes clz(n - 1)).
+//   ops[5 k ..]: {0, x.first, x.second, score, -} activate; {1, x.first, x.second, -, -} deactivate;
+//                {2, p.first, p.second, q.first, q.second} rmq(p, q) -> out[2 k] = pos of the returned point (-1: none),
+//                out[2 k + 1] = its score (an inactive leaf can be returned: score = MIN).
+//   state[i] = tree[i].p after the script, i < tree.size() (returned; state may be null).
+namespace {
+struct RefCoor {
+  pair<int, int> x;
+  int score, pos;
+  bool operator<(const RefCoor &a) const { return x < a.x; }
+};
+}  // namespace
+int ref_segtree_script(const int *pts, int n, const int *ops, int nops, int *out, int *state, int state_cap) {
+  if (n < 2) return -1;
+  vector<RefCoor> ys;
+  for (int i = 0; i < n; i++) ys.push_back({{pts[2 * i], pts[2 * i + 1]}, SegmentTree<RefCoor>::MIN, i});
+  SegmentTree<RefCoor> tree(ys);
+  for (int k = 0; k < nops; k++) {
+    const int *o = ops + 5 * k;
+    out[2 * k] = out[2 * k + 1] = -2;
+    if (o[0] == 0) {
+      tree.activate({o[1], o[2]}, o[3]);
+    } else if (o[0] == 1) {
+      tree.deactivate({o[1], o[2]});
+    } else {
+      const int j = tree.rmq({o[1], o[2]}, {o[3], o[4]});
+      out[2 * k] = j == -1 ? -1 : ys[j].pos;
+      out[2 * k + 1] = j == -1 ? 0 : ys[j].score;
+    }
+  }
+  const int size = (int)tree.tree.size();
+  if (state)
+    for (int i = 0; i < size && i < state_cap; i++) state[i] = tree.tree[i].p;
+  return size;
 }
 
 // CLI scoring overrides (src/align_main.cc:343-352 assign these statics; src/align.cc:84-86,343-456 read them)

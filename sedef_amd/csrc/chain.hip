@@ -324,4 +324,35 @@ __global__ __launch_bounds__(64) void chain_kernel(const sdf_anchor *__restrict_
   nbound[p] = nb;
 }
 
+// Test hook (tests/test_chain_oracle.py): one thread replays a script of activate / deactivate / rmq calls on the device
+// tree above, in the script format of oracle/ref_align_driver.cc: ref_segtree_script (which drives the reference's own
+// SegmentTree class).  work: 4 n + 4 size words (points, nodes).
+__global__ void chain_tree_script_kernel(const int32_t *__restrict__ pts_in, int n, const int32_t *__restrict__ ops, int nops,
+                                         int32_t *__restrict__ work, int size, int32_t *__restrict__ out,
+                                         int32_t *__restrict__ state) {
+  if (blockIdx.x || threadIdx.x) return;
+  Pt *pts = reinterpret_cast<Pt *>(work);
+  Node *nodes = reinterpret_cast<Node *>(work + 4 * n);
+  for (int i = 0; i < n; ++i) pts[i] = Pt{P2{pts_in[2 * i], pts_in[2 * i + 1]}, TREE_MIN, i};
+  heap_sort(pts, n, [](const Pt &x, const Pt &y) { return lt(x.x, y.x); });
+  for (int i = 0; i < size; ++i) nodes[i] = Node{-1, -1, P2{0, 0}};
+  Tree tr{nodes, pts, size};
+  tr.build(n);
+  for (int k = 0; k < nops; ++k) {
+    const int32_t *o = ops + 5 * k;
+    out[2 * k] = out[2 * k + 1] = -2;
+    if (o[0] == 0) {
+      tr.activate(P2{o[1], o[2]}, o[3]);
+    } else if (o[0] == 1) {
+      tr.deactivate(P2{o[1], o[2]});
+    } else {
+      const int nd = tr.rmq(P2{o[1], o[2]}, P2{o[3], o[4]});
+      const int j = nd == -1 ? -1 : nodes[nd].a;
+      out[2 * k] = j == -1 ? -1 : pts[j].pos;
+      out[2 * k + 1] = j == -1 ? 0 : pts[j].score;
+    }
+  }
+  for (int i = 0; i < size; ++i) state[i] = nodes[i].p;
+}
+
 }  // namespace sdf

@@ -181,6 +181,11 @@ class RangeMax {
     }
   }
 
+  int dump_tops(int *state, int cap) const {  // (test hook: the node each node's best point sits in)
+    for (int i = 0; i < (int)top.size() && i < cap; i++) state[i] = top[(size_t)i];
+    return (int)top.size();
+  }
+
  private:
   int leaf_of(int64_t k) const {
     int i = 0;
@@ -192,6 +197,30 @@ class RangeMax {
   mutable std::vector<int> stack_;
 };
 }  // namespace
+
+// Test hook: replays a script of activate / deactivate / best_in calls on a RangeMax over the given points -- the same
+// script format as oracle/ref_align_driver.cc: ref_segtree_script, which drives the reference's own SegmentTree class;
+// the tests compare every answer and the tree's final state.  pts[2 i + 1] must be i.
+int rangemax_script(const int *pts, int n, const int *ops, int nops, int *out, int *state, int state_cap) {
+  std::vector<int64_t> keys((size_t)n);
+  for (int i = 0; i < n; i++) keys[(size_t)i] = key_of(pts[2 * i], pts[2 * i + 1]);
+  std::sort(keys.begin(), keys.end());
+  RangeMax tree(keys);
+  for (int k = 0; k < nops; k++) {
+    const int *o = ops + 5 * k;
+    out[2 * k] = out[2 * k + 1] = -2;
+    if (o[0] == 0) {
+      tree.activate(key_of(o[1], o[2]), o[3]);
+    } else if (o[0] == 1) {
+      tree.deactivate(key_of(o[1], o[2]));
+    } else {
+      const int pt = tree.best_in(key_of(o[1], o[2]), key_of(o[3], o[4]));
+      out[2 * k] = pt == -1 ? -1 : (int)(uint32_t)tree.key[(size_t)pt];
+      out[2 * k + 1] = pt == -1 ? 0 : tree.score[(size_t)pt];
+    }
+  }
+  return tree.dump_tops(state, state_cap);
+}
 
 std::pair<std::vector<int>, std::vector<std::pair<int, bool>>> chain_anchors(std::vector<Anchor> &anchors,
                                                                             const Params &P) {

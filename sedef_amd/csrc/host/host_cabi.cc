@@ -372,6 +372,11 @@ int sdfh_chain_raw(const int32_t *anchors, int m, int max_chain_gap, int match_c
   }
 }
 
+// Test hook: the priority search tree of chain_anchors driven by a script (see chain.cc: rangemax_script)
+int sdfh_rangemax_script(const int *pts, int n, const int *ops, int nops, int *out, int *state, int state_cap) {
+  return rangemax_script(pts, n, ops, nops, out, state, state_cap);
+}
+
 // Hit::extend (reference: src/hit.cc:200-207): io = {query_start, query_end, ref_start, ref_end}
 int sdfh_hit_extend(int *io, double factor, int max_extend) {
   Hit h;

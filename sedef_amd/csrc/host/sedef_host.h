@@ -276,6 +276,9 @@ std::vector<Anchor> generate_anchors(const std::string &query, const std::string
 std::pair<std::vector<int>, std::vector<std::pair<int, bool>>> chain_anchors(std::vector<Anchor> &anchors,
                                                                             const Params &p);
 
+// test hook (tests/test_chain_oracle.py): a script of tree operations on chain_anchors' range-maximum structure
+int rangemax_script(const int *pts, int n, const int *ops, int nops, int *out, int *state, int state_cap);
+
 // ---- per-pair job: fast_align (src/chain.cc:203-268) + refine_chains (src/refine.cc:23-193), staged ----
 class PairJob {
  public:

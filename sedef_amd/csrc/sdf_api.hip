@@ -748,6 +748,33 @@ extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const in
   return SDF_OK;
 }
 
+// Test hook: a script of tree operations on chain.hip's device tree (host buffers; one GPU thread).  Returns the number
+// of tree nodes (state[i] = node i's p pointer, i < min(nodes, state_cap)) or a negative error code.
+extern "C" int sdf_debug_chain_tree_script(sdf_ctx *ctx, const int32_t *pts, int n, const int32_t *ops, int nops, int32_t *out,
+                                           int32_t *state, int state_cap) {
+  if (!ctx || !pts || n < 1 || nops < 0 || (nops && (!ops || !out))) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  int bits = 0;
+  for (unsigned v = (unsigned)n - 1u; v; v >>= 1) ++bits;
+  const int size = (1 << bits) << 1;
+  SDF_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t w_pts = (size_t)2 * n, w_ops = (size_t)5 * std::max(nops, 1), w_work = (size_t)4 * n + (size_t)4 * size,
+               w_out = (size_t)2 * std::max(nops, 1);
+  SDF_HIP(ctx->ch_work.reserve((w_pts + w_ops + w_work + w_out + size) * 4 + 64));
+  int32_t *d = (int32_t *)ctx->ch_work.p;
+  int32_t *d_pts = d, *d_ops = d_pts + w_pts, *d_work = d_ops + w_ops, *d_out = d_work + w_work, *d_state = d_out + w_out;
+  SDF_HIP(hipMemcpyAsync(d_pts, pts, w_pts * 4, hipMemcpyHostToDevice, st));
+  if (nops) SDF_HIP(hipMemcpyAsync(d_ops, ops, (size_t)5 * nops * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(sdf::chain_tree_script_kernel, dim3(1), dim3(64), 0, st, d_pts, n, d_ops, nops, d_work, size, d_out, d_state);
+  SDF_HIP(hipGetLastError());
+  if (nops) SDF_HIP(hipMemcpyAsync(out, d_out, (size_t)2 * nops * 4, hipMemcpyDeviceToHost, st));
+  if (state && state_cap > 0)
+    SDF_HIP(hipMemcpyAsync(state, d_state, (size_t)std::min(size, state_cap) * 4, hipMemcpyDeviceToHost, st));
+  SDF_HIP(hipStreamSynchronize(st));
+  return size;
+}
+
 // ---- per-alignment columns of `stats generate` (reference: src/stats_main.cc:228-270) -------------------
 extern "C" int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_tasks, size_t n, const char *d_seq_pool,
                                         const uint32_t *d_cigar_pool, sdf_stats_cols *d_out, void *stream) {

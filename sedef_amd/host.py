@@ -116,6 +116,21 @@ def chain_raw(anchors, max_chain_gap=210, match_chain_score=4):
     return path[:m].copy(), bounds[:2 * nb].reshape(-1, 2).copy()
 
 
+def rangemax_script(pts, ops):
+    """Test hook: activate / deactivate / range-maximum calls on the host's priority search tree (chain.cc: RangeMax), in the
+    script format of oracle/ref_align_driver.cc: ref_segtree_script.  Returns (out [k, 2], top pointer of every node)."""
+    import numpy as np
+    lib = load_host()
+    pts = np.ascontiguousarray(pts, dtype=np.int32).reshape(-1, 2)
+    ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 5)
+    out = np.zeros((max(len(ops), 1), 2), np.int32)
+    cap = 4 << max(1, int(len(pts) - 1).bit_length())
+    state = np.zeros(cap, np.int32)
+    lib.sdfh_rangemax_script.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    size = lib.sdfh_rangemax_script(pts.ctypes.data, len(pts), ops.ctypes.data, len(ops), out.ctypes.data, state.ctypes.data, cap)
+    return out[:len(ops)].copy(), state[:size].copy()
+
+
 def fasta_get(path, name, start, end):
     lib, buf = load_host(), _buffer()
     e = C.c_int(0 if end is None else end)

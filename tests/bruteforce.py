@@ -16,11 +16,13 @@ code (sedef_amd/csrc/host) and the HIP kernels can be checked against something 
     0 <= i.q-(t.q+t.l) <= MAX_CHAIN_GAP (src/chain.cc:142-152) and 0 <= i.r-(t.r+t.l) <= MAX_CHAIN_GAP-1
     (src/chain.cc:157-158).  The tree returns a predecessor of maximal stored score dp[t]-(distance of t's end to the
     far corner) (src/chain.cc:175-176); WHICH one among equal scores depends on the priority-search tree's shape and
-    activation history (src/segment.tpp:62,89,128), so the checker treats every maximal one as admissible: dp values do
+    activation history (src/segment.tpp:62,89,128), so `check` treats every maximal one as admissible: dp values do
     not depend on the choice (dp[i] = w + stored + const(i)), only the `prev` pointers do.  Checked exactly: dp values
     through the chain order, chain starts (score-descending, index-descending, src/chain.cc:179-186), that each link
     is an admissible predecessor, that each chain stops exactly where no positive predecessor exists or the taken one
-    is used.  When no ties occur the expected output is unique and compared for equality.
+    is used.  The tie winner itself is pinned elsewhere: oracle/chain_oracle.c restates the tree, tests/test_chain_oracle.py
+    holds it equal to the reference's own SegmentTree class on tie-rich scripts, and `check_exact` compares a result with
+    the oracle's chains for equality -- ties included -- after checking the oracle's result against this definition.
 """
 import numpy as np
 
@@ -131,6 +133,15 @@ class ChainCheck:
                 i = next(iter(self.opt[i])) if self.opt[i] else -1
             bounds.append((len(path), int(bool(hu))))
         return path, bounds
+
+    def check_exact(self, path, bounds, oracle_result):
+        """`oracle_result` (oracle.binding.Oracle.chain_anchors: the sweep on the pinned tree) is itself admissible by
+        this definition, and (path, bounds) equals it exactly -- with the tie winners the reference's tree picks."""
+        assert np.array_equal(oracle_result["dp"], self.dp)
+        self.check(oracle_result["path"], oracle_result["bounds"])
+        assert np.array_equal(np.asarray(path, np.int64), oracle_result["path"]), "path differs from the oracle's"
+        assert np.array_equal(np.asarray(bounds, np.int64).reshape(-1, 2), oracle_result["bounds"]), "boundaries differ"
+        return True
 
     def check(self, path, bounds):
         """Asserts that (path, boundaries) is an output chain_anchors can produce for these anchors."""

@@ -154,7 +154,7 @@ def _chain_cases(host, rng, n_real, n_rand):
     return cases
 
 
-def test_host_chains_pass_bruteforce_check(host):
+def test_host_chains_pass_bruteforce_check(host, oracle):
     rng = np.random.default_rng(41)
     unique = 0
     cases = _chain_cases(host, rng, 24, 24)
@@ -163,6 +163,9 @@ def test_host_chains_pass_bruteforce_check(host):
             chk = bruteforce.ChainCheck(a, gap, score)
             path, bounds = host.chain_raw(a, gap, score)
             chk.check(path, bounds)
+            # ... and, ties included, exactly the chains of the oracle, whose tree is pinned on the reference's class
+            # (tests/test_chain_oracle.py)
+            chk.check_exact(path, bounds, oracle.chain_anchors(a, gap, score))
             exp = chk.expected_if_unique()
             if exp is not None:
                 unique += 1
@@ -171,7 +174,7 @@ def test_host_chains_pass_bruteforce_check(host):
 
 
 @pytest.mark.gpu
-def test_gpu_chains_pass_bruteforce_check(host):
+def test_gpu_chains_pass_bruteforce_check(host, oracle):
     import sedef_amd
     eng = sedef_amd.Extz2Engine(0)
     rng = np.random.default_rng(42)
@@ -181,6 +184,7 @@ def test_gpu_chains_pass_bruteforce_check(host):
         for a, (gp, gb) in zip(cases, got):
             chk = bruteforce.ChainCheck(a, gap, score)
             chk.check(gp, gb)
+            chk.check_exact(gp, gb, oracle.chain_anchors(a, gap, score))
             exp = chk.expected_if_unique()
             if exp is not None:
                 assert list(gp) == exp[0] and [tuple(b) for b in gb] == exp[1]
