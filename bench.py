@@ -288,6 +288,35 @@ def batch_cells(qlen, tlen, w):
     return cu[inv.reshape(-1)]
 
 
+def measured_copy_bandwidth(dev, mib=1024, reps=5):
+    """Achievable HBM bandwidth of this box, GB/s: a device-to-device copy of `mib` MiB timed with events on the current
+    stream, bytes read + bytes written over the best of `reps` (the second roofline denominator next to the
+    nominal 8 TB/s)."""
+    import torch
+    n = mib << 20
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.fill_(1)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
+def source_sha256(rel):
+    import hashlib
+    with open(os.path.join(ROOT, rel), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def encoding_split():
     """Per-encoding instruction counts of the steady row of the dominant kernel, from the committed ISA summary
     (profiles/pair_kernel_isa.json, made by profiles/isa_split.py from the device assembly of the built library)."""
@@ -585,13 +614,20 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9
         traffic = None
         valu = None
+        traffic_note = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp) and headline and n == 100000 and w == 128 and args.qlen == 1000:
             # NOT measured in this run: read from the committed rocprofv3 PMC passes of this exact workload and launch
             # (profiles/README.md, profiles/collect.sh)
             pmc = json.load(open(tp))
-            traffic = pmc.get("bytes_per_step") / iso_launches
-            if pmc.get("valu_insts_per_step"):
+            # ... and only while the kernel they were taken on is the kernel that ran: the JSON carries the sha256 of
+            # extz2_pair.hip at collection time (profiles/make_traffic_json.py); after any edit of that file the
+            # counters are stale and the line says null until profiles/collect.sh has run again
+            stale = pmc.get("kernel_source_sha256") != source_sha256("sedef_amd/csrc/extz2_pair.hip")
+            traffic_note = "profiles/hbm_traffic.json is older than sedef_amd/csrc/extz2_pair.hip: counters dropped" if stale else None
+            if not stale:
+                traffic = pmc.get("bytes_per_step") / iso_launches
+            if not stale and pmc.get("valu_insts_per_step"):
                 # What actually bounds the launch: VALU issue.  Counted wavefront VALU instructions over what the SIMDs can
                 # issue in the launch's live-measured duration, against BOTH rates: one per 2 cycles (MI355X_MICROARCH.md:
                 # wave64 on a SIMD-32) and one per 4.2 cycles (the measured rate of the VOP3P / VOP3 / DPP encodings
@@ -606,6 +642,8 @@ def main():
                         "steady_row_by_encoding": encoding_split(),
                         "source": "committed profile: " + str(pmc.get("valu_source"))}
         value = cells_all * args.steps / dt / 1e9
+        with torch.cuda.stream(estream):
+            peak_measured = measured_copy_bandwidth(dev)
         # End to end over PCIe (never `value`): H2D of the packed sequences, the batch, D2H of the results, back to back
         # without overlap, untimed extra passes (include/sedef_hip.h: sdf_extz2_batch is this plus packing on the host)
         incl_pcie = None
@@ -652,8 +690,12 @@ def main():
                                    "host_planning": round(plan_ms / args.steps, 3),
                                    "host_call_total": round(call_ms / args.steps, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": "committed profile (profiles/hbm_traffic.json), not measured in this run" if traffic else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "peak_measured": round(peak_measured, 1), "frac_of_measured": round(achieved / peak_measured, 5),
+                         "peak_measured_how": "device-to-device copy of 1 GiB in this run, read + write bytes over the best of 5",
+                         "traffic": traffic,
+                         "traffic_source": ("committed profile (profiles/hbm_traffic.json), not measured in this run" if traffic
+                                            else traffic_note),
                          "kernel": "extz2_pair_kernel<3> (extz2 DP)" if not hg19 else "all DP launches of the mixture",
                          "measured_on": roof_mode,
                          "launches": iso_launches, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
