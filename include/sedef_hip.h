@@ -166,6 +166,11 @@ long long sdf_last_paired(const sdf_ctx *ctx);
  * kernels because a stripe kernel's wavefront gave up waiting for its neighbour (SDF_STRIPE_SPIN_CAP polls; the stripe
  * protocol's forward progress rests on the dispatch order).  0 in normal operation. */
 long long sdf_last_reran(const sdf_ctx *ctx);
+/* Number of tasks of the last batch call that ran one per LANE (extz2_lane.hip): small full-band tasks -- both sequences of
+ * at most 256 bases, at most 16,384 cells; SEDEF's gap fills (reference: src/align.cc:235) -- of a batch that holds at
+ * least 8,192 of them, under a scoring with match + 2 (gap open + gap extend) <= 127.  They are sorted and planned on the
+ * device; the host only marks them. */
+long long sdf_last_lane_tasks(const sdf_ctx *ctx);
 
 /* ---- seed anchors on the GPU (next row of the scope table) -----------------------------------
  * Replaces generate_anchors (reference: src/chain.cc:24-101) for a batch of candidate pairs: maximal exact

@@ -112,6 +112,12 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   if (const char *sm = getenv("SDF_STRIPE_MIN")) ctx->stripe_min = std::max(128, atoi(sm));
   if (const char *bm = getenv("SDF_BSTRIPE_MIN_ROWS")) ctx->bstripe_min_rows = std::max(0, atoi(bm));
   if (const char *cp = getenv("SDF_STRIPE_SPIN_CAP")) ctx->stripe_spin_cap = std::max(1, atoi(cp));
+  const char *nl = getenv("SDF_NO_LANE");
+  ctx->lane_enabled = !(nl && nl[0] == '1');
+  if (const char *lm = getenv("SDF_LANE_MIN")) ctx->lane_min = (size_t)std::max(1, atoi(lm));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_lane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            want_lds);
+  (void)hipGetLastError();
   const char *pl = getenv("SDF_PIPELINE");
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
@@ -139,8 +145,11 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
                     &ctx->st_cig, &ctx->st_out})
     b->release();
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
-                    &ctx->h_pool, &ctx->h_out, &ctx->h_cig, &ctx->rr_out, &ctx->rr_cig, &ctx->rr_map})
+                    &ctx->h_pool, &ctx->h_out, &ctx->h_cig, &ctx->rr_out, &ctx->rr_cig, &ctx->rr_map, &ctx->ln_recs,
+                    &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
     b->release();
+  if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
+  ctx->host_lane.release();
   if (ctx->rerun_ctx) sdf_destroy(ctx->rerun_ctx);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0], ctx->aux_stream[1],
@@ -228,6 +237,7 @@ extern "C" float sdf_last_ms(const sdf_ctx *ctx, int which) {
 extern "C" int sdf_last_launches(const sdf_ctx *ctx) { return ctx ? ctx->launches : 0; }
 extern "C" long long sdf_last_paired(const sdf_ctx *ctx) { return ctx ? ctx->paired : 0; }
 extern "C" long long sdf_last_reran(const sdf_ctx *ctx) { return ctx ? ctx->reran : 0; }
+extern "C" long long sdf_last_lane_tasks(const sdf_ctx *ctx) { return ctx ? ctx->lane_tasks : 0; }
 
 namespace {
 
@@ -346,6 +356,19 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   env.no_stripe = ctx->no_stripe;
   env.stripe_min = ctx->stripe_min;
   env.bstripe_min_rows = ctx->bstripe_min_rows;
+  // lane kernel: a tame scoring (every byte of the reference's state stays in 0..127: no wrap-around, no signed /
+  // unsigned or sign-extension artefacts) and nothing but CIGAR / score / mte wanted
+  {
+    const int qe2 = 2 * (sc->gapo + sc->gape), zm = sc->mat[0] + qe2, zx = sc->mat[1] + qe2;
+    env.lane_ok = ctx->lane_enabled && ctx->pipeline && !ctx->force_general && !env.degenerate && !(want & SDF_WANT_EXT) &&
+                  sc->gapo >= 0 && sc->gape >= 0 && zm >= 0 && zm <= 127 && zx >= 0 && zx <= 127 && n >= ctx->lane_min;
+    env.lane_min = ctx->lane_min;
+    if (env.lane_ok) {
+      SDF_HIP(ctx->host_lane.reserve(n * sizeof(LaneRec)));
+      env.lane_recs = (LaneRec *)ctx->host_lane.p;
+    }
+  }
+  ctx->lane_tasks = 0;
   run.want_cigar = env.want_cigar;
   run.scoring = sc;
   run.tasks = tasks;
@@ -378,14 +401,16 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   const float dbg_a = host_ms();
 
   // ---- buffers ----
-  if (ctx->dir_ws.reserve(cut.region_need * cut.nreg_ws + cut.heavy_need) != hipSuccess) {
+  const size_t lane_need = cut.use_lane ? ((cut.lane_dir_bytes + 255) & ~(size_t)255) : 0;
+  if (ctx->dir_ws.reserve(cut.region_need * cut.nreg_ws + cut.heavy_need + lane_need) != hipSuccess) {
     ctx->err = "cannot allocate the direction-matrix workspace";
     (void)hipGetLastError();
     return SDF_ERR_NOMEM;
   }
   const size_t np = std::max<size_t>(cut.ntask_total, 1);
-  SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(cut.stage_total, 4) * 4));
-  SDF_HIP(ctx->plan_buf.reserve(np * sizeof(PlanTask)));
+  const size_t n_lane = cut.use_lane ? cut.n_lane : 0;
+  SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(cut.stage_total + (cut.use_lane ? cut.lane_stage_words : 0), 4) * 4));
+  SDF_HIP(ctx->plan_buf.reserve((np + n_lane) * sizeof(PlanTask)));
   const size_t nord = std::max<size_t>(cut.order_total, 2);
   SDF_HIP(ctx->order_buf.reserve(nord * sizeof(int32_t)));
   SDF_HIP(ctx->misc_buf.reserve(SDF_MISC_PARTS * 8 + ((n + 1023) / 1024 + 1) * 8));
@@ -405,6 +430,11 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n);
   SDF_HIP(hipEventRecord(run.ev_begin, st));
   // (the internal streams are ordered behind ev_begin by launch_chunk, each before its first use in this call)
+  if (cut.use_lane)
+    if (int lrc = launch_lane(run, n)) {
+      drain_streams(ctx, st);
+      return lrc;
+    }
 
   // ---- plan (worker threads, chunk order) and launch (this thread, chunk order) ----
   static const bool dbg_plan_chunks = getenv("SDF_DEBUG_PLAN") != nullptr;

@@ -42,6 +42,12 @@ __global__ void extz2_bstripe_kernel(const PlanTask *, const int32_t *, const ui
                                      unsigned long long *, int);
 __global__ void bstripe_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 __global__ void bstripe_finish_kernel(const PlanTask *, const int32_t *, int, int, const uint8_t *, sdf_result *);
+struct LaneRec;
+__global__ void lane_keys_kernel(const LaneRec *, int, uint32_t *, uint32_t *);
+__global__ void lane_sizes_kernel(const LaneRec *, const uint32_t *, int, unsigned long long *, unsigned long long *);
+__global__ void lane_plan_kernel(const LaneRec *, const uint32_t *, int, const unsigned long long *, const unsigned long long *,
+                                 int64_t, int64_t, PlanTask *);
+__global__ void extz2_lane_kernel(const PlanTask *, int, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
 template <int LAYOUT, int G>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
 __global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
@@ -196,6 +202,13 @@ struct sdf_ctx {
   DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
   DevBuf st_tasks, st_pool, st_cig, st_out;  // sdf_stats_columns_batch
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
+  // lane kernel (extz2_lane.hip): records as uploaded, sort keys / values (in, out), sizes and their scans, hipCUB scratch
+  HostBuf host_lane;
+  DevBuf ln_recs, ln_keys, ln_vals, ln_sizes, ln_tmp;
+  hipStream_t lane_stream = nullptr;
+  bool lane_enabled = true;   // SDF_NO_LANE=1: small full-band tasks stay on the window kernels
+  size_t lane_min = 8192;     // SDF_LANE_MIN: eligible tasks a batch must hold for the lane kernel to take them
+  long long lane_tasks = 0;   // tasks of the last batch call the lane kernel took
   sdf::WorkerPool *pool = nullptr;  // planning threads, started with the first batch large enough to use them
   sdf::BatchCut *cut = nullptr;  // chunk list and planning scratch of the last batch call (sdf_plan.hip)
   std::vector<hipEvent_t> events;

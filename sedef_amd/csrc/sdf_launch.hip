@@ -45,6 +45,7 @@ struct BatchRun {
   const sdf_scoring *scoring = nullptr;  // what the caller passed (a re-run of abandoned tasks passes them on)
   const sdf_task *tasks = nullptr;
   uint32_t want = 0;
+  hipEvent_t ev_lane = nullptr;  // the lane tasks' DP and traceback have finished
   hipStream_t began[12] = {};  // internal streams already ordered behind ev_begin in this call
   size_t nbegan = 0;
 };
@@ -61,7 +62,7 @@ static hipEvent_t next_event(sdf_ctx *ctx, size_t &cursor) {
 // every stream a batch call may have work on
 static void drain_streams(sdf_ctx *ctx, hipStream_t st) {
   for (hipStream_t q : {st, ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
-                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3]})
+                        ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3], ctx->lane_stream})
     if (q) (void)hipStreamSynchronize(q);
   (void)hipGetLastError();
 }
@@ -403,6 +404,64 @@ static int rerun_abandoned(BatchRun &run, unsigned long long count) {
   return SDF_OK;
 }
 
+// The lane tasks of a batch (extz2_lane.hip), start to finish on a stream of their own next to the chunks: the records the
+// scan wrote -> sort by (class, qlen, tlen) -> CIGAR-slot and flag-region offsets -> plan records behind the host-planned
+// ones -> one DP launch per class present -> traceback.  Nothing here waits for the host.
+static int launch_lane(BatchRun &run, size_t n) {
+  sdf_ctx *ctx = run.ctx;
+  const BatchCut &cut = *run.cut;
+  const size_t nl = cut.n_lane;
+  if (!ctx->lane_stream && hipStreamCreateWithFlags(&ctx->lane_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->err = "cannot create the lane kernel's stream";
+    return SDF_ERR_HIP;
+  }
+  hipStream_t sl = ctx->lane_stream;
+  SDF_HIP(hipStreamWaitEvent(sl, run.ev_begin, 0));
+  SDF_HIP(ctx->ln_recs.reserve(n * sizeof(LaneRec)));
+  SDF_HIP(ctx->ln_keys.reserve(n * 8));
+  SDF_HIP(ctx->ln_vals.reserve(n * 8));
+  SDF_HIP(ctx->ln_sizes.reserve(nl * 32 + 64));
+  LaneRec *d_recs = (LaneRec *)ctx->ln_recs.p;
+  uint32_t *k_in = (uint32_t *)ctx->ln_keys.p, *k_out = k_in + n, *v_in = (uint32_t *)ctx->ln_vals.p, *v_out = v_in + n;
+  unsigned long long *cap = (unsigned long long *)ctx->ln_sizes.p, *dirb = cap + nl, *cap_off = dirb + nl, *dir_off = cap_off + nl;
+  size_t t_sort = 0, t_scan = 0;
+  SDF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, k_in, k_out, v_in, v_out, (int)n, 0, 20, sl));
+  SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, cap, cap_off, (int)nl, sl));
+  const size_t t_bytes = std::max(t_sort, t_scan) + 256;
+  SDF_HIP(ctx->ln_tmp.reserve(t_bytes));
+  SDF_HIP(hipMemcpyAsync(d_recs, ctx->host_lane.p, n * sizeof(LaneRec), hipMemcpyHostToDevice, sl));
+  hipLaunchKernelGGL(lane_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sl, d_recs, (int)n, k_in, v_in);
+  size_t tb = t_bytes;
+  SDF_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->ln_tmp.p, tb, k_in, k_out, v_in, v_out, (int)n, 0, 20, sl));
+  const dim3 gl((unsigned)((nl + 255) / 256));
+  hipLaunchKernelGGL(lane_sizes_kernel, gl, dim3(256), 0, sl, d_recs, v_out, (int)nl, cap, dirb);
+  tb = t_bytes;
+  SDF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->ln_tmp.p, tb, cap, cap_off, (int)nl, sl));
+  tb = t_bytes;
+  SDF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->ln_tmp.p, tb, dirb, dir_off, (int)nl, sl));
+  // plan records behind the host-planned ones; staging slots behind theirs; flags in the slice behind the heavy tasks'
+  PlanTask *lp = run.d_plan + cut.ntask_total;
+  const int64_t dir0 = (int64_t)(cut.nreg_ws * cut.region_need + cut.heavy_need);
+  hipLaunchKernelGGL(lane_plan_kernel, gl, dim3(256), 0, sl, d_recs, v_out, (int)nl, cap_off, dir_off, cut.stage_total, dir0, lp);
+  size_t pos = 0;
+  for (int c = 0; c < 4; ++c) {  // (sorted by class first: the classes are consecutive ranges)
+    const size_t cnt = cut.lane_cls[c];
+    if (!cnt) continue;
+    hipLaunchKernelGGL(extz2_lane_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lane_lds_bytes(c), sl, lp + pos, (int)cnt,
+                       run.d_pool, run.sk, run.d_dir, run.d_out);
+    ++ctx->launches;
+    pos += cnt;
+  }
+  if (run.want_cigar)
+    launch_traceback<5>(false, nl, sl, lp, run.d_pool, run.d_dir, run.d_out, run.d_stage);
+  run.ev_lane = next_event(ctx, run.evc);
+  SDF_HIP(hipEventRecord(run.ev_lane, sl));
+  SDF_HIP(hipGetLastError());
+  ctx->lane_tasks = (long long)nl;
+  return SDF_OK;
+}
+
 // Closes the batch on the caller's stream: waits for every chunk's traceback, scans n_cigar into cigar_off,
 // compacts the CIGARs into the caller's pool and reads the timing events.
 static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_cap, size_t *cigar_used) {
@@ -411,11 +470,12 @@ static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_c
   if (run.cut->pipelined)
     for (auto &ev : run.cev)
       if (ev.tb1) SDF_HIP(hipStreamWaitEvent(st, ev.tb1, 0));
+  if (run.ev_lane) SDF_HIP(hipStreamWaitEvent(st, run.ev_lane, 0));
   unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
   hipEvent_t ev_c0 = next_event(ctx, run.evc), ev_c1 = next_event(ctx, run.evc), ev_end = next_event(ctx, run.evc);
   SDF_HIP(hipEventRecord(ev_c0, st));
   unsigned long long total = 0, gave_up = 0;  // (misc word 1: tasks whose stripe wavefronts gave up waiting for a neighbour)
-  const size_t np = run.cut->ntask_total;
+  const size_t np = run.cut->ntask_total + (run.cut->use_lane ? run.cut->n_lane : 0);  // (lane plan records follow the host's)
   if (run.any_stripe) {  // (one more round trip, for batches with stripe launches only)
     SDF_HIP(hipMemcpyAsync(&gave_up, d_total + 1, sizeof(gave_up), hipMemcpyDeviceToHost, st));
     SDF_HIP(hipStreamSynchronize(st));

@@ -29,6 +29,11 @@ struct PlanEnv {
   bool force_general = false, no_pair = false, no_stripe = false;
   int stripe_min = 400;
   int bstripe_min_rows = 4000;  // banded tasks with at least this many anti-diagonals: banded stripe kernel (0: off)
+  // lane kernel (extz2_lane.hip): small full-band tasks leave the host's planning altogether when the batch holds at least
+  // `lane_min` of them (fewer do not fill the device: a lane walks its matrix alone, ~100 cycles per cell)
+  bool lane_ok = false;     // the scoring is tame and only CIGAR / score / mte are wanted
+  size_t lane_min = 8192;
+  LaneRec *lane_recs = nullptr;  // pinned, one per task of the batch: filled by the scan
 };
 
 struct Launch {
@@ -72,9 +77,12 @@ struct BatchCut {
   std::vector<uint32_t> bound;      // per task: upper bound of its direction flags, in units of 256 bytes
   std::vector<uint32_t> cap;        // per task: CIGAR staging words | 0x80000000 when the task runs at all
   std::vector<uint32_t> hparts[16];  // heavy task indices, per scan thread
-  struct Block {  // sums over SDF_CUT_BLOCK consecutive tasks: all runnable ones / the heavy ones among them
-    uint64_t bd = 0, hbd = 0;  // direction-flag bounds, bytes
+  struct Block {  // sums over SDF_CUT_BLOCK consecutive tasks: all runnable ones / the heavy ones / the lane tasks among them
+    uint64_t bd = 0, hbd = 0, lbd = 0;  // direction-flag bounds, bytes
     uint32_t nt = 0, hnt = 0, sw = 0, hsw = 0, oc = 0, hoc = 0;  // tasks, CIGAR staging words, launch-order entries
+    uint32_t lnt = 0, lsw = 0, loc = 0;
+    uint64_t ldir = 0;          // direction-flag bytes of the lane tasks in the lane kernel's own layout
+    uint32_t lcls[4] = {0, 0, 0, 0};  // lane tasks per launch class (target length)
   };
   std::vector<Block> blocks;
   void reset() {
@@ -88,7 +96,18 @@ struct BatchCut {
     stage_total = 0;
     ntask_total = 0;
     order_total = 0;
+    use_lane = false;
+    n_lane = 0;
+    lane_stage_words = 0;
+    lane_dir_bytes = 0;
+    for (auto &c : lane_cls) c = 0;
   }
+  // lane kernel: tasks the scan found eligible (lane[k] != 0), taken out of the chunks when there are enough of them
+  std::vector<uint8_t> lane;
+  bool use_lane = false;
+  size_t n_lane = 0, lane_cls[4] = {0, 0, 0, 0};
+  int64_t lane_stage_words = 0;
+  size_t lane_dir_bytes = 0;
   bool split_heavy = false, pipelined = false;
   size_t nch = 1, max_regions = 1, n_heavy = 0;
   size_t region_need = 16, heavy_need = 0, nreg_ws = 1;
@@ -170,6 +189,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   static const bool dbg_cut = getenv("SDF_DEBUG_PLAN") != nullptr;
   const auto tc0 = std::chrono::steady_clock::now();
   std::vector<uint32_t> &bound = cut.bound, &cap = cut.cap;
+  const bool lane_scan = env.lane_ok && env.lane_recs && n >= env.lane_min;
+  if (lane_scan && cut.lane.size() < n) cut.lane.resize(n);
   // (not cleared: 8 MB of memset per million tasks, on this thread, before anything else can start -- the scan below
   // writes both words of every task, runnable or not)
   if (bound.size() < n) bound.resize(n);
@@ -201,6 +222,10 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         }
         bound[k] = 0;
         cap[k] = 0;
+        if (lane_scan) {
+          cut.lane[k] = 0;
+          env.lane_recs[k].flag = 0xffffu;
+        }
         if (!plan_detail::task_runs(t, env.degenerate)) continue;
         BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
         cap[k] = 0x80000000u;
@@ -235,6 +260,25 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           }
           bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
           blk.bd += (uint64_t)bound[k] << 8;
+          // a small full-band task with nothing special asked of it: the lane kernel's, if the batch has enough of them
+          if (lane_scan && t.qlen <= kLaneMaxLen && t.tlen <= kLaneMaxLen && (int64_t)t.qlen * t.tlen <= kLaneMaxCells &&
+              w >= std::max(t.qlen, t.tlen) && t.zdrop < 0 && !(t.flag & ~(SDF_FLAG_SCORE_ONLY | SDF_FLAG_REV_CIGAR)) &&
+              (uint64_t)t.q_off < 0xffffffffull && (uint64_t)t.t_off < 0xffffffffull && bd < heavy_min) {
+            cut.lane[k] = 1;
+            LaneRec &lr = env.lane_recs[k];
+            lr.q_word = (uint32_t)t.q_off;
+            lr.t_word = (uint32_t)t.t_off;
+            lr.out_idx = (uint32_t)k;
+            lr.qlen_m1 = (uint8_t)(t.qlen - 1);
+            lr.tlen_m1 = (uint8_t)(t.tlen - 1);
+            lr.flag = (uint16_t)((t.flag & SDF_FLAG_REV_CIGAR) | (with_dir ? 0 : SDF_FLAG_SCORE_ONLY));
+            ++blk.lnt;
+            blk.lbd += (uint64_t)bound[k] << 8;
+            blk.lsw += words;
+            blk.loc += oc;
+            blk.ldir += with_dir ? lane_dir_bytes(t.qlen, t.tlen) : 0;
+            ++blk.lcls[lane_class(t.tlen)];
+          }
           if (bd >= heavy_min) {
             ++pt.nh;
             pt.hb += bd;
@@ -280,13 +324,26 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       heavy_bytes += parts[q].hb;
     }
   }
+  if (lane_scan) {
+    for (const BatchCut::Block &blk : cut.blocks) {
+      cut.n_lane += blk.lnt;
+      cut.lane_stage_words += blk.lsw;
+      cut.lane_dir_bytes += blk.ldir;
+      for (int c = 0; c < 4; ++c) cut.lane_cls[c] += blk.lcls[c];
+    }
+    cut.use_lane = cut.n_lane >= env.lane_min;
+  }
   const auto tc1 = std::chrono::steady_clock::now();
   // Heavy tasks leave the chunk rotation when they are a minority: they are planned and launched FIRST, all together
   // (a launch of few long tasks lasts as long as its longest task: one such launch per kernel, not one per chunk), with
   // a workspace slice of their own, and run next to the chunks of ordinary tasks.
   cut.split_heavy = cut.pipelined && cut.n_heavy * 4 <= n;
   const size_t heavy_budget = cut.split_heavy && cut.n_heavy ? std::min(heavy_bytes + 256, ws_budget / 2) : 0;
-  const size_t region_budget = (ws_budget - heavy_budget) / cut.max_regions;
+  const size_t lane_budget = cut.use_lane ? std::min(cut.lane_dir_bytes + 256, ws_budget / 4) : 0;
+  if (cut.use_lane && cut.lane_dir_bytes + 256 > lane_budget) {  // (a quarter of the workspace in 4-bit flags: > 10^10 cells)
+    cut.use_lane = false;
+  }
+  const size_t region_budget = (ws_budget - heavy_budget - (cut.use_lane ? lane_budget : 0)) / cut.max_regions;
   cut.heavy.assign(cut.split_heavy ? n : 0, 0);
 
   // ---- chunk boundaries ----
@@ -333,6 +390,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     ChunkPlan cur;
     size_t acc = 0;
     const uint8_t *hv = cut.split_heavy ? cut.heavy.data() : nullptr;
+    const uint8_t *ln = cut.use_lane ? cut.lane.data() : nullptr;
     auto close_at = [&](size_t k) {
       cur.e = k;
       normal.push_back(cur);
@@ -347,16 +405,17 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       const size_t target = normal.empty() && nch > 1 ? first_target : chunk_target;
       // (all tasks of the range count towards the target, as they cost planning time whether they run or not)
       if (k0 > cur.s && k0 - cur.s >= target) close_at(k0);
-      const uint64_t bbd = blk.bd - (hv ? blk.hbd : 0);
+      const uint64_t bbd = blk.bd - (hv ? blk.hbd : 0) - (ln ? blk.lbd : 0);
       if (acc + bbd <= region_budget) {
         acc += bbd;
-        cur.ntask += blk.nt - (hv ? blk.hnt : 0);
-        cur.stage_words += blk.sw - (hv ? blk.hsw : 0);
-        cur.order_cap += blk.oc - (hv ? blk.hoc : 0);
+        cur.ntask += blk.nt - (hv ? blk.hnt : 0) - (ln ? blk.lnt : 0);
+        cur.stage_words += blk.sw - (hv ? blk.hsw : 0) - (ln ? blk.lsw : 0);
+        cur.order_cap += blk.oc - (hv ? blk.hoc : 0) - (ln ? blk.loc : 0);
         continue;
       }
       for (size_t k = k0; k < k1; ++k) {
         if (hv && hv[k]) continue;
+        if (ln && ln[k]) continue;
         const size_t bd = (size_t)bound[k] << 8;
         if (k > cur.s && acc + bd > region_budget) close_at(k);
         acc += bd;
@@ -416,6 +475,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
     const sdf_task &t = tasks[k];
     if (!c.heavy && cut.split_heavy && cut.heavy[k]) continue;
+    if (cut.use_lane && cut.lane[k]) continue;  // (planned on the device: extz2_lane.hip)
     if (!plan_detail::task_runs(t, env.degenerate)) continue;  // reference early return (:57,:81)
     PlanTask p;
     p.q_word = t.q_off;

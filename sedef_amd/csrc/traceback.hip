@@ -41,6 +41,10 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
   if (LAYOUT == 0) {
     a.idx = (int64_t)r * tk.ncol16 + (i - b.lo);
     a.meta = 0;
+  } else if (LAYOUT == 5) {
+    // lane kernel (extz2_lane.hip): rows of ceil(tlen / 8) words per query position, a nibble per cell
+    a.idx = (int64_t)j * ((tk.tlen + 7) >> 3) + (i >> 3);
+    a.meta = (uint32_t)((i & 7) * 4);
   } else if (LAYOUT == 4) {
     // banded stripes (extz2_bstripe.hip): a flag region per stripe of 128 * nreg target positions, 16-row blocks counted
     // from the block of the stripe's first row, slot t - T0
@@ -83,6 +87,9 @@ __device__ __forceinline__ uint32_t tb_load(const uint8_t *dir, const TbAddr a) 
   if (LAYOUT == 0) {
     const uint32_t d = dir[a.idx];
     return (a.meta & 0x100u) ? a.meta : d;
+  } else if (LAYOUT == 5) {
+    const uint32_t nib = reinterpret_cast<const uint32_t *>(dir)[a.idx] >> (a.meta & 31u);
+    return (a.meta & 0x100u) ? a.meta : ((nib & 3u) | ((nib & 12u) << 1));
   } else if (LAYOUT == 2) {
     const uint2 c = reinterpret_cast<const uint2 *>(dir)[a.idx];
     const uint32_t bit = a.meta & 31u;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   const int k = (int)blockIdx.x * PER + lane / G;
   bool active = k < n;
   PlanTask tk = plan[active ? k : 0];
-  active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : tk.pad_ == 7 ? 4 : 1) == LAYOUT &&
+  active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : tk.pad_ == 7 ? 4 : tk.pad_ == 8 ? 5 : 1) == LAYOUT &&
            !(tk.flag & SDF_FLAG_SCORE_ONLY);
   sdf_result rr = res[tk.out_idx];
   active = active && rr.n_cigar != -1;  // (-1: a stripe kernel gave the task up -- nothing to walk; it is run again)
@@ -248,6 +255,7 @@ SDF_TB_INST(1)
 SDF_TB_INST(2)
 SDF_TB_INST(3)
 SDF_TB_INST(4)
+SDF_TB_INST(5)
 #undef SDF_TB_INST
 
 // Exclusive scan of n_cigar over the result records in record order -> cigar_off, in three small launches:

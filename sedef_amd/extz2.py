@@ -98,6 +98,8 @@ def load_library():
     L.sdf_last_paired.argtypes = [C.c_void_p]
     L.sdf_last_reran.restype = C.c_longlong
     L.sdf_last_reran.argtypes = [C.c_void_p]
+    L.sdf_last_lane_tasks.restype = C.c_longlong
+    L.sdf_last_lane_tasks.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -288,6 +290,10 @@ class Extz2Engine:
     def last_paired(self):
         """Tasks of the last batch that ran two per wavefront (same-geometry pairs)."""
         return int(self.lib.sdf_last_paired(self.ctx))
+
+    def last_lane_tasks(self):
+        """Tasks of the last batch that ran one per lane (extz2_lane.hip: small full-band tasks of a large batch)."""
+        return int(self.lib.sdf_last_lane_tasks(self.ctx))
 
     def last_reran(self):
         """Tasks of the last batch that a stripe kernel gave up and the call ran again on another kernel."""

@@ -360,9 +360,102 @@ def test_tiny_tasks_bulk(engine, oracle):
     _check_fast(engine, oracle, pairs, [-1] * len(pairs))
 
 
-# ---- pair kernel: two tasks of equal (qlen, tlen, w) per wavefront (extz2_pair.hip) ----
+# ---- lane kernel: one small full-band task per lane (extz2_lane.hip) ----
+def _lane_pairs(rng, n):
+    """Small tasks of every shape the lane kernel takes (both sequences <= 256 bases, <= 16,384 cells): gap fills of a few
+    bases, the 210 x 209 limit of chain gaps, one-base sequences, N runs and all-N, unrelated sequences, homopolymers."""
+    pairs = []
+    for k in range(n):
+        u = rng.random()
+        if u < 0.4:
+            ql, tl = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+        elif u < 0.8:
+            ql = int(rng.integers(5, 101))
+            tl = max(1, min(209, ql + int(rng.integers(-20, 21))))
+        elif u < 0.9:
+            ql = int(rng.integers(1, 257))
+            tl = int(rng.integers(1, min(256, 16384 // ql) + 1))
+        else:
+            ql, tl = [(1, 256), (256, 1), (64, 256), (256, 64), (128, 128), (210, 78), (33, 32), (17, 31), (8, 9), (1, 1)][k % 10]
+        kind = rng.random()
+        q = random_codes(rng, ql, 0.05 if kind < 0.2 else 0.0)
+        if kind < 0.55:
+            t = _fit(rng, mutate(rng, q, 0.06, 0.03, 0.03), tl)
+        elif kind < 0.8:
+            t = random_codes(rng, tl, 0.02)
+        elif kind < 0.9:
+            t = np.full(tl, int(rng.integers(0, 4)), np.uint8)
+            q = np.full(ql, int(t[0]) if rng.random() < 0.5 else int(rng.integers(0, 4)), np.uint8)
+        else:
+            t = np.full(tl, 4, np.uint8) if rng.random() < 0.5 else _fit(rng, q, tl)
+        pairs.append((q, t))
+    return pairs
+
+
 def _fit(rng, t, tl):
     return t[:tl] if len(t) >= tl else np.concatenate([t, random_codes(rng, tl - len(t))])
+
+
+def test_lane_kernel_small_full_band_tasks(oracle):
+    """A batch of small full-band tasks runs one task per LANE, sorted and planned on the device: every field the fast path
+    returns, the CIGAR and the column counts against the oracle; explicit bands >= both lengths count as full; reversed
+    CIGARs and score-only tasks in between."""
+    eng = _engine_with_env(SDF_LANE_MIN=2048)
+    rng = np.random.default_rng(7001)
+    pairs = _lane_pairs(rng, 9000)
+    ws = [-1 if k % 3 else max(len(q), len(t)) + k % 5 for k, (q, t) in enumerate(pairs)]
+    flags = [0x80 if k % 11 == 3 else 0x01 if k % 13 == 5 else 0 for k in range(len(pairs))]
+    _check_fast(eng, oracle, pairs, ws, flags)
+    assert eng.last_lane_tasks() == len(pairs)
+    # want = SCORE for the whole batch: no flags, no CIGAR
+    import sedef_amd
+    res, cig = eng.align_pairs(pairs[:3000], w=-1, want=sedef_amd.extz2.WANT_SCORE)
+    assert eng.last_lane_tasks() == 3000 and len(cig) == 0
+    for (q, t), r in zip(pairs[:3000], res):
+        exp = oracle.extz2(q, t)
+        assert (int(r["score"]), int(r["mte"]), int(r["mte_q"]), int(r["n_cigar"])) == (exp["score"], exp["mte"], exp["mte_q"], 0)
+
+
+def test_lane_kernel_other_scorings(oracle):
+    """Tame scorings (match + 2 (q + e) <= 127: every byte of the reference's state stays in 0..127) take the lane kernel and
+    agree with the oracle; a scoring beyond that keeps to the window kernels, which emulate the wrap-around."""
+    eng = _engine_with_env(SDF_LANE_MIN=1024)
+    rng = np.random.default_rng(7002)
+    took = 0
+    for it in range(14):
+        ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
+        go, ge = int(rng.integers(0, 60)), int(rng.integers(0, 5))
+        if it == 0:
+            ma, mi, go, ge = 5, -4, 60, 1   # cap = 127: the last tame one
+        if it == 1:
+            ma, mi, go, ge = 5, -4, 61, 1   # cap = 129: not tame
+        if it == 2:
+            ma, mi, go, ge = 1, -1, 0, 0
+        pairs = _lane_pairs(rng, 1500)
+        _check_fast(eng, oracle, pairs, [-1] * len(pairs), mat=sedef_mat(ma, mi), gapo=go, gape=ge)
+        tame = ma + 2 * (go + ge) <= 127 and -mi <= 2 * (go + ge)
+        assert (eng.last_lane_tasks() == len(pairs)) == tame, (ma, mi, go, ge, eng.last_lane_tasks())
+        took += tame
+    assert took >= 8
+
+
+def test_lane_kernel_next_to_the_other_kernels(oracle):
+    """One batch with lane tasks, banded tasks of the same sizes (not eligible), wide full-band tasks (stripe kernel) and
+    long banded ones: the lane tasks leave the chunks, everything else is planned as before, one result array."""
+    eng = _engine_with_env(SDF_LANE_MIN=1024)
+    rng = np.random.default_rng(7003)
+    pairs = _lane_pairs(rng, 6000)
+    ws = [-1] * len(pairs)
+    for k in range(0, len(pairs), 7):  # a band below the lengths: not a lane task
+        ws[k] = max(1, max(len(pairs[k][0]), len(pairs[k][1])) // 2)
+    extra, extra_w = _stripe_mix(rng)
+    for k, (p_, w_) in enumerate(zip(extra, extra_w)):
+        pairs.insert(500 * k + 17, p_)
+        ws.insert(500 * k + 17, w_)
+    _check_dropped_max(eng, oracle, pairs, ws)
+    n_lane = sum(1 for (q, t), w in zip(pairs, ws) if len(q) <= 256 and len(t) <= 256 and len(q) * len(t) <= 16384 and
+                 (w < 0 or w >= max(len(q), len(t))))
+    assert eng.last_lane_tasks() == n_lane > 4000
 
 
 def _same_geometry_tasks(rng, ql, tl, copies, n_frac=0.0):
@@ -516,7 +609,10 @@ def test_config4_hg19_task_mixture(engine, oracle):
     import bench
     batch, w = bench.synth_hg19_mixture(30000, seed=404, big=2500)
     _batch_vs_cpu(engine, oracle, batch, w)
-    assert engine.last_paired() > 20000
+    assert engine.last_lane_tasks() > 29000  # the gap fills, one per lane (extz2_lane.hip); the rest in pairs and stripes
+    solo = _engine_with_env(SDF_NO_LANE=1)
+    _batch_vs_cpu(solo, oracle, batch, w)
+    assert solo.last_lane_tasks() == 0 and solo.last_paired() > 20000
 
 
 def test_config5_mm8_mixed_bands(engine, oracle):
