@@ -31,6 +31,8 @@ def run(name, batch, w, eng, dev, steps=3):
     cap = int((qlen.astype(np.int64) + tlen + 2).sum())
     d_cig = torch.empty(cap, dtype=torch.int32, device=dev)
     want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
+    if os.environ.get("SHAPES_SCORE_ONLY") == "1":  # (probe: the DP without its direction flags and traceback)
+        want = sedef_amd.extz2.WANT_SCORE
     eng.align_batch_device(tasks, d_pool.data_ptr(), d_out.data_ptr(), d_cig.data_ptr(), cap, want=want)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

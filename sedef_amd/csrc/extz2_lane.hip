@@ -21,8 +21,8 @@
 // ("hard parts").  Everything else keeps to the window kernels.  The exact H is followed along the first
 // column and, through the row sums of u, along the last one (score, mte; :226-267 read u, v as bytes).
 //
-// Direction flags: 4 bits per cell (a > z | b > z' in bits 0-1 as 0 / 1 / 2, x > 0, y > 0), rows of ceil(tlen / 8)
-// words per query position, one region per task (traceback.hip: layout 5).
+// Direction flags: 4 bits per cell (a > z | b > z' in bits 0-1 as 0 / 1 / 2, x > 0, y > 0), 8 bytes per query position
+// and tile of 16 target positions, tile after tile, one region per task (traceback.hip: layout 5).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -40,11 +40,12 @@ struct LaneRec {      // what the host uploads per task of the batch (16 bytes; 
 constexpr int kLaneMaxLen = 256;      // longest sequence of a lane task
 constexpr int kLaneMaxCells = 16384;  // most cells of a lane task: a lane alone on its row costs ~100 cycles per cell
 
-__host__ __device__ inline int lane_row_words(int tlen) { return (tlen + 7) >> 3; }
-__host__ __device__ inline size_t lane_dir_bytes(int qlen, int tlen) { return (size_t)qlen * (size_t)lane_row_words(tlen) * 4; }
-// launch classes by target length: the LDS of a wavefront is 256 bytes per target position of its longest task
-__host__ __device__ inline int lane_class(int tlen) { return tlen <= 32 ? 0 : tlen <= 64 ? 1 : tlen <= 128 ? 2 : 3; }
-__host__ __device__ inline size_t lane_lds_bytes(int cls) { return (size_t)256 * (size_t)((32 << cls) + 1); }
+// direction flags of a task: per column tile of 16 target positions one 8-byte record per query position (a nibble per
+// cell), the records of a tile back to back -- a lane writes its region front to back, 8 bytes per row of a tile
+__host__ __device__ inline size_t lane_dir_bytes(int qlen, int tlen) { return (size_t)((tlen + 15) >> 4) * (size_t)qlen * 8; }
+// launch classes by query length: the LDS of a wavefront is 128 bytes per query position of its longest task
+__host__ __device__ inline int lane_class(int qlen) { return qlen <= 32 ? 0 : qlen <= 64 ? 1 : qlen <= 128 ? 2 : 3; }
+__host__ __device__ inline size_t lane_lds_bytes(int cls) { return (size_t)128 * (size_t)((32 << cls) + 2); }
 
 __device__ __forceinline__ int lane_wave_max(int v) {
 #pragma unroll
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void lane_keys_kernel(const LaneRec *__restric
   if (k >= n) return;
   const LaneRec r = recs[k];
   // class, query length, target length: the tasks of a wavefront get (nearly) equal matrices; others sort to the end
-  keys[k] = r.flag == 0xffffu ? 0xfffffu : ((uint32_t)lane_class(r.tlen_m1 + 1) << 16) | ((uint32_t)r.qlen_m1 << 8) | r.tlen_m1;
+  keys[k] = r.flag == 0xffffu ? 0xfffffu : ((uint32_t)lane_class(r.qlen_m1 + 1) << 16) | ((uint32_t)r.qlen_m1 << 8) | r.tlen_m1;
   vals[k] = (uint32_t)k;
 }
 
@@ -105,93 +106,125 @@ __global__ __launch_bounds__(256) void lane_plan_kernel(const LaneRec *__restric
 }
 
 // ---- the DP -----------------------------------------------------------------------------------------------------
+// The matrix of a lane is walked in column TILES of 16 target positions: the tile's column state -- u | y << 8 | target
+// base << 16 of the cell above, one register per column -- stays in registers for all rows (the row loop is outside, the
+// sixteen cells of a row are unrolled: static register indices), x and v run along the row in two more, and what crosses
+// a tile's right edge -- x and v of its last column, per row -- waits in LDS for the next tile (16 bits per row and lane,
+// fetched one row ahead).  No LDS access and no lane mask inside a full tile's row: a wavefront's tasks have (nearly)
+// equal lengths, only the last tile of a row is ragged.
+constexpr int kLaneTile = 16;
+
+template <bool RAGGED>
+__device__ __forceinline__ void lane_row(uint32_t (&W)[kLaneTile], int &x, int &v, uint32_t &dw0, uint32_t &dw1, const int ncol,
+                                         const uint32_t qc, const int z_eq, const int z_ne, const int zwild, const int cap,
+                                         const int gq) {
+#pragma unroll
+  for (int k = 0; k < kLaneTile; ++k) {
+    if (!RAGGED || k < ncol) {
+      const uint32_t w = W[k];
+      const int uo = (int)(w & 0xffu), yo = (int)((w >> 8) & 0xffu);
+      const uint32_t tc = w >> 16;
+      int z = tc == qc ? z_eq : z_ne;
+      z = tc == 4u ? zwild : z;
+      int a = x + v, b = yo + uo;
+      const uint32_t fa = a > z ? 1u : 0u;  // ties: diagonal before E before F (:173-178)
+      z = a > z ? a : z;
+      const uint32_t d = b > z ? 2u : fa;
+      z = b > z ? b : z;
+      z = z < cap ? z : cap;
+      const int un = z - v, vn = z - uo;
+      z -= gq;
+      a -= z;
+      b -= z;
+      x = a > 0 ? a : 0;
+      const int yn = b > 0 ? b : 0;
+      const uint32_t nib = d | (a > 0 ? 4u : 0u) | (b > 0 ? 8u : 0u);
+      if (k < 8) dw0 |= nib << (4 * (k & 7));
+      else dw1 |= nib << (4 * (k & 7));
+      v = vn;
+      W[k] = (uint32_t)un | ((uint32_t)yn << 8) | (w & 0xffff0000u);
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void extz2_lane_kernel(const PlanTask *__restrict__ plan, int n,
                                                         const uint32_t *__restrict__ pool, ScoreK sc,
                                                         uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
-  extern __shared__ __align__(16) uint32_t lane_lds[];  // [target position][lane]: u | y << 8 | target base << 16
+  extern __shared__ __align__(16) uint16_t lane_edge[];  // [query position][lane]: x | v << 8 at a tile's right edge
   const int lane = threadIdx.x;
-  const int p = blockIdx.x * 64 + lane;
+  // (the tasks are sorted by size, ascending: the largest go first -- a launch ends with the wavefront that starts last)
+  const int p = ((int)gridDim.x - 1 - (int)blockIdx.x) * 64 + lane;
   const bool have = p < n;
   const PlanTask tk = plan[have ? p : n - 1];
   const int qlen = have ? tk.qlen : 0, tlen = have ? tk.tlen : 0;
   const int Qw = lane_wave_max(qlen), Tw = lane_wave_max(tlen);
+  const int Tmin = -lane_wave_max(have ? -tlen : -kLaneMaxLen);  // tiles below it are full for every lane that has a task
   const uint32_t *tw = pool + tk.t_word, *tn = tw + (tk.tlen + 15) / 16;
   const uint32_t *qw = pool + tk.q_word, *qn = qw + (tk.qlen + 15) / 16;
   const int gq = sc.q, qe = sc.qe;
-  uint32_t *col = lane_lds + lane;
-
-  // first row's upper neighbours (:121: y = 0, u = q beyond the first column) and the target bases (N: 4)
-  {
-    uint32_t cw = 0, nm = 0;
-    for (int i = 0; i < Tw; ++i) {
-      if (i < tlen) {
-        if ((i & 15) == 0) cw = tw[i >> 4];
-        if ((i & 31) == 0) nm = tn[i >> 5];
-        const uint32_t c = ((nm >> (i & 31)) & 1u) ? 4u : ((cw >> ((i & 15) * 2)) & 3u);
-        col[i * 64] = (i ? (uint32_t)gq : 0u) | (c << 16);
-      }
-    }
-  }
+  uint16_t *edge = lane_edge + lane;
   const int zm = (int)(int8_t)sc.sc_match + 2 * qe, zmis = (int)(int8_t)sc.sc_mis + 2 * qe, zwild = 2 * qe;
-  const int cap = (int)(int8_t)sc.sc_match + 2 * qe;
+  const int cap = zm;
   const bool with_dir = have && !(tk.flag & SDF_FLAG_SCORE_ONLY);
-  const int rw = lane_row_words(tlen);
-  uint32_t *dirp = reinterpret_cast<uint32_t *>(dirbase + tk.dir_off);
+  uint2 *dirp = reinterpret_cast<uint2 *>(dirbase + tk.dir_off);
 
-  int32_t h0 = 0;                // exact H of cell (0, j)
-  int32_t mte = SDF_NEG_INF, mte_j = -1, score = SDF_NEG_INF;
-  uint32_t qcw = 0, qnm = 0;
-  for (int j = 0; j < Qw; ++j) {
-    const bool row_on = j < qlen;
-    if (row_on) {
-      if ((j & 15) == 0) qcw = qw[j >> 4];
-      if ((j & 31) == 0) qnm = qn[j >> 5];
-    }
-    const bool q_n = ((qnm >> (j & 31)) & 1u) != 0u;
-    const uint32_t qc = (qcw >> ((j & 15) * 2)) & 3u;
-    const int z_eq = q_n ? zwild : zm, z_ne = q_n ? zwild : zmis;
-    int x = 0, v = j ? gq : 0;  // left of the first column (:120)
-    int usum = 0;
-    uint32_t dw = 0u;
-    uint32_t w = col[0];
-    for (int i = 0; i < Tw; ++i) {
-      const uint32_t wn = col[(i + 1) * 64];  // (the next position's word: one row of slack behind the last)
-      if (row_on && i < tlen) {
-        const int uo = (int)(w & 0xffu), yo = (int)((w >> 8) & 0xffu);
-        const uint32_t tc = w >> 16;
-        int z = tc == qc ? z_eq : z_ne;
-        z = tc == 4u ? zwild : z;
-        int a = x + v, b = yo + uo;
-        const uint32_t fa = a > z ? 1u : 0u;  // ties: diagonal before E before F (:173-178)
-        z = a > z ? a : z;
-        const uint32_t d = b > z ? 2u : fa;
-        z = b > z ? b : z;
-        z = z < cap ? z : cap;
-        const int un = z - v, vn = z - uo;
-        z -= gq;
-        a -= z;
-        b -= z;
-        x = a > 0 ? a : 0;
-        const int yn = b > 0 ? b : 0;
-        const uint32_t nib = d | (a > 0 ? 4u : 0u) | (b > 0 ? 8u : 0u);
-        dw = (dw >> 4) | (nib << 28);
-        v = vn;
-        col[i * 64] = (uint32_t)un | ((uint32_t)yn << 8) | (tc << 16);
-        if (i == 0) h0 += j ? vn - qe : vn - 2 * qe;  // (:249: H(0,0) = v - 2 (q + e); :231 along the first column)
-        else usum += un;
-        if ((i & 7) == 7 && with_dir) dirp[(size_t)j * rw + (i >> 3)] = dw;
+  int32_t hrow0 = 0;  // exact H of the last cell of row 0 seen so far: (t0 + ncol - 1, 0)
+  int32_t hl = 0, mte = SDF_NEG_INF, mte_j = -1, score = SDF_NEG_INF;
+  for (int t0 = 0; t0 < Tw; t0 += kLaneTile) {
+    const bool tile_on = t0 < tlen;                 // this lane has columns in the tile
+    const int ncol = tile_on ? (tlen - t0 < kLaneTile ? tlen - t0 : kLaneTile) : 0;
+    const bool full = t0 + kLaneTile <= Tmin;       // wave-uniform
+    const bool last_tile = tile_on && tlen <= t0 + kLaneTile;
+    const bool more = t0 + kLaneTile < Tw;          // wave-uniform: a tile follows
+    // the tile's columns above the first row (:121: y = 0, u = q beyond the first column) and its target bases (N: 4)
+    uint32_t W[kLaneTile];
+    {
+      const uint32_t cw = tile_on ? tw[t0 >> 4] : 0u;
+      const uint32_t nm = tile_on ? tn[t0 >> 5] >> (t0 & 16) : 0u;
+#pragma unroll
+      for (int k = 0; k < kLaneTile; ++k) {
+        const uint32_t c = ((nm >> k) & 1u) ? 4u : ((cw >> (2 * k)) & 3u);
+        W[k] = ((t0 + k) ? (uint32_t)gq : 0u) | (c << 16);
       }
-      w = wn;
     }
-    if (row_on) {
-      if (with_dir && (tlen & 7)) dirp[(size_t)j * rw + (tlen >> 3)] = dw >> ((8 - (tlen & 7)) * 4);
-      // exact H of the row's last cell: along the first column to (0, j), then along the row (:231, u read as a byte)
-      const int32_t hl = h0 + usum - (tlen - 1) * qe;
-      if (hl > mte) {  // (:252: strict, rows in ascending order)
-        mte = hl;
-        mte_j = j;
+    uint32_t qcw = 0u, qnm = 0u;
+    uint32_t e_next = t0 ? edge[0] : 0u;
+    for (int j = 0; j < Qw; ++j) {
+      const bool row_on = j < qlen && tile_on;
+      if (j < qlen) {
+        if ((j & 15) == 0) qcw = qw[j >> 4];
+        if ((j & 31) == 0) qnm = qn[j >> 5];
       }
-      score = hl;  // (the last row's value stays: :255)
+      const uint32_t e_cur = e_next;
+      if (t0) e_next = edge[(j + 1) * 64];  // (one row of slack behind the last)
+      if (row_on) {
+        const bool q_n = ((qnm >> (j & 31)) & 1u) != 0u;
+        const uint32_t qc = (qcw >> ((j & 15) * 2)) & 3u;
+        const int z_eq = q_n ? zwild : zm, z_ne = q_n ? zwild : zmis;
+        int x = t0 ? (int)(e_cur & 0xffu) : 0, v = t0 ? (int)(e_cur >> 8) : (j ? gq : 0);  // (:120 left of the first column)
+        uint32_t dw0 = 0u, dw1 = 0u;
+        if (full) lane_row<false>(W, x, v, dw0, dw1, ncol, qc, z_eq, z_ne, zwild, cap, gq);
+        else lane_row<true>(W, x, v, dw0, dw1, ncol, qc, z_eq, z_ne, zwild, cap, gq);
+        if (more) edge[j * 64] = (uint16_t)((uint32_t)x | ((uint32_t)v << 8));
+        if (with_dir) dirp[(size_t)(t0 >> 4) * qlen + j] = make_uint2(dw0, dw1);
+        if (j == 0) {
+          // exact H along the first row (:231, u read as a byte): H(0, 0) is the substitution score of the first bases
+          // (:249: v - 2 (q + e) with v = z there), every further cell adds its u - (q + e)
+          if (t0 == 0) hrow0 = (int)(W[0] & 0xffu) /* u(0,0) = z(0,0) */ - 2 * qe;
+#pragma unroll
+          for (int k = 0; k < kLaneTile; ++k)
+            if (k < ncol && t0 + k > 0) hrow0 += (int)(W[k] & 0xffu) - qe;
+        }
+        if (last_tile) {
+          // ... and down the last column (v read as a byte): rows in ascending order, the first maximum stays (:252)
+          hl = j ? hl + v - qe : hrow0;
+          if (hl > mte) {
+            mte = hl;
+            mte_j = j;
+          }
+          score = hl;  // (the last row's value is the score, :255)
+        }
+      }
     }
   }
   if (have) {

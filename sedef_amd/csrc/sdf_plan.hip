@@ -78,11 +78,11 @@ struct BatchCut {
   std::vector<uint32_t> cap;        // per task: CIGAR staging words | 0x80000000 when the task runs at all
   std::vector<uint32_t> hparts[16];  // heavy task indices, per scan thread
   struct Block {  // sums over SDF_CUT_BLOCK consecutive tasks: all runnable ones / the heavy ones / the lane tasks among them
-    uint64_t bd = 0, hbd = 0, lbd = 0;  // direction-flag bounds, bytes
+    uint64_t bd = 0, hbd = 0;  // direction-flag bounds, bytes
     uint32_t nt = 0, hnt = 0, sw = 0, hsw = 0, oc = 0, hoc = 0;  // tasks, CIGAR staging words, launch-order entries
-    uint32_t lnt = 0, lsw = 0, loc = 0;
+    uint32_t lnt = 0, lsw = 0;  // lane tasks (not in the sums above) and their staging words
     uint64_t ldir = 0;          // direction-flag bytes of the lane tasks in the lane kernel's own layout
-    uint32_t lcls[4] = {0, 0, 0, 0};  // lane tasks per launch class (target length)
+    uint32_t lcls[4] = {0, 0, 0, 0};  // lane tasks per launch class (query length)
   };
   std::vector<Block> blocks;
   void reset() {
@@ -213,6 +213,52 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       bool bad = false;
     };
     const size_t hv_limit = n / 4 + 1;
+    // what a task needs of the chunks' budgets -- flag bytes whichever window kernel takes it, staging words, launch-order
+    // entries -- into its block's sums
+    auto account = [&](size_t k, Part &pt, std::vector<uint32_t> &hv) {
+      const sdf_task &t = tasks[k];
+      BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
+      cap[k] = 0x80000000u;
+      const uint32_t oc = order_entries(t);
+      ++blk.nt;
+      blk.oc += oc;
+      // A task that wants no CIGAR needs no direction flags -- except on the stripe kernels, whose progress words,
+      // hand-over values and edge columns live in HBM right behind the task's flag blocks: those tasks reserve the
+      // whole layout whatever they want.
+      const bool with_dir = env.want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY);
+      const uint32_t words = with_dir ? (uint32_t)(t.qlen + t.tlen + 2) : 0u;
+      cap[k] |= words;
+      blk.sw += words;
+      const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
+      const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
+      const size_t nrow = (size_t)t.qlen + t.tlen - 1;
+      const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
+      size_t bd = 0;
+      if (with_dir) {
+        bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
+        if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+        // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
+        if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
+      }
+      if (t.tlen > env.stripe_min && t.tlen <= 8192 && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
+        for (int nr = 1; nr <= 4; nr *= 2)
+          bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
+      if (banded_long(t)) {
+        const int nr = plan_detail::bstripe_nreg(t.tlen);
+        bd = std::max(bd, (bstripe_dir_bytes(t.qlen, t.tlen, w, nr) + bstripe_sync_bytes(t.qlen, t.tlen, w, nr) + 255) & ~(size_t)255);
+      }
+      bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
+      blk.bd += (uint64_t)bound[k] << 8;
+      if (bd >= heavy_min) {
+        ++pt.nh;
+        pt.hb += bd;
+        ++blk.hnt;
+        blk.hbd += (uint64_t)bound[k] << 8;
+        blk.hsw += words;
+        blk.hoc += oc;
+        if (pt.nh <= hv_limit) hv.push_back((uint32_t)k);  // (beyond a quarter of the batch there is no split)
+      }
+    };
     auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv) {  // (lo: a multiple of the block size)
       for (size_t k = lo; k < hi; ++k) {
         const sdf_task &t = tasks[k];
@@ -227,68 +273,29 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           env.lane_recs[k].flag = 0xffffu;
         }
         if (!plan_detail::task_runs(t, env.degenerate)) continue;
-        BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
-        cap[k] = 0x80000000u;
-        const uint32_t oc = order_entries(t);
-        ++blk.nt;
-        blk.oc += oc;
-        {
-          // A task that wants no CIGAR needs no direction flags -- except on the stripe kernels, whose progress words,
-          // hand-over values and edge columns live in HBM right behind the task's flag blocks: those tasks reserve the
-          // whole layout whatever they want.
+        // a small full-band task with nothing special asked of it is the lane kernel's (if the batch turns out to hold
+        // enough of them: else these tasks are accounted for in a second pass, below): sixteen bytes for the device
+        // and four sums, nothing else
+        if (lane_scan && t.qlen <= kLaneMaxLen && t.tlen <= kLaneMaxLen && (int64_t)t.qlen * t.tlen <= kLaneMaxCells &&
+            (t.w < 0 || t.w >= std::max(t.qlen, t.tlen)) && t.zdrop < 0 && !(t.flag & ~(SDF_FLAG_SCORE_ONLY | SDF_FLAG_REV_CIGAR)) &&
+            (uint64_t)t.q_off < 0xffffffffull && (uint64_t)t.t_off < 0xffffffffull) {
           const bool with_dir = env.want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY);
-          const uint32_t words = with_dir ? (uint32_t)(t.qlen + t.tlen + 2) : 0u;
-          cap[k] |= words;
-          blk.sw += words;
-          const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
-          const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
-          const size_t nrow = (size_t)t.qlen + t.tlen - 1;
-          const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
-          size_t bd = 0;
-          if (with_dir) {
-            bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
-            if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
-            // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
-            if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
-          }
-          if (t.tlen > env.stripe_min && t.tlen <= 8192 && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
-            for (int nr = 1; nr <= 4; nr *= 2)
-              bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
-          if (banded_long(t)) {
-            const int nr = plan_detail::bstripe_nreg(t.tlen);
-            bd = std::max(bd, (bstripe_dir_bytes(t.qlen, t.tlen, w, nr) + bstripe_sync_bytes(t.qlen, t.tlen, w, nr) + 255) & ~(size_t)255);
-          }
-          bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
-          blk.bd += (uint64_t)bound[k] << 8;
-          // a small full-band task with nothing special asked of it: the lane kernel's, if the batch has enough of them
-          if (lane_scan && t.qlen <= kLaneMaxLen && t.tlen <= kLaneMaxLen && (int64_t)t.qlen * t.tlen <= kLaneMaxCells &&
-              w >= std::max(t.qlen, t.tlen) && t.zdrop < 0 && !(t.flag & ~(SDF_FLAG_SCORE_ONLY | SDF_FLAG_REV_CIGAR)) &&
-              (uint64_t)t.q_off < 0xffffffffull && (uint64_t)t.t_off < 0xffffffffull && bd < heavy_min) {
-            cut.lane[k] = 1;
-            LaneRec &lr = env.lane_recs[k];
-            lr.q_word = (uint32_t)t.q_off;
-            lr.t_word = (uint32_t)t.t_off;
-            lr.out_idx = (uint32_t)k;
-            lr.qlen_m1 = (uint8_t)(t.qlen - 1);
-            lr.tlen_m1 = (uint8_t)(t.tlen - 1);
-            lr.flag = (uint16_t)((t.flag & SDF_FLAG_REV_CIGAR) | (with_dir ? 0 : SDF_FLAG_SCORE_ONLY));
-            ++blk.lnt;
-            blk.lbd += (uint64_t)bound[k] << 8;
-            blk.lsw += words;
-            blk.loc += oc;
-            blk.ldir += with_dir ? lane_dir_bytes(t.qlen, t.tlen) : 0;
-            ++blk.lcls[lane_class(t.tlen)];
-          }
-          if (bd >= heavy_min) {
-            ++pt.nh;
-            pt.hb += bd;
-            ++blk.hnt;
-            blk.hbd += (uint64_t)bound[k] << 8;
-            blk.hsw += words;
-            blk.hoc += oc;
-            if (pt.nh <= hv_limit) hv.push_back((uint32_t)k);  // (beyond a quarter of the batch there is no split)
-          }
+          BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
+          cut.lane[k] = 1;
+          LaneRec &lr = env.lane_recs[k];
+          lr.q_word = (uint32_t)t.q_off;
+          lr.t_word = (uint32_t)t.t_off;
+          lr.out_idx = (uint32_t)k;
+          lr.qlen_m1 = (uint8_t)(t.qlen - 1);
+          lr.tlen_m1 = (uint8_t)(t.tlen - 1);
+          lr.flag = (uint16_t)((t.flag & SDF_FLAG_REV_CIGAR) | (with_dir ? 0 : SDF_FLAG_SCORE_ONLY));
+          ++blk.lnt;
+          blk.lsw += with_dir ? (uint32_t)(t.qlen + t.tlen + 2) : 0u;
+          blk.ldir += with_dir ? lane_dir_bytes(t.qlen, t.tlen) : 0;
+          ++blk.lcls[lane_class(t.qlen)];
+          continue;
         }
+        account(k, pt, hv);
       }
     };
     // (on the context's parked planning threads when there are any; this thread takes a share too)
@@ -315,6 +322,24 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     for (int q = 1; q < nthr; ++q) pool->submit([work, q] { work(q); });
     work(0);
     while (share->done.load() < nrun) std::this_thread::yield();  // (a helper still inside its last run)
+    if (lane_scan) {
+      for (const BatchCut::Block &blk : cut.blocks) {
+        cut.n_lane += blk.lnt;
+        cut.lane_stage_words += blk.lsw;
+        cut.lane_dir_bytes += blk.ldir;
+        for (int c = 0; c < 4; ++c) cut.lane_cls[c] += blk.lcls[c];
+      }
+      // (a quarter of the workspace in 4-bit flags would be more than 10^10 cells of small tasks)
+      cut.use_lane = cut.n_lane >= env.lane_min && cut.lane_dir_bytes + 256 <= ws_budget / 4;
+      if (!cut.use_lane && cut.n_lane) {  // too few of them after all: they are ordinary tasks
+        for (size_t k = 0; k < n; ++k)
+          if (cut.lane[k]) {
+            cut.lane[k] = 0;
+            account(k, parts[0], hparts[0]);
+          }
+        cut.n_lane = 0;
+      }
+    }
     for (int q = 0; q < nthr; ++q) {
       if (parts[q].bad) {
         *err = "unknown task flag";
@@ -324,26 +349,14 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       heavy_bytes += parts[q].hb;
     }
   }
-  if (lane_scan) {
-    for (const BatchCut::Block &blk : cut.blocks) {
-      cut.n_lane += blk.lnt;
-      cut.lane_stage_words += blk.lsw;
-      cut.lane_dir_bytes += blk.ldir;
-      for (int c = 0; c < 4; ++c) cut.lane_cls[c] += blk.lcls[c];
-    }
-    cut.use_lane = cut.n_lane >= env.lane_min;
-  }
   const auto tc1 = std::chrono::steady_clock::now();
   // Heavy tasks leave the chunk rotation when they are a minority: they are planned and launched FIRST, all together
   // (a launch of few long tasks lasts as long as its longest task: one such launch per kernel, not one per chunk), with
   // a workspace slice of their own, and run next to the chunks of ordinary tasks.
   cut.split_heavy = cut.pipelined && cut.n_heavy * 4 <= n;
   const size_t heavy_budget = cut.split_heavy && cut.n_heavy ? std::min(heavy_bytes + 256, ws_budget / 2) : 0;
-  const size_t lane_budget = cut.use_lane ? std::min(cut.lane_dir_bytes + 256, ws_budget / 4) : 0;
-  if (cut.use_lane && cut.lane_dir_bytes + 256 > lane_budget) {  // (a quarter of the workspace in 4-bit flags: > 10^10 cells)
-    cut.use_lane = false;
-  }
-  const size_t region_budget = (ws_budget - heavy_budget - (cut.use_lane ? lane_budget : 0)) / cut.max_regions;
+  const size_t lane_budget = cut.use_lane ? cut.lane_dir_bytes + 256 : 0;
+  const size_t region_budget = (ws_budget - heavy_budget - lane_budget) / cut.max_regions;
   cut.heavy.assign(cut.split_heavy ? n : 0, 0);
 
   // ---- chunk boundaries ----
@@ -405,12 +418,12 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       const size_t target = normal.empty() && nch > 1 ? first_target : chunk_target;
       // (all tasks of the range count towards the target, as they cost planning time whether they run or not)
       if (k0 > cur.s && k0 - cur.s >= target) close_at(k0);
-      const uint64_t bbd = blk.bd - (hv ? blk.hbd : 0) - (ln ? blk.lbd : 0);
+      const uint64_t bbd = blk.bd - (hv ? blk.hbd : 0);  // (lane tasks are not in a block's sums)
       if (acc + bbd <= region_budget) {
         acc += bbd;
-        cur.ntask += blk.nt - (hv ? blk.hnt : 0) - (ln ? blk.lnt : 0);
-        cur.stage_words += blk.sw - (hv ? blk.hsw : 0) - (ln ? blk.lsw : 0);
-        cur.order_cap += blk.oc - (hv ? blk.hoc : 0) - (ln ? blk.loc : 0);
+        cur.ntask += blk.nt - (hv ? blk.hnt : 0);
+        cur.stage_words += blk.sw - (hv ? blk.hsw : 0);
+        cur.order_cap += blk.oc - (hv ? blk.hoc : 0);
         continue;
       }
       for (size_t k = k0; k < k1; ++k) {

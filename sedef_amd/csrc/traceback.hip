@@ -42,8 +42,8 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
     a.idx = (int64_t)r * tk.ncol16 + (i - b.lo);
     a.meta = 0;
   } else if (LAYOUT == 5) {
-    // lane kernel (extz2_lane.hip): rows of ceil(tlen / 8) words per query position, a nibble per cell
-    a.idx = (int64_t)j * ((tk.tlen + 7) >> 3) + (i >> 3);
+    // lane kernel (extz2_lane.hip): per tile of 16 target positions two words per query position, a nibble per cell
+    a.idx = ((int64_t)(i >> 4) * tk.qlen + j) * 2 + ((i >> 3) & 1);
     a.meta = (uint32_t)((i & 7) * 4);
   } else if (LAYOUT == 4) {
     // banded stripes (extz2_bstripe.hip): a flag region per stripe of 128 * nreg target positions, 16-row blocks counted
