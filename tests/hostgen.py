@@ -260,6 +260,114 @@ def make_big_genome(path, seed=7, chrom_lens=(25_000_000, 18_000_000, 9_000_000,
     return genome, len(beds)
 
 
+def _write_fasta(path, names, seqs, rng, n_runs_per_mb=0.5):
+    """FASTA (60 columns) + .fai from code arrays: ~40 % soft-masked in runs of 50..400, a few N runs.  Returns
+    {name: genome string}."""
+    genome = {}
+    with open(path, "wb") as f, open(path + ".fai", "w") as fai:
+        off = 0
+        for name, s in zip(names, seqs):
+            L = len(s)
+            ch = _CODE2CHR[s]
+            runs = rng.integers(50, 400, L // 100 + 10)
+            ends = np.cumsum(runs)
+            ends = ends[ends < L]
+            masked = rng.random(len(ends) + 1) < 0.4
+            mask = np.repeat(masked, np.diff(np.concatenate(([0], ends, [L]))))
+            ch = np.where(mask, ch + 32, ch).astype(np.uint8)
+            for _ in range(max(2, int(L / 1e6 * n_runs_per_mb))):
+                p, n = int(rng.integers(0, L - 6000)), int(rng.integers(100, 5000))
+                ch[p:p + n] = ord("N")
+            head = (">%s synthetic\n" % name).encode()
+            f.write(head)
+            off += len(head)
+            fai.write("%s\t%d\t%d\t60\t61\n" % (name, L, off))
+            full = L // 60
+            body = np.empty((full, 61), np.uint8)
+            body[:, :60] = ch[:full * 60].reshape(full, 60)
+            body[:, 60] = 10
+            f.write(body.tobytes())
+            off += full * 61
+            if L % 60:
+                f.write(ch[full * 60:].tobytes() + b"\n")
+                off += L % 60 + 1
+            genome[name] = ch.tobytes().decode()
+    return genome
+
+
+def make_chr1_genome(path, seed=13, chrom_lens=(249_000_000, 6_000_000), n_pairs=2100, slot=125_000, small=12_500):
+    """BASELINE configs[2] at size: a chr1-sized chromosome (249 Mb) and a small second one with
+    `n_pairs` planted duplications of 1-100 kb (log-uniform) at 2-25 % divergence -- forward and reverse-complement, a
+    third with one or two large indels (50-3000 bases), every tenth a TANDEM copy on the same chromosome and strand right
+    behind its source (the extended hits overlap: src/chain.cc:67-69, src/refine.cc:42-53), copies flush against both
+    chromosome ends -- plus FASTA, .fai and the seed BED `sedef search` would hand to `align bucket`.  Long duplications
+    mean many chains per pair, far gaps between hits of a refined path (src/refine.cc:77), hits extended to the 15 kb cap
+    (src/hit.cc:200-207) and DP tasks of 10^7 cells inside the stage.  Returns ({name: genome string}, seed lines)."""
+    rng = np.random.default_rng(seed)
+    names = ["chr1", "chr1b"][:len(chrom_lens)]
+    seqs = [rng.integers(0, 4, L, dtype=np.uint8) for L in chrom_lens]
+    # regions: slots of `slot` bases for copies of more than 10 kb, a ninth of them cut into slots of `small` bases for the
+    # short ones; (chromosome, start, size), in random order
+    big = [(c, k * slot, slot) for c, L in enumerate(chrom_lens) for k in range(1, L // slot - 1)]
+    ends = [(c, (L // slot - 1) * slot, L - (L // slot - 1) * slot) for c, L in enumerate(chrom_lens)] + \
+           [(c, 0, slot) for c, L in enumerate(chrom_lens)]
+    big = [big[i] for i in rng.permutation(len(big))]
+    n_cut = len(big) // 9
+    tiny = [(c, st + q * small, small) for (c, st, _) in big[:n_cut] for q in range(slot // small)]
+    tiny = [tiny[i] for i in rng.permutation(len(tiny))]
+    big = big[n_cut:]
+    beds = []
+    k = 0
+    while len(beds) < n_pairs:
+        L = int(np.exp(rng.uniform(np.log(1000), np.log(100_000))))
+        d = float(rng.uniform(0.02, 0.25))
+        if k < len(ends):  # (the copies at the chromosome ends must survive the chaining: moderate length and divergence)
+            L, d = int(rng.integers(12_000, 40_000)), float(rng.uniform(0.02, 0.08))
+        pool = tiny if L <= small - 2500 else big
+        if len(pool) < 2:
+            break
+        sc, s0, ssz = pool.pop()
+        tandem = k % 10 == 9 and 2 * L + 4500 < ssz
+        sp = s0 if tandem else s0 + int(rng.integers(0, ssz - L + 1))
+        out = _mutate_codes(rng, seqs[sc][sp:sp + L], d)
+        if rng.random() < 0.33 and len(out) > 600:
+            for _ in range(int(rng.integers(1, 3))):
+                if len(out) <= 600:
+                    break
+                kk = int(rng.integers(200, len(out) - 200))
+                n_ind = int(rng.integers(50, 3000))
+                if rng.random() < 0.5:
+                    out = np.concatenate([out[:kk], rng.integers(0, 4, n_ind, dtype=np.uint8), out[kk:]])
+                else:
+                    out = np.concatenate([out[:kk], out[min(len(out) - 100, kk + n_ind):]])
+        rcf = bool(rng.random() < 0.45) and not tandem
+        if k < len(ends):
+            rcf = bool(k % 2)
+        if tandem:  # same chromosome, same strand, right behind the source
+            out = out[:ssz - L - 1500]
+            dc, dp = sc, sp + L + int(rng.integers(0, 1500))
+        elif k < len(ends):  # flush against a chromosome end / start
+            dc, d0, dsz = ends[k]
+            out = out[:dsz]
+            dp = chrom_lens[dc] - len(out) if d0 else 0
+        else:
+            dc, d0, dsz = pool.pop()
+            out = out[:dsz]
+            dp = d0 + int(rng.integers(0, dsz - len(out) + 1))
+        if rcf:
+            out = (3 - out)[::-1]
+        seqs[dc][dp:dp + len(out)] = out
+        j = int(rng.integers(0, 60))  # seeds are never exact
+        beds.append((names[sc], sp + j, sp + L - j, names[dc], dp + j // 2, dp + len(out) - j, rcf))
+        k += 1
+    genome = _write_fasta(path, names, seqs, rng, n_runs_per_mb=0.2)
+    with open(path + ".seeds.bed", "w") as f:
+        for (qn, qs, qe, rn, rs, re_, rcf) in beds:
+            f.write("%s\t%d\t%d\t%s\t%d\t%d\t\t\t+\t%s\t%d\t0\t\tOK\n" % (qn, qs, qe, rn, rs, re_, "-" if rcf else "+",
+                                                                        max(qe - qs, re_ - rs)))
+    return genome, len(beds)
+
+
 def chunk_case(seed=5, n=60050, d=0.03):
     """Two related sequences longer than Align::MAX_KSW_SEQ_LEN = 60,000 (reference: src/globals.h:54): align_helper
     cuts them into 60 kb x 60 kb chunks at equal offsets (src/align.cc:46-57)."""

@@ -18,6 +18,7 @@ import hostgen
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHA_FILE = os.path.join(ROOT, "tests", "golden", "stage_scale.sha256")
+SHA_CHR1 = os.path.join(ROOT, "tests", "golden", "stage_chr1.sha256")
 NBUCKETS = 4
 
 
@@ -187,3 +188,57 @@ def test_stage_scoring_overrides_gpu_equals_cpu(host, oracle, tmp_path):
     r = subprocess.run([CLI, "align", "generate", "-k", "11", "--match", "3", "--mismatch", "-5", "--gap-open", "-20",
                         "--gap-extend", "-2", fa, fa + ".bed"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout == open(cpu).read()
+
+
+# ---------------------------------------------------------------- BASELINE configs[2] at size: chr1-vs-chr1, fwd + rc
+@pytest.fixture(scope="module")
+def chr1_genome(tmp_path_factory):
+    d = tmp_path_factory.mktemp("chr1")
+    fa = str(d / "genome.fa")
+    genome, nseeds = hostgen.make_chr1_genome(fa)
+    return fa, genome, nseeds
+
+
+def _chr1_checks(lines, genome, nseeds):
+    """What the chr1-sized run must exercise besides byte equality: every line consistent with the genome, both strands,
+    alignments of tens of kilobases, copies on the same chromosome right behind their source, chromosome ends."""
+    assert nseeds >= 1800 and len(genome["chr1"]) >= 249_000_000
+    assert len(lines) >= 1500
+    check_bedpe(lines, genome)
+    f = [ln.split("\t") for ln in lines]
+    spans = np.array([int(x[11]) for x in f])
+    assert (spans >= 50_000).sum() >= 40 and (spans >= 10_000).sum() >= 500 and spans.max() >= 90_000
+    assert sum(1 for x in f if x[9] == "-") >= 500 and sum(1 for x in f if x[9] == "+") >= 500
+    near = sum(1 for x in f if x[0] == x[3] and x[9] == "+" and abs(int(x[4]) - int(x[2])) < 3000)
+    assert near >= 60  # tandem copies: query end and reference start a gap apart
+    at_end = sum(1 for x in f if len(genome[x[3]]) - int(x[5]) <= 8 or int(x[4]) <= 8)
+    assert at_end >= 2
+
+
+def test_stage_chr1_scale_cpu_reference_kernel(host, oracle, chr1_genome, tmp_path):
+    """configs[2] at size, CPU leg: a 249 Mb chromosome with 1-100 kb duplications at 2-25 % divergence through `align
+    bucket` -> `align generate`, the reference's own ksw_extz2_sse as the DP -> the committed stdout hash."""
+    fa, genome, nseeds = chr1_genome
+    hook, _keep = cpu_dp_hook(oracle)
+    text, pairs, tasks = run_stage(host, tmp_path, "cpu", fa, hook)
+    lines, rc, chroms = _summary(text)
+    assert nseeds - 20 <= pairs <= nseeds and tasks >= 500_000  # (`align bucket` merges seeds that overlap)
+    _chr1_checks(lines, genome, nseeds)
+    sha = hashlib.sha256(text.encode()).hexdigest()
+    if os.environ.get("SDF_WRITE_GOLDEN"):
+        open(SHA_CHR1, "w").write("%s  %d lines, %d pairs, %d DP tasks (tests/hostgen.py: make_chr1_genome seed 13)\n" % (
+            sha, len(lines), pairs, tasks))
+    assert sha == (open(SHA_CHR1).read().split()[0] if os.path.exists(SHA_CHR1) else None)
+
+
+@pytest.mark.gpu
+def test_stage_chr1_scale_gpu_equals_cpu_and_committed_hash(host, oracle, chr1_genome, tmp_path):
+    fa, genome, nseeds = chr1_genome
+    hook, _keep = cpu_dp_hook(oracle)
+    cpu, pairs, _ = run_stage(host, tmp_path, "cpu", fa, hook)
+    gpu, gpairs, gtasks = run_stage(host, tmp_path, "gpu", fa, None)
+    assert gpairs == pairs and gtasks >= 500_000
+    assert gpu == cpu
+    lines, rc, chroms = _summary(gpu)
+    _chr1_checks(lines, genome, nseeds)
+    assert hashlib.sha256(gpu.encode()).hexdigest() == open(SHA_CHR1).read().split()[0]
