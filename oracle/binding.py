@@ -364,6 +364,12 @@ class ReferenceAlign:
         n, s, r = self.buf.value.decode().split("|")
         return n, s, r == "1"
 
+    def fmt_double(self, x):
+        """fmt::format("{}", double) of the reference's vendored fmt (extern/format.cc)."""
+        self.lib.ref_fmt_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
+        assert self.lib.ref_fmt_double(float(x), self.buf, len(self.buf)) == 0
+        return self.buf.value.decode()
+
     def segtree_script(self, pts, ops):
         """The reference's own SegmentTree<T> (src/segment.h, src/segment.tpp) driven by a script of activate /
         deactivate / rmq calls (oracle/ref_align_driver.cc: ref_segtree_script).  At least two points."""

@@ -211,6 +211,10 @@ int ref_segtree_script(const int *pts, int n, const int *ops, int nops, int *out
   return size;
 }
 
+// fmt::format("{}", double) of the reference's vendored fmt (extern/format.cc, 4.0.1): how `stats generate` prints its
+// floating-point columns (src/stats_main.cc:315-334)
+int ref_fmt_double(double x, char *out, size_t cap) { return emit(fmt::format("{}", x), out, cap); }
+
 // CLI scoring overrides (src/align_main.cc:343-352 assign these statics; src/align.cc:84-86,343-456 read them)
 int ref_set_scoring(int match, int mismatch, int gap_open, int gap_extend) {
   Globals::Align::MATCH = match;

@@ -4,6 +4,7 @@
   stage_bench.py [genome_len] [n_duplications] [runs]     the product CLI (GPU provider) on one bucket (round 1 / 2 genomes)
   stage_bench.py --chr1 [runs]                            BASELINE configs[2] at size: tests/hostgen.py: make_chr1_genome
                                                           (249 Mb, 1-100 kb copies at 2-25 %) -> align bucket (4) -> generate
+  ... --one-bucket                                        (with --chr1) all seed pairs in ONE bucket file: one process
   ... --cpu                                               the same host pipeline with the REFERENCE kernel as the DP
                                                           (oracle/_ref: ksw_extz2_sse behind the library's test hook, one
                                                           task stream per usable host core) instead of the GPU: the
@@ -60,7 +61,7 @@ def main():
         genome, nseeds = hostgen.make_chr1_genome(fa)
         out = os.path.join(d, "buckets")
         os.makedirs(out)
-        host.bucket(fa + ".seeds.bed", 4, out, fa)
+        host.bucket(fa + ".seeds.bed", 1 if "--one-bucket" in sys.argv else 4, out, fa)
         beds = [os.path.join(out, f) for f in sorted(os.listdir(out))]
         print("chr1-sized genome (%d + %d bp), %d seed pairs in %d buckets (generated in %.1fs)" % (
             len(genome["chr1"]), len(genome["chr1b"]), nseeds, len(beds), time.time() - t0), flush=True)
@@ -74,7 +75,7 @@ def main():
         print("genome %d bp, %d planted duplications (generated in %.1fs)" % (glen, nsd, time.time() - t0), flush=True)
     hook = cpu_hook() if cpu else None
     for it in range(runs):
-        total, lines, tasks, cells = 0.0, 0, 0, 0
+        total, lines, tasks, cells, stage_s = 0.0, 0, 0, 0, 0.0
         for bed in beds:
             if cpu:
                 t0 = time.time()
@@ -86,12 +87,16 @@ def main():
             else:
                 rc, dt, nl, tail = run_cli(fa, bed)
                 lines += nl
+                own = [ln for ln in tail if "Finished" in ln]
+                if own:  # the stage's own clock (src/align_main.cc:335-336 prints the same line): without process start-up
+                    stage_s += float(own[0].split(" in ")[1].split("s")[0])
                 print("  run %d %s: rc=%d wall %.2fs, %d output lines\n    %s" % (it, os.path.basename(bed), rc, dt, nl, "\n    ".join(tail)),
                       flush=True)
             total += dt
         print("run %d: %s, all buckets one after the other: %.2fs wall, %d output lines%s" % (
             it, "CPU leg (reference kernel on %d usable cores of %d)" % (cores(), os.cpu_count()) if cpu else "GPU path (product CLI)",
-            total, lines, (", %d DP tasks, %.3e cells" % (tasks, cells)) if cpu else ""), flush=True)
+            total, lines, (", %d DP tasks, %.3e cells" % (tasks, cells)) if cpu else
+            (" (%.2fs on the stage's own clock: without process start-up and HIP initialisation)" % stage_s)), flush=True)
 
 
 if __name__ == "__main__":

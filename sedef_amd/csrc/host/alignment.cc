@@ -423,6 +423,39 @@ void Alignment::trim_back() {
   recount(best_matches);
 }
 
+// ---- a range of columns (reference: subhit, src/stats_main.cc:33-84, up to the trims) ------------------------
+Alignment Alignment::slice_columns(int start, int end, int &sa, int &la, int &sb, int &lb) const {
+  Alignment out;
+  out.seq_a = seq_a;
+  out.seq_b = seq_b;
+  out.len_a = len_a;
+  out.len_b = len_b;
+  sa = la = sb = lb = 0;
+  int col = 0;
+  for (auto &run : cigar) {
+    const int lo = std::max(col, start), hi = std::min(col + run.second, end);
+    const int before = std::min(col + run.second, start) - col;  // columns of the run before `start`
+    if (before > 0) {
+      if (takes_a(run.first)) sa += before;
+      if (takes_b(run.first)) sb += before;
+    }
+    if (hi > lo) {
+      out.cigar.push_back({run.first, hi - lo});
+      if (takes_a(run.first)) la += hi - lo;
+      if (takes_b(run.first)) lb += hi - lo;
+    }
+    col += run.second;
+    if (col >= end) break;
+  }
+  out.start_a = start_a + sa;
+  out.end_a = out.start_a + la;
+  out.start_b = start_b + sb;
+  out.end_b = out.start_b + lb;
+  out.normalise();
+  out.recount(count_matches(seq_a + out.start_a, seq_b + out.start_b, out.cigar));
+  return out;
+}
+
 // ---- merge -------------------------------------------------------------------------------------------
 // Columns leave from the end until `trim` bases of the query (or of the reference) have gone with them; a column that
 // does not consume that sequence leaves too while the count is still short (src/align.cc:511-517, :543-549).

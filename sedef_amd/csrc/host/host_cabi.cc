@@ -62,6 +62,33 @@ int sdfh_generate(const char *ref_path, const char *bed_path, int kmer, const ch
   }
 }
 
+// `sedef stats generate genome.fa final.bed > out` (reference: src/stats_main.cc:339-389); test_cols: the oracle's column
+// walker instead of the device (CPU tests).  stats: hits read, pieces, columns; returns the lines written or -1.
+long sdfh_stats_generate(const char *ref_path, const char *bed_path, const char *out_path, int max_ok_gap, int min_split,
+                         int min_uppercase, double max_error, test_cols_fn test_cols, int device, long long *stats) {
+  try {
+    StatsParams sp;
+    sp.max_ok_gap = max_ok_gap;
+    sp.min_split = min_split;
+    sp.min_uppercase = min_uppercase;
+    sp.max_scaled_error = max_error;
+    FILE *out = fopen(out_path, "w");
+    if (!out) throw std::string("Cannot open output ") + out_path;
+    const long lines = stats_generate(ref_path, bed_path, out, sp, test_cols, device, stats);
+    fclose(out);
+    return lines;
+  } catch (std::string &s) {
+    g_err = s;
+    return -1;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// fmt 4.0.1 "{}" of a double, as `stats generate` prints it (test hook)
+int sdfh_format_double(double x, char *buf, size_t cap) { return copy_out(format_double(x), buf, cap); }
+
 // Alignment(fa, fb) (reference: src/align.cc:76-88): CIGAR string + counters {matches, mismatches, gaps, gap_bases, span}
 static int alignment_pair_impl(const Params &p, const char *fa, const char *fb, test_dp_fn test_dp, int device,
                                char *cigar, size_t cap, int *counts);

@@ -202,6 +202,23 @@ class Alignment {
   void trim_front();  // keep the best-scoring suffix of the columns (src/align.cc:343-398)
   void trim_back();   // keep the best-scoring prefix (src/align.cc:400-456)
 
+  // the alignment of columns [start, end) of this one: runs rebuilt from the remaining columns like
+  // cigar_from_alignment does (src/align.cc:480-501), counters recounted; sa / sb = bases of a / b in the columns before
+  // `start`, la / lb = in the kept ones (src/stats_main.cc:33-56: subhit's own counting)
+  Alignment slice_columns(int start, int end, int &sa, int &la, int &sb, int &lb) const;
+  // every column in order: f(column, character of a or '-', character of b or '-')
+  template <typename F>
+  void for_each_column(F f) const {
+    int ia = start_a, ib = start_b, col = 0;
+    for (auto &run : cigar)
+      for (int i = 0; i < run.second; i++, col++) {
+        const char ca = run.first != 'I' ? seq_a[ia++] : '-', cb = run.first != 'D' ? seq_b[ib++] : '-';
+        f(col, ca, cb);
+      }
+  }
+  const char *bases_a() const { return seq_a + start_a; }  // the bases the columns cover
+  const char *bases_b() const { return seq_b + start_b; }
+
   std::string cigar_string() const;
   int span() const { return columns_; }  // alignment columns
   int matches() const { return error.matches; }
@@ -261,6 +278,20 @@ class FastaReference {
   size_t size_ = 0;
   std::map<std::string, FastaIndexEntry> index_;
 };
+
+// ---- `sedef stats generate` (reference: src/stats_main.cc:33-336), scope row f4 -----------------------
+struct StatsParams {  // Globals::Stats (src/globals.cc:36-39), CLI overrides src/stats_main.cc:485-488
+  int max_ok_gap = -1, min_split = 1000, min_uppercase = 100;
+  double max_scaled_error = 0.5;
+};
+// TEST HOOK: a column walker with the oracle's signature (oracle/stats_oracle.c: sdfo_stats_columns) instead of the device
+typedef int (*test_cols_fn)(const char *, int, const char *, int, const uint32_t *, int, int32_t *, char *, char *);
+// Reads the BEDPE of `align generate`, writes the table of `stats generate` to `out`; the per-column counters of every
+// piece come from sdf_stats_columns_batch on `device` (or from `test`).  Returns the number of lines written (header
+// excluded); stats[0..2] = hits read, pieces examined, alignment columns walked.
+long stats_generate(const std::string &ref_path, const std::string &bed_path, FILE *out, const StatsParams &sp,
+                    test_cols_fn test, int device, long long *stats);
+std::string format_double(double x);  // fmt 4.0.1 "{}" of a double, as the reference prints columns 22-25 and 35
 
 // ---- utilities (reference: src/util.cc:33-48, src/common.h:56-99) ----------------------------------
 void set_alignment_scoring(const Params &p);  // Align::MATCH and co. are process-wide (src/globals.cc:25-28)

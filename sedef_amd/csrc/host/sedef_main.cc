@@ -92,7 +92,9 @@ int main(int argc, char **argv) {
               "  params: -k/--kmer, --match, --mismatch, --gap-open, --gap-extend (default 5, -4, -40, -1)\n"
               "sedef align bucket -n [count] [bed_directory(/)] [buckets/] [genome.fa]\n"
               "  bucket BEDs into [count] files for the alignment stage (--extend-ratio, --max-extend, --merge-dist)\n"
-              "Other SEDEF stages (search, stats, translate) are not part of this build.\n");
+              "sedef stats generate [genome.fa] [final.bed]\n"
+              "  the per-alignment table of the final calls (--max-ok-gap, --min-split, --uppercase, --max-error)\n"
+              "Other SEDEF stages (search, stats diff, translate) are not part of this build.\n");
       return 0;
     } else if (command == "align") {
       Args a(argc - 2, argv + 2);
@@ -128,6 +130,22 @@ int main(int argc, char **argv) {
       } else {
         throw std::string("Unknown align command");
       }
+    } else if (command == "stats") {
+      // `sedef stats generate [--max-ok-gap N --min-split N --uppercase N --max-error X] genome.fa final.bed`
+      // (reference: src/stats_main.cc:482-510); `stats diff` (WGAC comparison) is not part of this build
+      Args a(argc - 2, argv + 2);
+      StatsParams sp;
+      a.get({"max-ok-gap"}, sp.max_ok_gap);
+      a.get({"min-split"}, sp.min_split);
+      a.get({"uppercase"}, sp.min_uppercase);
+      a.getd({"max-error"}, sp.max_scaled_error);
+      if (a.pos.size() < 3) throw std::string("Not enough arguments to stats");
+      if (a.pos[0] != "generate") throw std::string("Unknown stats command");
+      const char *dv = getenv("SDF_DEVICE");
+      long long st[3] = {0, 0, 0};
+      const long lines = stats_generate(a.pos[1], a.pos[2], stdout, sp, nullptr, dv ? atoi(dv) : 0, st);
+      fprintf(stderr, "Processed hit %lld out of %lld... done! (%lld pieces, %lld columns on the device, %ld lines)\n", st[0], st[0],
+              st[1], st[2], lines);
     } else {
       fprintf(stderr, "Whoops, invalid command!\n");
     }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_SRC = os.path.join(_HERE, "csrc", "host")
 LIB = os.path.join(_HERE, "lib", "libsedef_host.so")
 CLI = os.path.join(_HERE, "bin", "sedef")
-_SOURCES = ["alignment.cc", "hit_fasta.cc", "chain.cc", "pipeline.cc", "bucket.cc", "host_cabi.cc"]
+_SOURCES = ["alignment.cc", "hit_fasta.cc", "chain.cc", "pipeline.cc", "bucket.cc", "stats.cc", "host_cabi.cc"]
 
 
 def build_host(force=False):
@@ -142,6 +142,28 @@ def fasta_get(path, name, start, end):
 def merge(bed_lines, merge_dist=250):
     lib, buf = load_host(), _buffer()
     _err(lib, lib.sdfh_merge("\n".join(bed_lines).encode(), merge_dist, buf, len(buf)))
+    return buf.value.decode()
+
+
+def stats_generate(ref_path, bed_path, out_path, max_ok_gap=-1, min_split=1000, uppercase=100, max_error=0.5,
+                   test_cols=None, device=0):
+    """`sedef stats generate` (reference: src/stats_main.cc:339-389): the table of the final calls.  test_cols: a column
+    walker with the oracle's signature (oracle/stats_oracle.c) instead of the device.  Returns (lines, hits, pieces, columns)."""
+    lib = load_host()
+    st = (C.c_longlong * 3)()
+    lib.sdfh_stats_generate.restype = C.c_long
+    lib.sdfh_stats_generate.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
+                                        C.c_int, C.c_void_p]
+    n = lib.sdfh_stats_generate(ref_path.encode(), bed_path.encode(), out_path.encode(), max_ok_gap, min_split, uppercase,
+                                max_error, test_cols, device, st)
+    _err(lib, min(n, 0))
+    return (int(n),) + tuple(int(x) for x in st)
+
+
+def format_double(x):
+    lib, buf = load_host(), _buffer()
+    lib.sdfh_format_double.argtypes = [C.c_double, C.c_char_p, C.c_size_t]
+    _err(lib, lib.sdfh_format_double(float(x), buf, len(buf)))
     return buf.value.decode()
 
 
