@@ -49,6 +49,10 @@ __global__ void lane_sizes_kernel(const LaneRec *, const uint32_t *, int, unsign
 __global__ void lane_plan_kernel(const LaneRec *, const uint32_t *, int, const unsigned long long *, const unsigned long long *,
                                  int64_t, int64_t, PlanTask *);
 __global__ void extz2_lane_kernel(const PlanTask *, int, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
+__global__ void extz2_strip_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
+__global__ void extz2_strip_chain_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *,
+                                         unsigned long long *, int);
+__global__ void strip_chain_init_kernel(const PlanTask *, const int32_t *, uint8_t *);
 template <int LAYOUT, int G>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
 __global__ void cigar_scan_blocks_kernel(sdf_result *, int, unsigned long long *);
@@ -168,8 +172,9 @@ class WorkerPool {
       std::function<void()> job;
       {
         // A parked thread takes 0.1 - 3 ms to wake up on a box with a CPU quota -- as long as the whole scan of a million
-        // tasks it is woken for.  Batch calls come back to back (the bench loop, the stage driver's rounds): after a
-        // job a thread keeps looking for the next one for a short while before it parks.
+        // tasks it is woken for.  SDF_POOL_SPIN_US lets a thread keep looking for the next job for a while before it
+        // parks.  Off by default: measured on the 40,000-pair stage run (three lanes, 16-CPU quota) 300 us of looking cost
+        // more in throttled periods than it saved -- 0.42-0.95 s per run against 0.32-0.46 s.
         const auto t0 = std::chrono::steady_clock::now();
         bool got = false;
         while (!got && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_)) {
@@ -210,7 +215,7 @@ class WorkerPool {
   std::atomic<int> njobs_{0};
   int spin_us_ = [] {
     const char *e = getenv("SDF_POOL_SPIN_US");
-    return e ? atoi(e) : 300;
+    return e ? atoi(e) : 0;
   }();
 };
 }
@@ -234,6 +239,7 @@ struct sdf_ctx {
   HostBuf host_lane;
   DevBuf ln_recs, ln_keys, ln_vals, ln_sizes, ln_tmp;
   hipStream_t lane_stream = nullptr;
+  bool strip_enabled = true;  // SDF_NO_STRIP=1: full-band tasks of 257..1024 target bases stay on the window / stripe kernels
   bool lane_enabled = true;   // SDF_NO_LANE=1: small full-band tasks stay on the window kernels
   size_t lane_min = 8192;     // SDF_LANE_MIN: eligible tasks a batch must hold for the lane kernel to take them
   long long lane_tasks = 0;   // tasks of the last batch call the lane kernel took
@@ -254,6 +260,9 @@ struct sdf_ctx {
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
   int stripe_spin_cap = 1 << 24;  // SDF_STRIPE_SPIN_CAP: polls before a stripe's wait gives its task up (extz2_stripe.hip)
+  sdf_ctx *part_ctx = nullptr;    // second context of this device: the first part of a very large batch (sdf_api.hip)
+  hipEvent_t part_ev = nullptr;
+  bool is_part = false, pool_shared = false;
   sdf_ctx *rerun_ctx = nullptr;   // context without stripe kernels for the tasks they gave up (created when first needed)
   DevBuf rr_out, rr_cig, rr_map;  // its outputs, and the (record, staging slot) map of the merge
   long long reran = 0;            // tasks of the last batch call that were re-run after a stripe gave up

@@ -119,6 +119,13 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 118: SDF_PAIR(8, true); break;
     case 123: SDF_PAIR_TRACK(3); break;
     case 126: SDF_PAIR_TRACK(6); break;
+    case 600: /* chained strips: edge columns and row-0 sums reset first */
+      hipLaunchKernelGGL(strip_chain_init_kernel, one, dim3(64), 0, sdp, lp, lo, dir_reg);
+      hipLaunchKernelGGL(extz2_strip_chain_kernel, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap);
+      break;
+    case 500:
+      hipLaunchKernelGGL(extz2_strip_kernel, half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);
+      break;
     case 301: SDF_STRIPE(1) break;
     case 302: SDF_STRIPE(2) break;
     case 304: SDF_STRIPE(4) break;
@@ -242,7 +249,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
     // milliseconds each), the others for the ordinary chunks, which would otherwise queue behind them
     int qi = 0;
     if (pipelined) {
-      if (piped && L.cnt >= 2048 && L.bs < 300) {  // (a stripe class counts stripes, and lasts as long as its longest task)
+      if (piped && L.cnt >= 2048 && (L.bs < 300 || L.bs == 500)) {  // (a stripe class counts stripes, and lasts as long as its longest task)
         qi = ui;
       } else {  // least estimated work queued; with heavy tasks in the batch Q[0], Q[1], Q[4], Q[5] are theirs
         qi = run.have_heavy ? (heavy_chunk ? 0 : 2) : 1;
@@ -266,7 +273,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
     }
     launch_dp(L, sdp, run.d_plan + pb, run.d_order + ob + L.off, run.d_pool, run.sk, dir_reg, run.d_out, slabs,
               (unsigned long long *)ctx->misc_buf.p + 1, ctx->stripe_spin_cap);
-    if (L.bs >= 300 && L.bs < 500) run.any_stripe = true;
+    if ((L.bs >= 300 && L.bs < 500) || L.bs == 600) run.any_stripe = true;
     ++ctx->launches;
   }
   for (int q = 0; q < 8; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
@@ -300,6 +307,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       return s2;
     };
     const PlanTask *lp = run.d_plan + pb;
+    if (layouts & 64u) launch_traceback<6>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
     if (layouts & 16u) launch_traceback<4>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
     if (layouts & 8u) launch_traceback<3>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
     if (layouts & 4u) launch_traceback<2>(tb_solo, cnt, tb_on(), lp, run.d_pool, dir_reg, run.d_out, run.d_stage);
@@ -464,32 +472,54 @@ static int launch_lane(BatchRun &run, size_t n) {
 
 // Closes the batch on the caller's stream: waits for every chunk's traceback, scans n_cigar into cigar_off,
 // compacts the CIGARs into the caller's pool and reads the timing events.
-static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_cap, size_t *cigar_used) {
+// every traceback (and the lane tasks) of a part has finished on its stream; the tasks its stripe kernels gave up are run again
+static int join_part(BatchRun &run) {
   sdf_ctx *ctx = run.ctx;
   hipStream_t st = run.st;
   if (run.cut->pipelined)
     for (auto &ev : run.cev)
       if (ev.tb1) SDF_HIP(hipStreamWaitEvent(st, ev.tb1, 0));
   if (run.ev_lane) SDF_HIP(hipStreamWaitEvent(st, run.ev_lane, 0));
-  unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
-  hipEvent_t ev_c0 = next_event(ctx, run.evc), ev_c1 = next_event(ctx, run.evc), ev_end = next_event(ctx, run.evc);
-  SDF_HIP(hipEventRecord(ev_c0, st));
-  unsigned long long total = 0, gave_up = 0;  // (misc word 1: tasks whose stripe wavefronts gave up waiting for a neighbour)
-  const size_t np = run.cut->ntask_total + (run.cut->use_lane ? run.cut->n_lane : 0);  // (lane plan records follow the host's)
   if (run.any_stripe) {  // (one more round trip, for batches with stripe launches only)
-    SDF_HIP(hipMemcpyAsync(&gave_up, d_total + 1, sizeof(gave_up), hipMemcpyDeviceToHost, st));
+    unsigned long long gave_up = 0;  // (misc word 1: tasks whose stripe wavefronts gave up waiting for a neighbour)
+    SDF_HIP(hipMemcpyAsync(&gave_up, (unsigned long long *)ctx->misc_buf.p + 1, sizeof(gave_up), hipMemcpyDeviceToHost, st));
     SDF_HIP(hipStreamSynchronize(st));
     if (gave_up)
       if (int rc = rerun_abandoned(run, gave_up)) return rc;
-    gave_up = 0;
   }
+  return SDF_OK;
+}
+
+// `head`: the part of the call that was launched first, on another context and stream (null: the call is one part);
+// n / d_out: the whole call's.
+static int finish_batch(BatchRun &run, BatchRun *head, size_t n, sdf_result *d_out, uint32_t *d_cig, size_t cigar_cap,
+                        size_t *cigar_used) {
+  sdf_ctx *ctx = run.ctx;
+  hipStream_t st = run.st;
+  if (head) {
+    if (int rc = join_part(*head)) {
+      ctx->err = head->ctx->err;
+      return rc;
+    }
+    hipEvent_t done = next_event(head->ctx, head->evc);
+    SDF_HIP(hipEventRecord(done, head->st));
+    SDF_HIP(hipStreamWaitEvent(st, done, 0));
+  }
+  if (int rc = join_part(run)) return rc;
+  unsigned long long *d_total = (unsigned long long *)ctx->misc_buf.p;
+  hipEvent_t ev_c0 = next_event(ctx, run.evc), ev_c1 = next_event(ctx, run.evc), ev_end = next_event(ctx, run.evc);
+  SDF_HIP(hipEventRecord(ev_c0, st));
+  unsigned long long total = 0, gave_up = 0;
+  auto plan_records = [](const BatchRun &r) {  // (lane plan records follow the host's)
+    return r.cut->ntask_total + (r.cut->use_lane ? r.cut->n_lane : 0);
+  };
   if (run.want_cigar) {
     {
       const int nb = (int)((n + 1023) / 1024);
       unsigned long long *d_part = d_total + SDF_MISC_PARTS;
-      hipLaunchKernelGGL(cigar_scan_blocks_kernel, dim3((unsigned)nb), dim3(1024), 0, st, run.d_out, (int)n, d_part);
+      hipLaunchKernelGGL(cigar_scan_blocks_kernel, dim3((unsigned)nb), dim3(1024), 0, st, d_out, (int)n, d_part);
       hipLaunchKernelGGL(cigar_scan_parts_kernel, dim3(1), dim3(1024), 0, st, d_part, nb, d_total);
-      hipLaunchKernelGGL(cigar_scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, run.d_out, (int)n,
+      hipLaunchKernelGGL(cigar_scan_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n,
                          (const unsigned long long *)d_part);
     }
     SDF_HIP(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, st));
@@ -499,9 +529,13 @@ static int finish_batch(BatchRun &run, size_t n, uint32_t *d_cig, size_t cigar_c
       ctx->err = "CIGAR pool too small";
       return SDF_ERR_CIGAR_OVERFLOW;
     }
-    if (np)
-      hipLaunchKernelGGL(cigar_compact_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, st, run.d_plan, (int)np,
-                         run.d_out, run.d_stage, d_cig, (unsigned long long)cigar_cap);
+    for (const BatchRun *r : {(const BatchRun *)head, (const BatchRun *)&run}) {
+      if (!r) continue;
+      const size_t np = plan_records(*r);
+      if (np)
+        hipLaunchKernelGGL(cigar_compact_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, st, r->d_plan, (int)np,
+                           r->d_out, r->d_stage, d_cig, (unsigned long long)cigar_cap);
+    }
   }
   SDF_HIP(hipEventRecord(ev_c1, st));
   SDF_HIP(hipEventRecord(ev_end, st));

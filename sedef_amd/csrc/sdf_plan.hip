@@ -31,6 +31,7 @@ struct PlanEnv {
   int bstripe_min_rows = 4000;  // banded tasks with at least this many anti-diagonals: banded stripe kernel (0: off)
   // lane kernel (extz2_lane.hip): small full-band tasks leave the host's planning altogether when the batch holds at least
   // `lane_min` of them (fewer do not fill the device: a lane walks its matrix alone, ~100 cycles per cell)
+  bool strip_ok = false;    // strip kernel (extz2_strip.hip): the scoring is tame
   bool lane_ok = false;     // the scoring is tame and only CIGAR / score / mte are wanted
   size_t lane_min = 8192;
   LaneRec *lane_recs = nullptr;  // pinned, one per task of the batch: filled by the scan
@@ -148,6 +149,7 @@ struct PlanScratch {
   std::vector<plan_detail::Cls> cls;
   std::vector<char> tracked;
   std::vector<int32_t> stripe_lane, stripe_fill;
+  std::vector<uint64_t> strip_keys;
 };
 
 // Returns SDF_OK or an error code with *err set.
@@ -247,6 +249,14 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         const int nr = plan_detail::bstripe_nreg(t.tlen);
         bd = std::max(bd, (bstripe_dir_bytes(t.qlen, t.tlen, w, nr) + bstripe_sync_bytes(t.qlen, t.tlen, w, nr) + 255) & ~(size_t)255);
       }
+      // (strip kernel: a region per PAIR of tasks with as many column blocks, sized by the one with more rows -- which
+      // this pass does not know.  Every member reserves blocks x (1.5 rows + 127) records: a pair of m and M rows needs
+      // blocks x (M + 63), never more than the two reservations together)
+      // (wider targets: a chain of wavefronts, the edge columns between the blocks behind the records -- reserved, like
+      // the other stripe kernels' inter-stripe words, whatever the task wants)
+      if (env.strip_ok && t.tlen > 256 && t.tlen <= kStripChainMaxT && w >= std::max(t.qlen, t.tlen) &&
+          (with_dir || t.tlen > kStripMaxT))
+        bd = std::max(bd, ((size_t)strip_blocks(t.tlen) * (size_t)(t.qlen + t.qlen / 2 + 127) * 520 + 512 + 255) & ~(size_t)255);
       bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
       blk.bd += (uint64_t)bound[k] << 8;
       if (bd >= heavy_min) {
@@ -566,7 +576,19 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
     p.cig_slot = stage_words;
     stage_words += p.cig_cap;
-    if (p.pad_ != 7 && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
+    if (env.strip_ok && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) && t.tlen > 256 && t.tlen <= kStripMaxT &&
+        t.qlen >= 64 && t.qlen < (1 << 20) && strip_lds_bytes(t.qlen + t.qlen / 2 + 64, t.tlen) <= (size_t)env.max_dyn_lds) {
+      // full band, a few hundred to a thousand target bases: row-major strips, two tasks per wavefront
+      p.nreg = 1;
+      p.pad_ = 9;
+      win_need.back() = 0;
+    } else if (env.strip_ok && !env.no_stripe && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) &&
+               t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT && t.qlen >= 64 && t.qlen < (1 << 20)) {
+      // ... wider: the same strips, a wavefront per block of 512 columns, chained through HBM
+      p.nreg = 1;
+      p.pad_ = 10;
+      win_need.back() = 0;
+    } else if (p.pad_ != 7 && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
         t.tlen > env.stripe_min && t.tlen <= 8192) {
       // wide full-band task: one wavefront per stripe of 128 * nreg target positions (nreg: after this pass)
       if (stripe_lds_bytes(t.qlen, 4) <= (size_t)env.max_dyn_lds) {
@@ -700,6 +722,37 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     }
   }
 
+  {  // strip kernel: two tasks per wavefront, neighbours in the order of (column blocks, rows, columns) -- the wavefront
+     // steps through the larger of its two matrices; a task left over is paired with itself
+    std::vector<int32_t> &sl = sx.stripe_lane;  // (scratch)
+    std::vector<uint64_t> &keys = sx.strip_keys;
+    keys.clear();
+    for (size_t k = 0; k < cnt; ++k)
+      if (cp[k].pad_ == 9 || cp[k].pad_ == 10)  // (blocks, rows, columns, index): 5 + 20 + 14 + 24 bits
+        keys.push_back(((uint64_t)(strip_blocks(cp[k].tlen) - 1) << 58) | ((uint64_t)(uint32_t)cp[k].qlen << 38) |
+                       ((uint64_t)(uint32_t)cp[k].tlen << 24) | (uint64_t)k);
+    std::sort(keys.begin(), keys.end());
+    sl.resize(keys.size());
+    for (size_t q = 0; q < keys.size(); ++q) sl[q] = (int32_t)(keys[q] & 0xffffffu);
+    for (size_t q = 0; q < sl.size();) {
+      const int32_t x = sl[q];
+      int32_t y = x;  // the next one, if it has as many column blocks and at most half as many rows again
+      if (q + 1 < sl.size() && strip_blocks(cp[sl[q + 1]].tlen) == strip_blocks(cp[x].tlen) &&
+          cp[sl[q + 1]].qlen <= cp[x].qlen + cp[x].qlen / 2 + 64)
+        y = sl[q + 1];
+      q += y == x ? 1 : 2;
+      const int32_t lo = std::min(x, y), hi = std::max(x, y);
+      partner[lo] = hi;
+      partner[hi] = lo;
+      // (the rows the wavefront steps through: the traceback finds a block's records by it)
+      cp[lo].ncol16 = cp[hi].ncol16 = std::max(cp[lo].qlen, cp[hi].qlen);
+      if (cp[lo].pad_ == 10) {  // (the chain kernel finds a task's partner through its plan record)
+        cp[lo].zdrop = hi;
+        cp[hi].zdrop = lo;
+      }
+      if (lo != hi) c.paired += 2;
+    }
+  }
   tp2 = std::chrono::steady_clock::now();
   // launch classes: (kernel, LDS bytes rounded to a power of two); the direction-flag layout inside this chunk's
   // workspace region is fixed in the same pass
@@ -710,7 +763,18 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     {
       size_t need = 0;
       // (the stripe kernels keep their inter-stripe words behind the flag blocks: reserved for score-only tasks as well)
-      if (p.pad_ == 5)
+      if (p.pad_ == 9 || p.pad_ == 10) {
+        // one flag region per wavefront: task A's words are the even, its partner's the odd ones of the same records
+        if (partner[k] < (int32_t)k) {
+          need = 0;  // (placed with its partner, below)
+        } else {
+          const PlanTask &pb = cp[partner[k]];
+          const int qm = std::max(p.qlen, pb.qlen), tm = std::max(p.tlen, pb.tlen);
+          need = (strip_dir_bytes(qm, tm) + 255) & ~(size_t)255;
+          if (p.pad_ == 10) need += strip_chain_sync_bytes(qm, tm);
+          if (partner[k] != (int32_t)k) cp[partner[k]].dir_off = (int64_t)dir_acc + 4;
+        }
+      } else if (p.pad_ == 5)
         need = (stripe_dir_bytes(p.qlen, p.tlen, p.nreg) + stripe_sync_bytes(p.qlen, p.tlen, p.nreg) + 255) & ~(size_t)255;
       else if (p.pad_ == 7)
         need = (bstripe_dir_bytes(p.qlen, p.tlen, p.w, p.nreg) + bstripe_sync_bytes(p.qlen, p.tlen, p.w, p.nreg) + 255) & ~(size_t)255;
@@ -720,14 +784,25 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         else if (p.nreg) need = nblk * (size_t)p.nreg * 1024;
         else need = ((size_t)(p.qlen + p.tlen - 1) * (size_t)p.ncol16 + 16 + 255) & ~(size_t)255;
       }
-      p.dir_off = (int64_t)dir_acc;
+      if (!((p.pad_ == 9 || p.pad_ == 10) && partner[k] < (int32_t)k)) p.dir_off = (int64_t)dir_acc;
       dir_acc += need;
     }
-    c.layouts |= 1u << (p.nreg == 0 ? 0 : p.pad_ == 2 ? 2 : p.pad_ == 5 ? 3 : p.pad_ == 7 ? 4 : 1);
+    c.layouts |= 1u << (p.nreg == 0 ? 0 : p.pad_ == 2 ? 2 : p.pad_ == 5 ? 3 : p.pad_ == 7 ? 4 : (p.pad_ == 9 || p.pad_ == 10) ? 6 : 1);
     const int width = std::min(p.ncol16, (p.tlen + 15) / 16 * 16);
     int bs = width > 1024 ? 1024 : width > 256 ? 256 : 64;  // 4 cells per thread and pass over the row
     size_t lds = 2048, need;
-    if (p.pad_ == 2) {
+    if (p.pad_ == 10) {
+      if (partner[k] < (int32_t)k) continue;  // (its partner's entry stands for both)
+      bs = 600;  // chained strips: one wavefront (workgroup) per block of 512 columns of a pair of tasks
+      need = 16;
+      lds = 1024;
+    } else if (p.pad_ == 9) {
+      if (partner[k] < (int32_t)k) continue;  // placed together with its partner
+      bs = 500;  // strip kernel, one wavefront per pair of tasks
+      need = strip_lds_bytes(std::max(p.qlen, cp[partner[k]].qlen), std::max(p.tlen, cp[partner[k]].tlen));
+      lds = 1024;
+      while (lds < need) lds *= 2;
+    } else if (p.pad_ == 2) {
       if (partner[k] < (int32_t)k) continue;  // placed together with its partner
       // 100 + NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
       bs = tracked[k] ? 120 + p.nreg : 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
@@ -776,11 +851,11 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     cl->need_max = std::max(cl->need_max, need);
     {  // rough per-workgroup rates: general 64 / 256 / 1024 threads, HBM state, wave, pair
       const double rate = bs == 64 ? 0.03 : bs == 256 ? 0.1 : bs == 1024 ? 0.6 : bs == 2256 ? 0.3 : bs == 3024 ? 0.85
-                          : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 400 ? 0.3 : bs >= 300 ? 1.0 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..126)
+                          : bs == 2001 ? 0.3 : bs >= 1000 ? 0.08 : bs >= 600 ? 2.0 : bs >= 500 ? 0.5 : bs >= 400 ? 0.3 : bs >= 300 ? 1.0 : bs >= 200 ? 2.2 : bs >= 100 ? 0.25 : 0.13;  // (pair classes are 100..126)
       cl->est = std::max(cl->est, (double)(p.qlen + p.tlen) * (double)p.ncol16 / rate);
     }
     cl->idx.push_back((int32_t)k);
-    if (p.pad_ == 2) cl->idx.push_back(partner[k]);
+    if (p.pad_ == 2 || p.pad_ == 9) cl->idx.push_back(partner[k]);
   }
   c.dir_bytes = dir_acc;
   if (dir_acc > (c.heavy ? cut.heavy_need : cut.region_need)) {
@@ -813,7 +888,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       wmax = std::max(wmax, wk);
     }
     if (wmax < 2 * wmin) continue;  // tasks of one size: the order does not matter
-    if (x.bs >= 100 && x.bs < 200) {
+    if ((x.bs >= 100 && x.bs < 200) || x.bs == 500) {
       std::vector<std::pair<int32_t, int32_t>> pr(x.idx.size() / 2);
       for (size_t q = 0; q < pr.size(); ++q) pr[q] = {x.idx[2 * q], x.idx[2 * q + 1]};
       std::stable_sort(pr.begin(), pr.end(), [&](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) {
@@ -834,7 +909,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   for (auto &x : cls) {
     const bool hbm_cls = x.bs == 1000 || x.bs == 1001 || x.bs == 2001;
     const size_t lds_bytes = hbm_cls ? ((x.need_max + 255) & ~(size_t)255) : std::min(x.lds, (x.need_max + 511) & ~(size_t)511);
-    if (x.bs >= 300 && x.bs < 500) {
+    if ((x.bs >= 300 && x.bs < 500) || x.bs == 600) {
       // Stripe kernel: one entry per stripe, (stripe << 24) | task.  Workgroup i runs on XCD i mod 8 and workgroups
       // are dispatched in index order.  The tasks are dealt to the eight residues (most stripes first, to the residue
       // with the fewest so far): a task's stripes share an XCD (its L2 carries their edge words).  A task is a chain:
@@ -845,16 +920,25 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // ones fill in behind.  The key grows with s, so a stripe's left neighbour -- the only wavefront it ever waits
       // for -- has a smaller index on the same XCD: resident or finished.
       // (Entries with stripe index 255 do nothing: they keep the residues aligned where the lists differ in length.)
-      const bool banded = x.bs >= 400;  // (banded stripe kernel: stripes over the padded target, 2 * 128 * nreg rows apart)
-      const int nreg = x.bs - (banded ? 400 : 300);
+      // (chained strips, extz2_strip.hip: an entry stands for a PAIR of tasks -- the one listed and its partner --, a
+      // "stripe" is a block of 512 columns of the wider of the two, 64 steps behind the block to its left, and the chain
+      // is as long as the rows of the longer plus 64 per block)
+      const bool chained = x.bs == 600;
+      const bool banded = !chained && x.bs >= 400;  // (banded stripe kernel: stripes over the padded target, 2 * 128 * nreg rows apart)
+      const int nreg = chained ? 1 : x.bs - (banded ? 400 : 300);
       const size_t first = cursor;
-      const int nslot = banded ? 256 * nreg : 128 * nreg;  // rows between the starts of consecutive stripes
+      const int nslot = chained ? 64 : banded ? 256 * nreg : 128 * nreg;  // rows between the starts of consecutive stripes
       auto stripes_of = [&](int32_t rel) {
+        if (chained) return strip_blocks(std::max(cp[rel].tlen, cp[partner[rel]].tlen));
         return banded ? bstripe_geom(cp[rel].qlen, cp[rel].tlen, cp[rel].w, nreg).nst : (cp[rel].tlen + 128 * nreg - 1) / (128 * nreg);
+      };
+      auto chain_rows = [&](int32_t rel) {
+        if (chained) return std::max(cp[rel].qlen, cp[partner[rel]].qlen) + 64 * stripes_of(rel);
+        return cp[rel].qlen + cp[rel].tlen;
       };
       // (the start keys are taken in units of the rows between two stripes' starts: a counting sort per residue)
       int rq_max = 0, lane_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int32_t rel : x.idx) rq_max = std::max(rq_max, (cp[rel].qlen + cp[rel].tlen) / nslot);
+      for (int32_t rel : x.idx) rq_max = std::max(rq_max, chain_rows(rel) / nslot);
       const int nbucket = rq_max + 258;  // key of (task, s): s - (qlen + tlen) / nslot + rq_max, 0 <= s < 255
       std::vector<int32_t> &lane_of = sx.stripe_lane, &fill = sx.stripe_fill;
       lane_of.resize(x.idx.size());
@@ -864,7 +948,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         int to = 0;
         for (int q = 1; q < 8; ++q)
           if (lane_sum[q] < lane_sum[to]) to = q;
-        const int nst = stripes_of(rel), key0 = rq_max - (cp[rel].qlen + cp[rel].tlen) / nslot;
+        const int nst = stripes_of(rel), key0 = rq_max - chain_rows(rel) / nslot;
         lane_of[j] = to;
         lane_sum[to] += nst;
         for (int sidx = 0; sidx < nst; ++sidx) ++fill[(size_t)to * nbucket + key0 + sidx + 1];
@@ -887,7 +971,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
             if (pos >= lane_sum[q]) order[c.ob + first + (size_t)pos * 8 + q] = idle;
         for (size_t j = 0; j < x.idx.size(); ++j) {
           const int32_t rel = x.idx[j];
-          const int to = lane_of[j], nst = stripes_of(rel), key0 = rq_max - (cp[rel].qlen + cp[rel].tlen) / nslot;
+          const int to = lane_of[j], nst = stripes_of(rel), key0 = rq_max - chain_rows(rel) / nslot;
           for (int sidx = 0; sidx < nst; ++sidx) {
             const int pos = fill[(size_t)to * nbucket + key0 + sidx]++ - base[to];
             order[c.ob + first + (size_t)pos * 8 + to] = (int32_t)(((uint32_t)sidx << 24) | (uint32_t)rel);

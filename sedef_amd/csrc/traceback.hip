@@ -41,6 +41,12 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
   if (LAYOUT == 0) {
     a.idx = (int64_t)r * tk.ncol16 + (i - b.lo);
     a.meta = 0;
+  } else if (LAYOUT == 6) {
+    // strip kernel (extz2_strip.hip): per step and lane one word of this task (the records are 8 bytes: its partner's
+    // word sits beside it), step = the row + the lane, a block of 512 columns after the other
+    const int il = i & 511, ln = il >> 3;
+    a.idx = (((int64_t)(i >> 9) * (tk.ncol16 + 63) + j + ln) * 64 + ln) * 2;  // (ncol16: the rows of the wavefront's larger task)
+    a.meta = (uint32_t)(7 - (il & 7));
   } else if (LAYOUT == 5) {
     // lane kernel (extz2_lane.hip): per tile of 16 target positions two words per query position, a nibble per cell
     a.idx = ((int64_t)(i >> 4) * tk.qlen + j) * 2 + ((i >> 3) & 1);
@@ -87,6 +93,10 @@ __device__ __forceinline__ uint32_t tb_load(const uint8_t *dir, const TbAddr a) 
   if (LAYOUT == 0) {
     const uint32_t d = dir[a.idx];
     return (a.meta & 0x100u) ? a.meta : d;
+  } else if (LAYOUT == 6) {
+    const uint32_t w = reinterpret_cast<const uint32_t *>(dir)[a.idx] >> (a.meta & 7u);
+    const uint32_t fa = w & 1u, fb = (w >> 8) & 1u, fx = (w >> 16) & 1u, fy = (w >> 24) & 1u;
+    return (a.meta & 0x100u) ? a.meta : ((fb ? 2u : fa) | (fx << 3) | (fy << 4));
   } else if (LAYOUT == 5) {
     const uint32_t nib = reinterpret_cast<const uint32_t *>(dir)[a.idx] >> (a.meta & 31u);
     return (a.meta & 0x100u) ? a.meta : ((nib & 3u) | ((nib & 12u) << 1));
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(64) void traceback_kernel(const PlanTask *__restric
   const int k = (int)blockIdx.x * PER + lane / G;
   bool active = k < n;
   PlanTask tk = plan[active ? k : 0];
-  active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : tk.pad_ == 7 ? 4 : tk.pad_ == 8 ? 5 : 1) == LAYOUT &&
+  active = active && (tk.nreg == 0 ? 0 : tk.pad_ == 2 ? 2 : tk.pad_ == 5 ? 3 : tk.pad_ == 7 ? 4 : tk.pad_ == 8 ? 5 : (tk.pad_ == 9 || tk.pad_ == 10) ? 6 : 1) == LAYOUT &&
            !(tk.flag & SDF_FLAG_SCORE_ONLY);
   sdf_result rr = res[tk.out_idx];
   active = active && rr.n_cigar != -1;  // (-1: a stripe kernel gave the task up -- nothing to walk; it is run again)
@@ -256,6 +266,7 @@ SDF_TB_INST(2)
 SDF_TB_INST(3)
 SDF_TB_INST(4)
 SDF_TB_INST(5)
+SDF_TB_INST(6)
 #undef SDF_TB_INST
 
 // Exclusive scan of n_cigar over the result records in record order -> cigar_off, in three small launches:

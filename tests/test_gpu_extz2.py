@@ -458,6 +458,89 @@ def test_lane_kernel_next_to_the_other_kernels(oracle):
     assert eng.last_lane_tasks() == n_lane > 4000
 
 
+# ---- strip kernel: full-band tasks of 257..1024 target bases, row-major strips, two tasks per wavefront (extz2_strip.hip) ----
+def _strip_pairs(rng, n):
+    """Tasks the strip kernel takes -- every block count and ragged last strips, queries from 64 bases to several
+    thousand, partners of equal geometry and tasks without one, N runs, unrelated sequences, big indels."""
+    pairs = []
+    geos = [(500, 500), (500, 431), (500, 377), (64, 257), (1000, 1000), (1000, 1024), (777, 512), (300, 513), (2500, 600),
+            (128, 1023), (999, 264), (65, 300)]
+    for k in range(n):
+        ql, tl = geos[k % len(geos)] if k % 3 else (int(rng.integers(64, 1500)), int(rng.integers(257, 1025)))
+        kind = rng.random()
+        q = random_codes(rng, ql, 0.01 if kind < 0.25 else 0.0)
+        if kind < 0.7:
+            t = mutate(rng, q, 0.06, 0.02, 0.02)
+            if kind < 0.3 and len(t) > 300:
+                at, ln = int(rng.integers(0, len(t) - 100)), int(rng.integers(1, 300))
+                t = np.concatenate([t[:at], random_codes(rng, ln), t[at:]]) if rng.random() < 0.5 else np.concatenate([t[:at], t[at + ln:]])
+            t = _fit(rng, t, tl)
+        elif kind < 0.9:
+            t = random_codes(rng, tl, 0.02)
+        else:
+            t = np.full(tl, 4, np.uint8) if rng.random() < 0.3 else np.full(tl, int(q[0]) & 3, np.uint8)
+        pairs.append((q, t))
+    return pairs
+
+
+def test_strip_kernel_full_band_mid_size_tasks(engine, oracle):
+    rng = np.random.default_rng(8001)
+    pairs = _strip_pairs(rng, 400)
+    ws = [-1 if k % 4 else max(len(q), len(t)) for k, (q, t) in enumerate(pairs)]
+    flags = [0x80 if k % 9 == 4 else 0x01 if k % 11 == 6 else 0 for k in range(len(pairs))]
+    _check_fast(engine, oracle, pairs, ws, flags)
+    assert engine.last_paired() >= 100  # partners of equal geometry share a wavefront
+    # the same tasks on the window / stripe kernels
+    old = _engine_with_env(SDF_NO_STRIP=1)
+    _check_fast(old, oracle, pairs[:60], ws[:60], flags[:60])
+
+
+def _wide_strip_pairs(rng):
+    """Full-band tasks whose targets take 3 .. 16 blocks of 512 columns: a chain of wavefronts (extz2_strip.hip)."""
+    pairs = []
+    for ql, tl in [(1500, 1025), (1500, 1030), (3000, 3000), (2900, 3050), (6000, 6000), (700, 8192), (5000, 2049),
+                   (2000, 1537), (2000, 1537), (2100, 1600), (64, 4000), (1200, 1200), (1201, 1234), (4097, 4100)]:
+        kind = rng.random()
+        q = random_codes(rng, ql, 0.004 if kind < 0.3 else 0.0)
+        if kind < 0.8:
+            t = mutate(rng, q, 0.06, 0.02, 0.02)
+            at = int(rng.integers(0, max(1, len(t) - 1)))
+            t = np.concatenate([t[:at], random_codes(rng, int(rng.integers(1, 400))), t[at:]])
+            t = _fit(rng, t, tl)
+        else:
+            t = random_codes(rng, tl)
+        pairs.append((q, t))
+    return pairs
+
+
+def test_strip_chain_wide_full_band_tasks(engine, oracle):
+    rng = np.random.default_rng(8003)
+    pairs = _wide_strip_pairs(rng)
+    flags = [0x80 if k % 5 == 2 else 0x01 if k == 7 else 0 for k in range(len(pairs))]
+    _check_fast(engine, oracle, pairs, [-1] * len(pairs), flags)
+    assert engine.last_paired() >= 8 and engine.last_reran() == 0
+    # between tasks of the other kernels, several chains side by side
+    more = _strip_pairs(rng, 30) + pairs + _wide_strip_pairs(rng)
+    _check_fast(engine, oracle, more, [-1] * len(more))
+    # a wait that gives up: both tasks of the pair run again on another kernel
+    eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1)
+    _check_fast(eng, oracle, pairs, [-1] * len(pairs), flags)
+    assert eng.last_reran() >= 6
+
+
+def test_strip_kernel_other_scorings(engine, oracle):
+    rng = np.random.default_rng(8002)
+    for it in range(10):
+        ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
+        go, ge = int(rng.integers(0, 60)), int(rng.integers(0, 5))
+        if it == 0:
+            ma, mi, go, ge = 5, -4, 60, 1  # cap = 127
+        if it == 1:
+            ma, mi, go, ge = 5, -4, 61, 1  # not tame: the stripe kernels
+        pairs = _strip_pairs(rng, 36)
+        _check_fast(engine, oracle, pairs, [-1] * len(pairs), mat=sedef_mat(ma, mi), gapo=go, gape=ge)
+
+
 def _same_geometry_tasks(rng, ql, tl, copies, n_frac=0.0):
     """`copies` tasks with the same lengths and unrelated contents (related, diverged, random, N runs)."""
     out = []
@@ -613,6 +696,10 @@ def test_config4_hg19_task_mixture(engine, oracle):
     solo = _engine_with_env(SDF_NO_LANE=1)
     _batch_vs_cpu(solo, oracle, batch, w)
     assert solo.last_lane_tasks() == 0 and solo.last_paired() > 20000
+    # the batch in two parts (SDF_SPLIT_MIN: the first eighth on a second context while the rest is still being read)
+    split = _engine_with_env(SDF_SPLIT_MIN=20000)
+    _batch_vs_cpu(split, oracle, batch, w)
+    assert split.last_lane_tasks() > 29000
 
 
 def test_config5_mm8_mixed_bands(engine, oracle):
