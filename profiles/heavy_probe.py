@@ -13,7 +13,7 @@ from shapes_bench import bench, sedef_amd  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 dev = torch.device("cuda", 0)
-(pool, q_off, qlen, t_off, tlen), w = bench.synth_hg19_mixture(n, seed=404, big=6000)
+(pool, q_off, qlen, t_off, tlen), w = bench.synth_hg19_mixture_fast(n, seed=404, big=6000)
 eng = sedef_amd.Extz2Engine(0, 64 << 30)
 for name, sel in (("stripe tasks (>= 1200)", qlen >= 1200), ("600..1000", (qlen >= 600) & (qlen < 1200)),
                   ("500 x ~500", qlen == 500), ("ordinary (< 500)", qlen < 500), ("all", qlen > 0)):

@@ -29,13 +29,14 @@
 
 namespace sdf {
 
-constexpr int kStripBlock = 512;  // columns per block: 64 lanes x 8
-constexpr int kStripMaxT = 1024;       // widest target of one wavefront: two blocks, one after the other
+// columns per lane: 8 (a block of 512 columns per wavefront), or 4 for chains of few wavefronts -- a step of four cells
+// is half as long, and a chain of blocks runs at the pace of its steps
+constexpr int kStripMaxT = 512;        // widest target of the one-wavefront kernel: one block of 8 columns per lane
 constexpr int kStripChainMaxT = 8192;  // ... of a chain of wavefronts, one per block (extz2_strip_chain_kernel)
 
-__host__ __device__ inline int strip_blocks(int tlen) { return (tlen + kStripBlock - 1) / kStripBlock; }
-__host__ __device__ inline size_t strip_dir_bytes(int qlen, int tlen) {
-  return (size_t)strip_blocks(tlen) * (size_t)(qlen + 63) * 512;
+__host__ __device__ inline int strip_blocks(int tlen, int cols = 8) { return (tlen + 64 * cols - 1) / (64 * cols); }
+__host__ __device__ inline size_t strip_dir_bytes(int qlen, int tlen, int cols = 8, bool solo = false) {
+  return (size_t)strip_blocks(tlen, cols) * (size_t)(qlen + 63) * (solo ? 256 : 512);
 }
 __host__ __device__ inline size_t strip_lds_bytes(int qlen, int tlen) {
   return strip_blocks(tlen) > 1 ? ((size_t)(qlen + 66) * 4 + 15) & ~(size_t)15 : 16;
@@ -50,9 +51,13 @@ __device__ __forceinline__ unsigned strip_code2(const uint32_t *wa, const uint32
   return ca | (cb << 16);
 }
 
-__device__ __forceinline__ unsigned strip_pick(const unsigned (&v)[8], const int k) {  // k: wave-uniform, 0..7
-  const unsigned a = (k & 1) ? v[1] : v[0], b = (k & 1) ? v[3] : v[2], c = (k & 1) ? v[5] : v[4], d = (k & 1) ? v[7] : v[6];
-  const unsigned e = (k & 2) ? b : a, f = (k & 2) ? d : c;
+template <int C>
+__device__ __forceinline__ unsigned strip_pick(const unsigned (&v)[C], const int k) {  // k: wave-uniform, 0 .. C - 1
+  const unsigned a = (k & 1) ? v[1] : v[0], b = (k & 1) ? v[3] : v[2];
+  const unsigned e = (k & 2) ? b : a;
+  if (C == 4) return e;
+  const unsigned c = (k & 1) ? v[C - 3] : v[C - 4], d = (k & 1) ? v[C - 1] : v[C - 2];
+  const unsigned f = (k & 2) ? d : c;
   return (k & 4) ? f : e;
 }
 
@@ -71,7 +76,7 @@ struct StripH {
 // One block of 512 columns, all rows.  Tasks A and B need not be equal: the wavefront steps through max(qlen) rows of
 // max(tlen) columns, and what a task's half computes beyond its own matrix feeds nothing inside it (cells depend on
 // cells above and to the left only); each half follows its own last column and its own last row.
-template <bool HASN, bool CHAIN>
+template <bool HASN, bool CHAIN, int C>
 __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const int qa, const int ta, const int qb, const int tb,
                                             const int lane, const uint32_t *twa, const uint32_t *tna, const uint32_t *twb,
                                             const uint32_t *tnb, const uint32_t *qwa, const uint32_t *qna, const uint32_t *qwb,
@@ -79,25 +84,27 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
                                             const unsigned ZW2, const unsigned CAP2, uint32_t *edge, uint2 *dir,
                                             const bool with_dir_a, const bool with_dir_b, StripH &ha, StripH &hb,
                                             const uint32_t *edge_in = nullptr, uint32_t *edge_out = nullptr,
-                                            const sdf_result *mark = nullptr, const int spin_cap = 0, int *sums = nullptr) {
+                                            const sdf_result *mark = nullptr, const int spin_cap = 0, int *sums = nullptr,
+                                            const bool solo = false) {
   const unsigned Q2 = (unsigned)gq * 0x00010001u;
   unsigned one2 = 0x00010001u, two2 = 0x00020002u;
   SDF_OPQ(one2);
   SDF_OPQ(two2);
   const int qmax = qa > qb ? qa : qb;
-  const int c0 = blk * kStripBlock + lane * 8;
-  unsigned U[8], Y[8], TC[8];
+  constexpr int BW = 64 * C;  // columns of a block
+  const int c0 = blk * BW + lane * C;
+  unsigned U[C], Y[C], TC[C];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < C; ++k) {
     TC[k] = strip_code2(twa, tna, ta, twb, tnb, tb, c0 + k);
     U[k] = (c0 + k) ? Q2 : 0u;  // (:121: u = q beyond the first column, y = 0 above the first row)
     Y[k] = 0u;
   }
   // the lane's columns inside each target; each target's last column, if it lies in this block (wave-uniform)
-  const int nva = ta - c0 < 0 ? 0 : ta - c0 > 8 ? 8 : ta - c0, nvb = tb - c0 < 0 ? 0 : tb - c0 > 8 ? 8 : tb - c0;
-  const int cla = ta - 1 - blk * kStripBlock, clb = tb - 1 - blk * kStripBlock;
-  const bool last_a = cla >= 0 && cla < kStripBlock, last_b = clb >= 0 && clb < kStripBlock;
-  const int kca = last_a ? (cla & 7) : -1, kcb = last_b ? (clb & 7) : -1, lla = cla >> 3, llb = clb >> 3;
+  const int nva = ta - c0 < 0 ? 0 : ta - c0 > C ? C : ta - c0, nvb = tb - c0 < 0 ? 0 : tb - c0 > C ? C : tb - c0;
+  const int cla = ta - 1 - blk * BW, clb = tb - 1 - blk * BW;
+  const bool last_a = cla >= 0 && cla < BW, last_b = clb >= 0 && clb < BW;
+  const int kca = last_a ? (cla % C) : 0, kcb = last_b ? (clb % C) : 0, lla = cla / C, llb = clb / C;
   const bool more = blk + 1 < nblk;
   const int nstep = qmax + 63;
   unsigned xo = 0u, vo = 0u, qc = 0u, vcap = 0u;
@@ -154,9 +161,9 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
     const int j = s - lane;  // this lane's row
     if (j >= 0 && j < qmax) {
       unsigned Fa = 0u, Fb = 0u, Fx = 0u, Fy = 0u;
-      unsigned VN[8];
+      unsigned VN[C];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < C; ++k) {
         // score + 2 (q + e): match / mismatch by the bases, 2 (q + e) with an N on either side (:124-138)
         const unsigned dd = TC[k] ^ qc;
         unsigned z = pk_mad(pk_minu(dd, one2), ZD2, ZM2);
@@ -198,13 +205,19 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
       {
         const unsigned wa = (Fa & 0xffu) | ((Fb & 0xffu) << 8) | ((Fx & 0xffu) << 16) | ((Fy & 0xffu) << 24);
         const unsigned wb = ((Fa >> 16) & 0xffu) | (((Fb >> 16) & 0xffu) << 8) | (((Fx >> 16) & 0xffu) << 16) | ((Fy >> 16) << 24);
-        if (with_dir_a && with_dir_b) drow[(size_t)s * 64] = make_uint2(wa, wb);
-        else if (with_dir_a) drow[(size_t)s * 64].x = wa;
-        else if (with_dir_b) drow[(size_t)s * 64].y = wb;
+        if (solo) {  // (a task without a partner: records of one word)
+          if (with_dir_a) reinterpret_cast<uint32_t *>(dir)[((size_t)blk * nstep + s) * 64 + lane] = wa;
+        } else if (with_dir_a && with_dir_b) {
+          drow[(size_t)s * 64] = make_uint2(wa, wb);
+        } else if (with_dir_a) {
+          drow[(size_t)s * 64].x = wa;
+        } else if (with_dir_b) {
+          drow[(size_t)s * 64].y = wb;
+        }
       }
       if (j == 0) {  // exact H along the first row: the sum of u (:231, read as bytes) over the lane's columns
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < C; ++k) {
           if (k < nva) ha.sum0 += (int)(U[k] & 0xffffu);
           if (k < nvb) hb.sum0 += (int)(U[k] >> 16);
         }
@@ -260,15 +273,15 @@ __global__ __launch_bounds__(64) void extz2_strip_kernel(const PlanTask *__restr
   StripH ha, hb;
   for (int blk = 0; blk < nblk; ++blk) {
     if (has_n)
-      strip_steps<true, false>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2, ZD2, ZW2, CAP2,
-                               strip_edge, dir, with_dir_a, with_dir_b, ha, hb);
+      strip_steps<true, false, 8>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2, ZD2, ZW2, CAP2,
+                               strip_edge, dir, with_dir_a, with_dir_b, ha, hb, nullptr, nullptr, nullptr, 0, nullptr, ib == ia);
     else
-      strip_steps<false, false>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2, ZD2, ZW2, CAP2,
-                                strip_edge, dir, with_dir_a, with_dir_b, ha, hb);
+      strip_steps<false, false, 8>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2, ZD2, ZW2, CAP2,
+                                strip_edge, dir, with_dir_a, with_dir_b, ha, hb, nullptr, nullptr, nullptr, 0, nullptr, ib == ia);
   }
   // H of the last cell of row 0: u(0,0) - 2 (q + e) (:249), every further cell of the row + its u - (q + e) (:231)
   const int row0a = strip_wave_sum(ha.sum0) - (ta - 1) * qe - 2 * qe, row0b = strip_wave_sum(hb.sum0) - (tb - 1) * qe - 2 * qe;
-  const int lla = ((ta - 1) & (kStripBlock - 1)) >> 3, llb = ((tb - 1) & (kStripBlock - 1)) >> 3;
+  const int lla = ((ta - 1) & 511) >> 3, llb = ((tb - 1) & 511) >> 3;
   const int fa = __builtin_amdgcn_readlane(ha.hrel, lla), fb = __builtin_amdgcn_readlane(hb.hrel, llb);
   const int ba = __builtin_amdgcn_readlane(ha.best, lla), bb = __builtin_amdgcn_readlane(hb.best, llb);
   const int ja = __builtin_amdgcn_readlane(ha.bestj, lla), jb = __builtin_amdgcn_readlane(hb.bestj, llb);
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(64) void extz2_strip_kernel(const PlanTask *__restr
 // finished; a wait that runs out of polls abandons both tasks (stripe_abandon) and the batch call runs them again.
 // A block's partial exact-H values (the first row's sum of u; the last column's running H) are added up through three
 // words per task behind the edge columns.
-__host__ __device__ inline size_t strip_chain_sync_bytes(int qmax, int tmax) {
-  return ((size_t)(strip_blocks(tmax) - 1) * (size_t)(qmax + 64) * 4 + 64 + 255) & ~(size_t)255;
+__host__ __device__ inline size_t strip_chain_sync_bytes(int qmax, int tmax, int cols) {
+  return ((size_t)(strip_blocks(tmax, cols) - 1) * (size_t)(qmax + 64) * 4 + 64 + 255) & ~(size_t)255;
 }
 
 __global__ __launch_bounds__(64) void strip_chain_init_kernel(const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
@@ -309,9 +322,10 @@ __global__ __launch_bounds__(64) void strip_chain_init_kernel(const PlanTask *__
   const int blk = (int)((uint32_t)entry >> 24);
   const PlanTask tka = plan[entry & 0xffffff], tkb = plan[tka.zdrop];
   const int qmax = tka.qlen > tkb.qlen ? tka.qlen : tkb.qlen, tmax = tka.tlen > tkb.tlen ? tka.tlen : tkb.tlen;
-  const int nblk = strip_blocks(tmax);
+  const int nblk = strip_blocks(tmax, tka.nreg);  // (nreg: columns per lane)
   if (blk >= nblk) return;
-  uint32_t *sync = reinterpret_cast<uint32_t *>(dirbase + tka.dir_off + (int64_t)strip_dir_bytes(qmax, tmax));
+  uint32_t *sync = reinterpret_cast<uint32_t *>(dirbase + tka.dir_off +
+                                                (int64_t)strip_dir_bytes(qmax, tmax, tka.nreg, tka.zdrop == (entry & 0xffffff)));
   if (blk == 0)
     for (int k = threadIdx.x; k < 16; k += 64) sync[k] = 0u;  // the row-0 sums of both tasks
   if (blk + 1 < nblk) {
@@ -320,6 +334,7 @@ __global__ __launch_bounds__(64) void strip_chain_init_kernel(const PlanTask *__
   }
 }
 
+template <int C>
 __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
                                                                const uint32_t *__restrict__ pool, ScoreK sc,
                                                                uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res,
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
   const int lane = threadIdx.x;
   const int qa = tka.qlen, ta = tka.tlen, qb = tkb.qlen, tb = tkb.tlen;
   const int qmax = qa > qb ? qa : qb, tmax = ta > tb ? ta : tb;
-  const int nblk = strip_blocks(tmax);
+  const int nblk = strip_blocks(tmax, C);
   if (blk >= nblk) return;  // (a padding entry of the launch order)
   if (qmax + tmax >= 8192) __builtin_amdgcn_s_setprio(2);  // (long chains first, as in the stripe kernels)
   const uint32_t *twa = pool + tka.t_word, *tna = twa + (ta + 15) / 16;
@@ -355,19 +370,19 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
   const unsigned ZW2 = (unsigned)(2 * qe) * 0x00010001u, CAP2 = ZM2;
   const bool with_dir_a = !(tka.flag & SDF_FLAG_SCORE_ONLY), with_dir_b = ib != ia && !(tkb.flag & SDF_FLAG_SCORE_ONLY);
   uint2 *dir = reinterpret_cast<uint2 *>(dirbase + tka.dir_off);
-  uint32_t *sync = reinterpret_cast<uint32_t *>(dirbase + tka.dir_off + (int64_t)strip_dir_bytes(qmax, tmax));
+  uint32_t *sync = reinterpret_cast<uint32_t *>(dirbase + tka.dir_off + (int64_t)strip_dir_bytes(qmax, tmax, C, ib == ia));
   int *sums = reinterpret_cast<int *>(sync);  // [0] row-0 sum of u of task A, [1] of task B (all blocks add theirs)
   uint32_t *cols = sync + 16;
   const uint32_t *edge_in = cols + (size_t)(blk ? blk - 1 : 0) * (qmax + 64);
   uint32_t *edge_out = cols + (size_t)blk * (qmax + 64);
   StripH ha, hb;
   const sdf_result *mark = res + tka.out_idx;
-  const bool ok = has_n ? strip_steps<true, true>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2,
+  const bool ok = has_n ? strip_steps<true, true, C>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2,
                                                   ZD2, ZW2, CAP2, nullptr, dir, with_dir_a, with_dir_b, ha, hb, edge_in, edge_out,
-                                                  mark, spin_cap, sums)
-                        : strip_steps<false, true>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2,
+                                                  mark, spin_cap, sums, ib == ia)
+                        : strip_steps<false, true, C>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2,
                                                    ZD2, ZW2, CAP2, nullptr, dir, with_dir_a, with_dir_b, ha, hb, edge_in, edge_out,
-                                                   mark, spin_cap, sums);
+                                                   mark, spin_cap, sums, ib == ia);
   if (!ok) {  // (the batch call runs both tasks again on another kernel)
     stripe_abandon(gave_up, res + tka.out_idx, tka.out_idx, lane);
     if (ib != ia) stripe_abandon(gave_up, res + tkb.out_idx, tkb.out_idx, lane);
@@ -376,10 +391,10 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
   // (every block has added its share of the first row's sums of u at its step 64; the blocks holding a task's last
   // column read the totals now, after all their rows -- rows whose edge words left the blocks to their left behind
   // those blocks' own additions)
-  const int bla = (ta - 1) >> 9, blb = (tb - 1) >> 9;  // the blocks with the tasks' last columns
+  const int bla = (ta - 1) / (64 * C), blb = (tb - 1) / (64 * C);  // the blocks with the tasks' last columns
   if (blk != bla && blk != blb) return;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-  const int lla = ((ta - 1) & (kStripBlock - 1)) >> 3, llb = ((tb - 1) & (kStripBlock - 1)) >> 3;
+  const int lla = ((ta - 1) % (64 * C)) / C, llb = ((tb - 1) % (64 * C)) / C;
   const int fa = __builtin_amdgcn_readlane(ha.hrel, lla), fb = __builtin_amdgcn_readlane(hb.hrel, llb);
   const int ba = __builtin_amdgcn_readlane(ha.best, lla), bb = __builtin_amdgcn_readlane(hb.best, llb);
   const int ja = __builtin_amdgcn_readlane(ha.bestj, lla), jb = __builtin_amdgcn_readlane(hb.bestj, llb);
@@ -401,5 +416,10 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
     res[lane ? tkb.out_idx : tka.out_idx] = o;
   }
 }
+
+template __global__ void extz2_strip_chain_kernel<8>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                                     sdf_result *, unsigned long long *, int);
+template __global__ void extz2_strip_chain_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
+                                                     sdf_result *, unsigned long long *, int);
 
 }  // namespace sdf

@@ -114,6 +114,9 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   if (const char *cp = getenv("SDF_STRIPE_SPIN_CAP")) ctx->stripe_spin_cap = std::max(1, atoi(cp));
   const char *nsp = getenv("SDF_NO_STRIP");
   ctx->strip_enabled = !(nsp && nsp[0] == '1');
+  const char *sa = getenv("SDF_STRIP_ALWAYS");
+  ctx->strip_always = sa && sa[0] == '1';
+  if (const char *scl = getenv("SDF_STRIP_COLS")) ctx->strip_cols = atoi(scl);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             want_lds);
   const char *nl = getenv("SDF_NO_LANE");
@@ -360,6 +363,8 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     env.lane_ok = ctx->lane_enabled && ctx->pipeline && !ctx->force_general && !env.degenerate && !(want & SDF_WANT_EXT) &&
                   sc->gapo >= 0 && sc->gape >= 0 && zm >= 0 && zm <= 127 && zx >= 0 && zx <= 127 && n >= ctx->lane_min;
     env.lane_min = ctx->lane_min;
+    env.strip_always = ctx->strip_always;
+    env.strip_cols = ctx->strip_cols;
     env.strip_ok = ctx->strip_enabled && !ctx->force_general && !env.degenerate && sc->gapo >= 0 && sc->gape >= 0 && zm >= 0 &&
                    zm <= 127 && zx >= 0 && zx <= 127;
     if (env.lane_ok) {
@@ -518,6 +523,9 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         ctx->part_ctx->no_stripe = ctx->no_stripe;
         ctx->part_ctx->lane_enabled = ctx->lane_enabled;
         ctx->part_ctx->lane_min = ctx->lane_min;
+        ctx->part_ctx->strip_enabled = ctx->strip_enabled;
+        ctx->part_ctx->strip_always = ctx->strip_always;
+        ctx->part_ctx->strip_cols = ctx->strip_cols;
       }
     }
     if (sdf_ctx *pc = ctx->part_ctx) {

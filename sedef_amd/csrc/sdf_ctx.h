@@ -50,6 +50,7 @@ __global__ void lane_plan_kernel(const LaneRec *, const uint32_t *, int, const u
                                  int64_t, int64_t, PlanTask *);
 __global__ void extz2_lane_kernel(const PlanTask *, int, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
 __global__ void extz2_strip_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
+template <int C>
 __global__ void extz2_strip_chain_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *,
                                          unsigned long long *, int);
 __global__ void strip_chain_init_kernel(const PlanTask *, const int32_t *, uint8_t *);
@@ -239,7 +240,9 @@ struct sdf_ctx {
   HostBuf host_lane;
   DevBuf ln_recs, ln_keys, ln_vals, ln_sizes, ln_tmp;
   hipStream_t lane_stream = nullptr;
-  bool strip_enabled = true;  // SDF_NO_STRIP=1: full-band tasks of 257..1024 target bases stay on the window / stripe kernels
+  bool strip_enabled = true;  // SDF_NO_STRIP=1: full-band tasks of 257..8192 target bases stay on the window / stripe kernels
+  bool strip_always = false;  // SDF_STRIP_ALWAYS=1 (tests): the strip kernels whatever the number of tasks
+  int strip_cols = 0;         // SDF_STRIP_COLS=4|8 (tests)
   bool lane_enabled = true;   // SDF_NO_LANE=1: small full-band tasks stay on the window kernels
   size_t lane_min = 8192;     // SDF_LANE_MIN: eligible tasks a batch must hold for the lane kernel to take them
   long long lane_tasks = 0;   // tasks of the last batch call the lane kernel took

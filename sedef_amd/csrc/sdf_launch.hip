@@ -119,9 +119,13 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 118: SDF_PAIR(8, true); break;
     case 123: SDF_PAIR_TRACK(3); break;
     case 126: SDF_PAIR_TRACK(6); break;
-    case 600: /* chained strips: edge columns and row-0 sums reset first */
+    case 608: /* chained strips: edge columns and row-0 sums reset first */
       hipLaunchKernelGGL(strip_chain_init_kernel, one, dim3(64), 0, sdp, lp, lo, dir_reg);
-      hipLaunchKernelGGL(extz2_strip_chain_kernel, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap);
+      hipLaunchKernelGGL(extz2_strip_chain_kernel<8>, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap);
+      break;
+    case 604:
+      hipLaunchKernelGGL(strip_chain_init_kernel, one, dim3(64), 0, sdp, lp, lo, dir_reg);
+      hipLaunchKernelGGL(extz2_strip_chain_kernel<4>, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap);
       break;
     case 500:
       hipLaunchKernelGGL(extz2_strip_kernel, half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);
@@ -273,7 +277,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
     }
     launch_dp(L, sdp, run.d_plan + pb, run.d_order + ob + L.off, run.d_pool, run.sk, dir_reg, run.d_out, slabs,
               (unsigned long long *)ctx->misc_buf.p + 1, ctx->stripe_spin_cap);
-    if ((L.bs >= 300 && L.bs < 500) || L.bs == 600) run.any_stripe = true;
+    if ((L.bs >= 300 && L.bs < 500) || L.bs == 604 || L.bs == 608) run.any_stripe = true;
     ++ctx->launches;
   }
   for (int q = 0; q < 8; ++q) {  // the traceback stream collects every stream the chunk's DP ran on

@@ -32,6 +32,8 @@ struct PlanEnv {
   // lane kernel (extz2_lane.hip): small full-band tasks leave the host's planning altogether when the batch holds at least
   // `lane_min` of them (fewer do not fill the device: a lane walks its matrix alone, ~100 cycles per cell)
   bool strip_ok = false;    // strip kernel (extz2_strip.hip): the scoring is tame
+  bool strip_always = false;  // SDF_STRIP_ALWAYS=1 (tests): ... whatever the number of tasks
+  int strip_cols = 0;         // SDF_STRIP_COLS (tests): columns per lane of the chained strips
   bool lane_ok = false;     // the scoring is tame and only CIGAR / score / mte are wanted
   size_t lane_min = 8192;
   LaneRec *lane_recs = nullptr;  // pinned, one per task of the batch: filled by the scan
@@ -250,13 +252,15 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         bd = std::max(bd, (bstripe_dir_bytes(t.qlen, t.tlen, w, nr) + bstripe_sync_bytes(t.qlen, t.tlen, w, nr) + 255) & ~(size_t)255);
       }
       // (strip kernel: a region per PAIR of tasks with as many column blocks, sized by the one with more rows -- which
-      // this pass does not know.  Every member reserves blocks x (1.5 rows + 127) records: a pair of m and M rows needs
-      // blocks x (M + 63), never more than the two reservations together)
+      // this pass does not know.  A pair of m and M <= 1.5 m + 64 rows needs blocks x (M + 63) records of 8 bytes, a task
+      // without a partner blocks x (rows + 63) records of 4; every task reserves blocks x (0.8 rows + 100) x 520 bytes:
+      // enough for either, the chains' edge columns included)
       // (wider targets: a chain of wavefronts, the edge columns between the blocks behind the records -- reserved, like
       // the other stripe kernels' inter-stripe words, whatever the task wants)
       if (env.strip_ok && t.tlen > 256 && t.tlen <= kStripChainMaxT && w >= std::max(t.qlen, t.tlen) &&
           (with_dir || t.tlen > kStripMaxT))
-        bd = std::max(bd, ((size_t)strip_blocks(t.tlen) * (size_t)(t.qlen + t.qlen / 2 + 127) * 520 + 512 + 255) & ~(size_t)255);
+        bd = std::max(bd, ((size_t)strip_blocks(t.tlen, t.tlen > kStripMaxT && env.strip_cols == 4 ? 4 : 8) *
+                               (size_t)(t.qlen - t.qlen / 5 + 100) * 520 + 512 + 255) & ~(size_t)255);
       bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
       blk.bd += (uint64_t)bound[k] << 8;
       if (bd >= heavy_min) {
@@ -493,6 +497,26 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   size_t n_stripe_tasks = 0;   // stripe tasks of the chunk,
   double stripe_cells = 0;     // their cells,
   int stripe_rows = 0;         // the anti-diagonals of the longest of them
+  // Strip kernels (extz2_strip.hip) are throughput kernels: a step of eight cells per lane is a microsecond on a wavefront
+  // alone, a 500 x 500 task 0.55 ms where the window kernels take 0.3, a chain of twelve blocks 6.5 ms against the
+  // stripe kernel's 3.0 (profiles/r03_strip.txt).  They take a chunk's tasks only when there are enough of them to fill
+  // the device: 1,024 one-wavefront tasks, 3,072 chain wavefronts.
+  bool use_strip = false, use_chain = false;
+  if (env.strip_ok) {
+    const bool force = env.strip_always;  // (tests: whatever the count)
+    size_t n9 = 0, w10 = 0;
+    for (size_t pos = c.s; pos < c.e; ++pos) {
+      const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
+      const sdf_task &t = tasks[k];
+      if (t.tlen <= 256 || t.tlen > kStripChainMaxT || t.qlen < 64) continue;
+      if (!c.heavy && cut.split_heavy && cut.heavy[k]) continue;
+      if (t.w >= 0 && t.w < std::max(t.qlen, t.tlen)) continue;
+      if (t.tlen <= kStripMaxT) ++n9;
+      else w10 += (size_t)strip_blocks(t.tlen, 8);
+    }
+    use_strip = force || n9 >= 1024;
+    use_chain = force || w10 / 2 >= 3072;
+  }
   for (size_t pos = c.s; pos < c.e; ++pos) {
     if (c.heavy && pos + 16 < c.e) __builtin_prefetch(&tasks[cut.heavy_idx[pos + 16]]);
     const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
@@ -576,16 +600,16 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     p.cig_cap = (p.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
     p.cig_slot = stage_words;
     stage_words += p.cig_cap;
-    if (env.strip_ok && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) && t.tlen > 256 && t.tlen <= kStripMaxT &&
-        t.qlen >= 64 && t.qlen < (1 << 20) && strip_lds_bytes(t.qlen + t.qlen / 2 + 64, t.tlen) <= (size_t)env.max_dyn_lds) {
-      // full band, a few hundred to a thousand target bases: row-major strips, two tasks per wavefront
-      p.nreg = 1;
+    if (use_strip && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) && t.tlen > 256 && t.tlen <= kStripMaxT &&
+        t.qlen >= 64 && t.qlen < (1 << 20)) {
+      // full band, a few hundred target bases: row-major strips, two tasks per wavefront
+      p.nreg = 8;  // (columns per lane)
       p.pad_ = 9;
       win_need.back() = 0;
-    } else if (env.strip_ok && !env.no_stripe && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) &&
+    } else if (use_chain && !env.no_stripe && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) &&
                t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT && t.qlen >= 64 && t.qlen < (1 << 20)) {
-      // ... wider: the same strips, a wavefront per block of 512 columns, chained through HBM
-      p.nreg = 1;
+      // ... wider: the same strips, a wavefront per block of columns, chained through HBM
+      p.nreg = 8;  // (columns per lane: 8, or 4 when the chunk has few chains -- decided below)
       p.pad_ = 10;
       win_need.back() = 0;
     } else if (p.pad_ != 7 && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
@@ -727,17 +751,35 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     std::vector<int32_t> &sl = sx.stripe_lane;  // (scratch)
     std::vector<uint64_t> &keys = sx.strip_keys;
     keys.clear();
+    // Chains: a wavefront alone on its SIMD issues an instruction every ~7 cycles whatever it does, a chain of blocks runs
+    // at the pace of its steps, and a step of four columns is half as long as one of eight: few chains (the few long
+    // tasks of a batch: fewer wavefronts than the device has slots for) take four columns per lane, many take eight
+    // (less per-step overhead per cell).  One width per chunk: one launch.
+    {
+      const int force_cols = env.strip_cols;
+      size_t chain_waves = 0;
+      for (size_t k = 0; k < cnt; ++k)
+        if (cp[k].pad_ == 10) chain_waves += (size_t)strip_blocks(cp[k].tlen, 8);
+      // (measured, profiles/r03_strip.txt: four columns shorten a lone chain -- 5.3 against 6.5 ms for 6000 x 6000 -- but
+      // cost throughput -- 1,364 against 1,612 Gcell/s on 20,000 x 1000 x 1000 --, and lone chains are the stripe
+      // kernel's anyway: eight unless SDF_STRIP_COLS says otherwise)
+      const int cols = force_cols == 4 || force_cols == 8 ? force_cols : 8;
+      (void)chain_waves;
+      for (size_t k = 0; k < cnt; ++k)
+        if (cp[k].pad_ == 10) cp[k].nreg = cols;
+    }
     for (size_t k = 0; k < cnt; ++k)
-      if (cp[k].pad_ == 9 || cp[k].pad_ == 10)  // (blocks, rows, columns, index): 5 + 20 + 14 + 24 bits
-        keys.push_back(((uint64_t)(strip_blocks(cp[k].tlen) - 1) << 58) | ((uint64_t)(uint32_t)cp[k].qlen << 38) |
-                       ((uint64_t)(uint32_t)cp[k].tlen << 24) | (uint64_t)k);
+      if (cp[k].pad_ == 9 || cp[k].pad_ == 10)  // (blocks, rows, columns, index): 6 + 20 + 14 + 24 bits
+        keys.push_back(((uint64_t)(strip_blocks(cp[k].tlen, cp[k].nreg) - 1 + (cp[k].pad_ == 10 ? 32 : 0)) << 58) |
+                       ((uint64_t)(uint32_t)cp[k].qlen << 38) | ((uint64_t)(uint32_t)cp[k].tlen << 24) | (uint64_t)k);
     std::sort(keys.begin(), keys.end());
     sl.resize(keys.size());
     for (size_t q = 0; q < keys.size(); ++q) sl[q] = (int32_t)(keys[q] & 0xffffffu);
     for (size_t q = 0; q < sl.size();) {
       const int32_t x = sl[q];
       int32_t y = x;  // the next one, if it has as many column blocks and at most half as many rows again
-      if (q + 1 < sl.size() && strip_blocks(cp[sl[q + 1]].tlen) == strip_blocks(cp[x].tlen) &&
+      if (q + 1 < sl.size() && cp[sl[q + 1]].pad_ == cp[x].pad_ &&
+          strip_blocks(cp[sl[q + 1]].tlen, cp[x].nreg) == strip_blocks(cp[x].tlen, cp[x].nreg) &&
           cp[sl[q + 1]].qlen <= cp[x].qlen + cp[x].qlen / 2 + 64)
         y = sl[q + 1];
       q += y == x ? 1 : 2;
@@ -745,7 +787,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       partner[lo] = hi;
       partner[hi] = lo;
       // (the rows the wavefront steps through: the traceback finds a block's records by it)
-      cp[lo].ncol16 = cp[hi].ncol16 = std::max(cp[lo].qlen, cp[hi].qlen);
+      cp[lo].ncol16 = cp[hi].ncol16 = std::max(cp[lo].qlen, cp[hi].qlen) | (lo == hi ? 1 << 30 : 0);  // (bit 30: no partner)
       if (cp[lo].pad_ == 10) {  // (the chain kernel finds a task's partner through its plan record)
         cp[lo].zdrop = hi;
         cp[hi].zdrop = lo;
@@ -770,8 +812,8 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         } else {
           const PlanTask &pb = cp[partner[k]];
           const int qm = std::max(p.qlen, pb.qlen), tm = std::max(p.tlen, pb.tlen);
-          need = (strip_dir_bytes(qm, tm) + 255) & ~(size_t)255;
-          if (p.pad_ == 10) need += strip_chain_sync_bytes(qm, tm);
+          need = (strip_dir_bytes(qm, tm, p.nreg, partner[k] == (int32_t)k) + 255) & ~(size_t)255;
+          if (p.pad_ == 10) need += strip_chain_sync_bytes(qm, tm, p.nreg);
           if (partner[k] != (int32_t)k) cp[partner[k]].dir_off = (int64_t)dir_acc + 4;
         }
       } else if (p.pad_ == 5)
@@ -793,7 +835,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     size_t lds = 2048, need;
     if (p.pad_ == 10) {
       if (partner[k] < (int32_t)k) continue;  // (its partner's entry stands for both)
-      bs = 600;  // chained strips: one wavefront (workgroup) per block of 512 columns of a pair of tasks
+      bs = 600 + p.nreg;  // chained strips: one wavefront (workgroup) per block of 64 x nreg columns of a pair of tasks
       need = 16;
       lds = 1024;
     } else if (p.pad_ == 9) {
@@ -909,7 +951,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   for (auto &x : cls) {
     const bool hbm_cls = x.bs == 1000 || x.bs == 1001 || x.bs == 2001;
     const size_t lds_bytes = hbm_cls ? ((x.need_max + 255) & ~(size_t)255) : std::min(x.lds, (x.need_max + 511) & ~(size_t)511);
-    if ((x.bs >= 300 && x.bs < 500) || x.bs == 600) {
+    if ((x.bs >= 300 && x.bs < 500) || x.bs == 604 || x.bs == 608) {
       // Stripe kernel: one entry per stripe, (stripe << 24) | task.  Workgroup i runs on XCD i mod 8 and workgroups
       // are dispatched in index order.  The tasks are dealt to the eight residues (most stripes first, to the residue
       // with the fewest so far): a task's stripes share an XCD (its L2 carries their edge words).  A task is a chain:
@@ -923,13 +965,13 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // (chained strips, extz2_strip.hip: an entry stands for a PAIR of tasks -- the one listed and its partner --, a
       // "stripe" is a block of 512 columns of the wider of the two, 64 steps behind the block to its left, and the chain
       // is as long as the rows of the longer plus 64 per block)
-      const bool chained = x.bs == 600;
+      const bool chained = x.bs >= 600;
       const bool banded = !chained && x.bs >= 400;  // (banded stripe kernel: stripes over the padded target, 2 * 128 * nreg rows apart)
-      const int nreg = chained ? 1 : x.bs - (banded ? 400 : 300);
+      const int nreg = chained ? x.bs - 600 : x.bs - (banded ? 400 : 300);
       const size_t first = cursor;
       const int nslot = chained ? 64 : banded ? 256 * nreg : 128 * nreg;  // rows between the starts of consecutive stripes
       auto stripes_of = [&](int32_t rel) {
-        if (chained) return strip_blocks(std::max(cp[rel].tlen, cp[partner[rel]].tlen));
+        if (chained) return strip_blocks(std::max(cp[rel].tlen, cp[partner[rel]].tlen), nreg);
         return banded ? bstripe_geom(cp[rel].qlen, cp[rel].tlen, cp[rel].w, nreg).nst : (cp[rel].tlen + 128 * nreg - 1) / (128 * nreg);
       };
       auto chain_rows = [&](int32_t rel) {

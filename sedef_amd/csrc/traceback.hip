@@ -44,9 +44,12 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
   } else if (LAYOUT == 6) {
     // strip kernel (extz2_strip.hip): per step and lane one word of this task (the records are 8 bytes: its partner's
     // word sits beside it), step = the row + the lane, a block of 512 columns after the other
-    const int il = i & 511, ln = il >> 3;
-    a.idx = (((int64_t)(i >> 9) * (tk.ncol16 + 63) + j + ln) * 64 + ln) * 2;  // (ncol16: the rows of the wavefront's larger task)
-    a.meta = (uint32_t)(7 - (il & 7));
+    // (nreg: the columns per lane, 8 or 4; ncol16: the rows of the wavefront's larger task, bit 30: the task has the
+    // wavefront to itself -- records of one word)
+    const int sh = tk.nreg == 8 ? 3 : 2, il = i & ((64 << sh) - 1), ln = il >> sh;
+    const int rows = tk.ncol16 & 0x3fffffff;
+    a.idx = (((int64_t)(i >> (6 + sh)) * (rows + 63) + j + ln) * 64 + ln) * ((tk.ncol16 >> 30) ? 1 : 2);
+    a.meta = (uint32_t)(tk.nreg - 1 - (il & (tk.nreg - 1)));
   } else if (LAYOUT == 5) {
     // lane kernel (extz2_lane.hip): per tile of 16 target positions two words per query position, a nibble per cell
     a.idx = ((int64_t)(i >> 4) * tk.qlen + j) * 2 + ((i >> 3) & 1);

@@ -483,13 +483,22 @@ def _strip_pairs(rng, n):
     return pairs
 
 
-def test_strip_kernel_full_band_mid_size_tasks(engine, oracle):
+@pytest.fixture(scope="module")
+def strip_engine():
+    """The strip kernels whatever the number of tasks (they take a chunk's tasks only when there are enough to fill the
+    device: SDF_STRIP_ALWAYS lifts that for the parity tests)."""
+    return _engine_with_env(SDF_STRIP_ALWAYS=1)
+
+
+def test_strip_kernel_full_band_mid_size_tasks(strip_engine, oracle):
+    engine = strip_engine
     rng = np.random.default_rng(8001)
     pairs = _strip_pairs(rng, 400)
     ws = [-1 if k % 4 else max(len(q), len(t)) for k, (q, t) in enumerate(pairs)]
     flags = [0x80 if k % 9 == 4 else 0x01 if k % 11 == 6 else 0 for k in range(len(pairs))]
     _check_fast(engine, oracle, pairs, ws, flags)
     assert engine.last_paired() >= 100  # partners of equal geometry share a wavefront
+    assert engine.last_reran() == 0
     # the same tasks on the window / stripe kernels
     old = _engine_with_env(SDF_NO_STRIP=1)
     _check_fast(old, oracle, pairs[:60], ws[:60], flags[:60])
@@ -513,7 +522,8 @@ def _wide_strip_pairs(rng):
     return pairs
 
 
-def test_strip_chain_wide_full_band_tasks(engine, oracle):
+def test_strip_chain_wide_full_band_tasks(strip_engine, oracle):
+    engine = strip_engine
     rng = np.random.default_rng(8003)
     pairs = _wide_strip_pairs(rng)
     flags = [0x80 if k % 5 == 2 else 0x01 if k == 7 else 0 for k in range(len(pairs))]
@@ -523,12 +533,18 @@ def test_strip_chain_wide_full_band_tasks(engine, oracle):
     more = _strip_pairs(rng, 30) + pairs + _wide_strip_pairs(rng)
     _check_fast(engine, oracle, more, [-1] * len(more))
     # a wait that gives up: both tasks of the pair run again on another kernel
-    eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1)
+    eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1, SDF_STRIP_ALWAYS=1)
     _check_fast(eng, oracle, pairs, [-1] * len(pairs), flags)
     assert eng.last_reran() >= 6
+    # four columns per lane (blocks of 256 columns: twice as many, shorter steps)
+    eng4 = _engine_with_env(SDF_STRIP_COLS=4, SDF_STRIP_ALWAYS=1)
+    _check_fast(eng4, oracle, pairs, [-1] * len(pairs), flags)
+    # by itself the planner gives so few wide tasks to the stripe kernel
+    _check_fast(_engine_with_env(SDF_NO_LANE=1), oracle, pairs[:6], [-1] * 6)
 
 
-def test_strip_kernel_other_scorings(engine, oracle):
+def test_strip_kernel_other_scorings(strip_engine, oracle):
+    engine = strip_engine
     rng = np.random.default_rng(8002)
     for it in range(10):
         ma, mi = int(rng.integers(1, 12)), -int(rng.integers(1, 12))
