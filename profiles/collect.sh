@@ -19,7 +19,10 @@ SDF_PIPELINE=0 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d 
 SDF_PIPELINE=0 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $out/sq -o run -- $B1 > $out/sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_hg19 -o run -- python3 profiles/mix_probe.py hg19 1000000 > $out/stats_hg19.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_mm8 -o run -- python3 profiles/mix_probe.py mm8 3000 > $out/stats_mm8.log 2>&1
-for d in stats_iso stats_pipe stats_hg19 stats_mm8; do cp $(find $out/$d -name "*kernel_stats.csv" | head -1) $out/${d}_kernel_stats.csv; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_mm8big -o run -- python3 profiles/mix_probe.py mm8 100000 > $out/stats_mm8big.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_fullband -o run -- python3 profiles/chain_probe.py > $out/stats_fullband.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_lane -o run -- python3 profiles/lane_probe.py 400000 > $out/stats_lane.log 2>&1
+for d in stats_iso stats_pipe stats_hg19 stats_mm8 stats_mm8big stats_fullband stats_lane; do cp $(find $out/$d -name "*kernel_stats.csv" | head -1) $out/${d}_kernel_stats.csv; done
 python3 profiles/pmc_summary.py $out/fetch > $out/pmc_fetch.txt
 python3 profiles/pmc_summary.py $out/write > $out/pmc_write.txt
 python3 profiles/pmc_summary.py $out/sq extz2_ 199900000 > $out/pmc_sq.txt
@@ -28,7 +31,7 @@ python3 profiles/timeline.py $out/stats_hg19 40 > $out/timeline_hg19.txt
 python3 profiles/timeline.py $out/stats_mm8 24 > $out/timeline_mm8.txt
 tail -1 $out/stats_iso.log > $out/bench_iso.json
 tail -1 $out/stats_pipe.log > $out/bench_pipe.json
-grep -h "tasks" $out/stats_hg19.log $out/stats_mm8.log > $out/mix_lines.txt
+grep -h "tasks" $out/stats_hg19.log $out/stats_mm8.log $out/stats_mm8big.log $out/stats_fullband.log $out/stats_lane.log > $out/mix_lines.txt
 python3 profiles/make_traffic_json.py $out profiles/${tag}_pair_kernel_pmc.txt > $out/hbm_traffic_line.txt
 cat $out/stats_iso_kernel_stats.csv | head -8; cat $out/pmc_fetch.txt $out/pmc_write.txt $out/pmc_sq.txt | grep "pair_kernel\|traceback"; cat $out/mix_lines.txt
-rm -rf $out/stats_iso $out/stats_pipe $out/fetch $out/write $out/sq $out/stats_hg19 $out/stats_mm8
+rm -rf $out/stats_iso $out/stats_pipe $out/fetch $out/write $out/sq $out/stats_hg19 $out/stats_mm8 $out/stats_mm8big $out/stats_fullband $out/stats_lane

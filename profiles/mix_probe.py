@@ -15,7 +15,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else (3000 if which == "mm8" else 3000
 eng = sedef_amd.Extz2Engine(0, 64 << 30)
 dev = torch.device("cuda", 0)
 if which == "mm8":
-    b, w = bench.synth_mm8_mixture(n, seed=505)
+    b, w = bench.synth_mm8_mixture(n, seed=505) if n <= 5000 else bench.synth_mm8_mixture_fast(n, seed=505)
 else:
-    b, w = bench.synth_hg19_mixture(n, seed=404, big=6000)
+    b, w = bench.synth_hg19_mixture_fast(n, seed=404, big=6000)
 shapes_bench.run(which, b, w, eng, dev, steps=1)
