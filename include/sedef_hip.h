@@ -233,8 +233,9 @@ int sdf_stats_columns_batch(sdf_ctx *ctx, const sdf_stats_task *tasks, size_t n,
                             const uint32_t *cigar_pool, size_t cigar_words, sdf_stats_cols *out);
 /* The same with tasks, pools and results resident in HBM; asynchronous on `stream` (a hipStream_t; NULL = the
  * context's own stream, synchronised before returning).  Offsets are not checked against the pools here.  One
- * wavefront takes one alignment: the host-buffer call cuts alignments of more than 1,024 runs into pieces of 512 runs
- * first and adds the pieces' counters up; a caller of this entry point with very long alignments does the same. */
+ * wavefront takes one alignment; an alignment of more than 1,024 runs is cut into segments of 512 runs on the device, which
+ * wavefronts of a second launch count side by side (a list of 2^18 segments in the context: calls on one context do not
+ * overlap). */
 int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_tasks, size_t n, const char *d_seq_pool,
                              const uint32_t *d_cigar_pool, sdf_stats_cols *d_out, void *stream);
 

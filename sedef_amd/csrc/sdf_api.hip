@@ -99,6 +99,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->force_general = fg && fg[0] == '1';
   const char *np = getenv("SDF_NO_PAIR");
   ctx->no_pair = np && np[0] == '1';
+  if (const char *e = getenv("SDF_STATS_ITEMS")) ctx->stats_items = (unsigned)std::max(1, atoi(e));  // (tests: a list that overflows)
   for (const void *f : {reinterpret_cast<const void *>(&extz2_stripe_kernel<1>),
                         reinterpret_cast<const void *>(&extz2_stripe_kernel<2>),
                         reinterpret_cast<const void *>(&extz2_stripe_kernel<4>),
@@ -908,8 +909,17 @@ extern "C" int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_ta
   if (n == 0) return SDF_OK;
   SDF_HIP(hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  // the list for the segments of long alignments (stats_cols.hip): 2^18 segments of 512 runs; an alignment that finds it
+  // full is counted by its own wavefront
+  const unsigned kItems = ctx->stats_items;
+  SDF_HIP(ctx->st_items.reserve((size_t)kItems * sizeof(sdf::StatsItem) + 64));
+  unsigned *d_counter = reinterpret_cast<unsigned *>((char *)ctx->st_items.p + (size_t)kItems * sizeof(sdf::StatsItem));
+  SDF_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned), st));
   hipLaunchKernelGGL(sdf::stats_columns_kernel, dim3((unsigned)((n + sdf::STATS_WAVES - 1) / sdf::STATS_WAVES)),
-                     dim3(64 * sdf::STATS_WAVES), 0, st, d_tasks, (int)n, d_seq_pool, d_cigar_pool, d_out);
+                     dim3(64 * sdf::STATS_WAVES), 0, st, d_tasks, (int)n, d_seq_pool, d_cigar_pool, d_out,
+                     (sdf::StatsItem *)ctx->st_items.p, d_counter, kItems);
+  hipLaunchKernelGGL(sdf::stats_segments_kernel, dim3(2048), dim3(64 * sdf::STATS_WAVES), 0, st,
+                     (const sdf::StatsItem *)ctx->st_items.p, d_counter, kItems, d_seq_pool, d_cigar_pool, d_out);
   SDF_HIP(hipGetLastError());
   if (!stream) SDF_HIP(hipStreamSynchronize(st));
   return SDF_OK;
@@ -939,48 +949,10 @@ extern "C" int sdf_stats_columns_batch(sdf_ctx *ctx, const sdf_stats_task *tasks
   if (n == 0) return SDF_OK;
   SDF_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  // The kernel gives an alignment to one wavefront.  A long alignment is cut here at every STATS_SEG runs into pieces
-  // that run side by side -- a piece is an alignment of its own: the sequences' ranges its runs consume -- and the
-  // pieces' counters are added up afterwards (every counter is a sum over columns or runs).
-  constexpr uint32_t STATS_SEG = 512, STATS_LONG = 1024;
-  std::vector<sdf_stats_task> pieces;
-  std::vector<size_t> first;
-  bool any_long = false;
-  for (size_t i = 0; i < n && !any_long; i++) any_long = tasks[i].n_cigar > STATS_LONG;
-  if (any_long) {
-    first.resize(n + 1);
-    for (size_t i = 0; i < n; i++) {
-      const sdf_stats_task &t = tasks[i];
-      first[i] = pieces.size();
-      if (t.n_cigar <= STATS_LONG) {
-        pieces.push_back(t);
-        continue;
-      }
-      uint64_t ia = 0, ib = 0;
-      for (uint32_t k0 = 0; k0 < t.n_cigar; k0 += STATS_SEG) {
-        const uint32_t nk = std::min(STATS_SEG, t.n_cigar - k0);
-        uint64_t da = 0, db = 0;
-        bool ok = true;
-        for (uint32_t k = 0; k < nk; k++) {
-          const uint32_t w = cigar_pool[t.cigar_off + k0 + k], op = w & 15u;
-          ok &= op <= 2;
-          if (op != 2) da += w >> 4;
-          if (op != 1) db += w >> 4;
-        }
-        if (!ok || ia + da > t.a_len || ib + db > t.b_len) {
-          ctx->err = "alignment " + std::to_string(i) + ": the CIGAR does not fit its sequences";
-          return SDF_ERR_INVALID;
-        }
-        pieces.push_back({t.a_off + ia, t.b_off + ib, (uint32_t)da, (uint32_t)db, t.cigar_off + k0, nk, 0});
-        ia += da, ib += db;
-      }
-    }
-    first[n] = pieces.size();
-  }
-  const sdf_stats_task *up = any_long ? pieces.data() : tasks;
-  const size_t nup = any_long ? pieces.size() : n;
-  std::vector<sdf_stats_cols> piece_out(any_long ? nup : 0);
-  sdf_stats_cols *down = any_long ? piece_out.data() : out;
+  // (long alignments are cut into segments on the device: stats_cols.hip)
+  const sdf_stats_task *up = tasks;
+  const size_t nup = n;
+  sdf_stats_cols *down = out;
   SDF_HIP(ctx->st_tasks.reserve(nup * sizeof(sdf_stats_task)));
   SDF_HIP(ctx->st_pool.reserve(pool_bytes + 16));
   SDF_HIP(ctx->st_cig.reserve(cigar_words * 4 + 16));
@@ -993,17 +965,7 @@ extern "C" int sdf_stats_columns_batch(sdf_ctx *ctx, const sdf_stats_task *tasks
   if (rc != SDF_OK) return rc;
   SDF_HIP(hipMemcpyAsync(down, ctx->st_out.p, nup * sizeof(sdf_stats_cols), hipMemcpyDeviceToHost, st));
   SDF_HIP(hipStreamSynchronize(st));
-  if (any_long)
-    for (size_t i = 0; i < n; i++) {
-      static_assert(sizeof(sdf_stats_cols) == 16 * sizeof(int32_t), "sdf_stats_cols is sixteen counters");
-      int32_t acc[16] = {0};
-      for (size_t k = first[i]; k < first[i + 1]; k++) {
-        const int32_t *v = reinterpret_cast<const int32_t *>(&piece_out[k]);
-        for (int f = 0; f < 15; f++) acc[f] += v[f];
-        acc[15] |= v[15];
-      }
-      memcpy(&out[i], acc, sizeof(acc));
-    }
+  static_assert(sizeof(sdf_stats_cols) == 16 * sizeof(int32_t), "sdf_stats_cols is sixteen counters");
   for (size_t i = 0; i < n; i++)
     if (out[i].flags) {
       ctx->err = "alignment " + std::to_string(i) + ": the CIGAR does not fit its sequences";

@@ -235,6 +235,8 @@ struct sdf_ctx {
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
   DevBuf st_tasks, st_pool, st_cig, st_out;  // sdf_stats_columns_batch
+  DevBuf st_items;                           // sdf_stats_columns_device: segments of long alignments + their counter
+  unsigned stats_items = 1u << 18;           // ... capacity of that list (SDF_STATS_ITEMS)
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
   // lane kernel (extz2_lane.hip): records as uploaded, sort keys / values (in, out), sizes and their scans, hipCUB scratch
   HostBuf host_lane;

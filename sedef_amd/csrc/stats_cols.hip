@@ -9,12 +9,24 @@
 // unit (two per round, so that four loads are in flight), finds its run by a six-step search of the chunk's unit offsets
 // in LDS, reads its characters with one unaligned 8-byte load per sequence and counts them four columns per 32-bit word.
 // HBM-bound byte pass: a_len + b_len + 4 n_cigar + 64 bytes per alignment.
+//
+// A long alignment (more than STATS_LONG runs) would be one wavefront's work for milliseconds: its wavefront only sums the
+// advances of its runs, STATS_SEG at a time, and leaves one work item per segment -- an alignment of its own: the sequences'
+// ranges the segment's runs consume -- in a list (stats_columns_kernel); a second launch of a fixed number of wavefronts
+// takes the items and adds their counters to the alignment's record (stats_segments_kernel).
 #pragma once
 #include "sdf_internal.h"
 
 namespace sdf {
 
 constexpr int STATS_WAVES = 4;  // alignments per workgroup
+constexpr uint32_t STATS_SEG = 512, STATS_LONG = 1024;  // runs per segment of a long alignment / runs that make one long
+
+struct StatsItem {  // a segment of a long alignment
+  sdf_stats_task t;
+  uint32_t task;  // the alignment it belongs to (0xffffffff: nothing to do)
+  uint32_t pad;
+};
 
 // Prefix sums and sums over the wavefront (all 64 lanes active): an inclusive scan inside each row of sixteen lanes
 // (row_shr 1, 2, 4, 8), the rows' totals passed on (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3) --
@@ -51,20 +63,14 @@ __device__ __forceinline__ uint64_t stats_fetch8(const char *s, int pos, int sle
 
 constexpr uint64_t STATS_DASHES = 0x2D2D2D2D2D2D2D2DULL;
 
-__global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(const sdf_stats_task *__restrict__ tasks, int n,
-                                                                         const char *__restrict__ pool,
-                                                                         const uint32_t *__restrict__ cigars,
-                                                                         sdf_stats_cols *__restrict__ out) {
-  __shared__ int s_unit[STATS_WAVES][64], s_a[STATS_WAVES][64], s_b[STATS_WAVES][64], s_len[STATS_WAVES][64];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int task = blockIdx.x * STATS_WAVES + wv;
-  if (task >= n) return;  // whole wavefronts leave; the kernel has no workgroup barrier
-  const sdf_stats_task T = tasks[task];
+// the counters of one alignment (or segment), summed over the wavefront: v[0..11], and whether its CIGAR fits
+__device__ __forceinline__ int stats_count_alignment(const sdf_stats_task &T, const char *__restrict__ pool,
+                                                     const uint32_t *__restrict__ cigars, int *unit, int *sa, int *sb, int *sl,
+                                                     const int lane, int (&v)[12]) {
   const char *a = pool + T.a_off, *b = pool + T.b_off;
   const uint32_t *cg = cigars + T.cigar_off;
   const int n_cigar = (int)T.n_cigar, a_len = (int)T.a_len, b_len = (int)T.b_len;
   const bool wide_a = a_len >= 8, wide_b = b_len >= 8;
-  int *unit = s_unit[wv], *sa = s_a[wv], *sb = s_b[wv], *sl = s_len[wv];
 
   // mismatchB = alnB - matchB, transversionsB = mismatchB - transitionsB, mismatches = alnB - matches: derived at the end
   int indel_a = 0, indel_b = 0, aln_b = 0, match_b = 0, ts = 0, up_a = 0, up_b = 0, up_m = 0;
@@ -196,16 +202,102 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
     __builtin_amdgcn_wave_barrier();
     ia += tot_a, ib += tot_b;
   }
-  int v[12] = {indel_a, indel_b, aln_b, match_b, ts, up_a, up_b, up_m, matches, gaps, gap_bases, span_l};
+  const int w_[12] = {indel_a, indel_b, aln_b, match_b, ts, up_a, up_b, up_m, matches, gaps, gap_bases, span_l};
 #pragma unroll
-  for (int i = 0; i < 12; i++) v[i] = stats_wave_sum(v[i]);
-  if (lane == 0) {
-    sdf_stats_cols R;
-    R.indel_a = v[0], R.indel_b = v[1], R.aln_b = v[2], R.match_b = v[3], R.mismatch_b = v[2] - v[3];
-    R.transitions_b = v[4], R.transversions_b = v[2] - v[3] - v[4], R.uppercase_a = v[5], R.uppercase_b = v[6];
-    R.uppercase_matches = v[7], R.matches = v[8], R.mismatches = v[2] - v[8], R.gaps = v[9], R.gap_bases = v[10];
-    R.span = v[11], R.flags = bad;
-    out[task] = R;
+  for (int i = 0; i < 12; i++) v[i] = stats_wave_sum(w_[i]);
+  return bad;
+}
+
+__device__ __forceinline__ sdf_stats_cols stats_record(const int (&v)[12], const int bad) {
+  sdf_stats_cols R;
+  R.indel_a = v[0], R.indel_b = v[1], R.aln_b = v[2], R.match_b = v[3], R.mismatch_b = v[2] - v[3];
+  R.transitions_b = v[4], R.transversions_b = v[2] - v[3] - v[4], R.uppercase_a = v[5], R.uppercase_b = v[6];
+  R.uppercase_matches = v[7], R.matches = v[8], R.mismatches = v[2] - v[8], R.gaps = v[9], R.gap_bases = v[10];
+  R.span = v[11], R.flags = bad;
+  return R;
+}
+
+// One wavefront per alignment.  items / counter / cap: the list for the segments of long alignments (items == nullptr:
+// every alignment is counted by its own wavefront).
+__global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(const sdf_stats_task *__restrict__ tasks, int n,
+                                                                         const char *__restrict__ pool,
+                                                                         const uint32_t *__restrict__ cigars,
+                                                                         sdf_stats_cols *__restrict__ out,
+                                                                         StatsItem *__restrict__ items,
+                                                                         unsigned *__restrict__ counter, unsigned cap) {
+  __shared__ int s_unit[STATS_WAVES][64], s_a[STATS_WAVES][64], s_b[STATS_WAVES][64], s_len[STATS_WAVES][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int task = blockIdx.x * STATS_WAVES + wv;
+  if (task >= n) return;  // whole wavefronts leave; the kernel has no workgroup barrier
+  const sdf_stats_task T = tasks[task];
+  if (items && T.n_cigar > STATS_LONG) {
+    const unsigned nseg = (T.n_cigar + STATS_SEG - 1) / STATS_SEG;
+    unsigned first = 0;
+    if (lane == 0) first = atomicAdd(counter, nseg);
+    first = (unsigned)__builtin_amdgcn_readfirstlane((int)first);
+    if (first < cap && nseg <= cap - first) {
+      // the segments' advances: eight runs per lane and segment; the sequences' offsets are running sums over the segments
+      const uint32_t *cg = cigars + T.cigar_off;
+      uint64_t ia = 0, ib = 0;
+      int bad = 0;
+      for (unsigned sg = 0; sg < nseg; ++sg) {
+        const unsigned k0 = sg * STATS_SEG, nk = T.n_cigar - k0 < STATS_SEG ? T.n_cigar - k0 : STATS_SEG;
+        int da = 0, db = 0, wrong = 0;
+#pragma unroll
+        for (unsigned q = 0; q < STATS_SEG / 64; ++q) {
+          const unsigned k = q * 64 + lane;
+          const uint32_t w = k < nk ? cg[k0 + k] : 0u;
+          const uint32_t op = w & 15u, len = w >> 4;
+          wrong |= op > 2 || len > (1u << 24);
+          da += op != 2 ? (int)len : 0;
+          db += op != 1 ? (int)len : 0;
+        }
+        da = stats_wave_sum(da), db = stats_wave_sum(db);  // (<= 512 runs of <= 2^24: the sums may wrap only when `wrong` anyway)
+        bad |= __any(wrong) || da < 0 || db < 0 || ia + (uint64_t)da > T.a_len || ib + (uint64_t)db > T.b_len;
+        if (lane == 0) {
+          StatsItem it;
+          it.t.a_off = T.a_off + ia, it.t.b_off = T.b_off + ib;
+          it.t.a_len = (uint32_t)da, it.t.b_len = (uint32_t)db;
+          it.t.cigar_off = T.cigar_off + k0, it.t.n_cigar = nk, it.t.reserved = 0;
+          it.task = bad ? 0xffffffffu : (uint32_t)task;  // (nothing after a segment that does not fit is counted)
+          it.pad = 0;
+          items[first + sg] = it;
+        }
+        ia += (uint64_t)(bad ? 0 : da), ib += (uint64_t)(bad ? 0 : db);
+      }
+      if (lane == 0) {
+        const int zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        out[task] = stats_record(zero, bad);  // the segments add to it
+      }
+      return;
+    }
+    // the list is full: its slots (if any) stay empty and this wavefront counts the alignment itself
+    for (unsigned sg = lane; first < cap && sg < cap - first; sg += 64) items[first + sg].task = 0xffffffffu;
+  }
+  int v[12];
+  const int bad = stats_count_alignment(T, pool, cigars, s_unit[wv], s_a[wv], s_b[wv], s_len[wv], lane, v);
+  if (lane == 0) out[task] = stats_record(v, bad);
+}
+
+// The segments of the long alignments: wavefront g of the grid takes items g, g + G, ... and adds their counters up.
+__global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_segments_kernel(const StatsItem *__restrict__ items,
+                                                                          const unsigned *__restrict__ counter, unsigned cap,
+                                                                          const char *__restrict__ pool,
+                                                                          const uint32_t *__restrict__ cigars,
+                                                                          sdf_stats_cols *__restrict__ out) {
+  __shared__ int s_unit[STATS_WAVES][64], s_a[STATS_WAVES][64], s_b[STATS_WAVES][64], s_len[STATS_WAVES][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned total = *counter < cap ? *counter : cap;
+  for (unsigned i = blockIdx.x * STATS_WAVES + wv; i < total; i += gridDim.x * STATS_WAVES) {
+    const StatsItem it = items[i];
+    if (it.task == 0xffffffffu) continue;  // (wave-uniform)
+    int v[12];
+    const int bad = stats_count_alignment(it.t, pool, cigars, s_unit[wv], s_a[wv], s_b[wv], s_len[wv], lane, v);
+    const sdf_stats_cols R = stats_record(v, bad);
+    const int32_t *src = reinterpret_cast<const int32_t *>(&R);
+    int32_t *dst = reinterpret_cast<int32_t *>(&out[it.task]);
+    if (lane < 15) atomicAdd(dst + lane, src[lane]);
+    if (lane == 15 && bad) atomicOr(dst + 15, 1);
   }
 }
 
