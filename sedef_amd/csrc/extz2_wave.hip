@@ -209,7 +209,7 @@ __host__ __device__ inline int wave_qcap(int qlen, int nreg) {
 
 // STREAM: the sequences do not fit the LDS windows whole (long tasks); without it the window code compiles out.
 template <int NREG, bool STREAM>
-__global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : 2) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
+__global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 : 2) void extz2_wave_kernel(const PlanTask *__restrict__ plan,
                                                         const int32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ pool, ScoreK sc,
                                                         uint8_t *__restrict__ dirbase,
@@ -873,6 +873,14 @@ template __global__ void extz2_wave_kernel<1, true>(const PlanTask *, const int3
 template __global__ void extz2_wave_kernel<2, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
                                                      uint8_t *, sdf_result *);
 template __global__ void extz2_wave_kernel<2, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<3, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<3, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<6, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                     uint8_t *, sdf_result *);
+template __global__ void extz2_wave_kernel<6, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
                                                      uint8_t *, sdf_result *);
 template __global__ void extz2_wave_kernel<4, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
                                                      uint8_t *, sdf_result *);

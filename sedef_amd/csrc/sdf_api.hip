@@ -76,6 +76,14 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<2, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<3, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<3, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<6, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<6, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<4, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_wave_kernel<4, true>),
@@ -99,6 +107,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->force_general = fg && fg[0] == '1';
   const char *np = getenv("SDF_NO_PAIR");
   ctx->no_pair = np && np[0] == '1';
+  if (const char *e = getenv("SDF_SELF_PAIR_MAX")) ctx->self_pair_max = (size_t)std::max(0ll, atoll(e));
   if (const char *e = getenv("SDF_STATS_ITEMS")) ctx->stats_items = (unsigned)std::max(1, atoi(e));  // (tests: a list that overflows)
   for (const void *f : {reinterpret_cast<const void *>(&extz2_stripe_kernel<1>),
                         reinterpret_cast<const void *>(&extz2_stripe_kernel<2>),
@@ -354,6 +363,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   env.max_dyn_lds = ctx->max_dyn_lds;
   env.force_general = ctx->force_general;
   env.no_pair = ctx->no_pair;
+  env.self_pair_max = ctx->self_pair_max;
   env.no_stripe = ctx->no_stripe;
   env.stripe_min = ctx->stripe_min;
   env.bstripe_min_rows = ctx->bstripe_min_rows;
@@ -521,6 +531,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         ctx->part_ctx->is_part = true;
         ctx->part_ctx->force_general = ctx->force_general;
         ctx->part_ctx->no_pair = ctx->no_pair;
+        ctx->part_ctx->self_pair_max = ctx->self_pair_max;
         ctx->part_ctx->no_stripe = ctx->no_stripe;
         ctx->part_ctx->lane_enabled = ctx->lane_enabled;
         ctx->part_ctx->lane_min = ctx->lane_min;

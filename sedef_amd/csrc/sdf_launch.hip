@@ -101,6 +101,10 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 11: SDF_WAVE(1, true); break;
     case 2: SDF_WAVE(2, false); break;
     case 12: SDF_WAVE(2, true); break;
+    case 3: SDF_WAVE(3, false); break;
+    case 13: SDF_WAVE(3, true); break;
+    case 6: SDF_WAVE(6, false); break;
+    case 16: SDF_WAVE(6, true); break;
     case 4: SDF_WAVE(4, false); break;
     case 14: SDF_WAVE(4, true); break;
     case 8: SDF_WAVE(8, false); break;
@@ -190,8 +194,10 @@ static int launch_chunk(BatchRun &run, size_t ci) {
     // extra streams, created the first time they are wanted (a stream is a hardware queue: ~7 ms to set up): launches of
     // few tasks last as long as their longest task whatever else runs, so the more of them run side by side the better
     // (batches of a few ten thousand tasks, the stage driver's rounds, get by with two: 7 ms per stream is their budget)
+    // (a chunk of many launch classes -- a batch of banded tasks of all lengths -- wants three queues of its own next to
+    // the three of the chunk before it: see the assignment below)
     const size_t want_aux = nchunks == 1 ? (c.launches.size() > 4 ? std::min<size_t>(c.launches.size() - 4, 4) : 0)
-                                         : (cut.ntask_total >= 200000 ? 4 : 2);
+                                         : (cut.ntask_total >= 200000 || c.launches.size() > 4 ? 4 : 2);
     for (size_t a = 0; a < want_aux; ++a)
       if (!ctx->aux_stream[a] && hipStreamCreateWithFlags(&ctx->aux_stream[a], hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
@@ -256,11 +262,21 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       if (piped && L.cnt >= 2048 && (L.bs < 300 || L.bs == 500)) {  // (a stripe class counts stripes, and lasts as long as its longest task)
         qi = ui;
       } else {  // least estimated work queued; with heavy tasks in the batch Q[0], Q[1], Q[4], Q[5] are theirs
-        qi = run.have_heavy ? (heavy_chunk ? 0 : 2) : 1;
+        // Without heavy tasks, consecutive ordinary chunks keep to disjoint sets of queues -- Q[1], Q[4], Q[5] and Q[2],
+        // Q[6], Q[7]: a chunk's launches (and its plan upload, which every one of them waits for) must not queue behind
+        // the long-running small launches of the chunk before it, or the chunks run one after the other, each as long as
+        // its longest task (a 100,000-task batch of banded tasks of all lengths: 474 ms -> see profiles/r03_shapes.txt)
+        const bool split_q = !run.have_heavy && piped && nchunks > 1;
+        auto mine = [&](int q) { return (nj & 1) ? (q == 2 || q == 6 || q == 7) : (q == 1 || q == 4 || q == 5); };
+        qi = run.have_heavy ? (heavy_chunk ? 0 : 2) : split_q ? ui : 1;
         for (int q = qi + 1; q < 8; ++q) {
           if (!Q[q] || (run.have_heavy && heavy_chunk != (q == 1 || q == 4 || q == 5))) continue;
+          if (split_q && !mine(q)) continue;
           if (run.qload[q] < run.qload[qi]) qi = q;
         }
+        if (split_q)  // (the loop above starts at the upload queue: the lower queues of the set)
+          for (int q = 1; q < qi; ++q)
+            if (Q[q] && mine(q) && run.qload[q] < run.qload[qi]) qi = q;
       }
     }
     run.qload[qi] += L.est;

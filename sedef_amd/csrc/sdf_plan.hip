@@ -27,6 +27,7 @@ struct PlanEnv {
   int gapo = 0;
   int max_dyn_lds = 64 * 1024;
   bool force_general = false, no_pair = false, no_stripe = false;
+  size_t self_pair_max = 512;  // more tasks without a partner than this in a chunk: the wave kernel instead of pairing them with themselves (SDF_SELF_PAIR_MAX)
   int stripe_min = 400;
   int bstripe_min_rows = 4000;  // banded tasks with at least this many anti-diagonals: banded stripe kernel (0: off)
   // lane kernel (extz2_lane.hip): small full-band tasks leave the host's planning altogether when the batch holds at least
@@ -40,7 +41,7 @@ struct PlanEnv {
 };
 
 struct Launch {
-  int bs;  // 64 / 256 / 1024: general kernel with that many threads (+2000: PLAIN flavour); 1, 2, 4, 8: wave kernel with
+  int bs;  // 64 / 256 / 1024: general kernel with that many threads (+2000: PLAIN flavour); 1, 2, 3, 4, 6, 8: wave kernel with
            // NREG (+10: streamed windows); 100 + NREG: pair kernel (+10: streamed; 120 + NREG: TRACK flavour);
            // 300 + NREG: stripe kernel, 400 + NREG: banded stripe kernel (one launch-order entry per stripe);
            // 1000 / 1001 / 2001: general kernel with its state in HBM
@@ -588,7 +589,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         // window slots: one 16-row block of slack below, the score refresh overshoot above -- but never
         // beyond the target's last 16-cell block (cells past it are not part of any window)
         const int need = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
-        const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 512 ? 4 : need <= 1024 ? 8 : 0;
+        const int nreg = need <= 128 ? 1 : need <= 256 ? 2 : need <= 384 ? 3 : need <= 512 ? 4 : need <= 768 ? 6 : need <= 1024 ? 8 : 0;
         if (nreg && wave_lds_bytes(t.qlen, t.tlen, nreg) <= (size_t)env.max_dyn_lds) {
           p.nreg = nreg;
           wneed = need;
@@ -733,9 +734,13 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       }
     }
     // a task left without a partner is paired with itself (both halves compute the same task and write the
-    // same bytes) instead of occupying a launch of its own for a whole task latency
+    // same bytes) instead of occupying a launch of its own for a whole task latency -- when they are few.  Many of them
+    // (a batch of banded tasks of all lengths: BASELINE configs[4]) fill launches of their own on the one-task wave
+    // kernel, whose row is 30-40 % shorter than that of a wavefront whose halves compute the same thing.
+    size_t n_left = 0;
+    for (auto &e : table) n_left += e.second >= 0;
     for (auto &e : table) {
-      if (e.second < 0) continue;
+      if (e.second < 0 || n_left > env.self_pair_max) continue;
       PlanTask &y = cp[e.second];
       const int regs = (win_need[e.second] + 63) / 64;
       const int nreg = regs <= 4 ? regs : regs <= 6 ? 6 : 8;

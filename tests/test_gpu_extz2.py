@@ -1151,3 +1151,22 @@ def test_config2_full_size_banded_and_full_band(engine, oracle):
     assert done.all() and int(res["n_cigar"].astype(np.int64).sum()) > 3000000
     res, done = _full_size_properties(engine, batch, -1, np.sort(rng.choice(100000, 500, replace=False)), oracle)
     assert done.all()
+
+
+def test_many_unpaired_banded_tasks_take_the_wave_kernel(engine, oracle):
+    """More than 512 banded tasks of a chunk without a partner of their geometry are not paired with themselves: they fill
+    launches of the one-task wave kernel (a wavefront whose halves compute the same task wastes half its row)."""
+    rng = np.random.default_rng(4801)
+    pairs, ws, seen = [], [], set()
+    while len(pairs) < 640:
+        ql = int(rng.integers(30, 900))
+        tl = max(1, ql + int(rng.integers(-40, 40)))
+        w = int(rng.choice([16, 33, 64, 100, 128, 200, 256]))
+        if (ql, tl, w) in seen:
+            continue
+        seen.add((ql, tl, w))
+        pairs += _same_geometry_tasks(rng, ql, tl, 1, 0.02)
+        ws.append(w)
+    _check_fast(engine, oracle, pairs, ws)
+    assert engine.last_paired() == 0
+    _check_fast(engine, oracle, pairs[:300], ws[:300])  # few of them: paired with themselves, as before
