@@ -4,7 +4,10 @@
 // Planning lives in sdf_plan.hip, uploads and launches in sdf_launch.hip (same translation unit, see sdf_unity.hip).
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <atomic>
+#include <cstring>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -27,6 +30,24 @@ extern "C" int sdf_device_count(void) {
 extern "C" const char *sdf_last_error(const sdf_ctx *ctx) {
   return ctx ? ctx->err.c_str() : g_err.c_str();
 }
+
+namespace {
+std::atomic<int> g_live_contexts{0};
+// CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota
+int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : CPU_COUNT(&set), CPU_COUNT(&set));
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+    char q[32];
+    long period = 0;
+    if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+      n = std::min(n, (int)((atol(q) + period / 2) / period));
+    fclose(f);
+  }
+  return std::max(n, 1);
+}
+}  // namespace
 
 extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   int n = 0;
@@ -107,6 +128,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->force_general = fg && fg[0] == '1';
   const char *np = getenv("SDF_NO_PAIR");
   ctx->no_pair = np && np[0] == '1';
+  if (const char *e = getenv("SDF_CHAIN_MIN")) ctx->chain_min = (size_t)std::max(0ll, atoll(e));
   if (const char *e = getenv("SDF_SELF_PAIR_MAX")) ctx->self_pair_max = (size_t)std::max(0ll, atoll(e));
   if (const char *e = getenv("SDF_STATS_ITEMS")) ctx->stats_items = (unsigned)std::max(1, atoi(e));  // (tests: a list that overflows)
   for (const void *f : {reinterpret_cast<const void *>(&extz2_stripe_kernel<1>),
@@ -146,11 +168,13 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   // (three streams of our own: the runtime multiplexes streams onto GPU_MAX_HW_QUEUES -- default 4 -- hardware
   // queues, and two of ours landing on one queue serialises what the pipeline wants side by side; with the
   // caller's stream that makes four)
+  g_live_contexts.fetch_add(1);
   return ctx;
 }
 
 extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (!ctx) return;
+  g_live_contexts.fetch_sub(1);
   (void)hipSetDevice(ctx->device);
   for (hipStream_t q : {ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
                         ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3]})
@@ -287,11 +311,12 @@ int make_scorek(sdf_ctx *ctx, const sdf_scoring *sc, ScoreK &k, bool &degenerate
 class ChunkPlanner {
  public:
   // nworkers jobs on `pool` (may be null when nworkers == 0)
-  ChunkPlanner(const PlanEnv &env, BatchCut &cut, PlanTask *plan, int32_t *order, WorkerPool *pool, int nworkers)
+  // (`first`: the chunks before it have been planned and launched already -- the early start of the heavy chunks)
+  ChunkPlanner(const PlanEnv &env, BatchCut &cut, PlanTask *plan, int32_t *order, WorkerPool *pool, int nworkers, size_t first = 0)
       : env_(env), cut_(cut), plan_(plan), order_(order), pool_(nworkers > 0 ? pool : nullptr),
-        ready_(cut.chunks.size(), 0) {
+        ready_(cut.chunks.size(), 0), first_(first) {
     if (!pool_) return;
-    next_.store(1);  // chunk 0 is planned by the caller of wait(0): no hand-over in front of the GPU's start
+    next_.store(first + 1);  // chunk `first` is planned by the caller of wait(first): no hand-over in front of the GPU's start
     for (int t = 0; t < nworkers; ++t) pool_->submit([this] { work(); });
   }
   ~ChunkPlanner() {
@@ -299,7 +324,7 @@ class ChunkPlanner {
     if (pool_) pool_->wait_idle();
   }
   void wait(size_t ci) {
-    if (!pool_ || ci == 0) {
+    if (!pool_ || ci == first_) {
       plan_chunk(env_, cut_, cut_.chunks[ci], plan_, order_, own_);
       return;
     }
@@ -327,6 +352,7 @@ class ChunkPlanner {
   int32_t *order_;
   WorkerPool *pool_;
   std::vector<char> ready_;
+  size_t first_ = 0;
   std::atomic<size_t> next_{0};
   std::atomic<bool> stop_{false};
   std::mutex mu_;
@@ -376,6 +402,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     env.lane_min = ctx->lane_min;
     env.strip_always = ctx->strip_always;
     env.strip_cols = ctx->strip_cols;
+    env.chain_min = ctx->chain_min;
     env.strip_ok = ctx->strip_enabled && !ctx->force_general && !env.degenerate && sc->gapo >= 0 && sc->gape >= 0 && zm >= 0 &&
                    zm <= 127 && zx >= 0 && zx <= 127;
     if (env.lane_ok) {
@@ -394,10 +421,14 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   cut.reset();
   {
     const char *msg = nullptr;
-    static const int max_planners = [] {
+    // Planning threads of a context: SDF_PLAN_THREADS, else every CPU the process may use but this thread's when the
+    // context is the only one of the process (the scan of a million tasks is CPU-bound: 1.7 ms on eight threads, 0.86 ms on
+    // sixteen), seven when there are several (the stage driver's lanes share the machine).
+    static const int env_planners = [] {
       const char *e = getenv("SDF_PLAN_THREADS");
-      return e ? std::max(0, std::min(15, atoi(e))) : 7;
+      return e ? std::max(0, std::min(15, atoi(e))) : -1;
     }();
+    const int max_planners = env_planners >= 0 ? env_planners : g_live_contexts.load() > 1 ? 7 : std::max(1, std::min(15, usable_cpus() - 1));
     // (parked threads plan the chunks of batches of 120,000 tasks and more -- 250,000 tasks of the hg19 mixture:
     // 14.5 -> 10.1 ms, the headline batch unchanged -- and from 400,000 tasks the scan of the cut as well: there, below,
     // waking them cost more than they saved)
@@ -406,45 +437,102 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
       return e ? (size_t)atoll(e) : (size_t)120000;
     }();
     if (!ctx->pool && n >= pool_from && max_planners > 0 && !ctx->is_part) ctx->pool = new WorkerPool(max_planners);
-    if (int rc = cut_batch(env, ctx->pipeline, ctx->ws_budget, cut, &msg, ctx->pool)) {
-      ctx->err = msg ? msg : "invalid batch";
-      return rc;
-    }
   }
   run.cut = &cut;
+  static const bool dbg_plan_chunks = getenv("SDF_DEBUG_PLAN") != nullptr;
+
+  // ---- buffers and the start of the call on the device: once with upper bounds, before the early start of the heavy
+  // chunks (while the batch is still being read), and / or with the cut's sums ----
+  bool begun = false;
+  auto prepare = [&](const bool early) -> int {
+    const size_t lane_need = cut.use_lane ? ((cut.lane_dir_bytes + 255) & ~(size_t)255) : 0;
+    // (heavy tasks' slice first: it stays where it is when the workspace has to grow after the early start -- an
+    // outgrown buffer is retired, not freed -- and the chunks launched by then keep their pointer)
+    const size_t dir_bytes = early ? cut.heavy_need : cut.heavy_need + cut.region_need * cut.nreg_ws + lane_need;
+    if (ctx->dir_ws.reserve(std::max<size_t>(dir_bytes, 256)) != hipSuccess) {
+      ctx->err = "cannot allocate the direction-matrix workspace";
+      (void)hipGetLastError();
+      return SDF_ERR_NOMEM;
+    }
+    const size_t n_lane = cut.use_lane ? cut.n_lane : 0;
+    const size_t np = early ? n : std::max<size_t>(cut.ntask_total, 1);
+    const size_t np_dev = early ? n : np + n_lane;
+    const int64_t words = early ? cut.stage_upper : cut.stage_total + (cut.use_lane ? cut.lane_stage_words : 0);
+    const size_t nord = early ? std::max<size_t>(cut.order_upper, 2) : std::max<size_t>(cut.order_total, 2);
+    SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(words, 4) * 4));
+    SDF_HIP(ctx->plan_buf.reserve(np_dev * sizeof(PlanTask)));
+    SDF_HIP(ctx->order_buf.reserve(nord * sizeof(int32_t)));
+    SDF_HIP(ctx->misc_buf.reserve(SDF_MISC_PARTS * 8 + ((std::max(n, n_scan) + 1023) / 1024 + 1) * 8));
+    SDF_HIP(ctx->host_plan.reserve(np * sizeof(PlanTask)));
+    SDF_HIP(ctx->host_order.reserve(nord * sizeof(int32_t)));
+    if (begun && (run.plan != (PlanTask *)ctx->host_plan.p || run.order != (int32_t *)ctx->host_order.p ||
+                  run.d_plan != (PlanTask *)ctx->plan_buf.p || run.d_order != (int32_t *)ctx->order_buf.p ||
+                  run.d_stage != (uint32_t *)ctx->stage_ws.p)) {
+      ctx->err = "internal: a buffer sized by its upper bound had to grow after the early start";
+      return SDF_ERR_INVALID;
+    }
+    run.plan = (PlanTask *)ctx->host_plan.p;  // pinned: the uploads are asynchronous
+    run.order = (int32_t *)ctx->host_order.p;
+    run.d_plan = (PlanTask *)ctx->plan_buf.p;
+    run.d_order = (int32_t *)ctx->order_buf.p;
+    run.d_dir = (uint8_t *)ctx->dir_ws.p;
+    run.d_stage = (uint32_t *)ctx->stage_ws.p;
+    if (!begun) {
+      run.heavy_dir = run.d_dir;
+      SDF_HIP(hipMemsetAsync((unsigned long long *)ctx->misc_buf.p + 1, 0, sizeof(unsigned long long), st));
+      run.ev_begin = next_event(ctx, run.evc);
+      hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n);
+      SDF_HIP(hipEventRecord(run.ev_begin, st));
+      // (the internal streams are ordered behind ev_begin by launch_chunk, each before its first use in this call)
+      begun = true;
+    }
+    return SDF_OK;
+  };
+  // the early start: plan and launch the heavy chunks (cut.chunks at that moment) on this thread
+  PlanScratch early_scratch;
+  const std::function<int()> early = [&]() -> int {
+    if (int prc = prepare(true)) return prc;
+    run.have_heavy = true;
+    run.more_chunks = true;
+    run.cev.assign(cut.chunks.size(), ChunkEv{});
+    for (size_t ci = 0; ci < cut.chunks.size(); ++ci) {
+      ChunkPlan &c = cut.chunks[ci];
+      plan_chunk(env, cut, c, run.plan, run.order, early_scratch);
+      if (ci == 0) ctx->ms[4] = host_ms();
+      if (c.err) {
+        ctx->err = c.err;
+        return SDF_ERR_INVALID;
+      }
+      ctx->paired += c.paired;
+      const float tw = host_ms();
+      if (int lrc = launch_chunk(run, ci)) return lrc;
+      if (dbg_plan_chunks) fprintf(stderr, "[chunk %zu: %zu tasks (heavy, early) planned by %.2f ms, launched by %.2f ms]\n", ci, c.cnt, tw, host_ms());
+      cut.n_early = ci + 1;
+    }
+    return SDF_OK;
+  };
+  {
+    const char *msg = nullptr;
+    static const bool early_on = [] {
+      const char *e = getenv("SDF_EARLY_HEAVY");  // (0: the heavy chunks wait for the whole cut, as every other chunk)
+      return !(e && e[0] == '0');
+    }();
+    const int crc = cut_batch(env, ctx->pipeline, ctx->ws_budget, cut, &msg, ctx->pool, early_on && !ctx->is_part ? &early : nullptr);
+    run.more_chunks = false;
+    if (crc) {
+      if (ctx->err.empty()) ctx->err = msg ? msg : "invalid batch";
+      if (begun) drain_streams(ctx, st);
+      return crc;
+    }
+  }
   run.have_heavy = !cut.chunks.empty() && cut.chunks[0].heavy;
   const float dbg_a = host_ms();
-
-  // ---- buffers ----
-  const size_t lane_need = cut.use_lane ? ((cut.lane_dir_bytes + 255) & ~(size_t)255) : 0;
-  if (ctx->dir_ws.reserve(cut.region_need * cut.nreg_ws + cut.heavy_need + lane_need) != hipSuccess) {
-    ctx->err = "cannot allocate the direction-matrix workspace";
-    (void)hipGetLastError();
-    return SDF_ERR_NOMEM;
+  if (int prc = prepare(false)) {
+    if (cut.n_early) drain_streams(ctx, st);
+    return prc;
   }
-  const size_t np = std::max<size_t>(cut.ntask_total, 1);
-  const size_t n_lane = cut.use_lane ? cut.n_lane : 0;
-  SDF_HIP(ctx->stage_ws.reserve((size_t)std::max<int64_t>(cut.stage_total + (cut.use_lane ? cut.lane_stage_words : 0), 4) * 4));
-  SDF_HIP(ctx->plan_buf.reserve((np + n_lane) * sizeof(PlanTask)));
-  const size_t nord = std::max<size_t>(cut.order_total, 2);
-  SDF_HIP(ctx->order_buf.reserve(nord * sizeof(int32_t)));
-  SDF_HIP(ctx->misc_buf.reserve(SDF_MISC_PARTS * 8 + ((std::max(n, n_scan) + 1023) / 1024 + 1) * 8));
-  SDF_HIP(ctx->host_plan.reserve(np * sizeof(PlanTask)));
-  SDF_HIP(ctx->host_order.reserve(nord * sizeof(int32_t)));
-  run.plan = (PlanTask *)ctx->host_plan.p;  // pinned: the uploads are asynchronous
-  run.order = (int32_t *)ctx->host_order.p;
-  run.d_plan = (PlanTask *)ctx->plan_buf.p;
-  run.d_order = (int32_t *)ctx->order_buf.p;
-  run.d_dir = (uint8_t *)ctx->dir_ws.p;
-  run.d_stage = (uint32_t *)ctx->stage_ws.p;
-  run.cev.assign(cut.chunks.size(), ChunkEv{});
+  run.cev.resize(cut.chunks.size(), ChunkEv{});
   const float dbg_b = host_ms();
-
-  SDF_HIP(hipMemsetAsync((unsigned long long *)ctx->misc_buf.p + 1, 0, sizeof(unsigned long long), st));
-  run.ev_begin = next_event(ctx, run.evc);
-  hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n);
-  SDF_HIP(hipEventRecord(run.ev_begin, st));
-  // (the internal streams are ordered behind ev_begin by launch_chunk, each before its first use in this call)
   if (cut.use_lane)
     if (int lrc = launch_lane(run, n)) {
       drain_streams(ctx, st);
@@ -452,7 +540,6 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     }
 
   // ---- plan (worker threads, chunk order) and launch (this thread, chunk order) ----
-  static const bool dbg_plan_chunks = getenv("SDF_DEBUG_PLAN") != nullptr;
   int rc = SDF_OK;
   float dbg_c = 0.f;
   {
@@ -461,9 +548,9 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     const int nthr = ctx->pool && cut.chunks.size() >= 3
                          ? (int)std::min<size_t>(ctx->pool->size(), cut.chunks.size())
                          : 0;
-    ChunkPlanner planner(env, cut, run.plan, run.order, ctx->pool, nthr);
+    ChunkPlanner planner(env, cut, run.plan, run.order, ctx->pool, nthr, cut.n_early);
     dbg_c = host_ms();
-    for (size_t ci = 0; ci < cut.chunks.size() && rc == SDF_OK; ++ci) {
+    for (size_t ci = cut.n_early; ci < cut.chunks.size() && rc == SDF_OK; ++ci) {
       planner.wait(ci);
       if (ci == 0) ctx->ms[4] = host_ms();
       const ChunkPlan &c = cut.chunks[ci];
@@ -538,6 +625,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         ctx->part_ctx->strip_enabled = ctx->strip_enabled;
         ctx->part_ctx->strip_always = ctx->strip_always;
         ctx->part_ctx->strip_cols = ctx->strip_cols;
+        ctx->part_ctx->chain_min = ctx->chain_min;
       }
     }
     if (sdf_ctx *pc = ctx->part_ctx) {

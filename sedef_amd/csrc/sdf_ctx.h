@@ -264,6 +264,7 @@ struct sdf_ctx {
                                // stripe kernel (extz2_bstripe.hip); 0: never
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   size_t self_pair_max = 512;  // SDF_SELF_PAIR_MAX: see PlanEnv
+  size_t chain_min = 3072;     // SDF_CHAIN_MIN: see PlanEnv
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
   int stripe_spin_cap = 1 << 24;  // SDF_STRIPE_SPIN_CAP: polls before a stripe's wait gives its task up (extz2_stripe.hip)
   sdf_ctx *part_ctx = nullptr;    // second context of this device: the first part of a very large batch (sdf_api.hip)

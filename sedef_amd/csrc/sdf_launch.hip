@@ -33,6 +33,8 @@ struct BatchRun {
   PlanTask *plan = nullptr, *d_plan = nullptr;  // pinned host copy / device copy
   int32_t *order = nullptr, *d_order = nullptr;
   uint8_t *d_dir = nullptr;
+  uint8_t *heavy_dir = nullptr;  // the heavy chunks' slice (the workspace as it was when they were launched)
+  bool more_chunks = false;      // early start: chunks of ordinary tasks will follow those in cut->chunks
   uint32_t *d_stage = nullptr;
   const BatchCut *cut = nullptr;
   bool want_cigar = false, have_heavy = false;
@@ -189,7 +191,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   const bool pipelined = cut.pipelined, heavy_chunk = c.heavy;
   const bool piped = pipelined && !heavy_chunk;
   const size_t nj = run.normal_ids.size();  // ordinal among the ordinary chunks
-  const size_t nchunks = cut.chunks.size();
+  const size_t nchunks = cut.chunks.size() + (run.more_chunks ? 1 : 0);
   if (pipelined) {
     // extra streams, created the first time they are wanted (a stream is a hardware queue: ~7 ms to set up): launches of
     // few tasks last as long as their longest task whatever else runs, so the more of them run side by side the better
@@ -226,7 +228,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   // (the tracebacks of consecutive ordinary chunks alternate between two streams: the last one starts when its DP
   // ends, not when the previous chunk's walk does)
   hipStream_t stb = piped ? ((nj & 1) && ctx->aux_stream[2] ? ctx->aux_stream[2] : Q[3]) : Q[0];
-  uint8_t *dir_reg = heavy_chunk ? run.d_dir + cut.nreg_ws * cut.region_need : run.d_dir + (nj % cut.nreg_ws) * cut.region_need;
+  uint8_t *dir_reg = heavy_chunk ? run.heavy_dir : run.d_dir + cut.heavy_need + (nj % cut.nreg_ws) * cut.region_need;
   hipEvent_t region_ev = nullptr;  // the region's previous user has been traced back
   if (piped && nj >= cut.nreg_ws) region_ev = run.cev[run.normal_ids[nj - cut.nreg_ws]].tb1;
   if (!heavy_chunk) run.normal_ids.push_back(ci);
@@ -470,7 +472,7 @@ static int launch_lane(BatchRun &run, size_t n) {
   SDF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->ln_tmp.p, tb, dirb, dir_off, (int)nl, sl));
   // plan records behind the host-planned ones; staging slots behind theirs; flags in the slice behind the heavy tasks'
   PlanTask *lp = run.d_plan + cut.ntask_total;
-  const int64_t dir0 = (int64_t)(cut.nreg_ws * cut.region_need + cut.heavy_need);
+  const int64_t dir0 = (int64_t)(cut.heavy_need + cut.nreg_ws * cut.region_need);
   hipLaunchKernelGGL(lane_plan_kernel, gl, dim3(256), 0, sl, d_recs, v_out, (int)nl, cap_off, dir_off, cut.stage_total, dir0, lp);
   size_t pos = 0;
   for (int c = 0; c < 4; ++c) {  // (sorted by class first: the classes are consecutive ranges)

@@ -35,6 +35,7 @@ struct PlanEnv {
   bool strip_ok = false;    // strip kernel (extz2_strip.hip): the scoring is tame
   bool strip_always = false;  // SDF_STRIP_ALWAYS=1 (tests): ... whatever the number of tasks
   int strip_cols = 0;         // SDF_STRIP_COLS (tests): columns per lane of the chained strips
+  size_t chain_min = 3072;    // chain wavefronts a chunk must hold for the chained strips (SDF_CHAIN_MIN)
   bool lane_ok = false;     // the scoring is tame and only CIGAR / score / mte are wanted
   size_t lane_min = 8192;
   LaneRec *lane_recs = nullptr;  // pinned, one per task of the batch: filled by the scan
@@ -101,6 +102,9 @@ struct BatchCut {
     ntask_total = 0;
     order_total = 0;
     use_lane = false;
+    n_early = 0;
+    stage_upper = 0;
+    order_upper = 0;
     n_lane = 0;
     lane_stage_words = 0;
     lane_dir_bytes = 0;
@@ -118,6 +122,11 @@ struct BatchCut {
   int64_t stage_total = 0;
   size_t ntask_total = 0;
   size_t order_total = 0;
+  // early start (cut_batch's `early` callback): the heavy chunks are cut after a first pass over the BIG tasks only and
+  // handed to the caller -- which plans and launches them -- while the pass over the rest of the batch runs
+  size_t n_early = 0;         // chunks of `chunks` (its first ones, all heavy) that the callback has launched
+  int64_t stage_upper = 0;    // upper bound of stage_total + the lane tasks' words, known after the first pass
+  size_t order_upper = 0;     // upper bound of order_total
 };
 
 namespace plan_detail {
@@ -156,8 +165,12 @@ struct PlanScratch {
 };
 
 // Returns SDF_OK or an error code with *err set.
+// `early` (optional): called once the heavy chunks are known -- cut.chunks holds them, with their bases; cut.heavy_need,
+// stage_upper, order_upper are set -- while the rest of the batch is still being read: it plans and launches them and
+// sets cut.n_early (batches of 400,000 tasks and more on a context with planning threads: the long tasks of a batch are
+// the launch that ends it, and the pass over a million task records is 1-2 ms it need not wait for).
 static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget, BatchCut &cut, const char **err,
-                     WorkerPool *pool = nullptr) {
+                     WorkerPool *pool = nullptr, const std::function<int()> *early = nullptr) {
   const sdf_task *tasks = env.tasks;
   const size_t n = env.n;
   // The batch is cut into chunks that are planned, uploaded and launched one after the other: while the GPU runs
@@ -200,7 +213,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   // writes both words of every task, runnable or not)
   if (bound.size() < n) bound.resize(n);
   if (cap.size() < n) cap.resize(n);
-  size_t heavy_bytes = 0;
+  size_t heavy_bytes = 0, heavy_budget = 0;
+  std::vector<ChunkPlan> heavy_chunks;
   std::vector<uint32_t> (&hparts)[16] = cut.hparts;
   for (auto &hp : hparts) hp.clear();
   const size_t nblk = (n + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK;
@@ -216,11 +230,13 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     struct Part {
       size_t nh = 0, hb = 0;
       bool bad = false;
+      int64_t words = 0;       // first pass: q + t + 2 of every task, the big tasks' launch-order entries, their number
+      size_t big_oc = 0, nbig = 0;
     };
     const size_t hv_limit = n / 4 + 1;
     // what a task needs of the chunks' budgets -- flag bytes whichever window kernel takes it, staging words, launch-order
     // entries -- into its block's sums
-    auto account = [&](size_t k, Part &pt, std::vector<uint32_t> &hv) {
+    auto account = [&](size_t k, Part &pt, std::vector<uint32_t> &hv, const bool may_be_heavy = true) {
       const sdf_task &t = tasks[k];
       BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
       cap[k] = 0x80000000u;
@@ -264,7 +280,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
                                (size_t)(t.qlen - t.qlen / 5 + 100) * 520 + 512 + 255) & ~(size_t)255);
       bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
       blk.bd += (uint64_t)bound[k] << 8;
-      if (bd >= heavy_min) {
+      if (bd >= heavy_min && may_be_heavy) {
         ++pt.nh;
         pt.hb += bd;
         ++blk.hnt;
@@ -274,9 +290,23 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         if (pt.nh <= hv_limit) hv.push_back((uint32_t)k);  // (beyond a quarter of the batch there is no split)
       }
     };
-    auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv) {  // (lo: a multiple of the block size)
+    // mode 0: every task; 1: the big tasks only (and the sums of the early start); 2: the others, none of them heavy
+    // (big: everything a stripe / strip kernel may take -- more than 256 target bases --, and from 40,000 cells or 1,000
+    // anti-diagonals; the others have two launch-order entries and no direction-flag bound near heavy_min)
+    auto is_big = [](const sdf_task &t) {
+      return t.tlen > 256 || (int64_t)t.qlen * t.tlen >= 40000 || (int64_t)t.qlen + t.tlen >= 1000;
+    };
+    auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv, const int mode) {  // (lo: a multiple of the block size)
       for (size_t k = lo; k < hi; ++k) {
         const sdf_task &t = tasks[k];
+        if (mode == 1) {
+          pt.words += (int64_t)t.qlen + t.tlen + 2;
+          if (!is_big(t)) continue;
+          ++pt.nbig;
+          pt.big_oc += order_entries(t);
+        } else if (mode == 2 && is_big(t)) {
+          continue;
+        }
         if (t.flag & 0x300) {  // (not KSW_EZ_* bits of the extz2 kernel)
           pt.bad = true;
           return;
@@ -310,7 +340,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           ++blk.lcls[lane_class(t.qlen)];
           continue;
         }
-        account(k, pt, hv);
+        account(k, pt, hv, mode != 2);
       }
     };
     // (on the context's parked planning threads when there are any; this thread takes a share too)
@@ -324,19 +354,118 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     struct Share {
       std::atomic<size_t> next{0}, done{0};
     };
-    auto share = std::make_shared<Share>();  // (outlives this call: a helper may wake up after everything is done)
     const size_t run_blocks = 16, nrun = (nblk + run_blocks - 1) / run_blocks;  // (runs of 1 / 2 / 4 blocks: 3.3-4.0 / 2.0-2.7 / 1.8-2.5 ms
                                                                                 // per million tasks against 1.3-2.1)
-    auto work = [&, share, nrun](int q) {  // (touches nothing of this frame once the runs are handed out)
-      for (size_t ru = share->next.fetch_add(1); ru < nrun; ru = share->next.fetch_add(1)) {
-        if (!parts[q].bad)
-          scan(ru * run_blocks * SDF_CUT_BLOCK, std::min(n, (ru + 1) * run_blocks * SDF_CUT_BLOCK), parts[q], hparts[q]);
-        share->done.fetch_add(1);
-      }
+    // one pass over the batch in `mode` (see scan); `meanwhile`: what this thread does first, while the helpers read
+    auto run_pass = [&](const int mode, const std::function<void()> *meanwhile) {
+      auto share = std::make_shared<Share>();  // (outlives this call: a helper may wake up after everything is done)
+      auto work = [&, share, nrun, mode](int q) {  // (touches nothing of this frame once the runs are handed out)
+        for (size_t ru = share->next.fetch_add(1); ru < nrun; ru = share->next.fetch_add(1)) {
+          if (!parts[q].bad)
+            scan(ru * run_blocks * SDF_CUT_BLOCK, std::min(n, (ru + 1) * run_blocks * SDF_CUT_BLOCK), parts[q], hparts[q], mode);
+          share->done.fetch_add(1);
+        }
+      };
+      for (int q = 1; q < nthr; ++q) pool->submit([work, q] { work(q); });
+      if (meanwhile) (*meanwhile)();
+      work(0);
+      while (share->done.load() < nrun) std::this_thread::yield();  // (a helper still inside its last run)
     };
-    for (int q = 1; q < nthr; ++q) pool->submit([work, q] { work(q); });
-    work(0);
-    while (share->done.load() < nrun) std::this_thread::yield();  // (a helper still inside its last run)
+    // Heavy tasks leave the chunk rotation when they are a minority: they are planned and launched FIRST, all together
+    // (a launch of few long tasks lasts as long as its longest task: one such launch per kernel, not one per chunk), with
+    // a workspace slice of their own, and run next to the chunks of ordinary tasks.
+    auto cut_heavy = [&]() {  // (after the pass that finds them)
+      for (int q = 0; q < nthr; ++q) {
+        cut.n_heavy += parts[q].nh;
+        heavy_bytes += parts[q].hb;
+      }
+      cut.split_heavy = cut.pipelined && cut.n_heavy * 4 <= n;
+      heavy_budget = cut.split_heavy && cut.n_heavy ? std::min(heavy_bytes + 256, ws_budget / 2) : 0;
+      cut.heavy.assign(cut.split_heavy ? n : 0, 0);
+      if (!cut.split_heavy) return;
+      // heavy chunks: ranges of the (ascending) list of heavy tasks
+      for (auto &hp : hparts) cut.heavy_idx.insert(cut.heavy_idx.end(), hp.begin(), hp.end());
+      std::sort(cut.heavy_idx.begin(), cut.heavy_idx.end());  // (the scan threads took their runs of blocks in any order)
+      ChunkPlan hcur;
+      hcur.heavy = true;
+      size_t hacc = 0;
+      for (size_t pos = 0; pos < cut.heavy_idx.size(); ++pos) {
+        if (pos + 16 < cut.heavy_idx.size()) {  // (the heavy tasks lie scattered over the batch: a cache miss each)
+          const uint32_t kn = cut.heavy_idx[pos + 16];
+          __builtin_prefetch(&tasks[kn]);
+          __builtin_prefetch(&bound[kn]);
+          __builtin_prefetch(&cap[kn]);
+        }
+        const uint32_t k = cut.heavy_idx[pos];
+        const size_t bd = (size_t)bound[k] << 8;
+        cut.heavy[k] = 1;
+        if (pos > hcur.s && hacc + bd > heavy_budget) {
+          hcur.e = pos;
+          heavy_chunks.push_back(hcur);
+          cut.heavy_need = std::max(cut.heavy_need, hacc);
+          hcur = ChunkPlan();
+          hcur.heavy = true;
+          hcur.s = pos;
+          hacc = 0;
+        }
+        hacc += bd;
+        ++hcur.ntask;
+        hcur.stage_words += cap[k] & 0x7fffffffu;
+        hcur.order_cap += order_entries(tasks[k]);
+      }
+      if (!cut.heavy_idx.empty()) {
+        hcur.e = cut.heavy_idx.size();
+        heavy_chunks.push_back(hcur);
+        cut.heavy_need = std::max(cut.heavy_need, hacc);
+      }
+      cut.heavy_need = (cut.heavy_need + 255) & ~(size_t)255;
+    };
+    auto any_bad = [&]() {
+      for (int q = 0; q < nthr; ++q)
+        if (parts[q].bad) return true;
+      return false;
+    };
+    const bool two_pass = early && *early && nthr > 1 && cut.pipelined;
+    int early_rc = SDF_OK;
+    if (two_pass) {
+      run_pass(1, nullptr);
+      if (any_bad()) {
+        *err = "unknown task flag";
+        return SDF_ERR_UNSUPPORTED;
+      }
+      size_t nbig = 0, big_oc = 0;
+      for (int q = 0; q < nthr; ++q) {
+        cut.stage_upper += parts[q].words;
+        nbig += parts[q].nbig;
+        big_oc += parts[q].big_oc;
+      }
+      cut.order_upper = big_oc + 2 * (n - nbig) + 64;
+      cut_heavy();
+      for (int q = 0; q < nthr; ++q) parts[q].nh = parts[q].hb = 0;
+      const std::function<void()> start = [&]() {
+        if (!cut.split_heavy || heavy_chunks.empty()) return;
+        cut.chunks = heavy_chunks;  // (their bases: heavy chunks come first)
+        size_t pb = 0, ob = 0;
+        int64_t stage = 0;
+        for (ChunkPlan &c : cut.chunks) {
+          c.pb = pb;
+          c.ob = ob;
+          c.stage0 = stage;
+          pb += c.ntask;
+          ob += c.order_cap;
+          stage += c.stage_words;
+        }
+        early_rc = (*early)();
+        for (size_t q = 0; q < heavy_chunks.size() && q < cut.chunks.size(); ++q) heavy_chunks[q] = cut.chunks[q];  // (planned)
+      };
+      run_pass(2, &start);
+    } else {
+      run_pass(0, nullptr);
+    }
+    if (early_rc != SDF_OK) {
+      *err = "early start of the heavy chunks failed";
+      return early_rc;
+    }
     if (lane_scan) {
       for (const BatchCut::Block &blk : cut.blocks) {
         cut.n_lane += blk.lnt;
@@ -350,68 +479,23 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         for (size_t k = 0; k < n; ++k)
           if (cut.lane[k]) {
             cut.lane[k] = 0;
-            account(k, parts[0], hparts[0]);
+            account(k, parts[0], hparts[0], !two_pass);
           }
         cut.n_lane = 0;
       }
     }
-    for (int q = 0; q < nthr; ++q) {
-      if (parts[q].bad) {
-        *err = "unknown task flag";
-        return SDF_ERR_UNSUPPORTED;
-      }
-      cut.n_heavy += parts[q].nh;
-      heavy_bytes += parts[q].hb;
+    if (any_bad()) {
+      *err = "unknown task flag";
+      return SDF_ERR_UNSUPPORTED;
     }
+    if (!two_pass) cut_heavy();
   }
   const auto tc1 = std::chrono::steady_clock::now();
-  // Heavy tasks leave the chunk rotation when they are a minority: they are planned and launched FIRST, all together
-  // (a launch of few long tasks lasts as long as its longest task: one such launch per kernel, not one per chunk), with
-  // a workspace slice of their own, and run next to the chunks of ordinary tasks.
-  cut.split_heavy = cut.pipelined && cut.n_heavy * 4 <= n;
-  const size_t heavy_budget = cut.split_heavy && cut.n_heavy ? std::min(heavy_bytes + 256, ws_budget / 2) : 0;
   const size_t lane_budget = cut.use_lane ? cut.lane_dir_bytes + 256 : 0;
   const size_t region_budget = (ws_budget - heavy_budget - lane_budget) / cut.max_regions;
-  cut.heavy.assign(cut.split_heavy ? n : 0, 0);
 
   // ---- chunk boundaries ----
-  std::vector<ChunkPlan> normal, heavy_chunks;
-  if (cut.split_heavy) {  // heavy chunks: ranges of the (ascending) list of heavy tasks
-    for (auto &hp : hparts) cut.heavy_idx.insert(cut.heavy_idx.end(), hp.begin(), hp.end());
-    std::sort(cut.heavy_idx.begin(), cut.heavy_idx.end());  // (the scan threads took their runs of blocks in any order)
-    ChunkPlan hcur;
-    hcur.heavy = true;
-    size_t hacc = 0;
-    for (size_t pos = 0; pos < cut.heavy_idx.size(); ++pos) {
-      if (pos + 16 < cut.heavy_idx.size()) {  // (the heavy tasks lie scattered over the batch: a cache miss each)
-        const uint32_t kn = cut.heavy_idx[pos + 16];
-        __builtin_prefetch(&tasks[kn]);
-        __builtin_prefetch(&bound[kn]);
-        __builtin_prefetch(&cap[kn]);
-      }
-      const uint32_t k = cut.heavy_idx[pos];
-      const size_t bd = (size_t)bound[k] << 8;
-      cut.heavy[k] = 1;
-      if (pos > hcur.s && hacc + bd > heavy_budget) {
-        hcur.e = pos;
-        heavy_chunks.push_back(hcur);
-        cut.heavy_need = std::max(cut.heavy_need, hacc);
-        hcur = ChunkPlan();
-        hcur.heavy = true;
-        hcur.s = pos;
-        hacc = 0;
-      }
-      hacc += bd;
-      ++hcur.ntask;
-      hcur.stage_words += cap[k] & 0x7fffffffu;
-      hcur.order_cap += order_entries(tasks[k]);
-    }
-    if (!cut.heavy_idx.empty()) {
-      hcur.e = cut.heavy_idx.size();
-      heavy_chunks.push_back(hcur);
-      cut.heavy_need = std::max(cut.heavy_need, hacc);
-    }
-  }
+  std::vector<ChunkPlan> normal;
   {
     // whole blocks of tasks at a time (their sums come from the scan above); task by task only inside a block that
     // does not fit the region as a whole
@@ -516,7 +600,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       else w10 += (size_t)strip_blocks(t.tlen, 8);
     }
     use_strip = force || n9 >= 1024;
-    use_chain = force || w10 / 2 >= 3072;
+    use_chain = force || w10 / 2 >= env.chain_min;
   }
   for (size_t pos = c.s; pos < c.e; ++pos) {
     if (c.heavy && pos + 16 < c.e) __builtin_prefetch(&tasks[cut.heavy_idx[pos + 16]]);
