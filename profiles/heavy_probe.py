@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 (pool, q_off, qlen, t_off, tlen), w = bench.synth_hg19_mixture_fast(n, seed=404, big=6000)
 eng = sedef_amd.Extz2Engine(0, 64 << 30)
 for name, sel in (("stripe tasks (>= 1200)", qlen >= 1200), ("600..1000", (qlen >= 600) & (qlen < 1200)),
-                  ("500 x ~500", qlen == 500), ("ordinary (< 500)", qlen < 500), ("all", qlen > 0)):
+                  ("500 x ~500", qlen == 500), ("long + 500 x ~500", qlen >= 500), ("ordinary (< 500)", qlen < 500), ("all", qlen > 0)):
     idx = np.flatnonzero(sel)
     b = (pool, q_off[idx], qlen[idx], t_off[idx], tlen[idx])
     shapes_bench.run(name, b, w, eng, dev, steps=3)

@@ -87,11 +87,11 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
                                                               uint8_t *__restrict__ dirbase,
                                                               sdf_result *__restrict__ res,
                                                               unsigned long long *__restrict__ gave_up,
-                                                              const int spin_cap) {
+                                                              const int spin_cap, unsigned *__restrict__ claim) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;
   constexpr int KT = NREG - 1;
-  const int32_t entry = order[blockIdx.x];
+  const int32_t entry = stripe_claim(order, claim);
   const PlanTask tk = plan[entry & 0xffffff];
   const int lane = threadIdx.x;
   const int sb = (int)((uint32_t)entry >> 24);
@@ -749,11 +749,11 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
 }
 
 template __global__ void extz2_bstripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                 sdf_result *, unsigned long long *, int);
+                                                 sdf_result *, unsigned long long *, int, unsigned *);
 template __global__ void extz2_bstripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                 sdf_result *, unsigned long long *, int);
+                                                 sdf_result *, unsigned long long *, int, unsigned *);
 template __global__ void extz2_bstripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                 sdf_result *, unsigned long long *, int);
+                                                 sdf_result *, unsigned long long *, int, unsigned *);
 
 // Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's record and the edge column of its
 // right boundary to zero (no word tagged as written)

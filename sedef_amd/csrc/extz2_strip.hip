@@ -338,8 +338,9 @@ template <int C>
 __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
                                                                const uint32_t *__restrict__ pool, ScoreK sc,
                                                                uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res,
-                                                               unsigned long long *__restrict__ gave_up, const int spin_cap) {
-  const int32_t entry = order[blockIdx.x];
+                                                               unsigned long long *__restrict__ gave_up, const int spin_cap,
+                                                               unsigned *__restrict__ claim) {
+  const int32_t entry = stripe_claim(order, claim);
   const int blk = (int)((uint32_t)entry >> 24);
   const int ia = entry & 0xffffff;
   const PlanTask tka = plan[ia];
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
 }
 
 template __global__ void extz2_strip_chain_kernel<8>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                     sdf_result *, unsigned long long *, int);
+                                                     sdf_result *, unsigned long long *, int, unsigned *);
 template __global__ void extz2_strip_chain_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                     sdf_result *, unsigned long long *, int);
+                                                     sdf_result *, unsigned long long *, int, unsigned *);
 
 }  // namespace sdf

@@ -83,17 +83,42 @@ __device__ __forceinline__ bool stripe_abandoned(const sdf_result *rec) {
   return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&rec->n_cigar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == -1;
 }
 
+// A workgroup's entry of the launch order.  The planner deals a launch's tasks to eight lists -- order[8 p + q] is entry p of
+// list q -- so that the stripes of a task share an XCD's L2 (their edge words) and every stripe's left neighbour stands
+// earlier in its list.  With `claim` (eight counters, zero at launch) a workgroup TAKES the next entry of the list of the
+// XCD it finds itself on (HW_REG_XCC_ID), or of the next list that has one left: whatever the dispatcher does -- other
+// launches' workgroups in between, another start XCD --, a task's stripes meet in one L2, and the neighbour a stripe waits
+// for has been taken before it, by a workgroup that is running or done (forward progress no longer rests on the dispatch
+// order).  Without `claim`: entry blockIdx.x, which is the same thing when workgroup i lands on XCD i mod 8.
+__device__ __forceinline__ int32_t stripe_claim(const int32_t *__restrict__ order, unsigned *__restrict__ claim) {
+  if (!claim) return order[blockIdx.x];
+  int32_t entry = (int32_t)(255u << 24);  // (idle)
+  if (threadIdx.x == 0) {
+    const unsigned per_list = gridDim.x / 8;
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID, bits 3:0
+    for (unsigned a = 0; a < 8; ++a) {
+      const unsigned q = (xcc + a) & 7u;
+      const unsigned p = atomicAdd(&claim[q], 1u);
+      if (p < per_list) {
+        entry = order[8 * p + q];
+        break;
+      }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(entry);  // (one-wavefront workgroups)
+}
+
 template <int NREG>
 __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__restrict__ plan,
                                                              const int32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ pool, ScoreK sc,
                                                              uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res,
                                                              const int rmax, unsigned long long *__restrict__ gave_up,
-                                                             const int spin_cap) {
+                                                             const int spin_cap, unsigned *__restrict__ claim) {
   extern __shared__ __align__(16) uint8_t lds[];
   constexpr int NSLOT = 128 * NREG;  // stripe width
   constexpr int KT = NREG - 1;
-  const int32_t entry = order[blockIdx.x];
+  const int32_t entry = stripe_claim(order, claim);
   const PlanTask tk = plan[entry & 0xffffff];
   const int lane = threadIdx.x;
   const int sb = (int)((uint32_t)entry >> 24);  // stripe of this wavefront
@@ -473,11 +498,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
 }
 
 template __global__ void extz2_stripe_kernel<1>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int, unsigned long long *, int);
+                                                sdf_result *, int, unsigned long long *, int, unsigned *);
 template __global__ void extz2_stripe_kernel<2>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int, unsigned long long *, int);
+                                                sdf_result *, int, unsigned long long *, int, unsigned *);
 template __global__ void extz2_stripe_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                sdf_result *, int, unsigned long long *, int);
+                                                sdf_result *, int, unsigned long long *, int, unsigned *);
 
 // Before the launch, one workgroup per launch-order entry (task, stripe): the stripe's progress and hand-over words to
 // "nothing done" and the edge column of its right boundary to zero (no word tagged as written)

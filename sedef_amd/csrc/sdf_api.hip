@@ -128,6 +128,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   ctx->force_general = fg && fg[0] == '1';
   const char *np = getenv("SDF_NO_PAIR");
   ctx->no_pair = np && np[0] == '1';
+  if (const char *e = getenv("SDF_STRIPE_CLAIM")) ctx->stripe_claim = e[0] != '0';  // (0: stripe workgroups take entry blockIdx.x)
   if (const char *e = getenv("SDF_CHAIN_MIN")) ctx->chain_min = (size_t)std::max(0ll, atoll(e));
   if (const char *e = getenv("SDF_SELF_PAIR_MAX")) ctx->self_pair_max = (size_t)std::max(0ll, atoll(e));
   if (const char *e = getenv("SDF_STATS_ITEMS")) ctx->stats_items = (unsigned)std::max(1, atoi(e));  // (tests: a list that overflows)
@@ -428,7 +429,15 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
       const char *e = getenv("SDF_PLAN_THREADS");
       return e ? std::max(0, std::min(15, atoi(e))) : -1;
     }();
-    const int max_planners = env_planners >= 0 ? env_planners : g_live_contexts.load() > 1 ? 7 : std::max(1, std::min(15, usable_cpus() - 1));
+    // (one process per GPU: the ranks of a node share its CPUs -- LOCAL_WORLD_SIZE / WORLD_SIZE as torch.distributed sets them)
+    static const int local_ranks = [] {
+      const char *e = getenv("LOCAL_WORLD_SIZE");
+      if (!e) e = getenv("WORLD_SIZE");
+      return e ? std::max(1, atoi(e)) : 1;
+    }();
+    const int max_planners = env_planners >= 0 ? env_planners
+                             : g_live_contexts.load() > 1 ? 7
+                                                          : std::max(1, std::min(15, usable_cpus() / local_ranks - 1));
     // (parked threads plan the chunks of batches of 120,000 tasks and more -- 250,000 tasks of the hg19 mixture:
     // 14.5 -> 10.1 ms, the headline batch unchanged -- and from 400,000 tasks the scan of the cut as well: there, below,
     // waking them cost more than they saved)
@@ -479,6 +488,8 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     run.d_stage = (uint32_t *)ctx->stage_ws.p;
     if (!begun) {
       run.heavy_dir = run.d_dir;
+      SDF_HIP(ctx->claim_buf.reserve(kClaimSets * 8 * sizeof(unsigned)));
+      SDF_HIP(hipMemsetAsync(ctx->claim_buf.p, 0, kClaimSets * 8 * sizeof(unsigned), st));
       SDF_HIP(hipMemsetAsync((unsigned long long *)ctx->misc_buf.p + 1, 0, sizeof(unsigned long long), st));
       run.ev_begin = next_event(ctx, run.evc);
       hipLaunchKernelGGL(reset_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_out, (int)n);

@@ -36,11 +36,11 @@ size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 bool pair_fits_whole(int qlen, int tlen, int nreg);
 template <int NREG>
 __global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                    sdf_result *, int, unsigned long long *, int);
+                                    sdf_result *, int, unsigned long long *, int, unsigned *);
 __global__ void stripe_sync_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 template <int NREG>
 __global__ void extz2_bstripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *,
-                                     unsigned long long *, int);
+                                     unsigned long long *, int, unsigned *);
 __global__ void bstripe_init_kernel(const PlanTask *, const int32_t *, int, uint8_t *);
 __global__ void bstripe_finish_kernel(const PlanTask *, const int32_t *, int, int, const uint8_t *, sdf_result *);
 struct LaneRec;
@@ -52,7 +52,7 @@ __global__ void extz2_lane_kernel(const PlanTask *, int, const uint32_t *, Score
 __global__ void extz2_strip_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
 template <int C>
 __global__ void extz2_strip_chain_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *,
-                                         unsigned long long *, int);
+                                         unsigned long long *, int, unsigned *);
 __global__ void strip_chain_init_kernel(const PlanTask *, const int32_t *, uint8_t *);
 template <int LAYOUT, int G>
 __global__ void traceback_kernel(const PlanTask *, int, const uint32_t *, const uint8_t *, sdf_result *, uint32_t *);
@@ -235,6 +235,7 @@ struct sdf_ctx {
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
   DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
   DevBuf st_tasks, st_pool, st_cig, st_out;  // sdf_stats_columns_batch
+  DevBuf claim_buf;                          // stripe launches: eight entry counters each (stripe_claim), zeroed per call
   DevBuf st_items;                           // sdf_stats_columns_device: segments of long alignments + their counter
   unsigned stats_items = 1u << 18;           // ... capacity of that list (SDF_STATS_ITEMS)
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
@@ -265,6 +266,7 @@ struct sdf_ctx {
   bool no_stripe = false;      // SDF_NO_STRIPE=1: wide full-band tasks stay on the general kernel (extz2_stripe.hip off)
   size_t self_pair_max = 512;  // SDF_SELF_PAIR_MAX: see PlanEnv
   size_t chain_min = 3072;     // SDF_CHAIN_MIN: see PlanEnv
+  bool stripe_claim = true;    // SDF_STRIPE_CLAIM=0: the stripe kernels' workgroups take launch-order entry blockIdx.x
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
   int stripe_spin_cap = 1 << 24;  // SDF_STRIPE_SPIN_CAP: polls before a stripe's wait gives its task up (extz2_stripe.hip)
   sdf_ctx *part_ctx = nullptr;    // second context of this device: the first part of a very large batch (sdf_api.hip)

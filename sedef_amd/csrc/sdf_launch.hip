@@ -23,6 +23,8 @@ struct ChunkEv {
                                                                          // stream; traceback (begin, end)
 };
 
+constexpr size_t kClaimSets = 2048;  // stripe launches per call that take their entries through counters (the rest by index)
+
 // Progress of one batch call on the device.
 struct BatchRun {
   sdf_ctx *ctx = nullptr;
@@ -34,6 +36,7 @@ struct BatchRun {
   int32_t *order = nullptr, *d_order = nullptr;
   uint8_t *d_dir = nullptr;
   uint8_t *heavy_dir = nullptr;  // the heavy chunks' slice (the workspace as it was when they were launched)
+  size_t claim_sets = 0;         // stripe launches of the call so far (each has eight entry counters in ctx->claim_buf)
   bool more_chunks = false;      // early start: chunks of ordinary tasks will follow those in cut->chunks
   uint32_t *d_stage = nullptr;
   const BatchCut *cut = nullptr;
@@ -48,6 +51,7 @@ struct BatchRun {
   const sdf_task *tasks = nullptr;
   uint32_t want = 0;
   hipEvent_t ev_lane = nullptr;  // the lane tasks' DP and traceback have finished
+  hipEvent_t ev_lane0 = nullptr;  // ... are about to start (debug timing)
   hipStream_t began[12] = {};  // internal streams already ordered behind ev_begin in this call
   size_t nbegan = 0;
 };
@@ -72,7 +76,7 @@ static void drain_streams(sdf_ctx *ctx, hipStream_t st) {
 // One DP launch of a planned class.  slabs: HBM state of the very long tasks (HBM-state classes only).
 static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, const int32_t *lo, const uint32_t *d_pool,
                       const ScoreK &sk, uint8_t *dir_reg, sdf_result *d_out, uint8_t *slabs, unsigned long long *gave_up,
-                      int spin_cap) {
+                      int spin_cap, unsigned *claim = nullptr) {
   const dim3 one((unsigned)L.cnt), half((unsigned)(L.cnt / 2));
 #define SDF_WAVE(N, S) \
   hipLaunchKernelGGL((extz2_wave_kernel<N, S>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
@@ -83,12 +87,12 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
 #define SDF_STRIPE(N) /* one workgroup of one wavefront per stripe; progress words and edge columns reset first */ \
   {                                                                                                              \
     hipLaunchKernelGGL(stripe_sync_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                      \
-    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax, gave_up, spin_cap); \
+    hipLaunchKernelGGL((extz2_stripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, L.rmax, gave_up, spin_cap, claim); \
   }
 #define SDF_BSTRIPE(N) /* banded stripes: records and edge columns reset first, the records merged afterwards */    \
   {                                                                                                               \
     hipLaunchKernelGGL(bstripe_init_kernel, one, dim3(64), 0, sdp, lp, lo, N, dir_reg);                           \
-    hipLaunchKernelGGL((extz2_bstripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap); \
+    hipLaunchKernelGGL((extz2_bstripe_kernel<N>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap, claim); \
     hipLaunchKernelGGL(bstripe_finish_kernel, dim3((unsigned)((L.cnt + 63) / 64)), dim3(64), 0, sdp, lp, lo,     \
                        (int)L.cnt, N, dir_reg, d_out);                                                            \
   }
@@ -127,11 +131,11 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 126: SDF_PAIR_TRACK(6); break;
     case 608: /* chained strips: edge columns and row-0 sums reset first */
       hipLaunchKernelGGL(strip_chain_init_kernel, one, dim3(64), 0, sdp, lp, lo, dir_reg);
-      hipLaunchKernelGGL(extz2_strip_chain_kernel<8>, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap);
+      hipLaunchKernelGGL(extz2_strip_chain_kernel<8>, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap, claim);
       break;
     case 604:
       hipLaunchKernelGGL(strip_chain_init_kernel, one, dim3(64), 0, sdp, lp, lo, dir_reg);
-      hipLaunchKernelGGL(extz2_strip_chain_kernel<4>, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap);
+      hipLaunchKernelGGL(extz2_strip_chain_kernel<4>, one, dim3(64), 0, sdp, lp, lo, d_pool, sk, dir_reg, d_out, gave_up, spin_cap, claim);
       break;
     case 500:
       hipLaunchKernelGGL(extz2_strip_kernel, half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);
@@ -293,8 +297,12 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       slabs = (uint8_t *)ctx->gstate_buf.p + gs_off;
       gs_off += L.lds * L.cnt;
     }
+    unsigned *claim = nullptr;  // a stripe launch's entry counters (stripe_claim): one set of eight per launch of the call
+    if (((L.bs >= 300 && L.bs < 500) || L.bs == 604 || L.bs == 608) && ctx->stripe_claim && L.cnt % 8 == 0 &&
+        run.claim_sets < kClaimSets)
+      claim = (unsigned *)ctx->claim_buf.p + 8 * run.claim_sets++;
     launch_dp(L, sdp, run.d_plan + pb, run.d_order + ob + L.off, run.d_pool, run.sk, dir_reg, run.d_out, slabs,
-              (unsigned long long *)ctx->misc_buf.p + 1, ctx->stripe_spin_cap);
+              (unsigned long long *)ctx->misc_buf.p + 1, ctx->stripe_spin_cap, claim);
     if ((L.bs >= 300 && L.bs < 500) || L.bs == 604 || L.bs == 608) run.any_stripe = true;
     ++ctx->launches;
   }
@@ -474,6 +482,8 @@ static int launch_lane(BatchRun &run, size_t n) {
   PlanTask *lp = run.d_plan + cut.ntask_total;
   const int64_t dir0 = (int64_t)(cut.heavy_need + cut.nreg_ws * cut.region_need);
   hipLaunchKernelGGL(lane_plan_kernel, gl, dim3(256), 0, sl, d_recs, v_out, (int)nl, cap_off, dir_off, cut.stage_total, dir0, lp);
+  run.ev_lane0 = next_event(ctx, run.evc);
+  SDF_HIP(hipEventRecord(run.ev_lane0, sl));
   size_t pos = 0;
   for (int c = 0; c < 4; ++c) {  // (sorted by class first: the classes are consecutive ranges)
     const size_t cnt = cut.lane_cls[c];
@@ -602,6 +612,26 @@ static int finish_batch(BatchRun &run, BatchRun *head, size_t n, sdf_result *d_o
     }
     return len;
   };
+  static const bool dbg_iv = getenv("SDF_DEBUG_PLAN") != nullptr;
+  if (dbg_iv) {  // the chunks' DP intervals per stream and the lane kernel's, from the start of the call
+    for (size_t ci = 0; ci < run.cev.size(); ++ci) {
+      const ChunkEv &ev = run.cev[ci];
+      if (!ev.dp0) continue;
+      for (int q = 0; q < 8; ++q)
+        if (ev.dpe[q]) {
+          float a = 0, b = 0;
+          (void)hipEventElapsedTime(&a, run.ev_begin, ev.dp0);
+          (void)hipEventElapsedTime(&b, run.ev_begin, ev.dpe[q]);
+          fprintf(stderr, "[chunk %zu%s stream %d: DP %.2f - %.2f ms]\n", ci, run.cut->chunks[ci].heavy ? " (heavy)" : "", q, a, b);
+        }
+    }
+    if (run.ev_lane0 && run.ev_lane) {
+      float a = 0, b = 0;
+      (void)hipEventElapsedTime(&a, run.ev_begin, run.ev_lane0);
+      (void)hipEventElapsedTime(&b, run.ev_begin, run.ev_lane);
+      fprintf(stderr, "[lane kernel: DP + traceback %.2f - %.2f ms]\n", a, b);
+    }
+  }
   float s0 = 0, s1 = 0;
   ctx->ms[0] = span(false, s0);
   ctx->ms[1] = span(true, s1);

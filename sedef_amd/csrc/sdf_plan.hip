@@ -585,7 +585,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   // Strip kernels (extz2_strip.hip) are throughput kernels: a step of eight cells per lane is a microsecond on a wavefront
   // alone, a 500 x 500 task 0.55 ms where the window kernels take 0.3, a chain of twelve blocks 6.5 ms against the
   // stripe kernel's 3.0 (profiles/r03_strip.txt).  They take a chunk's tasks only when there are enough of them to fill
-  // the device: 1,024 one-wavefront tasks, 3,072 chain wavefronts.
+  // the device: 1,024 one-wavefront tasks, 3,072 chain wavefronts (1,024 for the heavy tasks of a large batch).
   bool use_strip = false, use_chain = false;
   if (env.strip_ok) {
     const bool force = env.strip_always;  // (tests: whatever the count)
@@ -600,7 +600,11 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       else w10 += (size_t)strip_blocks(t.tlen, 8);
     }
     use_strip = force || n9 >= 1024;
-    use_chain = force || w10 / 2 >= env.chain_min;
+    // (the heavy tasks of a large batch share the device with everything else it holds: what counts there is the work per
+    // cell, not the pace of a lone chain -- the hg19 mixture's 608 long tasks, 2,900 chain wavefronts: 13.5-14.0 ms as chains
+    // against 14.2-15.2 on the stripe kernel; the same tasks alone: 10-15 % slower as chains)
+    const size_t chain_min = c.heavy && cut.n_heavy * 16 <= env.n ? std::min<size_t>(env.chain_min, 1024) : env.chain_min;
+    use_chain = force || w10 / 2 >= chain_min;
   }
   for (size_t pos = c.s; pos < c.e; ++pos) {
     if (c.heavy && pos + 16 < c.e) __builtin_prefetch(&tasks[cut.heavy_idx[pos + 16]]);
