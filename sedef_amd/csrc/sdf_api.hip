@@ -175,7 +175,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
 
 extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (!ctx) return;
-  g_live_contexts.fetch_sub(1);
+  if (!ctx->is_part) g_live_contexts.fetch_sub(1);
   (void)hipSetDevice(ctx->device);
   for (hipStream_t q : {ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
                         ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3]})
@@ -611,22 +611,29 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // result array; the CIGAR scan and the compaction at the end cover both.  Measured on the 1,000,000-task hg19 mixture:
   // 16.5 ms against 17.2 ms on one box, 17.7 against 15.4 on another -- within the box-to-box noise, and a second set of
   // streams and buffers: off by default, kept under test (tests/test_gpu_extz2.py).
-  static const size_t split_min = [] {
+  // By default (end of round 3) batches of 50,000 to 400,000 tasks on a process's only context start that way with a first
+  // part of 8,192 tasks: their cut is a pass on ONE thread (1 ms for the 100,000 tasks of the headline batch) that the
+  // first launch no longer waits for -- 1,110 against 1,088-1,090 Gcell/s, three runs each on one box.  Larger batches
+  // start their heavy chunks early instead (cut_batch's two passes); SDF_SPLIT_MIN=0 turns the split off.
+  static const long long split_env = [] {
     const char *e = getenv("SDF_SPLIT_MIN");
-    return e ? (size_t)atoll(e) : ~(size_t)0;  // (off unless asked for: see the comment above)
+    return e ? atoll(e) : -1ll;  // (-1: the default rule; 0: off)
   }();
   static const int split_div = [] {
     const char *e = getenv("SDF_SPLIT_DIV");
     return e ? std::max(2, atoi(e)) : 8;
   }();
+  const bool split_default = split_env < 0 && n >= 50000 && n < 400000 && g_live_contexts.load() == 1;
+  const bool split_asked = split_env > 0 && n >= (size_t)split_env;
   BatchRun run, first;
   BatchRun *head = nullptr;
   size_t n_first = 0;
-  if (ctx->pipeline && n >= split_min && !ctx->is_part) {
+  if (ctx->pipeline && (split_default || split_asked) && !ctx->is_part) {
     if (!ctx->part_ctx) {
       ctx->part_ctx = sdf_create(ctx->device, ctx->ws_budget / 4);
       if (ctx->part_ctx) {
         ctx->part_ctx->is_part = true;
+        g_live_contexts.fetch_sub(1);  // (a part context is not another user of the process's CPUs)
         ctx->part_ctx->force_general = ctx->force_general;
         ctx->part_ctx->no_pair = ctx->no_pair;
         ctx->part_ctx->self_pair_max = ctx->self_pair_max;
@@ -640,7 +647,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
       }
     }
     if (sdf_ctx *pc = ctx->part_ctx) {
-      n_first = (n / split_div + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK * SDF_CUT_BLOCK;
+      n_first = split_asked ? (n / split_div + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK * SDF_CUT_BLOCK : 2 * SDF_CUT_BLOCK;
       // the part's stream starts where the caller's stream is
       if (ctx->part_ev == nullptr) (void)hipEventCreate(&ctx->part_ev);
       SDF_HIP(hipEventRecord(ctx->part_ev, st));

@@ -227,9 +227,17 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
            (banded_long(t) ? (uint32_t)(t.tlen + 15 + 127) / 128 : 0u);
   };
   {
+    // (what a task needs depends on (qlen, tlen, w, SCORE_ONLY) alone, and batches repeat their geometries -- the headline
+    // batch has a hundred of them in 100,000 tasks: a small direct-mapped memo per scan thread)
+    struct Memo {
+      int32_t qlen = -1, tlen = -1, w = 0, so = 0;
+      uint32_t oc = 0, words = 0;
+      size_t bd = 0;
+    };
     struct Part {
       size_t nh = 0, hb = 0;
       bool bad = false;
+      Memo memo[256];
       int64_t words = 0;       // first pass: q + t + 2 of every task, the big tasks' launch-order entries, their number
       size_t big_oc = 0, nbig = 0;
     };
@@ -240,21 +248,31 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       const sdf_task &t = tasks[k];
       BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
       cap[k] = 0x80000000u;
-      const uint32_t oc = order_entries(t);
+      Memo &mm = pt.memo[((uint32_t)t.qlen * 31u + (uint32_t)t.tlen * 17u + (uint32_t)t.w) & 255u];
+      const int32_t so = t.flag & SDF_FLAG_SCORE_ONLY;
+      size_t bd = 0;
+      uint32_t oc, words;
+      if (mm.qlen == t.qlen && mm.tlen == t.tlen && mm.w == t.w && mm.so == so) {
+        oc = mm.oc, words = mm.words, bd = mm.bd;
+        ++blk.nt;
+        blk.oc += oc;
+        cap[k] |= words;
+        blk.sw += words;
+      } else {
+      oc = order_entries(t);
       ++blk.nt;
       blk.oc += oc;
       // A task that wants no CIGAR needs no direction flags -- except on the stripe kernels, whose progress words,
       // hand-over values and edge columns live in HBM right behind the task's flag blocks: those tasks reserve the
       // whole layout whatever they want.
       const bool with_dir = env.want_cigar && !(t.flag & SDF_FLAG_SCORE_ONLY);
-      const uint32_t words = with_dir ? (uint32_t)(t.qlen + t.tlen + 2) : 0u;
+      words = with_dir ? (uint32_t)(t.qlen + t.tlen + 2) : 0u;
       cap[k] |= words;
       blk.sw += words;
       const int w = t.w < 0 ? std::max(t.qlen, t.tlen) : t.w;
       const int ncol16 = ((std::min(std::min(t.qlen, t.tlen), w + 1) + 15) / 16 + 1) * 16;
       const size_t nrow = (size_t)t.qlen + t.tlen - 1;
       const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
-      size_t bd = 0;
       if (with_dir) {
         bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
         if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
@@ -278,6 +296,9 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           (with_dir || t.tlen > kStripMaxT))
         bd = std::max(bd, ((size_t)strip_blocks(t.tlen, t.tlen > kStripMaxT && env.strip_cols == 4 ? 4 : 8) *
                                (size_t)(t.qlen - t.qlen / 5 + 100) * 520 + 512 + 255) & ~(size_t)255);
+      mm.qlen = t.qlen, mm.tlen = t.tlen, mm.w = t.w, mm.so = so;
+      mm.oc = oc, mm.words = words, mm.bd = bd;
+      }
       bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
       blk.bd += (uint64_t)bound[k] << 8;
       if (bd >= heavy_min && may_be_heavy) {
