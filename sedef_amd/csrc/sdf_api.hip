@@ -474,8 +474,11 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     SDF_HIP(ctx->misc_buf.reserve(SDF_MISC_PARTS * 8 + ((std::max(n, n_scan) + 1023) / 1024 + 1) * 8));
     SDF_HIP(ctx->host_plan.reserve(np * sizeof(PlanTask)));
     SDF_HIP(ctx->host_order.reserve(nord * sizeof(int32_t)));
-    if (begun && (run.plan != (PlanTask *)ctx->host_plan.p || run.order != (int32_t *)ctx->host_order.p ||
-                  run.d_plan != (PlanTask *)ctx->plan_buf.p || run.d_order != (int32_t *)ctx->order_buf.p ||
+    // (the plan records and the CIGAR staging of the chunks started early are read again at the end of the call -- the
+    // traceback's counters, the compaction, a re-run of abandoned tasks: their buffers were sized by bounds that hold.  The
+    // launch order is not: a chunk's segment is uploaded and read by its own launches only, and an outgrown buffer --
+    // device or pinned -- stays alive until the context goes, so the order buffers may grow here.)
+    if (begun && (run.plan != (PlanTask *)ctx->host_plan.p || run.d_plan != (PlanTask *)ctx->plan_buf.p ||
                   run.d_stage != (uint32_t *)ctx->stage_ws.p)) {
       ctx->err = "internal: a buffer sized by its upper bound had to grow after the early start";
       return SDF_ERR_INVALID;
@@ -1186,20 +1189,38 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   BatchCut cut;
   const char *msg = nullptr;
   const auto tc0 = std::chrono::steady_clock::now();
+  std::vector<PlanTask> plan;
+  std::vector<int32_t> order;
+  // SDF_DEBUG_PLAN_EARLY=1: the cut in two passes with the early start of the heavy chunks (batch_part's, minus the
+  // device): buffers by their upper bounds, the heavy chunks planned from the callback
+  PlanScratch early_scratch;
+  const std::function<int()> early = [&]() -> int {
+    plan.resize(std::max<size_t>(n, 1));
+    order.resize(std::max<size_t>(cut.order_upper, 2));
+    for (size_t ci = 0; ci < cut.chunks.size(); ++ci) {
+      plan_chunk(env, cut, cut.chunks[ci], plan.data(), order.data(), early_scratch);
+      if (cut.chunks[ci].err) return SDF_ERR_INVALID;
+      cut.n_early = ci + 1;
+    }
+    return SDF_OK;
+  };
   {
     WorkerPool cut_pool(std::max(nthreads, 1));
-    if (int rc = cut_batch(env, true, ws_budget, cut, &msg, nthreads > 0 ? &cut_pool : nullptr)) return rc;
+    if (int rc = cut_batch(env, true, ws_budget, cut, &msg, nthreads > 0 ? &cut_pool : nullptr,
+                           getenv("SDF_DEBUG_PLAN_EARLY") ? &early : nullptr))
+      return rc;
   }
   if (getenv("SDF_DEBUG_PLAN"))
-    fprintf(stderr, "[sdf] debug plan: cut %.2f ms (%zu tasks, %d threads)\n",
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(), n, nthreads);
+    fprintf(stderr, "[sdf] debug plan: cut %.2f ms (%zu tasks, %d threads, %zu chunks started early)\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(), n, nthreads, cut.n_early);
   const size_t np = std::max<size_t>(cut.ntask_total, 1);
-  std::vector<PlanTask> plan(np);
-  std::vector<int32_t> order(std::max<size_t>(cut.order_total, 2));
+  if (cut.n_early && np > plan.size()) return SDF_ERR_INVALID;  // (the upper bound of the plan records holds)
+  if (!cut.n_early) plan.resize(np);
+  if (order.size() < std::max<size_t>(cut.order_total, 2)) order.resize(std::max<size_t>(cut.order_total, 2));
   {
     WorkerPool pool(std::max(nthreads, 1));
-    ChunkPlanner planner(env, cut, plan.data(), order.data(), &pool, nthreads);
-    for (size_t ci = 0; ci < cut.chunks.size(); ++ci) planner.wait(ci);
+    ChunkPlanner planner(env, cut, plan.data(), order.data(), &pool, nthreads, cut.n_early);
+    for (size_t ci = cut.n_early; ci < cut.chunks.size(); ++ci) planner.wait(ci);
   }
   for (size_t k = 0; k < n * 7; ++k) per_task[k] = -1;
   *nchunks = cut.chunks.size();

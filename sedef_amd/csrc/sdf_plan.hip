@@ -314,8 +314,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     // mode 0: every task; 1: the big tasks only (and the sums of the early start); 2: the others, none of them heavy
     // (big: everything a stripe / strip kernel may take -- more than 256 target bases --, and from 40,000 cells or 1,000
     // anti-diagonals; the others have two launch-order entries and no direction-flag bound near heavy_min)
-    auto is_big = [](const sdf_task &t) {
-      return t.tlen > 256 || (int64_t)t.qlen * t.tlen >= 40000 || (int64_t)t.qlen + t.tlen >= 1000;
+    auto is_big = [&](const sdf_task &t) {
+      return t.tlen > 256 || (int64_t)t.qlen * t.tlen >= 40000 || (int64_t)t.qlen + t.tlen >= 1000 || banded_long(t);
     };
     auto scan = [&](size_t lo, size_t hi, Part &pt, std::vector<uint32_t> &hv, const int mode) {  // (lo: a multiple of the block size)
       for (size_t k = lo; k < hi; ++k) {

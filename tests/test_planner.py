@@ -142,3 +142,32 @@ def test_stripe_kernel_routing_and_widths():
     assert pt[2, 1] == 401 and pt[7, 1] == 401                # bands that run out: banded stripes whatever their width
     assert pt[5, 1] // 10 in (10, 11) and pt[6, 1] == 401     # too short / just long enough (and its band runs out)
     _check(t, pt, pc)
+
+
+def test_two_pass_cut_with_early_heavy_chunks(monkeypatch):
+    """Batches of 400,000 tasks and more are cut in two passes -- the big tasks first, whose heavy chunks are planned (and,
+    on a device, launched) from a callback while the rest of the batch is read: every runnable task is still planned exactly
+    once, the heavy chunks come first, the buffers sized by the first pass's upper bounds hold, and the plan is a valid one
+    (regions and staging slots disjoint) -- the same invariants as the one-pass cut, which marks the same tasks heavy."""
+    rng = np.random.default_rng(5)
+    n = 420000
+    q = rng.integers(1, 210, n)
+    tl = np.maximum(1, q + rng.integers(-6, 6, n))
+    big = rng.choice(n, 700, replace=False)
+    q[big[:300]] = rng.integers(1200, 6000, 300)
+    tl[big[:300]] = q[big[:300]] + rng.integers(-60, 60, 300)
+    q[big[300:]] = 500
+    tl[big[300:]] = 500 + rng.integers(-10, 10, 400)
+    q[rng.choice(n, 40, replace=False)] = 0
+    t = _tasks(q, tl)
+    rc0, pt0, pc0 = _plan(t, threads=3)
+    assert rc0 == 0
+    monkeypatch.setenv("SDF_DEBUG_PLAN_EARLY", "1")
+    rc, pt, pc = _plan(t, threads=3)
+    assert rc == 0
+    heavy = np.flatnonzero(pc[:, 0])
+    assert len(heavy) >= 1 and (heavy == np.arange(len(heavy))).all()
+    _check(t, pt, pc)
+    in_heavy, in_heavy0 = np.isin(pt[:, 0], heavy), np.isin(pt0[:, 0], np.flatnonzero(pc0[:, 0]))
+    assert in_heavy.sum() >= 650 and (in_heavy == in_heavy0).all()
+    assert ((pt[:, 0] >= 0) == (pt0[:, 0] >= 0)).all()  # the same tasks run
