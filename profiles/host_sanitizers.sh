@@ -17,4 +17,16 @@ LD_PRELOAD="$ASAN $STD" ASAN_OPTIONS=detect_leaks=0:log_path=/tmp/sdf_asan UBSAN
 rc=$?
 ls /tmp/sdf_asan.* /tmp/sdf_ubsan.* 2>/dev/null && echo "sanitizer reports above" || echo "no sanitizer report"
 python3 -c "from sedef_amd.host import build_host; build_host(force=True)"
-exit $rc
+# ... and the host side of the HIP library itself (batch cut and chunk planner, sdf_plan.hip; device code not instrumented):
+# the planner tests through the sdf_debug_plan hook -- one- and two-pass cut, planning on several threads.  End of round 3:
+# 9 passed, no report.
+cp sedef_amd/lib/libsedef_hip.so /tmp/sdf_libsedef_hip.keep
+/opt/rocm/bin/hipcc -O1 -g -std=c++17 --offload-arch=gfx950 -fPIC -shared -fsanitize=address,undefined -fno-gpu-sanitize \
+    -fno-omit-frame-pointer -Wno-unused-function -o sedef_amd/lib/libsedef_hip.so sedef_amd/csrc/sdf_unity.hip || { cp /tmp/sdf_libsedef_hip.keep sedef_amd/lib/libsedef_hip.so; exit 1; }
+RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+LD_PRELOAD="$RT $STD" ASAN_OPTIONS=detect_leaks=0:log_path=/tmp/sdf_asan UBSAN_OPTIONS=print_stacktrace=1:log_path=/tmp/sdf_ubsan \
+  python3 -m pytest tests/test_planner.py tests/test_cabi_exports.py -q
+rc2=$?
+ls /tmp/sdf_asan.* /tmp/sdf_ubsan.* 2>/dev/null && echo "sanitizer reports above" || echo "no sanitizer report"
+cp /tmp/sdf_libsedef_hip.keep sedef_amd/lib/libsedef_hip.so
+exit $((rc | rc2))
