@@ -28,5 +28,14 @@ LD_PRELOAD="$RT $STD" ASAN_OPTIONS=detect_leaks=0:log_path=/tmp/sdf_asan UBSAN_O
   python3 -m pytest tests/test_planner.py tests/test_cabi_exports.py -q
 rc2=$?
 ls /tmp/sdf_asan.* /tmp/sdf_ubsan.* 2>/dev/null && echo "sanitizer reports above" || echo "no sanitizer report"
+# ... and ThreadSanitizer over the same planner tests (the cut's scan threads, the two passes with the early start next to
+# the second, the chunk planner's workers).  End of round 3: 5 passed, no report.
+/opt/rocm/bin/hipcc -O1 -g -std=c++17 --offload-arch=gfx950 -fPIC -shared -fsanitize=thread -fno-gpu-sanitize \
+    -fno-omit-frame-pointer -Wno-unused-function -o sedef_amd/lib/libsedef_hip.so sedef_amd/csrc/sdf_unity.hip || { cp /tmp/sdf_libsedef_hip.keep sedef_amd/lib/libsedef_hip.so; exit 1; }
+RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.tsan-x86_64.so)
+rm -f /tmp/sdf_tsan.*
+LD_PRELOAD="$RT" TSAN_OPTIONS="log_path=/tmp/sdf_tsan report_signal_unsafe=0" python3 -m pytest tests/test_planner.py -q
+rc3=$?
+ls /tmp/sdf_tsan.* 2>/dev/null && echo "thread sanitizer reports above" || echo "no thread sanitizer report"
 cp /tmp/sdf_libsedef_hip.keep sedef_amd/lib/libsedef_hip.so
-exit $((rc | rc2))
+exit $((rc | rc2 | rc3))
