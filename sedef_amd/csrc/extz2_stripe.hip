@@ -63,8 +63,10 @@ __device__ __forceinline__ void st_agent(T *p, T v) {
 }
 
 // A wait gives up after `spin_cap` polls (context field, SDF_STRIPE_SPIN_CAP in the environment of sdf_create; 2^24 by
-// default: seconds) -- the protocol's forward progress rests on the dispatch order (a stripe's left neighbour is resident or
-// finished), which a part with another XCD count, or other launches holding the wavefront slots, may not honour.  The
+// default: seconds).  With claimed entries (stripe_claim below) a stripe's left neighbour has always been taken by a
+// workgroup that is running or done; taken by index (SDF_STRIPE_CLAIM=0, or a launch without counters) the protocol's forward
+// progress rests on the dispatch order, which a part with another XCD count, or other launches holding the wavefront slots,
+// may not honour -- and a wavefront preempted for good would stall its right neighbours either way.  The
 // wavefront then marks its TASK as abandoned (n_cigar = -1 in the task's result record, which nothing else touches before
 // the traceback; the task's index is appended to the list behind the give-up counter, once per task) and ends; the other
 // stripes of the task see the mark within 64 polls and end too.  The batch call re-runs abandoned tasks on the
