@@ -231,7 +231,12 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   const int ui = piped ? (run.have_heavy ? ((nj & 1) && Q[7] ? 7 : 2) : 1 + (int)(nj & 1)) : 0;
   // (the tracebacks of consecutive ordinary chunks alternate between two streams: the last one starts when its DP
   // ends, not when the previous chunk's walk does)
-  hipStream_t stb = piped ? ((nj & 1) && ctx->aux_stream[2] ? ctx->aux_stream[2] : Q[3]) : Q[0];
+  // (without the extra streams the call's LAST chunk walks on its own upload / DP stream, which no later chunk waits on:
+  // the last two chunks end together when they shared the device, and their walks then run side by side)
+  const bool last_chunk = ci + 1 == cut.chunks.size() && !run.more_chunks;
+  hipStream_t stb = piped ? ((nj & 1) && ctx->aux_stream[2] ? ctx->aux_stream[2]
+                                                             : (last_chunk && nj > 0 && !run.have_heavy ? Q[ui] : Q[3]))
+                          : Q[0];
   uint8_t *dir_reg = heavy_chunk ? run.heavy_dir : run.d_dir + cut.heavy_need + (nj % cut.nreg_ws) * cut.region_need;
   hipEvent_t region_ev = nullptr;  // the region's previous user has been traced back
   if (piped && nj >= cut.nreg_ws) region_ev = run.cev[run.normal_ids[nj - cut.nreg_ws]].tb1;
