@@ -80,7 +80,7 @@ __host__ __device__ inline int pair_qcap(int qlen, int nreg) {
 // (best H, row); one reduction at the end applies the reference's tie order (earliest row, then its 4-lane scan order).
 // Such a task is launched paired with itself: both halves compute it, half B is ignored.
 template <int NREG, bool STREAM, bool TRACK>
-__global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 4 ? 3 : 2) void extz2_pair_kernel(
+__device__ __forceinline__ void pair_body(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -316,9 +316,9 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
           xt1[0] = (unsigned)__builtin_amdgcn_update_dpp((int)xcarry, (int)X[0], 0x138, 0xf, 0xf, false);
           vt1[0] = (unsigned)__builtin_amdgcn_update_dpp((int)vcarry, (int)V[0], 0x138, 0xf, 0xf, false);
         } else {
-          const int x0 = __builtin_amdgcn_update_dpp((int)xt1[k], (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          const int x0 = __builtin_amdgcn_mov_dpp((int)X[k - 1], 0x13C, 0x1, 0x1, false);
           xt1[k] = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-          const int v0 = __builtin_amdgcn_update_dpp((int)vt1[k], (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          const int v0 = __builtin_amdgcn_mov_dpp((int)V[k - 1], 0x13C, 0x1, 0x1, false);
           vt1[k] = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
         }
       }
@@ -438,9 +438,9 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
           if (STEADY) vt1[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)V[0], 0x138, 0xf, 0xf, true);
           else vt1[0] = (unsigned)__builtin_amdgcn_update_dpp((int)vcar, (int)V[0], 0x138, 0xf, 0xf, false);
         } else {  // lane 0 from the register below, lanes 1..63 from this one: all lanes overwritten in place
-          const int x0 = __builtin_amdgcn_update_dpp((int)xt1[k], (int)X[k - 1], 0x13C, 0x1, 0x1, false);
+          const int x0 = __builtin_amdgcn_mov_dpp((int)X[k - 1], 0x13C, 0x1, 0x1, false);
           xt1[k] = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-          const int v0 = __builtin_amdgcn_update_dpp((int)vt1[k], (int)V[k - 1], 0x13C, 0x1, 0x1, false);
+          const int v0 = __builtin_amdgcn_mov_dpp((int)V[k - 1], 0x13C, 0x1, 0x1, false);
           vt1[k] = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
         }
       }
@@ -805,6 +805,23 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
 #undef tt0
 #undef we0
 
+template <int NREG, bool STREAM, bool TRACK>
+__global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 4 ? 3 : 2) void extz2_pair_kernel(
+    const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
+    ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
+  pair_body<NREG, STREAM, TRACK>(plan, order, pool, sc, dirbase, res);
+}
+// The instantiation of the headline batch (w = 128: three registers, sequences whole in LDS) is held to 112 VGPRs -- the
+// attribute counts half of the unified file on gfx950: 56 -- which the body fits without a spill (116 otherwise): four of
+// its wavefronts then leave 64 registers of a SIMD free, room for a traceback wavefront (50 VGPRs) of the chunk before
+// NEXT to them instead of in the place of one (profiles/r03_shapes.txt).
+template <>
+__global__ __launch_bounds__(64, 4) __attribute__((amdgpu_num_vgpr(56))) void extz2_pair_kernel<3, false, false>(
+    const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
+    ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
+  pair_body<3, false, false>(plan, order, pool, sc, dirbase, res);
+}
+
 #define SDF_PAIR_INST(N)                                                                                               \
   template __global__ void extz2_pair_kernel<N, false, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, \
                                                               uint8_t *, sdf_result *);                               \
@@ -812,7 +829,8 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
                                                              uint8_t *, sdf_result *);
 SDF_PAIR_INST(1)
 SDF_PAIR_INST(2)
-SDF_PAIR_INST(3)
+template __global__ void extz2_pair_kernel<3, true, false>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
+                                                           uint8_t *, sdf_result *);  // (<3, false, false>: specialised above)
 SDF_PAIR_INST(4)
 SDF_PAIR_INST(6)
 SDF_PAIR_INST(8)
