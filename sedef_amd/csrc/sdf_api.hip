@@ -421,7 +421,6 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   BatchCut &cut = *ctx->cut;
   cut.reset();
   {
-    const char *msg = nullptr;
     // Planning threads of a context: SDF_PLAN_THREADS, else every CPU the process may use but this thread's when the
     // context is the only one of the process (the scan of a million tasks is CPU-bound: 1.7 ms on eight threads, 0.86 ms on
     // sixteen), seven when there are several (the stage driver's lanes share the machine).
@@ -614,8 +613,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // result array; the CIGAR scan and the compaction at the end cover both.  Measured on the 1,000,000-task hg19 mixture:
   // 16.5 ms against 17.2 ms on one box, 17.7 against 15.4 on another -- within the box-to-box noise, and a second set of
   // streams and buffers: off by default, kept under test (tests/test_gpu_extz2.py).
-  // By default (end of round 3) batches of 50,000 to 400,000 tasks on a process's only context start that way with a first
-  // part of 8,192 tasks: their cut is a pass on ONE thread (1 ms for the 100,000 tasks of the headline batch) that the
+  // By default (end of round 3) batches of 50,000 to 400,000 tasks of one size (see uniform_mid) on a process's only context
+  // start that way with a first part of 8,192 tasks: their cut is a pass on ONE thread (1 ms for the 100,000 tasks of the headline batch) that the
   // first launch no longer waits for -- 1,110 against 1,088-1,090 Gcell/s, three runs each on one box.  Larger batches
   // start their heavy chunks early instead (cut_batch's two passes); SDF_SPLIT_MIN=0 turns the split off.
   static const long long split_env = [] {
@@ -626,7 +625,25 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     const char *e = getenv("SDF_SPLIT_DIV");
     return e ? std::max(2, atoi(e)) : 8;
   }();
-  const bool split_default = split_env < 0 && n >= 50000 && n < 400000 && g_live_contexts.load() == 1;
+  // (only batches of tasks of one size, none of them long or small, by a sample of 256: 8,192 of them must keep the device
+  // busy for the millisecond the cut of the rest takes, and a second context's streams next to the many small launches of a
+  // batch of mixed lengths cost more than the early start brings -- mm8-like mixed bands, 100,000 tasks: 585 ms against 441;
+  // hg19-shaped 250,000: 7.8 against 7.3)
+  auto uniform_mid = [&] {
+    const size_t step = n / 256;
+    int mn = 0x7fffffff, mx = 0;
+    double cells = 0;
+    for (size_t i = 0; i < 256; ++i) {
+      const sdf_task &t = tasks[i * step];
+      const int d = t.qlen + t.tlen;
+      mn = std::min(mn, d);
+      mx = std::max(mx, d);
+      const double full = (double)t.qlen * t.tlen;
+      cells += t.w < 0 ? full : std::min(full, (2.0 * t.w + 1) * std::min(t.qlen, t.tlen));
+    }
+    return mn > 0 && mx <= 2 * mn && mx <= 4096 && cells >= 256 * 1e5;
+  };
+  const bool split_default = split_env < 0 && n >= 50000 && n < 400000 && g_live_contexts.load() == 1 && uniform_mid();
   const bool split_asked = split_env > 0 && n >= (size_t)split_env;
   BatchRun run, first;
   BatchRun *head = nullptr;
