@@ -45,3 +45,15 @@ def test_no_gpu_means_loud_failure():
         import pytest
         with pytest.raises(sedef_amd.SdfError):
             sedef_amd.Extz2Engine(0)
+
+
+def test_committed_pmc_counters_belong_to_the_current_kernel_source():
+    """profiles/hbm_traffic.json (what bench.py prints as roofline.traffic / valu_issue) carries the sha256 of
+    extz2_pair.hip as it was when the PMC passes were taken: a kernel change without a new profiles/collect.sh run would
+    make the bench line say `traffic: null` -- caught here instead of at the end of a round."""
+    import hashlib
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    with open(os.path.join(ROOT, "sedef_amd", "csrc", "extz2_pair.hip"), "rb") as f:
+        assert d["kernel_source_sha256"] == hashlib.sha256(f.read()).hexdigest()
+    assert 0.5 < d["bytes_per_step"] / 24.35e9 < 1.2  # (HBM bytes of the launch against its algorithmic bytes)
