@@ -39,7 +39,7 @@ def klass(ins, ops):
 
 def main():
     lines = open(sys.argv[1]).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3sdf17extz2_pair_kernelILi3ELb0EE") and l.rstrip().endswith("sdf_result"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3sdf17extz2_pair_kernelILi3ELb0ELb0EE") and l.rstrip().endswith("sdf_result"))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     body = lines[start:end]
     labels = {}
@@ -62,7 +62,7 @@ def main():
         if (op.startswith("s_cbranch") or op == "s_branch") and ops.strip() in labels and labels[ops.strip()] <= k:
             loops.append((labels[ops.strip()], k))
     inner = [(a, b) for (a, b) in loops if not any(a <= c and d <= b and (c, d) != (a, b) for (c, d) in loops)]
-    out = {"kernel": "extz2_pair_kernel<3,false>", "source": "hipcc -O3 --offload-arch=gfx950 -S of sedef_amd/csrc/sdf_unity.hip",
+    out = {"kernel": "extz2_pair_kernel<3,false,false>", "source": "hipcc -O3 --offload-arch=gfx950 -S of sedef_amd/csrc/sdf_unity.hip",
            "whole_kernel": {}, "innermost_loops": []}
     for op, ops in ins:
         c = klass(op, ops)

@@ -148,8 +148,8 @@ __device__ __forceinline__ void pair_body(
   const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
   const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
   const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
-  unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16
-  SDF_OPQ(one2);
+  unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16 (in a scalar register)
+  asm("" : "+s"(one2));
   unsigned z_match_v = z_match;  // kept in a VGPR: v_pk_mad_u16 takes one scalar operand only
   SDF_OPQ(z_match_v);
 
@@ -178,7 +178,7 @@ __device__ __forceinline__ void pair_body(
   uint2 *dir_a = reinterpret_cast<uint2 *>(dirbase + tk.dir_off);
   uint2 *dir_b = reinterpret_cast<uint2 *>(dirbase + tkb.dir_off);
   const int nrow = qlen + tlen - 1;
-  const int bperm_idx = ((lane + 16) & 63) * 4;
+#define bperm_idx (((lane + 16) & 63) * 4)  // (used once per re-base: not worth a register)
 
   int base = 0;
   int prev_lo = -1;
@@ -189,14 +189,7 @@ __device__ __forceinline__ void pair_body(
   int32_t ez_zdropped = 0;
   int drop_row = -1;  // row of the current block at which the reference window left slots 0..15
   int r0 = 0;
-  unsigned qaddr = 0u, qnext[NREG];  // LDS address of the next row to fetch / prefetched query codes (lean rows)
-  int qrow = -1;                     // row whose codes sit in qnext
-#pragma unroll
-  for (int k = 0; k < NREG; ++k) qnext[k] = 0u;
-  auto fetch_q = [&]() {
-#pragma unroll
-    for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 256 * k);
-  };
+  unsigned qaddr = 0u;  // LDS address of the query codes of the lean row about to be computed
   unsigned hacc_a = 0u, hacc_b = 0u;  // lane-distributed parts of the H path sums (lean rows), folded lazily
   int hcnt = 0;                       // number of path steps in them (each subtracts q+e)
   auto fold_h = [&]() {  // bring the scalar path values up to date
@@ -398,12 +391,9 @@ __device__ __forceinline__ void pair_body(
     constexpr bool STEADY = decltype(steady_c)::value;
     constexpr int KT = NREG - 1;
     if (SCALARH) fold_h();
-    if (qrow != rb) {  // (re)start the one-row-ahead query fetch at this row
-      qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 - we0 + lane));
-      fetch_q();
-      qaddr -= 4;  // address of the row after `qnext`
-    }
-    qrow = re;
+    // (the row's query codes are read at its start: a fetch one row ahead costs four register copies a row and three
+    // registers, and with four or five wavefronts on the SIMD the LDS latency is covered anyway)
+    qaddr = (unsigned)(2 * tcap + 4 * (qlen - 1 - rb + base + 32 - we0 + lane));
     if (STEADY && !SCALARH) hcnt += re - rb;  // every steady row takes one path step
     const unsigned vcar = base == 0 ? qb2 : 0u;  // v carry into slot 0 (r > 0)
 #pragma unroll 1
@@ -418,8 +408,7 @@ __device__ __forceinline__ void pair_body(
       const int off_hi = (hi0 | 15) - base;
       unsigned qcur[NREG];
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) qcur[k] = qnext[k];
-      fetch_q();
+      for (int k = 0; k < NREG; ++k) qcur[k] = *reinterpret_cast<const uint32_t *>(lds + qaddr + 256 * k);
       qaddr -= 4;
       // boundary cell t = r: y = 0, u = gap open (reference :122)
       if (!STEADY && off_hi + base >= r) {
@@ -598,7 +587,6 @@ __device__ __forceinline__ void pair_body(
 #undef SDF_SHIFT16
         }
         base = b0.lo;
-        qrow = -1;  // the window moved: query addresses change
         if (STREAM && __builtin_expect(base + NSLOT > tt0 + tcap, 0)) {  // the band has moved beyond the resident part of the target
           fill_target(base);
           __syncthreads();
@@ -615,7 +603,6 @@ __device__ __forceinline__ void pair_body(
           const int from = e_hi + 1 - qcap;
           fill_query(from < 0 ? 0 : from);
           __syncthreads();
-          qrow = -1;
         }
       }
     }
@@ -804,6 +791,7 @@ __device__ __forceinline__ void pair_body(
 
 #undef tt0
 #undef we0
+#undef bperm_idx
 
 template <int NREG, bool STREAM, bool TRACK>
 __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 4 ? 3 : 2) void extz2_pair_kernel(
@@ -811,12 +799,12 @@ __global__ __launch_bounds__(64, NREG <= 1 ? 6 : NREG <= 2 ? 5 : NREG <= 3 ? 4 :
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
   pair_body<NREG, STREAM, TRACK>(plan, order, pool, sc, dirbase, res);
 }
-// The instantiation of the headline batch (w = 128: three registers, sequences whole in LDS) is held to 112 VGPRs -- the
-// attribute counts half of the unified file on gfx950: 56 -- which the body fits without a spill (116 otherwise): four of
-// its wavefronts then leave 64 registers of a SIMD free, room for a traceback wavefront (50 VGPRs) of the chunk before
-// NEXT to them instead of in the place of one (profiles/r03_shapes.txt).
+// The instantiation of the headline batch (w = 128: three registers, sequences whole in LDS) runs FIVE wavefronts per SIMD
+// (96 VGPRs; LDS allows six): every row loop fits without a scratch access, eight registers of block-level state are
+// spilled (32 bytes; one store and a few loads per 16-row block).  19.4-19.6 ms for the whole batch in one launch against
+// 20.1-20.2 at four wavefronts (profiles/r03_shapes.txt).
 template <>
-__global__ __launch_bounds__(64, 4) __attribute__((amdgpu_num_vgpr(56))) void extz2_pair_kernel<3, false, false>(
+__global__ __launch_bounds__(64, 5) void extz2_pair_kernel<3, false, false>(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
   pair_body<3, false, false>(plan, order, pool, sc, dirbase, res);
