@@ -424,8 +424,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["configs1", "hg19mix"], default="configs1",
                     help="configs1: BASELINE configs[1], the metric's headline (default); hg19mix: the hg19-shaped task "
                          "mixture of BASELINE configs[3]")
