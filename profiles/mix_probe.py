@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One warm-up and one timed call of a mixture batch, for `rocprofv3 --kernel-trace` + profiles/timeline.py.
-usage: mix_probe.py mm8|hg19 [n]"""
+usage: mix_probe.py mm8|hg19 [n] [workspace GiB]"""
 import os
 import sys
 
@@ -12,7 +12,8 @@ from shapes_bench import bench, sedef_amd  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "mm8"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else (3000 if which == "mm8" else 300000)
-eng = sedef_amd.Extz2Engine(0, 64 << 30)
+ws_gib = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+eng = sedef_amd.Extz2Engine(0, ws_gib << 30)
 dev = torch.device("cuda", 0)
 if which == "mm8":
     b, w = bench.synth_mm8_mixture(n, seed=505) if n <= 5000 else bench.synth_mm8_mixture_fast(n, seed=505)

@@ -72,6 +72,25 @@ __host__ __device__ inline int pair_qcap(int qlen, int nreg) {
     }                                                                   \
   }
 
+// Mixed pairs (round 4): the band schedule of the reference, lo0 = max(0, r - qlen + 1, (r - w + 1) >> 1), hi0 = min(tlen - 1, r,
+// (r + w) >> 1) (extern/ksw2_extz2_sse.cc:101-115), depends on the lengths only where the r - qlen + 1 / tlen - 1 clips bite:
+// on the last ~w anti-diagonals of a task.  Two tasks of the same (w, flag) but different lengths therefore share every lane
+// predicate and every scalar decision up to the first row at which a clip bites for either of them.
+// pair_clip_free: the last anti-diagonal r such that on ALL rows 0..r neither clip changes the band of a (qlen, tlen, w)
+// task AND the top cell is not yet the target's last column (min(r, (r + w) >> 1) < tlen - 1: the row code tests that too).
+__host__ __device__ inline int pair_clip_free(int qlen, int tlen, int w) {
+  const int a = 2 * qlen - w - 2;  // r - qlen + 1 <= (r - w + 1) >> 1 for every r up to here (and r - qlen + 1 <= 0 while that is negative)
+  const int b = tlen - 2 > 2 * tlen - w - 3 ? tlen - 2 : 2 * tlen - w - 3;  // min(r, (r + w) >> 1) < tlen - 1
+  return a < b ? a : b;
+}
+// rows [0, shared) of two tasks with band w run side by side in one wavefront: a multiple of 16 (the kernel works in
+// 16-row blocks), and row `shared` itself is still clip-free for both (a row looks one row ahead for its top cell)
+__host__ __device__ inline int pair_shared_rows(int qa, int ta, int qb, int tb, int w) {
+  const int ca = pair_clip_free(qa, ta, w), cb = pair_clip_free(qb, tb, w);
+  const int c = ca < cb ? ca : cb;
+  return c >= 16 ? c / 16 * 16 : 0;
+}
+
 // STREAM: the sequences do not fit the LDS windows whole (long tasks); without it the window code compiles out.
 // TRACK: for banded tasks whose band cannot reach the end of both sequences (|qlen - tlen| > w): the reference runs out
 // of band, sets zdropped and backtracks from the best cell seen (extern/ksw2_extz2_sse.cc:116, :292-295), so the exact H
@@ -79,7 +98,12 @@ __host__ __device__ inline int pair_qcap(int qlen, int nreg) {
 // a 32-bit register (H[t] += v[t] - (q+e); the top cell from its lower neighbour's old H and u, :226-258) and a running
 // (best H, row); one reduction at the end applies the reference's tie order (earliest row, then its 4-lane scan order).
 // Such a task is launched paired with itself: both halves compute it, half B is ignored.
-template <int NREG, bool STREAM, bool TRACK>
+// MIXED: the two tasks may differ in (qlen, tlen).  Three phases: rows [0, shared) side by side as a virtual task of
+// (max qlen, max tlen) -- the shorter query shifted in the LDS window so that one address serves both --, then task A's
+// remaining rows with A in both halves (B's state waits in LDS), then task B's with B in both halves: phases two and
+// three are the kernel's self-paired mode, entered at row `shared` with the state phase one left.  Tasks of equal
+// geometry (or a task paired with itself) run as one phase, as without MIXED.
+template <int NREG, bool STREAM, bool TRACK, bool MIXED = false>
 __device__ __forceinline__ void pair_body(
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
@@ -92,47 +116,76 @@ __device__ __forceinline__ void pair_body(
   else if (tk.qlen + tk.tlen >= 6144) __builtin_amdgcn_s_setprio(2);
   const PlanTask tkb = plan[order[2 * blockIdx.x + 1]];  // task B (high halves): same qlen, tlen, w, flag
   const int lane = threadIdx.x;
-  const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
+  static_assert(!(MIXED && TRACK), "band-exhausting tasks run paired with themselves");
+  const int w = tk.w;
+  // (MIXED: the geometry the row code sees changes with the phase; otherwise these are the constants they always were)
+  const bool mixed = MIXED && (tk.qlen != tkb.qlen || tk.tlen != tkb.tlen);  // wave-uniform
+  const int qmax = MIXED && tkb.qlen > tk.qlen ? tkb.qlen : tk.qlen, tmax = MIXED && tkb.tlen > tk.tlen ? tkb.tlen : tk.tlen;
+  typename std::conditional<MIXED, int, const int>::type qlen = qmax, tlen = tmax;
   // Sequence windows in LDS.  Tb[i] = target position tt0 + i (bytes A | B << 8, zero beyond the ends); W[i] =
   // entry we0 + i of the reversed query with a 32-element front pad (entry j = QR[j-32], QR[e] = query[qlen-1-e];
   // A | B << 16, ready to use).  Short sequences fit whole (tt0 = we0 = 0 for ever); of long ones only the part
   // the band is moving through is resident (1024 entries of slack) and the windows are re-filled from the packed
   // pool when a block start finds them too far behind: the LDS footprint does not grow with the sequence length.
-  const int tcap = pair_tcap(tlen, NREG), qcap = pair_qcap(qlen, NREG);
+  const int tcap = pair_tcap(tmax, NREG), qcap = pair_qcap(qmax, NREG);
   uint16_t *Tb = reinterpret_cast<uint16_t *>(lds);
   uint32_t *W = reinterpret_cast<uint32_t *>(lds + 2 * tcap);
-  const int64_t tw_a = tk.t_word, tw_b = tkb.t_word, qw_a = tk.q_word, qw_b = tkb.q_word;
+  // what the two halves of the windows are filled from (MIXED: per phase -- (A, B) with their own lengths, then (A, A), then (B, B))
+  typename std::conditional<MIXED, int64_t, const int64_t>::type tw_a = tk.t_word, tw_b = tkb.t_word, qw_a = tk.q_word, qw_b = tkb.q_word;
+  typename std::conditional<MIXED, int, const int>::type tl_a = tk.tlen, tl_b = MIXED ? tkb.tlen : tk.tlen, ql_a = tk.qlen,
+                                                        ql_b = MIXED ? tkb.qlen : tk.qlen;
   int tt0_v = 0, we0_v = 0;  // window origins (always 0 without STREAM)
 #define tt0 (STREAM ? tt0_v : 0)
 #define we0 (STREAM ? we0_v : 0)
   auto fill_target = [&](const int from) {  // (pointers rebuilt here: re-fills are rare, registers are not)
-    const uint32_t *twa = pool + tw_a, *tna = twa + (tlen + 15) / 16;
-    const uint32_t *twb = pool + tw_b, *tnb = twb + (tlen + 15) / 16;
+    const uint32_t *twa = pool + tw_a, *tna = twa + (tl_a + 15) / 16;
+    const uint32_t *twb = pool + tw_b, *tnb = twb + (tl_b + 15) / 16;
     tt0_v = from;
     for (int i = lane; i < tcap; i += 64) {
       const int t = from + i;
-      Tb[i] = t < tlen ? (uint16_t)(pool_code8(twa, tna, t, sc.wild) | (pool_code8(twb, tnb, t, sc.wild) << 8)) : 0;
+      if (MIXED) {  // (each half ends with its own target: zeroes beyond, as the reference's calloc'ed arena, :83-85)
+        const uint32_t ca = t < tl_a ? pool_code8(twa, tna, t, sc.wild) : 0u, cb = t < tl_b ? pool_code8(twb, tnb, t, sc.wild) : 0u;
+        Tb[i] = (uint16_t)(ca | (cb << 8));
+      } else {
+        Tb[i] = t < tlen ? (uint16_t)(pool_code8(twa, tna, t, sc.wild) | (pool_code8(twb, tnb, t, sc.wild) << 8)) : 0;
+      }
     }
   };
   auto fill_query = [&](const int from) {
-    const uint32_t *qwa = pool + qw_a, *qna = qwa + (qlen + 15) / 16;
-    const uint32_t *qwb = pool + qw_b, *qnb = qwb + (qlen + 15) / 16;
+    const uint32_t *qwa = pool + qw_a, *qna = qwa + (ql_a + 15) / 16;
+    const uint32_t *qwb = pool + qw_b, *qnb = qwb + (ql_b + 15) / 16;
     we0_v = from;
     for (int i = lane; i < qcap; i += 64) {
       const int e = from + i - 32;
-      const bool in = e >= 0 && e < qlen;
-      W[i] = in ? (pool_code8(qwa, qna, qlen - 1 - e, sc.wild) | (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 16)) : 0u;
+      if (MIXED) {
+        // entry e of the window is QR[e] of a query of `qlen` bases; a shorter query lies qlen - ql entries higher, so that
+        // the address of row r's codes, qlen - 1 - r + t, reads QR_x[ql_x - 1 - r + t] of either task (zeroes around it)
+        const int ea = e - (qlen - ql_a), eb = e - (qlen - ql_b);
+        const uint32_t ca = ea >= 0 && ea < ql_a ? pool_code8(qwa, qna, ql_a - 1 - ea, sc.wild) : 0u;
+        const uint32_t cb = eb >= 0 && eb < ql_b ? pool_code8(qwb, qnb, ql_b - 1 - eb, sc.wild) : 0u;
+        W[i] = ca | (cb << 16);
+      } else {
+        const bool in = e >= 0 && e < qlen;
+        W[i] = in ? (pool_code8(qwa, qna, qlen - 1 - e, sc.wild) | (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 16)) : 0u;
+      }
     }
   };
 
   // ---- unpack the 2-bit / N-mask sequences of both tasks into LDS ----
   int has_n;
   {
-    const uint32_t *tna = pool + tw_a + (tlen + 15) / 16, *tnb = pool + tw_b + (tlen + 15) / 16;
-    const uint32_t *qna = pool + qw_a + (qlen + 15) / 16, *qnb = pool + qw_b + (qlen + 15) / 16;
+    const uint32_t *tna = pool + tw_a + (tl_a + 15) / 16, *tnb = pool + tw_b + (tl_b + 15) / 16;
+    const uint32_t *qna = pool + qw_a + (ql_a + 15) / 16, *qnb = pool + qw_b + (ql_b + 15) / 16;
     uint32_t n_seen = 0;
-    for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tna[k] | tnb[k];
-    for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qna[k] | qnb[k];
+    if (MIXED) {
+      for (int k = lane; k < (tl_a + 31) / 32; k += 64) n_seen |= tna[k];
+      for (int k = lane; k < (tl_b + 31) / 32; k += 64) n_seen |= tnb[k];
+      for (int k = lane; k < (ql_a + 31) / 32; k += 64) n_seen |= qna[k];
+      for (int k = lane; k < (ql_b + 31) / 32; k += 64) n_seen |= qnb[k];
+    } else {
+      for (int k = lane; k < (tlen + 31) / 32; k += 64) n_seen |= tna[k] | tnb[k];
+      for (int k = lane; k < (qlen + 31) / 32; k += 64) n_seen |= qna[k] | qnb[k];
+    }
     has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0));  // wave-uniform
     fill_target(0);
     // row 0 reads entries up to qlen + NSLOT + 31: the window's top there
@@ -175,9 +228,9 @@ __device__ __forceinline__ void pair_body(
   }
 
   const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
-  uint2 *dir_a = reinterpret_cast<uint2 *>(dirbase + tk.dir_off);
-  uint2 *dir_b = reinterpret_cast<uint2 *>(dirbase + tkb.dir_off);
-  const int nrow = qlen + tlen - 1;
+  typename std::conditional<MIXED, uint2 *, uint2 *const>::type dir_a = reinterpret_cast<uint2 *>(dirbase + tk.dir_off),
+                                                              dir_b = reinterpret_cast<uint2 *>(dirbase + tkb.dir_off);
+  typename std::conditional<MIXED, int, const int>::type nrow = qlen + tlen - 1, out_a = tk.out_idx, out_b = tkb.out_idx;
 #define bperm_idx (((lane + 16) & 63) * 4)  // (used once per re-base: not worth a register)
 
   int base = 0;
@@ -551,7 +604,74 @@ __device__ __forceinline__ void pair_body(
   int win_hi = -1;    // last cell of the reference window so far (cells above it were never computed)
   int dirty_hi = -1;  // cells in (win_hi, dirty_hi] may hold scratch values left by lean rows
 
-  for (r0 = 0; r0 < nrow && !ez_zdropped; r0 += 16) {
+  // MIXED, tasks of different lengths: rows [0, shared) together (phase 0), then [shared, nrow) of task A (phase 1) and of
+  // task B (phase 2), each with the task in both halves.  State of half B across phase 1: in LDS behind the windows.
+  const int shared = mixed ? pair_shared_rows(tk.qlen, tk.tlen, tkb.qlen, tkb.tlen, w) : 0;
+  uint32_t *keep = reinterpret_cast<uint32_t *>(lds + ((2 * tcap + 4 * qcap + 15) & ~15));  // 5 x NREG x 64 words (MIXED launches only)
+  int kp_base = 0, kp_prev_lo = 0, kp_win_hi = 0, kp_dirty_hi = 0, kp_h_top = 0, kp_h_under = 0, kp_score = 0, kp_mte = 0, kp_mte_q = 0;
+  bool kp_zero_low = false;
+#pragma nounroll
+  for (int phase = 0; phase < (mixed ? 3 : 1); ++phase) {
+  int row_first = 0, row_last = nrow;
+  if constexpr (MIXED) {
+    if (!mixed) {
+    } else if (phase == 0) {
+      row_last = shared;
+    } else {
+      fold_h();
+      if (phase == 1) {  // half B waits; half A goes on in both halves
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          keep[(0 * NREG + k) * 64 + lane] = U[k];
+          keep[(1 * NREG + k) * 64 + lane] = V[k];
+          keep[(2 * NREG + k) * 64 + lane] = X[k];
+          keep[(3 * NREG + k) * 64 + lane] = Y[k];
+          keep[(4 * NREG + k) * 64 + lane] = S[k];
+          U[k] = __builtin_amdgcn_perm(U[k], U[k], 0x01000100u);
+          V[k] = __builtin_amdgcn_perm(V[k], V[k], 0x01000100u);
+          X[k] = __builtin_amdgcn_perm(X[k], X[k], 0x01000100u);
+          Y[k] = __builtin_amdgcn_perm(Y[k], Y[k], 0x01000100u);
+          S[k] = __builtin_amdgcn_perm(S[k], S[k], 0x01000100u);
+        }
+        kp_base = base, kp_prev_lo = prev_lo, kp_win_hi = win_hi, kp_dirty_hi = dirty_hi, kp_zero_low = zero_low;
+        kp_h_top = h_top[1], kp_h_under = h_under[1], kp_score = ez_score[1], kp_mte = ez_mte[1], kp_mte_q = ez_mte_q[1];
+        h_top[1] = h_top[0], h_under[1] = h_under[0], ez_score[1] = ez_score[0], ez_mte[1] = ez_mte[0], ez_mte_q[1] = ez_mte_q[0];
+        tw_b = tw_a, qw_b = qw_a, tl_b = tl_a, ql_b = ql_a;
+        dir_b = dir_a;
+        out_b = out_a;
+      } else {  // task B, as phase 0 left it, in both halves
+#pragma unroll
+        for (int k = 0; k < NREG; ++k) {
+          const unsigned u = keep[(0 * NREG + k) * 64 + lane], v = keep[(1 * NREG + k) * 64 + lane];
+          const unsigned x = keep[(2 * NREG + k) * 64 + lane], y = keep[(3 * NREG + k) * 64 + lane];
+          const unsigned sv = keep[(4 * NREG + k) * 64 + lane];
+          U[k] = __builtin_amdgcn_perm(u, u, 0x03020302u);
+          V[k] = __builtin_amdgcn_perm(v, v, 0x03020302u);
+          X[k] = __builtin_amdgcn_perm(x, x, 0x03020302u);
+          Y[k] = __builtin_amdgcn_perm(y, y, 0x03020302u);
+          S[k] = __builtin_amdgcn_perm(sv, sv, 0x03020302u);
+        }
+        base = kp_base, prev_lo = kp_prev_lo, win_hi = kp_win_hi, dirty_hi = kp_dirty_hi, zero_low = kp_zero_low;
+        h_top[0] = h_top[1] = kp_h_top, h_under[0] = h_under[1] = kp_h_under;
+        ez_score[0] = ez_score[1] = kp_score, ez_mte[0] = ez_mte[1] = kp_mte, ez_mte_q[0] = ez_mte_q[1] = kp_mte_q;
+        tw_a = tw_b = tkb.t_word, qw_a = qw_b = tkb.q_word, tl_a = tl_b = tkb.tlen, ql_a = ql_b = tkb.qlen;
+        dir_a = dir_b = reinterpret_cast<uint2 *>(dirbase + tkb.dir_off);
+        out_a = out_b = tkb.out_idx;
+      }
+      qlen = ql_a, tlen = tl_a;
+      nrow = qlen + tlen - 1;
+      row_first = shared, row_last = nrow;
+      // the windows again, from this task alone in its own layout (the block start below re-bases and checks the query window)
+      __syncthreads();
+      fill_target(STREAM ? base : 0);
+      if (STREAM) we0_v = 1 << 28;  // (out of reach: the block start fills the query window where this row needs it)
+      else fill_query(0);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NREG; ++k) Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[base - tt0 + 64 * k + lane], 0x0c010c00u);
+    }
+  }
+  for (r0 = row_first; r0 < row_last && !ez_zdropped; r0 += 16) {
     // ---- block start: re-base the window to the reference's band start of this row ----
     {
       Band b0;
@@ -745,6 +865,7 @@ __device__ __forceinline__ void pair_body(
 #pragma unroll
     for (int k = 0; k < NREG; ++k) Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
   }
+  if (MIXED && mixed && phase == 0) continue;  // (results: at the end of each task's own phase)
 
   fold_h();
   int32_t ez_max = 0, ez_max_t = -1, ez_max_q = -1;
@@ -785,8 +906,9 @@ __device__ __forceinline__ void pair_body(
     o.n_cigar = 0;
     o.cigar_off = 0;
     o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
-    res[second ? tkb.out_idx : tk.out_idx] = o;
+    res[second ? out_b : out_a] = o;
   }
+  }  // phase
 }
 
 #undef tt0
@@ -828,6 +950,32 @@ template __global__ void extz2_pair_kernel<3, true, true>(const PlanTask *, cons
                                                           uint8_t *, sdf_result *);
 template __global__ void extz2_pair_kernel<6, true, true>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK,
                                                           uint8_t *, sdf_result *);
+
+// Mixed pairs (two tasks of one band and flag set, any lengths): windows always streamed (a window that holds its
+// sequences whole never re-fills), 2 .. 9 registers of 64 slots -- 9: w = 512, whose window of 576 slots no other
+// register-resident kernel holds for two tasks.
+template <int NREG>
+__global__ __launch_bounds__(64, NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 5 ? 3 : 2) void extz2_pair_mixed_kernel(
+    const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
+    ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
+  pair_body<NREG, true, false, true>(plan, order, pool, sc, dirbase, res);
+}
+#define SDF_PAIR_MIXED_INST(N)                                                                                           \
+  template __global__ void extz2_pair_mixed_kernel<N>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, \
+                                                      sdf_result *);
+SDF_PAIR_MIXED_INST(2)
+SDF_PAIR_MIXED_INST(3)
+SDF_PAIR_MIXED_INST(4)
+SDF_PAIR_MIXED_INST(5)
+SDF_PAIR_MIXED_INST(6)
+SDF_PAIR_MIXED_INST(8)
+SDF_PAIR_MIXED_INST(9)
+#undef SDF_PAIR_MIXED_INST
+
+// LDS of a mixed pair: the windows of (max qlen, max tlen) and, behind them, the five state registers of half B per lane
+size_t pair_mixed_lds_bytes(int qmax, int tmax, int nreg) {
+  return ((2 * (size_t)pair_tcap(tmax, nreg) + 4 * (size_t)pair_qcap(qmax, nreg) + 15) & ~(size_t)15) + (size_t)5 * nreg * 256;
+}
 
 // the windows hold the sequences whole?
 bool pair_fits_whole(int qlen, int tlen, int nreg) {

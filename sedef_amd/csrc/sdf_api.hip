@@ -121,13 +121,22 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   SDF_PAIR_ATTR(1) SDF_PAIR_ATTR(2) SDF_PAIR_ATTR(3) SDF_PAIR_ATTR(4) SDF_PAIR_ATTR(6) SDF_PAIR_ATTR(8)
 #undef SDF_PAIR_ATTR
   for (const void *f : {reinterpret_cast<const void *>(&extz2_pair_kernel<3, true, true>),
-                        reinterpret_cast<const void *>(&extz2_pair_kernel<6, true, true>)})
+                        reinterpret_cast<const void *>(&extz2_pair_kernel<6, true, true>),
+                        reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<2>),
+                        reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<3>),
+                        reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<4>),
+                        reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<5>),
+                        reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<6>),
+                        reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<8>),
+                        reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<9>)})
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipGetLastError();
   const char *fg = getenv("SDF_FORCE_GENERAL");
   ctx->force_general = fg && fg[0] == '1';
   const char *np = getenv("SDF_NO_PAIR");
   ctx->no_pair = np && np[0] == '1';
+  if (const char *e = getenv("SDF_NO_MIXED")) ctx->no_mixed = e[0] == '1';
+  if (const char *e = getenv("SDF_MIXED_MIN")) ctx->mixed_min = (size_t)std::max(0ll, atoll(e));
   if (const char *e = getenv("SDF_STRIPE_CLAIM")) ctx->stripe_claim = e[0] != '0';  // (0: stripe workgroups take entry blockIdx.x)
   if (const char *e = getenv("SDF_CHAIN_MIN")) ctx->chain_min = (size_t)std::max(0ll, atoll(e));
   if (const char *e = getenv("SDF_SELF_PAIR_MAX")) ctx->self_pair_max = (size_t)std::max(0ll, atoll(e));
@@ -180,6 +189,8 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   for (hipStream_t q : {ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
                         ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3]})
     if (q) (void)hipStreamSynchronize(q);
+  for (hipStream_t q : ctx->wide_stream)
+    if (q) (void)hipStreamSynchronize(q);
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
   for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
                     &ctx->an_pos, &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff, &ctx->ch_an, &ctx->ch_off,
@@ -198,6 +209,8 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (hipStream_t s : {ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0], ctx->aux_stream[1],
                         ctx->aux_stream[2], ctx->aux_stream[3]})
+    if (s) (void)hipStreamDestroy(s);
+  for (hipStream_t s : ctx->wide_stream)
     if (s) (void)hipStreamDestroy(s);
   if (!ctx->pool_shared) delete ctx->pool;
   delete ctx->cut;
@@ -391,6 +404,8 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   env.force_general = ctx->force_general;
   env.no_pair = ctx->no_pair;
   env.self_pair_max = ctx->self_pair_max;
+  env.no_mixed = ctx->no_mixed;
+  env.mixed_min = ctx->mixed_min;
   env.no_stripe = ctx->no_stripe;
   env.stripe_min = ctx->stripe_min;
   env.bstripe_min_rows = ctx->bstripe_min_rows;
@@ -657,6 +672,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         ctx->part_ctx->force_general = ctx->force_general;
         ctx->part_ctx->no_pair = ctx->no_pair;
         ctx->part_ctx->self_pair_max = ctx->self_pair_max;
+        ctx->part_ctx->no_mixed = ctx->no_mixed;
+        ctx->part_ctx->mixed_min = ctx->mixed_min;
         ctx->part_ctx->no_stripe = ctx->no_stripe;
         ctx->part_ctx->lane_enabled = ctx->lane_enabled;
         ctx->part_ctx->lane_min = ctx->lane_min;

@@ -34,6 +34,8 @@ __global__ void extz2_pair_kernel(const PlanTask *, const int32_t *, const uint3
                                   sdf_result *);
 size_t pair_lds_bytes(int qlen, int tlen, int nreg);
 bool pair_fits_whole(int qlen, int tlen, int nreg);
+size_t pair_mixed_lds_bytes(int qmax, int tmax, int nreg);
+constexpr int kMixedMaxNeed = 576;  // widest window of a mixed pair: nine registers of 64 slots (w = 512)
 template <int NREG>
 __global__ void extz2_stripe_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                     sdf_result *, int, unsigned long long *, int, unsigned *);
@@ -228,6 +230,7 @@ struct sdf_ctx {
   hipStream_t stream = nullptr;
   size_t ws_budget = 0;
   hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr;  // chunk pipeline
+  hipStream_t wide_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // chunks of several mixed-pair launches (sdf_launch.hip)
   hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};    // more room for launches that end in a tail
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   HostBuf host_plan, host_order;  // pinned staging of the plan
@@ -268,6 +271,8 @@ struct sdf_ctx {
   size_t chain_min = 3072;     // SDF_CHAIN_MIN: see PlanEnv
   bool stripe_claim = true;    // SDF_STRIPE_CLAIM=0: the stripe kernels' workgroups take launch-order entry blockIdx.x
   bool no_pair = false;        // SDF_NO_PAIR=1: never pack two tasks into one wavefront (extz2_pair.hip)
+  bool no_mixed = false;       // SDF_NO_MIXED=1: no mixed pairs (banded tasks of different lengths in one wavefront)
+  size_t mixed_min = 4096;     // SDF_MIXED_MIN: see PlanEnv
   int stripe_spin_cap = 1 << 24;  // SDF_STRIPE_SPIN_CAP: polls before a stripe's wait gives its task up (extz2_stripe.hip)
   sdf_ctx *part_ctx = nullptr;    // second context of this device: the first part of a very large batch (sdf_api.hip)
   hipEvent_t part_ev = nullptr;

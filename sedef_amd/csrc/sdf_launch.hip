@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void reset_results_kernel(sdf_result *res, int
 }
 
 struct ChunkEv {
-  hipEvent_t dp0 = nullptr, dpe[8] = {}, tb0 = nullptr, tb1 = nullptr;  // plan uploaded; end of the DP launches per
+  hipEvent_t dp0 = nullptr, dpe[16] = {}, tb0 = nullptr, tb1 = nullptr;  // plan uploaded; end of the DP launches per
                                                                          // stream; traceback (begin, end)
 };
 
@@ -43,7 +43,7 @@ struct BatchRun {
   bool want_cigar = false, have_heavy = false;
   std::vector<ChunkEv> cev;
   std::vector<size_t> normal_ids;  // chunk indices of the ordinary chunks launched so far
-  double qload[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // estimated DP work queued on each stream during this call
+  double qload[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // estimated DP work queued on each stream during this call
   size_t evc = 0;
   hipEvent_t ev_begin = nullptr;
   bool any_stripe = false;  // a stripe kernel was launched: its give-up list is looked at before the batch closes
@@ -52,7 +52,7 @@ struct BatchRun {
   uint32_t want = 0;
   hipEvent_t ev_lane = nullptr;  // the lane tasks' DP and traceback have finished
   hipEvent_t ev_lane0 = nullptr;  // ... are about to start (debug timing)
-  hipStream_t began[12] = {};  // internal streams already ordered behind ev_begin in this call
+  hipStream_t began[24] = {};  // internal streams already ordered behind ev_begin in this call
   size_t nbegan = 0;
 };
 
@@ -70,6 +70,8 @@ static void drain_streams(sdf_ctx *ctx, hipStream_t st) {
   for (hipStream_t q : {st, ctx->stream, ctx->dp_stream[0], ctx->dp_stream[1], ctx->tb_stream, ctx->aux_stream[0],
                         ctx->aux_stream[1], ctx->aux_stream[2], ctx->aux_stream[3], ctx->lane_stream})
     if (q) (void)hipStreamSynchronize(q);
+  for (hipStream_t q : ctx->wide_stream)
+    if (q) (void)hipStreamSynchronize(q);
   (void)hipGetLastError();
 }
 
@@ -82,6 +84,8 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
   hipLaunchKernelGGL((extz2_wave_kernel<N, S>), one, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
 #define SDF_PAIR(N, S) \
   hipLaunchKernelGGL((extz2_pair_kernel<N, S, false>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
+#define SDF_PAIR_MIXED(N) \
+  hipLaunchKernelGGL((extz2_pair_mixed_kernel<N>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
 #define SDF_PAIR_TRACK(N) \
   hipLaunchKernelGGL((extz2_pair_kernel<N, true, true>), half, dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out)
 #define SDF_STRIPE(N) /* one workgroup of one wavefront per stripe; progress words and edge columns reset first */ \
@@ -127,6 +131,13 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 116: SDF_PAIR(6, true); break;
     case 108: SDF_PAIR(8, false); break;
     case 118: SDF_PAIR(8, true); break;
+    case 132: SDF_PAIR_MIXED(2); break;
+    case 133: SDF_PAIR_MIXED(3); break;
+    case 134: SDF_PAIR_MIXED(4); break;
+    case 135: SDF_PAIR_MIXED(5); break;
+    case 136: SDF_PAIR_MIXED(6); break;
+    case 138: SDF_PAIR_MIXED(8); break;
+    case 139: SDF_PAIR_MIXED(9); break;
     case 123: SDF_PAIR_TRACK(3); break;
     case 126: SDF_PAIR_TRACK(6); break;
     case 608: /* chained strips: edge columns and row-0 sums reset first */
@@ -157,6 +168,7 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
   }
 #undef SDF_WAVE
 #undef SDF_PAIR
+#undef SDF_PAIR_MIXED
 #undef SDF_PAIR_TRACK
 #undef SDF_STRIPE
 #undef SDF_BSTRIPE
@@ -210,20 +222,32 @@ static int launch_chunk(BatchRun &run, size_t ci) {
         ctx->aux_stream[a] = nullptr;
       }
   }
-  hipStream_t Q[8] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
-                      pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
-                      ctx->aux_stream[3]};
+  // A chunk of several mixed-pair launches (banded tasks of all lengths, extz2_pair.hip MIXED): each of them ends with its
+  // longest chain of rows whatever else runs, so they must START together -- eight more streams, four per chunk parity
+  size_t n_mixed_launches = 0;
+  for (const Launch &L : c.launches) n_mixed_launches += L.bs >= 130 && L.bs < 140;
+  if (pipelined && n_mixed_launches >= 2 && !run.have_heavy)
+    for (size_t a = 0; a < 8; ++a)
+      if (!ctx->wide_stream[a] && hipStreamCreateWithFlags(&ctx->wide_stream[a], hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->wide_stream[a] = nullptr;
+      }
+  constexpr int NQ = 16;
+  hipStream_t Q[NQ] = {st, pipelined ? ctx->dp_stream[0] : st, pipelined ? ctx->dp_stream[1] : st,
+                       pipelined ? ctx->tb_stream : st, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2],
+                       ctx->aux_stream[3]};
+  for (int a = 0; a < 8; ++a) Q[8 + a] = pipelined && !run.have_heavy ? ctx->wide_stream[a] : nullptr;
   // Every internal stream waits for the start of the call before its first use in it -- whatever it is used for (plan
   // upload, DP, traceback): the packed pool's upload, the reset of the result records, the give-up word and whatever the
   // caller ordered on its stream all lie before ev_begin.  (The extra streams are created lazily, above: a fixed list
   // at the start of the call would miss them.)
-  for (int q = 1; q < 8; ++q) {
+  for (int q = 1; q < NQ; ++q) {
     if (!Q[q] || Q[q] == st) continue;
     bool seen = false;
     for (size_t b = 0; b < run.nbegan; ++b) seen = seen || run.began[b] == Q[q];
     if (seen) continue;
     SDF_HIP(hipStreamWaitEvent(Q[q], run.ev_begin, 0));
-    if (run.nbegan < 12) run.began[run.nbegan++] = Q[q];
+    if (run.nbegan < 24) run.began[run.nbegan++] = Q[q];
   }
   // Q[4..7]: only the least-loaded-stream assignment below uses them (one-chunk batches without heavy tasks)
   // upload stream (and the big launches'): consecutive ordinary chunks alternate between two, so that a chunk's upload
@@ -249,7 +273,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
   ev.tb0 = next_event(ctx, run.evc);
   ev.tb1 = next_event(ctx, run.evc);
   SDF_HIP(hipEventRecord(ev.dp0, Q[ui]));
-  bool used[8] = {false, false, false, false, false, false, false, false};
+  bool used[NQ] = {};
   size_t gs_off = 0;
   {  // HBM state slabs of the very long tasks of this chunk: one allocation, a slice per launch
     size_t gs_total = 0;
@@ -265,12 +289,42 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       }
     }
   }
+  static const bool dbg_cls = getenv("SDF_DEBUG_CLASSES") != nullptr;
+  if (dbg_cls) {  // what each launch class of the chunk holds: tasks, anti-diagonals, in-band cells (profiles/r04_mm8_classes.txt)
+    for (const Launch &L : c.launches) {
+      const bool striped = (L.bs >= 300 && L.bs < 500) || L.bs == 604 || L.bs == 608;
+      long long nt = 0, rows = 0, cells = 0;
+      int32_t prev = -1;
+      auto add = [&](int32_t rel) {
+        const PlanTask &p = run.plan[pb + rel];
+        ++nt;
+        rows += p.qlen + p.tlen - 1;
+        cells += (p.w >= p.qlen && p.w >= p.tlen) ? (long long)p.qlen * p.tlen : sdf_band_cells(p.qlen, p.tlen, p.w);
+      };
+      for (size_t j = 0; j < L.cnt; ++j) {
+        const int32_t e = run.order[ob + L.off + j];
+        if (striped) {
+          if (((uint32_t)e >> 24) != 0) continue;  // (one entry per stripe: the first stands for the task)
+          const int32_t rel = e & 0xffffff;
+          add(rel);
+          if (L.bs >= 600 && run.plan[pb + rel].zdrop != rel) add(run.plan[pb + rel].zdrop);  // (chained strips: the partner)
+        } else if (e != prev) {  // (a task paired with itself is listed twice)
+          add(e);
+          prev = e;
+        }
+      }
+      fprintf(stderr, "[class chunk %zu%s bs %d entries %zu tasks %lld rows %lld cells %lld lds %zu]\n", ci, c.heavy ? " (heavy)" : "",
+              L.bs, L.cnt, nt, rows, cells, L.lds);
+    }
+  }
   for (const Launch &L : c.launches) {
     // with heavy tasks in the batch the streams are divided: Q[0], Q[1] for the heavy launches (tens of
     // milliseconds each), the others for the ordinary chunks, which would otherwise queue behind them
     int qi = 0;
     if (pipelined) {
-      if (piped && L.cnt >= 2048 && (L.bs < 300 || L.bs == 500)) {  // (a stripe class counts stripes, and lasts as long as its longest task)
+      const bool mixed_cls = L.bs >= 130 && L.bs < 140;  // (long and short banded tasks in one launch: it ends with its longest chain,
+                                                         // and runs next to the chunk's other launches rather than behind them)
+      if (piped && L.cnt >= 2048 && (L.bs < 300 || L.bs == 500) && !mixed_cls) {  // (a stripe class counts stripes, and lasts as long as its longest task)
         qi = ui;
       } else {  // least estimated work queued; with heavy tasks in the batch Q[0], Q[1], Q[4], Q[5] are theirs
         // Without heavy tasks, consecutive ordinary chunks keep to disjoint sets of queues -- Q[1], Q[4], Q[5] and Q[2],
@@ -278,9 +332,9 @@ static int launch_chunk(BatchRun &run, size_t ci) {
         // the long-running small launches of the chunk before it, or the chunks run one after the other, each as long as
         // its longest task (a 100,000-task batch of banded tasks of all lengths: 474 ms -> see profiles/r03_shapes.txt)
         const bool split_q = !run.have_heavy && piped && nchunks > 1;
-        auto mine = [&](int q) { return (nj & 1) ? (q == 2 || q == 6 || q == 7) : (q == 1 || q == 4 || q == 5); };
+        auto mine = [&](int q) { return (nj & 1) ? (q == 2 || q == 6 || q == 7 || q >= 12) : (q == 1 || q == 4 || q == 5 || (q >= 8 && q < 12)); };
         qi = run.have_heavy ? (heavy_chunk ? 0 : 2) : split_q ? ui : 1;
-        for (int q = qi + 1; q < 8; ++q) {
+        for (int q = qi + 1; q < NQ; ++q) {
           if (!Q[q] || (run.have_heavy && heavy_chunk != (q == 1 || q == 4 || q == 5))) continue;
           if (split_q && !mine(q)) continue;
           if (run.qload[q] < run.qload[qi]) qi = q;
@@ -311,7 +365,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
     if ((L.bs >= 300 && L.bs < 500) || L.bs == 604 || L.bs == 608) run.any_stripe = true;
     ++ctx->launches;
   }
-  for (int q = 0; q < 8; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
+  for (int q = 0; q < NQ; ++q) {  // the traceback stream collects every stream the chunk's DP ran on
     if (!used[q]) continue;
     ev.dpe[q] = next_event(ctx, run.evc);
     SDF_HIP(hipEventRecord(ev.dpe[q], Q[q]));
@@ -622,7 +676,7 @@ static int finish_batch(BatchRun &run, BatchRun *head, size_t n, sdf_result *d_o
     for (size_t ci = 0; ci < run.cev.size(); ++ci) {
       const ChunkEv &ev = run.cev[ci];
       if (!ev.dp0) continue;
-      for (int q = 0; q < 8; ++q)
+      for (int q = 0; q < 16; ++q)
         if (ev.dpe[q]) {
           float a = 0, b = 0;
           (void)hipEventElapsedTime(&a, run.ev_begin, ev.dp0);

@@ -28,6 +28,11 @@ struct PlanEnv {
   int max_dyn_lds = 64 * 1024;
   bool force_general = false, no_pair = false, no_stripe = false;
   size_t self_pair_max = 512;  // more tasks without a partner than this in a chunk: the wave kernel instead of pairing them with themselves (SDF_SELF_PAIR_MAX)
+  // mixed pairs (extz2_pair.hip, MIXED): banded tasks of one (w, flag) and different lengths two to a wavefront -- a
+  // throughput kernel: a chunk must hold `mixed_min` candidates (SDF_MIXED_MIN), and then its long banded tasks whose
+  // band reaches the end take it too, instead of the banded stripe kernel (SDF_NO_MIXED=1: off)
+  bool no_mixed = false;
+  size_t mixed_min = 4096;
   int stripe_min = 400;
   int bstripe_min_rows = 4000;  // banded tasks with at least this many anti-diagonals: banded stripe kernel (0: off)
   // lane kernel (extz2_lane.hip): small full-band tasks leave the host's planning altogether when the batch holds at least
@@ -163,7 +168,9 @@ struct PlanScratch {
   std::vector<int32_t> win_need, partner;
   std::vector<std::pair<int32_t, int32_t>> table;
   std::vector<plan_detail::Cls> cls;
-  std::vector<char> tracked;
+  std::vector<char> tracked, mixedf;
+  std::vector<int32_t> bs_alt;       // tasks given to the banded stripe kernel that a mixed pair could take: index, wave nreg, window need
+  std::vector<uint64_t> mix_keys;
   std::vector<int32_t> stripe_lane, stripe_fill;
   std::vector<uint64_t> strip_keys, strip_keys_tmp;
 };
@@ -192,12 +199,17 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   // (sixteen or twenty-four chunks for a million tasks were measured no better than eight)
   // (two, three or six chunks for the 100,000-task headline batch: within noise of four)
   if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? 8 : 4, n / 16384);
+  static const int force_nch = [] {
+    const char *e = getenv("SDF_CUT_NCH");  // (experiments: the number of ordinary chunks a large batch is cut into)
+    return e ? atoi(e) : 0;
+  }();
+  if (force_nch > 0 && cut.pipelined) cut.nch = (size_t)force_nch;
   cut.max_regions = cut.nch > 4 ? 8 : cut.nch > 1 ? 4 : 1;
-  const size_t nch = cut.nch;
+  bool chain_bound = false;  // (set after the scan: fewer chunks than the size of the batch alone would give)
+  const size_t nch_by_size = cut.nch;
   // the first chunk is small, so that the GPU starts early, but fills the wavefront slots of the device (4,096 pairs
   // of tasks of the headline shape) while the next chunks are being planned
-  const size_t first_target = nch > 1 ? std::max<size_t>(8192, n / (16 * nch + 1)) : n;
-  const size_t chunk_target = nch > 1 ? (n - first_target + nch - 1) / nch : n;
+  const size_t first_target0 = nch_by_size > 1 ? std::max<size_t>(8192, n / (16 * nch_by_size + 1)) : n;
 
   // A task is "heavy" when its wavefront (or workgroup) is busy for about a millisecond or more whatever else runs:
   // 500 x 500 and up at full band, i.e. from 256 KB of direction flags.
@@ -238,7 +250,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     struct Memo {
       int32_t qlen = -1, tlen = -1, w = 0, so = 0;
       uint32_t oc = 0, words = 0;
-      size_t bd = 0;
+      size_t bd = 0, hvb = 0;
     };
     struct Part {
       size_t nh = 0, hb = 0;
@@ -246,6 +258,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       Memo memo[256];
       int64_t words = 0;       // first pass: q + t + 2 of every task, the big tasks' launch-order entries, their number
       size_t big_oc = 0, nbig = 0;
+      int64_t rows_max = 0;    // anti-diagonals of the longest task accounted for
     };
     const size_t hv_limit = n / 4 + 1;
     // what a task needs of the chunks' budgets -- flag bytes whichever window kernel takes it, staging words, launch-order
@@ -254,12 +267,13 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       const sdf_task &t = tasks[k];
       BatchCut::Block &blk = cut.blocks[k / SDF_CUT_BLOCK];
       cap[k] = 0x80000000u;
+      pt.rows_max = std::max(pt.rows_max, (int64_t)t.qlen + t.tlen);
       Memo &mm = pt.memo[((uint32_t)t.qlen * 31u + (uint32_t)t.tlen * 17u + (uint32_t)t.w) & 255u];
       const int32_t so = t.flag & SDF_FLAG_SCORE_ONLY;
-      size_t bd = 0;
+      size_t bd = 0, hvb = 0;
       uint32_t oc, words;
       if (mm.qlen == t.qlen && mm.tlen == t.tlen && mm.w == t.w && mm.so == so) {
-        oc = mm.oc, words = mm.words, bd = mm.bd;
+        oc = mm.oc, words = mm.words, bd = mm.bd, hvb = mm.hvb;
         ++blk.nt;
         blk.oc += oc;
         cap[k] |= words;
@@ -280,8 +294,23 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       const size_t nrow = (size_t)t.qlen + t.tlen - 1;
       const int need = std::min(ncol16 + 32, (t.tlen + 15) / 16 * 16);
       if (with_dir) {
-        bd = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;
-        if (need <= 1024) bd = std::max(bd, (nrow + 15) / 16 * (size_t)((need + 127) / 128) * 1024);
+        // (the reference's byte per cell is the general kernel's layout: a task with nothing special asked of it, whose band
+        // reaches the end and whose window a register-resident kernel holds never goes there -- plan_chunk's `plain_ok`;
+        // for a batch of long banded tasks the byte rows are twice the bits, and the bound is what cuts it into chunks)
+        bool bits_only = false;
+        if (need <= 1024 && !env.force_general && !(env.want & SDF_WANT_EXT) && t.zdrop < 0 && env.gapo >= 0 &&
+            !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY | SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP)) &&
+            (w >= 1 || nrow == 1)) {
+          Band bl;
+          const int wn = need <= 128 ? 1 : need <= 256 ? 2 : need <= 384 ? 3 : need <= 512 ? 4 : need <= 768 ? 6 : 8;
+          bits_only = band_of((int)nrow - 1, t.qlen, t.tlen, w, bl) && wave_lds_bytes(t.qlen, t.tlen, wn) <= (size_t)env.max_dyn_lds;
+        }
+        hvb = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;  // (what "heavy" is measured by, whichever layout the task takes)
+        if (!bits_only) bd = hvb;
+        // (the wave kernel's blocks: 1 KiB per register of 128 slots -- 1, 2, 3, 4, 6 or 8 of them; the pair kernels' 512 B per
+        // register of 64 slots, up to nine, stay below)
+        if (need <= 1024)
+          bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 512 ? (need + 127) / 128 : need <= 768 ? 6 : 8) * 1024);
         // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
         if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
       }
@@ -303,11 +332,11 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         bd = std::max(bd, ((size_t)strip_blocks(t.tlen, t.tlen > kStripMaxT && env.strip_cols == 4 ? 4 : 8) *
                                (size_t)(t.qlen - t.qlen / 5 + 100) * 520 + 512 + 255) & ~(size_t)255);
       mm.qlen = t.qlen, mm.tlen = t.tlen, mm.w = t.w, mm.so = so;
-      mm.oc = oc, mm.words = words, mm.bd = bd;
+      mm.oc = oc, mm.words = words, mm.bd = bd, mm.hvb = hvb;
       }
       bound[k] = (uint32_t)std::min<size_t>(bd >> 8, 0xffffffffu);
       blk.bd += (uint64_t)bound[k] << 8;
-      if (bd >= heavy_min && may_be_heavy) {
+      if (std::max(bd, hvb) >= heavy_min && may_be_heavy) {
         ++pt.nh;
         pt.hb += bd;
         ++blk.hnt;
@@ -532,12 +561,35 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       return SDF_ERR_UNSUPPORTED;
     }
     if (!two_pass) cut_heavy();
+    // A launch lasts as long as its longest task -- a chain of qlen + tlen dependent rows, ~0.5 us each when the wavefront
+    // shares its SIMD -- whatever else runs: a chunk whose whole work is a few such chains long keeps the device waiting
+    // for one wavefront at the end of each of its launches (a batch of banded tasks of all lengths, BASELINE configs[4]:
+    // fourteen chunks 400-580 ms, one chunk 220 ms, profiles/r04_shapes.txt).  Such a batch is cut into fewer chunks:
+    // each at least six chains' worth of work (the bytes of the direction flags stand for the cells: ~0.65 B each at a
+    // Tcell/s), the workspace permitting.
+    if (!two_pass && !cut.split_heavy && cut.nch > 1 && !force_nch) {
+      int64_t rows_max = 0;
+      uint64_t bytes = 0;
+      for (int q = 0; q < nthr; ++q) rows_max = std::max(rows_max, parts[q].rows_max);
+      for (const BatchCut::Block &blk : cut.blocks) bytes += blk.bd;
+      const double chain_ms = (double)rows_max * 0.5e-3, work_ms = (double)bytes / 0.65e9;
+      const size_t nch_max = (size_t)std::max(1.0, work_ms / (6.0 * chain_ms));
+      if (nch_max < cut.nch) {
+        cut.nch = nch_max;
+        cut.max_regions = std::min<size_t>(4, cut.nch + 1);
+        chain_bound = true;
+      }
+    }
   }
   const auto tc1 = std::chrono::steady_clock::now();
   const size_t lane_budget = cut.use_lane ? cut.lane_dir_bytes + 256 : 0;
   const size_t region_budget = (ws_budget - heavy_budget - lane_budget) / cut.max_regions;
 
   // ---- chunk boundaries ----
+  const size_t nch = cut.nch;
+  const size_t first_target = nch_by_size > 1 ? first_target0 : n;
+  const size_t chunk_target = nch_by_size > 1 ? (n - first_target + nch - 1) / nch : n;
+  (void)chain_bound;
   std::vector<ChunkPlan> normal;
   {
     // whole blocks of tasks at a time (their sums come from the scan above); task by task only inside a block that
@@ -557,7 +609,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     for (size_t b = 0; b < nblk; ++b) {
       const size_t k0 = b * SDF_CUT_BLOCK, k1 = std::min(n, k0 + SDF_CUT_BLOCK);
       const BatchCut::Block &blk = cut.blocks[b];
-      const size_t target = normal.empty() && nch > 1 ? first_target : chunk_target;
+      const size_t target = normal.empty() && nch_by_size > 1 ? first_target : chunk_target;
       // (all tasks of the range count towards the target, as they cost planning time whether they run or not)
       if (k0 > cur.s && k0 - cur.s >= target) close_at(k0);
       const uint64_t bbd = blk.bd - (hv ? blk.hbd : 0);  // (lane tasks are not in a block's sums)
@@ -620,6 +672,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   std::vector<int32_t> &win_need = sx.win_need, &partner = sx.partner;
   std::vector<Cls> &cls = sx.cls;
   win_need.clear();
+  sx.bs_alt.clear();
   size_t np = c.pb;
   int64_t stage_words = c.stage0;
   size_t n_stripe_tasks = 0;   // stripe tasks of the chunk,
@@ -699,6 +752,14 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         if (nr && bstripe_lds_bytes(p.w, nr) <= (size_t)env.max_dyn_lds) {
           p.nreg = nr;
           p.pad_ = 7;
+          if (plain_ok && bneed <= kMixedMaxNeed && !env.no_pair && !env.no_mixed) {  // (band_whole: a mixed pair can take it)
+            const int wn = bneed <= 128 ? 1 : bneed <= 256 ? 2 : bneed <= 384 ? 3 : bneed <= 512 ? 4 : 6;
+            if (wave_lds_bytes(t.qlen, t.tlen, wn) <= (size_t)env.max_dyn_lds) {
+              sx.bs_alt.push_back((int32_t)(np - c.pb));
+              sx.bs_alt.push_back(wn);
+              sx.bs_alt.push_back(bneed);
+            }
+          }
         }
       }
       // the same request on a band that runs out before the end of both sequences: the pair kernel's TRACK flavour
@@ -814,6 +875,26 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     }
   }
 
+  // Mixed pairs are a throughput kernel (a wavefront of nine registers takes ~1.3 us per row when it shares its SIMD): the
+  // chunk's banded tasks take them when there are enough to fill the device, and then the long ones whose band reaches the
+  // end come back from the banded stripe kernel (0.73 VALU instructions per cell measured there against ~0.4-0.5 here,
+  // profiles/r04_mm8_pmc.txt); in a chunk of few tasks a long task stays a chain of short stripe rows.
+  bool use_mixed = false;
+  std::vector<char> &mixedf = sx.mixedf;
+  mixedf.assign(cnt, 0);
+  if (!env.no_pair && !env.no_mixed && !env.force_general) {
+    size_t ncand = sx.bs_alt.size() / 3;
+    for (size_t k = 0; k < cnt; ++k)
+      ncand += cp[k].nreg && cp[k].pad_ == 0 && win_need[k] > 0 && win_need[k] <= kMixedMaxNeed && cp[k].w < std::max(cp[k].qlen, cp[k].tlen);
+    use_mixed = ncand >= env.mixed_min;
+    if (use_mixed)
+      for (size_t j = 0; j + 2 < sx.bs_alt.size(); j += 3) {
+        PlanTask &p = cp[sx.bs_alt[j]];
+        p.pad_ = 0;
+        p.nreg = sx.bs_alt[j + 1];
+        win_need[sx.bs_alt[j]] = sx.bs_alt[j + 2];
+      }
+  }
   // Pair kernel: two wave-eligible tasks of the chunk with the same (qlen, tlen, w, flag) and a window of at
   // most 512 slots share a wavefront (extz2_pair.hip).  partner[k] = the other task, or -1.  One pass with an
   // open-addressing table keyed by the geometry: entry = (first task seen with the key, the task of that key
@@ -861,6 +942,99 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         c.paired += 2;
         e.second = -1;
         break;
+      }
+    }
+    if (use_mixed) {
+      // Mixed pairs: the tasks without a partner of their geometry (and those whose window of 513..576 slots no other pair
+      // kernel holds), sorted by (w, flag, last clip-free row): neighbours share the most rows.  Worth it when the shared
+      // rows are at least half of the longer task's (a row of a pair costs ~1.3 rows of the one-task wave kernel).
+      std::vector<uint64_t> &keys = sx.mix_keys;
+      keys.clear();
+      auto add_key = [&](size_t k) {
+        const PlanTask &y = cp[k];
+        if (y.w >= std::max(y.qlen, y.tlen) || y.w >= (1 << 14) || (y.flag & ~0xff) || k >= ((size_t)1 << 22)) return;
+        int cf = pair_clip_free(y.qlen, y.tlen, y.w);
+        cf = cf < 0 ? 0 : cf > 0xfffff ? 0xfffff : cf;
+        keys.push_back(((uint64_t)(uint32_t)y.w << 50) | ((uint64_t)(uint32_t)(y.flag & 0xff) << 42) | ((uint64_t)cf << 22) | (uint64_t)k);
+      };
+      for (auto &e : table)
+        if (e.second >= 0) add_key((size_t)e.second);
+      for (size_t k = 0; k < cnt; ++k)
+        if (cp[k].nreg && cp[k].pad_ == 0 && win_need[k] > 512 && win_need[k] <= kMixedMaxNeed) add_key(k);
+      // (a batch of few geometries -- the headline's 100,000 tasks of ~50 target lengths -- leaves a handful without a
+      // partner: they are paired with themselves inside the tuned launch, as before, not given a launch of their own)
+      if (keys.size() * 16 < cnt) keys.clear();
+      std::sort(keys.begin(), keys.end());
+      for (size_t q = 0; q + 1 < keys.size();) {
+        const size_t a = (size_t)(keys[q] & 0x3fffffu), b = (size_t)(keys[q + 1] & 0x3fffffu);
+        PlanTask &x = cp[a], &y = cp[b];
+        bool ok = (keys[q] >> 42) == (keys[q + 1] >> 42);  // same band and flags
+        int nreg = 0;
+        if (ok) {
+          const int shared = (x.qlen == y.qlen && x.tlen == y.tlen) ? x.qlen + x.tlen : pair_shared_rows(x.qlen, x.tlen, y.qlen, y.tlen, x.w);
+          ok = 2 * shared >= std::max(x.qlen + x.tlen, y.qlen + y.tlen);
+          const int regs = (std::max(win_need[a], win_need[b]) + 63) / 64;
+          nreg = regs <= 2 ? 2 : regs <= 6 ? regs : regs <= 8 ? 8 : 9;
+          ok = ok && pair_mixed_lds_bytes(std::max(x.qlen, y.qlen), std::max(x.tlen, y.tlen), nreg) <= (size_t)env.max_dyn_lds;
+        }
+        if (!ok) {
+          ++q;
+          continue;
+        }
+        x.nreg = y.nreg = nreg;
+        x.pad_ = y.pad_ = 2;
+        partner[a] = (int32_t)b;
+        partner[b] = (int32_t)a;
+        mixedf[a] = mixedf[b] = 1;
+        c.paired += 2;
+        q += 2;
+      }
+      // ... and what is left of them: a long task alone would be a launch of its own on the one-task kernels, as long as its
+      // chain of rows; paired with itself it is one more wavefront of the mixed launch (a short one keeps its old routes)
+      size_t n_mixed = 0;
+      for (size_t q = 0; q < keys.size(); ++q) {
+        const size_t a = (size_t)(keys[q] & 0x3fffffu);
+        if (partner[a] >= 0) {
+          ++n_mixed;
+          continue;
+        }
+        PlanTask &x = cp[a];
+        if (x.qlen + x.tlen < 2000) continue;
+        const int regs = (win_need[a] + 63) / 64;
+        const int nreg = regs <= 2 ? 2 : regs <= 6 ? regs : regs <= 8 ? 8 : 9;
+        if (pair_mixed_lds_bytes(x.qlen, x.tlen, nreg) > (size_t)env.max_dyn_lds) continue;
+        x.nreg = nreg;
+        x.pad_ = 2;
+        partner[a] = (int32_t)a;
+        mixedf[a] = 1;
+      }
+      // pairs of equal geometry among the banded tasks join the mixed launches when they are the few (a batch of tasks of all
+      // lengths: one launch fewer per register count, each as long as its longest chain); a batch of few geometries keeps
+      // its tuned instantiations
+      size_t n_exact = 0;
+      for (size_t k = 0; k < cnt; ++k)
+        n_exact += cp[k].pad_ == 2 && !mixedf[k] && !tracked[k] && partner[k] >= 0 && partner[k] != (int32_t)k && cp[k].w < std::max(cp[k].qlen, cp[k].tlen);
+      if (n_exact * 4 <= n_mixed)
+        for (size_t k = 0; k < cnt; ++k) {
+          PlanTask &x = cp[k];
+          if (x.pad_ != 2 || mixedf[k] || tracked[k] || partner[k] <= (int32_t)k || x.w >= std::max(x.qlen, x.tlen)) continue;
+          const int regs = (win_need[k] + 63) / 64;
+          const int nreg = regs <= 2 ? 2 : regs <= 6 ? regs : regs <= 8 ? 8 : 9;
+          if (pair_mixed_lds_bytes(x.qlen, x.tlen, nreg) > (size_t)env.max_dyn_lds) continue;
+          x.nreg = cp[partner[k]].nreg = nreg;
+          mixedf[k] = mixedf[partner[k]] = 1;
+        }
+      for (auto &e : table)  // (no longer waiting)
+        if (e.second >= 0 && partner[e.second] >= 0) e.second = -1;
+      // a long task that came over from the banded stripe kernel and found nobody goes back to it
+      for (size_t j = 0; j + 2 < sx.bs_alt.size(); j += 3) {
+        const int32_t k = sx.bs_alt[j];
+        if (partner[k] >= 0) continue;
+        cp[k].pad_ = 7;
+        cp[k].nreg = plan_detail::bstripe_nreg(cp[k].tlen);
+        win_need[k] = 0;
+        for (auto &e : table)
+          if (e.second == k) e.second = -1;
       }
     }
     // a task left without a partner is paired with itself (both halves compute the same task and write the
@@ -1003,8 +1177,9 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     } else if (p.pad_ == 2) {
       if (partner[k] < (int32_t)k) continue;  // placed together with its partner
       // 100 + NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
-      bs = tracked[k] ? 120 + p.nreg : 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
-      need = pair_lds_bytes(p.qlen, p.tlen, p.nreg);
+      bs = tracked[k] ? 120 + p.nreg : mixedf[k] ? 130 + p.nreg : 100 + p.nreg + (pair_fits_whole(p.qlen, p.tlen, p.nreg) ? 0 : 10);
+      need = mixedf[k] ? pair_mixed_lds_bytes(std::max(p.qlen, cp[partner[k]].qlen), std::max(p.tlen, cp[partner[k]].tlen), p.nreg)
+                       : pair_lds_bytes(p.qlen, p.tlen, p.nreg);
       lds = 8192;
       while (lds < need) lds *= 2;
     } else if (p.pad_ == 5) {
@@ -1077,7 +1252,8 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   // inside a launch of few tasks the longest go first too (workgroups are dispatched in order: a long task that
   // starts last is the tail of the launch); pair-kernel entries move as (task, partner) units
   for (auto &x : cls) {
-    if (x.idx.size() >= 8192 || x.idx.size() < 3) continue;
+    const bool mixed_cls = x.bs >= 130 && x.bs < 140;  // (long and short tasks in one launch: the long chains start first)
+    if ((x.idx.size() >= 8192 && !mixed_cls) || x.idx.size() < 3) continue;
     auto work = [&](int32_t k) { return (int64_t)(cp[k].qlen + cp[k].tlen) * cp[k].ncol16; };
     int64_t wmin = work(x.idx[0]), wmax = wmin;
     for (int32_t k : x.idx) {

@@ -1170,3 +1170,46 @@ def test_many_unpaired_banded_tasks_take_the_wave_kernel(engine, oracle):
     _check_fast(engine, oracle, pairs, ws)
     assert engine.last_paired() == 0
     _check_fast(engine, oracle, pairs[:300], ws[:300])  # few of them: paired with themselves, as before
+
+
+def _mixed_length_tasks(rng, n, ws, lo, hi, n_frac=0.01):
+    """Banded tasks of the bands `ws` and lengths lo..hi (log-uniform), targets mutated copies with the odd indel or
+    unrelated stretch -- and |qlen - tlen| small enough for most bands to reach the corner."""
+    pairs, out_w = [], []
+    for _ in range(n):
+        w = int(rng.choice(ws))
+        ql = int(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+        q = random_codes(rng, ql, n_frac if rng.random() < 0.3 else 0.0)
+        d = float(rng.choice([0.0, 0.02, 0.1, 0.3]))
+        t = mutate(rng, q, d, d / 4, d / 4)
+        if rng.random() < 0.3 and len(t) > 60:
+            k, L = int(rng.integers(0, len(t) - 10)), int(rng.integers(1, max(2, w // 2)))
+            t = np.concatenate([t[:k], random_codes(rng, L), t[k:]]) if rng.random() < 0.5 else np.concatenate([t[:k], t[k + L:]])
+        if len(t) == 0:
+            t = random_codes(rng, 1)
+        pairs.append((q, t))
+        out_w.append(w)
+    return pairs, out_w
+
+
+def test_mixed_pairs_banded_tasks_of_different_lengths(oracle):
+    """Round 4: two banded tasks of one (w, flag) and DIFFERENT lengths per wavefront (extz2_pair.hip, MIXED): the rows on
+    which neither task's sequence ends clip the band run side by side, each task's last ~w rows alone.  Every register
+    count (2..9: windows of up to 576 slots, w = 512), sequences longer than the LDS windows, bands at the 16-cell
+    block edges, N runs, indels at the band edge, tasks whose band runs out in the same batch (they keep their routes)."""
+    eng = _engine_with_env(SDF_MIXED_MIN=2)
+    rng = np.random.default_rng(4104)
+    pairs, ws = _mixed_length_tasks(rng, 700, [15, 16, 17, 31, 33, 64, 100, 128, 129, 200, 256, 300, 448, 512], 40, 1500)
+    p2, w2 = _mixed_length_tasks(rng, 60, [64, 128, 256, 512], 2000, 4200)  # (4000+ rows: back from the banded stripe kernel)
+    pairs, ws = pairs + p2, ws + w2
+    _check_fast(eng, oracle, pairs, ws)
+    assert eng.last_paired() >= 500
+    off = _engine_with_env(SDF_NO_MIXED=1)
+    _check_fast(off, oracle, pairs[:200], ws[:200])
+    assert off.last_paired() < eng.last_paired()
+    # other scorings (the bytes wrap), score-only tasks next to CIGAR tasks
+    sc = dict(mat=sedef_mat(2, -7), gapo=6, gape=3)
+    _check_fast(eng, oracle, pairs[:300], ws[:300], **sc)
+    _check_fast(eng, oracle, pairs[:300], ws[:300], mat=sedef_mat(11, -9), gapo=55, gape=4)
+    flags = [int(rng.choice([0, 0, 1])) for _ in range(300)]
+    _check_fast(eng, oracle, pairs[300:600], ws[300:600], flags=flags)
