@@ -470,8 +470,22 @@ def main():
         raise SystemExit("bench.py: rank %d wants device %d, %d visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (with --gpus 1): the distributed path on ONE rank -- the nccl (= RCCL) backend initialised on the
+    # device, every step through ResultGatherV on device tensors (count all-gather on RCCL, stream ordering through wait(),
+    # the rank's own part compared) and, with BENCH_LOOPBACK unset or 1, the rank's two ranges sent to itself through the
+    # communicator's point-to-point pair: what a box with one GPU can execute of the N > 1 path.
+    force_dist = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            import socket
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         if debug_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -523,9 +537,13 @@ def main():
     copy_done = [None] * nsets
 
     gathers = []
-    if world > 1:
+    loopback_note = None
+    if dist_on:
         gdev = torch.device("cpu") if debug_one_gpu else dev
         gathers = [ResultGatherV(gdev, torch.int32) for _ in range(nsets)]
+        for g in gathers:  # (receive buffers at their high-water mark from the start: no step allocates)
+            g.reserve(world * n * 16 + 16, world * cig_cap + 16)
+            g.loopback = force_dist and os.environ.get("BENCH_LOOPBACK", "1") == "1"
     step_no = [0]
     last_used = [0] * nsets
 
@@ -557,10 +575,19 @@ def main():
         for g in gathers:
             g.wait()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if gathers and gathers[0].loopback:
+        try:  # (a send to oneself inside a group: if this build of the backend refuses it, the count all-gather still runs)
+            step()
+            sync()
+        except Exception as ex:  # noqa: BLE001
+            loopback_note = "refused by the backend: %s" % (str(ex).splitlines()[0][:160],)
+            for g in gathers:
+                g.loopback, g.handles = False, []
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync()
@@ -577,7 +604,7 @@ def main():
         launches += eng.last_launches()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         rdev = torch.device("cpu") if debug_one_gpu else dev
         tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -595,6 +622,10 @@ def main():
     if gathers:  # every rank holds every rank's results: this rank's own part of the last gather is what it computed
         pr, pc = gathers[lb].part(rank)
         assert torch.equal(pr.cpu(), h_outs[lb]) and torch.equal(pc.cpu(), h_cigs[lb][:used])
+        if gathers[lb].loopback:  # what came back through the send / receive pair is what went out
+            lr, lc = gathers[lb].loopback_part()
+            assert torch.equal(lr.cpu(), h_outs[lb]) and torch.equal(lc.cpu(), h_cigs[lb][:used])
+            loopback_note = "records and CIGAR words sent to this rank itself through the communicator: equal"
         if whole is not None and rank == 0:
             # --strong: the union of the shards against ONE GPU aligning the whole batch (untimed)
             wpool, wq_off, wqlen, wt_off, wtlen, _ = whole
@@ -710,11 +741,13 @@ def main():
             "data": "synthetic",
             "value_incl_pcie": incl_pcie,
             "timed_region": "planning + DP + traceback + CIGAR compaction + result D2H (pinned, double-buffered under the "
-                            "next step)" + (" + all-gatherv of records and CIGARs" if world > 1 else ""),
+                            "next step)" + (" + all-gatherv of records and CIGARs" if dist_on else ""),
             "config": {"workload": wl, "tasks_this_rank": n, "band": int(w) if np.ndim(w) == 0 else "mixed",
                        "cells_per_step_this_rank": cells_rank, "cells_per_step_all_ranks": cells_all,
                        "parallelism": "task-sharded x%d + all-gatherv of result records" % world,
-                       "union_check": union_check},
+                       "union_check": union_check,
+                       "dist_backend": (dist.get_backend() if dist_on else None),
+                       "forced_dist_one_rank": force_dist or None, "loopback": loopback_note},
             "kernel_ms_per_step": {"dp_launches": launches / args.steps,
                                    "dp": round(dp_ms / args.steps, 3), "traceback": round(tb_ms / args.steps, 3),
                                    "compact": round(cp_ms / args.steps, 3),
@@ -732,10 +765,12 @@ def main():
                          "launches": iso_launches, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "valu_issue": valu},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # (at every N: rank 0's shard on this box's host cores while the other ranks wait at the barrier below -- the
+            # ratio to quote is value / cpu_baseline.value per cpu_baseline.cores cores)
             line["cpu_baseline"] = cpu_baseline(pool, q_off, qlen, t_off, tlen, cells_task, w)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -414,7 +414,18 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
     o.n_cigar = 0;
     o.cigar_off = 0;
     o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
-    res[lane ? tkb.out_idx : tka.out_idx] = o;
+    // (n_cigar is where a block that gave up marks the task, -1: the blocks to the right of this one watch task A's record
+    // only and may have marked both tasks already -- the record goes out around that field, which the batch's reset left 0,
+    // so that the mark stays and nobody appends the task to the give-up list a second time)
+    sdf_result *dst = res + (lane ? tkb.out_idx : tka.out_idx);
+    const int keep = __hip_atomic_load(&dst->n_cigar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    o.n_cigar = keep == -1 ? -1 : 0;
+    const int32_t *src = reinterpret_cast<const int32_t *>(&o);
+    int32_t *out = reinterpret_cast<int32_t *>(dst);
+    constexpr int at = offsetof(sdf_result, n_cigar) / 4;
+#pragma unroll
+    for (int f = 0; f < (int)(sizeof(sdf_result) / 4); ++f)
+      if (f != at) out[f] = src[f];
   }
 }
 

@@ -72,7 +72,7 @@ __device__ __forceinline__ void st_agent(T *p, T v) {
 // stripes of the task see the mark within 64 polls and end too.  The batch call re-runs abandoned tasks on the
 // one-wavefront / one-workgroup kernels (sdf_launch.hip: rerun_abandoned).
 #define SDF_GAVEUP_LIST 32   // (in 64-bit words behind the counter: the list of abandoned tasks, 32-bit entries)
-#define SDF_GAVEUP_CAP 1024  // entries of the list
+#define SDF_GAVEUP_CAP 65536  // entries of the list (beyond it the batch call fails: "more tasks than can be re-run")
 #define SDF_MISC_PARTS (1 + SDF_GAVEUP_LIST + SDF_GAVEUP_CAP / 2)  // (64-bit words of the context's misc buffer before the scan's partial sums)
 __device__ __forceinline__ void stripe_abandon(unsigned long long *gave_up, sdf_result *rec, int out_idx, int lane) {
   if (lane != 0) return;

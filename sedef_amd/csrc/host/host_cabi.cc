@@ -72,10 +72,20 @@ long sdfh_stats_generate(const char *ref_path, const char *bed_path, const char 
     sp.min_split = min_split;
     sp.min_uppercase = min_uppercase;
     sp.max_scaled_error = max_error;
-    FILE *out = fopen(out_path, "w");
-    if (!out) throw std::string("Cannot open output ") + out_path;
-    const long lines = stats_generate(ref_path, bed_path, out, sp, test_cols, device, stats);
-    fclose(out);
+    struct Out {  // (closed on every path; a run that throws leaves no truncated table behind -- ADVICE r3)
+      FILE *f = nullptr;
+      std::string path;
+      bool done = false;
+      ~Out() {
+        if (f) fclose(f);
+        if (f && !done) remove(path.c_str());
+      }
+    } out;
+    out.path = out_path;
+    out.f = fopen(out_path, "w");
+    if (!out.f) throw std::string("Cannot open output ") + out_path;
+    const long lines = stats_generate(ref_path, bed_path, out.f, sp, test_cols, device, stats);
+    out.done = true;
     return lines;
   } catch (std::string &s) {
     g_err = s;

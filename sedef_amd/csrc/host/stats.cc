@@ -251,7 +251,9 @@ long stats_generate(const std::string &ref_path, const std::string &bed_path, FI
     if (!(c.uppercase_a >= sp.min_uppercase && c.uppercase_b >= sp.min_uppercase && !too_big_overlap &&
           errorScaled <= sp.max_scaled_error && c.uppercase_matches >= sp.min_uppercase))
       continue;
-    Hit hb;  // to_bed(false, false) of the piece with name "S" and no comment (:311-313)
+    Hit hb;  // to_bed(false, false) of the piece with name "S" and no comment (:311-313; the reference passes &fr for its
+             // translation_index, src/hit.cc:144-171, which nothing in the reference ever fills -- src/fasta.h:54 is its only
+             // other mention -- so the renaming branch is dead there and has no counterpart here)
     hb.query = h.query;
     hb.ref = h.ref;
     hb.query_start = h.query_start;

@@ -182,6 +182,12 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   return ctx;
 }
 
+void mark_internal_context(sdf_ctx *c) {
+  if (!c || c->is_part) return;
+  c->is_part = true;
+  g_live_contexts.fetch_sub(1);
+}
+
 extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (!ctx) return;
   if (!ctx->is_part) g_live_contexts.fetch_sub(1);
@@ -667,8 +673,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
     if (!ctx->part_ctx) {
       ctx->part_ctx = sdf_create(ctx->device, ctx->ws_budget / 4);
       if (ctx->part_ctx) {
-        ctx->part_ctx->is_part = true;
-        g_live_contexts.fetch_sub(1);  // (a part context is not another user of the process's CPUs)
+        mark_internal_context(ctx->part_ctx);  // (a part context is not another user of the process's CPUs)
         ctx->part_ctx->force_general = ctx->force_general;
         ctx->part_ctx->no_pair = ctx->no_pair;
         ctx->part_ctx->self_pair_max = ctx->self_pair_max;
@@ -683,8 +688,13 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
         ctx->part_ctx->chain_min = ctx->chain_min;
       }
     }
-    if (sdf_ctx *pc = ctx->part_ctx) {
-      n_first = split_asked ? (n / split_div + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK * SDF_CUT_BLOCK : 2 * SDF_CUT_BLOCK;
+    // (a batch of fewer than two blocks has no second part: SDF_SPLIT_MIN below 4,096 tasks would otherwise round the first
+    // part up past the end of the batch -- ADVICE r3)
+    size_t want_first = split_asked ? (n / split_div + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK * SDF_CUT_BLOCK : 2 * SDF_CUT_BLOCK;
+    if (n >= 2 * SDF_CUT_BLOCK && want_first + SDF_CUT_BLOCK > n) want_first = (n - SDF_CUT_BLOCK) / SDF_CUT_BLOCK * SDF_CUT_BLOCK;
+    sdf_ctx *pc = n >= 2 * SDF_CUT_BLOCK && want_first >= SDF_CUT_BLOCK ? ctx->part_ctx : nullptr;
+    if (pc) {
+      n_first = want_first;
       // the part's stream starts where the caller's stream is
       if (ctx->part_ev == nullptr) (void)hipEventCreate(&ctx->part_ev);
       SDF_HIP(hipEventRecord(ctx->part_ev, st));

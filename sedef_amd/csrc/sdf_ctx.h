@@ -282,6 +282,10 @@ struct sdf_ctx {
   long long reran = 0;            // tasks of the last batch call that were re-run after a stripe gave up
 };
 
+// a context another context owns (the first part of a split batch, the re-run of abandoned stripe tasks): not another
+// user of the process's CPUs (defined in sdf_api.hip)
+void mark_internal_context(sdf_ctx *c);
+
 #define SDF_HIP(call)                                                                          \
   do {                                                                                         \
     hipError_t e_ = (call);                                                                    \

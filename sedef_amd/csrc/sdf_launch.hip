@@ -455,6 +455,10 @@ static int rerun_abandoned(BatchRun &run, unsigned long long count) {
   SDF_HIP(hipMemcpyAsync(idx.data(), d_gave + SDF_GAVEUP_LIST, count * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   SDF_HIP(hipStreamSynchronize(st));
   std::sort(idx.begin(), idx.end());
+  // (a task can stand in the list twice: a block that still held a task's last column may have written the task's
+  // record over the mark of a block that had given up, and a third block then marked it again -- ADVICE r3)
+  idx.erase(std::unique(idx.begin(), idx.end()), idx.end());
+  count = idx.size();
   // their plan entries (staging slots): one pass over the batch's plan
   std::vector<RerunMap> map(count);
   std::vector<sdf_task> sub(count);
@@ -479,6 +483,18 @@ static int rerun_abandoned(BatchRun &run, unsigned long long count) {
       ctx->err = "cannot create the context that re-runs the tasks a stripe kernel gave up";
       return SDF_ERR_NOMEM;
     }
+    // (like a part context: not another user of the process's CPUs -- the split rule and the planner's thread count look at
+    // the number of live contexts --, and with the parent's planner switches, not the environment's -- ADVICE r3)
+    mark_internal_context(ctx->rerun_ctx);
+    ctx->rerun_ctx->force_general = ctx->force_general;
+    ctx->rerun_ctx->no_pair = ctx->no_pair;
+    ctx->rerun_ctx->no_mixed = ctx->no_mixed;
+    ctx->rerun_ctx->mixed_min = ctx->mixed_min;
+    ctx->rerun_ctx->self_pair_max = ctx->self_pair_max;
+    ctx->rerun_ctx->lane_enabled = ctx->lane_enabled;
+    ctx->rerun_ctx->lane_min = ctx->lane_min;
+    ctx->rerun_ctx->strip_enabled = ctx->strip_enabled;
+    ctx->rerun_ctx->strip_always = false;
     ctx->rerun_ctx->no_stripe = true;
     ctx->rerun_ctx->bstripe_min_rows = 0;
   }

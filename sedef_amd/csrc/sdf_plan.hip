@@ -241,7 +241,10 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     return env.bstripe_min_rows > 0 && t.w >= 1 && t.qlen + t.tlen - 1 >= env.bstripe_min_rows && plan_detail::bstripe_nreg(t.tlen) > 0;
   };
   auto order_entries = [&](const sdf_task &t) -> uint32_t {  // a task paired with itself is listed twice, a stripe task
-    return 2 + (t.tlen > env.stripe_min && t.tlen <= 8192 ? (uint32_t)(t.tlen + 127) / 128 : 0u) +  // once per stripe
+    // (chained strips take full-band targets of 513..8192 bases whatever stripe_min is: eight idle entries of padding per
+    // block at most -- ADVICE r3: with SDF_STRIPE_MIN above 512 their launch order overflowed)
+    const bool chain = env.strip_ok && t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT;
+    return 2 + (t.tlen > env.stripe_min && t.tlen <= 8192 ? (uint32_t)(t.tlen + 127) / 128 : chain ? 8u * (uint32_t)strip_blocks(t.tlen, 4) : 0u) +  // once per stripe
            (banded_long(t) ? (uint32_t)(t.tlen + 15 + 127) / 128 : 0u);
   };
   {

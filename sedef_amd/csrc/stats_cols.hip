@@ -242,18 +242,22 @@ __global__ __launch_bounds__(64 * STATS_WAVES, 6) void stats_columns_kernel(cons
       int bad = 0;
       for (unsigned sg = 0; sg < nseg; ++sg) {
         const unsigned k0 = sg * STATS_SEG, nk = T.n_cigar - k0 < STATS_SEG ? T.n_cigar - k0 : STATS_SEG;
-        int da = 0, db = 0, wrong = 0;
+        // (512 runs of up to 2^24 columns add up to 2^33: the low twelve bits and the rest of every length are summed apart --
+        // each sum stays below 2^21 -- and put together in 64 bits; a segment of 2^31 columns or more does not fit its item)
+        int da_lo = 0, da_hi = 0, db_lo = 0, db_hi = 0, wrong = 0;
 #pragma unroll
         for (unsigned q = 0; q < STATS_SEG / 64; ++q) {
           const unsigned k = q * 64 + lane;
           const uint32_t w = k < nk ? cg[k0 + k] : 0u;
           const uint32_t op = w & 15u, len = w >> 4;
           wrong |= op > 2 || len > (1u << 24);
-          da += op != 2 ? (int)len : 0;
-          db += op != 1 ? (int)len : 0;
+          da_lo += op != 2 ? (int)(len & 4095u) : 0, da_hi += op != 2 ? (int)(len >> 12) : 0;
+          db_lo += op != 1 ? (int)(len & 4095u) : 0, db_hi += op != 1 ? (int)(len >> 12) : 0;
         }
-        da = stats_wave_sum(da), db = stats_wave_sum(db);  // (<= 512 runs of <= 2^24: the sums may wrap only when `wrong` anyway)
-        bad |= __any(wrong) || da < 0 || db < 0 || ia + (uint64_t)da > T.a_len || ib + (uint64_t)db > T.b_len;
+        const int64_t da64 = ((int64_t)stats_wave_sum(da_hi) << 12) + stats_wave_sum(da_lo);
+        const int64_t db64 = ((int64_t)stats_wave_sum(db_hi) << 12) + stats_wave_sum(db_lo);
+        const int da = (int)(da64 > 0x7fffffff ? 0x7fffffff : da64), db = (int)(db64 > 0x7fffffff ? 0x7fffffff : db64);
+        bad |= __any(wrong) || da64 > 0x7ffffffe || db64 > 0x7ffffffe || ia + (uint64_t)da64 > T.a_len || ib + (uint64_t)db64 > T.b_len;
         if (lane == 0) {
           StatsItem it;
           it.t.a_off = T.a_off + ia, it.t.b_off = T.b_off + ib;

@@ -83,6 +83,26 @@ class ResultGatherV:
         self.counts = None
         self.handles = []
         self.keep = None
+        # the counts come to the host through pinned memory behind an event: the host waits for that copy alone, not for
+        # the device (a `.cpu()` of the table synchronises the whole current stream)
+        self.on_gpu = torch.device(device).type == "cuda"
+        self.counts_host = torch.zeros(self.world * 2, dtype=torch.int64)
+        if self.on_gpu:
+            self.counts_host = self.counts_host.pin_memory()
+            self.counts_ev = torch.cuda.Event()
+        # loopback (world == 1 only, bench.py's BENCH_FORCE_DIST=1): this rank's two ranges also travel to ITSELF through
+        # the communicator's send / receive pair, into buffers of their own -- the point-to-point path of the all-gatherv
+        # on a box with one GPU
+        self.loopback = False
+        self.loop_recs = self.loop_cig = None
+
+    def reserve(self, rec_words, cig_words):
+        """Sizes the receive buffers once (all ranks' records and CIGAR words): no step allocates after this."""
+        import torch
+        if self.recs.numel() < rec_words:
+            self.recs = torch.empty(int(rec_words), dtype=self.dtype, device=self.device)
+        if self.cig.numel() < cig_words:
+            self.cig = torch.empty(int(cig_words), dtype=self.dtype, device=self.device)
 
     def start(self, records, cigars, used):
         import torch
@@ -94,7 +114,13 @@ class ResultGatherV:
         self.mine[0] = records.numel()
         self.mine[1] = used
         dist.all_gather_into_tensor(self.counts_dev, self.mine, group=self.group)
-        counts = self.counts_dev.view(self.world, 2).cpu()
+        if self.on_gpu:
+            self.counts_host.copy_(self.counts_dev, non_blocking=True)
+            self.counts_ev.record()
+            self.counts_ev.synchronize()
+        else:
+            self.counts_host.copy_(self.counts_dev)
+        counts = self.counts_host.view(self.world, 2).clone()
         self.counts = counts
         rec_off = np.concatenate([[0], np.cumsum(counts[:, 0].numpy())])
         cig_off = np.concatenate([[0], np.cumsum(counts[:, 1].numpy())])
@@ -122,7 +148,20 @@ class ResultGatherV:
                     ops.append(dist.P2POp(dist.isend, buf[off[me]:off[me + 1]], peer, self.group))
                 if off[r + 1] > off[r]:
                     ops.append(dist.P2POp(dist.irecv, buf[off[r]:off[r + 1]], peer, self.group))
+        if self.loopback and self.world == 1:
+            if self.loop_recs is None or self.loop_recs.numel() < rec_off[1] or self.loop_cig.numel() < cig_off[1]:
+                self.loop_recs, self.loop_cig = torch.empty_like(self.recs), torch.empty_like(self.cig)
+            peer = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            for buf, dst, off in ((self.recs, self.loop_recs, rec_off), (self.cig, self.loop_cig, cig_off)):
+                if off[1] > off[0]:
+                    ops.append(dist.P2POp(dist.isend, buf[off[0]:off[1]], peer, self.group))
+                    ops.append(dist.P2POp(dist.irecv, dst[off[0]:off[1]], peer, self.group))
         self.handles = dist.batch_isend_irecv(ops) if ops else []
+
+    def loopback_part(self):
+        """(records, CIGAR words) as they arrived through the loopback transfers of the last `start`."""
+        self.wait()
+        return self.loop_recs[:int(self.rec_off[1])], self.loop_cig[:int(self.cig_off[1])]
 
     def wait(self):
         for h in self.handles:

@@ -45,3 +45,17 @@ def test_bench_refuses_more_ranks_than_devices():
     p = _run("--gpus", str(n))
     assert p.returncode != 0 and p.stdout.strip() == ""
     assert "visible" in p.stderr
+
+
+def test_bench_forced_dist_one_rank_runs_the_nccl_backend():
+    """BENCH_FORCE_DIST=1 python bench.py --gpus 1: the nccl (= RCCL) backend initialised on the device with one rank, every
+    step through ResultGatherV on DEVICE tensors -- the count all-gather on RCCL, the stream ordering through wait(), the
+    rank's own part equal to what it computed -- and the rank's two ranges sent to itself through the communicator's
+    send / receive pair (or the backend's refusal noted): what a box with one GPU can execute of the N > 1 path."""
+    p = _run("--gpus", "1", "--tasks", "20000", "--steps", "3", "--warmup", "1", "--no-pcie-pass", BENCH_FORCE_DIST="1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["dist_backend"] == "nccl" and d["config"]["forced_dist_one_rank"] is True
+    assert "all-gatherv" in d["timed_region"]
+    assert d["config"]["loopback"]  # either "... equal" or the backend's refusal, spelled out
+    assert d["cpu_baseline"]["value"] > 0

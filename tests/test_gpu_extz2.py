@@ -987,7 +987,7 @@ def test_stripe_wait_gives_up_and_tasks_run_again(oracle):
     # the same context again, a larger batch (heavy split, several chunks): the counters of a call start at zero
     pairs2, ws2 = pairs * 40, ws * 40
     res2, cig2 = eng.align_pairs(pairs2, w=ws2, want=want)
-    assert 100 <= eng.last_reran() <= 1024  # (the give-up list holds 1,024 tasks; beyond that the call fails)
+    assert 100 <= eng.last_reran() <= 1024  # (the give-up list holds 65,536 tasks; beyond that the call fails)
     exp = [oracle.extz2(q, t, w=w) for (q, t), w in zip(pairs, ws)]
     for k, r in enumerate(res2):
         e = exp[k % len(pairs)]
