@@ -3,7 +3,9 @@
 // Restates generate_anchors (reference: src/chain.cc:24-101) as sort / search / scan kernels and returns the
 // anchors in the reference's order (query position ascending, then reference position ascending):
 //   1. every reference k-mer (2 bits per base, windows with an N skipped, :28-40) becomes a 64-bit key
-//      pair:20 | hash:22 | position:22; one radix sort groups equal k-mers of a pair, positions ascending;
+//      pair | hash (2k bits) | position (as many bits as the call's longest reference needs); one radix sort over the
+//      bits in use groups equal k-mers of a pair, positions ascending.  A call whose pairs do not fit the bits left of
+//      hash and position (k up to 15, references up to 2 Gb) is run range of pairs by range of pairs (sdf_api.hip);
 //   2. every query k-mer finds its run of equal keys by binary search; runs of >= 1000 are disabled (:61);
 //   3. an exclusive scan of the run lengths enumerates the candidate (q, r) pairs in reference order;
 //   4. a candidate starts an anchor iff no earlier enabled k-mer of the same uninterrupted match run lies on its
@@ -41,14 +43,17 @@ __device__ __forceinline__ bool kmer_at(const char *s, int k, uint32_t &h) {
   return ok;
 }
 
-__global__ __launch_bounds__(256) void ref_keys_kernel(const AnchorPairDev *pairs, const char *pool, int k,
-                                                       unsigned long long *keys) {
-  const AnchorPairDev p = pairs[blockIdx.y];
+// (grid: x = 32 blocks over a pair's k-mers, y x z = the pairs, 65,535 rows per layer; pos_bits: bits of the position field)
+__global__ __launch_bounds__(256) void ref_keys_kernel(const AnchorPairDev *pairs, int npairs, const char *pool, int k,
+                                                       int pos_bits, unsigned long long *keys) {
+  const unsigned pr = blockIdx.z * 65535u + blockIdx.y;
+  if (pr >= (unsigned)npairs) return;
+  const AnchorPairDev p = pairs[pr];
   const int nk = p.rlen - k + 1;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
     uint32_t h;
     const bool ok = kmer_at(pool + p.r_off + i, k, h);
-    keys[p.rk_start + i] = ok ? (((unsigned long long)blockIdx.y << 44) | ((unsigned long long)h << 22) | (unsigned)i)
+    keys[p.rk_start + i] = ok ? (((unsigned long long)pr << (2 * k + pos_bits)) | ((unsigned long long)h << pos_bits) | (unsigned)i)
                               : ~0ull;
   }
 }
@@ -62,20 +67,24 @@ __device__ __forceinline__ long long lower_bound_u64(const unsigned long long *a
   return lo;
 }
 
-__global__ __launch_bounds__(256) void query_lookup_kernel(const AnchorPairDev *pairs, const char *pool, int k,
-                                                           const unsigned long long *keys, long long nkeys,
+__global__ __launch_bounds__(256) void query_lookup_kernel(const AnchorPairDev *pairs, int npairs, const char *pool, int k,
+                                                           int pos_bits, const unsigned long long *keys, long long nkeys,
                                                            uint32_t *qlo, uint32_t *qcnt, uint32_t *qeff,
                                                            uint32_t *qpair) {
-  const AnchorPairDev p = pairs[blockIdx.y];
+  const unsigned pr = blockIdx.z * 65535u + blockIdx.y;
+  if (pr >= (unsigned)npairs) return;
+  const AnchorPairDev p = pairs[pr];
   const int nk = p.qlen - k + 1;
+  const int nrk = p.rlen - k + 1 > 0 ? p.rlen - k + 1 : 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
     uint32_t h;
     const bool ok = kmer_at(pool + p.q_off + i, k, h);
     uint32_t lo = 0, cnt = 0;
     if (ok) {
-      const unsigned long long base = ((unsigned long long)blockIdx.y << 44) | ((unsigned long long)h << 22);
-      const long long a = lower_bound_u64(keys, nkeys, base);
-      const long long b = lower_bound_u64(keys, nkeys, base + (1ull << 22));
+      // (the sorted keys of a pair lie where its unsorted ones were written: the pair index is the top field)
+      const unsigned long long base = ((unsigned long long)pr << (2 * k + pos_bits)) | ((unsigned long long)h << pos_bits);
+      const long long a = p.rk_start + lower_bound_u64(keys + p.rk_start, nrk, base);
+      const long long b = p.rk_start + lower_bound_u64(keys + p.rk_start, nrk, base + (1ull << pos_bits));
       lo = (uint32_t)a;
       cnt = (uint32_t)(b - a);
     }
@@ -83,8 +92,9 @@ __global__ __launch_bounds__(256) void query_lookup_kernel(const AnchorPairDev *
     qlo[g] = lo;
     qcnt[g] = cnt;
     qeff[g] = cnt < 1000 ? cnt : 0;  // it->second.size() >= 1000 -> skipped (:61)
-    qpair[g] = blockIdx.y;
+    qpair[g] = pr;
   }
+  (void)nkeys;
 }
 
 struct CandOut {
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256) void candidates_kernel(const AnchorPairDev *pa
                                                          const unsigned long long *keys, const uint32_t *qlo,
                                                          const uint32_t *qcnt, const unsigned long long *cand_off,
                                                          const uint32_t *qpair, long long nq, long long ncand,
-                                                         uint32_t *flag, CandOut *cand) {
+                                                         uint32_t *flag, CandOut *cand, int pos_bits) {
   const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncand) return;
   // owner query k-mer: last g with cand_off[g] <= c
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256) void candidates_kernel(const AnchorPairDev *pa
   const AnchorPairDev p = pairs[qpair[g]];
   const int q = (int)(g - p.qk_start);
   const int j = (int)((unsigned long long)c - cand_off[g]);
-  const int r = (int)(keys[qlo[g] + j] & ((1u << 22) - 1));
+  const int r = (int)(keys[qlo[g] + j] & ((1ull << pos_bits) - 1));
   const char *Q = pool + p.q_off, *R = pool + p.r_off;
   bool start = !(p.same_chr && abs(p.delta + r - q) <= k);
   // an earlier enabled k-mer of the same match run on this diagonal already covers this one

@@ -169,12 +169,12 @@ class GpuProvider : public DpProvider {
       if (!said.exchange(true)) fprintf(stderr, "\n[sedef_amd] seed anchors on the host for this input: %s\n", why);
       return false;
     };
-    if (kmer > 11) return host_instead("GPU anchors implement k-mer sizes up to 11");
+    if (kmer > 15) return host_instead("GPU anchors implement k-mer sizes up to 15");
     std::vector<sdf_anchor_pair> pairs(jobs.size());
     size_t total = 0;
     for (size_t k = 0; k < jobs.size(); k++) {
-      if (jobs[k].query->size() >= (1u << 22) || jobs[k].ref->size() >= (1u << 22))
-        return host_instead("GPU anchors implement sequences shorter than 4 Mb");
+      if (jobs[k].query->size() >= (1u << 31) || jobs[k].ref->size() >= (1u << 31))
+        return host_instead("GPU anchors implement sequences shorter than 2 Gb");
       pairs[k].q_off = (int64_t)total;
       total += jobs[k].query->size();
       pairs[k].r_off = (int64_t)total;

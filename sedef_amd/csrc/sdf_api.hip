@@ -840,9 +840,12 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
 }
 
 // ---- seed anchors (reference: src/chain.cc:24-101) ---------------------------------------------------
-static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *d_pool, int kmer,
+static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *d_pool, int kmer, int pos_bits,
                          sdf_anchor *out, size_t out_cap, int64_t *out_off, size_t *out_used, hipStream_t st) {
   using namespace sdf;
+  int pair_bits = 1;
+  while (((size_t)1 << pair_bits) < n) ++pair_bits;
+  const int key_bits = std::min(64, pair_bits + 2 * kmer + pos_bits);  // (the sort looks at the bits in use only)
   std::vector<AnchorPairDev> hp(n);
   long long nrk = 0, nqk = 0;
   for (size_t i = 0; i < n; i++) {
@@ -872,17 +875,17 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
   uint32_t *d_qlo = (uint32_t *)ctx->an_q.p, *d_qcnt = d_qlo + nqk, *d_qeff = d_qcnt + nqk, *d_qpair = d_qeff + nqk;
   unsigned long long *d_off = (unsigned long long *)ctx->an_off.p;
   SDF_HIP(hipMemcpyAsync(d_pairs, hp.data(), n * sizeof(AnchorPairDev), hipMemcpyHostToDevice, st));
-  const dim3 grid(32, (unsigned)n);
-  hipLaunchKernelGGL(ref_keys_kernel, grid, dim3(256), 0, st, d_pairs, d_pool, kmer, d_keys);
+  const dim3 grid(32, (unsigned)std::min<size_t>(n, 65535), (unsigned)((n + 65534) / 65535));
+  hipLaunchKernelGGL(ref_keys_kernel, grid, dim3(256), 0, st, d_pairs, (int)n, d_pool, kmer, pos_bits, d_keys);
   size_t tmp_bytes = 0;
-  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, 64, st));
+  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, key_bits, st));
   size_t scan_bytes = 0;
   SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (unsigned long long *)nullptr,
                                            (int)(nqk + 1), st));
   SDF_HIP(ctx->an_tmp.reserve(std::max(tmp_bytes, scan_bytes) + 256));
-  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(ctx->an_tmp.p, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, 64, st));
-  hipLaunchKernelGGL(query_lookup_kernel, grid, dim3(256), 0, st, d_pairs, d_pool, kmer, d_keys2, nrk, d_qlo, d_qcnt,
-                     d_qeff, d_qpair);
+  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(ctx->an_tmp.p, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, key_bits, st));
+  hipLaunchKernelGGL(query_lookup_kernel, grid, dim3(256), 0, st, d_pairs, (int)n, d_pool, kmer, pos_bits, d_keys2, nrk, d_qlo,
+                     d_qcnt, d_qeff, d_qpair);
   // exclusive scan over nqk+1 entries (the extra input element is ignored by the exclusive form)
   SDF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->an_tmp.p, scan_bytes, d_qeff, d_off, (int)(nqk + 1), st));
   unsigned long long ncand = 0;
@@ -901,7 +904,7 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
   CandOut *d_cand = (CandOut *)ctx->an_cand.p;
   const unsigned nb = (unsigned)((ncand + 255) / 256);
   hipLaunchKernelGGL(candidates_kernel, dim3(nb), dim3(256), 0, st, d_pairs, d_pool, kmer, d_keys2, d_qlo, d_qcnt, d_off,
-                     d_qpair, nqk, (long long)ncand, d_flag, d_cand);
+                     d_qpair, nqk, (long long)ncand, d_flag, d_cand, pos_bits);
   SDF_HIP(hipMemsetAsync(d_flag + ncand, 0, 4, st));
   size_t scan2 = 0;
   SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan2, d_flag, d_pos, (int)(ncand + 1), st));
@@ -941,20 +944,18 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
     ctx->err = "invalid arguments";
     return SDF_ERR_INVALID;
   }
-  if (n > 65535) {  // one grid row of workgroups per pair (gridDim.y)
-    ctx->err = "at most 65,535 pairs per sdf_anchors_batch call";
-    return SDF_ERR_INVALID;
-  }
-  if (kmer < 1 || kmer > 11) {
-    ctx->err = "GPU anchors implement k-mer sizes up to 11";
+  if (kmer < 1 || kmer > 15) {  // (the reference's hash is the 2-bit code of the k-mer in 32 bits, src/chain.cc:30-35)
+    ctx->err = "GPU anchors implement k-mer sizes up to 15";
     return SDF_ERR_UNSUPPORTED;
   }
+  int32_t rmax = 1;
   for (size_t i = 0; i < n; i++) {
     const sdf_anchor_pair &p = pairs[i];
-    if (p.qlen < 0 || p.rlen < 0 || p.qlen >= (1 << 22) || p.rlen >= (1 << 22)) {
-      ctx->err = "GPU anchors implement sequences shorter than 4 Mb";
-      return SDF_ERR_UNSUPPORTED;
+    if (p.qlen < 0 || p.rlen < 0) {
+      ctx->err = "negative sequence length";
+      return SDF_ERR_INVALID;
     }
+    rmax = std::max(rmax, p.rlen);
     if (p.q_off < 0 || p.r_off < 0 || (size_t)p.q_off + p.qlen > pool_bytes || (size_t)p.r_off + p.rlen > pool_bytes) {
       ctx->err = "pair sequence range outside the pool";
       return SDF_ERR_INVALID;
@@ -971,7 +972,50 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
   SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (dbg_t) SDF_HIP(hipStreamSynchronize(ctx->stream));
   const auto dbg1 = std::chrono::steady_clock::now();
-  const int rc = anchors_range(ctx, pairs, n, (const char *)ctx->an_pool.p, kmer, out, out_cap, out_off, out_used, ctx->stream);
+  // Key = pair | hash (2k bits) | position: the pairs are run in ranges that fit the bits the other two fields leave (k = 11
+  // and references of up to 100 kb: 33 million pairs a range; k = 15 and 5 Mb: 2,048) -- and whose k-mers fit 32-bit indices.
+  int pos_bits = 1;
+  while (pos_bits < 31 && ((int64_t)1 << pos_bits) < (int64_t)rmax) ++pos_bits;
+  const int pair_bits = std::min(30, 64 - 2 * kmer - pos_bits);
+  const size_t range_max = (size_t)1 << pair_bits;
+  int rc = SDF_OK;
+  size_t used_total = 0;
+  out_off[0] = 0;
+  for (size_t s = 0; s < n && rc == SDF_OK;) {
+    size_t e = s;
+    int64_t nrk = 0, nqk = 0;
+    while (e < n && e - s < range_max) {
+      const int64_t a = std::max(0, pairs[e].rlen - kmer + 1), b = std::max(0, pairs[e].qlen - kmer + 1);
+      if (e > s && (nrk + a > 0x7fffff00ll || nqk + b > 0x7fffff00ll)) break;
+      nrk += a, nqk += b;
+      ++e;
+    }
+    if (nrk > 0x7fffff00ll || nqk > 0x7fffff00ll) {
+      ctx->err = "a pair of sequences of 2 Gb or more";
+      return SDF_ERR_UNSUPPORTED;
+    }
+    size_t used = 0;
+    const int64_t first = out_off[s];
+    rc = anchors_range(ctx, pairs + s, e - s, (const char *)ctx->an_pool.p, kmer, pos_bits, out ? out + used_total : nullptr,
+                       out_cap > used_total ? out_cap - used_total : 0, out_off + s, &used, ctx->stream);
+    for (size_t i = s; i <= e; i++) out_off[i] += first;  // (the range's offsets start at 0)
+    if (rc == SDF_ERR_CIGAR_OVERFLOW) {  // the caller wants the size needed: count the remaining ranges too
+      size_t more = 0;
+      for (size_t s2 = e; s2 < n;) {
+        size_t e2 = std::min(n, s2 + range_max), u2 = 0;
+        std::vector<int64_t> tmp_off(e2 - s2 + 1);
+        (void)anchors_range(ctx, pairs + s2, e2 - s2, (const char *)ctx->an_pool.p, kmer, pos_bits, nullptr, 0, tmp_off.data(), &u2,
+                            ctx->stream);
+        more += u2;
+        s2 = e2;
+      }
+      used_total += used + more;
+      break;
+    }
+    used_total += used;
+    s = e;
+  }
+  *out_used = used_total;
   if (dbg_t)
     fprintf(stderr, "[sdf_anchors_batch n=%zu pool=%zu anchors=%zu] upload %.1f ms, rest %.1f ms\n", n, pool_bytes, *out_used,
             std::chrono::duration<double, std::milli>(dbg1 - dbg0).count(),

@@ -1141,6 +1141,22 @@ def test_config5_full_size_mixed_bands(engine, oracle):
     assert 2500 < int(done.sum()) < 3000  # the one-sided kb-scale indels leave their bands
 
 
+def test_config5_throughput_batch_of_100000_tasks(oracle):
+    """configs[4] at the size profiles/mix_probe.py mm8 100000 times (round 4: the batch whose banded tasks of different
+    lengths run two to a wavefront): every task through the size-independent checks, a sample of 600 -- the longest tasks
+    among them -- against the reference kernel.  128 GiB of workspace, as the probe: the batch's direction flags are 131 GB."""
+    import bench
+    import sedef_amd
+    batch, w = bench.synth_mm8_mixture_fast(100000, seed=505)
+    eng = sedef_amd.Extz2Engine(0, 128 << 30)
+    qlen = batch[2]
+    rng = np.random.default_rng(3)
+    sample = np.unique(np.r_[rng.choice(100000, 560, replace=False), np.argsort(qlen)[-40:]])
+    res, done = _full_size_properties(eng, batch, w, sample, oracle)
+    assert eng.last_paired() > 80000
+    assert 90000 < int(done.sum()) < 100000  # (every 20th long task lost 1-5 kb of its target: its band runs out)
+
+
 def test_config2_full_size_banded_and_full_band(engine, oracle):
     """configs[1] at the size bench.py times: the 100,000 seed-42 tasks at w = 128, and the same inputs in SEDEF's real
     mode (w = -1), every task through the size-independent checks, a sample against the CPU path."""

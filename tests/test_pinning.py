@@ -133,6 +133,47 @@ def test_gpu_anchors_equal_bruteforce(host):
             assert g == bruteforce.anchors_bruteforce(q, r, k, same, 0, delta), (len(q), len(r), same, delta, k)
 
 
+def _np_seq(rng, n):
+    return np.frombuffer(b"ACGTacgt", np.uint8)[rng.integers(0, 8, n)].tobytes().decode()
+
+
+@pytest.mark.gpu
+def test_gpu_anchors_k_up_to_15_long_sequences_and_many_pairs(host):
+    """Round 4: the cliffs of sdf_anchors_batch are gone -- k up to 15 (`-k` is a CLI parameter of the reference,
+    src/align_main.cc:366-370), references beyond 4 Mb (the position field of the sort key takes the bits the call's longest
+    reference needs), more than 65,535 pairs a call (pairs beyond the bits left of hash and position run range by range)."""
+    import sedef_amd
+    eng = sedef_amd.Extz2Engine(0)
+    rng = np.random.default_rng(33)
+    cases = _anchor_cases(rng, 16)
+    for k in (8, 12, 14, 15):
+        got = eng.anchors_batch(cases, k)
+        for (q, r, same, delta), g in zip(cases, got):
+            assert g == bruteforce.anchors_bruteforce(q, r, k, same, 0, delta), (len(q), len(r), same, delta, k)
+    # a 5.2 Mb reference (23 position bits: at k = 15 eleven bits are left for the pair index -> 2,048 pairs a range) with
+    # 2,300 small pairs behind it: three ranges; expected = the host's sort-merge join (equal to the brute force above)
+    r_big = _np_seq(rng, 5200000)
+    q_big = "".join(hostgen.mut(rng, r_big[a:a + 2000], 0.03) + _np_seq(rng, 500)
+                    for a in rng.integers(0, 5000000, 60).tolist())
+    small = [(hostgen.rseq(rng, int(rng.integers(20, 400))),) for _ in range(2300)]
+    small = [(q[0], hostgen.mut(rng, q[0], 0.05) + hostgen.rseq(rng, 30), False, 0) for q in small]
+    cases = [(q_big, r_big, False, 0)] + small
+    got = eng.anchors_batch(cases, 15)
+    assert len(got[0]) > 2000
+    for idx in [0] + rng.choice(np.arange(1, len(cases)), 150, replace=False).tolist() + [len(cases) - 1, 2047, 2048, 2049]:
+        q, r, same, delta = cases[idx]
+        assert got[idx] == host.anchors(q, r, 15, same_chr=same, qstart=0, rstart=delta), idx
+    # 70,000 pairs in one call (gridDim.y holds 65,535)
+    tiny = []
+    for _ in range(70000):
+        q = _np_seq(rng, int(rng.integers(12, 60)))
+        tiny.append((q, q[3:] + "ACGT", False, 0))
+    got = eng.anchors_batch(tiny, 8)
+    for idx in rng.choice(70000, 300, replace=False).tolist() + [0, 65534, 65535, 65536, 69999]:
+        q, r, same, delta = tiny[idx]
+        assert got[idx] == bruteforce.anchors_bruteforce(q, r, 8, same, 0, delta), idx
+
+
 # ---------------------------------------------------------------- C2: chaining vs. brute force
 def _chain_cases(host, rng, n_real, n_rand):
     cases = [np.zeros((0, 4), np.int32), np.array([[5, 9, 11, 1]], np.int32),
