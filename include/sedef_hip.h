@@ -239,6 +239,33 @@ int sdf_stats_columns_batch(sdf_ctx *ctx, const sdf_stats_task *tasks, size_t n,
 int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_tasks, size_t n, const char *d_seq_pool,
                              const uint32_t *d_cigar_pool, sdf_stats_cols *d_out, void *stream);
 
+/* ---- multi-GPU: the one exchange step of the path.  DP tasks are independent (the reference runs one
+ * single-threaded process per bucket file and concatenates their output files, sedef.sh:187-190,218-221), so a batch is
+ * sharded over the GPUs of a node with no data-path collective; after the DP an RCCL all-gatherv over xGMI gives every GPU
+ * every shard's result records and CIGAR words.  One communicator per (process, device): either
+ *   rank 0: sdf_comm_unique_id(id, 128) -> id handed to the other processes out of band -> every rank:
+ *   sdf_comm_create(device, world, rank, id)                                   (one process per GPU), or
+ *   sdf_comm_create_all(devices, n, comms)                                      (one process, a thread per GPU).
+ * RCCL is dlopen'ed by the first of these calls. */
+typedef struct sdf_comm sdf_comm;
+int sdf_comm_unique_id(void *id, size_t bytes /* >= 128 */);
+sdf_comm *sdf_comm_create(int device, int world, int rank, const void *id);
+int sdf_comm_create_all(const int *devices, int n, sdf_comm **out);
+void sdf_comm_destroy(sdf_comm *c);
+int sdf_comm_world(const sdf_comm *c);
+int sdf_comm_rank(const sdf_comm *c);
+const char *sdf_comm_last_error(const sdf_comm *c);
+/* All-gatherv of one batch's results: d_out[n_tasks] and d_cig[cig_used] are this rank's (HBM, what
+ * sdf_extz2_batch_device left), d_all_out / d_all_cig receive every rank's back to back in rank order -- exactly
+ * counts[2 r] records and counts[2 r + 1] CIGAR words from rank r (counts: host, 2 * world entries; cigar_off of a record
+ * stays relative to its rank's words).  Two collectives whatever the world size: an all-gather of the counts and one
+ * group of point-to-point transfers on the exact sizes.  Enqueued on `stream` (NULL: the communicator's own, synchronised
+ * before returning); with a stream the call returns once the counts are on the host and the transfers are enqueued.
+ * SDF_ERR_CIGAR_OVERFLOW: a capacity is too small (counts holds the sizes). */
+int sdf_allgatherv_results(sdf_comm *c, const sdf_result *d_out, size_t n_tasks, const uint32_t *d_cig, size_t cig_used,
+                           sdf_result *d_all_out, size_t all_out_cap, uint32_t *d_all_cig, size_t all_cig_cap,
+                           uint64_t *counts, void *stream);
+
 /* ---- one-task drop-in: same contract as ksw_extz2_sse (extern/ksw2.h:50).  `km` is ignored
  * like in the reference build (no HAVE_KALLOC).  Uses a process-wide context on device 0 (or
  * the device named by SDF_DEVICE).  On a fatal error prints to stderr and exits with 120, the

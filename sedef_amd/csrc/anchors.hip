@@ -75,16 +75,17 @@ __global__ __launch_bounds__(256) void query_lookup_kernel(const AnchorPairDev *
   if (pr >= (unsigned)npairs) return;
   const AnchorPairDev p = pairs[pr];
   const int nk = p.qlen - k + 1;
-  const int nrk = p.rlen - k + 1 > 0 ? p.rlen - k + 1 : 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
     uint32_t h;
     const bool ok = kmer_at(pool + p.q_off + i, k, h);
     uint32_t lo = 0, cnt = 0;
     if (ok) {
-      // (the sorted keys of a pair lie where its unsorted ones were written: the pair index is the top field)
+      // (over the whole sorted array: the keys of windows with an N, all ones, have gathered at its end -- a pair's keys no
+      // longer lie where they were written)
       const unsigned long long base = ((unsigned long long)pr << (2 * k + pos_bits)) | ((unsigned long long)h << pos_bits);
-      const long long a = p.rk_start + lower_bound_u64(keys + p.rk_start, nrk, base);
-      const long long b = p.rk_start + lower_bound_u64(keys + p.rk_start, nrk, base + (1ull << pos_bits));
+      const long long a = lower_bound_u64(keys, nkeys, base);
+      const unsigned long long top = base + (1ull << pos_bits);  // (wraps for the all-T k-mer of the last pair of a 64-bit key)
+      const long long b = lower_bound_u64(keys, nkeys, top > base ? top : ~0ull);
       lo = (uint32_t)a;
       cnt = (uint32_t)(b - a);
     }
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(256) void query_lookup_kernel(const AnchorPairDev *
     qeff[g] = cnt < 1000 ? cnt : 0;  // it->second.size() >= 1000 -> skipped (:61)
     qpair[g] = pr;
   }
-  (void)nkeys;
 }
 
 struct CandOut {

@@ -955,7 +955,7 @@ template __global__ void extz2_pair_kernel<6, true, true>(const PlanTask *, cons
 // sequences whole never re-fills), 2 .. 9 registers of 64 slots -- 9: w = 512, whose window of 576 slots no other
 // register-resident kernel holds for two tasks.
 template <int NREG>
-__global__ __launch_bounds__(64, NREG <= 2 ? 5 : NREG <= 3 ? 4 : NREG <= 5 ? 3 : 2) void extz2_pair_mixed_kernel(
+__global__ __launch_bounds__(64, NREG <= 3 ? 4 : NREG <= 5 ? 3 : 2) void extz2_pair_mixed_kernel(  // (LDS: ~10 KB a wavefront at two registers -- four to a SIMD at most)
     const PlanTask *__restrict__ plan, const int32_t *__restrict__ order, const uint32_t *__restrict__ pool,
     ScoreK sc, uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res) {
   pair_body<NREG, true, false, true>(plan, order, pool, sc, dirbase, res);

@@ -11,15 +11,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_SRC = os.path.join(_HERE, "csrc", "host")
 LIB = os.path.join(_HERE, "lib", "libsedef_host.so")
 CLI = os.path.join(_HERE, "bin", "sedef")
+MULTI = os.path.join(_HERE, "bin", "sdf_multi")
 _SOURCES = ["alignment.cc", "hit_fasta.cc", "chain.cc", "pipeline.cc", "bucket.cc", "stats.cc", "host_cabi.cc"]
 
 
 def build_host(force=False):
     """g++ build of the host library and the `sedef` CLI (needs libsedef_hip.so next to it)."""
     srcs = [os.path.join(HOST_SRC, f) for f in _SOURCES]
-    deps = srcs + [os.path.join(HOST_SRC, "sedef_host.h"), os.path.join(HOST_SRC, "sedef_main.cc")]
-    fresh = os.path.exists(LIB) and os.path.exists(CLI) and all(
-        os.path.getmtime(d) <= min(os.path.getmtime(LIB), os.path.getmtime(CLI)) for d in deps)
+    deps = srcs + [os.path.join(HOST_SRC, "sedef_host.h"), os.path.join(HOST_SRC, "sedef_main.cc"),
+                   os.path.join(HOST_SRC, "multi_gpu.cc")]
+    fresh = os.path.exists(LIB) and os.path.exists(CLI) and os.path.exists(MULTI) and all(
+        os.path.getmtime(d) <= min(os.path.getmtime(LIB), os.path.getmtime(CLI), os.path.getmtime(MULTI)) for d in deps)
     if fresh and not force:
         return LIB
     gxx = shutil.which("g++") or "g++"
@@ -30,6 +32,12 @@ def build_host(force=False):
                           ["-L" + libdir, "-lsedef_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     subprocess.check_call([gxx, "-O2", "-std=c++17", "-Wall", "-o", CLI, os.path.join(HOST_SRC, "sedef_main.cc"),
                            "-L" + libdir, "-lsedef_host", "-lsedef_hip", "-lpthread", "-Wl,-rpath,$ORIGIN/../lib"])
+    # sdf_multi: one batch sharded over the GPUs of a node + RCCL all-gatherv of the results, host C++ above the C ABI
+    # (device buffers: hipcc, host code only)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-Wall", "-x", "hip", "--offload-arch=gfx950", "-o", MULTI,
+                           os.path.join(HOST_SRC, "multi_gpu.cc"), "-L" + libdir, "-lsedef_hip", "-lpthread",
+                           "-Wl,-rpath,$ORIGIN/../lib"])
     return LIB
 
 
