@@ -391,6 +391,10 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   for (float &m : ctx->ms) m = 0.f;
   ctx->launches = 0;
   ctx->paired = 0;
+  // (nothing of this context's earlier calls is in flight: what they outgrew is idle now -- sdf_ctx.h: DevBuf)
+  for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->gstate_buf, &ctx->h_pool, &ctx->h_out,
+                    &ctx->h_cig, &ctx->ln_recs, &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
+    b->new_call();
   const auto host_t0 = std::chrono::steady_clock::now();
   auto host_ms = [&] { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); };
   run.ctx = ctx;
@@ -478,7 +482,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     // (heavy tasks' slice first: it stays where it is when the workspace has to grow after the early start -- an
     // outgrown buffer is retired, not freed -- and the chunks launched by then keep their pointer)
     const size_t dir_bytes = early ? cut.heavy_need : cut.heavy_need + cut.region_need * cut.nreg_ws + lane_need;
-    if (ctx->dir_ws.reserve(std::max<size_t>(dir_bytes, 256)) != hipSuccess) {
+    if (ctx->dir_ws.reserve(std::max<size_t>(dir_bytes, 256), ctx->ws_budget + 4096) != hipSuccess) {
       ctx->err = "cannot allocate the direction-matrix workspace";
       (void)hipGetLastError();
       return SDF_ERR_NOMEM;

@@ -69,23 +69,32 @@ __global__ void reset_results_kernel(sdf_result *res, int n);
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
-  hipError_t reserve(size_t bytes) {
+  // `limit`: no headroom beyond this many bytes (the direction-flag workspace: the context's budget)
+  hipError_t reserve(size_t bytes, size_t limit = ~(size_t)0) {
     if (bytes <= cap) return hipSuccess;
     static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     const size_t old = cap;
     // hipFree waits for the whole DEVICE -- the other lanes' batches included: 100-170 ms measured in a stage run, where
-    // the allocation itself takes 0.2 ms -- so an outgrown buffer is only retired here and freed with the context
-    // (sizes grow by half each time: the retired ones add up to less than twice the last)
-    if (p) retired.push_back(p);
+    // the allocation itself takes 0.2 ms -- so an outgrown buffer is only retired here: work of THIS call may still use it.
+    // Buffers retired during EARLIER calls (new_call() has moved them to `stale`) are idle and are freed now, in the stall
+    // this growth costs anyway: a context holds its buffer and at most the one it outgrew last (every outgrown
+    // buffer used to stay until the context died).
+    release_stale();
+    if (p) {
+      retired.push_back(p);
+      retired_bytes += cap;
+    }
     p = nullptr;
     cap = 0;
     size_t want = bytes + std::min<size_t>(bytes / 2, (size_t)8 << 30) + 4096;
+    if (want > limit) want = std::max(bytes, limit);
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {  // short of memory: give the retired buffers back first, then without headroom
       (void)hipGetLastError();
       for (void *q : retired) (void)hipFree(q);
       retired.clear();
+      retired_bytes = 0;
       e = hipMalloc(&p, want);
       if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -99,14 +108,32 @@ struct DevBuf {
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return e;
   }
+  // at the start of a batch call (nothing of the context's earlier calls is in flight): what earlier calls retired is idle
+  // from here on -- freed at the next growth, or right away when it is more than `keep` bytes
+  void new_call(size_t keep = (size_t)4 << 30) {
+    stale.insert(stale.end(), retired.begin(), retired.end());
+    stale_bytes += retired_bytes;
+    retired.clear();
+    retired_bytes = 0;
+    if (stale_bytes > keep) release_stale();
+  }
+  void release_stale() {
+    for (void *q : stale) (void)hipFree(q);
+    stale.clear();
+    stale_bytes = 0;
+  }
   void release() {
     if (p) (void)hipFree(p);
     for (void *q : retired) (void)hipFree(q);
     retired.clear();
+    retired_bytes = 0;
+    release_stale();
     p = nullptr;
     cap = 0;
   }
-  std::vector<void *> retired;
+  size_t held_bytes() const { return cap + retired_bytes + stale_bytes; }
+  std::vector<void *> retired, stale;
+  size_t retired_bytes = 0, stale_bytes = 0;
 };
 
 struct HostBuf {  // pinned host memory
