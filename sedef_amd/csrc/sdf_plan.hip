@@ -578,8 +578,19 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       const double chain_ms = (double)rows_max * 0.5e-3, work_ms = (double)bytes / 0.65e9;
       const size_t nch_max = (size_t)std::max(1.0, work_ms / (6.0 * chain_ms));
       if (nch_max < cut.nch) {
-        cut.nch = nch_max;
-        cut.max_regions = std::min<size_t>(4, cut.nch + 1);
+        // (no small first chunk either: it would hold a whole region of the workspace for a twelfth of the tasks, and the
+        // planning it hides is a few milliseconds of a call of hundreds)
+        // Chunks of equal task counts, a workspace region each while the flags of the whole batch fit the workspace; beyond
+        // that two regions, the chunks as large as a region holds (two in flight, the third waits for the first's walk).
+        const size_t avail = ws_budget - std::min(ws_budget / 2, (size_t)cut.lane_dir_bytes);
+        const double need = (double)bytes * 1.05;
+        if (need <= (double)avail) {
+          cut.nch = nch_max;
+          cut.max_regions = std::max<size_t>(1, cut.nch);
+        } else {
+          cut.max_regions = 2;
+          cut.nch = std::max<size_t>(2, (size_t)(need / ((double)avail / 2.0)) + 1);
+        }
         chain_bound = true;
       }
     }
@@ -590,9 +601,8 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
 
   // ---- chunk boundaries ----
   const size_t nch = cut.nch;
-  const size_t first_target = nch_by_size > 1 ? first_target0 : n;
-  const size_t chunk_target = nch_by_size > 1 ? (n - first_target + nch - 1) / nch : n;
-  (void)chain_bound;
+  const size_t first_target = chain_bound ? (n + nch - 1) / nch : nch_by_size > 1 ? first_target0 : n;
+  const size_t chunk_target = chain_bound ? (n + nch - 1) / nch : nch_by_size > 1 ? (n - first_target + nch - 1) / nch : n;
   std::vector<ChunkPlan> normal;
   {
     // whole blocks of tasks at a time (their sums come from the scan above); task by task only inside a block that

@@ -66,7 +66,11 @@ def _check(tasks, per_task, per_chunk):
     for k in np.flatnonzero(part >= 0):
         p = int(part[k])
         assert part[p] == k and per_task[p, 0] == per_task[k, 0] and per_task[p, 1] == per_task[k, 1]
-        assert (tasks["qlen"][p], tasks["tlen"][p], tasks["w"][p]) == (tasks["qlen"][k], tasks["tlen"][k], tasks["w"][k])
+        if 130 <= per_task[k, 1] < 140:  # mixed pair (extz2_pair.hip, MIXED): one band and flag set, any lengths
+            assert tasks["w"][p] == tasks["w"][k] and tasks["flag"][p] == tasks["flag"][k]
+            assert per_task[k, 2] == per_task[p, 2]  # ... in the same number of window registers
+        else:
+            assert (tasks["qlen"][p], tasks["tlen"][p], tasks["w"][p]) == (tasks["qlen"][k], tasks["tlen"][k], tasks["w"][k])
 
 
 def test_headline_batch_is_chunked_paired_and_deterministic():
@@ -171,3 +175,42 @@ def test_two_pass_cut_with_early_heavy_chunks(monkeypatch):
     in_heavy, in_heavy0 = np.isin(pt[:, 0], heavy), np.isin(pt0[:, 0], np.flatnonzero(pc0[:, 0]))
     assert in_heavy.sum() >= 650 and (in_heavy == in_heavy0).all()
     assert ((pt[:, 0] >= 0) == (pt0[:, 0] >= 0)).all()  # the same tasks run
+
+
+def _mm8_like(rng, n):
+    q = np.exp(rng.uniform(np.log(200), np.log(20000), n)).astype(np.int64)
+    t = np.maximum(1, q + (rng.normal(0, 1, n) * np.sqrt(0.04 * q)).astype(np.int64))
+    cut = (np.arange(n) % 20 == 0) & (t > 6000)
+    t = np.where(cut, t - rng.integers(1000, 5001, n), t)
+    return _tasks(q, t, w=rng.choice([64, 128, 256, 512], n))
+
+
+def test_banded_tasks_of_all_lengths_mixed_pairs_and_fewer_chunks():
+    """BASELINE configs[4]'s shape (lengths log-uniform 200..20,000, bands 64..512): in a batch large enough to fill the
+    device the banded tasks whose band reaches the end run two to a wavefront whatever their lengths (launch classes 132..139:
+    the MIXED pair kernel with 2..9 window registers, w = 512 included), the long ones among them leave the banded stripe
+    kernel, tasks whose band runs out keep it; and the batch is cut into FEWER chunks than its size alone would give -- a
+    launch lasts as long as its longest chain of rows, so a chunk must hold several chains' worth of work.  A batch of
+    3,000 such tasks stays as it was: long tasks on banded stripes, no mixed pairs."""
+    rng = np.random.default_rng(11)
+    t = _mm8_like(rng, 40000)
+    rc, pt, pc = _plan(t)
+    assert rc == 0 and 1 <= len(pc) <= 3 and not pc[:, 0].any()  # (by size alone: a small first chunk + four)
+    assert pc[:, 1].min() > 0.4 * pc[:, 1].max()                  # ... of about equal size (whole blocks of 4,096 tasks), no small first chunk
+    mixed = (pt[:, 1] >= 130) & (pt[:, 1] < 140)
+    assert mixed.sum() > 34000 and (pt[mixed, 6] >= 0).all()
+    assert set(np.unique(pt[mixed, 1])) >= {132, 133, 135, 139}
+    w512 = (t["w"] == 512) & mixed
+    assert (pt[w512, 1] == 139).all() and w512.sum() > 7000
+    runs_out = np.abs(t["qlen"].astype(np.int64) - t["tlen"]) > t["w"]
+    long_out = runs_out & (t["qlen"] + t["tlen"] >= 4001)
+    assert long_out.sum() > 200 and (pt[long_out, 1] // 100 == 4).all() and not mixed[runs_out].any()
+    _check(t, pt, pc)
+    rc2, pt2, pc2 = _plan(t, threads=3)
+    assert rc2 == 0 and (pt2 == pt).all() and (pc2 == pc).all()
+    small = _mm8_like(rng, 3000)
+    rc, pt, pc = _plan(small)
+    assert rc == 0 and len(pc) == 1 and not ((pt[:, 1] >= 130) & (pt[:, 1] < 140)).any()
+    long_wide = (small["qlen"] + small["tlen"] >= 4001) & (small["w"] >= 256)
+    assert (pt[long_wide, 1] // 100 == 4).all()
+    _check(small, pt, pc)
