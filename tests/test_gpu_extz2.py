@@ -1132,6 +1132,39 @@ def test_config4_full_size_one_million_tasks(engine, oracle):
     assert done.all() and len(heavy) > 300 and len(qlen) == 1000000 and int(res["n_cigar"].astype(np.int64).sum()) > 2000000
 
 
+def _device_bytes(eng, batch, w):
+    """(result records, CIGAR words) of one batch call through the host-buffer entry point, as bytes."""
+    import sedef_amd
+    pool, q_off, qlen, t_off, tlen = batch
+    tasks = np.zeros(len(qlen), sedef_amd.TASK_DTYPE)
+    tasks["q_off"], tasks["t_off"], tasks["qlen"], tasks["tlen"], tasks["w"], tasks["zdrop"] = q_off, t_off, qlen, tlen, w, -1
+    res, cig = eng.align_batch(tasks, pool, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+    return res.tobytes(), np.ascontiguousarray(cig).tobytes()
+
+
+@pytest.mark.parametrize("switch", ["SDF_SPLIT_MIN", "SDF_EARLY_HEAVY", "SDF_NO_MIXED"])
+def test_start_paths_on_and_off_give_the_same_bytes(engine, switch):
+    """The paths that change HOW a large batch starts or pairs, never what it returns, each on against off on a batch that
+    takes it: the two-part start of mid-size batches of one size (SDF_SPLIT_MIN=0: off), the early start of the heavy chunks
+    of a 400,000+ task batch (SDF_EARLY_HEAVY=0: off), the mixed pairs (SDF_NO_MIXED=1: off).  Same records, same CIGAR words."""
+    import bench
+    if switch == "SDF_SPLIT_MIN":  # (the default rule wants the process's only context: asked for here)
+        batch, w = bench.synth_batch(60000, 400, seed=9), 64
+        engine, off = _engine_with_env(SDF_SPLIT_MIN=20000), _engine_with_env(SDF_SPLIT_MIN=0)
+    elif switch == "SDF_EARLY_HEAVY":
+        (batch, w) = bench.synth_hg19_mixture_fast(420000, seed=10, big=3000)
+        off = _engine_with_env(SDF_EARLY_HEAVY=0)
+    else:
+        (batch, w) = bench.synth_mm8_mixture_fast(12000, seed=11, max_len=6000)
+        off = _engine_with_env(SDF_NO_MIXED=1)
+    a = _device_bytes(engine, batch, w)
+    paired_on = engine.last_paired()
+    b = _device_bytes(off, batch, w)
+    assert a[0] == b[0] and a[1] == b[1]
+    if switch == "SDF_NO_MIXED":
+        assert paired_on > 8000 > off.last_paired()
+
+
 def test_config5_full_size_mixed_bands(engine, oracle):
     """configs[4] at the size profiles/mix_probe.py mm8 runs: 3,000 tasks up to 20 kb, bands 64..512 in one batch."""
     import bench
