@@ -1127,9 +1127,14 @@ extern "C" int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_ta
   SDF_HIP(ctx->st_items.reserve((size_t)kItems * sizeof(sdf::StatsItem) + 64));
   unsigned *d_counter = reinterpret_cast<unsigned *>((char *)ctx->st_items.p + (size_t)kItems * sizeof(sdf::StatsItem));
   SDF_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned), st));
+  static const unsigned group_max = [] {
+    const char *e = getenv("SDF_STATS_GROUP_MAX");
+    return e ? (unsigned)std::max(0, atoi(e)) : sdf::STATS_GROUP_MAX;
+  }();
+  static_assert(sdf::STATS_WAVES == 4, "a workgroup is the four wavefronts of four consecutive alignments");
   hipLaunchKernelGGL(sdf::stats_columns_kernel, dim3((unsigned)((n + sdf::STATS_WAVES - 1) / sdf::STATS_WAVES)),
                      dim3(64 * sdf::STATS_WAVES), 0, st, d_tasks, (int)n, d_seq_pool, d_cigar_pool, d_out,
-                     (sdf::StatsItem *)ctx->st_items.p, d_counter, kItems);
+                     (sdf::StatsItem *)ctx->st_items.p, d_counter, kItems, group_max);
   hipLaunchKernelGGL(sdf::stats_segments_kernel, dim3(2048), dim3(64 * sdf::STATS_WAVES), 0, st,
                      (const sdf::StatsItem *)ctx->st_items.p, d_counter, kItems, d_seq_pool, d_cigar_pool, d_out);
   SDF_HIP(hipGetLastError());
