@@ -491,6 +491,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
+        # (a second, gloo group for the LAST barrier: while rank 0 times the CPU baseline the other ranks wait in a socket
+        # read -- a barrier on the GPU would have them poll their streams on the host cores the baseline is measured on)
+        quiet = dist.new_group(backend="gloo") if world > 1 and not debug_one_gpu else None
 
     # ---- the workload: every rank's shard of the batch ----
     hg19 = args.workload == "hg19mix"
@@ -771,7 +774,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pool, q_off, qlen, t_off, tlen, cells_task, w)
         print(json.dumps(line))
     if dist_on:
-        dist.barrier()
+        dist.barrier(group=quiet) if quiet is not None else dist.barrier()
         dist.destroy_process_group()
 
 
