@@ -2,7 +2,7 @@
 # Round 4, the mm8-like batch of 100,000 tasks after the mixed pairs: kernel trace, SQ / FETCH / WRITE counters per kernel,
 # tasks / rows / cells per launch class, at a 128 GiB workspace.   bash profiles/r04_collect_b.sh
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=${HQ:-8}
+export TMPDIR=/tmp GPU_MAX_HW_QUEUES=${HQ:-24}
 out=gpurun_out/r04b2; mkdir -p $out
 M="python3 profiles/mix_probe.py mm8 100000 128"
 for i in 1 2 3; do $M > $out/run$i.log 2>&1; tail -1 $out/run$i.log; done
