@@ -30,7 +30,8 @@ for rd in range(rounds):
             t = np.concatenate([t[:k], random_codes(rng, L), t[k:]]) if rng.random() < 0.5 else np.concatenate([t[:k], t[k + L:]])
         if len(t) == 0: t = random_codes(rng, 1)
         pairs.append((q, t)); ws.append(w)
-    flags = [1 if rng.random() < 0.05 else 0 for _ in range(N)]  # a few score-only tasks (their own pairing class)
+    # a few score-only tasks and a few that leave their CIGAR reversed (KSW_EZ_REV_CIGAR): pairing classes of their own
+    flags = [int(rng.choice([1, 0x80, 0x80])) if rng.random() < 0.12 else 0 for _ in range(N)]
     res, cig = eng.align_pairs(pairs, w=np.array(ws, np.int32), flag=np.array(flags, np.int32), want=3)
     paired += eng.last_paired()
     for (q, t), w, f, r in zip(pairs, ws, flags, res):

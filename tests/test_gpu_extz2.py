@@ -1260,5 +1260,5 @@ def test_mixed_pairs_banded_tasks_of_different_lengths(oracle):
     sc = dict(mat=sedef_mat(2, -7), gapo=6, gape=3)
     _check_fast(eng, oracle, pairs[:300], ws[:300], **sc)
     _check_fast(eng, oracle, pairs[:300], ws[:300], mat=sedef_mat(11, -9), gapo=55, gape=4)
-    flags = [int(rng.choice([0, 0, 1])) for _ in range(300)]
+    flags = [int(rng.choice([0, 0, 1, 0x80])) for _ in range(300)]  # (score only; KSW_EZ_REV_CIGAR)
     _check_fast(eng, oracle, pairs[300:600], ws[300:600], flags=flags)
