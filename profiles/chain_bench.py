@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Times sdf_chain_batch (GPU, one thread per pair) against the host chain_anchors on the same anchor sets.
+"""Times sdf_chain_batch (GPU: one wavefront per pair with everything in LDS for pairs of up to ~400 anchors, one thread per
+pair beyond; SDF_CHAIN_THREADS=1: one thread per pair throughout) against the host chain_anchors on the same anchor sets.  The
+GPU figure is the whole call through the Python binding (list handling, uploads, kernels, downloads): kernel times come from
+`rocprofv3 --kernel-trace --stats` of this script.
 usage: chain_bench.py [npairs] [seqlen]"""
 import os
 import sys

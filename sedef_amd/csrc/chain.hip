@@ -112,7 +112,11 @@ struct Tree {
 
   // src/segment.tpp:29-66; returns a node index or -1
   __device__ int rmq(const P2 &p, const P2 &q) const {
-    int st_i[48], st_state[48], st_m1[48];
+    int st_i[48], st_state[48], st_m1[48];  // (dynamically indexed: scratch memory)
+    return rmq(p, q, st_i, st_state, st_m1);
+  }
+  // ... with the recursion's stack where the caller wants it (chain_wave_kernel: in LDS, 3 x 48 words)
+  __device__ int rmq(const P2 &p, const P2 &q, int *st_i, int *st_state, int *st_m1) const {
     int sp = 0, ret = -1;
     st_i[0] = 0;
     st_state[0] = 0;
@@ -224,13 +228,16 @@ struct Tree {
 // ws_off[p] (in 32-bit words: 12 m + 4 nodes).  Out: path[off[p] + k] = anchor index (within the pair) of the k-th
 // element of the reference's `path`; bounds[2 * (off[p] + p + b)] = {path position, has_u} of the b-th boundary;
 // nbound[p] = number of boundaries (>= 1: the initial {0, 0}).
+// (which: the pairs this launch takes, `npairs` of them -- round 4: those too large for the LDS of chain_wave_kernel; null: all)
 __global__ __launch_bounds__(64) void chain_kernel(const sdf_anchor *__restrict__ anchors,
                                                    const int64_t *__restrict__ off, const int64_t *__restrict__ ws_off,
                                                    int npairs, int max_chain_gap, int match_chain_score,
                                                    int32_t *__restrict__ work, int32_t *__restrict__ path,
-                                                   int32_t *__restrict__ bounds, int32_t *__restrict__ nbound) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npairs) return;
+                                                   int32_t *__restrict__ bounds, int32_t *__restrict__ nbound,
+                                                   const int32_t *__restrict__ which) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= npairs) return;
+  const int p = which ? which[slot] : slot;
   const sdf_anchor *A = anchors + off[p];
   const int m = (int)(off[p + 1] - off[p]);
   int32_t *pth = path + off[p];
@@ -322,6 +329,196 @@ __global__ __launch_bounds__(64) void chain_kernel(const sdf_anchor *__restrict_
     ++nb;
   }
   nbound[p] = nb;
+}
+
+// ---- round 4: one WAVEFRONT per pair, everything in LDS ----------------------------------------------------------------
+// The sweep itself stays what it is -- a chain of tree operations whose tie winners depend on the tree's shape and history
+// (DESIGN.md 8, f3), walked by lane 0 with the device functions above -- but (1) every array it touches lies in LDS (a
+// dependent access costs ~100 cycles instead of the ~1,500 of a miss in HBM: the thread-per-pair kernel spends ~100 us per
+// anchor), and (2) what is not a chain runs on all 64 lanes: the three sorts (a bitonic network on 64-bit keys, every
+// compare-exchange ascending so that lengths need not be powers of two), the initialisation, and the tree's construction
+// (a node's point range follows from its index alone).  LDS per pair: 64 m + 16 nodes bytes (m anchors -- their records
+// included --, nodes = 2 * 2^ceil(log2 m) <= 4 m); pairs beyond the launch's LDS go to the thread-per-pair kernel.
+
+// ascending sort of a[0 .. n) in LDS by the workgroup's single wavefront (normalised bitonic network: the first step of a
+// merge pairs i with its mirror image in the block, the others i with i + j; a partner at or beyond n is a virtual +inf)
+__device__ __forceinline__ void chain_sort_u64(unsigned long long *a, const int n, const int lane) {
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int idx = lane; idx < np2 / 2; idx += 64) {
+      const int blk = idx / (k / 2), off = idx % (k / 2);
+      const int i = blk * k + off, j = blk * k + k - 1 - off;
+      if (j < n) {
+        const unsigned long long x = a[i], y = a[j];
+        if (x > y) a[i] = y, a[j] = x;
+      }
+    }
+    __syncthreads();
+    for (int jj = k / 4; jj >= 1; jj >>= 1) {
+      for (int idx = lane; idx < np2 / 2; idx += 64) {
+        const int i = (idx / jj) * 2 * jj + idx % jj, j = i + jj;
+        if (j < n) {
+          const unsigned long long x = a[i], y = a[j];
+          if (x > y) a[i] = y, a[j] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__host__ __device__ inline size_t chain_wave_lds_bytes(int m) {
+  if (m <= 0) return 16;
+  int bits = 0;
+  for (unsigned v = (unsigned)m - 1u; v; v >>= 1) ++bits;
+  return (size_t)64 * m + (size_t)16 * ((size_t)2 << bits) + 3 * 48 * 4 + 64;
+}
+
+// grid: one workgroup of 64 lanes per entry of `which` (pair indices, those whose arrays fit `lds_cap`)
+__global__ __launch_bounds__(64) void chain_wave_kernel(const sdf_anchor *__restrict__ anchors, const int64_t *__restrict__ off,
+                                                        const int32_t *__restrict__ which, int max_chain_gap, int match_chain_score,
+                                                        int32_t *__restrict__ path, int32_t *__restrict__ bounds,
+                                                        int32_t *__restrict__ nbound) {
+  extern __shared__ __align__(16) unsigned char chain_lds[];
+  const int p = which[blockIdx.x], lane = threadIdx.x;
+  const sdf_anchor *A = anchors + off[p];
+  const int m = (int)(off[p + 1] - off[p]);
+  int32_t *pth = path + off[p];
+  int32_t *bnd = bounds + 2 * (off[p] + p);
+  if (m == 0) {
+    if (lane == 0) bnd[0] = 0, bnd[1] = 0, nbound[p] = 1;
+    return;
+  }
+  int bits = 0;
+  for (unsigned v = (unsigned)m - 1u; v; v >>= 1) ++bits;
+  const int tsize = (1 << bits) << 1;
+  // layout: kx [2m] u64 (event keys; after the sweep: the dp keys) | ys [m] Pt | nodes [tsize] Node | anchors [m] | prev [m] |
+  // used [m] | dpv [m]  (the keys of the points, ky, lie over prev + used until the points are written)
+  unsigned long long *kx = reinterpret_cast<unsigned long long *>(chain_lds);
+  Pt *ys = reinterpret_cast<Pt *>(kx + 2 * m);
+  Node *nodes = reinterpret_cast<Node *>(ys + m);
+  sdf_anchor *L = reinterpret_cast<sdf_anchor *>(nodes + tsize);
+  int32_t *prev = reinterpret_cast<int32_t *>(L + m), *used = prev + m, *dpv = used + m;
+  int32_t *stk = dpv + m;  // the range query's recursion stack: 3 x 48 words (private arrays would be scratch memory in HBM)
+  unsigned long long *ky = reinterpret_cast<unsigned long long *>(prev);
+  static_assert(sizeof(sdf_anchor) == 16 && sizeof(Pt) == 16 && sizeof(Node) == 16, "sixteen-byte records");
+  int max_q = 0, max_r = 0;
+  for (int i = lane; i < m; i += 64) {
+    const sdf_anchor a = A[i];
+    L[i] = a;
+    kx[2 * i] = ((unsigned long long)(unsigned)a.q << 32) | (unsigned)i;            // start event (x, anchor)
+    kx[2 * i + 1] = ((unsigned long long)(unsigned)(a.q + a.l) << 32) | (unsigned)i;  // end event
+    ky[i] = ((unsigned long long)(unsigned)(a.r + a.l - 1) << 32) | (unsigned)i;
+    max_q = max(max_q, a.q + a.l);
+    max_r = max(max_r, a.r + a.l);
+    dpv[i] = 0;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    max_q = max(max_q, __shfl_xor(max_q, o));
+    max_r = max(max_r, __shfl_xor(max_r, o));
+  }
+  __syncthreads();
+  chain_sort_u64(kx, 2 * m, lane);
+  chain_sort_u64(ky, m, lane);
+  // the points in their sorted order, then (ky is dead) prev / used
+  for (int i = lane; i < m; i += 64) {
+    const unsigned long long kv = ky[i];
+    ys[i] = Pt{P2{(int)(kv >> 32), (int)(kv & 0xffffffffu)}, TREE_MIN, (int)(kv & 0xffffffffu)};
+  }
+  __syncthreads();
+  for (int i = lane; i < m; i += 64) prev[i] = -1, used[i] = 0;
+  // the tree (src/segment.tpp:172-192): node i covers the point range [s, e) its index implies -- root [0, m), children
+  // [s, (s + e + 1) / 2) and [(s + e + 1) / 2, e) --; one point: a leaf holding point s; more: h = the key of its last point
+  for (int i = lane; i < tsize; i += 64) {
+    int depth = 0;
+    for (unsigned v = (unsigned)i + 1u; v > 1u; v >>= 1) ++depth;
+    int sgm = 0, e = m;
+    bool exists = true;
+    for (int d = depth - 1; d >= 0 && exists; --d) {
+      if (sgm + 1 >= e) {
+        exists = false;  // an ancestor is already a leaf
+        break;
+      }
+      const int bndp = (sgm + e + 1) / 2;
+      if ((((unsigned)i + 1u) >> d) & 1u) sgm = bndp;  // (bit d of i + 1 below its leading one: 1 = right child)
+      else e = bndp;
+    }
+    Node nd;
+    nd.p = -1;
+    nd.a = -1;
+    nd.h = P2{0, 0};
+    if (exists && sgm < e) {
+      nd.a = sgm + 1 == e ? sgm : -1;
+      nd.h = ys[e - 1].x;
+    }
+    nodes[i] = nd;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    Tree tr{nodes, ys, tsize};
+    int deactivate_bound = 0;
+    for (int xi = 0; xi < 2 * m; ++xi) {
+      const unsigned long long ev = kx[xi];
+      const int i = (int)(ev & 0xffffffffu), x = (int)(ev >> 32);
+      const sdf_anchor a = L[i];
+      if (x == a.q) {  // start point
+        while (deactivate_bound < xi) {
+          const unsigned long long dv = kx[deactivate_bound];
+          const int t = (int)(dv & 0xffffffffu);
+          const sdf_anchor at = L[t];
+          if ((int)(dv >> 32) == at.q + at.l) {  // an end point
+            if (a.q - (at.q + at.l) <= max_chain_gap) break;
+            tr.deactivate(P2{at.r + at.l - 1, t});
+          }
+          ++deactivate_bound;
+        }
+        const int wgt = match_chain_score * a.has_u + (match_chain_score / 2) * (a.l - a.has_u);
+        const int node = tr.rmq(P2{a.r - max_chain_gap, 0}, P2{a.r - 1, m}, stk, stk + 48, stk + 96);
+        int j = node == -1 ? -1 : nodes[node].a;
+        int val = wgt;
+        if (j != -1 && ys[j].score != TREE_MIN) {
+          j = ys[j].pos;
+          const sdf_anchor pa = L[j];
+          const int gap = (a.q - (pa.q + pa.l) + a.r - (pa.r + pa.l));
+          if (wgt + dpv[j] - gap > 0) {
+            val = wgt + dpv[j] - gap;
+            prev[i] = j;
+          }
+        }
+        dpv[i] = val;
+      } else {  // end point: the anchor becomes available as a predecessor
+        const int gap = (max_q + 1 - (a.q + a.l) + max_r + 1 - (a.r + a.l));
+        tr.activate(P2{a.r + a.l - 1, i}, dpv[i] - gap);
+      }
+    }
+  }
+  __syncthreads();
+  // sort(dp, greater) on (score, anchor): ascending on the complemented key
+  for (int i = lane; i < m; i += 64) kx[i] = ~(((unsigned long long)(unsigned)dpv[i] << 32) | (unsigned)i);
+  __syncthreads();
+  chain_sort_u64(kx, m, lane);
+  if (lane == 0) {
+    bnd[0] = 0;
+    bnd[1] = 0;
+    int nb = 1, np = 0;
+    for (int k = 0; k < m; ++k) {
+      int maxi = (int)(~kx[k] & 0xffffffffu);
+      if (used[maxi]) continue;
+      int has_u = 0;
+      while (maxi != -1 && !used[maxi]) {
+        pth[np++] = maxi;
+        has_u += L[maxi].has_u;
+        used[maxi] = 1;
+        maxi = prev[maxi];
+      }
+      bnd[2 * nb] = np;
+      bnd[2 * nb + 1] = has_u != 0;  // int -> bool: "any uppercase anchor"
+      ++nb;
+    }
+    nbound[p] = nb;
+  }
 }
 
 // Test hook (tests/test_chain_oracle.py): one thread replays a script of activate / deactivate / rmq calls on the device

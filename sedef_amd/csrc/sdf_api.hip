@@ -200,7 +200,7 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   for (auto ev : ctx->events) (void)hipEventDestroy(ev);
   for (DevBuf *b : {&ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag,
                     &ctx->an_pos, &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff, &ctx->ch_an, &ctx->ch_off,
-                    &ctx->ch_wsoff, &ctx->ch_work, &ctx->ch_path, &ctx->ch_bounds, &ctx->ch_nb, &ctx->st_tasks, &ctx->st_pool,
+                    &ctx->ch_wsoff, &ctx->ch_work, &ctx->ch_path, &ctx->ch_bounds, &ctx->ch_nb, &ctx->ch_which, &ctx->st_tasks, &ctx->st_pool,
                     &ctx->st_cig, &ctx->st_out})
     b->release();
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
@@ -1037,6 +1037,19 @@ extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const in
     return SDF_ERR_INVALID;
   }
   if (n == 0) return SDF_OK;
+  // Round 4: a pair whose arrays fit the LDS of a workgroup is swept by ONE WAVEFRONT with everything in LDS
+  // (chain_wave_kernel: launch classes by LDS size, the pairs of most anchors first); the others keep the thread-per-pair
+  // kernel with its scratch in HBM.  SDF_CHAIN_THREADS=1: every pair on the latter (tests).
+  static const bool threads_only = [] {
+    const char *e = getenv("SDF_CHAIN_THREADS");
+    return e && e[0] == '1';
+  }();
+  // (classes of up to 32 KiB, ~400 anchors, whatever their number; up to the device's LDS per workgroup when they are FEW: a wavefront
+  // sweeps an anchor in ~14 us where a thread chasing nodes in HBM takes ~85 -- the launch is its largest pair --, but two
+  // such workgroups fit a CU: 8,192 pairs of ~700 anchors take 150 ms that way against 59 ms with every pair in flight on
+  // the thread-per-pair kernel; profiles/r04_chain_bench.txt)
+  const size_t caps[6] = {2048, 4096, 8192, 16384, 32768, (size_t)std::max(ctx->max_dyn_lds, 65536)};
+  std::vector<int32_t> cls[7];  // [6]: thread-per-pair
   std::vector<int64_t> ws_off(n + 1);
   int64_t words = 0;
   for (size_t i = 0; i < n; i++) {
@@ -1046,13 +1059,38 @@ extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const in
       return SDF_ERR_INVALID;
     }
     ws_off[i] = words;
-    if (m > 0) {
+    int c = 6;
+    if (!threads_only && m < (1 << 20)) {
+      const size_t need = sdf::chain_wave_lds_bytes((int)m);
+      for (int q = 5; q >= 0; --q)
+        if (need <= caps[q]) c = q;
+    }
+    cls[c].push_back((int32_t)i);
+    if (c == 6 && m > 0) {
       int bits = 0;
       for (unsigned v = (unsigned)m - 1u; v; v >>= 1) ++bits;
       words += 12 * m + 4 * ((int64_t)2 << bits);
     }
   }
+  if (cls[5].size() > 512) {  // many large pairs: every one of them in flight instead
+    for (int32_t i : cls[5]) {
+      const int64_t m = off[i + 1] - off[i];
+      int bits = 0;
+      for (unsigned v = (unsigned)m - 1u; v; v >>= 1) ++bits;
+      ws_off[i] = words;
+      words += 12 * m + 4 * ((int64_t)2 << bits);
+    }
+    cls[6].insert(cls[6].end(), cls[5].begin(), cls[5].end());
+    cls[5].clear();
+  }
   ws_off[n] = words;
+  std::vector<int32_t> which;
+  size_t cls_first[7];
+  for (int c = 0; c < 7; ++c) {
+    std::stable_sort(cls[c].begin(), cls[c].end(), [&](int32_t a, int32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+    cls_first[c] = which.size();
+    which.insert(which.end(), cls[c].begin(), cls[c].end());
+  }
   const size_t total = (size_t)off[n];
   if (total && (!anchors || !path)) {
     ctx->err = "invalid arguments";
@@ -1070,10 +1108,25 @@ extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const in
   if (total) SDF_HIP(hipMemcpyAsync(ctx->ch_an.p, anchors, total * sizeof(sdf_anchor), hipMemcpyHostToDevice, st));
   SDF_HIP(hipMemcpyAsync(ctx->ch_off.p, off, (n + 1) * 8, hipMemcpyHostToDevice, st));
   SDF_HIP(hipMemcpyAsync(ctx->ch_wsoff.p, ws_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(sdf::chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st,
-                     (const sdf_anchor *)ctx->ch_an.p, (const int64_t *)ctx->ch_off.p, (const int64_t *)ctx->ch_wsoff.p,
-                     (int)n, max_chain_gap, match_chain_score, (int32_t *)ctx->ch_work.p, (int32_t *)ctx->ch_path.p,
-                     (int32_t *)ctx->ch_bounds.p, (int32_t *)ctx->ch_nb.p);
+  SDF_HIP(ctx->ch_which.reserve(n * 4 + 16));
+  SDF_HIP(hipMemcpyAsync(ctx->ch_which.p, which.data(), n * 4, hipMemcpyHostToDevice, st));
+  static std::once_flag lds_once;
+  std::call_once(lds_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sdf::chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)caps[5]);
+    (void)hipGetLastError();
+  });
+  for (int c = 0; c < 6; ++c)
+    if (!cls[c].empty())
+      hipLaunchKernelGGL(sdf::chain_wave_kernel, dim3((unsigned)cls[c].size()), dim3(64), caps[c], st,
+                         (const sdf_anchor *)ctx->ch_an.p, (const int64_t *)ctx->ch_off.p,
+                         (const int32_t *)ctx->ch_which.p + cls_first[c], max_chain_gap, match_chain_score,
+                         (int32_t *)ctx->ch_path.p, (int32_t *)ctx->ch_bounds.p, (int32_t *)ctx->ch_nb.p);
+  if (!cls[6].empty())
+    hipLaunchKernelGGL(sdf::chain_kernel, dim3((unsigned)((cls[6].size() + 63) / 64)), dim3(64), 0, st,
+                       (const sdf_anchor *)ctx->ch_an.p, (const int64_t *)ctx->ch_off.p, (const int64_t *)ctx->ch_wsoff.p,
+                       (int)cls[6].size(), max_chain_gap, match_chain_score, (int32_t *)ctx->ch_work.p, (int32_t *)ctx->ch_path.p,
+                       (int32_t *)ctx->ch_bounds.p, (int32_t *)ctx->ch_nb.p, (const int32_t *)ctx->ch_which.p + cls_first[6]);
   SDF_HIP(hipGetLastError());
   if (total) SDF_HIP(hipMemcpyAsync(path, ctx->ch_path.p, total * 4, hipMemcpyDeviceToHost, st));
   SDF_HIP(hipMemcpyAsync(bounds, ctx->ch_bounds.p, (total + n) * 8, hipMemcpyDeviceToHost, st));

@@ -263,7 +263,7 @@ struct sdf_ctx {
   HostBuf host_plan, host_order;  // pinned staging of the plan
   HostBuf host_pool, host_out;    // pinned staging of the host-buffer entry point (packed sequences; results + CIGARs)
   DevBuf an_pool, an_pairs, an_keys, an_keys2, an_q, an_off, an_flag, an_pos, an_cand, an_out, an_tmp, an_outoff;
-  DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb;
+  DevBuf ch_an, ch_off, ch_wsoff, ch_work, ch_path, ch_bounds, ch_nb, ch_which;
   DevBuf st_tasks, st_pool, st_cig, st_out;  // sdf_stats_columns_batch
   DevBuf claim_buf;                          // stripe launches: eight entry counters each (stripe_claim), zeroed per call
   DevBuf st_items;                           // sdf_stats_columns_device: segments of long alignments + their counter
