@@ -219,8 +219,13 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 :
   const PlanTask tk = plan[order[blockIdx.x]];
   // (a long task is a chain of dependent rows that ends the launch: its wavefront gets the SIMD before those of short
   // tasks sharing it)
-  if (tk.qlen + tk.tlen >= 16384) __builtin_amdgcn_s_setprio(3);
-  else if (tk.qlen + tk.tlen >= 6144) __builtin_amdgcn_s_setprio(2);
+  // (one level below the banded stripes' (extz2_bstripe.hip: 2 / 3): a window of at most 256 slots walks its rows in a quarter of
+  // the time a stripe at the band's edge takes for the same row -- in a batch that holds both, the stripes' chain is the
+  // one that ends the call)
+  // (measured on the mm8-like batch of 3,000 tasks: 3 / 2 as the pair kernel 21.1 ms, 2 / 1 20.1-20.5 ms, 1 / 0 21.8-22.5 ms -- the
+  // one-task kernel's own long chains then become the end of the call)
+  if (tk.qlen + tk.tlen >= 16384) __builtin_amdgcn_s_setprio(2);
+  else if (tk.qlen + tk.tlen >= 6144) __builtin_amdgcn_s_setprio(1);
   const int lane = threadIdx.x;
   const int qlen = tk.qlen, tlen = tk.tlen, w = tk.w;
   // Sequence windows in LDS.  Tb[i] = target position tt0 + i (16-bit codes, zero beyond the ends); W[i] = entry
