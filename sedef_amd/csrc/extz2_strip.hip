@@ -32,7 +32,8 @@ namespace sdf {
 // columns per lane: 8 (a block of 512 columns per wavefront), or 4 for chains of few wavefronts -- a step of four cells
 // is half as long, and a chain of blocks runs at the pace of its steps
 constexpr int kStripMaxT = 512;        // widest target of the one-wavefront kernel: one block of 8 columns per lane
-constexpr int kStripChainMaxT = 8192;  // ... of a chain of wavefronts, one per block (extz2_strip_chain_kernel)
+constexpr int kStripChainMaxT = 65536;  // ... of a chain of wavefronts, one per block (extz2_strip_chain_kernel): the block index
+                                       // of a launch entry has eight bits (256 blocks of 256 columns); the stage's tasks end at 60 kb
 
 __host__ __device__ inline int strip_blocks(int tlen, int cols = 8) { return (tlen + 64 * cols - 1) / (64 * cols); }
 __host__ __device__ inline size_t strip_dir_bytes(int qlen, int tlen, int cols = 8, bool solo = false) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(64) void extz2_strip_kernel(const PlanTask *__restr
 }
 
 // ---- wide targets: a chain of wavefronts, one per block of 512 columns ----------------------------------------------
-// Targets of 1025 .. 8192 bases: block b of a pair of tasks is the work of one wavefront (its own workgroup), 64 steps
+// Targets of 513 .. 65536 bases: block b of a pair of tasks is the work of one wavefront (its own workgroup), 64 steps
 // behind the wavefront of block b - 1, which hands x, v of its last column over through HBM: one word per row for both
 // tasks, bit 7 set when written (x <= 127: the bit is free), relaxed atomics of agent scope, fetched sixteen rows at a
 // time.  Forward progress as in extz2_stripe.hip: a pair's blocks share an XCD (workgroup index mod 8) and are listed

@@ -722,8 +722,15 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   };
   g_us_chain = 0;
   g_us_rest = 0;
+  // SDF_DEBUG_TIMING: one line per phase of every super-batch, milliseconds since the stage clock started
+  static const bool dbg_tl = getenv("SDF_DEBUG_TIMING") != nullptr;
+  auto mark = [&](int base, const char *what) {
+    if (dbg_tl) fprintf(stderr, "[stage %7.1f ms] batch@%d %s\n", since(t0) * 1e3, base, what);
+  };
   std::vector<Hit> schedule = read_schedule(bed_path, log);
+  mark(-1, "schedule read");
   FastaReference fr(ref_path);
+  mark(-1, "fasta index open");
   fprintf(log, "Using k-mer size %d\n", kmer_size);
   const int total = (int)schedule.size();
 
@@ -771,6 +778,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   auto do_batch = [&](int base, int n, DpProvider &dp, Acc &a, std::vector<std::string> &lines,
                       std::vector<int> &nhits) {
     std::vector<Item> items(n);
+    mark(base, "start");
     const auto tf = now();
     parallel_for(n, [&](int k) {  // src/align_main.cc:299-306
       Item &it = items[k];
@@ -781,6 +789,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
     });
     a.t_fetch += since(tf);
+    mark(base, "sequences fetched");
     DpProvider::AnchorBatch seeds;  // lives until the jobs have taken their copies (first round)
     {  // seed anchors of the whole super-batch in one device pass, when the provider offers it
       std::vector<DpProvider::AnchorJob> aj(n);
@@ -796,6 +805,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         a.anchor_secs += since(ta);
       }
     }
+    mark(base, "anchors done");
     // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch.
     // Results of the previous round: Cigars per pair (provider without a raw form), or the raw device words
     // and each pair's first request in them -- then the pair's own thread builds (and later frees) its Cigars
@@ -845,11 +855,13 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       a.t_collect += since(tc);
       if (!any) break;
       a.rounds++;
+      mark(base, "jobs advanced, requests collected");
       const auto td = now();
       std::vector<Cigar> got;
       have_raw = dp.run_raw(batch, p, raw);
       if (!have_raw) got = dp.run(batch, p);
       a.dp_secs += since(td);
+      mark(base, "DP round done");
       const auto tc2 = now();
       size_t cur = 0;
       std::fill(n_req.begin(), n_req.end(), 0);
@@ -891,6 +903,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       }
     });
     a.t_out += since(tout);
+    mark(base, "output formatted");
   };
   auto write_batch = [&](int base, int n, const std::vector<std::string> &lines, const std::vector<int> &nhits) {
     for (int k = 0; k < n; k++) {
@@ -933,6 +946,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
           } catch (std::string &) {  // no room for another device context: one lane fewer
           }
           prov[(size_t)l] = extra[(size_t)l].get();
+          mark(-2 - l, "lane's device context ready");
           if (!prov[(size_t)l]) return;
         }
         std::vector<std::string> lines;

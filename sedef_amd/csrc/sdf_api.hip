@@ -64,6 +64,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
     g_err = "hipSetDevice failed";
     return nullptr;
   }
+  const auto t_create = std::chrono::steady_clock::now();
   sdf_ctx *ctx = new sdf_ctx();
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -71,9 +72,18 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
     delete ctx;
     return nullptr;
   }
+  auto lap = [&](const char *what) {
+    if (getenv("SDF_DEBUG_TIMING"))
+      fprintf(stderr, "[sdf_create %s at %.1f ms]\n", what,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
+  };
+  lap("first stream");
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
+  lap("mem info");
   size_t budget = workspace_bytes ? workspace_bytes : (size_t)64 << 30;
+  if (const char *e = getenv("SDF_WORKSPACE_GIB"))  // (overrides the caller's figure: experiments with the stage driver)
+    if (atof(e) > 0) budget = (size_t)(atof(e) * 1073741824.0);
   if (free_b && budget > free_b / 2) budget = free_b / 2;
   ctx->ws_budget = budget;
   // allow the general kernel its full 160 KiB of LDS
@@ -167,6 +177,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_lane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             want_lds);
   (void)hipGetLastError();
+  lap("attributes");
   const char *pl = getenv("SDF_PIPELINE");
   ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
@@ -179,6 +190,9 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   // queues, and two of ours landing on one queue serialises what the pipeline wants side by side; with the
   // caller's stream that makes four)
   g_live_contexts.fetch_add(1);
+  if (getenv("SDF_DEBUG_TIMING"))
+    fprintf(stderr, "[sdf_create device %d: %.1f ms]\n", device,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
   return ctx;
 }
 

@@ -241,7 +241,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     return env.bstripe_min_rows > 0 && t.w >= 1 && t.qlen + t.tlen - 1 >= env.bstripe_min_rows && plan_detail::bstripe_nreg(t.tlen) > 0;
   };
   auto order_entries = [&](const sdf_task &t) -> uint32_t {  // a task paired with itself is listed twice, a stripe task
-    // (chained strips take full-band targets of 513..8192 bases whatever stripe_min is: eight idle entries of padding per
+    // (chained strips take full-band targets of 513..65536 bases whatever stripe_min is: eight idle entries of padding per
     // block at most -- ADVICE r3: with SDF_STRIPE_MIN above 512 their launch order overflowed)
     const bool chain = env.strip_ok && t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT;
     return 2 + (t.tlen > env.stripe_min && t.tlen <= 8192 ? (uint32_t)(t.tlen + 127) / 128 : chain ? 8u * (uint32_t)strip_blocks(t.tlen, 4) : 0u) +  // once per stripe
@@ -806,14 +806,17 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     p.cig_slot = stage_words;
     stage_words += p.cig_cap;
     if (use_strip && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) && t.tlen > 256 && t.tlen <= kStripMaxT &&
-        t.qlen >= 64 && t.qlen < (1 << 20)) {
+        t.qlen >= 64 && t.qlen < (1 << 18)) {
       // full band, a few hundred target bases: row-major strips, two tasks per wavefront
       p.nreg = 8;  // (columns per lane)
       p.pad_ = 9;
       win_need.back() = 0;
-    } else if (use_chain && !env.no_stripe && p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) &&
-               t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT && t.qlen >= 64 && t.qlen < (1 << 20)) {
-      // ... wider: the same strips, a wavefront per block of columns, chained through HBM
+    } else if ((use_chain || (env.strip_ok && t.tlen > 8192)) && !env.no_stripe && p.pad_ != 7 && plain_ok &&
+               p.w >= std::max(t.qlen, t.tlen) && t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT && t.qlen >= 64 &&
+               t.qlen < (1 << 18)) {
+      // ... wider: the same strips, a wavefront per block of columns, chained through HBM.  Targets beyond the stripe
+      // kernel's 8192 bases are chains however few they are: the alternative is the workgroup kernel walking its window
+      // through LDS at ~3 us per row (the stage's far-gap tasks of 8-10 kb a side: 52 ms as eight workgroups, profiles/r04_stage.txt)
       p.nreg = 8;  // (columns per lane: 8, or 4 when the chunk has few chains -- decided below)
       p.pad_ = 10;
       win_need.back() = 0;
@@ -1091,9 +1094,13 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         if (cp[k].pad_ == 10) cp[k].nreg = cols;
     }
     for (size_t k = 0; k < cnt; ++k)
-      if (cp[k].pad_ == 9 || cp[k].pad_ == 10)  // (blocks, rows, columns, index): 6 + 20 + 14 + 24 bits
-        keys.push_back(((uint64_t)(strip_blocks(cp[k].tlen, cp[k].nreg) - 1 + (cp[k].pad_ == 10 ? 32 : 0)) << 58) |
-                       ((uint64_t)(uint32_t)cp[k].qlen << 38) | ((uint64_t)(uint32_t)cp[k].tlen << 24) | (uint64_t)k);
+      if (cp[k].pad_ == 9 || cp[k].pad_ == 10) {
+        // (blocks, rows, columns within the last block, index): 8 + 18 + 9 + 24 bits -- up to 256 blocks; a one-wavefront
+        // task has one block and a chain at least two, so the two kinds stay apart
+        const int bw = 64 * cp[k].nreg;
+        keys.push_back(((uint64_t)(strip_blocks(cp[k].tlen, cp[k].nreg) - 1) << 51) | ((uint64_t)(uint32_t)cp[k].qlen << 33) |
+                       ((uint64_t)(uint32_t)((cp[k].tlen - 1) % bw) << 24) | (uint64_t)k);
+      }
     // (8,747 keys in the heavy chunk of the hg19 mixture, planned in front of the call's first launch: a byte-wise radix
     // sort over the bytes that differ takes 0.05 ms where std::sort takes 0.25)
     if (keys.size() >= 2048) {

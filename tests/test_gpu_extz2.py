@@ -543,6 +543,29 @@ def test_strip_chain_wide_full_band_tasks(strip_engine, oracle):
     _check_fast(_engine_with_env(SDF_NO_LANE=1), oracle, pairs[:6], [-1] * 6)
 
 
+def test_strip_chain_targets_wider_than_8192(engine, oracle):
+    """Full-band targets beyond the stripe kernel's 8192 bases (the stage's far-gap tasks: 8-10 kb a side and up to the 60 kb
+    of a chunk, src/align.cc:129-175) are chains of up to 256 blocks however few they are; before round 4 they were the
+    workgroup kernel's, ~3 us per row."""
+    rng = np.random.default_rng(8004)
+    pairs = []
+    for ql, tl in [(9000, 8200), (8700, 8700), (8650, 8710), (3000, 12000), (12000, 9000), (20000, 16400), (64, 30000),
+                   (15000, 20000), (500, 8193)]:
+        q = random_codes(rng, ql, 0.003 if len(pairs) % 3 == 1 else 0.0)
+        t = mutate(rng, q, 0.05, 0.01, 0.01)
+        at = int(rng.integers(0, max(1, len(t) - 1)))
+        t = _fit(rng, np.concatenate([t[:at], random_codes(rng, int(rng.integers(1, 3000))), t[at:]]), tl)
+        pairs.append((q, t))
+    flags = [0x80 if k == 3 else 0x01 if k == 6 else 0 for k in range(len(pairs))]
+    _check_fast(engine, oracle, pairs, [-1] * len(pairs), flags)
+    assert engine.last_reran() == 0
+    # the same through four columns per lane (blocks of 256 columns) and with a wait that gives up
+    _check_fast(_engine_with_env(SDF_STRIP_COLS=4), oracle, pairs[:5], [-1] * 5, flags[:5])
+    eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1)
+    _check_fast(eng, oracle, pairs[:4], [-1] * 4, flags[:4])
+    assert eng.last_reran() >= 2
+
+
 def test_strip_kernel_other_scorings(strip_engine, oracle):
     engine = strip_engine
     rng = np.random.default_rng(8002)
