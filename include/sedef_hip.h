@@ -114,6 +114,20 @@ int sdf_device_count(void);
  * (sdf_last_error(NULL) has the reason). */
 sdf_ctx *sdf_create(int device, size_t workspace_bytes);
 void sdf_destroy(sdf_ctx *ctx);
+/* Sizes the context's buffers ONCE for host-buffer batch calls of up to max_tasks tasks whose sequences add up to
+ * max_bases bases: the pinned staging (task plan, launch order, packed sequences, results), the device copies of
+ * those, the CIGAR staging and the streams of the call's pipeline -- no call within the bounds allocates, pins or sets
+ * up a hardware queue afterwards (pinning runs at ~4 MB per
+ * millisecond: a first call of 700,000 tasks spends 40-50 ms on it) -- and workspace_bytes of the direction-flag
+ * workspace (clamped to the context's budget; 0: left to the first call that needs it).  Larger calls still grow the
+ * buffers.  Call it where a context is set up: pinning takes the process's memory-map lock, and a pageable upload that
+ * runs meanwhile (sdf_anchors_batch) waits for it -- measured: 46-78 ms for a 34-54 MB upload next to a reserve on another
+ * thread, 4 ms without.  It must have returned before the context's first batch call.  (The stage driver: once per lane,
+ * with the lane's context, host/pipeline.cc.) */
+#define SDF_RESERVE_BRIEF 1u /* the caller reads results through sdf_extz2_batch_brief: 16 bytes of result staging per task */
+int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, size_t workspace_bytes, uint32_t flags);
+/* Device bytes the context holds at this moment (buffers in use, outgrown ones not yet freed). */
+size_t sdf_device_bytes(const sdf_ctx *ctx);
 const char *sdf_last_error(const sdf_ctx *ctx);
 
 /* ---- packed sequence format --------------------------------------------------------------
@@ -135,6 +149,19 @@ size_t sdf_pack_tasks(const uint8_t *codes, const int64_t *q_off, const int32_t 
 int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
                     const uint8_t *seq_pool, size_t pool_bytes, uint32_t want, sdf_result *out,
                     uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+
+/* The same call with 16-byte result records: what a caller that only stitches CIGARs reads (the stage driver:
+ * src/align.cc:129-175 keeps the CIGAR of every piece and nothing else of ksw_extz_t) -- a quarter of the bytes
+ * of sdf_result across PCIe and through the caller's caches.  Always computes CIGARs. */
+typedef struct {
+  int64_t cigar_off; /* first word of the task's CIGAR in cigar_pool */
+  int32_t n_cigar;
+  int32_t matches;   /* 'M' columns with equal bases (what src/align.cc:274-311 counts as error.matches) */
+} sdf_result_brief;
+int sdf_extz2_batch_brief(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                          const uint8_t *seq_pool, size_t pool_bytes, sdf_result_brief *out,
+                          uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+
 
 /* Device-resident form: d_packed_pool, d_out and d_cigar_pool are HBM pointers on ctx's device;
  * tasks (host) carry word offsets into d_packed_pool.  Work is enqueued on `stream`

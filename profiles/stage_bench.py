@@ -27,7 +27,7 @@ import hostgen  # noqa: E402
 from sedef_amd import host  # noqa: E402
 from sedef_amd.host import CLI, build_host  # noqa: E402
 
-KEEP = ("Finished", "host CPU", "driver (", "sdf_extz2_batch", "sdf_anchors", "DevBuf", "slow plan", "process:", "[stage ", "sdf_create", "[class ", "[batch ", "[plan")
+KEEP = ("Finished", "host CPU", "driver (", "sdf_extz2_batch", "sdf_anchors", "DevBuf", "slow plan", "process:", "[stage ", "sdf_create", "[class ", "[batch ", "[plan", "[sdf_reserve", "[chunk ", "[lane ")
 
 
 def cores():

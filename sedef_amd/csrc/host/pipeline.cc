@@ -78,13 +78,87 @@ void fill_mat(const Params &p, int8_t mat[25]) {  // src/align.cc:41-44
 
 class GpuProvider : public DpProvider {
  public:
-  explicit GpuProvider(int device) : device_(device) {
-    ctx_ = sdf_create(device, 0);
-    if (!ctx_) throw std::string("GPU DP backend unavailable: ") + sdf_last_error(nullptr);
+  // (`spares`: that many more providers, started before this one's own context so that all of them are set up side by side)
+  // `max_batch_bytes` (0: unknown, prepare() will tell): the buffers are sized here, with the context.
+  explicit GpuProvider(int device, int spares = 0, const std::vector<int> &devices = std::vector<int>(),
+                       size_t max_batch_bytes = 0)
+      : device_(device) {
+    if (spares > 0) start_spares(spares, devices, max_batch_bytes);
+    ctx_ = sdf_create(device, stage_workspace());
+    if (!ctx_) {
+      for (auto &t : spare_threads_)
+        if (t.joinable()) t.join();
+      throw std::string("GPU DP backend unavailable: ") + sdf_last_error(nullptr);
+    }
+    if (max_batch_bytes) {
+      prepared_ = true;
+      reserve(max_batch_bytes);
+    }
   }
-  ~GpuProvider() override { sdf_destroy(ctx_); }
+  ~GpuProvider() override {
+    ready();
+    for (auto &t : spare_threads_)
+      if (t.joinable()) t.join();
+    spares_.clear();
+    sdf_destroy(ctx_);
+  }
+  // Direction-flag workspace of a stage lane: 8 GiB unless SDF_STAGE_WS_GIB says otherwise (the library's default is 64).
+  // A round of the stage that needs more runs in chunks; in exchange the lane allocates its workspace ONCE, up front on the
+  // thread of prepare(): a 23 GiB request in the middle of a run took 0.4 ms or 580 ms, box and run dependent
+  // (profiles/r04_stage.txt).
+  static size_t stage_workspace() {
+    const char *e = getenv("SDF_STAGE_WS_GIB");
+    const double gib = e && atof(e) > 0 ? atof(e) : 8.0;
+    return (size_t)(gib * 1073741824.0);
+  }
+  // Spare providers for the other lanes, each created on a thread of its own (make_gpu_providers)
+  void start_spares(int n, const std::vector<int> &devices, size_t max_batch_bytes) {
+    spares_.resize((size_t)n);
+    spare_dev_.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+      spare_dev_[(size_t)i] = devices.empty() ? device_ : devices[(size_t)(i + 1) % devices.size()];
+      spare_threads_.emplace_back([this, i, max_batch_bytes] {
+        try {
+          spares_[(size_t)i].reset(new GpuProvider(spare_dev_[(size_t)i], 0, std::vector<int>(), max_batch_bytes));
+        } catch (std::string &) {  // (no room for another context: clone() will try again, the lane does without)
+        }
+      });
+    }
+  }
   std::unique_ptr<DpProvider> clone(int device = -1) override {
-    return std::unique_ptr<DpProvider>(new GpuProvider(device < 0 ? device_ : device));
+    const int want = device < 0 ? device_ : device;
+    {
+      std::lock_guard<std::mutex> g(spare_mu_);
+      for (size_t i = 0; i < spares_.size(); i++) {
+        if (spare_dev_[i] != want || spare_taken_.count(i)) continue;
+        spare_taken_.insert(i);
+        if (spare_threads_[i].joinable()) spare_threads_[i].join();
+        if (spares_[i]) return std::unique_ptr<DpProvider>(spares_[i].release());
+      }
+    }
+    return std::unique_ptr<DpProvider>(new GpuProvider(want));
+  }
+  // Buffers sized once per lane (include/sedef_hip.h: sdf_reserve), on a thread of its own.  The bounds follow the stage's
+  // rounds as measured: a task per ~250 bytes of a super-batch's sequences at most (chr1-sized run: 708,600 tasks of
+  // 182 MB), a tenth of the bytes as bases of DP tasks.
+  // (a provider that was not told the size when it was set up -- the C ABI's generate entry point -- sizes its buffers on a
+  // thread of its own while the driver fetches sequences; pinning next to the first anchors upload slows that one down,
+  // include/sedef_hip.h: sdf_reserve)
+  void prepare(size_t max_batch_bytes) override {
+    if (prepared_) return;
+    prepared_ = true;
+    reserve_thread_ = std::thread([this, max_batch_bytes] { reserve(max_batch_bytes); });
+  }
+  void reserve(size_t max_batch_bytes) {
+    const size_t tasks = max_batch_bytes / 250 + 65536, bases = max_batch_bytes / 6 + (1u << 20);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = sdf_reserve(ctx_, tasks, bases, stage_workspace(), SDF_RESERVE_BRIEF);
+    if (getenv("SDF_DEBUG_TIMING"))
+      fprintf(stderr, "[sdf_reserve tasks %zu bases %zu: rc %d, %.1f ms]\n", tasks, bases, rc,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+  void ready() {
+    if (reserve_thread_.joinable()) reserve_thread_.join();
   }
   std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) override {
     std::vector<Cigar> out(reqs.size());
@@ -132,14 +206,15 @@ class GpuProvider : public DpProvider {
     fill_mat(p, sc.mat);
     sc.gapo = (int8_t)(-p.gap_open);
     sc.gape = (int8_t)(-p.gap_extend);
-    std::vector<sdf_result> res(tr.size());
-    // (not a std::vector: the capacity is the worst case, hundreds of megabytes that would be zero-filled and
-    // paged in although the call writes only the words it reports in `used`)
+    // (plain arrays, not std::vectors: the CIGAR capacity is the worst case, hundreds of megabytes that would be
+    // zero-filled and paged in although the call writes only the words it reports in `used`)
+    std::unique_ptr<sdf_result_brief[]> res(new sdf_result_brief[tr.size()]);
     std::unique_ptr<uint32_t[]> cig(new uint32_t[cap]);
     size_t used = 0;
+    ready();
     const auto tp1 = std::chrono::steady_clock::now();
-    const int rc = sdf_extz2_batch(ctx_, &sc, tasks.data(), tasks.size(), pool.data(), pool.size(),
-                                   SDF_WANT_CIGAR | SDF_WANT_SCORE, res.data(), cig.get(), cap, &used);
+    const int rc = sdf_extz2_batch_brief(ctx_, &sc, tasks.data(), tasks.size(), pool.data(), pool.size(), res.get(),
+                                         cig.get(), cap, &used);
     if (rc != SDF_OK) throw std::string("DP batch failed: ") + sdf_last_error(ctx_);
     const auto tp2 = std::chrono::steady_clock::now();
     raw.off.resize(tr.size());
@@ -211,6 +286,13 @@ class GpuProvider : public DpProvider {
   sdf_ctx *ctx_;
   int device_;
   int64_t tasks_ = 0;
+  bool prepared_ = false;
+  std::thread reserve_thread_;
+  std::vector<std::unique_ptr<GpuProvider>> spares_;
+  std::vector<int> spare_dev_;
+  std::vector<std::thread> spare_threads_;
+  std::set<size_t> spare_taken_;
+  std::mutex spare_mu_;
 };
 
 struct OracleResult {  // layout of sdfo_result (oracle/extz2_oracle.h)
@@ -264,6 +346,69 @@ Cigar DpProvider::Raw::cigar(size_t req) const {
 }
 
 std::unique_ptr<DpProvider> make_gpu_provider(int device) { return std::unique_ptr<DpProvider>(new GpuProvider(device)); }
+
+std::unique_ptr<DpProvider> make_gpu_providers(int device, int lanes, const std::vector<int> &devices, size_t max_batch_bytes) {
+  return std::unique_ptr<DpProvider>(new GpuProvider(device, std::max(lanes - 1, 0), devices, max_batch_bytes));
+}
+
+static int stage_super_batch(int total, int nlanes, int super_batch) {
+  if (nlanes > 1) super_batch = std::max(1024, std::min(super_batch, (total + 2 * nlanes - 1) / (2 * nlanes)));
+  if (const char *sb = getenv("SDF_SUPER_BATCH")) super_batch = std::max(1, atoi(sb));
+  return super_batch;
+}
+
+StageHint stage_hint(const std::string &bed_path, int super_batch) {
+  StageHint h;
+  std::vector<int64_t> bytes;
+  if (FILE *f = fopen(bed_path.c_str(), "rb")) {
+    // columns 2, 3 and 5, 6 of a line: the two intervals (src/hit.cc: Hit::from_bed); anything else is skipped
+    std::vector<char> line(1 << 16);
+    while (fgets(line.data(), (int)line.size(), f)) {
+      int64_t v[6] = {0, 0, 0, 0, 0, 0};
+      int col = 0;
+      for (const char *c = line.data(); *c && *c != '\n' && col < 6; ++col) {
+        const char *e = c;
+        while (*e && *e != '\t' && *e != '\n') ++e;
+        if (col == 1 || col == 2 || col == 4 || col == 5) v[col] = atoll(c);
+        c = *e == '\t' ? e + 1 : e;
+      }
+      bytes.push_back(std::max<int64_t>(0, v[2] - v[1]) + std::max<int64_t>(0, v[5] - v[4]));
+    }
+    fclose(f);
+  }
+  h.pairs = (int)bytes.size();
+  h.lanes = stage_lane_count(h.pairs, &h.devices);
+  h.super_batch = stage_super_batch(h.pairs, h.lanes, super_batch);
+  // the largest super-batch holds at most the `super_batch` largest pairs (and at most 1 GiB + one pair)
+  const size_t k = std::min<size_t>(bytes.size(), (size_t)h.super_batch);
+  std::partial_sort(bytes.begin(), bytes.begin() + (long)k, bytes.end(), std::greater<int64_t>());
+  int64_t sum = 0;
+  for (size_t i = 0; i < k && sum < ((int64_t)1 << 30); i++) sum += bytes[i];
+  h.max_batch_bytes = (size_t)sum;
+  return h;
+}
+
+int stage_lane_count(int total, std::vector<int> *devices) {
+  // A second context costs 50-120 ms to set up, so small inputs stay on one lane; medium ones are cut into at least two
+  // super-batches per lane.  (measured: 40,000 pairs 1.19 / 0.93 / 1.03 s with 2 / 3 / 4 lanes)
+  int nlanes = total >= 12288 ? 3 : total >= 4096 ? 2 : 1;
+  // SDF_DEVICES=0,1,...: the lanes after the first go round-robin over these devices (one node, several GPUs; the
+  // first lane stays on the provider's own device, which should be the first of the list); at least one lane each
+  std::vector<int> dv;
+  if (const char *e = getenv("SDF_DEVICES")) {
+    for (const char *c = e; *c;) {
+      char *end = nullptr;
+      const long d = strtol(c, &end, 10);
+      if (end == c) break;
+      dv.push_back((int)d);
+      c = *end == ',' ? end + 1 : end;
+    }
+    if (dv.size() > 1) nlanes = std::max<int>(nlanes, (int)std::min<size_t>(dv.size(), 8));
+  }
+  if (const char *e = getenv("SDF_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
+  if (devices) *devices = dv;
+  return nlanes;
+}
 std::unique_ptr<DpProvider> make_test_provider(test_dp_fn fn) { return std::unique_ptr<DpProvider>(new TestProvider(fn)); }
 
 // ======================================================================================================
@@ -745,24 +890,11 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   // Lanes: super-batches are independent, so two or three of them are in flight, each on its own device context -- while
   // one waits for the device, the host threads work on the other.  A second context costs ~0.1 s to set up, so
   // small inputs stay on one lane; medium ones are cut into at least two super-batches per lane.
-  int nlanes = total >= 12288 ? 3 : total >= 4096 ? 2 : 1;  // (measured: 40,000 pairs 1.19 / 0.93 / 1.03 s with 2 / 3 / 4 lanes)
-  // SDF_DEVICES=0,1,...: the lanes after the first go round-robin over these devices (one node, several GPUs; the
-  // first lane stays on the provider's own device, which should be the first of the list); at least one lane each
   std::vector<int> devices;
-  if (const char *e = getenv("SDF_DEVICES")) {
-    for (const char *c = e; *c;) {
-      char *end = nullptr;
-      const long d = strtol(c, &end, 10);
-      if (end == c) break;
-      devices.push_back((int)d);
-      c = *end == ',' ? end + 1 : end;
-    }
-    if (devices.size() > 1) nlanes = std::max<int>(nlanes, (int)std::min<size_t>(devices.size(), 8));
-  }
-  if (const char *e = getenv("SDF_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
-  if (nlanes > 1) super_batch = std::max(1024, std::min(super_batch, (total + 2 * nlanes - 1) / (2 * nlanes)));
-  if (const char *sb = getenv("SDF_SUPER_BATCH")) super_batch = std::max(1, atoi(sb));
+  int nlanes = stage_lane_count(total, &devices);
+  super_batch = stage_super_batch(total, nlanes, super_batch);
   std::vector<std::pair<int, int>> batches;  // (first pair, pairs)
+  int64_t max_batch_bytes = 0;
   for (int base = 0, n = 0; base < total; base += n) {
     int64_t bytes = 0;
     n = 0;
@@ -772,7 +904,9 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       ++n;
     }
     batches.push_back({base, n});
+    max_batch_bytes = std::max(max_batch_bytes, bytes);
   }
+  dp0.prepare((size_t)max_batch_bytes);
 
   // One super-batch from the sequences to its formatted output lines (one string per pair, schedule order).
   auto do_batch = [&](int base, int n, DpProvider &dp, Acc &a, std::vector<std::string> &lines,
@@ -948,6 +1082,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
           prov[(size_t)l] = extra[(size_t)l].get();
           mark(-2 - l, "lane's device context ready");
           if (!prov[(size_t)l]) return;
+          prov[(size_t)l]->prepare((size_t)max_batch_bytes);
         }
         std::vector<std::string> lines;
         std::vector<int> nhits;

@@ -118,6 +118,9 @@ class DpProvider {
   // Optional: another provider of the same kind (own device context) for a second lane of the stage driver.
   // (device < 0: the same device as this one)
   virtual std::unique_ptr<DpProvider> clone(int /*device*/ = -1) { return nullptr; }
+  // Optional: the bytes of sequence the largest super-batch of the run holds, told before the provider's first call: a
+  // provider with device and pinned buffers sizes them once, on a thread of its own, while the driver fetches sequences.
+  virtual void prepare(size_t /*max_batch_bytes*/) {}
   // Optional: generate_anchors for a batch of pairs on the device.  Returns false if the provider cannot do it
   // for these inputs (the caller then computes them on the host with generate_anchors()).
   struct AnchorJob {
@@ -137,6 +140,22 @@ class DpProvider {
 
 // The product provider: sdf_extz2_batch on a HIP device.  Throws std::string when no device / library.
 std::unique_ptr<DpProvider> make_gpu_provider(int device);
+// The same with `lanes` - 1 more providers created side by side with the first (threads of their own; a device context
+// costs 50-120 ms, most of it its four streams): clone() of the returned provider hands them out.  `devices`: the
+// ordinals the lanes after the first go round-robin over (empty: all on `device`).
+// `max_batch_bytes` (0: unknown): as DpProvider::prepare takes it -- every provider then sizes its buffers where it is set up.
+std::unique_ptr<DpProvider> make_gpu_providers(int device, int lanes, const std::vector<int> &devices, size_t max_batch_bytes);
+// What the stage driver will do with a BED file of seed pairs, from a light pass over its lines: pairs, lanes (and the
+// devices of SDF_DEVICES), pairs per super-batch, an upper bound of the sequence bytes of the largest super-batch.
+struct StageHint {
+  int pairs = 0, lanes = 1, super_batch = 8192;
+  std::vector<int> devices;
+  size_t max_batch_bytes = 0;
+};
+StageHint stage_hint(const std::string &bed_path, int super_batch = 8192);
+// Lanes of the stage driver for `total` seed pairs (SDF_LANES / SDF_DEVICES in the environment decide otherwise), and the
+// device list of SDF_DEVICES.
+int stage_lane_count(int total, std::vector<int> *devices);
 
 // TEST HOOK: a provider that calls a single-task function with the oracle's signature
 // (oracle/extz2_oracle.h: sdfo_extz2).  Never constructed by the CLI.

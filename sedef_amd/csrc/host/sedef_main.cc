@@ -109,7 +109,10 @@ int main(int argc, char **argv) {
         if (!a.get({"k", "kmer"}, k)) throw std::string("Must provide k-mer size (--kmer)");
         const char *dv = getenv("SDF_DEVICE");
         const auto t0 = std::chrono::steady_clock::now();
-        auto dp = make_gpu_provider(dv ? atoi(dv) : 0);
+        // (the lanes of the stage driver and the size of its super-batches follow from the seed pairs: the lanes' device
+        // contexts and buffers are set up side by side here, not one after the other inside the stage)
+        const StageHint hint = stage_hint(a.pos[2]);
+        auto dp = make_gpu_providers(dv ? atoi(dv) : 0, hint.lanes, hint.devices, hint.max_batch_bytes);
         const auto t1 = std::chrono::steady_clock::now();
         generate_alignments(a.pos[1], a.pos[2], k, p, *dp, stdout, stderr);
         const auto t2 = std::chrono::steady_clock::now();

@@ -218,7 +218,7 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
                     &ctx->st_cig, &ctx->st_out})
     b->release();
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf,
-                    &ctx->h_pool, &ctx->h_out, &ctx->h_cig, &ctx->rr_out, &ctx->rr_cig, &ctx->rr_map, &ctx->ln_recs,
+                    &ctx->h_pool, &ctx->h_out, &ctx->h_brief, &ctx->h_cig, &ctx->rr_out, &ctx->rr_cig, &ctx->rr_map, &ctx->ln_recs,
                     &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
     b->release();
   if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
@@ -407,7 +407,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   ctx->paired = 0;
   // (nothing of this context's earlier calls is in flight: what they outgrew is idle now -- sdf_ctx.h: DevBuf)
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->gstate_buf, &ctx->h_pool, &ctx->h_out,
-                    &ctx->h_cig, &ctx->ln_recs, &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
+                    &ctx->h_brief, &ctx->h_cig, &ctx->ln_recs, &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
     b->new_call();
   const auto host_t0 = std::chrono::steady_clock::now();
   auto host_ms = [&] { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count(); };
@@ -755,15 +755,26 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   return SDF_OK;
 }
 
-extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
-                               const uint8_t *seq_pool, size_t pool_bytes, uint32_t want,
-                               sdf_result *out, uint32_t *cigar_pool, size_t cigar_cap,
-                               size_t *cigar_used) {
+__global__ void brief_results_kernel(const sdf_result *__restrict__ res, sdf_result_brief *__restrict__ out, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  sdf_result_brief b;
+  b.cigar_off = res[k].cigar_off;
+  b.n_cigar = (int32_t)res[k].n_cigar;
+  b.matches = res[k].matches;
+  out[k] = b;
+}
+
+// The host-buffer call: sequences packed into pinned memory, one upload, the device-resident call, results and CIGARs back
+// through pinned staging.  `brief`: 16-byte records instead of sdf_result (sdf_extz2_batch_brief).
+static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, const uint8_t *seq_pool,
+                      size_t pool_bytes, uint32_t want, sdf_result *out, sdf_result_brief *brief, uint32_t *cigar_pool,
+                      size_t cigar_cap, size_t *cigar_used) {
   if (!ctx) return SDF_ERR_INVALID;
   ctx->err.clear();
   if (cigar_used) *cigar_used = 0;
   if (n == 0) return SDF_OK;
-  if (!tasks || !out || (!seq_pool && pool_bytes)) {
+  if (!tasks || (!out && !brief) || (!seq_pool && pool_bytes)) {
     ctx->err = "invalid arguments";
     return SDF_ERR_INVALID;
   }
@@ -771,7 +782,10 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
   // pack every referenced sequence once (2-bit codes + N mask) and rewrite offsets to words
   static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
   const auto dbg0 = std::chrono::steady_clock::now();
-  std::vector<sdf_task> t2(tasks, tasks + n);
+  // (the task array with word offsets: kept by the context -- a fresh vector of 700,000 tasks is 34 MB of page faults per
+  // call -- the offsets written here, the other fields copied by the packing threads below)
+  std::vector<sdf_task> &t2 = ctx->host_tasks;
+  if (t2.size() < n) t2.resize(n + n / 2);
   size_t words = 0;
   for (size_t k = 0; k < n; ++k) {
     const sdf_task &t = tasks[k];
@@ -791,6 +805,10 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
   uint32_t *packed = (uint32_t *)ctx->host_pool.p;
   auto pack_range = [&](size_t lo, size_t hi) {
     for (size_t k = lo; k < hi; ++k) {
+      const int64_t qo = t2[k].q_off, to = t2[k].t_off;
+      t2[k] = tasks[k];
+      t2[k].q_off = qo;
+      t2[k].t_off = to;
       if (tasks[k].qlen > 0) sdf_pack_codes(seq_pool + tasks[k].q_off, tasks[k].qlen, packed + t2[k].q_off);
       if (tasks[k].tlen > 0) sdf_pack_codes(seq_pool + tasks[k].t_off, tasks[k].tlen, packed + t2[k].t_off);
     }
@@ -827,16 +845,24 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
   if (cigar_used) *cigar_used = used;
   if (rc != SDF_OK) return rc;
   const auto dbg2 = std::chrono::steady_clock::now();
-  const size_t out_bytes = n * sizeof(sdf_result), cig_bytes = (used && cigar_pool) ? used * 4 : 0;
+  const size_t out_bytes = n * (brief ? sizeof(sdf_result_brief) : sizeof(sdf_result)), cig_bytes = (used && cigar_pool) ? used * 4 : 0;
   SDF_HIP(ctx->host_out.reserve(out_bytes + cig_bytes + 64));
   uint8_t *stg = (uint8_t *)ctx->host_out.p;
-  SDF_HIP(hipMemcpyAsync(stg, ctx->h_out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  const void *d_res = ctx->h_out.p;
+  if (brief) {
+    SDF_HIP(ctx->h_brief.reserve(out_bytes));
+    hipLaunchKernelGGL(brief_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const sdf_result *)ctx->h_out.p, (sdf_result_brief *)ctx->h_brief.p, (int)n);
+    d_res = ctx->h_brief.p;
+  }
+  void *const out_any = brief ? (void *)brief : (void *)out;
+  SDF_HIP(hipMemcpyAsync(stg, d_res, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (cig_bytes) SDF_HIP(hipMemcpyAsync(stg + out_bytes, ctx->h_cig.p, cig_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDF_HIP(hipStreamSynchronize(ctx->stream));
   {
     auto copy_range = [&](int q, int of) {
       const size_t a = out_bytes * (size_t)q / (size_t)of, b = out_bytes * (size_t)(q + 1) / (size_t)of;
-      memcpy((uint8_t *)out + a, stg + a, b - a);
+      memcpy((uint8_t *)out_any + a, stg + a, b - a);
       const size_t c = cig_bytes * (size_t)q / (size_t)of, d = cig_bytes * (size_t)(q + 1) / (size_t)of;
       if (d > c) memcpy((uint8_t *)cigar_pool + c, stg + out_bytes + c, d - c);
     };
@@ -855,6 +881,81 @@ extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_ta
             n, words, cigar_cap, used, ms(dbg0, dbg1), ms(dbg1, dbg2), ctx->ms[4], ctx->ms[0], ctx->ms[1], ms(dbg2, dbg3));
   }
   return SDF_OK;
+}
+
+extern "C" int sdf_extz2_batch(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                               const uint8_t *seq_pool, size_t pool_bytes, uint32_t want,
+                               sdf_result *out, uint32_t *cigar_pool, size_t cigar_cap,
+                               size_t *cigar_used) {
+  return batch_host(ctx, sc, tasks, n, seq_pool, pool_bytes, want, out, nullptr, cigar_pool, cigar_cap, cigar_used);
+}
+
+extern "C" int sdf_extz2_batch_brief(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                                     const uint8_t *seq_pool, size_t pool_bytes, sdf_result_brief *out,
+                                     uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used) {
+  return batch_host(ctx, sc, tasks, n, seq_pool, pool_bytes, SDF_WANT_CIGAR | SDF_WANT_SCORE, nullptr, out, cigar_pool, cigar_cap,
+                    cigar_used);
+}
+
+// Buffers sized once (include/sedef_hip.h).  The bounds per task are the planner's: a launch-order entry per task and
+// stripe / block of columns, a CIGAR staging slot of qlen + tlen + 2 words.
+extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, size_t workspace_bytes, uint32_t flags) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  SDF_HIP(hipSetDevice(ctx->device));
+  const size_t n = std::max<size_t>(max_tasks, 1);
+  const size_t words = max_bases / 16 + max_bases / 32 + 4 * n + 16;  // (packed sequences: two roundings per sequence)
+  const size_t cig_words = max_bases + 2 * n + 16;
+  const size_t nord = 3 * n + max_bases / 16 + 1024;
+  // pinned staging
+  SDF_HIP(ctx->host_pool.reserve_exact(words * 4));
+  SDF_HIP(ctx->host_plan.reserve_exact(n * sizeof(PlanTask)));
+  SDF_HIP(ctx->host_order.reserve_exact(nord * sizeof(int32_t)));
+  SDF_HIP(ctx->host_lane.reserve_exact(n * sizeof(LaneRec)));
+  // (results + CIGAR words: a quarter of the CIGAR bound -- the stage's rounds fill a tenth of it)
+  SDF_HIP(ctx->host_out.reserve_exact(n * ((flags & SDF_RESERVE_BRIEF) ? sizeof(sdf_result_brief) : sizeof(sdf_result)) +
+                                      cig_words / 4 * 4 + 64));
+  if (ctx->host_tasks.size() < n) ctx->host_tasks.resize(n);
+  // device
+  SDF_HIP(ctx->h_pool.reserve_exact(words * 4));
+  SDF_HIP(ctx->h_out.reserve_exact(n * sizeof(sdf_result)));
+  SDF_HIP(ctx->h_brief.reserve_exact(n * sizeof(sdf_result_brief)));
+  SDF_HIP(ctx->h_cig.reserve_exact(cig_words * 4));
+  SDF_HIP(ctx->stage_ws.reserve_exact(cig_words * 4));
+  SDF_HIP(ctx->plan_buf.reserve_exact(2 * n * sizeof(PlanTask)));  // (host-planned records, the lane tasks' behind them)
+  SDF_HIP(ctx->order_buf.reserve_exact(nord * sizeof(int32_t)));
+  SDF_HIP(ctx->misc_buf.reserve_exact(SDF_MISC_PARTS * 8 + ((n + 1023) / 1024 + 1) * 8));
+  SDF_HIP(ctx->ln_recs.reserve_exact(n * sizeof(LaneRec)));
+  SDF_HIP(ctx->ln_keys.reserve_exact(n * 8));
+  SDF_HIP(ctx->ln_vals.reserve_exact(n * 8));
+  SDF_HIP(ctx->ln_sizes.reserve_exact(n * 32 + 64));
+  // the streams the pipeline would create the first time it wants them (a stream is a hardware queue: 7-15 ms each to set
+  // up -- the stage's first two rounds spent 35 ms on five of them)
+  if (ctx->pipeline) {
+    for (hipStream_t *q : {&ctx->lane_stream, &ctx->aux_stream[0], &ctx->aux_stream[1], &ctx->aux_stream[2], &ctx->aux_stream[3]})
+      if (!*q && hipStreamCreateWithFlags(q, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        *q = nullptr;
+      }
+  }
+  if (workspace_bytes) {
+    const size_t ws = std::min(workspace_bytes, ctx->ws_budget);
+    if (ctx->dir_ws.reserve_exact(ws) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->err = "cannot allocate the direction-matrix workspace";
+      return SDF_ERR_NOMEM;
+    }
+  }
+  return SDF_OK;
+}
+
+extern "C" size_t sdf_device_bytes(const sdf_ctx *ctx) {
+  if (!ctx) return 0;
+  size_t sum = 0;
+  for (const DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->h_pool, &ctx->h_out,
+                          &ctx->h_brief, &ctx->h_cig, &ctx->ln_recs, &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
+    sum += b->held_bytes();
+  return sum;
 }
 
 // ---- seed anchors (reference: src/chain.cc:24-101) ---------------------------------------------------

@@ -108,6 +108,8 @@ struct DevBuf {
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return e;
   }
+  // without headroom (sdf_reserve: the caller's bound IS the headroom)
+  hipError_t reserve_exact(size_t bytes) { return reserve(bytes, bytes); }
   // at the start of a batch call (nothing of the context's earlier calls is in flight): what earlier calls retired is idle
   // from here on -- freed at the next growth, or right away when it is more than `keep` bytes
   void new_call(size_t keep = (size_t)4 << 30) {
@@ -149,6 +151,15 @@ struct HostBuf {  // pinned host memory
     const size_t want = bytes + bytes / 2 + 4096;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
+    return e;
+  }
+  hipError_t reserve_exact(size_t bytes) {  // (sdf_reserve: no headroom on top of the caller's bound)
+    if (bytes <= cap) return hipSuccess;
+    if (p) retired.push_back(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
     return e;
   }
   void release() {
@@ -269,6 +280,8 @@ struct sdf_ctx {
   DevBuf st_items;                           // sdf_stats_columns_device: segments of long alignments + their counter
   unsigned stats_items = 1u << 18;           // ... capacity of that list (SDF_STATS_ITEMS)
   DevBuf h_pool, h_out, h_cig;  // device buffers of the host-buffer entry point
+  DevBuf h_brief;               // ... 16-byte result records (sdf_extz2_batch_brief)
+  std::vector<sdf_task> host_tasks;  // ... the task array with word offsets
   // lane kernel (extz2_lane.hip): records as uploaded, sort keys / values (in, out), sizes and their scans, hipCUB scratch
   HostBuf host_lane;
   DevBuf ln_recs, ln_keys, ln_vals, ln_sizes, ln_tmp;

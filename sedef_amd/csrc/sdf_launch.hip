@@ -530,6 +530,13 @@ static int launch_lane(BatchRun &run, size_t n) {
     return SDF_ERR_HIP;
   }
   hipStream_t sl = ctx->lane_stream;
+  static const bool dbg_lane = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const auto lt0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (dbg_lane)
+      fprintf(stderr, "[lane %s at %.2f ms]\n", what,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt0).count());
+  };
   SDF_HIP(hipStreamWaitEvent(sl, run.ev_begin, 0));
   SDF_HIP(ctx->ln_recs.reserve(n * sizeof(LaneRec)));
   SDF_HIP(ctx->ln_keys.reserve(n * 8));
@@ -543,10 +550,14 @@ static int launch_lane(BatchRun &run, size_t n) {
   SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, cap, cap_off, (int)nl, sl));
   const size_t t_bytes = std::max(t_sort, t_scan) + 256;
   SDF_HIP(ctx->ln_tmp.reserve(t_bytes));
+  lap("buffers");
   SDF_HIP(hipMemcpyAsync(d_recs, ctx->host_lane.p, n * sizeof(LaneRec), hipMemcpyHostToDevice, sl));
+  lap("records uploaded");
   hipLaunchKernelGGL(lane_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sl, d_recs, (int)n, k_in, v_in);
+  lap("keys");
   size_t tb = t_bytes;
   SDF_HIP(hipcub::DeviceRadixSort::SortPairs(ctx->ln_tmp.p, tb, k_in, k_out, v_in, v_out, (int)n, 0, 20, sl));
+  lap("sort");
   const dim3 gl((unsigned)((nl + 255) / 256));
   hipLaunchKernelGGL(lane_sizes_kernel, gl, dim3(256), 0, sl, d_recs, v_out, (int)nl, cap, dirb);
   tb = t_bytes;
@@ -557,6 +568,7 @@ static int launch_lane(BatchRun &run, size_t n) {
   PlanTask *lp = run.d_plan + cut.ntask_total;
   const int64_t dir0 = (int64_t)(cut.heavy_need + cut.nreg_ws * cut.region_need);
   hipLaunchKernelGGL(lane_plan_kernel, gl, dim3(256), 0, sl, d_recs, v_out, (int)nl, cap_off, dir_off, cut.stage_total, dir0, lp);
+  lap("scans, plan");
   run.ev_lane0 = next_event(ctx, run.evc);
   SDF_HIP(hipEventRecord(run.ev_lane0, sl));
   size_t pos = 0;
@@ -574,6 +586,7 @@ static int launch_lane(BatchRun &run, size_t n) {
   SDF_HIP(hipEventRecord(run.ev_lane, sl));
   SDF_HIP(hipGetLastError());
   ctx->lane_tasks = (long long)nl;
+  lap("DP, traceback");
   return SDF_OK;
 }
 
