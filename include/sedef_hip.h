@@ -125,6 +125,8 @@ void sdf_destroy(sdf_ctx *ctx);
  * thread, 4 ms without.  It must have returned before the context's first batch call.  (The stage driver: once per lane,
  * with the lane's context, host/pipeline.cc.) */
 #define SDF_RESERVE_BRIEF 1u /* the caller reads results through sdf_extz2_batch_brief: 16 bytes of result staging per task */
+#define SDF_RESERVE_ANCHORS 2u /* the caller will use sdf_anchors_batch: one tiny call now, so that the first real one does not
+                                  pay for the first launch of its kernels and of the library sort behind it */
 int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, size_t workspace_bytes, uint32_t flags);
 /* Device bytes the context holds at this moment (buffers in use, outgrown ones not yet freed). */
 size_t sdf_device_bytes(const sdf_ctx *ctx);
@@ -202,8 +204,8 @@ long long sdf_last_lane_tasks(const sdf_ctx *ctx);
 /* ---- seed anchors on the GPU (next row of the scope table) -----------------------------------
  * Replaces generate_anchors (reference: src/chain.cc:24-101) for a batch of candidate pairs: maximal exact
  * k-mer matches, in the reference's order (query position, then reference position).  Sequences are the raw
- * FASTA characters (case = soft-masking, N = unknown).  kmer <= 11, sequences shorter than 4 Mb (SDF_ERR_UNSUPPORTED
- * otherwise), at most 65,535 pairs per call. */
+ * FASTA characters (case = soft-masking, N = unknown).  kmer <= 15 and sequences shorter than 2 Gb (SDF_ERR_UNSUPPORTED
+ * otherwise); any number of pairs per call (the call runs them in ranges that fit its 64-bit sort key). */
 typedef struct {
   int64_t q_off, r_off; /* byte offsets of query / reference characters in seq_pool */
   int32_t qlen, rlen;

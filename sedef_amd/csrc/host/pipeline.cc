@@ -80,11 +80,12 @@ class GpuProvider : public DpProvider {
  public:
   // (`spares`: that many more providers, started before this one's own context so that all of them are set up side by side)
   // `max_batch_bytes` (0: unknown, prepare() will tell): the buffers are sized here, with the context.
+  // `lanes`: the providers that share the device's memory with this one (itself included): the workspace budget is per process.
   explicit GpuProvider(int device, int spares = 0, const std::vector<int> &devices = std::vector<int>(),
-                       size_t max_batch_bytes = 0)
-      : device_(device) {
+                       size_t max_batch_bytes = 0, int lanes = 0)
+      : device_(device), ws_(stage_workspace(lanes > 0 ? lanes : spares + 1)) {
     if (spares > 0) start_spares(spares, devices, max_batch_bytes);
-    ctx_ = sdf_create(device, stage_workspace());
+    ctx_ = sdf_create(device, ws_);
     if (!ctx_) {
       for (auto &t : spare_threads_)
         if (t.joinable()) t.join();
@@ -102,13 +103,15 @@ class GpuProvider : public DpProvider {
     spares_.clear();
     sdf_destroy(ctx_);
   }
-  // Direction-flag workspace of a stage lane: 8 GiB unless SDF_STAGE_WS_GIB says otherwise (the library's default is 64).
-  // A round of the stage that needs more runs in chunks; in exchange the lane allocates its workspace ONCE, up front on the
-  // thread of prepare(): a 23 GiB request in the middle of a run took 0.4 ms or 580 ms, box and run dependent
-  // (profiles/r04_stage.txt).
-  static size_t stage_workspace() {
+  // Direction-flag workspace of a stage lane: 8 GiB per process, shared out over its lanes (at least 2 GiB each), unless
+  // SDF_STAGE_WS_GIB gives the figure per lane (the library's default is 64).  A round of the stage that needs more runs in
+  // chunks; in exchange a lane allocates its workspace ONCE, where it is set up.  A process that starts right after another
+  // one released tens of gigabytes sometimes waits SECONDS for a large hipMalloc (profiles/alloc_probe.py: 24 and 64 GiB
+  // 0.3 ms or 1.8-4.0 s, 8 GiB 0.3 ms in every sample; inside a stage run: a 23 GiB request 0.4 or 580 ms) -- and a run of
+  // `sedef align` is one such process per bucket, one after the other.
+  static size_t stage_workspace(int lanes) {
     const char *e = getenv("SDF_STAGE_WS_GIB");
-    const double gib = e && atof(e) > 0 ? atof(e) : 8.0;
+    const double gib = e && atof(e) > 0 ? atof(e) : std::max(2.0, 8.0 / std::max(lanes, 1));
     return (size_t)(gib * 1073741824.0);
   }
   // Spare providers for the other lanes, each created on a thread of its own (make_gpu_providers)
@@ -117,9 +120,9 @@ class GpuProvider : public DpProvider {
     spare_dev_.resize((size_t)n);
     for (int i = 0; i < n; i++) {
       spare_dev_[(size_t)i] = devices.empty() ? device_ : devices[(size_t)(i + 1) % devices.size()];
-      spare_threads_.emplace_back([this, i, max_batch_bytes] {
+      spare_threads_.emplace_back([this, i, n, max_batch_bytes] {
         try {
-          spares_[(size_t)i].reset(new GpuProvider(spare_dev_[(size_t)i], 0, std::vector<int>(), max_batch_bytes));
+          spares_[(size_t)i].reset(new GpuProvider(spare_dev_[(size_t)i], 0, std::vector<int>(), max_batch_bytes, n + 1));
         } catch (std::string &) {  // (no room for another context: clone() will try again, the lane does without)
         }
       });
@@ -136,7 +139,7 @@ class GpuProvider : public DpProvider {
         if (spares_[i]) return std::unique_ptr<DpProvider>(spares_[i].release());
       }
     }
-    return std::unique_ptr<DpProvider>(new GpuProvider(want));
+    return std::unique_ptr<DpProvider>(new GpuProvider(want, 0, std::vector<int>(), 0, 3));
   }
   // Buffers sized once per lane (include/sedef_hip.h: sdf_reserve), on a thread of its own.  The bounds follow the stage's
   // rounds as measured: a task per ~250 bytes of a super-batch's sequences at most (chr1-sized run: 708,600 tasks of
@@ -152,7 +155,7 @@ class GpuProvider : public DpProvider {
   void reserve(size_t max_batch_bytes) {
     const size_t tasks = max_batch_bytes / 250 + 65536, bases = max_batch_bytes / 6 + (1u << 20);
     const auto t0 = std::chrono::steady_clock::now();
-    const int rc = sdf_reserve(ctx_, tasks, bases, stage_workspace(), SDF_RESERVE_BRIEF);
+    const int rc = sdf_reserve(ctx_, tasks, bases, ws_, SDF_RESERVE_BRIEF | SDF_RESERVE_ANCHORS);
     if (getenv("SDF_DEBUG_TIMING"))
       fprintf(stderr, "[sdf_reserve tasks %zu bases %zu: rc %d, %.1f ms]\n", tasks, bases, rc,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -238,6 +241,7 @@ class GpuProvider : public DpProvider {
       return !(e && e[0] == '0');
     }();
     if (!enabled || jobs.empty()) return false;
+    ready();  // (a reserve still running on its thread uses the context: its warm-up call, its pinning next to this upload)
     // what the device kernels do not cover goes to the host's generate_anchors -- said once, not silently
     auto host_instead = [](const char *why) {
       static std::atomic<bool> said(false);
@@ -285,6 +289,7 @@ class GpuProvider : public DpProvider {
  private:
   sdf_ctx *ctx_;
   int device_;
+  size_t ws_;
   int64_t tasks_ = 0;
   bool prepared_ = false;
   std::thread reserve_thread_;
@@ -832,9 +837,12 @@ static void parallel_for(int n, const std::function<void(int)> &body) {
 static std::vector<Hit> read_schedule(const std::string &bed_path, FILE *log) {  // src/align_main.cc:200-283, nbins=1
   std::ifstream fin(bed_path.c_str());
   if (!fin.is_open()) throw "BED file " + bed_path + " does not exist";
-  std::vector<Hit> hits;
+  // (the lines are parsed on the host threads: 40,000 lines take 26 ms on one)
+  std::vector<std::string> text;
   std::string s;
-  while (std::getline(fin, s)) hits.push_back(Hit::from_bed(s));
+  while (std::getline(fin, s)) text.push_back(std::move(s));
+  std::vector<Hit> hits(text.size());
+  parallel_for((int)text.size(), [&](int k) { hits[(size_t)k] = Hit::from_bed(text[(size_t)k]); });
   fprintf(log, "Read %d alignments in %s\n", (int)hits.size(), bed_path.c_str());
   fprintf(log, "Read total %d alignments\n", (int)hits.size());
   int max_complexity = 0;
@@ -842,11 +850,16 @@ static std::vector<Hit> read_schedule(const std::string &bed_path, FILE *log) { 
     return (int)std::sqrt(double(h.query_end - h.query_start) * double(h.ref_end - h.ref_start));
   };
   for (auto &h : hits) max_complexity = std::max(max_complexity, cx(h));
-  std::vector<std::vector<Hit>> bins(max_complexity / 1000 + 1);
-  for (auto &h : hits) bins[cx(h) / 1000].push_back(h);
-  std::vector<Hit> order;
-  for (auto &b : bins)
-    for (auto &h : b) order.push_back(h);
+  // (a stable counting sort by bin, the records moved, not copied: a Hit owns two shared sequences and three strings)
+  std::vector<int> bin(hits.size());
+  std::vector<size_t> start(max_complexity / 1000 + 2, 0);
+  for (size_t k = 0; k < hits.size(); k++) {
+    bin[k] = cx(hits[k]) / 1000;
+    start[(size_t)bin[k] + 1]++;
+  }
+  for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];
+  std::vector<Hit> order(hits.size());
+  for (size_t k = 0; k < hits.size(); k++) order[start[(size_t)bin[k]]++] = std::move(hits[k]);
   return order;
 }
 
@@ -908,6 +921,15 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   }
   dp0.prepare((size_t)max_batch_bytes);
 
+  std::mutex cleanup_mu;
+  std::vector<std::thread> cleanup;
+  struct JoinAll {  // (also on the way out with an exception)
+    std::vector<std::thread> &v;
+    ~JoinAll() {
+      for (auto &t : v)
+        if (t.joinable()) t.join();
+    }
+  } join_cleanup{cleanup};
   // One super-batch from the sequences to its formatted output lines (one string per pair, schedule order).
   auto do_batch = [&](int base, int n, DpProvider &dp, Acc &a, std::vector<std::string> &lines,
                       std::vector<int> &nhits) {
@@ -1038,6 +1060,11 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     });
     a.t_out += since(tout);
     mark(base, "output formatted");
+    // (the pairs' jobs hold hundreds of megabytes in small pieces: freeing them took a lane 15-50 ms between two
+    // super-batches -- a thread of its own does it while the lane fetches the next one's sequences)
+    auto *gone = new std::vector<Item>(std::move(items));
+    std::lock_guard<std::mutex> g(cleanup_mu);
+    cleanup.emplace_back([gone] { delete gone; });
   };
   auto write_batch = [&](int base, int n, const std::vector<std::string> &lines, const std::vector<int> &nhits) {
     for (int k = 0; k < n; k++) {
@@ -1065,8 +1092,24 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       write_batch(b.first, b.second, lines, nhits);
     }
   } else {
+    // The super-batches with the most sequence first (the schedule is sorted by size: its last super-batch is the
+    // heaviest, and taken last it ran on alone while the other lanes had nothing left); a finished super-batch keeps its
+    // lines until every earlier one of the schedule has been written.
+    std::vector<size_t> turn(batches.size());
+    {
+      std::vector<int64_t> weight(batches.size(), 0);
+      for (size_t b = 0; b < batches.size(); b++)
+        for (int k = 0; k < batches[b].second; k++) {
+          const Hit &h = schedule[(size_t)(batches[b].first + k)];
+          weight[b] += (int64_t)(h.query_end - h.query_start) + (h.ref_end - h.ref_start);
+        }
+      for (size_t b = 0; b < turn.size(); b++) turn[b] = b;
+      std::stable_sort(turn.begin(), turn.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+    }
+    std::vector<std::vector<std::string>> done_lines(batches.size());
+    std::vector<std::vector<int>> done_nhits(batches.size());
+    std::vector<char> is_done(batches.size(), 0);
     std::mutex mu;
-    std::condition_variable cv;
     size_t next_write = 0;
     std::atomic<size_t> next_batch(0);
     std::string failure;
@@ -1087,28 +1130,35 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         std::vector<std::string> lines;
         std::vector<int> nhits;
         for (;;) {
-          const size_t bi = next_batch.fetch_add(1);
-          if (bi >= batches.size()) return;
+          const size_t ti = next_batch.fetch_add(1);
+          if (ti >= batches.size()) return;
+          const size_t bi = turn[ti];
           try {
             do_batch(batches[bi].first, batches[bi].second, *prov[(size_t)l], acc[(size_t)l], lines, nhits);
           } catch (std::string &e) {
             std::lock_guard<std::mutex> g(mu);
             if (!failed) failure = e.empty() ? std::string("error") : e;
             failed = true;
-            cv.notify_all();
             return;
           }
-          std::unique_lock<std::mutex> g(mu);
-          cv.wait(g, [&] { return failed || next_write == bi; });
+          std::lock_guard<std::mutex> g(mu);
           if (failed) return;
-          write_batch(batches[bi].first, batches[bi].second, lines, nhits);
-          ++next_write;
-          cv.notify_all();
+          done_lines[bi].swap(lines);
+          done_nhits[bi].swap(nhits);
+          is_done[bi] = 1;
+          while (next_write < batches.size() && is_done[next_write]) {  // (whoever completes the next one in line writes)
+            write_batch(batches[next_write].first, batches[next_write].second, done_lines[next_write], done_nhits[next_write]);
+            std::vector<std::string>().swap(done_lines[next_write]);
+            ++next_write;
+          }
         }
       });
     for (auto &t : lanes) t.join();
     if (failed) throw failure;
   }
+  const double secs = since(t0);  // (the output is complete; what is left is giving memory back)
+  for (auto &t : cleanup) t.join();
+  cleanup.clear();
   Acc a;
   for (int l = 0; l < nlanes; l++) {
     a.dp_secs += acc[l].dp_secs;
@@ -1131,7 +1181,6 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     t_call += d->t_call;
     t_unpack += d->t_unpack;
   }
-  const double secs = since(t0);
   fprintf(log, "\nFinished BED %s in %.2fs (%d lines, generated %d hits)\n", bed_path.c_str(), secs, st.lines,
           st.total_written);
   fprintf(log, "  [%d lane(s); host CPU: anchors+chaining %.2fs, stitching+refinement %.2fs (summed over threads); device "

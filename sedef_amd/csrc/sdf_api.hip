@@ -877,8 +877,9 @@ static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    fprintf(stderr, "[sdf_extz2_batch n=%zu words=%zu cap=%zu used=%zu] pack %.1f ms, h2d+device %.1f ms (plan %.1f, dp %.1f, tb %.1f), d2h %.1f ms\n",
-            n, words, cigar_cap, used, ms(dbg0, dbg1), ms(dbg1, dbg2), ctx->ms[4], ctx->ms[0], ctx->ms[1], ms(dbg2, dbg3));
+    fprintf(stderr, "[sdf_extz2_batch n=%zu words=%zu cap=%zu used=%zu] pack %.1f ms, h2d+device %.1f ms (plan %.1f, dp %.1f, tb %.1f), d2h %.1f ms%s\n",
+            n, words, cigar_cap, used, ms(dbg0, dbg1), ms(dbg1, dbg2), ctx->ms[4], ctx->ms[0], ctx->ms[1], ms(dbg2, dbg3),
+            ctx->reran ? (", " + std::to_string(ctx->reran) + " tasks given up by a stripe wait and run again").c_str() : "");
   }
   return SDF_OK;
 }
@@ -945,6 +946,24 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
       ctx->err = "cannot allocate the direction-matrix workspace";
       return SDF_ERR_NOMEM;
     }
+  }
+  if (flags & SDF_RESERVE_ANCHORS) {  // two copies of a short sequence: a handful of anchors through every kernel of the path
+    char seq[192];
+    uint32_t x = 12345u;
+    for (int i = 0; i < 96; ++i) {
+      x = x * 1664525u + 1013904223u;
+      seq[i] = seq[96 + i] = "ACGT"[x >> 30];
+    }
+    sdf_anchor_pair pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.q_off = 0;
+    pr.r_off = 96;
+    pr.qlen = pr.rlen = 96;
+    sdf_anchor out[256];
+    int64_t off[2];
+    size_t used = 0;
+    (void)sdf_anchors_batch(ctx, &pr, 1, seq, sizeof(seq), 11, out, 256, off, &used);
+    ctx->err.clear();
   }
   return SDF_OK;
 }
