@@ -930,6 +930,14 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   SDF_HIP(ctx->ln_keys.reserve_exact(n * 8));
   SDF_HIP(ctx->ln_vals.reserve_exact(n * 8));
   SDF_HIP(ctx->ln_sizes.reserve_exact(n * 32 + 64));
+  {  // (the library sort / scan of the lane tasks' planning: sdf_launch.hip, launch_lane)
+    size_t t_sort = 0, t_scan = 0;
+    SDF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                               (uint32_t *)nullptr, (int)n, 0, 20, ctx->stream));
+    SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)n,
+                                             ctx->stream));
+    SDF_HIP(ctx->ln_tmp.reserve_exact(std::max(t_sort, t_scan) + 256));
+  }
   // the streams the pipeline would create the first time it wants them (a stream is a hardware queue: 7-15 ms each to set
   // up -- the stage's first two rounds spent 35 ms on five of them)
   if (ctx->pipeline) {

@@ -24,6 +24,9 @@ RESULT_DTYPE = np.dtype([("score", "<i4"), ("max", "<i4"), ("max_q", "<i4"), ("m
 ANCHOR_PAIR_DTYPE = np.dtype([("q_off", "<i8"), ("r_off", "<i8"), ("qlen", "<i4"), ("rlen", "<i4"),
                               ("same_chr", "<i4"), ("delta", "<i4")])
 ANCHOR_DTYPE = np.dtype([("q", "<i4"), ("r", "<i4"), ("l", "<i4"), ("has_u", "<i4")])
+BRIEF_DTYPE = np.dtype([("cigar_off", "<i8"), ("n_cigar", "<i4"), ("matches", "<i4")])  # sdf_result_brief
+RESERVE_BRIEF, RESERVE_ANCHORS = 1, 2
+assert BRIEF_DTYPE.itemsize == 16
 assert TASK_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 64 and ANCHOR_PAIR_DTYPE.itemsize == 32
 # include/sedef_hip.h: sdf_stats_task / sdf_stats_cols
 STATS_TASK_DTYPE = np.dtype([("a_off", "<u8"), ("b_off", "<u8"), ("a_len", "<u4"), ("b_len", "<u4"),
@@ -74,6 +77,13 @@ def load_library():
     L.sdf_extz2_batch.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t,
                                   C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdf_extz2_batch_brief.restype = C.c_int
+    L.sdf_extz2_batch_brief.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdf_reserve.restype = C.c_int
+    L.sdf_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32]
+    L.sdf_device_bytes.restype = C.c_size_t
+    L.sdf_device_bytes.argtypes = [C.c_void_p]
     L.sdf_extz2_batch_device.restype = C.c_int
     L.sdf_extz2_batch_device.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -195,6 +205,28 @@ class Extz2Engine:
                                       cigar_cap, C.byref(used))
         self._check(rc)
         return out, cig[:used.value]
+
+    def align_batch_brief(self, tasks, pool, mat=None, gapo=40, gape=1, cigar_cap=None):
+        """sdf_extz2_batch_brief: 16-byte records (cigar_off, n_cigar, matches) instead of sdf_result."""
+        tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        n = len(tasks)
+        sc = _scoring(sedef_mat() if mat is None else mat, gapo, gape)
+        out = np.zeros(n, BRIEF_DTYPE)
+        if cigar_cap is None:
+            cigar_cap = int((tasks["qlen"].astype(np.int64) + tasks["tlen"] + 2).sum()) + 1
+        cig = np.zeros(cigar_cap, np.uint32)
+        used = C.c_size_t(0)
+        self._check(self.lib.sdf_extz2_batch_brief(self.ctx, C.byref(sc), tasks.ctypes.data, n, pool.ctypes.data, pool.nbytes,
+                                                   out.ctypes.data, cig.ctypes.data, cigar_cap, C.byref(used)))
+        return out, cig[:used.value]
+
+    def reserve(self, max_tasks, max_bases, workspace_bytes=0, flags=0):
+        """sdf_reserve: buffers, pinned staging and pipeline streams sized once (flags: RESERVE_BRIEF | RESERVE_ANCHORS)."""
+        self._check(self.lib.sdf_reserve(self.ctx, int(max_tasks), int(max_bases), int(workspace_bytes), int(flags)))
+
+    def device_bytes(self):
+        return int(self.lib.sdf_device_bytes(self.ctx))
 
     def align_batch_device(self, tasks, d_pool, d_out, d_cig, cigar_cap, mat=None, gapo=40, gape=1,
                            want=WANT_ALL, stream=None):

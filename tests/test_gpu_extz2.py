@@ -1285,3 +1285,55 @@ def test_mixed_pairs_banded_tasks_of_different_lengths(oracle):
     _check_fast(eng, oracle, pairs[:300], ws[:300], mat=sedef_mat(11, -9), gapo=55, gape=4)
     flags = [int(rng.choice([0, 0, 1, 0x80])) for _ in range(300)]  # (score only; KSW_EZ_REV_CIGAR)
     _check_fast(eng, oracle, pairs[300:600], ws[300:600], flags=flags)
+
+
+def test_brief_results_and_buffers_sized_once(oracle):
+    """sdf_extz2_batch_brief returns (cigar_off, n_cigar, matches) of the full records; after sdf_reserve twenty batches within
+    the bounds leave the context's device memory where the reserve put it (no growth after the first batch,
+    nothing hoarded), and a batch beyond the bounds still runs (the buffers grow)."""
+    import sedef_amd
+    from sedef_amd.extz2 import TASK_DTYPE, RESERVE_BRIEF, RESERVE_ANCHORS
+    eng = sedef_amd.Extz2Engine(0, workspace_bytes=2 << 30)
+    eng.reserve(40000, 6_000_000, workspace_bytes=2 << 30, flags=RESERVE_BRIEF | RESERVE_ANCHORS)
+    held = eng.device_bytes()
+    assert held >= (2 << 30)
+    rng = np.random.default_rng(4242)
+
+    def batch(n, lo, hi):
+        pairs = []
+        for _ in range(n):
+            q = random_codes(rng, int(rng.integers(lo, hi)), 0.002)
+            pairs.append((q, mutate(rng, q, 0.05, 0.01, 0.01)))
+        tasks = np.zeros(n, TASK_DTYPE)
+        off, chunks = 0, []
+        for k, (q, t) in enumerate(pairs):
+            tasks["q_off"][k], tasks["qlen"][k] = off, len(q)
+            off += len(q)
+            tasks["t_off"][k], tasks["tlen"][k] = off, len(t)
+            off += len(t)
+            chunks += [q, t]
+        tasks["w"], tasks["zdrop"] = -1, -1
+        return pairs, tasks, np.concatenate(chunks)
+
+    for it in range(20):
+        pairs, tasks, pool = batch(int(rng.integers(200, 30000)) if it % 4 else 12000, 8, 120 if it % 3 else 400)
+        brief, cig_b = eng.align_batch_brief(tasks, pool)
+        if it % 5 == 0:
+            full, cig_f = eng.align_batch(tasks, pool, want=sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE)
+            assert np.array_equal(cig_b, cig_f)
+            for f in ("cigar_off", "n_cigar", "matches"):
+                assert np.array_equal(brief[f], full[f].astype(brief[f].dtype)), f
+            for k in range(0, len(pairs), 97):
+                exp = oracle.extz2(pairs[k][0], pairs[k][1], w=-1)
+                got = cig_b[int(brief["cigar_off"][k]):int(brief["cigar_off"][k]) + int(brief["n_cigar"][k])]
+                assert cigar_to_str(got) == cigar_to_str(exp["cigar"])
+        assert eng.device_bytes() == held, (it, eng.device_bytes(), held)
+    # beyond the bounds: the buffers grow, the results stay right
+    pairs, tasks, pool = batch(60000, 8, 200)
+    brief, cig_b = eng.align_batch_brief(tasks, pool)
+    for k in range(0, len(pairs), 1999):
+        exp = oracle.extz2(pairs[k][0], pairs[k][1], w=-1)
+        got = cig_b[int(brief["cigar_off"][k]):int(brief["cigar_off"][k]) + int(brief["n_cigar"][k])]
+        assert cigar_to_str(got) == cigar_to_str(exp["cigar"])
+    assert eng.device_bytes() > held
+    eng.close()
