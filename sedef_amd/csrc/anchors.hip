@@ -75,17 +75,38 @@ __global__ __launch_bounds__(256) void query_lookup_kernel(const AnchorPairDev *
   if (pr >= (unsigned)npairs) return;
   const AnchorPairDev p = pairs[pr];
   const int nk = p.qlen - k + 1;
+  // The pair's keys are one run of the sorted array (the keys of windows with an N, all ones, have gathered at the array's
+  // end: a pair's keys no longer lie where they were written): one thread finds the run, every k-mer is then looked up inside
+  // it -- 17 probes into 800 kB for a 100 kb reference instead of 27 into the whole array -- and the end of its matches by
+  // galloping from their start (most k-mers have none or a few).  Round 4: 12.2 -> see profiles/r04_stage.txt.
+  __shared__ long long seg[2];
+  if (threadIdx.x == 0) {
+    const int shift = 2 * k + pos_bits;
+    const unsigned long long first = (unsigned long long)pr << shift, next = ((unsigned long long)pr + 1) << shift;
+    seg[0] = lower_bound_u64(keys, nkeys, first);
+    seg[1] = lower_bound_u64(keys, nkeys, next > first ? next : ~0ull);  // (the last pair of a 64-bit key: up to the all-ones keys)
+  }
+  __syncthreads();
+  const long long s_lo = seg[0], s_hi = seg[1];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
     uint32_t h;
     const bool ok = kmer_at(pool + p.q_off + i, k, h);
     uint32_t lo = 0, cnt = 0;
     if (ok) {
-      // (over the whole sorted array: the keys of windows with an N, all ones, have gathered at its end -- a pair's keys no
-      // longer lie where they were written)
       const unsigned long long base = ((unsigned long long)pr << (2 * k + pos_bits)) | ((unsigned long long)h << pos_bits);
-      const long long a = lower_bound_u64(keys, nkeys, base);
-      const unsigned long long top = base + (1ull << pos_bits);  // (wraps for the all-T k-mer of the last pair of a 64-bit key)
-      const long long b = lower_bound_u64(keys, nkeys, top > base ? top : ~0ull);
+      const unsigned long long top0 = base + (1ull << pos_bits);  // (wraps for the all-T k-mer of the last pair of a 64-bit key)
+      const unsigned long long top = top0 > base ? top0 : ~0ull;
+      const long long a = s_lo + lower_bound_u64(keys + s_lo, s_hi - s_lo, base);
+      long long b = a;
+      if (a < s_hi && keys[a] < top) {
+        long long at = a, step = 1;  // keys[at] < top
+        while (at + step < s_hi && keys[at + step] < top) {
+          at += step;
+          step <<= 1;
+        }
+        const long long hi = at + step < s_hi ? at + step : s_hi;  // keys[hi] >= top, or the run's end
+        b = at + 1 + lower_bound_u64(keys + at + 1, hi - (at + 1), top);
+      }
       lo = (uint32_t)a;
       cnt = (uint32_t)(b - a);
     }

@@ -223,6 +223,7 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
     b->release();
   if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
   ctx->host_lane.release();
+  ctx->host_an.release();
   if (ctx->rerun_ctx) sdf_destroy(ctx->rerun_ctx);
   if (ctx->part_ctx) sdf_destroy(ctx->part_ctx);
   if (ctx->part_ev) (void)hipEventDestroy(ctx->part_ev);
@@ -955,6 +956,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
       return SDF_ERR_NOMEM;
     }
   }
+  if (flags & SDF_RESERVE_ANCHORS) SDF_HIP(ctx->host_an.reserve_exact((size_t)48 << 20));  // (3 million anchors: more go out pageable)
   if (flags & SDF_RESERVE_ANCHORS) {  // two copies of a short sequence: a handful of anchors through every kernel of the path
     char seq[192];
     uint32_t x = 12345u;
@@ -1073,7 +1075,22 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
     SDF_HIP(ctx->an_out.reserve((size_t)total * sizeof(CandOut)));
     hipLaunchKernelGGL(anchors_compact_kernel, dim3(nb), dim3(256), 0, st, d_flag, d_pos, d_cand, (long long)ncand,
                        (CandOut *)ctx->an_out.p, total);
-    SDF_HIP(hipMemcpyAsync(out, ctx->an_out.p, (size_t)total * sizeof(sdf_anchor), hipMemcpyDeviceToHost, st));
+    const size_t bytes = (size_t)total * sizeof(sdf_anchor);
+    if (bytes >= ((size_t)1 << 20) && bytes <= ctx->host_an.cap) {  // through pinned staging, copied out on a few threads
+      SDF_HIP(hipMemcpyAsync(ctx->host_an.p, ctx->an_out.p, bytes, hipMemcpyDeviceToHost, st));
+      SDF_HIP(hipStreamSynchronize(st));
+      const int nthr = 4;
+      std::vector<std::thread> thr;
+      auto part = [&](int q) {
+        const size_t a = bytes * (size_t)q / nthr, b = bytes * (size_t)(q + 1) / nthr;
+        memcpy((uint8_t *)out + a, (const uint8_t *)ctx->host_an.p + a, b - a);
+      };
+      for (int q = 1; q < nthr; ++q) thr.emplace_back(part, q);
+      part(0);
+      for (auto &t : thr) t.join();
+    } else {
+      SDF_HIP(hipMemcpyAsync(out, ctx->an_out.p, bytes, hipMemcpyDeviceToHost, st));
+    }
   }
   SDF_HIP(hipStreamSynchronize(st));
   SDF_HIP(hipGetLastError());

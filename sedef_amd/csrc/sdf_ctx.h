@@ -284,6 +284,7 @@ struct sdf_ctx {
   std::vector<sdf_task> host_tasks;  // ... the task array with word offsets
   // lane kernel (extz2_lane.hip): records as uploaded, sort keys / values (in, out), sizes and their scans, hipCUB scratch
   HostBuf host_lane;
+  HostBuf host_an;  // pinned staging of the anchors call's output (sdf_reserve with SDF_RESERVE_ANCHORS; a pageable copy runs at ~3 GB/s)
   DevBuf ln_recs, ln_keys, ln_vals, ln_sizes, ln_tmp;
   hipStream_t lane_stream = nullptr;
   bool strip_enabled = true;  // SDF_NO_STRIP=1: full-band tasks of 257..8192 target bases stay on the window / stripe kernels
