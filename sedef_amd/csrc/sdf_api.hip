@@ -478,8 +478,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
                              : g_live_contexts.load() > 1 ? 7
                                                           : std::max(1, std::min(15, usable_cpus() / local_ranks - 1));
     // (parked threads plan the chunks of batches of 120,000 tasks and more -- 250,000 tasks of the hg19 mixture:
-    // 14.5 -> 10.1 ms, the headline batch unchanged -- and from 400,000 tasks the scan of the cut as well: there, below,
-    // waking them cost more than they saved)
+    // 14.5 -> 10.1 ms, the headline batch unchanged -- and scan the cut as well: sdf_plan.hip, scan_from)
     static const size_t pool_from = [] {
       const char *e = getenv("SDF_PLAN_POOL_FROM");
       return e ? (size_t)atoll(e) : (size_t)120000;

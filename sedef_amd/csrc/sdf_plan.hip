@@ -408,7 +408,15 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     // (on the context's parked planning threads when there are any; this thread takes a share too)
     // (from 400,000 tasks: on the 100,000-task headline batch four scan threads were measured at 5.2 ms of planning
     // before the first launch against 1.2 ms on this thread alone -- the wake-up of parked threads, not the scan)
-    const int nthr = pool && n >= 400000 ? std::min(16, pool->size() + 1) : 1;
+    // (the parked threads scan the cut of every batch that has them -- sdf_api.hip: from 120,000 tasks -- : with them the scan
+    // runs in two passes and the heavy chunks start after the first, over the big tasks only.  It was 400,000 until round 4:
+    // an eighth / a quarter of the hg19 mixture, what a rank of an 8- / 4-GPU strong-scaling run gets, 5.6-5.7 -> 4.9-5.3 ms
+    // and 7.2-7.5 -> 5.9-6.0 ms, first launch at 0.56 instead of 1.39 ms.  SDF_SCAN_POOL_FROM overrides.)
+    static const size_t scan_from = [] {
+      const char *e = getenv("SDF_SCAN_POOL_FROM");
+      return e ? (size_t)atoll(e) : (size_t)120000;
+    }();
+    const int nthr = pool && n >= scan_from ? std::min(16, pool->size() + 1) : 1;
     Part parts[16];
     // Runs of sixteen blocks are handed out through a counter: this thread starts at once, a parked helper joins when it
     // has woken up (which takes up to milliseconds on a box with a CPU quota) and takes what is left -- nobody waits
