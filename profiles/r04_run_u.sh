@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8
+export TMPDIR=/tmp
 out=gpurun_out/r04x; mkdir -p $out
-SDF_DEBUG_PLAN=1 SDF_DEBUG_CLASSES=1 python3 profiles/mix_probe.py hg19 500000 > $out/hg500_plan.log 2>&1
-SDF_DEBUG_PLAN=1 SDF_DEBUG_CLASSES=1 python3 profiles/mix_probe.py hg19 330000 > $out/hg330_plan.log 2>&1
+timeout 1500 python3 -m pytest tests/test_gpu_extz2.py -x -q -m gpu -k "strip or config4 or start_paths" > $out/tests.log 2>&1; tail -3 $out/tests.log

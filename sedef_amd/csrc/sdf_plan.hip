@@ -1096,8 +1096,10 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // (measured, profiles/r03_strip.txt: four columns shorten a lone chain -- 5.3 against 6.5 ms for 6000 x 6000 -- but
       // cost throughput -- 1,364 against 1,612 Gcell/s on 20,000 x 1000 x 1000 --, and lone chains are the stripe
       // kernel's anyway: eight unless SDF_STRIP_COLS says otherwise)
-      const int cols = force_cols == 4 || force_cols == 8 ? force_cols : 8;
-      (void)chain_waves;
+      // (round 4: a chunk whose chains leave the SIMDs with fewer than four of their wavefronts each takes four -- the heavy
+      // chunk of the hg19 mixture, 608 long tasks = 2,900 wavefronts of eight columns: 14.0-14.2 against 14.65-14.85 ms for the
+      // 1,000,000-task batch, its DP 9.3-10.8 against 11.6-11.9 ms)
+      const int cols = force_cols == 4 || force_cols == 8 ? force_cols : chain_waves / 2 <= 4096 ? 4 : 8;  // (two tasks a wavefront)
       for (size_t k = 0; k < cnt; ++k)
         if (cp[k].pad_ == 10) cp[k].nreg = cols;
     }

@@ -536,9 +536,11 @@ def test_strip_chain_wide_full_band_tasks(strip_engine, oracle):
     eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1, SDF_STRIP_ALWAYS=1)
     _check_fast(eng, oracle, pairs, [-1] * len(pairs), flags)
     assert eng.last_reran() >= 6
-    # four columns per lane (blocks of 256 columns: twice as many, shorter steps)
-    eng4 = _engine_with_env(SDF_STRIP_COLS=4, SDF_STRIP_ALWAYS=1)
-    _check_fast(eng4, oracle, pairs, [-1] * len(pairs), flags)
+    # four columns per lane (blocks of 256 columns: twice as many, shorter steps: what a chunk of few chains takes by itself
+    # since round 4) and eight (a chunk of more than 4,096 chain wavefronts)
+    for cols in (4, 8):
+        engc = _engine_with_env(SDF_STRIP_COLS=cols, SDF_STRIP_ALWAYS=1)
+        _check_fast(engc, oracle, pairs, [-1] * len(pairs), flags)
     # by itself the planner gives so few wide tasks to the stripe kernel
     _check_fast(_engine_with_env(SDF_NO_LANE=1), oracle, pairs[:6], [-1] * 6)
 
@@ -559,8 +561,8 @@ def test_strip_chain_targets_wider_than_8192(engine, oracle):
     flags = [0x80 if k == 3 else 0x01 if k == 6 else 0 for k in range(len(pairs))]
     _check_fast(engine, oracle, pairs, [-1] * len(pairs), flags)
     assert engine.last_reran() == 0
-    # the same through four columns per lane (blocks of 256 columns) and with a wait that gives up
-    _check_fast(_engine_with_env(SDF_STRIP_COLS=4), oracle, pairs[:5], [-1] * 5, flags[:5])
+    # the same through eight columns per lane (blocks of 512 columns: few chains take four by themselves) and with a wait that gives up
+    _check_fast(_engine_with_env(SDF_STRIP_COLS=8), oracle, pairs[:5], [-1] * 5, flags[:5])
     eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1)
     _check_fast(eng, oracle, pairs[:4], [-1] * 4, flags[:4])
     assert eng.last_reran() >= 2
@@ -1165,11 +1167,12 @@ def _device_bytes(eng, batch, w):
     return res.tobytes(), np.ascontiguousarray(cig).tobytes()
 
 
-@pytest.mark.parametrize("switch", ["SDF_SPLIT_MIN", "SDF_EARLY_HEAVY", "SDF_NO_MIXED"])
+@pytest.mark.parametrize("switch", ["SDF_SPLIT_MIN", "SDF_EARLY_HEAVY", "SDF_NO_MIXED", "SDF_STRIP_COLS", "SDF_SCAN_POOL_FROM"])
 def test_start_paths_on_and_off_give_the_same_bytes(engine, switch):
     """The paths that change HOW a large batch starts or pairs, never what it returns, each on against off on a batch that
     takes it: the two-part start of mid-size batches of one size (SDF_SPLIT_MIN=0: off), the early start of the heavy chunks
-    of a 400,000+ task batch (SDF_EARLY_HEAVY=0: off), the mixed pairs (SDF_NO_MIXED=1: off).  Same records, same CIGAR words."""
+    of a large batch (SDF_EARLY_HEAVY=0: off), the mixed pairs (SDF_NO_MIXED=1: off), the chains' block width, the threaded scan
+    of the cut.  Same records, same CIGAR words."""
     import bench
     if switch == "SDF_SPLIT_MIN":  # (the default rule wants the process's only context: asked for here)
         batch, w = bench.synth_batch(60000, 400, seed=9), 64
@@ -1177,6 +1180,12 @@ def test_start_paths_on_and_off_give_the_same_bytes(engine, switch):
     elif switch == "SDF_EARLY_HEAVY":
         (batch, w) = bench.synth_hg19_mixture_fast(420000, seed=10, big=3000)
         off = _engine_with_env(SDF_EARLY_HEAVY=0)
+    elif switch == "SDF_STRIP_COLS":  # (chains of few wavefronts take blocks of 256 columns by themselves: against 512)
+        (batch, w) = bench.synth_hg19_mixture_fast(300000, seed=12, big=5000)
+        off = _engine_with_env(SDF_STRIP_COLS=8)
+    elif switch == "SDF_SCAN_POOL_FROM":  # (the threaded two-pass scan of batches from 120,000 tasks: against the one-thread scan)
+        (batch, w) = bench.synth_hg19_mixture_fast(150000, seed=13, big=4000)
+        off = _engine_with_env(SDF_SCAN_POOL_FROM=100000000)
     else:
         (batch, w) = bench.synth_mm8_mixture_fast(12000, seed=11, max_len=6000)
         off = _engine_with_env(SDF_NO_MIXED=1)
