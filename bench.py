@@ -438,7 +438,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie-pass", action="store_true", help="skip the untimed pass that measures value_incl_pcie")
     ap.add_argument("--workspace-gib", type=float, default=48.0)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batch calls in flight, each on a device context and host thread of its own (1: one call after the other)")
     args = ap.parse_args()
+    args.inflight = max(1, min(2, args.inflight))
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -518,7 +521,12 @@ def main():
     tasks["w"], tasks["zdrop"], tasks["flag"] = w, -1, 0
     cells_rank = int(cells_task.sum())
 
-    eng = sedef_amd.Extz2Engine(local, int(args.workspace_gib * (1 << 30)))
+    # --inflight 2 (default): two device contexts, the steps alternate between them, each call on a host thread of its own
+    # -- the planning of step i + 1 (0.6-1.6 ms before its first launch) and the tail of step i (last traceback, compaction)
+    # overlap the other step's DP, as two lanes of the stage driver do (host/pipeline.cc).  Every step is still one whole
+    # pass of the hot path over the batch, all K of them complete inside the timed region.
+    engs = [sedef_amd.Extz2Engine(local, int(args.workspace_gib * (1 << 30))) for _ in range(args.inflight)]
+    eng = engs[0]
     d_pool = torch.from_numpy(words.view(np.int32)).to(dev)
     cig_cap = int((qlen.astype(np.int64) + tlen + 2).sum())
     if not hg19:
@@ -535,7 +543,8 @@ def main():
     # The engine works on a torch stream of its own, entered as the current stream: a gather's wait() then orders THIS
     # stream (and with it everything the engine launches: its internal streams fork from it) behind the collective that
     # last read the buffer set the step is about to overwrite.
-    estream = torch.cuda.Stream(device=dev)
+    estreams = [torch.cuda.Stream(device=dev) for _ in engs]
+    estream = estreams[0]
     cstream = torch.cuda.Stream(device=dev)  # result D2H
     copy_done = [None] * nsets
 
@@ -549,18 +558,21 @@ def main():
             g.loopback = force_dist and os.environ.get("BENCH_LOOPBACK", "1") == "1"
     step_no = [0]
     last_used = [0] * nsets
+    acc = {"dp": 0.0, "tb": 0.0, "cp": 0.0, "plan": 0.0, "call": 0.0, "launches": 0, "used": 0}
+    pending = []  # steps started and not yet retired, oldest first: (buffer set, engine, future or result)
+    pool_ex = None
+    if len(engs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool_ex = ThreadPoolExecutor(len(engs))
 
-    def step():
-        b = step_no[0] % nsets
-        step_no[0] += 1
-        with torch.cuda.stream(estream):
-            if gathers:
-                gathers[b].wait()  # the gather that last read this buffer set
-            if copy_done[b] is not None:
-                estream.wait_event(copy_done[b])  # ... and the D2H that did
-            used = eng.align_batch_device(tasks, d_pool.data_ptr(), d_outs[b].data_ptr(), d_cigs[b].data_ptr(),
-                                          cig_cap, want=want, stream=estream.cuda_stream)
-            # (the call returns after its stream has drained: the results are complete here)
+    def compute(b, e):  # (a worker thread when two calls are in flight: the C call releases the GIL)
+        return engs[e].align_batch_device(tasks, d_pool.data_ptr(), d_outs[b].data_ptr(), d_cigs[b].data_ptr(),
+                                          cig_cap, want=want, stream=estreams[e].cuda_stream)
+
+    def retire():  # main thread, in step order: the call has returned (its stream drained: the results are complete)
+        b, e, fut = pending.pop(0)
+        used = fut.result() if hasattr(fut, "result") else fut
+        with torch.cuda.stream(estreams[e]):
             if gathers:  # all-gatherv of result records + CIGAR words, asynchronous
                 if debug_one_gpu:
                     gathers[b].start(d_outs[b].cpu(), d_cigs[b][:used].cpu(), used)
@@ -572,9 +584,33 @@ def main():
             copy_done[b] = torch.cuda.Event()
             copy_done[b].record(cstream)
         last_used[b] = used
+        acc["dp"] += engs[e].last_ms(0)
+        acc["tb"] += engs[e].last_ms(1)
+        acc["cp"] += engs[e].last_ms(2)
+        acc["plan"] += engs[e].last_ms(4)
+        acc["call"] += engs[e].last_ms(5)
+        acc["launches"] += engs[e].last_launches()
+        acc["used"] = used
         return used
 
+    def step():
+        i = step_no[0]
+        step_no[0] += 1
+        b, e = i % nsets, i % len(engs)
+        while len(pending) >= len(engs):  # (the step that used this context and buffer set before)
+            retire()
+        with torch.cuda.stream(estreams[e]):
+            if gathers:
+                gathers[b].wait()  # the gather that last read this buffer set
+            if copy_done[b] is not None:
+                estreams[e].wait_event(copy_done[b])  # ... and the D2H that did
+        pending.append((b, e, pool_ex.submit(compute, b, e) if pool_ex else compute(b, e)))
+        if not pool_ex:
+            retire()
+
     def sync():
+        while pending:
+            retire()
         for g in gathers:
             g.wait()
         torch.cuda.synchronize()
@@ -594,19 +630,15 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    dp_ms, tb_ms, cp_ms, launches, plan_ms, call_ms = 0.0, 0.0, 0.0, 0, 0.0, 0.0
+    for k in acc:
+        acc[k] = 0
     t0 = time.perf_counter()
-    used = 0
     for _ in range(args.steps):
-        used = step()
-        dp_ms += eng.last_ms(0)
-        tb_ms += eng.last_ms(1)
-        cp_ms += eng.last_ms(2)
-        plan_ms += eng.last_ms(4)
-        call_ms += eng.last_ms(5)
-        launches += eng.last_launches()
+        step()
     sync()
     dt = time.perf_counter() - t0
+    dp_ms, tb_ms, cp_ms, launches, plan_ms, call_ms = acc["dp"], acc["tb"], acc["cp"], acc["launches"], acc["plan"], acc["call"]
+    used = acc["used"]
     if dist_on:
         rdev = torch.device("cpu") if debug_one_gpu else dev
         tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
@@ -744,10 +776,13 @@ def main():
             "data": "synthetic",
             "value_incl_pcie": incl_pcie,
             "timed_region": "planning + DP + traceback + CIGAR compaction + result D2H (pinned, double-buffered under the "
-                            "next step)" + (" + all-gatherv of records and CIGARs" if dist_on else ""),
+                            "next step)" + (" + all-gatherv of records and CIGARs" if dist_on else "") +
+                            ("; two batch calls in flight on two device contexts: a step's planning and tail run under the "
+                             "other step's DP" if len(engs) > 1 else ""),
             "config": {"workload": wl, "tasks_this_rank": n, "band": int(w) if np.ndim(w) == 0 else "mixed",
                        "cells_per_step_this_rank": cells_rank, "cells_per_step_all_ranks": cells_all,
                        "parallelism": "task-sharded x%d + all-gatherv of result records" % world,
+                       "calls_in_flight": len(engs),
                        "union_check": union_check,
                        "dist_backend": (dist.get_backend() if dist_on else None),
                        "forced_dist_one_rank": force_dist or None, "loopback": loopback_note},

@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp GPU_MAX_HW_QUEUES=8
+export TMPDIR=/tmp
 out=gpurun_out/r04x; mkdir -p $out
-SDF_DEBUG_PLAN=1 python3 profiles/mix_probe.py hg19 1000000 > $out/hg1m_plan.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/hgprof -o run -- python3 profiles/mix_probe.py hg19 1000000 > $out/hgprof.log 2>&1
-cp $(find $out/hgprof -name "*kernel_stats.csv" | head -1) $out/hg19_kernel_stats.csv; rm -rf $out/hgprof
-head -8 $out/hg19_kernel_stats.csv | cut -c1-200
+for f in 1 2 1 2; do echo -n "inflight $f: "; python bench.py --inflight $f --no-pcie-pass --no-cpu-baseline 2>&1 | tail -1 | cut -c1-190; done
+for f in 1 2; do echo -n "hg19 inflight $f: "; python bench.py --inflight $f --workload hg19mix --tasks 1000000 --steps 10 --warmup 3 --no-pcie-pass --no-cpu-baseline 2>&1 | tail -1 | cut -c1-190; done
+timeout 1500 python3 -m pytest tests/test_bench_launch.py -x -q -m gpu > $out/bench_tests.log 2>&1; tail -3 $out/bench_tests.log
