@@ -474,9 +474,10 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
       if (!e) e = getenv("WORLD_SIZE");
       return e ? std::max(1, atoi(e)) : 1;
     }();
-    const int max_planners = env_planners >= 0 ? env_planners
-                             : g_live_contexts.load() > 1 ? 7
-                                                          : std::max(1, std::min(15, usable_cpus() / local_ranks - 1));
+    // (several contexts in one process AND several processes on the node -- bench.py's two calls in flight per rank: seven, or
+    // the rank's share of the CPUs if that is less)
+    const int share = std::max(1, std::min(15, usable_cpus() / local_ranks - 1));
+    const int max_planners = env_planners >= 0 ? env_planners : g_live_contexts.load() > 1 ? std::min(7, share) : share;
     // (parked threads plan the chunks of batches of 120,000 tasks and more -- 250,000 tasks of the hg19 mixture:
     // 14.5 -> 10.1 ms, the headline batch unchanged -- and scan the cut as well: sdf_plan.hip, scan_from)
     static const size_t pool_from = [] {
