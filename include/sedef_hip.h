@@ -127,6 +127,9 @@ void sdf_destroy(sdf_ctx *ctx);
 #define SDF_RESERVE_BRIEF 1u /* the caller reads results through sdf_extz2_batch_brief: 16 bytes of result staging per task */
 #define SDF_RESERVE_ANCHORS 2u /* the caller will use sdf_anchors_batch: one tiny call now, so that the first real one does not
                                   pay for the first launch of its kernels and of the library sort behind it */
+#define SDF_RESERVE_FEW_STREAMS 4u /* this context is one of several that share the device (the lanes of the stage driver): it
+                                       never creates the four extra pipeline streams -- a stream costs 7-15 ms to set up, and the
+                                       other contexts' work fills the device where the extra streams would */
 int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, size_t workspace_bytes, uint32_t flags);
 /* Device bytes the context holds at this moment (buffers in use, outgrown ones not yet freed). */
 size_t sdf_device_bytes(const sdf_ctx *ctx);

@@ -83,7 +83,7 @@ class GpuProvider : public DpProvider {
   // `lanes`: the providers that share the device's memory with this one (itself included): the workspace budget is per process.
   explicit GpuProvider(int device, int spares = 0, const std::vector<int> &devices = std::vector<int>(),
                        size_t max_batch_bytes = 0, int lanes = 0)
-      : device_(device), ws_(stage_workspace(lanes > 0 ? lanes : spares + 1)) {
+      : device_(device), ws_(stage_workspace(lanes > 0 ? lanes : spares + 1)), lanes_(lanes > 0 ? lanes : spares + 1) {
     if (spares > 0) start_spares(spares, devices, max_batch_bytes);
     ctx_ = sdf_create(device, ws_);
     if (!ctx_) {
@@ -155,7 +155,7 @@ class GpuProvider : public DpProvider {
   void reserve(size_t max_batch_bytes) {
     const size_t tasks = max_batch_bytes / 250 + 65536, bases = max_batch_bytes / 6 + (1u << 20);
     const auto t0 = std::chrono::steady_clock::now();
-    const int rc = sdf_reserve(ctx_, tasks, bases, ws_, SDF_RESERVE_BRIEF | SDF_RESERVE_ANCHORS);
+    const int rc = sdf_reserve(ctx_, tasks, bases, ws_, SDF_RESERVE_BRIEF | SDF_RESERVE_ANCHORS | (lanes_ > 1 ? SDF_RESERVE_FEW_STREAMS : 0u));
     if (getenv("SDF_DEBUG_TIMING"))
       fprintf(stderr, "[sdf_reserve tasks %zu bases %zu: rc %d, %.1f ms]\n", tasks, bases, rc,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -290,6 +290,7 @@ class GpuProvider : public DpProvider {
   sdf_ctx *ctx_;
   int device_;
   size_t ws_;
+  int lanes_;
   int64_t tasks_ = 0;
   bool prepared_ = false;
   std::thread reserve_thread_;

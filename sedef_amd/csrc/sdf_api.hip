@@ -941,12 +941,15 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   }
   // the streams the pipeline would create the first time it wants them (a stream is a hardware queue: 7-15 ms each to set
   // up -- the stage's first two rounds spent 35 ms on five of them)
+  if (flags & SDF_RESERVE_FEW_STREAMS) ctx->aux_limit = 0;
   if (ctx->pipeline) {
-    for (hipStream_t *q : {&ctx->lane_stream, &ctx->aux_stream[0], &ctx->aux_stream[1], &ctx->aux_stream[2], &ctx->aux_stream[3]})
+    for (hipStream_t *q : {&ctx->lane_stream, &ctx->aux_stream[0], &ctx->aux_stream[1], &ctx->aux_stream[2], &ctx->aux_stream[3]}) {
+      if (q != &ctx->lane_stream && (size_t)(q - &ctx->aux_stream[0]) >= ctx->aux_limit) continue;
       if (!*q && hipStreamCreateWithFlags(q, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
         *q = nullptr;
       }
+    }
   }
   if (workspace_bytes) {
     const size_t ws = std::min(workspace_bytes, ctx->ws_budget);

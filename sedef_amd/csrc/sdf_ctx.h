@@ -269,6 +269,7 @@ struct sdf_ctx {
   size_t ws_budget = 0;
   hipStream_t dp_stream[2] = {nullptr, nullptr}, tb_stream = nullptr;  // chunk pipeline
   hipStream_t wide_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // chunks of several mixed-pair launches (sdf_launch.hip)
+  size_t aux_limit = 4;  // extra pipeline streams this context may create (sdf_reserve with SDF_RESERVE_FEW_STREAMS: 0)
   hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};    // more room for launches that end in a tail
   DevBuf dir_ws, stage_ws, plan_buf, order_buf, misc_buf, gstate_buf;
   HostBuf host_plan, host_order;  // pinned staging of the plan

@@ -216,7 +216,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
     // the three of the chunk before it: see the assignment below)
     const size_t want_aux = nchunks == 1 ? (c.launches.size() > 4 ? std::min<size_t>(c.launches.size() - 4, 4) : 0)
                                          : (cut.ntask_total >= 200000 || c.launches.size() > 4 ? 4 : 2);
-    for (size_t a = 0; a < want_aux; ++a)
+    for (size_t a = 0; a < want_aux && a < ctx->aux_limit; ++a)
       if (!ctx->aux_stream[a] && hipStreamCreateWithFlags(&ctx->aux_stream[a], hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
         ctx->aux_stream[a] = nullptr;
