@@ -131,6 +131,10 @@ void sdf_destroy(sdf_ctx *ctx);
                                        never creates the four extra pipeline streams -- a stream costs 7-15 ms to set up, and the
                                        other contexts' work fills the device where the extra streams would */
 int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, size_t workspace_bytes, uint32_t flags);
+/* Debug: out[4096] receives the wavefronts the chained-strip launches started per (XCD, shader engine, CU, SIMD) since the
+ * last call (index xcd << 9 | se << 6 | cu << 2 | simd) and the counters are cleared; the first call (out may be NULL) switches
+ * the counting on for the process. */
+int sdf_debug_placement(sdf_ctx *ctx, uint32_t *out);
 /* Device bytes the context holds at this moment (buffers in use, outgrown ones not yet freed). */
 size_t sdf_device_bytes(const sdf_ctx *ctx);
 const char *sdf_last_error(const sdf_ctx *ctx);

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
   const int qmax = qa > qb ? qa : qb, tmax = ta > tb ? ta : tb;
   const int nblk = strip_blocks(tmax, C);
   if (blk >= nblk) return;  // (a padding entry of the launch order)
+  place_note();
   if (qmax + tmax >= 8192) __builtin_amdgcn_s_setprio(2);  // (long chains first, as in the stripe kernels)
   const uint32_t *twa = pool + tka.t_word, *tna = twa + (ta + 15) / 16;
   const uint32_t *qwa = pool + tka.q_word, *qna = qwa + (qa + 15) / 16;

@@ -92,6 +92,21 @@ __device__ __forceinline__ bool stripe_abandoned(const sdf_result *rec) {
 // launches' workgroups in between, another start XCD --, a task's stripes meet in one L2, and the neighbour a stripe waits
 // for has been taken before it, by a workgroup that is running or done (forward progress no longer rests on the dispatch
 // order).  Without `claim`: entry blockIdx.x, which is the same thing when workgroup i lands on XCD i mod 8.
+// Debug (sdf_debug_placement): wavefronts started per (XCD, shader engine, CU, SIMD) by the kernels that call place_note().
+// (What it showed, profiles/placement_probe.py: the 5,600 chain wavefronts of the hg19 mixture's heavy chunk land 4..7 to a SIMD
+// -- mean 5.5 --, and a chain runs at the pace of its slowest block.  Workgroups of four wavefronts, one per SIMD of a CU, were
+// tried against it: the dispatcher spreads them LESS evenly over the CUs, 35..56 per CU against 40..50, and the batch took
+// 15.5 instead of 14.3-14.7 ms.)
+__device__ unsigned *g_place = nullptr;
+__device__ __forceinline__ void place_note() {
+  unsigned *p = g_place;
+  if (p && threadIdx.x == 0) {
+    const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_REG_HW_ID: SIMD 5:4, CU 11:8, SE 15:13
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+    atomicAdd(p + ((xcc << 9) | (((hw >> 13) & 7u) << 6) | (((hw >> 8) & 15u) << 2) | ((hw >> 4) & 3u)), 1u);
+  }
+}
+
 __device__ __forceinline__ int32_t stripe_claim(const int32_t *__restrict__ order, unsigned *__restrict__ claim) {
   if (!claim) return order[blockIdx.x];
   int32_t entry = (int32_t)(255u << 24);  // (idle)

@@ -981,6 +981,25 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   return SDF_OK;
 }
 
+// Debug: wavefronts started per (XCD, shader engine, CU, SIMD) since the last call, 4096 counters indexed
+// xcd << 9 | se << 6 | cu << 2 | simd (the chained strips note theirs: how evenly the dispatcher spreads a launch).
+extern "C" int sdf_debug_placement(sdf_ctx *ctx, uint32_t *out) {
+  if (!ctx) return SDF_ERR_INVALID;
+  SDF_HIP(hipSetDevice(ctx->device));
+  static unsigned *buf = nullptr;
+  if (!buf) {
+    SDF_HIP(hipMalloc(&buf, 4096 * sizeof(unsigned)));
+    SDF_HIP(hipMemset(buf, 0, 4096 * sizeof(unsigned)));
+    SDF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sdf::g_place), &buf, sizeof(buf)));
+  }
+  SDF_HIP(hipDeviceSynchronize());
+  if (out) {
+    SDF_HIP(hipMemcpy(out, buf, 4096 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    SDF_HIP(hipMemset(buf, 0, 4096 * sizeof(unsigned)));
+  }
+  return SDF_OK;
+}
+
 extern "C" size_t sdf_device_bytes(const sdf_ctx *ctx) {
   if (!ctx) return 0;
   size_t sum = 0;
