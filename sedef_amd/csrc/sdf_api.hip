@@ -1003,9 +1003,16 @@ extern "C" int sdf_debug_placement(sdf_ctx *ctx, uint32_t *out) {
 extern "C" size_t sdf_device_bytes(const sdf_ctx *ctx) {
   if (!ctx) return 0;
   size_t sum = 0;
-  for (const DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->h_pool, &ctx->h_out,
-                          &ctx->h_brief, &ctx->h_cig, &ctx->ln_recs, &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
+  for (const DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf, &ctx->claim_buf,
+                          &ctx->h_pool, &ctx->h_out, &ctx->h_brief, &ctx->h_cig, &ctx->rr_out, &ctx->rr_cig, &ctx->rr_map, &ctx->ln_recs,
+                          &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp,
+                          // the anchors / chaining / stats entry points
+                          &ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag, &ctx->an_pos,
+                          &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff, &ctx->ch_an, &ctx->ch_off, &ctx->ch_wsoff, &ctx->ch_work,
+                          &ctx->ch_path, &ctx->ch_bounds, &ctx->ch_nb, &ctx->ch_which, &ctx->st_tasks, &ctx->st_pool, &ctx->st_cig, &ctx->st_out})
     sum += b->held_bytes();
+  if (ctx->part_ctx) sum += sdf_device_bytes(ctx->part_ctx);
+  if (ctx->rerun_ctx) sum += sdf_device_bytes(ctx->rerun_ctx);
   return sum;
 }
 
