@@ -35,32 +35,45 @@ struct TaskRef {
   int qlen, tlen;
 };
 
-// chunking of one request into DP tasks (src/align.cc:46-57): both sequences advance by the same SP
-void expand(const std::vector<DpRequest> &reqs, const Params &p, std::vector<TaskRef> &tasks,
-            std::vector<uint8_t> &pool) {
-  size_t total = 0;
-  for (auto &r : reqs) total += r.q.size() + r.t.size();
-  pool.resize(total);
-  size_t off = 0;
-  for (size_t k = 0; k < reqs.size(); k++) {
+// chunking of one request into DP tasks (src/align.cc:46-57): both sequences advance by the same SP.
+// A round of the stage holds hundreds of thousands of requests (708,600 in the chr1-sized run): offsets and task counts in one
+// serial pass, the copies and the task records on the host threads, the pool left unfilled where nothing is copied.
+struct TaskPool {
+  std::unique_ptr<uint8_t[]> bytes;
+  size_t size = 0;
+  const uint8_t *data() const { return bytes.get(); }
+};
+void expand(const std::vector<DpRequest> &reqs, const Params &p, std::vector<TaskRef> &tasks, TaskPool &pool) {
+  const size_t n = reqs.size(), step = (size_t)p.max_ksw_seq_len;
+  std::vector<size_t> off(n + 1, 0), first(n + 1, 0);
+  for (size_t k = 0; k < n; k++) {
     const DpRequest &r = reqs[k];
-    const size_t qo = off;
-    memcpy(pool.data() + off, r.q.data(), r.q.size());
-    off += r.q.size();
-    const size_t to = off;
-    memcpy(pool.data() + off, r.t.data(), r.t.size());
-    off += r.t.size();
+    off[k + 1] = off[k] + r.q.size() + r.t.size();
     const size_t lim = std::min(r.q.size(), r.t.size());
-    for (size_t sp = 0; sp < lim; sp += (size_t)p.max_ksw_seq_len) {
-      TaskRef t;
-      t.req = k;
-      t.q_off = qo + sp;
-      t.t_off = to + sp;
-      t.qlen = (int)std::min<size_t>(p.max_ksw_seq_len, r.q.size() - sp);
-      t.tlen = (int)std::min<size_t>(p.max_ksw_seq_len, r.t.size() - sp);
-      tasks.push_back(t);
-    }
+    first[k + 1] = first[k] + (lim + step - 1) / step;
   }
+  pool.size = off[n];
+  pool.bytes.reset(new uint8_t[std::max<size_t>(off[n], 1)]);
+  tasks.resize(first[n]);
+  const size_t block = 4096;
+  parallel_for((int)((n + block - 1) / block), [&](int b) {
+    for (size_t k = (size_t)b * block; k < std::min(n, ((size_t)b + 1) * block); k++) {
+      const DpRequest &r = reqs[k];
+      const size_t qo = off[k], to = qo + r.q.size();
+      memcpy(pool.bytes.get() + qo, r.q.data(), r.q.size());
+      memcpy(pool.bytes.get() + to, r.t.data(), r.t.size());
+      const size_t lim = std::min(r.q.size(), r.t.size());
+      size_t at = first[k];
+      for (size_t sp = 0; sp < lim; sp += step) {
+        TaskRef &t = tasks[at++];
+        t.req = k;
+        t.q_off = qo + sp;
+        t.t_off = to + sp;
+        t.qlen = (int)std::min<size_t>(step, r.q.size() - sp);
+        t.tlen = (int)std::min<size_t>(step, r.t.size() - sp);
+      }
+    }
+  });
 }
 
 inline void append_ops(Cigar &c, const uint32_t *w, int64_t n) {
@@ -180,28 +193,37 @@ class GpuProvider : public DpProvider {
     raw.match.clear();
     if (reqs.empty()) return true;
     std::vector<TaskRef> tr;
-    std::vector<uint8_t> pool;
+    TaskPool pool;
     const auto tp0 = std::chrono::steady_clock::now();
     expand(reqs, p, tr, pool);
     for (auto &t : tr) raw.first_task[t.req + 1]++;  // tasks are in request order
     for (size_t r = 0; r < reqs.size(); r++) raw.first_task[r + 1] += raw.first_task[r];
     if (tr.empty()) return true;
-    std::vector<sdf_task> tasks(tr.size());
+    std::unique_ptr<sdf_task[]> tasks(new sdf_task[tr.size()]);
+    const size_t nt = tr.size(), tblock = 16384, ntb = (nt + tblock - 1) / tblock;
+    std::vector<size_t> cap_part(ntb, 0);
+    std::vector<int64_t> cells_part(ntb, 0);
+    parallel_for((int)ntb, [&](int b) {
+      size_t cap_b = 0;
+      int64_t cells_b = 0;
+      for (size_t k = (size_t)b * tblock; k < std::min(nt, ((size_t)b + 1) * tblock); k++) {
+        sdf_task &t = tasks[k];
+        memset(&t, 0, sizeof(t));
+        t.q_off = (int64_t)tr[k].q_off;
+        t.t_off = (int64_t)tr[k].t_off;
+        t.qlen = tr[k].qlen;
+        t.tlen = tr[k].tlen;
+        t.w = -1;      // src/align.cc:86
+        t.zdrop = -1;  // src/align.cc:54
+        t.flag = 0;
+        cap_b += (size_t)t.qlen + t.tlen + 2;
+        cells_b += (int64_t)t.qlen * t.tlen;
+      }
+      cap_part[(size_t)b] = cap_b;
+      cells_part[(size_t)b] = cells_b;
+    });
     size_t cap = 0;
-    for (size_t k = 0; k < tr.size(); k++) {
-      sdf_task &t = tasks[k];
-      memset(&t, 0, sizeof(t));
-      t.q_off = (int64_t)tr[k].q_off;
-      t.t_off = (int64_t)tr[k].t_off;
-      t.qlen = tr[k].qlen;
-      t.tlen = tr[k].tlen;
-      t.w = -1;      // src/align.cc:86
-      t.zdrop = -1;  // src/align.cc:54
-      t.flag = 0;
-      cap += (size_t)t.qlen + t.tlen + 2;
-      cells += (int64_t)t.qlen * t.tlen;
-    }
-    tasks_ += 0;
+    for (size_t b = 0; b < ntb; b++) cap += cap_part[b], cells += cells_part[b];
     this->tasks += (int64_t)tr.size();
     sdf_scoring sc;
     memset(&sc, 0, sizeof(sc));
@@ -216,18 +238,19 @@ class GpuProvider : public DpProvider {
     size_t used = 0;
     ready();
     const auto tp1 = std::chrono::steady_clock::now();
-    const int rc = sdf_extz2_batch_brief(ctx_, &sc, tasks.data(), tasks.size(), pool.data(), pool.size(), res.get(),
-                                         cig.get(), cap, &used);
+    const int rc = sdf_extz2_batch_brief(ctx_, &sc, tasks.get(), nt, pool.data(), pool.size, res.get(), cig.get(), cap, &used);
     if (rc != SDF_OK) throw std::string("DP batch failed: ") + sdf_last_error(ctx_);
     const auto tp2 = std::chrono::steady_clock::now();
-    raw.off.resize(tr.size());
-    raw.cnt.resize(tr.size());
-    raw.match.resize(tr.size());
-    for (size_t k = 0; k < tr.size(); k++) {
-      raw.off[k] = res[k].cigar_off;
-      raw.cnt[k] = (int32_t)res[k].n_cigar;
-      raw.match[k] = res[k].matches;
-    }
+    raw.off.resize(nt);
+    raw.cnt.resize(nt);
+    raw.match.resize(nt);
+    parallel_for((int)ntb, [&](int b) {
+      for (size_t k = (size_t)b * tblock; k < std::min(nt, ((size_t)b + 1) * tblock); k++) {
+        raw.off[k] = res[k].cigar_off;
+        raw.cnt[k] = (int32_t)res[k].n_cigar;
+        raw.match[k] = res[k].matches;
+      }
+    });
     raw.words = std::move(cig);
     t_pack += std::chrono::duration<double>(tp1 - tp0).count();
     t_call += std::chrono::duration<double>(tp2 - tp1).count();
@@ -314,7 +337,7 @@ class TestProvider : public DpProvider {
   std::vector<Cigar> run(const std::vector<DpRequest> &reqs, const Params &p) override {
     std::vector<Cigar> out(reqs.size());
     std::vector<TaskRef> tr;
-    std::vector<uint8_t> pool;
+    TaskPool pool;
     expand(reqs, p, tr, pool);
     int8_t mat[25];
     fill_mat(p, mat);

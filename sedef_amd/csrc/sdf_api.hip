@@ -814,8 +814,10 @@ static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
       if (tasks[k].tlen > 0) sdf_pack_codes(seq_pool + tasks[k].t_off, tasks[k].tlen, packed + t2[k].t_off);
     }
   };
-  // (at most four: the stage driver runs up to three of these calls at once next to its own worker threads)
-  const int nthr = words >= (1u << 18) ? (int)std::min<unsigned>(4, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  // (at most four when the process has several contexts -- the stage driver runs up to three of these calls at once next to
+  // its own worker threads --, eight for a process's only context)
+  const unsigned thr_cap = g_live_contexts.load() > 1 ? 4u : (unsigned)std::max(1, std::min(8, usable_cpus() / 2));
+  const int nthr = words >= (1u << 18) ? (int)std::min<unsigned>(thr_cap, std::max(1u, std::thread::hardware_concurrency())) : 1;
   {
     // equal shares of words, not of tasks
     std::vector<size_t> cut(nthr + 1, n);
