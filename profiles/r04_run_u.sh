@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for l in 1 2 1 2; do echo -n "lanes $l: "; SDF_LANES=$l python3 profiles/stage_bench.py --chr1 --one-bucket 4 2>&1 | grep "Finished BED" | sed 's/.* in //' | cut -c1-6 | tr '\n' ' '; echo; done
+out=gpurun_out/r04x; mkdir -p $out
+timeout 2400 python3 -m pytest tests/ -x -q -m gpu > $out/pytest_gpu.log 2>&1; tail -3 $out/pytest_gpu.log

@@ -929,6 +929,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   SDF_HIP(ctx->plan_buf.reserve_exact(2 * n * sizeof(PlanTask)));  // (host-planned records, the lane tasks' behind them)
   SDF_HIP(ctx->order_buf.reserve_exact(nord * sizeof(int32_t)));
   SDF_HIP(ctx->misc_buf.reserve_exact(SDF_MISC_PARTS * 8 + ((n + 1023) / 1024 + 1) * 8));
+  SDF_HIP(ctx->claim_buf.reserve_exact(kClaimSets * 8 * sizeof(unsigned)));
   SDF_HIP(ctx->ln_recs.reserve_exact(n * sizeof(LaneRec)));
   SDF_HIP(ctx->ln_keys.reserve_exact(n * 8));
   SDF_HIP(ctx->ln_vals.reserve_exact(n * 8));
