@@ -11,8 +11,9 @@ export GPU_MAX_HW_QUEUES=8   # (setenv inside the program is too late under rocp
 out=gpurun_out/$tag
 mkdir -p $out
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie-pass"
-B1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-pass"
-SDF_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_iso -o run -- $B > $out/stats_iso.log 2>&1
+BI="$B --inflight 1"   # (the isolated-launch passes: one call at a time, or two whole-batch launches would overlap)
+B1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-pass --inflight 1"
+SDF_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_iso -o run -- $BI > $out/stats_iso.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_pipe -o run -- $B > $out/stats_pipe.log 2>&1
 SDF_PIPELINE=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $out/fetch -o run -- $B1 > $out/fetch.log 2>&1
 SDF_PIPELINE=0 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $out/write -o run -- $B1 > $out/write.log 2>&1
@@ -29,8 +30,8 @@ python3 profiles/pmc_summary.py $out/sq extz2_ 199900000 > $out/pmc_sq.txt
 python3 profiles/timeline.py $out/stats_pipe 14 > $out/timeline_pipe.txt
 python3 profiles/timeline.py $out/stats_hg19 40 > $out/timeline_hg19.txt
 python3 profiles/timeline.py $out/stats_mm8 24 > $out/timeline_mm8.txt
-tail -1 $out/stats_iso.log > $out/bench_iso.json
-tail -1 $out/stats_pipe.log > $out/bench_pipe.json
+grep -h "^{\"metric" $out/stats_iso.log > $out/bench_iso.json
+grep -h "^{\"metric" $out/stats_pipe.log > $out/bench_pipe.json
 grep -h "tasks" $out/stats_hg19.log $out/stats_mm8.log $out/stats_mm8big.log $out/stats_fullband.log $out/stats_lane.log > $out/mix_lines.txt
 python3 profiles/make_traffic_json.py $out profiles/${tag}_pair_kernel_pmc.txt > $out/hbm_traffic_line.txt
 cat $out/stats_iso_kernel_stats.csv | head -8; cat $out/pmc_fetch.txt $out/pmc_write.txt $out/pmc_sq.txt | grep "pair_kernel\|traceback"; cat $out/mix_lines.txt
