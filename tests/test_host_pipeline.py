@@ -271,6 +271,13 @@ def test_generate_stage_two_lanes_keep_schedule_order(host, oracle_dp, tmp_path,
     three = str(tmp_path / "three.bed")
     host.generate(fa, fa + ".bed", 11, three)
     assert open(three).read() == open(cpu).read()
+    # the product CLI sets its lanes up before the stage starts (spare providers made side by side with the first, buffers
+    # sized from the BED file: host/sedef_main.cc, stage_hint) and takes the largest super-batches first
+    from sedef_amd.host import CLI
+    env = dict(os.environ, SDF_LANES="3", SDF_SUPER_BATCH="2")
+    env.pop("SDF_DEVICES", None)
+    r = subprocess.run([CLI, "align", "generate", "-k", "11", fa, fa + ".bed"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout == open(cpu).read() and "3 lane(s)" in r.stderr
 
 
 @pytest.mark.gpu
