@@ -21,8 +21,9 @@ import os
 # The chunk pipeline of the DP path keeps four streams busy (two for DP launches, traceback, the caller's).  The HIP
 # runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, shared with torch's own streams);
 # two of ours on one queue serialise what should overlap (measured: 27.7 instead of 22.6 ms per step).  Must be
-# set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# set before the runtime initialises.  Sixteen since two batch calls are in flight on two contexts (--inflight 2: 1,167-1,174 ->
+# 1,168-1,186 Gcell/s on configs[1], the hg19 mixture 1,047-1,087 -> 1,101-1,112, same box, alternating; eight with one call).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import json
 import os
 import sys
