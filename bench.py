@@ -442,7 +442,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="batch calls in flight, each on a device context and host thread of its own (1: one call after the other)")
     args = ap.parse_args()
-    args.inflight = max(1, min(2, args.inflight))
+    args.inflight = max(1, min(3, args.inflight))
     if args.gpus < 1:
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -535,7 +535,7 @@ def main():
     # Two sets of output buffers in rotation: the result D2H of step i (and, at N > 1, the all-gatherv of its records and
     # CIGAR words: RCCL, on the communicator's stream) runs under the DP of step i+1, which writes the other set; every
     # copy and every gather is waited for inside the timed region.
-    nsets = 2
+    nsets = max(2, args.inflight)
     d_outs = [torch.empty(n * 16, dtype=torch.int32, device=dev) for _ in range(nsets)]
     d_cigs = [torch.empty(cig_cap, dtype=torch.int32, device=dev) for _ in range(nsets)]
     h_outs = [torch.empty(n * 16, dtype=torch.int32).pin_memory() for _ in range(nsets)]
