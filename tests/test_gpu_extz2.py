@@ -568,6 +568,17 @@ def test_strip_chain_targets_wider_than_8192(engine, oracle):
     assert eng.last_reran() >= 2
 
 
+def test_strip_chain_one_task_of_a_whole_chunk(engine, oracle):
+    """The largest task the stage can ask for: both sides at the chunk length of align_helper's loop (MAX_KSW_SEQ_LEN = 60 kb,
+    src/align.cc:46-57), full band -- 240 chain blocks of 256 columns, 3.7e9 cells, 3.7 GB of direction flags."""
+    rng = np.random.default_rng(8005)
+    q = random_codes(rng, 61440, 0.001)
+    t = mutate(rng, q, 0.04, 0.008, 0.008)
+    t = _fit(rng, np.concatenate([t[:20000], random_codes(rng, 1500), t[20000:]]), 61440)
+    _check_fast(engine, oracle, [(q, t)], [-1])
+    assert engine.last_reran() == 0
+
+
 def test_strip_kernel_other_scorings(strip_engine, oracle):
     engine = strip_engine
     rng = np.random.default_rng(8002)
