@@ -38,6 +38,7 @@
 namespace sdf {
 
 // bytes of LDS of one stripe's wavefront (the reversed query, byte pairs, NSLOT entries of margin either side)
+constexpr int kStripeMaxT = 254 * 128;  // widest target: a launch entry has eight bits of stripe index, 255 = idle (sdf_plan.hip)
 __host__ __device__ inline size_t stripe_lds_bytes(int qlen, int nreg) {
   return ((size_t)2 * (size_t)(qlen + 256 * nreg) + 15) & ~(size_t)15;
 }

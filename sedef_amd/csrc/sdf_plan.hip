@@ -244,7 +244,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     // (chained strips take full-band targets of 513..65536 bases whatever stripe_min is: eight idle entries of padding per
     // block at most -- ADVICE r3: with SDF_STRIPE_MIN above 512 their launch order overflowed)
     const bool chain = env.strip_ok && t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT;
-    return 2 + (t.tlen > env.stripe_min && t.tlen <= 8192 ? (uint32_t)(t.tlen + 127) / 128 : chain ? 8u * (uint32_t)strip_blocks(t.tlen, 4) : 0u) +  // once per stripe
+    return 2 + (t.tlen > env.stripe_min && t.tlen <= kStripeMaxT ? (uint32_t)(t.tlen + 127) / 128 : chain ? 8u * (uint32_t)strip_blocks(t.tlen, 4) : 0u) +  // once per stripe
            (banded_long(t) ? (uint32_t)(t.tlen + 15 + 127) / 128 : 0u);
   };
   {
@@ -317,7 +317,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
         if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
       }
-      if (t.tlen > env.stripe_min && t.tlen <= 8192 && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
+      if (t.tlen > env.stripe_min && t.tlen <= kStripeMaxT && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
         for (int nr = 1; nr <= 4; nr *= 2)
           bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
       if (banded_long(t)) {
@@ -723,6 +723,24 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     const size_t chain_min = c.heavy && cut.n_heavy * 16 <= env.n ? std::min<size_t>(env.chain_min, 1024) : env.chain_min;
     use_chain = force || w10 / 2 >= chain_min;
   }
+  // A FEW tasks much longer than the rest of a chunk of chains: a chain's step is ~1 us on blocks of 256 columns, a stripe's row
+  // 0.25 us, and the launch ends with its longest task -- up to 64 full-band tasks of 12,000 rows + columns and more take the
+  // stripe kernel next to the chains (the chr1-sized stage run's far-gap round: eight tasks of 8.7 kb a side among 2,500 of
+  // 1.7 kb: the round's DP 21 -> see profiles/r04_stage.txt).
+  size_t n_long = 0;
+  auto long_task = [&](const sdf_task &t) {
+    return t.qlen + t.tlen >= 12000 && t.tlen > env.stripe_min && t.tlen <= kStripeMaxT && (t.w < 0 || t.w >= std::max(t.qlen, t.tlen)) &&
+           stripe_lds_bytes(t.qlen, 4) <= (size_t)env.max_dyn_lds;
+  };
+  if (use_chain && !env.strip_always && !env.no_stripe) {
+    for (size_t pos = c.s; pos < c.e; ++pos) {
+      const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
+      const sdf_task &t = c.heavy ? cut.heavy_tasks[pos] : tasks[k];
+      if (!c.heavy && cut.split_heavy && cut.heavy[k]) continue;
+      n_long += long_task(t);
+    }
+  }
+  const bool long_to_stripes = n_long > 0 && n_long <= 64;
   for (size_t pos = c.s; pos < c.e; ++pos) {
     const size_t k = c.heavy ? cut.heavy_idx[pos] : pos;
     const sdf_task &t = c.heavy ? cut.heavy_tasks[pos] : tasks[k];
@@ -819,17 +837,17 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       p.nreg = 8;  // (columns per lane)
       p.pad_ = 9;
       win_need.back() = 0;
-    } else if ((use_chain || (env.strip_ok && t.tlen > 8192)) && !env.no_stripe && p.pad_ != 7 && plain_ok &&
-               p.w >= std::max(t.qlen, t.tlen) && t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT && t.qlen >= 64 &&
-               t.qlen < (1 << 18)) {
+    } else if ((use_chain || (env.strip_ok && t.tlen > kStripeMaxT)) && !(long_to_stripes && long_task(t)) && !env.no_stripe &&
+               p.pad_ != 7 && plain_ok && p.w >= std::max(t.qlen, t.tlen) && t.tlen > kStripMaxT && t.tlen <= kStripChainMaxT &&
+               t.qlen >= 64 && t.qlen < (1 << 18)) {
       // ... wider: the same strips, a wavefront per block of columns, chained through HBM.  Targets beyond the stripe
-      // kernel's 8192 bases are chains however few they are: the alternative is the workgroup kernel walking its window
-      // through LDS at ~3 us per row (the stage's far-gap tasks of 8-10 kb a side: 52 ms as eight workgroups, profiles/r04_stage.txt)
+      // kernel's 32,512 bases are chains however few they are: the alternative is the workgroup kernel walking its window
+      // through LDS at ~3 us per row (a 61,440 x 61,440 task alone: 2,070 ms there, 80 ms here)
       p.nreg = 8;  // (columns per lane: 8, or 4 when the chunk has few chains -- decided below)
       p.pad_ = 10;
       win_need.back() = 0;
     } else if (p.pad_ != 7 && plain_ok && !env.no_stripe && p.w >= std::max(t.qlen, t.tlen) &&
-        t.tlen > env.stripe_min && t.tlen <= 8192) {
+        t.tlen > env.stripe_min && t.tlen <= kStripeMaxT) {
       // wide full-band task: one wavefront per stripe of 128 * nreg target positions (nreg: after this pass)
       if (stripe_lds_bytes(t.qlen, 4) <= (size_t)env.max_dyn_lds) {
         p.nreg = 4;

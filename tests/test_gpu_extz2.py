@@ -545,10 +545,10 @@ def test_strip_chain_wide_full_band_tasks(strip_engine, oracle):
     _check_fast(_engine_with_env(SDF_NO_LANE=1), oracle, pairs[:6], [-1] * 6)
 
 
-def test_strip_chain_targets_wider_than_8192(engine, oracle):
-    """Full-band targets beyond the stripe kernel's 8192 bases (the stage's far-gap tasks: 8-10 kb a side and up to the 60 kb
-    of a chunk, src/align.cc:129-175) are chains of up to 256 blocks however few they are; before round 4 they were the
-    workgroup kernel's, ~3 us per row."""
+def test_strip_chain_targets_wider_than_8192(engine, strip_engine, oracle):
+    """Full-band targets beyond 8192 bases (the stage's far-gap tasks: 8-10 kb a side and up to the 60 kb of a chunk,
+    src/align.cc:129-175): a few of them take the stripe kernel (up to 254 stripes: 32,512 bases), many -- or wider ones -- chains
+    of up to 256 blocks; before round 4 they were the workgroup kernel's, ~3 us per row."""
     rng = np.random.default_rng(8004)
     pairs = []
     for ql, tl in [(9000, 8200), (8700, 8700), (8650, 8710), (3000, 12000), (12000, 9000), (20000, 16400), (64, 30000),
@@ -559,13 +559,16 @@ def test_strip_chain_targets_wider_than_8192(engine, oracle):
         t = _fit(rng, np.concatenate([t[:at], random_codes(rng, int(rng.integers(1, 3000))), t[at:]]), tl)
         pairs.append((q, t))
     flags = [0x80 if k == 3 else 0x01 if k == 6 else 0 for k in range(len(pairs))]
-    _check_fast(engine, oracle, pairs, [-1] * len(pairs), flags)
+    _check_fast(engine, oracle, pairs, [-1] * len(pairs), flags)  # (nine tasks: the stripe kernel)
     assert engine.last_reran() == 0
-    # the same through eight columns per lane (blocks of 512 columns: few chains take four by themselves) and with a wait that gives up
-    _check_fast(_engine_with_env(SDF_STRIP_COLS=8), oracle, pairs[:5], [-1] * 5, flags[:5])
-    eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1)
-    _check_fast(eng, oracle, pairs[:4], [-1] * 4, flags[:4])
-    assert eng.last_reran() >= 2
+    _check_fast(strip_engine, oracle, pairs, [-1] * len(pairs), flags)  # (chains whatever their number)
+    assert strip_engine.last_reran() == 0
+    # chains of eight columns per lane (blocks of 512 columns: few chains take four by themselves) and with a wait that gives up
+    _check_fast(_engine_with_env(SDF_STRIP_COLS=8, SDF_STRIP_ALWAYS=1), oracle, pairs[:5], [-1] * 5, flags[:5])
+    for env in ({"SDF_STRIP_ALWAYS": 1}, {}):
+        eng = _engine_with_env(SDF_STRIPE_SPIN_CAP=1, **env)
+        _check_fast(eng, oracle, pairs[:4], [-1] * 4, flags[:4])
+        assert eng.last_reran() >= 2
 
 
 def test_strip_chain_one_task_of_a_whole_chunk(engine, oracle):
