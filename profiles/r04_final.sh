@@ -10,3 +10,5 @@ python3 profiles/mix_probe.py mm8 100000 > $out/mm8_100k.log 2>&1; tail -1 $out/
 python3 profiles/mix_probe.py mm8 100000 64 > $out/mm8_100k_64.log 2>&1; tail -1 $out/mm8_100k_64.log
 python3 profiles/mix_probe.py mm8 3000 > $out/mm8_3k.log 2>&1; tail -1 $out/mm8_3k.log
 python3 profiles/mix_probe.py hg19 1000000 > $out/hg19.log 2>&1; tail -1 $out/hg19.log
+python3 profiles/stage_bench.py --chr1 --one-bucket 5 2>&1 | grep "^run\|chr1-sized" > $out/stage_chr1.txt; cat $out/stage_chr1.txt | cut -c1-200
+python3 profiles/stage_bench.py 100000000 40000 6 2>&1 | grep "^run\|^genome" > $out/stage_40k.txt; cat $out/stage_40k.txt | cut -c1-200
