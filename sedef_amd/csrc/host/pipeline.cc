@@ -1215,6 +1215,12 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
                "%.2fs, all jobs %.2fs thread time), request collection %.2fs, output %.2fs; DP provider: request "
                "packing %.2fs, device call %.2fs, CIGAR unpacking %.2fs]\n",
           a.t_fetch, a.t_adv, a.t_longest, a.t_sum, a.t_collect, a.t_out, t_pack, t_call, t_unpack);
+  {  // (the extra lanes' device contexts side by side: a context takes 30-40 ms to give back)
+    std::vector<std::thread> gone;
+    for (auto &e : extra)
+      if (e) gone.emplace_back([&e] { e.reset(); });
+    for (auto &t : gone) t.join();
+  }
   return st;
 }
 
