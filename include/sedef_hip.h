@@ -297,7 +297,8 @@ const char *sdf_comm_last_error(const sdf_comm *c);
  * stays relative to its rank's words).  Two collectives whatever the world size: an all-gather of the counts and one
  * group of point-to-point transfers on the exact sizes.  Enqueued on `stream` (NULL: the communicator's own, synchronised
  * before returning); with a stream the call returns once the counts are on the host and the transfers are enqueued.
- * SDF_ERR_CIGAR_OVERFLOW: a capacity is too small (counts holds the sizes). */
+ * SDF_ERR_CIGAR_OVERFLOW: a capacity is too small ON ANY RANK (counts holds the sizes): the capacities travel with the
+ * counts, so every rank returns this together and none is left waiting in a receive. */
 int sdf_allgatherv_results(sdf_comm *c, const sdf_result *d_out, size_t n_tasks, const uint32_t *d_cig, size_t cig_used,
                            sdf_result *d_all_out, size_t all_out_cap, uint32_t *d_all_cig, size_t all_cig_cap,
                            uint64_t *counts, void *stream);

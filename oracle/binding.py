@@ -290,8 +290,8 @@ def mutate(rng, s, sub=0.06, dele=0.02, ins=0.02):
 def build_reference_align():
     so = os.path.join(_HERE, "_ref", "libref_align.so")
     have_ref = os.path.exists("/root/reference/src/align.cc")
-    drv = os.path.join(_HERE, "ref_align_driver.cc")
-    if os.path.exists(so) and not (have_ref and os.path.getmtime(so) < os.path.getmtime(drv)):
+    drv = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ref_align_driver.cc", "ref_hit_table.cc"))
+    if os.path.exists(so) and not (have_ref and os.path.getmtime(so) < drv):
         return so
     if have_ref:
         subprocess.check_call(["make", "-C", _HERE, "refalign"], stdout=subprocess.DEVNULL)
@@ -378,3 +378,74 @@ class ReferenceAlign:
     def set_scoring(self, match=5, mismatch=-4, gap_open=-40, gap_extend=-1):
         """Globals::Align::* as the CLI overrides set them (src/align_main.cc:343-352); process-wide in the reference."""
         self.lib.ref_set_scoring(match, mismatch, gap_open, gap_extend)
+
+    # ---- the reference's Hit / Alignment objects behind handles (oracle/ref_hit_table.cc) ----
+    def tab_open(self, query, ref):
+        """fast_align's shared sequences (src/chain.cc:207-208); drops the previous pair's handles."""
+        assert self.lib.ref_tab_open(query.encode(), ref.encode()) == 0
+
+    def tab_chain_hit(self, anchors, guide, qlo, qhi, rlo, rhi, up):
+        """Hit{...}; aln = Alignment(query, ref, anchors, guide); update_from_alignment (src/chain.cc:243-258)."""
+        a = np.ascontiguousarray(anchors, dtype=np.int32).reshape(-1, 4)
+        g = np.ascontiguousarray(guide, dtype=np.int32)
+        f = self.lib.ref_tab_chain_hit
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int] * 5
+        h = f(a.ctypes.data, len(a), g.ctypes.data, len(g), qlo, qhi, rlo, rhi, up)
+        assert h >= 0
+        return h
+
+    def tab_get(self, h):
+        """dict of query_start, query_end, ref_start, ref_end, jaccard, matches, mismatches, gap_bases, gaps, span."""
+        out = (C.c_int * 10)()
+        assert self.lib.ref_tab_get(h, out) == 0
+        return dict(zip(("qs", "qe", "rs", "re", "jaccard", "matches", "mismatches", "gap_bases", "gaps", "span"), list(out)))
+
+    def tab_cigar(self, h):
+        assert self.lib.ref_tab_cigar(h, self.buf, C.c_size_t(len(self.buf))) == 0
+        return self.buf.value.decode()
+
+    def tab_merge(self, prev, cur):
+        """prev->aln.merge(cur.aln, qseq, rseq); update_from_alignment(*prev) (src/refine.cc:172-173)."""
+        assert self.lib.ref_tab_merge(prev, cur) == 0
+
+    def tab_guide_hit(self, guide, qlo, qhi, rlo, rhi, side):
+        """Hit{...}; aln = Alignment(qseq, rseq, guide, side); update_from_alignment (src/refine.cc:164-183)."""
+        g = np.ascontiguousarray(guide, dtype=np.int32)
+        f = self.lib.ref_tab_guide_hit
+        f.argtypes = [C.c_void_p, C.c_int] + [C.c_int] * 5
+        h = f(g.ctypes.data, len(g), qlo, qhi, rlo, rhi, side)
+        assert h >= 0
+        return h
+
+    def tab_remap(self, h, qs, qe, rs, re_, qname, rname, ref_is_rc):
+        """The stage driver's in-place update of a result (src/align_main.cc:314-327) with coordinates the caller computed."""
+        assert self.lib.ref_tab_remap(h, qs, qe, rs, re_, qname.encode(), rname.encode(), int(ref_is_rc)) == 0
+
+    def tab_to_bed(self, h):
+        assert self.lib.ref_tab_to_bed(h, self.buf, C.c_size_t(len(self.buf))) == 0
+        return self.buf.value.decode()
+
+    def seed_to_bed(self, qname, q_rc, qs, qe, rname, r_rc, rs, re_, name, comment, jaccard):
+        """to_bed(0) of a Hit filled like Hit::from_bed fills it (src/hit.cc:29-63) from fields the caller split."""
+        f = self.lib.ref_seed_to_bed
+        f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p,
+                      C.c_int, C.c_char_p, C.c_size_t]
+        assert f(qname.encode(), int(q_rc), qs, qe, rname.encode(), int(r_rc), rs, re_, name.encode(), comment.encode(),
+                 jaccard, self.buf, len(self.buf)) == 0
+        return self.buf.value.decode()
+
+    # ---- the reference's SegmentTree, live (oracle/ref_hit_table.cc) ----
+    def tree_new(self, pts):
+        p = np.ascontiguousarray(pts, dtype=np.int32).reshape(-1, 2)
+        self.lib.ref_tree_new.argtypes = [C.c_void_p, C.c_int]
+        assert self.lib.ref_tree_new(p.ctypes.data, len(p)) == 0
+
+    def tree_activate(self, x, score):
+        self.lib.ref_tree_activate(int(x[0]), int(x[1]), int(score))
+
+    def tree_deactivate(self, x):
+        self.lib.ref_tree_deactivate(int(x[0]), int(x[1]))
+
+    def tree_rmq(self, p, q):
+        """-1: nothing; -2: a point that was never activated (ys[j].score == MIN, src/chain.cc:160); else ys[j].pos."""
+        return self.lib.ref_tree_rmq(int(p[0]), int(p[1]), int(q[0]), int(q[1]))

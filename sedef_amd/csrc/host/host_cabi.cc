@@ -296,6 +296,54 @@ int sdfh_guide_from_chains(const char *qstr_, const char *rstr_, const char *spe
   }
 }
 
+// fast_align(query, ref, orig, kmer) (reference: src/chain.cc:203-268, the per-pair entry src/align_main.cc:313 and
+// python/sedef.cpp:85 call): seed anchors, chains, chain alignments, refine_chains.  `orig` is given by the fields the
+// path reads: the two names and strands (same-chromosome rules, src/chain.cc:45-46, src/refine.cc:29-30) and the two
+// start coordinates.  Output: one line per refined hit, coordinates relative to the two strings:
+// "qs qe rs re cigar matches mismatches gaps gap_bases\n".
+int sdfh_fast_align(const char *query_, const char *ref_, const char *qname, const char *rname, int q_rc, int r_rc,
+                    int qstart, int rstart, int kmer, test_dp_fn test_dp, int device, char *outbuf, size_t cap) {
+  try {
+    Params p;
+    p.kmer = kmer;
+    set_alignment_scoring(p);
+    auto dp = provider(test_dp, device);
+    const std::string query = query_, ref = ref_;
+    Hit orig;
+    orig.query = std::make_shared<Sequence>(qname, "", false);
+    orig.ref = std::make_shared<Sequence>(rname, "", false);
+    orig.query->is_rc = q_rc != 0;
+    orig.ref->is_rc = r_rc != 0;
+    orig.query_start = qstart;
+    orig.ref_start = rstart;
+    orig.query_end = qstart + (int)query.size();
+    orig.ref_end = rstart + (int)ref.size();
+    PairJob job(query, ref, orig, p);
+    std::vector<Cigar> results;
+    for (;;) {
+      std::vector<DpRequest> reqs = job.advance(results);
+      if (reqs.empty()) break;
+      results = dp->run(reqs, p);
+    }
+    std::string out;
+    char nums[160];
+    for (auto &h : job.hits()) {
+      snprintf(nums, sizeof nums, "%d %d %d %d ", h.query_start, h.query_end, h.ref_start, h.ref_end);
+      out += nums;
+      out += h.aln.cigar_string();
+      snprintf(nums, sizeof nums, " %d %d %d %d\n", h.aln.matches(), h.aln.mismatches(), h.aln.gaps(), h.aln.gap_bases());
+      out += nums;
+    }
+    return copy_out(out, outbuf, cap);
+  } catch (std::string &s) {
+    g_err = s;
+    return -1;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // FastaReference::get_sequence (reference: src/fasta.cc:105-142); *end is updated like the reference does
 int sdfh_fasta_get(const char *path, const char *name, int start, int *end, char *buf, size_t cap) {
   try {

@@ -198,7 +198,7 @@ int main(int argc, char **argv) {
     sdf_result *d_out, *d_all_out;
     size_t all_cig_cap = 16;
     for (size_t k = 0; k < n; ++k) all_cig_cap += (size_t)b.qlen[k] + b.tlen[k] + 2;
-    if (w >= 0) cig_cap = std::min(cig_cap, 256 * m + 16), all_cig_cap = std::min(all_cig_cap, 256 * n + 16);
+    // (qlen + tlen + 2 words per task bound any CIGAR, as the stage sizes its pools: no guess per band)
     CHECK_HIP(hipMalloc((void **)&d_pool, (words + 1) * 4));
     CHECK_HIP(hipMalloc((void **)&d_cig, cig_cap * 4));
     CHECK_HIP(hipMalloc((void **)&d_out, (m + 1) * sizeof(sdf_result)));

@@ -176,6 +176,9 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   if (const char *lm = getenv("SDF_LANE_MIN")) ctx->lane_min = (size_t)std::max(1, atoi(lm));
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_lane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             want_lds);
+  // (per context, hence per device: a process-wide once-flag would leave a second GPU's copy of the kernel at 64 KiB)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sdf::chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            std::max(ctx->max_dyn_lds, 65536));
   (void)hipGetLastError();
   lap("attributes");
   const char *pl = getenv("SDF_PIPELINE");
@@ -1301,12 +1304,6 @@ extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const in
   SDF_HIP(hipMemcpyAsync(ctx->ch_wsoff.p, ws_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
   SDF_HIP(ctx->ch_which.reserve(n * 4 + 16));
   SDF_HIP(hipMemcpyAsync(ctx->ch_which.p, which.data(), n * 4, hipMemcpyHostToDevice, st));
-  static std::once_flag lds_once;
-  std::call_once(lds_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sdf::chain_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)caps[5]);
-    (void)hipGetLastError();
-  });
   for (int c = 0; c < 6; ++c)
     if (!cls[c].empty())
       hipLaunchKernelGGL(sdf::chain_wave_kernel, dim3((unsigned)cls[c].size()), dim3(64), caps[c], st,

@@ -3,7 +3,7 @@
 //
 // DP tasks are independent, so a batch is sharded over the GPUs of a node without any data-path collective; after the DP
 // every GPU holds the records and CIGAR words of its shard, and one exchange gives every GPU every shard's results: an
-// all-gather of the two counts per rank (ncclAllGather, 16 bytes a rank), a host read of that small table through pinned
+// all-gather of the two counts and the two capacities per rank (ncclAllGather, 32 bytes a rank), a host read of that small table through pinned
 // memory behind an event, and ONE group of point-to-point transfers on the exact sizes (ncclGroupStart ... ncclSend /
 // ncclRecv ... ncclGroupEnd: RCCL has no native gatherv; on the fully connected xGMI mesh the world - 1 transfers of a rank
 // are one hop each and run side by side).  Nothing padded travels.
@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,7 +24,7 @@
 struct sdf_comm {
   int device = 0, world = 1, rank = 0;
   ncclComm_t comm = nullptr;
-  uint64_t *h_counts = nullptr;  // pinned: [0..1] this rank's (tasks, CIGAR words); [2 ..] the table of all ranks
+  uint64_t *h_counts = nullptr;  // pinned: [0..3] this rank's (tasks, CIGAR words, record capacity, CIGAR capacity); [4 ..] the table of all ranks
   uint64_t *d_counts = nullptr;  // device: the same layout
   hipEvent_t ev = nullptr;
   hipStream_t own = nullptr;
@@ -63,7 +64,8 @@ Rccl &rccl() {
       r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.lib) {
-      r.err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "?");
+      const char *e = dlerror();  // (one call: it returns the message AND clears it)
+      r.err = std::string("cannot load librccl.so: ") + (e ? e : "?");
       return;
     }
 #define SDF_SYM(field, sym)                                      \
@@ -86,7 +88,7 @@ Rccl &rccl() {
 
 bool finish_comm(sdf_comm *c) {  // the small buffers of a communicator whose ncclComm_t exists
   if (hipSetDevice(c->device) != hipSuccess) return false;
-  const size_t bytes = (size_t)(2 + 2 * c->world) * sizeof(uint64_t);
+  const size_t bytes = (size_t)(4 + 4 * c->world) * sizeof(uint64_t);
   if (hipHostMalloc((void **)&c->h_counts, bytes, hipHostMallocDefault) != hipSuccess) return false;
   if (hipMalloc((void **)&c->d_counts, bytes) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) return false;
@@ -228,23 +230,32 @@ extern "C" int sdf_allgatherv_results(sdf_comm *c, const sdf_result *d_out, size
   SDF_CHIP(hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->own;
   const int W = c->world, me = c->rank;
-  // ---- the counts: 16 bytes a rank ----
+  // ---- the counts AND the capacities: 32 bytes a rank.  Whether the gathered buffers are large enough is decided from
+  // this shared table, so that every rank takes the same branch: a rank that returned on a local check would leave its
+  // peers waiting in ncclRecv for ever. ----
   c->h_counts[0] = n_tasks;
   c->h_counts[1] = cig_used;
-  SDF_CHIP(hipMemcpyAsync(c->d_counts, c->h_counts, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-  SDF_NCCL(R.AllGather(c->d_counts, c->d_counts + 2, 2, ncclUint64, c->comm, st));
-  SDF_CHIP(hipMemcpyAsync(c->h_counts + 2, c->d_counts + 2, (size_t)2 * W * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  c->h_counts[2] = d_all_out ? all_out_cap : 0;
+  c->h_counts[3] = d_all_cig ? all_cig_cap : 0;
+  SDF_CHIP(hipMemcpyAsync(c->d_counts, c->h_counts, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  SDF_NCCL(R.AllGather(c->d_counts, c->d_counts + 4, 4, ncclUint64, c->comm, st));
+  SDF_CHIP(hipMemcpyAsync(c->h_counts + 4, c->d_counts + 4, (size_t)4 * W * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   SDF_CHIP(hipEventRecord(c->ev, st));
   SDF_CHIP(hipEventSynchronize(c->ev));  // (this copy alone, not the device)
   std::vector<uint64_t> rec_off(W + 1, 0), cig_off(W + 1, 0);
+  uint64_t min_out_cap = ~0ull, min_cig_cap = ~0ull;
   for (int r = 0; r < W; ++r) {
-    counts[2 * r] = c->h_counts[2 + 2 * r];
-    counts[2 * r + 1] = c->h_counts[3 + 2 * r];
+    counts[2 * r] = c->h_counts[4 + 4 * r];
+    counts[2 * r + 1] = c->h_counts[5 + 4 * r];
     rec_off[r + 1] = rec_off[r] + counts[2 * r];
     cig_off[r + 1] = cig_off[r] + counts[2 * r + 1];
+    min_out_cap = std::min<uint64_t>(min_out_cap, c->h_counts[6 + 4 * r]);
+    min_cig_cap = std::min<uint64_t>(min_cig_cap, c->h_counts[7 + 4 * r]);
   }
-  if (rec_off[W] > all_out_cap || cig_off[W] > all_cig_cap || (rec_off[W] && !d_all_out) || (cig_off[W] && !d_all_cig)) {
-    c->err = "the gathered buffers are too small";
+  if (rec_off[W] > min_out_cap || cig_off[W] > min_cig_cap) {  // the same answer on every rank
+    c->err = (rec_off[W] > (d_all_out ? all_out_cap : 0) || cig_off[W] > (d_all_cig ? all_cig_cap : 0))
+                 ? "the gathered buffers are too small"
+                 : "the gathered buffers of another rank are too small";
     return SDF_ERR_CIGAR_OVERFLOW;
   }
   // ---- this rank's part: a local copy (or, in the one-rank self test, a send to itself) ----
@@ -259,14 +270,29 @@ extern "C" int sdf_allgatherv_results(sdf_comm *c, const sdf_result *d_out, size
   // Every rank derives the same list from the same table; empty ranges are skipped on both sides. ----
   if (W > 1 || self) {
     SDF_NCCL(R.GroupStart());
-    for (int r = 0; r < W; ++r) {
+    ncclResult_t bad = ncclSuccess;  // an error inside the group: close the group before returning, or the thread's
+    const char *what = "";           // next RCCL call would still be inside it
+    auto in_group = [&](ncclResult_t r_, const char *call) {
+      if (r_ != ncclSuccess && bad == ncclSuccess) bad = r_, what = call;
+      return bad == ncclSuccess;
+    };
+    for (int r = 0; r < W && bad == ncclSuccess; ++r) {
       if (r == me && !self) continue;
-      if (n_tasks) SDF_NCCL(R.Send(d_out, n_tasks * sizeof(sdf_result), ncclUint8, r, c->comm, st));
-      if (cig_used) SDF_NCCL(R.Send(d_cig, cig_used, ncclUint32, r, c->comm, st));
-      if (counts[2 * r]) SDF_NCCL(R.Recv(d_all_out + rec_off[r], counts[2 * r] * sizeof(sdf_result), ncclUint8, r, c->comm, st));
-      if (counts[2 * r + 1]) SDF_NCCL(R.Recv(d_all_cig + cig_off[r], counts[2 * r + 1], ncclUint32, r, c->comm, st));
+      if (n_tasks && !in_group(R.Send(d_out, n_tasks * sizeof(sdf_result), ncclUint8, r, c->comm, st), "ncclSend(records)")) break;
+      if (cig_used && !in_group(R.Send(d_cig, cig_used, ncclUint32, r, c->comm, st), "ncclSend(cigar)")) break;
+      if (counts[2 * r] &&
+          !in_group(R.Recv(d_all_out + rec_off[r], counts[2 * r] * sizeof(sdf_result), ncclUint8, r, c->comm, st), "ncclRecv(records)"))
+        break;
+      if (counts[2 * r + 1] &&
+          !in_group(R.Recv(d_all_cig + cig_off[r], counts[2 * r + 1], ncclUint32, r, c->comm, st), "ncclRecv(cigar)"))
+        break;
     }
-    SDF_NCCL(R.GroupEnd());
+    const ncclResult_t end = R.GroupEnd();
+    if (bad != ncclSuccess || end != ncclSuccess) {
+      c->err = std::string(bad != ncclSuccess ? what : "ncclGroupEnd") + ": " +
+               (R.GetErrorString ? R.GetErrorString(bad != ncclSuccess ? bad : end) : "RCCL error");
+      return SDF_ERR_HIP;
+    }
   }
   if (!stream) SDF_CHIP(hipStreamSynchronize(st));
   return SDF_OK;

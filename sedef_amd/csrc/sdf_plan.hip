@@ -316,6 +316,15 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 512 ? (need + 127) / 128 : need <= 768 ? 6 : 8) * 1024);
         // (the pair kernel's TRACK flavour rounds its window to 3 / 6 registers of 64 slots, 512 B each per block)
         if (need <= 384) bd = std::max(bd, (nrow + 15) / 16 * (size_t)(need <= 192 ? 3 : 6) * 512);
+        // (a MIXED pair gives both tasks the register count of the wider window: a banded task of a short target may sit next
+        // to one whose window is as wide as the band allows -- ((w + 1 + 15) / 16 + 1) * 16 + 32 slots, at most kMixedMaxNeed --
+        // at 512 B per register and block of its OWN rows)
+        if (bits_only && need <= kMixedMaxNeed && w < std::max(t.qlen, t.tlen)) {
+          const int wide = std::min(((w + 1 + 15) / 16 + 1) * 16 + 32, kMixedMaxNeed);
+          const int regs = (wide + 63) / 64;
+          const int nreg = regs <= 2 ? 2 : regs <= 6 ? regs : regs <= 8 ? 8 : 9;
+          bd = std::max(bd, (nrow + 15) / 16 * (size_t)nreg * 512);
+        }
       }
       if (t.tlen > env.stripe_min && t.tlen <= kStripeMaxT && w >= std::max(t.qlen, t.tlen))  // (stripe kernel, any width)
         for (int nr = 1; nr <= 4; nr *= 2)

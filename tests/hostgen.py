@@ -389,3 +389,240 @@ def far_equal_case(rng, gap):
     la, lb = len(a), len(b)
     spec = "0,0,%d|%d,%d,%d" % (la, la + gap, la + gap, lb)
     return q, r, spec, int(rng.choice([0, 500]))
+
+
+# ---------------------------------------------------------------- candidate pairs for the stage-level fixtures
+def _render(rng, codes, mask_frac=0.4, n_runs=0, lower_all=False):
+    """Code array -> FASTA characters: soft-masked runs of 50..400 (~mask_frac of the bases), `n_runs` short N runs."""
+    L = len(codes)
+    ch = _CODE2CHR[codes].copy()
+    if lower_all:
+        ch = ch + 32
+    elif mask_frac > 0 and L:
+        runs = rng.integers(50, 400, L // 50 + 4)
+        ends = np.cumsum(runs)
+        ends = ends[ends < L]
+        masked = rng.random(len(ends) + 1) < mask_frac
+        mask = np.repeat(masked, np.diff(np.concatenate(([0], ends, [L]))))
+        ch = np.where(mask, ch + 32, ch)
+    ch = ch.astype(np.uint8)
+    for _ in range(n_runs):
+        if L > 40:
+            p, n = int(rng.integers(0, L - 20)), int(rng.integers(1, 20))
+            ch[p:p + n] = ord("N")
+    return ch.tobytes().decode()
+
+
+def _rand(rng, n):
+    return rng.integers(0, 4, int(n), dtype=np.uint8)
+
+
+def _indels(rng, out, count, lo=50, hi=3000):
+    for _ in range(count):
+        if len(out) <= 600:
+            break
+        kk = int(rng.integers(200, len(out) - 200))
+        n_ind = int(rng.integers(lo, hi))
+        if rng.random() < 0.5:
+            out = np.concatenate([out[:kk], _rand(rng, n_ind), out[kk:]])
+        else:
+            out = np.concatenate([out[:kk], out[min(len(out) - 100, kk + n_ind):]])
+    return out
+
+
+STAGE_PAIR_KINDS = ("plain", "indel", "rc", "same_chr", "self_overlap", "tandem", "far_equal", "far_unequal", "far_cut",
+                    "threshold", "dp_tie", "low_upper", "n_runs", "long")
+
+
+def stage_pair_case(rng, kind):
+    """One candidate pair as fast_align sees it (src/chain.cc:203: two strings + the seed hit's names, strands, starts).
+    Returns dict(query, ref, qname, rname, q_rc, r_rc, qstart, rstart, kind)."""
+    d = float(rng.uniform(0.01, 0.18))
+    qname, rname, r_rc = "chr1", "chr2", False
+    qstart, rstart = int(rng.integers(0, 5_000_000)), int(rng.integers(0, 5_000_000))
+    fl = lambda lo=0, hi=1500: _rand(rng, rng.integers(lo, hi))
+    mask, nr = 0.4, 0
+    if kind in ("plain", "indel", "rc", "same_chr", "low_upper", "n_runs", "long"):
+        L = int(np.exp(rng.uniform(np.log(1000), np.log(9000))))
+        if kind == "long":
+            L = int(rng.integers(14000, 26000))
+        u = _rand(rng, L)
+        c = _mutate_codes(rng, u, d)
+        if kind in ("indel", "long") or rng.random() < 0.25:
+            c = _indels(rng, c, int(rng.integers(1, 4 if kind != "long" else 7)))
+        q = np.concatenate([fl(), u, fl()])
+        r = np.concatenate([fl(), c, fl()])
+        if kind == "rc":
+            r_rc, rname = True, str(rng.choice(["chr1", "chr2"]))
+        if kind == "same_chr":
+            rname = "chr1"
+            rstart = qstart + len(q) + int(rng.integers(0, 3000))
+        if kind == "low_upper":
+            mask = 0.97
+        if kind == "n_runs":
+            nr = int(rng.integers(2, 12))
+        qs, rs = _render(rng, q, mask, nr), _render(rng, r, mask, nr)
+    elif kind == "self_overlap":
+        # one region of a chromosome holding a tandem array; query and ref are overlapping windows of it on one strand
+        unit = _rand(rng, rng.integers(700, 2200))
+        parts = [fl(200, 900)]
+        for _ in range(int(rng.integers(3, 6))):
+            parts += [_mutate_codes(rng, unit, float(rng.uniform(0.01, 0.1))), fl(0, 300)]
+        parts.append(fl(200, 900))
+        g = _render(rng, np.concatenate(parts), mask)
+        G = len(g)
+        a0, a1 = 0, int(rng.integers(G // 2, G))
+        b0 = int(rng.integers(1, max(2, a1 - 600)))
+        b1 = G
+        qs, rs = g[a0:a1], g[b0:b1]
+        rname = "chr1"
+        rstart = qstart + b0
+    elif kind == "tandem":
+        unit = _rand(rng, rng.integers(900, 3000))
+        cp = lambda: _mutate_codes(rng, unit, float(rng.uniform(0.01, 0.12)))
+        q = np.concatenate([fl()] + [x for _ in range(int(rng.integers(1, 4))) for x in (cp(), fl(0, 250))] + [fl()])
+        r = np.concatenate([fl()] + [x for _ in range(int(rng.integers(2, 4))) for x in (cp(), fl(0, 250))] + [fl()])
+        qs, rs = _render(rng, q, mask), _render(rng, r, mask)
+    elif kind in ("far_equal", "far_unequal", "far_cut"):
+        a, b = _rand(rng, rng.integers(600, 2500)), _rand(rng, rng.integers(600, 2500))
+        dd = float(rng.uniform(0.0, 0.08))
+        if kind == "far_equal":
+            g1 = g2 = int(rng.integers(1001, 3000))
+        elif kind == "far_unequal":
+            g1, g2 = int(rng.integers(0, 4000)), int(rng.integers(1001, 9000))
+            if rng.random() < 0.5:
+                g1, g2 = g2, g1
+        else:
+            g1, g2 = int(rng.integers(0, 3000)), int(rng.integers(9900, 10200))
+            if rng.random() < 0.5:
+                g1, g2 = g2, g1
+        q = np.concatenate([fl(0, 700), a, _rand(rng, g1), b, fl(0, 700)])
+        r = np.concatenate([fl(0, 700), _mutate_codes(rng, a, dd), _rand(rng, g2), _mutate_codes(rng, b, dd), fl(0, 700)])
+        qs, rs = _render(rng, q, mask), _render(rng, r, mask)
+    elif kind == "threshold":
+        # an island of exact match whose chain span lands on either side of Search::MIN_READ_SIZE * (1 - MAX_ERROR) =
+        # 489.99999999999994 (src/chain.cc:233-238), inside a copy too diverged for seeds (substitutions only, so that the
+        # side extension of a kept chain still runs through it); the bases next to the island differ
+        isl = int(rng.choice([486, 488, 489, 489, 489, 490, 490, 490, 491, 493]))
+        core = _rand(rng, isl)
+        lf, rf = _rand(rng, rng.integers(350, 800)), _rand(rng, rng.integers(350, 800))
+
+        def subst(x, dv):
+            y = x.copy()
+            hit = rng.random(len(x)) < dv
+            y[hit] = (y[hit] + rng.integers(1, 4, int(hit.sum()), dtype=np.uint8)) % 4
+            return y
+        dv = float(rng.uniform(0.34, 0.4))
+        lf2, rf2 = subst(lf, dv), subst(rf, dv)
+        lf2[-1] = (lf[-1] + 1) % 4
+        rf2[0] = (rf[0] + 1) % 4
+        q = np.concatenate([fl(0, 400), lf, core, rf, fl(0, 400)])
+        r = np.concatenate([fl(0, 400), lf2, core, rf2, fl(0, 400)])
+        lower = bool(rng.random() < 0.7)
+        qs, rs = _render(rng, q, 0.0, 0, lower), _render(rng, r, 0.0, 0, lower)
+    elif kind == "dp_tie":
+        # an exact island P of L bases, `g` unrelated bases in BOTH sequences, then a long copy C: joining P to C costs
+        # int(1 * g) + int(100 + 0.5 * 0) and P scores 10 * L, so 10 L == g + 100 makes `sco >= dp[ai]` an equality
+        # (src/refine.cc:91-96)
+        L = int(rng.integers(95, 140))
+        g = 10 * L - 100 + int(rng.choice([0, 0, 0, 1, -1]))
+        p = _rand(rng, L)
+        c = _rand(rng, rng.integers(1200, 3000))
+        x, y = _rand(rng, g), _rand(rng, g)
+        # P's match must not grow by chance: the bases around it differ
+        lq, lr = _rand(rng, 300), _rand(rng, 300)
+        lr[-1] = (lq[-1] + 1) % 4
+        y[0] = (x[0] + 1) % 4
+        y[-1] = (x[-1] + 1) % 4
+        cc = c.copy()
+        q = np.concatenate([lq, p, x, c, fl(0, 300)])
+        r = np.concatenate([lr, p, y, cc, fl(0, 300)])
+        qs, rs = _render(rng, q, 0.0), _render(rng, r, 0.0)
+    else:
+        raise ValueError(kind)
+    return dict(kind=kind, query=qs, ref=rs, qname=qname, rname=rname, q_rc=False, r_rc=bool(r_rc), qstart=qstart,
+                rstart=rstart)
+
+
+def make_stage_fixture(seed, chrom_lens=(90_000, 50_000, 24_000), line_blens=(60, 50, 70), n_pairs=22, max_len=9000):
+    """A small genome as TEXT (FASTA, .fai) and a bucket file as `sedef align bucket` writes them (extended seeds:
+    Hit::extend does not clamp the ends, src/hit.cc:200-207), for the stage-level fixtures: planted duplications forward
+    and reverse-complement, tandem copies on one chromosome and strand (overlapping extended hits), copies flush against
+    chromosome starts and ends (FastaReference::get_sequence clamps, src/fasta.cc:112-116, before the rc remap uses the
+    clamped end, src/align_main.cc:317-321), seed lines of 10 to 15 fields, complexity classes (src/align_main.cc:243-264)
+    in shuffled file order."""
+    rng = np.random.default_rng(seed)
+    names = ["chrA", "chrB", "chrC"][:len(chrom_lens)]
+    seqs = [_rand(rng, L) for L in chrom_lens]
+    cursor = [300] * len(chrom_lens)  # next free position per chromosome for sources / copies
+    beds = []
+
+    def take(c, n):
+        p = cursor[c]
+        if p + n + 200 > chrom_lens[c]:
+            return None
+        cursor[c] = p + n + int(rng.integers(200, 1200))
+        return p
+    k = 0
+    while len(beds) < n_pairs and k < 10 * n_pairs:
+        k += 1
+        L = int(np.exp(rng.uniform(np.log(900), np.log(max_len))))
+        d = float(rng.uniform(0.01, 0.16))
+        sc = int(rng.integers(0, len(names)))
+        dc = int(rng.integers(0, len(names)))
+        mode = ["plain", "rc", "tandem", "end", "start"][len(beds) % 5] if len(beds) < 10 else str(rng.choice(["plain", "rc", "tandem"]))
+        sp = take(sc, L)
+        if sp is None:
+            continue
+        out = _mutate_codes(rng, seqs[sc][sp:sp + L], d)
+        if rng.random() < 0.35:
+            out = _indels(rng, out, int(rng.integers(1, 3)), 50, 1500)
+        rcf = mode == "rc" or (mode in ("end", "start") and rng.random() < 0.5)
+        if mode == "tandem":
+            dc = sc
+            dp = take(dc, len(out))
+        elif mode == "end":
+            dp = chrom_lens[dc] - len(out)
+            if cursor[dc] + 200 > dp:
+                continue
+        elif mode == "start":
+            if any(b[3] == names[dc] and b[4] < 300 + len(out) for b in beds) or len(out) > 290:
+                out = out[:290]
+            dp = 0
+        else:
+            dp = take(dc, len(out))
+        if dp is None:
+            continue
+        if rcf:
+            out = (3 - out)[::-1]
+        seqs[dc][dp:dp + len(out)] = out
+        j = int(rng.integers(0, 40))
+        qs, qe, rs, re_ = sp + j, sp + L - j, dp + j // 2, dp + len(out) - j // 3
+        w = min(2500, int(1.0 * max(qe - qs, re_ - rs)))  # Hit::extend(factor, max_extend) with small values: short windows
+        beds.append([names[sc], max(0, qs - w), qe + w, names[dc], max(0, rs - w), re_ + w, rcf, mode])
+    fasta, fai, off = "", "", 0
+    for name, s, lb in zip(names, seqs, line_blens):
+        text = _render(rng, s, 0.4, 2)
+        head = ">%s fixture chromosome\n" % name
+        fasta += head
+        off += len(head)
+        fai += "%s\t%d\t%d\t%d\t%d\n" % (name, len(text), off, lb, lb + 1)
+        body = "".join(text[i:i + lb] + "\n" for i in range(0, len(text), lb))
+        fasta += body
+        off += len(body)
+    order = rng.permutation(len(beds))
+    lines = []
+    for n_, i in enumerate(order):
+        qn, qs, qe, rn, rs, re_, rcf, mode = beds[i]
+        f = [qn, str(qs), str(qe), rn, str(rs), str(re_), "", "", "+", "-" if rcf else "+"]
+        nf = [13, 10, 14, 15, 13][n_ % 5]
+        if nf >= 13:
+            f += [str(max(qe - qs, re_ - rs)), "0", ""]
+        if nf >= 14:
+            f += [str(int(rng.integers(0, 50)))]
+        if nf >= 15:
+            f += ["seed%d" % n_]
+        if nf == 13 and n_ % 2:
+            f[6] = "name%d" % n_
+        lines.append("\t".join(f))
+    return dict(fasta=fasta, fai=fai, bed="\n".join(lines) + "\n", modes=[b[7] for b in beds])

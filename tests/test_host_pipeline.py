@@ -287,6 +287,16 @@ def test_alignment_golden_on_gpu(host, host_golden):
         assert cig == c["cigar"] and cnt == c["counts"]
     for c in host_golden["guides"]:
         assert host.guide_from_chains(c["q"], c["r"], c["spec"], c["side"]) == c["expect"]
+    # Alignment::merge runs inside the guides above (overlapping neighbours, src/refine.cc:172); the far gap of equal sides
+    # with its zero-length run (src/align.cc:135), the CLI's scoring overrides and the hit-level merge() of src/merge.cc
+    # (no DP in it: the same host code whichever provider is loaded) complete the reference-generated sections
+    for c in host_golden["far_equal"]:
+        assert host.guide_from_chains(c["q"], c["r"], c["spec"], c["side"]) == c["expect"]
+    for c in host_golden["scored"]:
+        cig, cnt = host.alignment_pair(c["a"], c["b"], scoring=c["scoring"])
+        assert cig == c["cigar"] and cnt == c["counts"]
+    for c in host_golden["merges"]:
+        assert host.merge(c["lines"], 250) == c["expect"]
 
 
 @pytest.mark.gpu
