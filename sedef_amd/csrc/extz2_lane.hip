@@ -105,6 +105,119 @@ __global__ __launch_bounds__(256) void lane_plan_kernel(const LaneRec *__restric
   plan[p] = t;
 }
 
+// ---- planning on the device, second form (round 5): counting sort, no workgroup waits for another ------------------
+// hipCUB's radix sort and scans pass their partial results from workgroup to workgroup (decoupled look-back): next to
+// kernels that hold every wavefront slot for milliseconds -- the chains and strips of the long tasks, launched first -- a
+// workgroup that has a slot waits for one that has none, and the sort of a million keys took 4.5-4.9 ms instead of 0.4
+// (profiles/r05_hg19_timeline_before.txt) with the lane DP, 38 % of the batch's work, queued behind it.  The key has 19 bits
+// -- class, score-only, query length, target length -- and every task of a key needs the same CIGAR slot and flag region:
+// a histogram, one scan over the BINS (count, staging words, flag bytes: three sums at once) and a pass that gives every
+// task its rank in its bin by an atomic add and writes its plan record.  Tasks of a bin are interchangeable (same matrix
+// size), so their order inside the bin does not matter to anything but the layout of the workspace.
+constexpr int kLaneKeyBits = 19, kLaneBins = 1 << kLaneKeyBits, kLaneScanBlock = 1024;
+__device__ __forceinline__ uint32_t lane_key(const LaneRec &r) {
+  return ((uint32_t)lane_class(r.qlen_m1 + 1) << 17) | ((r.flag & SDF_FLAG_SCORE_ONLY) ? 1u << 16 : 0u) | ((uint32_t)r.qlen_m1 << 8) | r.tlen_m1;
+}
+__device__ __forceinline__ uint32_t lane_key_cap(uint32_t key) {  // CIGAR staging words of a task of this key
+  return (key & (1u << 16)) ? 0u : ((key >> 8) & 0xffu) + (key & 0xffu) + 2u + 2u;
+}
+__device__ __forceinline__ uint32_t lane_key_dir(uint32_t key) {  // direction-flag bytes
+  return (key & (1u << 16)) ? 0u : (uint32_t)lane_dir_bytes((int)((key >> 8) & 0xffu) + 1, (int)(key & 0xffu) + 1);
+}
+__global__ __launch_bounds__(256) void lane_hist_kernel(const LaneRec *__restrict__ recs, int n, uint32_t *__restrict__ count) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const LaneRec r = recs[k];
+  if (r.flag != 0xffffu) atomicAdd(&count[lane_key(r)], 1u);
+}
+// per block of 1024 bins: exclusive prefixes inside the block (tasks, staging words, flag bytes) and the block's totals
+__global__ __launch_bounds__(256) void lane_bins_scan_kernel(const uint32_t *__restrict__ count, uint32_t *__restrict__ base,
+                                                             unsigned long long *__restrict__ capbase,
+                                                             unsigned long long *__restrict__ dirbase, uint32_t *__restrict__ tot_cnt,
+                                                             unsigned long long *__restrict__ tot_cap,
+                                                             unsigned long long *__restrict__ tot_dir) {
+  __shared__ unsigned long long sh[3][256];
+  const int t = threadIdx.x;
+  const uint32_t key0 = (uint32_t)blockIdx.x * kLaneScanBlock + 4u * t;
+  uint32_t c[4];
+  unsigned long long cap[4], dir[4], sc = 0, sp = 0, sd = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = count[key0 + j];
+    cap[j] = (unsigned long long)c[j] * lane_key_cap(key0 + j);
+    dir[j] = (unsigned long long)c[j] * lane_key_dir(key0 + j);
+    sc += c[j], sp += cap[j], sd += dir[j];
+  }
+  sh[0][t] = sc, sh[1][t] = sp, sh[2][t] = sd;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // (Hillis-Steele over the 256 partial sums)
+    unsigned long long a0 = 0, a1 = 0, a2 = 0;
+    if (t >= off) a0 = sh[0][t - off], a1 = sh[1][t - off], a2 = sh[2][t - off];
+    __syncthreads();
+    sh[0][t] += a0, sh[1][t] += a1, sh[2][t] += a2;
+    __syncthreads();
+  }
+  unsigned long long ec = sh[0][t] - sc, ep = sh[1][t] - sp, ed = sh[2][t] - sd;  // exclusive
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    base[key0 + j] = (uint32_t)ec;
+    capbase[key0 + j] = ep;
+    dirbase[key0 + j] = ed;
+    ec += c[j], ep += cap[j], ed += dir[j];
+  }
+  if (t == 255) tot_cnt[blockIdx.x] = (uint32_t)sh[0][255], tot_cap[blockIdx.x] = sh[1][255], tot_dir[blockIdx.x] = sh[2][255];
+}
+// the block totals (kLaneBins / kLaneScanBlock = 512 of them) to exclusive prefixes, in place: one workgroup
+__global__ __launch_bounds__(512) void lane_bins_top_kernel(uint32_t *__restrict__ tot_cnt, unsigned long long *__restrict__ tot_cap,
+                                                            unsigned long long *__restrict__ tot_dir) {
+  __shared__ unsigned long long sh[3][512];
+  const int t = threadIdx.x;
+  const unsigned long long c = tot_cnt[t], p = tot_cap[t], d = tot_dir[t];
+  sh[0][t] = c, sh[1][t] = p, sh[2][t] = d;
+  __syncthreads();
+  for (int off = 1; off < 512; off <<= 1) {
+    unsigned long long a0 = 0, a1 = 0, a2 = 0;
+    if (t >= off) a0 = sh[0][t - off], a1 = sh[1][t - off], a2 = sh[2][t - off];
+    __syncthreads();
+    sh[0][t] += a0, sh[1][t] += a1, sh[2][t] += a2;
+    __syncthreads();
+  }
+  tot_cnt[t] = (uint32_t)(sh[0][t] - c);
+  tot_cap[t] = sh[1][t] - p;
+  tot_dir[t] = sh[2][t] - d;
+}
+// every lane task to its place: rank in its bin by an atomic add, the plan record the DP and the traceback read
+__global__ __launch_bounds__(256) void lane_place_kernel(const LaneRec *__restrict__ recs, int n, uint32_t *__restrict__ cursor,
+                                                         const uint32_t *__restrict__ base, const unsigned long long *__restrict__ capbase,
+                                                         const unsigned long long *__restrict__ dirbase, const uint32_t *__restrict__ tot_cnt,
+                                                         const unsigned long long *__restrict__ tot_cap,
+                                                         const unsigned long long *__restrict__ tot_dir, int64_t stage0, int64_t dir0,
+                                                         PlanTask *__restrict__ plan) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const LaneRec r = recs[k];
+  if (r.flag == 0xffffu) return;
+  const uint32_t key = lane_key(r), blk = key / kLaneScanBlock;
+  const uint32_t rank = atomicAdd(&cursor[key], 1u);
+  const size_t p = (size_t)tot_cnt[blk] + base[key] + rank;
+  PlanTask t;
+  t.q_word = r.q_word;
+  t.t_word = r.t_word;
+  t.dir_off = dir0 + (int64_t)(tot_dir[blk] + dirbase[key] + (unsigned long long)rank * lane_key_dir(key));
+  t.cig_slot = stage0 + (int64_t)(tot_cap[blk] + capbase[key] + (unsigned long long)rank * lane_key_cap(key));
+  t.qlen = r.qlen_m1 + 1;
+  t.tlen = r.tlen_m1 + 1;
+  t.w = t.qlen > t.tlen ? t.qlen : t.tlen;
+  t.zdrop = -1;
+  t.flag = r.flag;
+  t.ncol16 = ((t.qlen < t.tlen ? t.qlen : t.tlen) + 15) / 16 * 16 + 16;
+  t.out_idx = (int32_t)r.out_idx;
+  t.cig_cap = (r.flag & SDF_FLAG_SCORE_ONLY) ? 0 : t.qlen + t.tlen + 2;
+  t.nreg = 1;
+  t.pad_ = 8;  // direction-flag layout 5 (traceback.hip)
+  plan[p] = t;
+}
+
 // ---- the DP -----------------------------------------------------------------------------------------------------
 // The matrix of a lane is walked in column TILES of 16 target positions: the tile's column state -- u | y << 8 | target
 // base << 16 of the cell above, one register per column -- stays in registers for all rows (the row loop is outside, the

@@ -86,11 +86,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
                                             const bool with_dir_a, const bool with_dir_b, StripH &ha, StripH &hb,
                                             const uint32_t *edge_in = nullptr, uint32_t *edge_out = nullptr,
                                             const sdf_result *mark = nullptr, const int spin_cap = 0, int *sums = nullptr,
-                                            const bool solo = false, const int s_begin = 0, const int s_end = 1 << 30,
-                                            uint32_t *state = nullptr) {
-  // (s_begin, s_end, state: the tiled chain kernel below runs a block's steps [s_begin, s_end) and carries the lane's
-  // registers from one call to the next through `state` -- 2 C + 4 words per lane, word w of lane l at state[64 w + l];
-  // loaded when s_begin > 0, stored when s_end stops short of the last step)
+                                            const bool solo = false) {
   const unsigned Q2 = (unsigned)gq * 0x00010001u;
   unsigned one2 = 0x00010001u, two2 = 0x00020002u;
   SDF_OPQ(one2);
@@ -99,16 +95,11 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
   constexpr int BW = 64 * C;  // columns of a block
   const int c0 = blk * BW + lane * C;
   unsigned U[C], Y[C], TC[C];
-  const bool resumed = state != nullptr && s_begin > 0;
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     TC[k] = strip_code2(twa, tna, ta, twb, tnb, tb, c0 + k);
     U[k] = (c0 + k) ? Q2 : 0u;  // (:121: u = q beyond the first column, y = 0 above the first row)
     Y[k] = 0u;
-    if (resumed) {
-      U[k] = state[64 * k + lane];
-      Y[k] = state[64 * (C + k) + lane];
-    }
   }
   // the lane's columns inside each target; each target's last column, if it lies in this block (wave-uniform)
   const int nva = ta - c0 < 0 ? 0 : ta - c0 > C ? C : ta - c0, nvb = tb - c0 < 0 ? 0 : tb - c0 > C ? C : tb - c0;
@@ -119,20 +110,10 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
   const int nstep = qmax + 63;
   unsigned xo = 0u, vo = 0u, qc = 0u, vcap = 0u;
   unsigned qwa_c = 0u, qna_c = 0u, qwb_c = 0u, qnb_c = 0u;
-  if (resumed) {
-    xo = state[64 * (2 * C) + lane];
-    vo = state[64 * (2 * C + 1) + lane];
-    qc = state[64 * (2 * C + 2) + lane];
-    vcap = state[64 * (2 * C + 3) + lane];
-    // (a resumed range starts on a multiple of 16: the 2-bit words are fetched by the step itself, the N-mask words every 32)
-    if (s_begin < qa) qna_c = qna[s_begin >> 5];
-    if (s_begin < qb) qnb_c = qnb[s_begin >> 5];
-  }
   unsigned e_next = (!CHAIN && blk) ? edge[0] : 0u;
   unsigned e16 = 0u;  // CHAIN: the edge words of rows (s & ~15) + lane, lanes 0..15
   uint2 *drow = dir + (size_t)blk * nstep * 64 + lane;
-  const int s_stop = s_end < nstep ? s_end : nstep;
-  for (int s = s_begin; s < s_stop; ++s) {
+  for (int s = 0; s < nstep; ++s) {
     if (CHAIN && s == 64) {
       // every lane has passed row 0: this block's share of the first row's sum of u, published before any edge word of
       // a row beyond 0 leaves lane 63 (the blocks holding the tasks' last columns read the totals at their very end)
@@ -152,7 +133,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
         e16 = row < qmax ? ld_agent(edge_in + row) : 0x80u;
         if (!__builtin_amdgcn_readfirstlane((int)__any((e16 & 0x80u) == 0u))) break;
         if (++spins >= spin_cap || ((spins & 63) == 63 && stripe_abandoned(mark))) return false;
-        if (s != s_begin) __builtin_amdgcn_s_sleep(4);
+        if (s) __builtin_amdgcn_s_sleep(4);
         else __builtin_amdgcn_s_sleep(64);
       }
     }
@@ -259,17 +240,6 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
       }
     }
   }
-  if (state != nullptr && s_stop < nstep) {
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-      state[64 * k + lane] = U[k];
-      state[64 * (C + k) + lane] = Y[k];
-    }
-    state[64 * (2 * C) + lane] = xo;
-    state[64 * (2 * C + 1) + lane] = vo;
-    state[64 * (2 * C + 2) + lane] = qc;
-    state[64 * (2 * C + 3) + lane] = vcap;
-  }
   return true;
 }
 
@@ -343,25 +313,13 @@ __global__ __launch_bounds__(64) void extz2_strip_kernel(const PlanTask *__restr
 // finished; a wait that runs out of polls abandons both tasks (stripe_abandon) and the batch call runs them again.
 // A block's partial exact-H values (the first row's sum of u; the last column's running H) are added up through three
 // words per task behind the edge columns.
-// Tiled chains (extz2_strip_tile_kernel): behind the edge columns every block keeps a header of 16 words ([0]: the number of
-// its tiles that are complete) and the registers a tile hands to the next one of the same block, 2 C + 12 words per lane.
-constexpr int kTileLag = 80;  // steps block b runs behind block b - 1: lane 63 is 63 steps behind lane 0 and a block fetches the
-                              // edge words of sixteen rows at a time (78), rounded to the sixteen-step grid of those fetches
-__host__ __device__ inline int strip_tile_words(int cols) { return 16 + 64 * (2 * cols + 12); }
-__host__ __device__ inline size_t strip_chain_cols_bytes(int qmax, int tmax, int cols) {
+__host__ __device__ inline size_t strip_chain_sync_bytes(int qmax, int tmax, int cols) {
   return ((size_t)(strip_blocks(tmax, cols) - 1) * (size_t)(qmax + 64) * 4 + 64 + 255) & ~(size_t)255;
 }
-__host__ __device__ inline size_t strip_chain_sync_bytes(int qmax, int tmax, int cols) {
-  return strip_chain_cols_bytes(qmax, tmax, cols) + (((size_t)strip_blocks(tmax, cols) * strip_tile_words(cols) * 4 + 255) & ~(size_t)255);
-}
-// the tiles (windows of S steps of the chain's clock, which block b joins 80 b steps late) block `blk` takes part in
-__host__ __device__ inline int strip_tile_first(int blk, int S) { return kTileLag * blk / S; }
-__host__ __device__ inline int strip_tile_last(int blk, int nstep, int S) { return (kTileLag * blk + nstep - 1) / S; }
 
 __global__ __launch_bounds__(64) void strip_chain_init_kernel(const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
-                                                              uint8_t *__restrict__ dirbase, const uint32_t *__restrict__ pool,
-                                                              const int stride) {
-  const int32_t entry = order[(size_t)blockIdx.x * stride];  // (stride 2: the tiled kernel's entries are pairs of words)
+                                                              uint8_t *__restrict__ dirbase) {
+  const int32_t entry = order[blockIdx.x];
   const int blk = (int)((uint32_t)entry >> 24);
   const PlanTask tka = plan[entry & 0xffffff], tkb = plan[tka.zdrop];
   const int qmax = tka.qlen > tkb.qlen ? tka.qlen : tkb.qlen, tmax = tka.tlen > tkb.tlen ? tka.tlen : tkb.tlen;
@@ -369,27 +327,12 @@ __global__ __launch_bounds__(64) void strip_chain_init_kernel(const PlanTask *__
   if (blk >= nblk) return;
   uint32_t *sync = reinterpret_cast<uint32_t *>(dirbase + tka.dir_off +
                                                 (int64_t)strip_dir_bytes(qmax, tmax, tka.nreg, tka.zdrop == (entry & 0xffffff)));
-  if (blk == 0) {
+  if (blk == 0)
     for (int k = threadIdx.x; k < 16; k += 64) sync[k] = 0u;  // the row-0 sums of both tasks
-    // [8]: does any of the four sequences hold an N?  (the tiled kernel enters a chain hundreds of times: asked once, here)
-    uint32_t seen = 0;
-    const uint32_t *tna = pool + tka.t_word + (tka.tlen + 15) / 16, *qna = pool + tka.q_word + (tka.qlen + 15) / 16;
-    const uint32_t *tnb = pool + tkb.t_word + (tkb.tlen + 15) / 16, *qnb = pool + tkb.q_word + (tkb.qlen + 15) / 16;
-    for (int k = threadIdx.x; k < (tka.tlen + 31) / 32; k += 64) seen |= tna[k];
-    for (int k = threadIdx.x; k < (tkb.tlen + 31) / 32; k += 64) seen |= tnb[k];
-    for (int k = threadIdx.x; k < (tka.qlen + 31) / 32; k += 64) seen |= qna[k];
-    for (int k = threadIdx.x; k < (tkb.qlen + 31) / 32; k += 64) seen |= qnb[k];
-    const bool any = __any(seen != 0);
-    if (threadIdx.x == 0) sync[8] = any ? 1u : 0u;
-  }
   if (blk + 1 < nblk) {
     uint32_t *col = sync + 16 + (size_t)blk * (qmax + 64);
     for (int k = threadIdx.x; k < qmax + 64; k += 64) col[k] = 0u;
   }
-  // the block's tile header (its registers are written before they are read)
-  uint32_t *tile = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(sync) + strip_chain_cols_bytes(qmax, tmax, tka.nreg)) +
-                   (size_t)blk * strip_tile_words(tka.nreg);
-  if (threadIdx.x < 16) tile[threadIdx.x] = 0u;
 }
 
 template <int C>
@@ -487,158 +430,6 @@ __global__ __launch_bounds__(64) void extz2_strip_chain_kernel(const PlanTask *_
       if (f != at) out[f] = src[f];
   }
 }
-
-// ---- tiled chains: persistent wavefronts, a block's steps cut into tiles ----------------------------------------------
-// A chain of blocks runs at the pace of its slowest block, and a wavefront bound to one block for all its rows runs at the
-// pace of the SIMD the dispatcher put it on: with four to seven chain wavefronts per SIMD the blocks of the hg19 mixture's
-// 304 chains waited 46 % of their cycles for their left neighbours (profiles/r04_hg19_pmc_cols4.txt).  Here a block is cut
-// into TILES -- windows of S steps of the chain's clock, which block b joins 80 b steps late (kTileLag) -- and the launch is
-// a fixed set of wavefronts that take tile after tile from the launch order: a slow SIMD takes fewer tiles, every block of
-// every chain advances with the whole device's pace.  A block's registers go from one of its tiles to the next through HBM
-// (2 C + 12 words per lane; a tile is S steps of ~30 instructions per column).
-// Order and forward progress: the planner lists a chain's tiles window by window, blocks ascending inside a window, chains
-// interleaved so that they END together; a list is claimed in order (stripe_claim's counters).  Tile (b, k) needs tile
-// (b, k - 1) complete -- its registers -- and, row by row, the edge words block b - 1 writes during ITS tile k (80 > 78):
-// both stand earlier in the list, so whoever a wavefront waits for has been taken by a wavefront that is running or done.
-template <int C>
-__global__ __launch_bounds__(64) void extz2_strip_tile_kernel(const PlanTask *__restrict__ plan, const int32_t *__restrict__ order,
-                                                              const uint32_t *__restrict__ pool, ScoreK sc,
-                                                              uint8_t *__restrict__ dirbase, sdf_result *__restrict__ res,
-                                                              unsigned long long *__restrict__ gave_up, const int spin_cap,
-                                                              unsigned *__restrict__ claim, const unsigned per_list, const int S) {
-  const int lane = threadIdx.x;
-  const int gq = sc.q, qe = sc.qe;
-  const int zm = (int)(int8_t)sc.sc_match + 2 * qe, zmis = (int)(int8_t)sc.sc_mis + 2 * qe;
-  const unsigned ZM2 = (unsigned)zm * 0x00010001u, ZD2 = ((unsigned)(zmis - zm) & 0xffffu) * 0x00010001u;
-  const unsigned ZW2 = (unsigned)(2 * qe) * 0x00010001u, CAP2 = ZM2;
-  place_note();
-  for (;;) {
-    // ---- the next tile of this XCD's list, or of the next list that has one left ----
-    int32_t e0 = 0, e1 = -1;  // (e1 = -1: every list is exhausted)
-    if (lane == 0) {
-      const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-      for (unsigned a = 0; a < 8; ++a) {
-        const unsigned q = (xcc + a) & 7u;
-        if (__hip_atomic_load(&claim[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per_list) continue;
-        const unsigned p = atomicAdd(&claim[q], 1u);
-        if (p < per_list) {
-          e0 = order[2 * ((size_t)8 * p + q)];
-          e1 = order[2 * ((size_t)8 * p + q) + 1];
-          break;
-        }
-      }
-    }
-    e0 = __builtin_amdgcn_readfirstlane(e0);
-    e1 = __builtin_amdgcn_readfirstlane(e1);
-    if (e1 < 0) break;
-    const int blk = (int)((uint32_t)e0 >> 24);
-    if (blk == 255) continue;  // (padding of the list)
-    const int ia = e0 & 0xffffff, kt = e1;
-    const PlanTask tka = plan[ia];
-    const int ib = tka.zdrop;
-    const PlanTask tkb = plan[ib];
-    const int qa = tka.qlen, ta = tka.tlen, qb = tkb.qlen, tb = tkb.tlen;
-    const int qmax = qa > qb ? qa : qb, tmax = ta > tb ? ta : tb;
-    const int nblk = strip_blocks(tmax, C), nstep = qmax + 63;
-    const sdf_result *mark = res + tka.out_idx;
-    if (stripe_abandoned(mark)) continue;  // (a tile of this pair gave up: the batch call runs both tasks again)
-    __builtin_amdgcn_s_setprio(qmax + tmax >= 8192 ? 2 : 0);
-    const uint32_t *twa = pool + tka.t_word, *tna = twa + (ta + 15) / 16;
-    const uint32_t *qwa = pool + tka.q_word, *qna = qwa + (qa + 15) / 16;
-    const uint32_t *twb = pool + tkb.t_word, *tnb = twb + (tb + 15) / 16;
-    const uint32_t *qwb = pool + tkb.q_word, *qnb = qwb + (qb + 15) / 16;
-    const bool with_dir_a = !(tka.flag & SDF_FLAG_SCORE_ONLY), with_dir_b = ib != ia && !(tkb.flag & SDF_FLAG_SCORE_ONLY);
-    uint2 *dir = reinterpret_cast<uint2 *>(dirbase + tka.dir_off);
-    uint8_t *sync8 = dirbase + tka.dir_off + (int64_t)strip_dir_bytes(qmax, tmax, C, ib == ia);
-    uint32_t *sync = reinterpret_cast<uint32_t *>(sync8);
-    int *sums = reinterpret_cast<int *>(sync);
-    uint32_t *cols = sync + 16;
-    const uint32_t *edge_in = cols + (size_t)(blk ? blk - 1 : 0) * (qmax + 64);
-    uint32_t *edge_out = cols + (size_t)blk * (qmax + 64);
-    uint32_t *tile = reinterpret_cast<uint32_t *>(sync8 + strip_chain_cols_bytes(qmax, tmax, C)) + (size_t)blk * strip_tile_words(C);
-    uint32_t *regs = tile + 16;
-    const bool has_n = __builtin_amdgcn_readfirstlane((int)sync[8]) != 0;
-    const int k0 = strip_tile_first(blk, S), k1 = strip_tile_last(blk, nstep, S);
-    const int s_begin = kt > k0 ? kt * S - kTileLag * blk : 0, s_end = (kt + 1) * S - kTileLag * blk;
-    StripH ha, hb;
-    if (kt > k0) {
-      // the tile before this one of the same block: taken earlier from the same list, by a wavefront that is running or done
-      int spins = 0;
-      while (__builtin_amdgcn_readfirstlane((int)ld_agent(tile)) != kt - k0) {
-        if (++spins >= spin_cap || ((spins & 63) == 63 && stripe_abandoned(mark))) {
-          spins = -1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(16);
-      }
-      if (spins < 0) {
-        stripe_abandon(gave_up, res + tka.out_idx, tka.out_idx, lane);
-        if (ib != ia) stripe_abandon(gave_up, res + tkb.out_idx, tkb.out_idx, lane);
-        continue;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      const uint32_t *hs = regs + 64 * (2 * C + 4);
-      ha.sum0 = (int)hs[lane], ha.hrel = (int)hs[64 + lane], ha.best = (int)hs[128 + lane], ha.bestj = (int)hs[192 + lane];
-      hb.sum0 = (int)hs[256 + lane], hb.hrel = (int)hs[320 + lane], hb.best = (int)hs[384 + lane], hb.bestj = (int)hs[448 + lane];
-    }
-    const bool ok = has_n ? strip_steps<true, true, C>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2,
-                                                    ZD2, ZW2, CAP2, nullptr, dir, with_dir_a, with_dir_b, ha, hb, edge_in, edge_out,
-                                                    mark, spin_cap, sums, ib == ia, s_begin, s_end, regs)
-                          : strip_steps<false, true, C>(blk, nblk, qa, ta, qb, tb, lane, twa, tna, twb, tnb, qwa, qna, qwb, qnb, gq, qe, ZM2,
-                                                     ZD2, ZW2, CAP2, nullptr, dir, with_dir_a, with_dir_b, ha, hb, edge_in, edge_out,
-                                                     mark, spin_cap, sums, ib == ia, s_begin, s_end, regs);
-    if (!ok) {
-      stripe_abandon(gave_up, res + tka.out_idx, tka.out_idx, lane);
-      if (ib != ia) stripe_abandon(gave_up, res + tkb.out_idx, tkb.out_idx, lane);
-      continue;
-    }
-    if (kt < k1) {  // hand the block over to its next tile
-      uint32_t *hs = regs + 64 * (2 * C + 4);
-      hs[lane] = (uint32_t)ha.sum0, hs[64 + lane] = (uint32_t)ha.hrel, hs[128 + lane] = (uint32_t)ha.best, hs[192 + lane] = (uint32_t)ha.bestj;
-      hs[256 + lane] = (uint32_t)hb.sum0, hs[320 + lane] = (uint32_t)hb.hrel, hs[384 + lane] = (uint32_t)hb.best, hs[448 + lane] = (uint32_t)hb.bestj;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      if (lane == 0) st_agent(tile, (uint32_t)(kt - k0 + 1));
-      continue;
-    }
-    // ---- the block's last tile: the tasks' results, as the chain kernel writes them ----
-    const int bla = (ta - 1) / (64 * C), blb = (tb - 1) / (64 * C);
-    if (blk != bla && blk != blb) continue;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    const int lla = ((ta - 1) % (64 * C)) / C, llb = ((tb - 1) % (64 * C)) / C;
-    const int fa = __builtin_amdgcn_readlane(ha.hrel, lla), fb = __builtin_amdgcn_readlane(hb.hrel, llb);
-    const int ba = __builtin_amdgcn_readlane(ha.best, lla), bb = __builtin_amdgcn_readlane(hb.best, llb);
-    const int ja = __builtin_amdgcn_readlane(ha.bestj, lla), jb = __builtin_amdgcn_readlane(hb.bestj, llb);
-    if (lane < 2 && (lane == 0 ? blk == bla : (ib != ia && blk == blb))) {
-      const int tl = lane ? tb : ta;
-      const int row0 = ld_agent(sums + lane) - (tl - 1) * qe - 2 * qe;
-      sdf_result o;
-      o.score = row0 + (lane ? fb : fa);
-      o.max = 0;
-      o.max_q = o.max_t = -1;
-      o.mqe = SDF_NEG_INF;
-      o.mqe_t = -1;
-      o.mte = row0 + (lane ? bb : ba);
-      o.mte_q = (lane ? jb : ja) + (tl - 1) - ((tl - 1) | 15);
-      o.zdropped = 0;
-      o.n_cigar = 0;
-      o.cigar_off = 0;
-      o.matches = o.mismatches = o.gaps = o.gap_bases = 0;
-      sdf_result *dst = res + (lane ? tkb.out_idx : tka.out_idx);
-      const int keep = __hip_atomic_load(&dst->n_cigar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      o.n_cigar = keep == -1 ? -1 : 0;
-      const int32_t *src = reinterpret_cast<const int32_t *>(&o);
-      int32_t *out = reinterpret_cast<int32_t *>(dst);
-      constexpr int at = offsetof(sdf_result, n_cigar) / 4;
-#pragma unroll
-      for (int f = 0; f < (int)(sizeof(sdf_result) / 4); ++f)
-        if (f != at) out[f] = src[f];
-    }
-  }
-}
-template __global__ void extz2_strip_tile_kernel<8>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                    sdf_result *, unsigned long long *, int, unsigned *, unsigned, int);
-template __global__ void extz2_strip_tile_kernel<4>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
-                                                    sdf_result *, unsigned long long *, int, unsigned *, unsigned, int);
 
 template __global__ void extz2_strip_chain_kernel<8>(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *,
                                                      sdf_result *, unsigned long long *, int, unsigned *);

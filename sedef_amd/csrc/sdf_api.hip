@@ -937,6 +937,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   SDF_HIP(ctx->ln_keys.reserve_exact(n * 8));
   SDF_HIP(ctx->ln_vals.reserve_exact(n * 8));
   SDF_HIP(ctx->ln_sizes.reserve_exact(n * 32 + 64));
+  SDF_HIP(ctx->ln_bins.reserve_exact((size_t)kLaneBins * (4 + 4 + 4 + 8 + 8) + (size_t)(kLaneBins / kLaneScanBlock) * 24 + 256));
   {  // (the library sort / scan of the lane tasks' planning: sdf_launch.hip, launch_lane)
     size_t t_sort = 0, t_scan = 0;
     SDF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
@@ -951,7 +952,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   if (ctx->pipeline) {
     for (hipStream_t *q : {&ctx->lane_stream, &ctx->aux_stream[0], &ctx->aux_stream[1], &ctx->aux_stream[2], &ctx->aux_stream[3]}) {
       if (q != &ctx->lane_stream && (size_t)(q - &ctx->aux_stream[0]) >= ctx->aux_limit) continue;
-      if (!*q && hipStreamCreateWithFlags(q, hipStreamNonBlocking) != hipSuccess) {
+      if (!*q && (q == &ctx->lane_stream ? create_lane_stream(q) : hipStreamCreateWithFlags(q, hipStreamNonBlocking)) != hipSuccess) {
         (void)hipGetLastError();
         *q = nullptr;
       }

@@ -50,6 +50,13 @@ __global__ void lane_keys_kernel(const LaneRec *, int, uint32_t *, uint32_t *);
 __global__ void lane_sizes_kernel(const LaneRec *, const uint32_t *, int, unsigned long long *, unsigned long long *);
 __global__ void lane_plan_kernel(const LaneRec *, const uint32_t *, int, const unsigned long long *, const unsigned long long *,
                                  int64_t, int64_t, PlanTask *);
+__global__ void lane_hist_kernel(const LaneRec *, int, uint32_t *);
+__global__ void lane_bins_scan_kernel(const uint32_t *, uint32_t *, unsigned long long *, unsigned long long *, uint32_t *,
+                                      unsigned long long *, unsigned long long *);
+__global__ void lane_bins_top_kernel(uint32_t *, unsigned long long *, unsigned long long *);
+__global__ void lane_place_kernel(const LaneRec *, int, uint32_t *, const uint32_t *, const unsigned long long *,
+                                  const unsigned long long *, const uint32_t *, const unsigned long long *,
+                                  const unsigned long long *, int64_t, int64_t, PlanTask *);
 __global__ void extz2_lane_kernel(const PlanTask *, int, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
 __global__ void extz2_strip_kernel(const PlanTask *, const int32_t *, const uint32_t *, ScoreK, uint8_t *, sdf_result *);
 template <int C>
@@ -287,6 +294,7 @@ struct sdf_ctx {
   HostBuf host_lane;
   HostBuf host_an;  // pinned staging of the anchors call's output (sdf_reserve with SDF_RESERVE_ANCHORS; a pageable copy runs at ~3 GB/s)
   DevBuf ln_recs, ln_keys, ln_vals, ln_sizes, ln_tmp;
+  DevBuf ln_bins;  // ... second form of the lane planning: per-key counts, ranks, prefixes (extz2_lane.hip: lane_hist_kernel and on)
   hipStream_t lane_stream = nullptr;
   bool strip_enabled = true;  // SDF_NO_STRIP=1: full-band tasks of 257..8192 target bases stay on the window / stripe kernels
   bool strip_always = false;  // SDF_STRIP_ALWAYS=1 (tests): the strip kernels whatever the number of tasks

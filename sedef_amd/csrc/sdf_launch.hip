@@ -517,6 +517,19 @@ static int rerun_abandoned(BatchRun &run, unsigned long long count) {
   return SDF_OK;
 }
 
+// The lane path is a chain of small kernels in front of its DP launches, next to chain and strip kernels that hold every
+// wavefront slot for milliseconds: on the highest queue priority its workgroups are the first to get a slot a finished
+// wavefront frees (the hg19-shaped mixture: 12.8 -> 12.2 ms per call under the profiler; SDF_LANE_PRIO=0: a stream like the others).
+hipError_t create_lane_stream(hipStream_t *out) {
+  static const bool lane_prio = [] {
+    const char *e = getenv("SDF_LANE_PRIO");
+    return !(e && e[0] == '0');
+  }();
+  int prio_lo = 0, prio_hi = 0;
+  if (lane_prio && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_hi = 0;
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, lane_prio ? prio_hi : 0);
+}
+
 // The lane tasks of a batch (extz2_lane.hip), start to finish on a stream of their own next to the chunks: the records the
 // scan wrote -> sort by (class, qlen, tlen) -> CIGAR-slot and flag-region offsets -> plan records behind the host-planned
 // ones -> one DP launch per class present -> traceback.  Nothing here waits for the host.
@@ -524,7 +537,7 @@ static int launch_lane(BatchRun &run, size_t n) {
   sdf_ctx *ctx = run.ctx;
   const BatchCut &cut = *run.cut;
   const size_t nl = cut.n_lane;
-  if (!ctx->lane_stream && hipStreamCreateWithFlags(&ctx->lane_stream, hipStreamNonBlocking) != hipSuccess) {
+  if (!ctx->lane_stream && create_lane_stream(&ctx->lane_stream) != hipSuccess) {
     (void)hipGetLastError();
     ctx->err = "cannot create the lane kernel's stream";
     return SDF_ERR_HIP;
@@ -538,6 +551,52 @@ static int launch_lane(BatchRun &run, size_t n) {
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt0).count());
   };
   SDF_HIP(hipStreamWaitEvent(sl, run.ev_begin, 0));
+  // Planning without a sort (extz2_lane.hip, "second form"): histogram over the 19-bit keys, one scan over the bins, every task
+  // to its rank in its bin.  SDF_LANE_PLAN=sort: round 4's hipCUB radix sort + two scans.
+  static const bool by_bins = [] {
+    const char *e = getenv("SDF_LANE_PLAN");
+    return !(e && e[0] == 's');
+  }();
+  if (by_bins) {
+    constexpr size_t nb = kLaneBins, nt = kLaneBins / kLaneScanBlock;
+    SDF_HIP(ctx->ln_recs.reserve(n * sizeof(LaneRec)));
+    SDF_HIP(ctx->ln_bins.reserve(nb * (4 + 4 + 4 + 8 + 8) + nt * (8 + 8 + 8) + 256));
+    LaneRec *d_recs = (LaneRec *)ctx->ln_recs.p;
+    unsigned long long *capbase = (unsigned long long *)ctx->ln_bins.p, *dirbase = capbase + nb, *tot_cap = dirbase + nb, *tot_dir = tot_cap + nt;
+    uint32_t *count = (uint32_t *)(tot_dir + nt), *cursor = count + nb, *base = cursor + nb, *tot_cnt = base + nb;
+    lap("buffers");
+    SDF_HIP(hipMemcpyAsync(d_recs, ctx->host_lane.p, n * sizeof(LaneRec), hipMemcpyHostToDevice, sl));
+    SDF_HIP(hipMemsetAsync(count, 0, 2 * nb * sizeof(uint32_t), sl));  // (count and cursor)
+    lap("records uploaded");
+    const dim3 gn((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(lane_hist_kernel, gn, dim3(256), 0, sl, d_recs, (int)n, count);
+    hipLaunchKernelGGL(lane_bins_scan_kernel, dim3((unsigned)nt), dim3(256), 0, sl, count, base, capbase, dirbase, tot_cnt, tot_cap, tot_dir);
+    hipLaunchKernelGGL(lane_bins_top_kernel, dim3(1), dim3((unsigned)nt), 0, sl, tot_cnt, tot_cap, tot_dir);
+    PlanTask *lp = run.d_plan + cut.ntask_total;
+    const int64_t dir0 = (int64_t)(cut.heavy_need + cut.nreg_ws * cut.region_need);
+    hipLaunchKernelGGL(lane_place_kernel, gn, dim3(256), 0, sl, d_recs, (int)n, cursor, base, capbase, dirbase, tot_cnt, tot_cap, tot_dir,
+                       cut.stage_total, dir0, lp);
+    lap("histogram, scan, plan");
+    run.ev_lane0 = next_event(ctx, run.evc);
+    SDF_HIP(hipEventRecord(run.ev_lane0, sl));
+    size_t pos = 0;
+    for (int c = 0; c < 4; ++c) {  // (the class is the key's top: the classes are consecutive ranges)
+      const size_t cnt = cut.lane_cls[c];
+      if (!cnt) continue;
+      hipLaunchKernelGGL(extz2_lane_kernel, dim3((unsigned)((cnt + 63) / 64)), dim3(64), lane_lds_bytes(c), sl, lp + pos, (int)cnt,
+                         run.d_pool, run.sk, run.d_dir, run.d_out);
+      ++ctx->launches;
+      pos += cnt;
+    }
+    if (run.want_cigar)
+      launch_traceback<5>(false, nl, sl, lp, run.d_pool, run.d_dir, run.d_out, run.d_stage);
+    run.ev_lane = next_event(ctx, run.evc);
+    SDF_HIP(hipEventRecord(run.ev_lane, sl));
+    SDF_HIP(hipGetLastError());
+    ctx->lane_tasks = (long long)nl;
+    lap("DP, traceback");
+    return SDF_OK;
+  }
   SDF_HIP(ctx->ln_recs.reserve(n * sizeof(LaneRec)));
   SDF_HIP(ctx->ln_keys.reserve(n * 8));
   SDF_HIP(ctx->ln_vals.reserve(n * 8));
