@@ -62,6 +62,33 @@ int sdfh_generate(const char *ref_path, const char *bed_path, int kmer, const ch
   }
 }
 
+// several buckets, one provider (host/pipeline.cc: generate_many): `beds` = bucket paths separated by newlines; every
+// bucket's lines go to `<bucket><out_suffix>`.  stats: per bucket {lines, hits} (2 x buckets entries).
+int sdfh_generate_many(const char *ref_path, const char *beds, int kmer, const char *out_suffix, const char *log_dir,
+                       test_dp_fn test_dp, int device, long long *stats) {
+  try {
+    Params p;
+    auto dp = provider(test_dp, device);
+    std::vector<std::string> list;
+    for (const char *c = beds; *c;) {
+      const char *e = strchr(c, '\n');
+      std::string one = e ? std::string(c, e) : std::string(c);
+      if (!one.empty()) list.push_back(one);
+      if (!e) break;
+      c = e + 1;
+    }
+    const auto sts = generate_many(ref_path, expand_buckets(list), kmer, p, *dp, out_suffix, log_dir ? log_dir : "", stderr);
+    for (size_t k = 0; stats && k < sts.size(); k++) stats[2 * k] = sts[k].lines, stats[2 * k + 1] = sts[k].total_written;
+    return (int)sts.size();
+  } catch (std::string &s) {
+    g_err = s;
+    return -1;
+  } catch (std::exception &e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // `sedef stats generate genome.fa final.bed > out` (reference: src/stats_main.cc:339-389); test_cols: the oracle's column
 // walker instead of the device (CPU tests).  stats: hits read, pieces, columns; returns the lines written or -1.
 long sdfh_stats_generate(const char *ref_path, const char *bed_path, const char *out_path, int max_ok_gap, int min_split,

@@ -17,6 +17,9 @@
 #include <thread>
 
 #include "../../../include/sedef_hip.h"
+#include <dirent.h>
+#include <sys/stat.h>
+
 #include "sedef_host.h"
 
 namespace sdfh {
@@ -113,6 +116,12 @@ class GpuProvider : public DpProvider {
     ready();
     for (auto &t : spare_threads_)
       if (t.joinable()) t.join();
+    {  // (the spare lanes' device contexts side by side: a context takes 30-40 ms to give back)
+      std::vector<std::thread> gone;
+      for (auto &e : spares_)
+        if (e) gone.emplace_back([&e] { e.reset(); });
+      for (auto &t : gone) t.join();
+    }
     spares_.clear();
     sdf_destroy(ctx_);
   }
@@ -153,6 +162,22 @@ class GpuProvider : public DpProvider {
       }
     }
     return std::unique_ptr<DpProvider>(new GpuProvider(want, 0, std::vector<int>(), 0, 3));
+  }
+  void give_back(std::unique_ptr<DpProvider> p) override {
+    GpuProvider *g = dynamic_cast<GpuProvider *>(p.get());
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(spare_mu_);
+    for (size_t i = 0; i < spares_.size(); i++)
+      if (spare_taken_.count(i) && !spares_[i] && spare_dev_[i] == g->device_) {
+        p.release();
+        spares_[i].reset(g);
+        spare_taken_.erase(i);
+        return;
+      }
+    p.release();  // (made by clone() beyond the spares the provider started with: one more place)
+    spares_.emplace_back(g);
+    spare_dev_.push_back(g->device_);
+    spare_threads_.emplace_back();
   }
   // Buffers sized once per lane (include/sedef_hip.h: sdf_reserve), on a thread of its own.  The bounds follow the stage's
   // rounds as measured: a task per ~250 bytes of a super-batch's sequences at most (chr1-sized run: 708,600 tasks of
@@ -944,6 +969,11 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     max_batch_bytes = std::max(max_batch_bytes, bytes);
   }
   dp0.prepare((size_t)max_batch_bytes);
+  auto zero_counters = [](DpProvider &d) {  // (a provider serves bucket after bucket of one process: the figures below are this run's)
+    d.tasks = d.cells = 0;
+    d.t_pack = d.t_call = d.t_unpack = 0;
+  };
+  zero_counters(dp0);
 
   std::mutex cleanup_mu;
   std::vector<std::thread> cleanup;
@@ -1149,6 +1179,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
           prov[(size_t)l] = extra[(size_t)l].get();
           mark(-2 - l, "lane's device context ready");
           if (!prov[(size_t)l]) return;
+          zero_counters(*prov[(size_t)l]);
           prov[(size_t)l]->prepare((size_t)max_batch_bytes);
         }
         std::vector<std::string> lines;
@@ -1215,13 +1246,86 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
                "%.2fs, all jobs %.2fs thread time), request collection %.2fs, output %.2fs; DP provider: request "
                "packing %.2fs, device call %.2fs, CIGAR unpacking %.2fs]\n",
           a.t_fetch, a.t_adv, a.t_longest, a.t_sum, a.t_collect, a.t_out, t_pack, t_call, t_unpack);
-  {  // (the extra lanes' device contexts side by side: a context takes 30-40 ms to give back)
-    std::vector<std::thread> gone;
-    for (auto &e : extra)
-      if (e) gone.emplace_back([&e] { e.reset(); });
-    for (auto &t : gone) t.join();
-  }
+  // (the extra lanes' providers go back to the one they came from: the next bucket of this process takes them again, and the
+  // first provider gives all their device contexts back side by side when it goes)
+  for (auto &e : extra)
+    if (e) dp0.give_back(std::move(e));
   return st;
+}
+
+// ---- several buckets, one process --------------------------------------------------------------------------------
+std::vector<std::string> expand_buckets(const std::vector<std::string> &beds) {
+  std::vector<std::string> out;
+  for (const std::string &b : beds) {
+    struct stat sb;
+    if (stat(b.c_str(), &sb) == 0 && S_ISDIR(sb.st_mode)) {
+      // the bucket files `sedef align bucket` wrote there (src/align_main.cc:178: "bucket_{:04d}"), not the outputs next to them
+      std::vector<std::string> names;
+      if (DIR *d = opendir(b.c_str())) {
+        while (struct dirent *e = readdir(d)) {
+          const std::string n = e->d_name;
+          if (n.size() == 11 && n.compare(0, 7, "bucket_") == 0 && n.find_first_not_of("0123456789", 7) == std::string::npos)
+            names.push_back(n);
+        }
+        closedir(d);
+      }
+      std::sort(names.begin(), names.end());
+      for (auto &n : names) out.push_back(b + (b.empty() || b.back() == '/' ? "" : "/") + n);
+    } else {
+      out.push_back(b);
+    }
+  }
+  return out;
+}
+
+StageHint stage_hint_many(const std::vector<std::string> &beds, int super_batch) {
+  StageHint all;
+  all.pairs = 0;
+  for (const std::string &b : beds) {
+    const StageHint h = stage_hint(b, super_batch);
+    all.pairs += h.pairs;
+    if (h.lanes > all.lanes) {
+      all.lanes = h.lanes;
+      all.devices = h.devices;
+    }
+    all.super_batch = std::max(all.super_batch, h.super_batch);
+    all.max_batch_bytes = std::max(all.max_batch_bytes, h.max_batch_bytes);
+  }
+  return all;
+}
+
+std::vector<GenerateStats> generate_many(const std::string &ref_path, const std::vector<std::string> &beds, int kmer_size,
+                                         const Params &p, DpProvider &dp, const std::string &out_suffix,
+                                         const std::string &log_dir, FILE *log, int super_batch) {
+  std::vector<GenerateStats> all;
+  for (const std::string &bed : beds) {
+    const std::string out_path = bed + out_suffix;
+    FILE *out = fopen(out_path.c_str(), "w");
+    if (!out) throw std::string("Cannot open file ") + out_path + " for writing";
+    FILE *blog = nullptr;
+    if (!log_dir.empty()) {
+      const size_t slash = bed.find_last_of('/');
+      const std::string lp = log_dir + "/" + (slash == std::string::npos ? bed : bed.substr(slash + 1)) + ".log";
+      blog = fopen(lp.c_str(), "w");
+      if (!blog) {
+        fclose(out);
+        throw std::string("Cannot open file ") + lp + " for writing";
+      }
+    }
+    try {
+      all.push_back(generate_alignments(ref_path, bed, kmer_size, p, dp, out, blog ? blog : log, super_batch));
+    } catch (...) {
+      fclose(out);
+      if (blog) fclose(blog);
+      throw;
+    }
+    fclose(out);
+    if (blog) {
+      fclose(blog);
+      fprintf(log, "Finished BED %s (%d lines, generated %d hits)\n", bed.c_str(), all.back().lines, all.back().total_written);
+    }
+  }
+  return all;
 }
 
 }  // namespace sdfh

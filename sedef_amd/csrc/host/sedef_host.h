@@ -118,6 +118,10 @@ class DpProvider {
   // Optional: another provider of the same kind (own device context) for a second lane of the stage driver.
   // (device < 0: the same device as this one)
   virtual std::unique_ptr<DpProvider> clone(int /*device*/ = -1) { return nullptr; }
+  // ... and back again: a lane that is done with a clone()d provider returns it, so that the next run of the stage in this
+  // process (several buckets, one process: generate_many) takes it again instead of setting up another device context.
+  // The default lets it go.
+  virtual void give_back(std::unique_ptr<DpProvider> p) { p.reset(); }
   // Optional: the bytes of sequence the largest super-batch of the run holds, told before the provider's first call: a
   // provider with device and pinned buffers sizes them once, on a thread of its own, while the driver fetches sequences.
   virtual void prepare(size_t /*max_batch_bytes*/) {}
@@ -392,5 +396,16 @@ struct GenerateStats {
 // Reads the bucket BED, aligns every candidate pair, writes the BEDPE lines to `out` in the reference's order.
 GenerateStats generate_alignments(const std::string &ref_path, const std::string &bed_path, int kmer_size,
                                   const Params &p, DpProvider &dp, FILE *out, FILE *log, int super_batch = 8192);
+// Several buckets in ONE process (the reference runs one process per bucket file, sedef.sh:187-190, and pays nothing to
+// start one; a process of this build pays 0.5-0.8 s of HIP initialisation, device contexts and teardown around a stage of
+// 0.2 s): every bucket's lines go to `<bucket><out_suffix>` -- the file sedef.sh redirects that bucket's stdout to --, byte
+// for byte what a one-bucket run prints, and its "Finished BED" line to `log` and, with a log directory, to
+// `<log_dir>/<basename>.log` (sedef.sh:195 counts those).  The providers and their lanes are set up once.
+// `beds`: bucket files, or directories holding `bucket_????` files.  Returns one GenerateStats per bucket.
+std::vector<std::string> expand_buckets(const std::vector<std::string> &beds);
+StageHint stage_hint_many(const std::vector<std::string> &beds, int super_batch = 8192);
+std::vector<GenerateStats> generate_many(const std::string &ref_path, const std::vector<std::string> &beds, int kmer_size,
+                                         const Params &p, DpProvider &dp, const std::string &out_suffix,
+                                         const std::string &log_dir, FILE *log, int super_batch = 8192);
 
 }  // namespace sdfh

@@ -89,6 +89,8 @@ int main(int argc, char **argv) {
       fprintf(stderr,
               "sedef align generate -k [kmer] [genome.fa] [initial.bed]\n"
               "  generates true alignments for [initial.bed] (BEDPE on stdout)\n"
+              "sedef align generate -k [kmer] [--log-dir dir] [genome.fa] [bucket ... | bucket directory]\n"
+              "  several buckets in one process: bucket b's BEDPE goes to b.aligned.bed, its log to dir/b.log\n"
               "  params: -k/--kmer, --match, --mismatch, --gap-open, --gap-extend (default 5, -4, -40, -1)\n"
               "sedef align bucket -n [count] [bed_directory(/)] [buckets/] [genome.fa]\n"
               "  bucket BEDs into [count] files for the alignment stage (--extend-ratio, --max-extend, --merge-dist)\n"
@@ -111,10 +113,31 @@ int main(int argc, char **argv) {
         const auto t0 = std::chrono::steady_clock::now();
         // (the lanes of the stage driver and the size of its super-batches follow from the seed pairs: the lanes' device
         // contexts and buffers are set up side by side here, not one after the other inside the stage)
-        const StageHint hint = stage_hint(a.pos[2]);
+        // `generate genome.fa bucket`: the reference's form, BEDPE on stdout.  With several bucket files, or a directory of
+        // `bucket_????` files, ONE process aligns them all: bucket b's lines go to `b.aligned.bed` (where sedef.sh:189 redirects
+        // that bucket's stdout), its "Finished BED" line to stderr and, with --log-dir, to `<dir>/<bucket>.log` (sedef.sh:195
+        // counts them) -- device contexts, lanes and buffers set up once instead of once per bucket.
+        std::vector<std::string> given(a.pos.begin() + 2, a.pos.end());
+        const std::vector<std::string> buckets = expand_buckets(given);
+        const bool many = buckets.size() != 1 || buckets[0] != given[0];
+        std::string log_dir, suffix = ".aligned.bed";
+        for (auto &pr : a.params) {
+          if (pr.first == "log-dir") log_dir = pr.second;
+          if (pr.first == "out-suffix") suffix = pr.second;
+        }
+        if (buckets.empty()) throw std::string("No bucket files in ") + given[0];
+        const StageHint hint = many ? stage_hint_many(buckets) : stage_hint(a.pos[2]);
         auto dp = make_gpu_providers(dv ? atoi(dv) : 0, hint.lanes, hint.devices, hint.max_batch_bytes);
         const auto t1 = std::chrono::steady_clock::now();
-        generate_alignments(a.pos[1], a.pos[2], k, p, *dp, stdout, stderr);
+        if (many) {
+          const auto sts = generate_many(a.pos[1], buckets, k, p, *dp, suffix, log_dir, stderr);
+          long long lines = 0, hits = 0;
+          for (auto &x : sts) lines += x.lines, hits += x.total_written;
+          fprintf(stderr, "All %zu buckets done in %.2fs (%lld lines, generated %lld hits)\n", sts.size(),
+                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), lines, hits);
+        } else {
+          generate_alignments(a.pos[1], a.pos[2], k, p, *dp, stdout, stderr);
+        }
         const auto t2 = std::chrono::steady_clock::now();
         dp.reset();
         if (getenv("SDF_DEBUG_TIMING"))

@@ -81,6 +81,18 @@ def generate(ref_path, bed_path, kmer, out_path, match=5, mismatch=-4, gap_open=
     return tuple(int(x) for x in stats)
 
 
+def generate_many(ref_path, beds, kmer, out_suffix=".aligned.bed", log_dir=None, test_dp=None, device=0):
+    """Several buckets through ONE provider (csrc/host/pipeline.cc: generate_many): bucket b's lines go to b + out_suffix.
+    `beds`: bucket files or directories of bucket_???? files.  Returns [(lines, hits)] per bucket."""
+    lib = load_host()
+    stats = (C.c_longlong * 4096)()
+    lib.sdfh_generate_many.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
+    n = lib.sdfh_generate_many(ref_path.encode(), "\n".join(beds).encode(), kmer, out_suffix.encode(),
+                               log_dir.encode() if log_dir else None, test_dp, device, stats)
+    _err(lib, min(n, 0))
+    return [(int(stats[2 * k]), int(stats[2 * k + 1])) for k in range(n)]
+
+
 _buf = None
 
 

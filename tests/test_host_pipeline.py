@@ -280,6 +280,75 @@ def test_generate_stage_two_lanes_keep_schedule_order(host, oracle_dp, tmp_path,
     assert r.returncode == 0 and r.stdout == open(cpu).read() and "3 lane(s)" in r.stderr
 
 
+def _buckets(host, tmp_path, seed=9, nsd=10, nb=3):
+    fa = str(tmp_path / "genome.fa")
+    genome, beds = hostgen.make_genome(fa, seed=seed, glen=90000, nsd=nsd)
+    seeds = tmp_path / "seeds"
+    seeds.mkdir()
+    rng = np.random.default_rng(seed)
+    with open(seeds / "a.bed", "w") as f:
+        for (a, e, b, e2, rcf) in beds:
+            o = int(rng.integers(0, 200))
+            f.write("chrT\t%d\t%d\tchrT\t%d\t%d\t\t\t+\t%s\t%d\t0\t\tOK\n" % (
+                a + o, a + o + 900, b + o, b + o + 900, "-" if rcf else "+", 900))
+    out = tmp_path / "align"
+    out.mkdir()
+    host.bucket(str(seeds), nb, str(out), fa)
+    return fa, out, sorted(str(out / n) for n in os.listdir(out))
+
+
+def test_several_buckets_in_one_run_equal_one_bucket_runs(host, oracle_dp, tmp_path):
+    """generate_many: one provider, bucket after bucket -- every bucket's file is what its own run writes; the directory
+    form takes `bucket_????` files only (not the outputs next to them)."""
+    fa, out, buckets = _buckets(host, tmp_path)
+    assert len(buckets) == 3
+    want = []
+    for b in buckets:
+        host.generate(fa, b, 11, b + ".single", test_dp=oracle_dp)
+        want.append(open(b + ".single").read())
+    assert sum(len(w) for w in want) > 0
+    logs = tmp_path / "logs"
+    logs.mkdir()
+    st = host.generate_many(fa, buckets, 11, log_dir=str(logs), test_dp=oracle_dp)
+    assert [open(b + ".aligned.bed").read() for b in buckets] == want
+    assert [x[0] for x in st] == [sum(1 for _ in open(b)) for b in buckets]
+    assert sorted(os.listdir(logs)) == [os.path.basename(b) + ".log" for b in buckets]
+    assert all("Finished BED" in open(logs / n).read() for n in os.listdir(logs))
+    for b in buckets:
+        os.remove(b + ".aligned.bed")
+    st2 = host.generate_many(fa, [str(out)], 11, test_dp=oracle_dp)  # the directory: the three bucket files, in order
+    assert st2 == st and [open(b + ".aligned.bed").read() for b in buckets] == want
+
+
+@pytest.mark.gpu
+def test_cli_several_buckets_one_process_gpu(host, tmp_path):
+    """`sedef align generate -k 11 genome.fa bucket_0000 bucket_0001 ...` and `... genome.fa align/`: one process, lanes and
+    device contexts set up once; every b.aligned.bed byte-identical to `sedef align generate ... b > b.aligned.bed`."""
+    from sedef_amd.host import CLI
+    fa, out, buckets = _buckets(host, tmp_path, seed=12, nsd=14, nb=4)
+    env = dict(os.environ)
+    env.pop("SDF_DEVICES", None)
+    want = []
+    for b in buckets:
+        r = subprocess.run([CLI, "align", "generate", "-k", "11", fa, b], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and "Finished BED" in r.stderr
+        want.append(r.stdout)
+    assert sum(len(w) for w in want) > 0
+    logs = tmp_path / "logs"
+    logs.mkdir()
+    for args, e in ((buckets, env), ([str(out)], dict(env, SDF_LANES="3", SDF_SUPER_BATCH="2"))):
+        for b in buckets:
+            if os.path.exists(b + ".aligned.bed"):
+                os.remove(b + ".aligned.bed")
+        r = subprocess.run([CLI, "align", "generate", "-k", "11", "--log-dir", str(logs), fa] + args, capture_output=True,
+                           text=True, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout == ""
+        assert [open(b + ".aligned.bed").read() for b in buckets] == want
+        assert r.stderr.count("Finished BED") == len(buckets) and "All 4 buckets done" in r.stderr
+        assert sum("Finished" in open(logs / n).read() for n in os.listdir(logs)) == len(buckets)  # (sedef.sh:195)
+
+
 @pytest.mark.gpu
 def test_alignment_golden_on_gpu(host, host_golden):
     for c in host_golden["pairs"]:
