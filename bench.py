@@ -710,22 +710,14 @@ def main():
         alg = algorithmic_bytes(qlen, tlen, cells_task, res["n_cigar"])
         # Roofline of the dominant kernel.  The timed steps above run the batch as a pipeline of chunks whose DP
         # launches overlap each other and the traceback, so a launch's own duration is taken from one extra,
-        # untimed pass of the same batch through a context created with SDF_PIPELINE=0: the whole batch in ONE
+        # untimed pass of the same batch through a context created with pipeline = 0 (sdf_config): the whole batch in ONE
         # DP launch on one stream, HIP events around it on that stream (sdf_last_ms(0)).  The committed rocprofv3
         # summary (profiles/) is of `SDF_PIPELINE=0 python bench.py ...`, the same launch.
         iso_ms, iso_launches = dp_ms / max(args.steps, 1), max(launches // max(args.steps, 1), 1)
         roof_mode = "pipelined launches (union of the DP intervals)"
         headline = world == 1 and not hg19
         if headline:
-            old = os.environ.get("SDF_PIPELINE")
-            os.environ["SDF_PIPELINE"] = "0"
-            try:
-                iso = sedef_amd.Extz2Engine(local, int(args.workspace_gib * (1 << 30)))
-            finally:
-                if old is None:
-                    del os.environ["SDF_PIPELINE"]
-                else:
-                    os.environ["SDF_PIPELINE"] = old
+            iso = sedef_amd.Extz2Engine(local, int(args.workspace_gib * (1 << 30)), config=dict(SDF_PIPELINE=0))
             for _ in range(2):  # warm-up + measured
                 iso.align_batch_device(tasks, d_pool.data_ptr(), d_outs[0].data_ptr(), d_cigs[0].data_ptr(), cig_cap,
                                        want=want, stream=estream.cuda_stream)

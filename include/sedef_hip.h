@@ -114,6 +114,44 @@ int sdf_device_count(void);
  * (sdf_last_error(NULL) has the reason). */
 sdf_ctx *sdf_create(int device, size_t workspace_bytes);
 void sdf_destroy(sdf_ctx *ctx);
+
+/* ---- configuration -------------------------------------------------------------------------------------------------
+ * Every tunable and test switch of the library in ONE struct.  sdf_create() fills it from the SDF_* environment variables,
+ * once, when the context is made (an unknown value or one out of range makes sdf_create fail with the reason);
+ * sdf_create_cfg() takes it from the caller instead -- tests force a kernel through sdf_config_set(&cfg, "SDF_NO_PAIR",
+ * "1", ...) and never touch the environment.  A context's settings do not change after it is made; the contexts it
+ * creates for itself (the first part of a split batch, the re-run of tasks a stripe kernel gave up) inherit them.
+ * Fields are int64_t (0 / 1 for switches) except workspace_gib; sdf_config_describe() lists name, environment
+ * variable, default and meaning of each, sdf_config_dump() the values of one struct (SDF_DEBUG_PLAN=1 prints that for
+ * every context made). */
+typedef struct sdf_config {
+  uint32_t size; /* sizeof(sdf_config), set by sdf_config_default / sdf_config_from_env */
+  uint32_t reserved;
+  /* which kernel serves a task */
+  int64_t force_general, no_pair, no_mixed, mixed_min, self_pair_max;
+  int64_t no_stripe, stripe_min, stripe_nreg, stripe_claim, stripe_spin_cap;
+  int64_t bstripe_min_rows, bstripe_nreg, bstripe_all;
+  int64_t no_strip, strip_always, strip_cols, chain_min;
+  int64_t no_lane, lane_min, lane_plan_sort, lane_prio;
+  /* how a batch is cut and planned */
+  int64_t pipeline, cut_chunks, heavy_bytes, early_heavy, split_min, split_div;
+  int64_t plan_threads, plan_pool_from, scan_pool_from, pool_spin_us;
+  double workspace_gib;
+  /* other entry points */
+  int64_t chain_threads_only, stats_items, stats_group_max;
+  /* diagnostics on stderr */
+  int64_t debug_plan, debug_timing, debug_classes, debug_plan_early;
+} sdf_config;
+void sdf_config_default(sdf_config *cfg);
+/* defaults, then every SDF_* variable that is set; SDF_ERR_INVALID + message for a value that is not a number or out of range */
+int sdf_config_from_env(sdf_config *cfg, char *err, size_t errcap);
+/* one setting by its environment variable's or its field's name */
+int sdf_config_set(sdf_config *cfg, const char *name, const char *value, char *err, size_t errcap);
+size_t sdf_config_dump(const sdf_config *cfg, char *buf, size_t cap); /* "NAME=value" lines; returns the bytes needed */
+size_t sdf_config_describe(char *buf, size_t cap);                    /* every setting: variable, field, default, meaning */
+/* sdf_create with the caller's settings (cfg == NULL: sdf_config_from_env, which is what sdf_create does) */
+sdf_ctx *sdf_create_cfg(int device, size_t workspace_bytes, const sdf_config *cfg);
+const sdf_config *sdf_get_config(const sdf_ctx *ctx);
 /* Sizes the context's buffers ONCE for host-buffer batch calls of up to max_tasks tasks whose sequences add up to
  * max_bases bases: the pinned staging (task plan, launch order, packed sequences, results), the device copies of
  * those, the CIGAR staging and the streams of the call's pipeline -- no call within the bounds allocates, pins or sets

@@ -14,6 +14,7 @@ namespace sdfh { void set_alignment_scoring(const Params &p); }
 static thread_local std::string g_err;
 
 static std::unique_ptr<DpProvider> provider(test_dp_fn fn, int device) {
+  set_stage_settings(StageSettings::from_env());  // (every run of an entry point: the stage driver's settings, read here once)
   if (fn) return make_test_provider(fn);
   return make_gpu_provider(device);
 }

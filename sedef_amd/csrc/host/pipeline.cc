@@ -132,8 +132,8 @@ class GpuProvider : public DpProvider {
   // 0.3 ms or 1.8-4.0 s, 8 GiB 0.3 ms in every sample; inside a stage run: a 23 GiB request 0.4 or 580 ms) -- and a run of
   // `sedef align` is one such process per bucket, one after the other.
   static size_t stage_workspace(int lanes) {
-    const char *e = getenv("SDF_STAGE_WS_GIB");
-    const double gib = e && atof(e) > 0 ? atof(e) : std::max(2.0, 8.0 / std::max(lanes, 1));
+    const double asked = stage_settings().stage_ws_gib;
+    const double gib = asked > 0 ? asked : std::max(2.0, 8.0 / std::max(lanes, 1));
     return (size_t)(gib * 1073741824.0);
   }
   // Spare providers for the other lanes, each created on a thread of its own (make_gpu_providers)
@@ -194,7 +194,7 @@ class GpuProvider : public DpProvider {
     const size_t tasks = max_batch_bytes / 250 + 65536, bases = max_batch_bytes / 6 + (1u << 20);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = sdf_reserve(ctx_, tasks, bases, ws_, SDF_RESERVE_BRIEF | SDF_RESERVE_ANCHORS | (lanes_ > 1 ? SDF_RESERVE_FEW_STREAMS : 0u));
-    if (getenv("SDF_DEBUG_TIMING"))
+    if (stage_settings().debug_timing)
       fprintf(stderr, "[sdf_reserve tasks %zu bases %zu: rc %d, %.1f ms]\n", tasks, bases, rc,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
@@ -284,11 +284,7 @@ class GpuProvider : public DpProvider {
 
   // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
   bool anchors(const std::vector<AnchorJob> &jobs, int kmer, AnchorBatch &out) override {
-    static const bool enabled = [] {
-      const char *e = getenv("SDF_GPU_ANCHORS");
-      return !(e && e[0] == '0');
-    }();
-    if (!enabled || jobs.empty()) return false;
+    if (!stage_settings().gpu_anchors || jobs.empty()) return false;
     ready();  // (a reserve still running on its thread uses the context: its warm-up call, its pinning next to this upload)
     // what the device kernels do not cover goes to the host's generate_anchors -- said once, not silently
     auto host_instead = [](const char *why) {
@@ -407,7 +403,7 @@ std::unique_ptr<DpProvider> make_gpu_providers(int device, int lanes, const std:
 
 static int stage_super_batch(int total, int nlanes, int super_batch) {
   if (nlanes > 1) super_batch = std::max(1024, std::min(super_batch, (total + 2 * nlanes - 1) / (2 * nlanes)));
-  if (const char *sb = getenv("SDF_SUPER_BATCH")) super_batch = std::max(1, atoi(sb));
+  if (stage_settings().super_batch > 0) super_batch = stage_settings().super_batch;
   return super_batch;
 }
 
@@ -448,18 +444,9 @@ int stage_lane_count(int total, std::vector<int> *devices) {
   int nlanes = total >= 12288 ? 3 : total >= 4096 ? 2 : 1;
   // SDF_DEVICES=0,1,...: the lanes after the first go round-robin over these devices (one node, several GPUs; the
   // first lane stays on the provider's own device, which should be the first of the list); at least one lane each
-  std::vector<int> dv;
-  if (const char *e = getenv("SDF_DEVICES")) {
-    for (const char *c = e; *c;) {
-      char *end = nullptr;
-      const long d = strtol(c, &end, 10);
-      if (end == c) break;
-      dv.push_back((int)d);
-      c = *end == ',' ? end + 1 : end;
-    }
-    if (dv.size() > 1) nlanes = std::max<int>(nlanes, (int)std::min<size_t>(dv.size(), 8));
-  }
-  if (const char *e = getenv("SDF_LANES")) nlanes = std::max(1, std::min(8, atoi(e)));
+  const std::vector<int> &dv = stage_settings().devices;
+  if (dv.size() > 1) nlanes = std::max<int>(nlanes, (int)std::min<size_t>(dv.size(), 8));
+  if (stage_settings().lanes > 0) nlanes = std::max(1, std::min(8, stage_settings().lanes));
   if (devices) *devices = dv;
   return nlanes;
 }
@@ -784,11 +771,49 @@ void PairJob::finish_paths() {  // acceptance replay: src/refine.cc:143-162,184-
 // ======================================================================================================
 // The per-pair host work (anchors, chaining, refinement, CIGAR algebra) is independent across pairs: run it on
 // all host cores (SDF_HOST_THREADS overrides).  The reference runs one single-threaded process per bucket.
+StageSettings StageSettings::from_env() {
+  StageSettings s;
+  auto num = [](const char *name, long lo, long hi, long dflt) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end) throw std::string(name) + "=" + e + ": not a number";
+    if (v < lo || v > hi) throw std::string(name) + "=" + e + ": out of range";
+    return v;
+  };
+  s.device = (int)num("SDF_DEVICE", 0, 1023, 0);
+  s.lanes = (int)num("SDF_LANES", 0, 8, 0);
+  s.super_batch = (int)num("SDF_SUPER_BATCH", 0, 1 << 30, 0);
+  s.gpu_anchors = num("SDF_GPU_ANCHORS", 0, 1, 1) != 0;
+  s.host_threads = (int)num("SDF_HOST_THREADS", 0, 4096, 0);
+  if (const char *e = getenv("SDF_STAGE_WS_GIB")) s.stage_ws_gib = atof(e) > 0 ? atof(e) : 0;
+  s.debug_timing = getenv("SDF_DEBUG_TIMING") != nullptr;
+  if (const char *e = getenv("SDF_DEVICES"))
+    for (const char *c = e; *c;) {
+      char *end = nullptr;
+      const long d = strtol(c, &end, 10);
+      if (end == c) throw std::string("SDF_DEVICES=") + e + ": a list of device ordinals";
+      s.devices.push_back((int)d);
+      c = *end == ',' ? end + 1 : end;
+    }
+  return s;
+}
+namespace {
+StageSettings g_stage_settings;
+std::mutex g_stage_settings_mu;
+}  // namespace
+const StageSettings &stage_settings() { return g_stage_settings; }
+void set_stage_settings(const StageSettings &s) {
+  std::lock_guard<std::mutex> g(g_stage_settings_mu);
+  g_stage_settings = s;
+}
+
 static void parallel_for(int n, const std::function<void(int)> &body) {
-  static int nthreads = [] {
-    const char *e = getenv("SDF_HOST_THREADS");
-    int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-    if (!e) {  // a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") counts, not the host's core count
+  const int nthreads = [] {
+    const int asked = stage_settings().host_threads;
+    int t = asked > 0 ? asked : (int)std::thread::hardware_concurrency();
+    if (asked <= 0) {  // a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>") counts, not the host's core count
       if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
         long long quota = 0, period = 0;
         if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
@@ -930,7 +955,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   g_us_chain = 0;
   g_us_rest = 0;
   // SDF_DEBUG_TIMING: one line per phase of every super-batch, milliseconds since the stage clock started
-  static const bool dbg_tl = getenv("SDF_DEBUG_TIMING") != nullptr;
+  const bool dbg_tl = stage_settings().debug_timing;
   auto mark = [&](int base, const char *what) {
     if (dbg_tl) fprintf(stderr, "[stage %7.1f ms] batch@%d %s\n", since(t0) * 1e3, base, what);
   };

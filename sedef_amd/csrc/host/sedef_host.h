@@ -387,6 +387,24 @@ std::vector<std::vector<std::string>> generate_translation(const std::string &re
 void bucket_alignments_extern(const std::string &bed_path, int nbins, const std::string &output_dir, bool extend,
                               const std::string &reference, const BucketParams &bp, FILE *log);
 
+// ---- the stage driver's own settings ---------------------------------------------------------------------
+// (the DP library's are include/sedef_hip.h: sdf_config).  Read from the environment in ONE place -- StageSettings::from_env,
+// called at the start of every run of the stage (the CLI, the sdfh_* entry points) -- and kept for that run; nothing else in
+// the host code calls getenv for a setting.
+struct StageSettings {
+  int device = 0;            // SDF_DEVICE: the first lane's GPU
+  int lanes = 0;             // SDF_LANES: super-batches in flight, each on a device context of its own (0: by the number of pairs)
+  std::vector<int> devices;  // SDF_DEVICES=0,1,...: the GPUs the lanes after the first go round-robin over
+  int super_batch = 0;       // SDF_SUPER_BATCH: candidate pairs per super-batch (0: by the number of pairs and lanes)
+  bool gpu_anchors = true;   // SDF_GPU_ANCHORS=0: generate_anchors on the host threads
+  int host_threads = 0;      // SDF_HOST_THREADS: threads of the per-pair host work (0: the CPUs the process may use, at most 64)
+  double stage_ws_gib = 0;   // SDF_STAGE_WS_GIB: direction-flag workspace per lane (0: 8 GiB per process shared out)
+  bool debug_timing = false; // SDF_DEBUG_TIMING: one line per phase of every super-batch
+  static StageSettings from_env();
+};
+const StageSettings &stage_settings();             // the current run's
+void set_stage_settings(const StageSettings &s);  // (the entry points: from_env(); tests may hand over their own)
+
 // ---- stage driver (reference: src/align_main.cc:200-337) ---------------------------------------------
 struct GenerateStats {
   int lines = 0, total_written = 0;

@@ -85,6 +85,7 @@ int main(int argc, char **argv) {
     return 1;
   }
   try {
+    set_stage_settings(StageSettings::from_env());  // (SDF_LANES, SDF_DEVICES, SDF_SUPER_BATCH, ...: read here, once; sedef_host.h)
     if (command == "help") {
       fprintf(stderr,
               "sedef align generate -k [kmer] [genome.fa] [initial.bed]\n"
@@ -109,7 +110,7 @@ int main(int argc, char **argv) {
       if (a.pos[0] == "generate") {
         int k;
         if (!a.get({"k", "kmer"}, k)) throw std::string("Must provide k-mer size (--kmer)");
-        const char *dv = getenv("SDF_DEVICE");
+        const int dv = stage_settings().device;
         const auto t0 = std::chrono::steady_clock::now();
         // (the lanes of the stage driver and the size of its super-batches follow from the seed pairs: the lanes' device
         // contexts and buffers are set up side by side here, not one after the other inside the stage)
@@ -127,7 +128,7 @@ int main(int argc, char **argv) {
         }
         if (buckets.empty()) throw std::string("No bucket files in ") + given[0];
         const StageHint hint = many ? stage_hint_many(buckets) : stage_hint(a.pos[2]);
-        auto dp = make_gpu_providers(dv ? atoi(dv) : 0, hint.lanes, hint.devices, hint.max_batch_bytes);
+        auto dp = make_gpu_providers(dv, hint.lanes, hint.devices, hint.max_batch_bytes);
         const auto t1 = std::chrono::steady_clock::now();
         if (many) {
           const auto sts = generate_many(a.pos[1], buckets, k, p, *dp, suffix, log_dir, stderr);
@@ -140,7 +141,7 @@ int main(int argc, char **argv) {
         }
         const auto t2 = std::chrono::steady_clock::now();
         dp.reset();
-        if (getenv("SDF_DEBUG_TIMING"))
+        if (stage_settings().debug_timing)
           fprintf(stderr, "  [process: device context %.2fs, stage %.2fs, context teardown %.2fs]\n",
                   std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(),
                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count());
@@ -167,9 +168,8 @@ int main(int argc, char **argv) {
       a.getd({"max-error"}, sp.max_scaled_error);
       if (a.pos.size() < 3) throw std::string("Not enough arguments to stats");
       if (a.pos[0] != "generate") throw std::string("Unknown stats command");
-      const char *dv = getenv("SDF_DEVICE");
       long long st[3] = {0, 0, 0};
-      const long lines = stats_generate(a.pos[1], a.pos[2], stdout, sp, nullptr, dv ? atoi(dv) : 0, st);
+      const long lines = stats_generate(a.pos[1], a.pos[2], stdout, sp, nullptr, stage_settings().device, st);
       fprintf(stderr, "Processed hit %lld out of %lld... done! (%lld pieces, %lld columns on the device, %ld lines)\n", st[0], st[0],
               st[1], st[2], lines);
     } else {

@@ -49,7 +49,50 @@ int usable_cpus() {
 }
 }  // namespace
 
-extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
+// the context's fields the planner and the launcher read, from its configuration (one place; the context's settings do
+// not change afterwards)
+static void apply_config(sdf_ctx *ctx) {
+  const sdf_config &c = ctx->cfg;
+  ctx->force_general = c.force_general != 0;
+  ctx->no_pair = c.no_pair != 0;
+  ctx->no_mixed = c.no_mixed != 0;
+  ctx->mixed_min = (size_t)c.mixed_min;
+  ctx->stripe_claim = c.stripe_claim != 0;
+  ctx->chain_min = (size_t)c.chain_min;
+  ctx->self_pair_max = (size_t)c.self_pair_max;
+  ctx->stats_items = (unsigned)c.stats_items;
+  ctx->no_stripe = c.no_stripe != 0;
+  ctx->stripe_min = (int)c.stripe_min;
+  ctx->bstripe_min_rows = (int)c.bstripe_min_rows;
+  ctx->stripe_spin_cap = (int)c.stripe_spin_cap;
+  ctx->strip_enabled = c.no_strip == 0;
+  ctx->strip_always = c.strip_always != 0;
+  ctx->strip_cols = (int)c.strip_cols;
+  ctx->lane_enabled = c.no_lane == 0;
+  ctx->lane_min = (size_t)c.lane_min;
+  ctx->pipeline = c.pipeline != 0;
+  if (c.debug_timing) g_debug_timing.store(true, std::memory_order_relaxed);
+}
+
+extern "C" const sdf_config *sdf_get_config(const sdf_ctx *ctx) { return ctx ? &ctx->cfg : nullptr; }
+
+extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) { return sdf_create_cfg(device, workspace_bytes, nullptr); }
+
+extern "C" sdf_ctx *sdf_create_cfg(int device, size_t workspace_bytes, const sdf_config *cfg_in) {
+  sdf_config cfg;
+  if (cfg_in) {
+    if (cfg_in->size != sizeof(sdf_config)) {
+      g_err = "sdf_create_cfg: the configuration was not initialised by sdf_config_default / sdf_config_from_env (size field)";
+      return nullptr;
+    }
+    cfg = *cfg_in;
+  } else {
+    char why[256];
+    if (sdf_config_from_env(&cfg, why, sizeof why) != SDF_OK) {  // (a typo in an SDF_* variable is an error, not a silent default)
+      g_err = std::string("environment: ") + why;
+      return nullptr;
+    }
+  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
@@ -67,13 +110,20 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   const auto t_create = std::chrono::steady_clock::now();
   sdf_ctx *ctx = new sdf_ctx();
   ctx->device = device;
+  ctx->cfg = cfg;
+  apply_config(ctx);
+  if (cfg.debug_plan) {
+    std::string dump(sdf_config_dump(&cfg, nullptr, 0), '\0');
+    sdf_config_dump(&cfg, &dump[0], dump.size());
+    fprintf(stderr, "[sdf_create device %d: configuration]\n%s", device, dump.c_str());
+  }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     g_err = "hipStreamCreate failed";
     delete ctx;
     return nullptr;
   }
   auto lap = [&](const char *what) {
-    if (getenv("SDF_DEBUG_TIMING"))
+    if (cfg.debug_timing)
       fprintf(stderr, "[sdf_create %s at %.1f ms]\n", what,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
   };
@@ -82,8 +132,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   (void)hipMemGetInfo(&free_b, &total_b);
   lap("mem info");
   size_t budget = workspace_bytes ? workspace_bytes : (size_t)64 << 30;
-  if (const char *e = getenv("SDF_WORKSPACE_GIB"))  // (overrides the caller's figure: experiments with the stage driver)
-    if (atof(e) > 0) budget = (size_t)(atof(e) * 1073741824.0);
+  if (cfg.workspace_gib > 0) budget = (size_t)(cfg.workspace_gib * 1073741824.0);  // (overrides the caller's figure: experiments with the stage driver)
   if (free_b && budget > free_b / 2) budget = free_b / 2;
   ctx->ws_budget = budget;
   // allow the general kernel its full 160 KiB of LDS
@@ -141,16 +190,6 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
                         reinterpret_cast<const void *>(&extz2_pair_mixed_kernel<9>)})
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipGetLastError();
-  const char *fg = getenv("SDF_FORCE_GENERAL");
-  ctx->force_general = fg && fg[0] == '1';
-  const char *np = getenv("SDF_NO_PAIR");
-  ctx->no_pair = np && np[0] == '1';
-  if (const char *e = getenv("SDF_NO_MIXED")) ctx->no_mixed = e[0] == '1';
-  if (const char *e = getenv("SDF_MIXED_MIN")) ctx->mixed_min = (size_t)std::max(0ll, atoll(e));
-  if (const char *e = getenv("SDF_STRIPE_CLAIM")) ctx->stripe_claim = e[0] != '0';  // (0: stripe workgroups take entry blockIdx.x)
-  if (const char *e = getenv("SDF_CHAIN_MIN")) ctx->chain_min = (size_t)std::max(0ll, atoll(e));
-  if (const char *e = getenv("SDF_SELF_PAIR_MAX")) ctx->self_pair_max = (size_t)std::max(0ll, atoll(e));
-  if (const char *e = getenv("SDF_STATS_ITEMS")) ctx->stats_items = (unsigned)std::max(1, atoi(e));  // (tests: a list that overflows)
   for (const void *f : {reinterpret_cast<const void *>(&extz2_stripe_kernel<1>),
                         reinterpret_cast<const void *>(&extz2_stripe_kernel<2>),
                         reinterpret_cast<const void *>(&extz2_stripe_kernel<4>),
@@ -159,21 +198,8 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
                         reinterpret_cast<const void *>(&extz2_bstripe_kernel<4>)})
     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want_lds);
   (void)hipGetLastError();
-  const char *ns = getenv("SDF_NO_STRIPE");
-  ctx->no_stripe = ns && ns[0] == '1';
-  if (const char *sm = getenv("SDF_STRIPE_MIN")) ctx->stripe_min = std::max(128, atoi(sm));
-  if (const char *bm = getenv("SDF_BSTRIPE_MIN_ROWS")) ctx->bstripe_min_rows = std::max(0, atoi(bm));
-  if (const char *cp = getenv("SDF_STRIPE_SPIN_CAP")) ctx->stripe_spin_cap = std::max(1, atoi(cp));
-  const char *nsp = getenv("SDF_NO_STRIP");
-  ctx->strip_enabled = !(nsp && nsp[0] == '1');
-  const char *sa = getenv("SDF_STRIP_ALWAYS");
-  ctx->strip_always = sa && sa[0] == '1';
-  if (const char *scl = getenv("SDF_STRIP_COLS")) ctx->strip_cols = atoi(scl);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             want_lds);
-  const char *nl = getenv("SDF_NO_LANE");
-  ctx->lane_enabled = !(nl && nl[0] == '1');
-  if (const char *lm = getenv("SDF_LANE_MIN")) ctx->lane_min = (size_t)std::max(1, atoi(lm));
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&extz2_lane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             want_lds);
   // (per context, hence per device: a process-wide once-flag would leave a second GPU's copy of the kernel at 64 KiB)
@@ -181,8 +207,6 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
                             std::max(ctx->max_dyn_lds, 65536));
   (void)hipGetLastError();
   lap("attributes");
-  const char *pl = getenv("SDF_PIPELINE");
-  ctx->pipeline = !(pl && pl[0] == '0');
   if (hipStreamCreateWithFlags(&ctx->dp_stream[0], hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->dp_stream[1], hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->tb_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -193,7 +217,7 @@ extern "C" sdf_ctx *sdf_create(int device, size_t workspace_bytes) {
   // queues, and two of ours landing on one queue serialises what the pipeline wants side by side; with the
   // caller's stream that makes four)
   g_live_contexts.fetch_add(1);
-  if (getenv("SDF_DEBUG_TIMING"))
+  if (cfg.debug_timing)
     fprintf(stderr, "[sdf_create device %d: %.1f ms]\n", device,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count());
   return ctx;
@@ -422,6 +446,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
 
   // ---- validate, cut into chunks ----
   PlanEnv env;
+  env.cfg = &ctx->cfg;
   env.tasks = tasks;
   env.n = n;
   env.want = want;
@@ -467,10 +492,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     // Planning threads of a context: SDF_PLAN_THREADS, else every CPU the process may use but this thread's when the
     // context is the only one of the process (the scan of a million tasks is CPU-bound: 1.7 ms on eight threads, 0.86 ms on
     // sixteen), seven when there are several (the stage driver's lanes share the machine).
-    static const int env_planners = [] {
-      const char *e = getenv("SDF_PLAN_THREADS");
-      return e ? std::max(0, std::min(15, atoi(e))) : -1;
-    }();
+    const int env_planners = (int)ctx->cfg.plan_threads;  // (-1: by the CPUs)
     // (one process per GPU: the ranks of a node share its CPUs -- LOCAL_WORLD_SIZE / WORLD_SIZE as torch.distributed sets them)
     static const int local_ranks = [] {
       const char *e = getenv("LOCAL_WORLD_SIZE");
@@ -483,14 +505,11 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     const int max_planners = env_planners >= 0 ? env_planners : g_live_contexts.load() > 1 ? std::min(7, share) : share;
     // (parked threads plan the chunks of batches of 120,000 tasks and more -- 250,000 tasks of the hg19 mixture:
     // 14.5 -> 10.1 ms, the headline batch unchanged -- and scan the cut as well: sdf_plan.hip, scan_from)
-    static const size_t pool_from = [] {
-      const char *e = getenv("SDF_PLAN_POOL_FROM");
-      return e ? (size_t)atoll(e) : (size_t)120000;
-    }();
-    if (!ctx->pool && n >= pool_from && max_planners > 0 && !ctx->is_part) ctx->pool = new WorkerPool(max_planners);
+    const size_t pool_from = (size_t)ctx->cfg.plan_pool_from;
+    if (!ctx->pool && n >= pool_from && max_planners > 0 && !ctx->is_part) ctx->pool = new WorkerPool(max_planners, (int)ctx->cfg.pool_spin_us);
   }
   run.cut = &cut;
-  static const bool dbg_plan_chunks = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const bool dbg_plan_chunks = ctx->cfg.debug_plan != 0;
 
   // ---- buffers and the start of the call on the device: once with upper bounds, before the early start of the heavy
   // chunks (while the batch is still being read), and / or with the cut's sums ----
@@ -569,10 +588,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   };
   {
     const char *msg = nullptr;
-    static const bool early_on = [] {
-      const char *e = getenv("SDF_EARLY_HEAVY");  // (0: the heavy chunks wait for the whole cut, as every other chunk)
-      return !(e && e[0] == '0');
-    }();
+    const bool early_on = ctx->cfg.early_heavy != 0;  // (0: the heavy chunks wait for the whole cut, as every other chunk)
     const int crc = cut_batch(env, ctx->pipeline, ctx->ws_budget, cut, &msg, ctx->pool, early_on && !ctx->is_part ? &early : nullptr);
     run.more_chunks = false;
     if (crc) {
@@ -625,8 +641,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     drain_streams(ctx, st);
     return rc;
   }
-  static const bool dbg_plan = getenv("SDF_DEBUG_PLAN") != nullptr;
-  if (dbg_plan)
+  if (ctx->cfg.debug_plan)
     fprintf(stderr, "[plan: n=%zu cut %.2f ms, buffers %.2f ms, planner up %.2f ms, first chunk planned %.2f ms, all launched %.2f ms; chunks %zu heavy %zu]\n", n,
             dbg_a, dbg_b, dbg_c, ctx->ms[4], host_ms(), cut.chunks.size(), cut.n_heavy);
   return SDF_OK;
@@ -648,7 +663,7 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   }
   SDF_HIP(hipSetDevice(ctx->device));
   hipStream_t st = stream_ ? (hipStream_t)stream_ : ctx->stream;
-  static const bool dbg_plan_chunks = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const bool dbg_plan_chunks = ctx->cfg.debug_plan != 0;
   // SDF_SPLIT_MIN=<tasks>: a batch of that many tasks or more starts in two parts.  Everything the GPU waits for before
   // its first launch is a pass over the caller's task array (40 bytes per task: 1.6-3 ms for a million tasks on eight
   // threads); the first part -- an eighth of the tasks (SDF_SPLIT_DIV) -- is cut, planned and launched on a second context
@@ -660,14 +675,8 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   // start that way with a first part of 8,192 tasks: their cut is a pass on ONE thread (1 ms for the 100,000 tasks of the headline batch) that the
   // first launch no longer waits for -- 1,110 against 1,088-1,090 Gcell/s, three runs each on one box.  Larger batches
   // start their heavy chunks early instead (cut_batch's two passes); SDF_SPLIT_MIN=0 turns the split off.
-  static const long long split_env = [] {
-    const char *e = getenv("SDF_SPLIT_MIN");
-    return e ? atoll(e) : -1ll;  // (-1: the default rule; 0: off)
-  }();
-  static const int split_div = [] {
-    const char *e = getenv("SDF_SPLIT_DIV");
-    return e ? std::max(2, atoi(e)) : 8;
-  }();
+  const long long split_env = (long long)ctx->cfg.split_min;  // (-1: the default rule; 0: off)
+  const int split_div = (int)ctx->cfg.split_div;
   // (only batches of tasks of one size, none of them long or small, by a sample of 256: 8,192 of them must keep the device
   // busy for the millisecond the cut of the rest takes, and a second context's streams next to the many small launches of a
   // batch of mixed lengths cost more than the early start brings -- mm8-like mixed bands, 100,000 tasks: 585 ms against 441;
@@ -693,22 +702,11 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   size_t n_first = 0;
   if (ctx->pipeline && (split_default || split_asked) && !ctx->is_part) {
     if (!ctx->part_ctx) {
-      ctx->part_ctx = sdf_create(ctx->device, ctx->ws_budget / 4);
-      if (ctx->part_ctx) {
-        mark_internal_context(ctx->part_ctx);  // (a part context is not another user of the process's CPUs)
-        ctx->part_ctx->force_general = ctx->force_general;
-        ctx->part_ctx->no_pair = ctx->no_pair;
-        ctx->part_ctx->self_pair_max = ctx->self_pair_max;
-        ctx->part_ctx->no_mixed = ctx->no_mixed;
-        ctx->part_ctx->mixed_min = ctx->mixed_min;
-        ctx->part_ctx->no_stripe = ctx->no_stripe;
-        ctx->part_ctx->lane_enabled = ctx->lane_enabled;
-        ctx->part_ctx->lane_min = ctx->lane_min;
-        ctx->part_ctx->strip_enabled = ctx->strip_enabled;
-        ctx->part_ctx->strip_always = ctx->strip_always;
-        ctx->part_ctx->strip_cols = ctx->strip_cols;
-        ctx->part_ctx->chain_min = ctx->chain_min;
-      }
+      sdf_config pc = ctx->cfg;  // (the parent's settings, whatever the environment says now)
+      pc.workspace_gib = 0;
+      pc.debug_plan = 0;
+      ctx->part_ctx = sdf_create_cfg(ctx->device, ctx->ws_budget / 4, &pc);
+      if (ctx->part_ctx) mark_internal_context(ctx->part_ctx);  // (a part context is not another user of the process's CPUs)
     }
     // (a batch of fewer than two blocks has no second part: SDF_SPLIT_MIN below 4,096 tasks would otherwise round the first
     // part up past the end of the batch -- ADVICE r3)
@@ -784,7 +782,7 @@ static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   }
   SDF_HIP(hipSetDevice(ctx->device));
   // pack every referenced sequence once (2-bit codes + N mask) and rewrite offsets to words
-  static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
+  const bool dbg_t = ctx->cfg.debug_timing != 0;
   const auto dbg0 = std::chrono::steady_clock::now();
   // (the task array with word offsets: kept by the context -- a fresh vector of 700,000 tasks is 34 MB of page faults per
   // call -- the offsets written here, the other fields copied by the packing threads below)
@@ -952,7 +950,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   if (ctx->pipeline) {
     for (hipStream_t *q : {&ctx->lane_stream, &ctx->aux_stream[0], &ctx->aux_stream[1], &ctx->aux_stream[2], &ctx->aux_stream[3]}) {
       if (q != &ctx->lane_stream && (size_t)(q - &ctx->aux_stream[0]) >= ctx->aux_limit) continue;
-      if (!*q && (q == &ctx->lane_stream ? create_lane_stream(q) : hipStreamCreateWithFlags(q, hipStreamNonBlocking)) != hipSuccess) {
+      if (!*q && (q == &ctx->lane_stream ? create_lane_stream(ctx, q) : hipStreamCreateWithFlags(q, hipStreamNonBlocking)) != hipSuccess) {
         (void)hipGetLastError();
         *q = nullptr;
       }
@@ -1165,7 +1163,7 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
     out_off[0] = 0;
     return SDF_OK;
   }
-  static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
+  const bool dbg_t = ctx->cfg.debug_timing != 0;
   const auto dbg0 = std::chrono::steady_clock::now();
   SDF_HIP(ctx->an_pool.reserve(pool_bytes + 16));
   SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1235,10 +1233,7 @@ extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const in
   // Round 4: a pair whose arrays fit the LDS of a workgroup is swept by ONE WAVEFRONT with everything in LDS
   // (chain_wave_kernel: launch classes by LDS size, the pairs of most anchors first); the others keep the thread-per-pair
   // kernel with its scratch in HBM.  SDF_CHAIN_THREADS=1: every pair on the latter (tests).
-  static const bool threads_only = [] {
-    const char *e = getenv("SDF_CHAIN_THREADS");
-    return e && e[0] == '1';
-  }();
+  const bool threads_only = ctx->cfg.chain_threads_only != 0;
   // (classes of up to 32 KiB, ~400 anchors, whatever their number; up to the device's LDS per workgroup when they are FEW: a wavefront
   // sweeps an anchor in ~14 us where a thread chasing nodes in HBM takes ~85 -- the launch is its largest pair --, but two
   // such workgroups fit a CU: 8,192 pairs of ~700 anchors take 150 ms that way against 59 ms with every pair in flight on
@@ -1369,10 +1364,7 @@ extern "C" int sdf_stats_columns_device(sdf_ctx *ctx, const sdf_stats_task *d_ta
   SDF_HIP(ctx->st_items.reserve((size_t)kItems * sizeof(sdf::StatsItem) + 64));
   unsigned *d_counter = reinterpret_cast<unsigned *>((char *)ctx->st_items.p + (size_t)kItems * sizeof(sdf::StatsItem));
   SDF_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned), st));
-  static const unsigned group_max = [] {
-    const char *e = getenv("SDF_STATS_GROUP_MAX");
-    return e ? (unsigned)std::max(0, atoi(e)) : sdf::STATS_GROUP_MAX;
-  }();
+  const unsigned group_max = ctx->cfg.stats_group_max >= 0 ? (unsigned)ctx->cfg.stats_group_max : sdf::STATS_GROUP_MAX;
   static_assert(sdf::STATS_WAVES == 4, "a workgroup is the four wavefronts of four consecutive alignments");
   hipLaunchKernelGGL(sdf::stats_columns_kernel, dim3((unsigned)((n + sdf::STATS_WAVES - 1) / sdf::STATS_WAVES)),
                      dim3(64 * sdf::STATS_WAVES), 0, st, d_tasks, (int)n, d_seq_pool, d_cigar_pool, d_out,
@@ -1521,6 +1513,12 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   env.n = n;
   env.want = want;
   env.want_cigar = (want & SDF_WANT_CIGAR) != 0;
+  sdf_config dcfg;  // (no context here: the environment's settings, like a context made now would get)
+  {
+    char why[256];
+    if (sdf_config_from_env(&dcfg, why, sizeof why) != SDF_OK) return SDF_ERR_INVALID;
+  }
+  env.cfg = &dcfg;
   ScoreK sk;
   if (int rc = make_scorek(&tmp, sc, sk, env.degenerate)) return rc;
   env.gapo = sc->gapo;
@@ -1546,10 +1544,10 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   {
     WorkerPool cut_pool(std::max(nthreads, 1));
     if (int rc = cut_batch(env, true, ws_budget, cut, &msg, nthreads > 0 ? &cut_pool : nullptr,
-                           getenv("SDF_DEBUG_PLAN_EARLY") ? &early : nullptr))
+                           dcfg.debug_plan_early ? &early : nullptr))
       return rc;
   }
-  if (getenv("SDF_DEBUG_PLAN"))
+  if (dcfg.debug_plan)
     fprintf(stderr, "[sdf] debug plan: cut %.2f ms (%zu tasks, %d threads, %zu chunks started early)\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(), n, nthreads, cut.n_early);
   const size_t np = std::max<size_t>(cut.ntask_total, 1);

@@ -72,6 +72,8 @@ __global__ void cigar_compact_kernel(const PlanTask *, int, const sdf_result *, 
                                      uint32_t *, unsigned long long);
 
 __global__ void reset_results_kernel(sdf_result *res, int n);
+// (diagnostics of buffers that have no context to ask: set by every sdf_create from its configuration's debug_timing)
+inline std::atomic<bool> g_debug_timing{false};
 
 struct DevBuf {
   void *p = nullptr;
@@ -79,7 +81,7 @@ struct DevBuf {
   // `limit`: no headroom beyond this many bytes (the direction-flag workspace: the context's budget)
   hipError_t reserve(size_t bytes, size_t limit = ~(size_t)0) {
     if (bytes <= cap) return hipSuccess;
-    static const bool dbg_t = getenv("SDF_DEBUG_TIMING") != nullptr;
+    const bool dbg_t = g_debug_timing.load(std::memory_order_relaxed);
     const auto t0 = std::chrono::steady_clock::now();
     const size_t old = cap;
     // hipFree waits for the whole DEVICE -- the other lanes' batches included: 100-170 ms measured in a stage run, where
@@ -188,7 +190,8 @@ struct BatchCut;
 // a hundred thousand tasks less than a millisecond: the threads are started once per context).
 class WorkerPool {
  public:
-  explicit WorkerPool(int n) {
+  explicit WorkerPool(int n, int spin_us = 0) {
+    spin_us_ = spin_us > 0 ? spin_us : 0;
     for (int t = 0; t < n; ++t) threads_.emplace_back([this] { loop(); });
   }
   ~WorkerPool() {
@@ -261,16 +264,14 @@ class WorkerPool {
   int pending_ = 0;
   bool quit_ = false;
   std::atomic<int> njobs_{0};
-  int spin_us_ = [] {
-    const char *e = getenv("SDF_POOL_SPIN_US");
-    return e ? atoi(e) : 0;
-  }();
+  int spin_us_ = 0;  // sdf_config.pool_spin_us (set_spin_us)
 };
 }
 using sdf::DevBuf;
 using sdf::HostBuf;
 
 struct sdf_ctx {
+  sdf_config cfg;  // the context's settings, fixed when it is made (sdf_config.hip; sdf_api.hip: apply_config)
   int device = 0;
   hipStream_t stream = nullptr;
   size_t ws_budget = 0;

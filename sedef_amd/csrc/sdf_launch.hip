@@ -289,7 +289,7 @@ static int launch_chunk(BatchRun &run, size_t ci) {
       }
     }
   }
-  static const bool dbg_cls = getenv("SDF_DEBUG_CLASSES") != nullptr;
+  const bool dbg_cls = ctx->cfg.debug_classes != 0;
   if (dbg_cls) {  // what each launch class of the chunk holds: tasks, anti-diagonals, in-band cells (profiles/r04_mm8_classes.txt)
     for (const Launch &L : c.launches) {
       const bool striped = (L.bs >= 300 && L.bs < 500) || L.bs == 604 || L.bs == 608;
@@ -478,25 +478,21 @@ static int rerun_abandoned(BatchRun &run, unsigned long long count) {
     return SDF_ERR_INVALID;
   }
   if (!ctx->rerun_ctx) {
-    ctx->rerun_ctx = sdf_create(ctx->device, ctx->ws_budget / 4);
+    // (with the parent's settings, not the environment's -- ADVICE r3 --, minus every kernel that waits for a neighbour)
+    sdf_config rc_cfg = ctx->cfg;
+    rc_cfg.strip_always = 0;
+    rc_cfg.no_stripe = 1;
+    rc_cfg.bstripe_min_rows = 0;
+    rc_cfg.workspace_gib = 0;
+    rc_cfg.debug_plan = 0;
+    ctx->rerun_ctx = sdf_create_cfg(ctx->device, ctx->ws_budget / 4, &rc_cfg);
     if (!ctx->rerun_ctx) {
       ctx->err = "cannot create the context that re-runs the tasks a stripe kernel gave up";
       return SDF_ERR_NOMEM;
     }
     // (like a part context: not another user of the process's CPUs -- the split rule and the planner's thread count look at
-    // the number of live contexts --, and with the parent's planner switches, not the environment's -- ADVICE r3)
+    // the number of live contexts)
     mark_internal_context(ctx->rerun_ctx);
-    ctx->rerun_ctx->force_general = ctx->force_general;
-    ctx->rerun_ctx->no_pair = ctx->no_pair;
-    ctx->rerun_ctx->no_mixed = ctx->no_mixed;
-    ctx->rerun_ctx->mixed_min = ctx->mixed_min;
-    ctx->rerun_ctx->self_pair_max = ctx->self_pair_max;
-    ctx->rerun_ctx->lane_enabled = ctx->lane_enabled;
-    ctx->rerun_ctx->lane_min = ctx->lane_min;
-    ctx->rerun_ctx->strip_enabled = ctx->strip_enabled;
-    ctx->rerun_ctx->strip_always = false;
-    ctx->rerun_ctx->no_stripe = true;
-    ctx->rerun_ctx->bstripe_min_rows = 0;
   }
   SDF_HIP(ctx->rr_out.reserve(count * sizeof(sdf_result)));
   SDF_HIP(ctx->rr_cig.reserve(cig_cap * 4));
@@ -520,11 +516,8 @@ static int rerun_abandoned(BatchRun &run, unsigned long long count) {
 // The lane path is a chain of small kernels in front of its DP launches, next to chain and strip kernels that hold every
 // wavefront slot for milliseconds: on the highest queue priority its workgroups are the first to get a slot a finished
 // wavefront frees (the hg19-shaped mixture: 12.8 -> 12.2 ms per call under the profiler; SDF_LANE_PRIO=0: a stream like the others).
-hipError_t create_lane_stream(hipStream_t *out) {
-  static const bool lane_prio = [] {
-    const char *e = getenv("SDF_LANE_PRIO");
-    return !(e && e[0] == '0');
-  }();
+hipError_t create_lane_stream(const sdf_ctx *ctx, hipStream_t *out) {
+  const bool lane_prio = ctx->cfg.lane_prio != 0;
   int prio_lo = 0, prio_hi = 0;
   if (lane_prio && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_hi = 0;
   return hipStreamCreateWithPriority(out, hipStreamNonBlocking, lane_prio ? prio_hi : 0);
@@ -537,13 +530,13 @@ static int launch_lane(BatchRun &run, size_t n) {
   sdf_ctx *ctx = run.ctx;
   const BatchCut &cut = *run.cut;
   const size_t nl = cut.n_lane;
-  if (!ctx->lane_stream && create_lane_stream(&ctx->lane_stream) != hipSuccess) {
+  if (!ctx->lane_stream && create_lane_stream(ctx, &ctx->lane_stream) != hipSuccess) {
     (void)hipGetLastError();
     ctx->err = "cannot create the lane kernel's stream";
     return SDF_ERR_HIP;
   }
   hipStream_t sl = ctx->lane_stream;
-  static const bool dbg_lane = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const bool dbg_lane = ctx->cfg.debug_plan != 0;
   const auto lt0 = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (dbg_lane)
@@ -553,10 +546,7 @@ static int launch_lane(BatchRun &run, size_t n) {
   SDF_HIP(hipStreamWaitEvent(sl, run.ev_begin, 0));
   // Planning without a sort (extz2_lane.hip, "second form"): histogram over the 19-bit keys, one scan over the bins, every task
   // to its rank in its bin.  SDF_LANE_PLAN=sort: round 4's hipCUB radix sort + two scans.
-  static const bool by_bins = [] {
-    const char *e = getenv("SDF_LANE_PLAN");
-    return !(e && e[0] == 's');
-  }();
+  const bool by_bins = ctx->cfg.lane_plan_sort == 0;
   if (by_bins) {
     constexpr size_t nb = kLaneBins, nt = kLaneBins / kLaneScanBlock;
     SDF_HIP(ctx->ln_recs.reserve(n * sizeof(LaneRec)));
@@ -759,7 +749,7 @@ static int finish_batch(BatchRun &run, BatchRun *head, size_t n, sdf_result *d_o
     }
     return len;
   };
-  static const bool dbg_iv = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const bool dbg_iv = ctx->cfg.debug_plan != 0;
   if (dbg_iv) {  // the chunks' DP intervals per stream and the lane kernel's, from the start of the call
     for (size_t ci = 0; ci < run.cev.size(); ++ci) {
       const ChunkEv &ev = run.cev[ci];

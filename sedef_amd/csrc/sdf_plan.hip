@@ -18,7 +18,17 @@
 
 namespace sdf {
 
+inline const sdf_config *default_config() {  // (a PlanEnv nobody gave a context's settings: the library's defaults)
+  static const sdf_config c = [] {
+    sdf_config d;
+    sdf_config_default(&d);
+    return d;
+  }();
+  return &c;
+}
+
 struct PlanEnv {
+  const sdf_config *cfg = default_config();  // the context's settings (sdf_config.hip); the fields below are derived per call
   const sdf_task *tasks = nullptr;
   size_t n = 0;
   uint32_t want = 0;
@@ -141,11 +151,7 @@ struct BatchCut {
 namespace plan_detail {
 
 // stripe width of the banded stripe kernel: the narrowest with at most 254 stripes (0: target too long)
-inline int bstripe_nreg(int tlen) {
-  static const int forced = [] {
-    const char *e = getenv("SDF_BSTRIPE_NREG");  // (tests: wider stripes than the target needs)
-    return e ? atoi(e) : 0;
-  }();
+inline int bstripe_nreg(int tlen, const int forced) {  // forced: sdf_config.bstripe_nreg (tests: wider stripes than the target needs)
   const int t16 = (tlen + 15) / 16 * 16;
   if ((forced == 2 || forced == 4) && t16 <= 254 * 128 * forced) return forced;
   return t16 <= 254 * 128 ? 1 : t16 <= 254 * 256 ? 2 : t16 <= 254 * 512 ? 4 : 0;
@@ -199,10 +205,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   // (sixteen or twenty-four chunks for a million tasks were measured no better than eight)
   // (two, three or six chunks for the 100,000-task headline batch: within noise of four)
   if (cut.pipelined && n >= 32768) cut.nch = std::min<size_t>(n >= 500000 ? 8 : 4, n / 16384);
-  static const int force_nch = [] {
-    const char *e = getenv("SDF_CUT_NCH");  // (experiments: the number of ordinary chunks a large batch is cut into)
-    return e ? atoi(e) : 0;
-  }();
+  const int force_nch = (int)env.cfg->cut_chunks;  // (experiments: the number of ordinary chunks a large batch is cut into)
   if (force_nch > 0 && cut.pipelined) cut.nch = (size_t)force_nch;
   cut.max_regions = cut.nch > 4 ? 8 : cut.nch > 1 ? 4 : 1;
   bool chain_bound = false;  // (set after the scan: fewer chunks than the size of the batch alone would give)
@@ -213,14 +216,11 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
 
   // A task is "heavy" when its wavefront (or workgroup) is busy for about a millisecond or more whatever else runs:
   // 500 x 500 and up at full band, i.e. from 256 KB of direction flags.
-  static const size_t heavy_min = [] {
-    const char *e = getenv("SDF_HEAVY_BYTES");
-    return e ? (size_t)atoll(e) : (size_t)256 << 10;
-  }();
+  const size_t heavy_min = env.cfg->heavy_bytes > 0 ? (size_t)env.cfg->heavy_bytes : (size_t)256 << 10;
   // ---- validation + upper bound of each task's direction flags, whichever kernel takes it ----
   // (on several threads for batches of hundreds of thousands of tasks: this pass and the loop below are all the
   // planning the GPU waits for besides the first chunk)
-  static const bool dbg_cut = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const bool dbg_cut = env.cfg->debug_plan != 0;
   const auto tc0 = std::chrono::steady_clock::now();
   std::vector<uint32_t> &bound = cut.bound, &cap = cut.cap;
   const bool lane_scan = env.lane_ok && env.lane_recs && n >= env.lane_min;
@@ -238,7 +238,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
   const size_t nblk = (n + SDF_CUT_BLOCK - 1) / SDF_CUT_BLOCK;
   cut.blocks.assign(nblk, BatchCut::Block());
   auto banded_long = [&](const sdf_task &t) {  // (a superset of what plan_chunk gives to the banded stripe kernel)
-    return env.bstripe_min_rows > 0 && t.w >= 1 && t.qlen + t.tlen - 1 >= env.bstripe_min_rows && plan_detail::bstripe_nreg(t.tlen) > 0;
+    return env.bstripe_min_rows > 0 && t.w >= 1 && t.qlen + t.tlen - 1 >= env.bstripe_min_rows && plan_detail::bstripe_nreg(t.tlen, (int)env.cfg->bstripe_nreg) > 0;
   };
   auto order_entries = [&](const sdf_task &t) -> uint32_t {  // a task paired with itself is listed twice, a stripe task
     // (chained strips take full-band targets of 513..65536 bases whatever stripe_min is: eight idle entries of padding per
@@ -330,7 +330,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         for (int nr = 1; nr <= 4; nr *= 2)
           bd = std::max(bd, (stripe_dir_bytes(t.qlen, t.tlen, nr) + stripe_sync_bytes(t.qlen, t.tlen, nr) + 255) & ~(size_t)255);
       if (banded_long(t)) {
-        const int nr = plan_detail::bstripe_nreg(t.tlen);
+        const int nr = plan_detail::bstripe_nreg(t.tlen, (int)env.cfg->bstripe_nreg);
         bd = std::max(bd, (bstripe_dir_bytes(t.qlen, t.tlen, w, nr) + bstripe_sync_bytes(t.qlen, t.tlen, w, nr) + 255) & ~(size_t)255);
       }
       // (strip kernel: a region per PAIR of tasks with as many column blocks, sized by the one with more rows -- which
@@ -421,10 +421,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     // runs in two passes and the heavy chunks start after the first, over the big tasks only.  It was 400,000 until round 4:
     // an eighth / a quarter of the hg19 mixture, what a rank of an 8- / 4-GPU strong-scaling run gets, 5.6-5.7 -> 4.9-5.3 ms
     // and 7.2-7.5 -> 5.9-6.0 ms, first launch at 0.56 instead of 1.39 ms.  SDF_SCAN_POOL_FROM overrides.)
-    static const size_t scan_from = [] {
-      const char *e = getenv("SDF_SCAN_POOL_FROM");
-      return e ? (size_t)atoll(e) : (size_t)120000;
-    }();
+    const size_t scan_from = (size_t)env.cfg->scan_pool_from;
     const int nthr = pool && n >= scan_from ? std::min(16, pool->size() + 1) : 1;
     Part parts[16];
     // Runs of sixteen blocks are handed out through a counter: this thread starts at once, a parked helper joins when it
@@ -696,7 +693,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   using plan_detail::Cls;
   const sdf_task *tasks = env.tasks;
   const bool want_cigar = env.want_cigar;
-  static const bool dbg_pc = getenv("SDF_DEBUG_PLAN") != nullptr;
+  const bool dbg_pc = env.cfg->debug_plan != 0;
   const auto tp0 = std::chrono::steady_clock::now();
   auto tp1 = tp0, tp2 = tp0, tp3 = tp0;
   std::vector<int32_t> &win_need = sx.win_need, &partner = sx.partner;
@@ -788,15 +785,12 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       // one wavefront, or the general kernel: 0.9 - 1.9 us per row in a mixed batch against 0.2 - 0.5), and every band
       // that runs out (the TRACK flavour: 0.6 us per row with three registers, 1.35 with six; mm8-like mixture with
       // those of up to 192 slots left on it 27.5 ms, without 24.1)
-      static const int bstripe_all = [] {
-        const char *e = getenv("SDF_BSTRIPE_ALL");  // (tests: every long banded task)
-        return e ? atoi(e) : 0;
-      }();
+      const int bstripe_all = (int)env.cfg->bstripe_all;  // (tests: every long banded task)
       constexpr int bstripe_plain_min = 192;  // (measured on the mm8-like mixture: 384 -> 47 ms, 192 -> 29-34 ms, 128 -> 36-39 ms)
       const int bneed = std::min(p.ncol16 + 32, (t.tlen + 15) / 16 * 16);
       if (simple && !env.force_general && env.bstripe_min_rows > 0 && nrow >= env.bstripe_min_rows && p.w >= 1 &&
           p.w < std::max(t.qlen, t.tlen) && (bstripe_all || bneed > bstripe_plain_min || !band_whole)) {
-        const int nr = plan_detail::bstripe_nreg(t.tlen);
+        const int nr = plan_detail::bstripe_nreg(t.tlen, (int)env.cfg->bstripe_nreg);
         if (nr && bstripe_lds_bytes(p.w, nr) <= (size_t)env.max_dyn_lds) {
           p.nreg = nr;
           p.pad_ = 7;
@@ -895,10 +889,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     // (a 6000 x 6000 task alone: 6.1 ms at 512 positions per stripe).  Many tasks want wide ones: per cell a wide stripe
     // spends fewer instructions on the edges and the loop (1k x 1k tasks by the thousand: 1180 Gcell/s at 512, 800 at
     // 128), and with a wavefront or more per SIMD the chains overlap anyway.
-    static const int force_nreg = [] {
-      const char *e = getenv("SDF_STRIPE_NREG");
-      return e ? atoi(e) : 0;
-    }();
+    const int force_nreg = (int)env.cfg->stripe_nreg;
     // -> the width with the smaller of: the launch's cells at the width's throughput (800 / 1100 / 1300 Gcell/s measured
     // on batches of equal tasks), its longest chain at the width's row time alone on a SIMD (0.24 / 0.27 / 0.50 us)
     int nr = 1;
@@ -1082,7 +1073,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
         const int32_t k = sx.bs_alt[j];
         if (partner[k] >= 0) continue;
         cp[k].pad_ = 7;
-        cp[k].nreg = plan_detail::bstripe_nreg(cp[k].tlen);
+        cp[k].nreg = plan_detail::bstripe_nreg(cp[k].tlen, (int)env.cfg->bstripe_nreg);
         win_need[k] = 0;
         for (auto &e : table)
           if (e.second == k) e.second = -1;
@@ -1420,7 +1411,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   }
   c.nord = cursor;
   if (c.nord > c.order_cap) c.err = "internal: launch-order segment overflow";
-  static const bool dbg_pc_all = getenv("SDF_DEBUG_PLAN") && getenv("SDF_DEBUG_PLAN")[0] == '2';
+  const bool dbg_pc_all = env.cfg->debug_plan >= 2;
   if (dbg_pc && (c.heavy || dbg_pc_all)) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     fprintf(stderr, "[plan_chunk %s %zu tasks: tasks %.2f ms, pairing %.2f ms, classes %.2f ms, order %.2f ms]\n", c.heavy ? "heavy" : "ordinary", c.cnt, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()));

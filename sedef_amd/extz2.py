@@ -147,12 +147,70 @@ def sedef_mat(match=5, mismatch=-4):
                     dtype=np.int8)
 
 
-class Extz2Engine:
-    """One context = one GPU (include/sedef_hip.h: sdf_create)."""
+class Config:
+    """include/sedef_hip.h: sdf_config -- the library's settings as one opaque struct.  Config() holds what sdf_create would
+    read from the environment NOW; Config(SDF_NO_PAIR=1, strip_cols=4) sets fields by their environment variable's or
+    their own name (a wrong name or a value out of range raises); nothing is written to os.environ."""
 
-    def __init__(self, device=0, workspace_bytes=0):
+    BYTES = 512  # (room for the struct: its first word is its size, checked below)
+
+    def __init__(self, from_env=True, **settings):
         self.lib = load_library()
-        self.ctx = self.lib.sdf_create(device, workspace_bytes)
+        self.buf = C.create_string_buffer(self.BYTES)
+        err = C.create_string_buffer(512)
+        if from_env:
+            self.lib.sdf_config_from_env.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+            if self.lib.sdf_config_from_env(self.buf, err, len(err)) != 0:
+                raise SdfError("environment: %s" % err.value.decode())
+        else:
+            self.lib.sdf_config_default.argtypes = [C.c_void_p]
+            self.lib.sdf_config_default(self.buf)
+        assert 0 < C.cast(self.buf, C.POINTER(C.c_uint32))[0] <= self.BYTES
+        self.set(**settings)
+
+    def set(self, **settings):
+        err = C.create_string_buffer(512)
+        self.lib.sdf_config_set.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        for k, v in settings.items():
+            if isinstance(v, bool):
+                v = int(v)
+            if self.lib.sdf_config_set(self.buf, k.encode(), str(v).encode(), err, len(err)) != 0:
+                raise SdfError(err.value.decode())
+        return self
+
+    def dump(self):
+        self.lib.sdf_config_dump.restype = C.c_size_t
+        self.lib.sdf_config_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        out = C.create_string_buffer(self.lib.sdf_config_dump(self.buf, None, 0))
+        self.lib.sdf_config_dump(self.buf, out, len(out))
+        return out.value.decode()
+
+    def as_dict(self):
+        return {k: float(v.split()[0]) for k, v in (ln.split("=", 1) for ln in self.dump().splitlines() if "=" in ln)}
+
+
+def describe_config():
+    lib = load_library()
+    lib.sdf_config_describe.restype = C.c_size_t
+    lib.sdf_config_describe.argtypes = [C.c_char_p, C.c_size_t]
+    out = C.create_string_buffer(lib.sdf_config_describe(None, 0))
+    lib.sdf_config_describe(out, len(out))
+    return out.value.decode()
+
+
+class Extz2Engine:
+    """One context = one GPU (include/sedef_hip.h: sdf_create / sdf_create_cfg).  config: a Config, or a dict of settings
+    on top of the environment's (Extz2Engine(0, config=dict(SDF_NO_PAIR=1)))."""
+
+    def __init__(self, device=0, workspace_bytes=0, config=None):
+        self.lib = load_library()
+        if config is None:
+            self.ctx = self.lib.sdf_create(device, workspace_bytes)
+        else:
+            cfg = config if isinstance(config, Config) else Config(**config)
+            self.lib.sdf_create_cfg.restype = C.c_void_p
+            self.lib.sdf_create_cfg.argtypes = [C.c_int, C.c_size_t, C.c_void_p]
+            self.ctx = self.lib.sdf_create_cfg(device, workspace_bytes, cfg.buf)
         if not self.ctx:
             raise SdfError("sdf_create failed: %s" % self.lib.sdf_last_error(None).decode())
 

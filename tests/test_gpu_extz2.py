@@ -17,32 +17,15 @@ def engine():
 @pytest.fixture(scope="module")
 def solo_engine():
     """Context with SDF_NO_PAIR=1: one task per wavefront (extz2_wave.hip) instead of the pair kernel."""
-    import os
     import sedef_amd
-    old = os.environ.get("SDF_NO_PAIR")
-    os.environ["SDF_NO_PAIR"] = "1"
-    try:
-        return sedef_amd.Extz2Engine(0)
-    finally:
-        if old is None:
-            del os.environ["SDF_NO_PAIR"]
-        else:
-            os.environ["SDF_NO_PAIR"] = old
+    return sedef_amd.Extz2Engine(0, config=dict(SDF_NO_PAIR=1))
 
 
 def _engine_with_env(**env):
-    import os
+    """A context whose settings differ from the environment's by `env` (SDF_* names): through the C ABI's configuration
+    struct (sdf_create_cfg), never through os.environ."""
     import sedef_amd
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        return sedef_amd.Extz2Engine(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+    return sedef_amd.Extz2Engine(0, config=env)
 
 
 @pytest.fixture(scope="module")
@@ -754,7 +737,10 @@ def test_config4_hg19_task_mixture(engine, oracle):
     # the batch in two parts (SDF_SPLIT_MIN: the first eighth on a second context while the rest is still being read)
     split = _engine_with_env(SDF_SPLIT_MIN=20000)
     _batch_vs_cpu(split, oracle, batch, w)
-    assert split.last_lane_tasks() > 29000
+    # (the first part -- an eighth of the batch, fewer tasks than the lane kernel asks for -- runs on the window kernels of
+    # the part's own context; until round 5 a function-local static froze the first SDF_SPLIT_MIN a process saw and this
+    # context never split)
+    assert 24000 < split.last_lane_tasks() < 27000
 
 
 def test_config5_mm8_mixed_bands(engine, oracle):

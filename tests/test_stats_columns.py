@@ -198,13 +198,8 @@ def test_gpu_stats_columns_long_and_short_in_one_call(oracle):
 def test_gpu_stats_columns_segment_list_overflow(oracle):
     """The device cuts long alignments into segments that a second launch counts; with a list of four segments most long
     alignments of a call find it full and are counted by their own wavefront: same counters either way."""
-    import os
     import sedef_amd
-    os.environ["SDF_STATS_ITEMS"] = "4"
-    try:
-        eng = sedef_amd.Extz2Engine(0)
-    finally:
-        del os.environ["SDF_STATS_ITEMS"]
+    eng = sedef_amd.Extz2Engine(0, config=dict(SDF_STATS_ITEMS=4))
     rng = np.random.default_rng(9)
     cases = [random_stats_case(rng, n_runs) for n_runs in (1100, 1500, 30, 2100, 1025, 700, 4000)]
     _check_batch(eng, oracle, cases)
