@@ -42,6 +42,18 @@ __device__ __forceinline__ bool lane_in(int lane, int a, int b) {
   return (unsigned)(lane - a) < (unsigned)(b > a ? b - a : 0);
 }
 
+// lanes [a, b) of the wavefront as a scalar mask (0 <= a; b may exceed 64), and a lane predicate from such a mask: the row
+// code's lane ranges follow from scalars, so the masks are SALU work and a select is ONE v_cndmask with an SGPR pair --
+// no v_cmp on the lane index (round 5: three VOPC fewer per steady row)
+__device__ __forceinline__ unsigned long long lane_mask(int a, int b) {
+  const unsigned long long hi = b >= 64 ? ~0ull : b <= 0 ? 0ull : (1ull << b) - 1ull;
+  const unsigned long long lo = a >= 64 ? ~0ull : a <= 0 ? 0ull : (1ull << a) - 1ull;
+  return hi & ~lo;
+}
+// (never with a compile-time constant: the LOW16 rows' `if (in_mask(0xffffffffffff0000))` computed wrong cells -- the
+// compiler folds the builtin on a constant into something else; lane compares stay where the mask is a literal)
+__device__ __forceinline__ bool in_mask(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // 0xff00 in the halves whose value is negative (the reference's sign-extended carry, :145-146)
 __device__ __forceinline__ unsigned sign_smear(unsigned c) {
   return ((c & 0x8000u) ? 0xff00u : 0u) | ((c & 0x80000000u) ? 0xff000000u : 0u);
@@ -495,9 +507,9 @@ __device__ __forceinline__ void pair_body(
         if (STEADY) {
           unsigned z;
           SDF_PFRESH(z, Tc[k], qcur[k], HASN)
-          if (NREG == 1) S[0] = lane_in(lane, ra, b_) ? z : S[0];
-          else if (k == 0) S[0] = lane >= ra ? z : S[0];
-          else if (k == KT) S[k] = lane < b_ ? z : S[k];
+          if (NREG == 1) S[0] = in_mask(lane_mask(ra, b_)) ? z : S[0];
+          else if (k == 0) S[0] = in_mask(lane_mask(ra, 64)) ? z : S[0];
+          else if (k == KT) S[k] = in_mask(lane_mask(0, b_)) ? z : S[k];
           else S[k] = z;
         } else if (b_ > 0) {
           unsigned z;
@@ -571,7 +583,7 @@ __device__ __forceinline__ void pair_body(
               val = (sl >> 6) == k ? ck : val;
             }
           }
-          if (lane == (sl & 63)) {
+          if (in_mask(1ull << (sl & 63))) {
             hacc_a += (val >> 8) & 0xffu;
             hacc_b += val >> 24;
           }
