@@ -110,8 +110,9 @@ typedef struct {
 /* ---- context ---------------------------------------------------------------------------- */
 int sdf_device_count(void);
 /* device: HIP ordinal.  workspace_bytes: HBM budget for direction matrices per internal
- * batch (0 = default 64 GiB, clamped to half of the free memory).  Returns NULL on failure
- * (sdf_last_error(NULL) has the reason). */
+ * batch (0 = half of the memory free when the context is made; any figure is clamped to that).  The
+ * workspace is allocated by need, up to the budget: a batch that needs more runs in chunks.
+ * Returns NULL on failure (sdf_last_error(NULL) has the reason). */
 sdf_ctx *sdf_create(int device, size_t workspace_bytes);
 void sdf_destroy(sdf_ctx *ctx);
 

@@ -35,4 +35,5 @@ grep -h "^{\"metric" $out/stats_pipe.log > $out/bench_pipe.json
 grep -h "tasks" $out/stats_hg19.log $out/stats_mm8.log $out/stats_mm8big.log $out/stats_fullband.log $out/stats_lane.log > $out/mix_lines.txt
 python3 profiles/make_traffic_json.py $out profiles/${tag}_pair_kernel_pmc.txt > $out/hbm_traffic_line.txt
 cat $out/stats_iso_kernel_stats.csv | head -8; cat $out/pmc_fetch.txt $out/pmc_write.txt $out/pmc_sq.txt | grep "pair_kernel\|traceback"; cat $out/mix_lines.txt
+cp profiles/hbm_traffic.json $out/hbm_traffic.json
 rm -rf $out/stats_iso $out/stats_pipe $out/fetch $out/write $out/sq $out/stats_hg19 $out/stats_mm8 $out/stats_mm8big $out/stats_fullband $out/stats_lane

@@ -131,7 +131,10 @@ extern "C" sdf_ctx *sdf_create_cfg(int device, size_t workspace_bytes, const sdf
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   lap("mem info");
-  size_t budget = workspace_bytes ? workspace_bytes : (size_t)64 << 30;
+  // (0: half of the free HBM -- the workspace is allocated by NEED, region by region (cut_batch), so a large budget costs a
+  // small batch nothing, and a batch of long banded tasks -- BASELINE configs[4] at 100,000 tasks: 131 GB of flags -- is not cut
+  // into more, smaller chunks because of a constructor default: 64 GiB until round 4, 252 ms against 201 at 128 GiB)
+  size_t budget = workspace_bytes ? workspace_bytes : free_b ? free_b / 2 : (size_t)64 << 30;
   if (cfg.workspace_gib > 0) budget = (size_t)(cfg.workspace_gib * 1073741824.0);  // (overrides the caller's figure: experiments with the stage driver)
   if (free_b && budget > free_b / 2) budget = free_b / 2;
   ctx->ws_budget = budget;
