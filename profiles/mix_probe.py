@@ -17,9 +17,10 @@ from shapes_bench import bench, sedef_amd  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "mm8"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else (3000 if which == "mm8" else 300000)
-# (the mm8-like batch of 100,000 tasks holds 131 GB of direction flags: at 128 GiB it runs as three chunks, at the library's
-# default of 64 GiB as six -- 201 against 252 ms, profiles/r04_shapes.txt)
-ws_gib = int(sys.argv[3]) if len(sys.argv) > 3 else (128 if which == "mm8" and n >= 20000 else 64)
+# (the mm8-like batch of 100,000 tasks holds 131 GB of direction flags: at 128 GiB it runs as three chunks, at 64 GiB as six --
+# 201 against 252 ms, profiles/r04_shapes.txt.  Round 5: the library's default, `sdf_create(device, 0)`, is half of the free HBM,
+# and that is what this probe runs with unless a figure is given)
+ws_gib = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 eng = sedef_amd.Extz2Engine(0, ws_gib << 30)
 dev = torch.device("cuda", 0)
 if which == "mm8":

@@ -1246,11 +1246,12 @@ def test_config5_full_size_mixed_bands(engine, oracle):
 def test_config5_throughput_batch_of_100000_tasks(oracle):
     """configs[4] at the size profiles/mix_probe.py mm8 100000 times (round 4: the batch whose banded tasks of different
     lengths run two to a wavefront): every task through the size-independent checks, a sample of 600 -- the longest tasks
-    among them -- against the reference kernel.  128 GiB of workspace, as the probe: the batch's direction flags are 131 GB."""
+    among them -- against the reference kernel.  The library's default workspace (`sdf_create(device, 0)`: half of the free HBM),
+    as the probe: the batch's direction flags are 131 GB."""
     import bench
     import sedef_amd
     batch, w = bench.synth_mm8_mixture_fast(100000, seed=505)
-    eng = sedef_amd.Extz2Engine(0, 128 << 30)
+    eng = sedef_amd.Extz2Engine(0)
     qlen = batch[2]
     rng = np.random.default_rng(3)
     sample = np.unique(np.r_[rng.choice(100000, 560, replace=False), np.argsort(qlen)[-40:]])
