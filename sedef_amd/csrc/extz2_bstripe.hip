@@ -186,7 +186,8 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   int32_t ez_score = SDF_NEG_INF, ez_mte = SDF_NEG_INF, ez_mte_q = -1;
   bool have_score = false;
 
-  uint32_t feed_xv = 0u, feed_h = 0u, next_xv = 0u, next_h = 0u;  // the left column's words of the block / the next one
+  uint32_t feed_xv = 0u, feed_h = 0u, next_xv = 0u, next_h = 0u;
+  uint32_t feed_c = 0u;  // (feed_xv without its tag bit: x | v << 16 as the rows take it)
   int feed_r0 = -0x40000000;
   uint32_t out_xv = 0u, out_h = 0u;  // my last column's words of the block (lane = row & 15)
   auto feed_load = [&](const int rfirst, uint32_t &xv, uint32_t &hh) {  // states after rows rfirst - 1 + (0 .. 15)
@@ -246,11 +247,13 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
 #endif
       feed_xv = gx;
       feed_h = gh;
+      feed_c = gx & ~1u;
       feed_r0 = r0;
       feed_load(r0 + 16, next_xv, next_h);
     } else {
       feed_xv = 1u;
       feed_h = 0u;
+      feed_c = 0u;
     }
     unsigned qaddr = (unsigned)(2 * (qlen - 1 - rb + T0 + 2 * lane - q0));
     unsigned qnext[NREG];
@@ -278,25 +281,24 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
 #pragma unroll
           for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
-          const uint32_t fxv = (uint32_t)__builtin_amdgcn_readlane((int)feed_xv, r - r0);
+          const int fc = __builtin_amdgcn_readlane((int)feed_c, r - r0);
           unsigned xt1[NREG], vt1[NREG];
+          unsigned P[NREG];  // (x and v of the lane's odd column in one word: see the ordinary rows below)
+#pragma unroll
+          for (int k = 0; k < NREG; ++k) P[k] = __builtin_amdgcn_perm(V[k], X[k], 0x07060302u);
 #pragma unroll
           for (int k = 0; k < NREG; ++k) {
-            unsigned xs, vs;
+            unsigned ps;
             if (k == 0) {
-              xs = (unsigned)__builtin_amdgcn_update_dpp((int)((fxv & 0xfffeu) << 16), (int)X[0], 0x138, 0xf, 0xf, false);
-              vs = (unsigned)__builtin_amdgcn_update_dpp((int)(fxv & 0xffff0000u), (int)V[0], 0x138, 0xf, 0xf, false);
+              ps = (unsigned)__builtin_amdgcn_update_dpp(fc, (int)P[0], 0x138, 0xf, 0xf, false);
             } else {
-              int ux, uv;
-              asm("" : "=v"(ux));
-              asm("" : "=v"(uv));
-              const int x0 = __builtin_amdgcn_update_dpp(ux, (int)X[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
-              xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-              const int v0 = __builtin_amdgcn_update_dpp(uv, (int)V[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
-              vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
+              int up;
+              asm("" : "=v"(up));
+              const int p0 = __builtin_amdgcn_update_dpp(up, (int)P[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+              ps = (unsigned)__builtin_amdgcn_update_dpp(p0, (int)P[k], 0x138, 0xf, 0xf, false);
             }
-            xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
-            vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
+            xt1[k] = __builtin_amdgcn_perm(X[k], ps, 0x05040100u);
+            vt1[k] = __builtin_amdgcn_perm(V[k], ps, 0x05040302u);
           }
 #pragma unroll
           for (int k = 0; k < NREG; ++k) S[k] = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
@@ -336,176 +338,206 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         }
       }
     }
+    // ---- ordinary rows, as long as they last (no border cell: hi < r): lane predicates against the row's band; the
+    // row on which the first computed cell's window moves (one in 32) takes the one branch ----
+    // The row's scalars -- band ends, computed blocks, the ranges of the score refresh -- are a dozen shifts, masks and
+    // compares each on the scalar unit; a stripe at the edge of the band is ONE wavefront on its SIMD, every instruction of
+    // it an issue slot of the task's chain of rows (round 4: 204 instructions a row, 103 of them scalar).  They depend on
+    // the row number alone: lane i of a few registers computes them for row r0 + i once per 16-row block, and a row reads
+    // its own with one v_readlane each.
+    int t_lo = 0, t_fix = 0, t_act = 0, t_a1 = 0, t_l1 = 0, t_a0 = 0, t_l0 = 0, t_lo0 = 0, t_span = 0;
+    unsigned m_stop = 0xffffu, m_moved = 0u, m_hrow = 0u, m_end = 0u;
+    if (r < re) {  // (a block of rows on which the band covers the whole stripe is done by now)
+      const int rr = r0 + (lane & 15);
+      int c_lo0 = (rr - w + 1) >> 1, c_hi0 = (rr + w) >> 1, c_plo = (rr - w) >> 1;
+      c_lo0 = c_lo0 < rr - qlen + 1 ? rr - qlen + 1 : c_lo0;
+      c_lo0 = c_lo0 < 0 ? 0 : c_lo0;
+      c_hi0 = c_hi0 > rr ? rr : c_hi0;
+      c_hi0 = c_hi0 > tlen - 1 ? tlen - 1 : c_hi0;
+      c_plo = c_plo < rr - qlen ? rr - qlen : c_plo;
+      c_plo = c_plo < 0 ? 0 : c_plo;
+      const int c_lo = c_lo0 & ~15, c_hi = c_hi0 | 15, c_prev = c_plo & ~15;
+      const bool c_moved = c_lo != c_prev && c_lo >= T0 && c_lo < T1;
+      const bool c_stop = c_lo0 > c_hi0 || rr == 0 || c_hi >= rr || (c_lo == 0 && T0 == 0);  // (not an ordinary row)
+      const int c_ra = c_lo0 - T0, c_rbe = c_ra + ((c_hi0 - c_lo0) & ~15) + 16;
+      const int c_a1 = (c_ra + 1) >> 1, c_b1 = (c_rbe + 1) >> 1, c_a0 = c_ra >> 1, c_b0 = c_rbe >> 1;
+      t_lo = c_lo;
+      t_lo0 = c_lo0;
+      t_fix = c_lo > 0 && !c_moved ? c_lo : -2;
+      t_a1 = c_a1;
+      t_a0 = c_a0;
+      t_l1 = c_b1 > c_a1 ? c_b1 - c_a1 : 0;
+      t_l0 = c_b0 > c_a0 ? c_b0 - c_a0 : 0;
+      t_act = c_hi - c_lo;
+      t_span = c_hi0 - c_lo0;
+      m_stop = (unsigned)__ballot(c_stop) & 0xffffu;
+      m_moved = (unsigned)__ballot(c_moved) & 0xffffu;
+      m_hrow = can_drop ? 0xffffu : (unsigned)__ballot(c_hi0 <= T1 + 1) & 0xffffu;  // (see can_drop)
+      m_end = (unsigned)__ballot(c_hi0 == tlen - 1 && c_hi0 >= T0 && c_hi0 < T1) & 0xffffu;
+    }
 #pragma unroll 1
     for (; r < re; ++r) {
-      // ---- ordinary rows, as long as they last (no border cell: hi < r): lane predicates against the row's band; the
-      // row on which the first computed cell's window moves (one in 32) takes the one branch ----
-      // (PURE: on every row of the block the band is [(r - w + 1) >> 1, (r + w) >> 1], clear of the matrix borders)
-      auto lean_rows = [&](auto pure_c) {
-      constexpr bool PURE = decltype(pure_c)::value;
-#pragma unroll 1
-      for (; r < re; ++r) {
+#ifndef SDF_BS_NO_LEAN
+      {
+        // (the run of ordinary rows ahead: up to the next row the table marks, or the end of the block)
         r = __builtin_amdgcn_readfirstlane(r);
-        int lo0 = (r - w + 1) >> 1, hi0 = (r + w) >> 1;
-        int plo = (r - w) >> 1;  // the previous row's band start
-        if (!PURE) {
-          lo0 = lo0 < r - qlen + 1 ? r - qlen + 1 : lo0;
-          lo0 = lo0 < 0 ? 0 : lo0;
-          hi0 = hi0 > r ? r : hi0;
-          hi0 = hi0 > tlen - 1 ? tlen - 1 : hi0;
-          plo = plo < r - qlen ? r - qlen : plo;
-          plo = plo < 0 ? 0 : plo;
-        }
-        const int lo = lo0 & ~15, hi = hi0 | 15, prev_lo = plo & ~15;
-        const bool moved_here = lo != prev_lo && lo >= T0 && lo < T1;
-        if (!PURE && (lo0 > hi0 || r == 0 || hi >= r || (lo == 0 && T0 == 0))) break;
-        unsigned qc[NREG];
+        const unsigned ahead = m_stop >> (r - r0);
+        int r_end = ahead ? r + __builtin_ctz(ahead) : re;
+        r_end = r_end < re ? r_end : re;
+        const int out_from = has_right ? next_a - 1 : 0x7fffffff;
+#pragma unroll 1
+        for (int rl = r; rl < r_end; ++rl) {
+          const int ri = rl - r0;
+          const int lo = __builtin_amdgcn_readlane(t_lo, ri), lo_fix = __builtin_amdgcn_readlane(t_fix, ri);
+          const int act_span = __builtin_amdgcn_readlane(t_act, ri);
+          const int a1 = __builtin_amdgcn_readlane(t_a1, ri), l1 = __builtin_amdgcn_readlane(t_l1, ri);
+          const int a0 = __builtin_amdgcn_readlane(t_a0, ri), l0 = __builtin_amdgcn_readlane(t_l0, ri);
+          const int lo0 = __builtin_amdgcn_readlane(t_lo0, ri);
+          const unsigned span = (unsigned)__builtin_amdgcn_readlane(t_span, ri);
+          unsigned qc[NREG];
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
-        qaddr -= 2;
-        asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
+          for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+          qaddr -= 2;
+          asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
-        const uint32_t fxv = (uint32_t)__builtin_amdgcn_readlane((int)feed_xv, r - r0);
-        const int32_t fh = __builtin_amdgcn_readlane((int)feed_h, r - r0);
-        unsigned xt1[NREG], vt1[NREG];
-        int32_t hleft[NREG];  // H (before this row) of the column to the left of the lane's even one
+          for (int k = 0; k < NREG; ++k) qnext[k] = *reinterpret_cast<const uint16_t *>(lds + qaddr + 256 * k);
+          // The (r-1, t-1) neighbours: the odd column of the lane to the left.  x and v of that column travel TOGETHER -- the
+          // word the stripes hand each other (x | v << 16, feed_c: the tag bit cleared) is also what one DPP shift moves
+          const int fc = __builtin_amdgcn_readlane((int)feed_c, ri);
+          const int32_t fh = __builtin_amdgcn_readlane((int)feed_h, ri);
+          unsigned xt1[NREG], vt1[NREG];
+          int32_t hleft[NREG];  // H (before this row) of the column to the left of the lane's even one
+          unsigned P[NREG];
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          unsigned xs, vs;
-          if (k == 0) {
-            xs = (unsigned)__builtin_amdgcn_update_dpp((int)((fxv & 0xfffeu) << 16), (int)X[0], 0x138, 0xf, 0xf, false);
-            vs = (unsigned)__builtin_amdgcn_update_dpp((int)(fxv & 0xffff0000u), (int)V[0], 0x138, 0xf, 0xf, false);
-            hleft[0] = __builtin_amdgcn_update_dpp(fh, Ho[0], 0x138, 0xf, 0xf, false);
-          } else {
-            int ux, uv, uh;
-            asm("" : "=v"(ux));
-            asm("" : "=v"(uv));
-            asm("" : "=v"(uh));
-            const int x0 = __builtin_amdgcn_update_dpp(ux, (int)X[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
-            xs = (unsigned)__builtin_amdgcn_update_dpp(x0, (int)X[k], 0x138, 0xf, 0xf, false);
-            const int v0 = __builtin_amdgcn_update_dpp(uv, (int)V[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
-            vs = (unsigned)__builtin_amdgcn_update_dpp(v0, (int)V[k], 0x138, 0xf, 0xf, false);
-            const int h0 = __builtin_amdgcn_update_dpp(uh, Ho[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
-            hleft[k] = __builtin_amdgcn_update_dpp(h0, Ho[k], 0x138, 0xf, 0xf, false);
-          }
-          xt1[k] = __builtin_amdgcn_alignbit(X[k], xs, 16);
-          vt1[k] = __builtin_amdgcn_alignbit(V[k], vs, 16);
-        }
-        // the first computed cell (lo: an even column), its window not moved: its left neighbour reads as 0
-        const int lo_fix = lo > 0 && !moved_here ? lo : -2;
-        if (moved_here) {  // moved (one row in 32): the slot to the left as it is, and a negative byte there also sets
-                           // the next three cells (the reference's sign extension, :145-146)
+          for (int k = 0; k < NREG; ++k) P[k] = __builtin_amdgcn_perm(V[k], X[k], 0x07060302u);
 #pragma unroll
           for (int k = 0; k < NREG; ++k) {
-            const int tb = T0 + 128 * k;
-            if (lo < tb || lo > tb + 127) continue;
-            const int ll = (lo - tb) >> 1;
-            const unsigned cx = (unsigned)__builtin_amdgcn_readlane((int)xt1[k], ll) & 0xffffu;
-            const unsigned cv = (unsigned)__builtin_amdgcn_readlane((int)vt1[k], ll) & 0xffffu;
-            const unsigned sx = (cx & 0x8000u) ? 0xff00u : 0u, sv = (cv & 0x8000u) ? 0xff00u : 0u;
-            const unsigned mx = lane == ll ? sx << 16 : lane == ll + 1 ? sx * 0x00010001u : 0u;
-            const unsigned mv = lane == ll ? sv << 16 : lane == ll + 1 ? sv * 0x00010001u : 0u;
-            xt1[k] |= mx;
-            vt1[k] |= mv;
+            unsigned ps;
+            if (k == 0) {
+              ps = (unsigned)__builtin_amdgcn_update_dpp(fc, (int)P[0], 0x138, 0xf, 0xf, false);
+              hleft[0] = __builtin_amdgcn_update_dpp(fh, Ho[0], 0x138, 0xf, 0xf, false);
+            } else {
+              int up, uh;
+              asm("" : "=v"(up));
+              asm("" : "=v"(uh));
+              const int p0 = __builtin_amdgcn_update_dpp(up, (int)P[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+              ps = (unsigned)__builtin_amdgcn_update_dpp(p0, (int)P[k], 0x138, 0xf, 0xf, false);
+              const int h0 = __builtin_amdgcn_update_dpp(uh, Ho[k > 0 ? k - 1 : 0], 0x13C, 0x1, 0x1, false);
+              hleft[k] = __builtin_amdgcn_update_dpp(h0, Ho[k], 0x138, 0xf, 0xf, false);
+            }
+            xt1[k] = __builtin_amdgcn_perm(X[k], ps, 0x05040100u);  // (neighbour's x | my even column's x << 16)
+            vt1[k] = __builtin_amdgcn_perm(V[k], ps, 0x05040302u);
           }
-        }
-        const int ra = lo0 - T0, rbe = ra + ((hi0 - lo0) & ~15) + 16;
+          // the first computed cell (lo: an even column), its window not moved: its left neighbour reads as 0 (lo_fix)
+          if ((m_moved >> ri) & 1u) {  // moved (one row in 32): the slot to the left as it is, and a negative byte there also
+                                       // sets the next three cells (the reference's sign extension, :145-146)
 #pragma unroll
-        for (int k = 0; k < NREG; ++k) {
-          const int te = T0 + 128 * k + 2 * lane;
-          const bool first = te == lo_fix;
-          xt1[k] = first ? (xt1[k] & 0xffff0000u) : xt1[k];
-          vt1[k] = first ? (vt1[k] & 0xffff0000u) : vt1[k];
-          unsigned z = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
-          if (has_n) {
-            unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
-            SDF_OPQ(nn);
-            z = (z_wild & nn) | (z & ~nn);
+            for (int k = 0; k < NREG; ++k) {
+              const int tb = T0 + 128 * k;
+              if (lo < tb || lo > tb + 127) continue;
+              const int ll = (lo - tb) >> 1;
+              const unsigned cx = (unsigned)__builtin_amdgcn_readlane((int)xt1[k], ll) & 0xffffu;
+              const unsigned cv = (unsigned)__builtin_amdgcn_readlane((int)vt1[k], ll) & 0xffffu;
+              const unsigned sx = (cx & 0x8000u) ? 0xff00u : 0u, sv = (cv & 0x8000u) ? 0xff00u : 0u;
+              const unsigned mx = lane == ll ? sx << 16 : lane == ll + 1 ? sx * 0x00010001u : 0u;
+              const unsigned mv = lane == ll ? sv << 16 : lane == ll + 1 ? sv * 0x00010001u : 0u;
+              xt1[k] |= mx;
+              vt1[k] |= mv;
+            }
           }
-          sel_lo_rng(S[k], z, (ra - 128 * k + 1) >> 1, (rbe - 128 * k + 1) >> 1, lane);
-          sel_hi_rng(S[k], z, (ra - 128 * k) >> 1, (rbe - 128 * k) >> 1, lane);
-          const bool act = (unsigned)(te - lo) <= (unsigned)(hi - lo);
-          const unsigned a_ = pk_add(xt1[k], vt1[k]);
-          const unsigned bb_ = pk_add(Y[k], U[k]);
-          const unsigned z0_ = S[k];
-          const unsigned z1_ = pk_maxi(z0_, a_);
-          const unsigned fa_ = pk_sub(z1_, z0_);
-          const unsigned zb_ = pk_maxi(z1_, bb_);
-          const unsigned fb_ = pk_sub(zb_, z1_);
-          const unsigned z2_ = pk_maxu(z1_, bb_);
-          const unsigned z3_ = pk_minu(z2_, capv);
-          const unsigned un_ = pk_sub(z3_, vt1[k]);
-          const unsigned vn_ = pk_sub(z3_, U[k]);
-          const unsigned zq_ = pk_sub(z3_, qv);
-          const unsigned xn_ = pk_maxi(pk_sub(a_, zq_), 0u);
-          const unsigned yn_ = pk_maxi(pk_sub(bb_, zq_), 0u);
-          U[k] = act ? un_ : U[k];
-          V[k] = act ? vn_ : V[k];
-          X[k] = act ? xn_ : X[k];
-          Y[k] = act ? yn_ : Y[k];
-          Fa[k] = shl1_or(Fa[k], pk_nonzero(fa_));
-          Fb[k] = shl1_or(Fb[k], pk_nonzero(fb_));
-          Fx[k] = shl1_or(Fx[k], pk_nonzero(xn_));
-          Fy[k] = shl1_or(Fy[k], pk_nonzero(yn_));
-          // H: the top cell (hi0 > 0 here) from the column to its left before this row, the cells below it from
-          // themselves
-          if (!(can_drop || hi0 <= T1 + 1)) continue;  // (wave-uniform; see can_drop)
-          const int32_t vE = (int32_t)((V[k] >> 8) & 0xffu), vO = (int32_t)(V[k] >> 24);
-          const int32_t uE = (int32_t)((U[k] >> 8) & 0xffu), uO = (int32_t)(U[k] >> 24);
-          const unsigned dE = (unsigned)(te - lo0), dO = dE + 1u, span = (unsigned)(hi0 - lo0);
-          const int32_t tE = hleft[k] + uE - sc.qe, tO = He[k] + uO - sc.qe;
-          const int32_t mE = He[k] + vE - sc.qe, mO = Ho[k] + vO - sc.qe;
-          const int32_t nE = dE < span ? mE : dE == span ? tE : He[k];
-          const int32_t nO = dO < span ? mO : dO == span ? tO : Ho[k];
-          He[k] = nE;
-          Ho[k] = nO;
-          if (can_drop) {
-            const bool gE = dE <= span && nE > bHe[k], gO = dO <= span && nO > bHo[k];
-            bHe[k] = gE ? nE : bHe[k];
-            bRe[k] = gE ? r : bRe[k];
-            bHo[k] = gO ? nO : bHo[k];
-            bRo[k] = gO ? r : bRo[k];
-          }
-        }
-        if (!PURE && hi0 == tlen - 1 && hi0 >= T0 && hi0 < T1) {  // the end of the target: mte, score (:259-262)
-          const int st = hi0 - T0;
-          int32_t hv = 0;
+          const bool h_row = (m_hrow >> ri) & 1u;
 #pragma unroll
-          for (int k = 0; k < NREG; ++k)
-            if ((st >> 7) == k) hv = (st & 1) ? __builtin_amdgcn_readlane(Ho[k], (st & 127) >> 1) : __builtin_amdgcn_readlane(He[k], (st & 127) >> 1);
-          if (hv > ez_mte) {
-            ez_mte = hv;
-            ez_mte_q = r - hi;
+          for (int k = 0; k < NREG; ++k) {
+            const int te = T0 + 128 * k + 2 * lane;
+            unsigned keep = te == lo_fix ? 0xffff0000u : 0xffffffffu;
+            SDF_OPQ(keep);
+            xt1[k] &= keep;
+            vt1[k] &= keep;
+            unsigned z = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+            if (has_n) {
+              unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
+              SDF_OPQ(nn);
+              z = (z_wild & nn) | (z & ~nn);
+            }
+            sel_lo_len(S[k], z, a1 - 64 * k, l1, lane);
+            sel_hi_len(S[k], z, a0 - 64 * k, l0, lane);
+            const bool act = (unsigned)(te - lo) <= (unsigned)act_span;
+            const unsigned a_ = pk_add(xt1[k], vt1[k]);
+            const unsigned bb_ = pk_add(Y[k], U[k]);
+            const unsigned z0_ = S[k];
+            const unsigned z1_ = pk_maxi(z0_, a_);
+            const unsigned fa_ = pk_sub(z1_, z0_);
+            const unsigned zb_ = pk_maxi(z1_, bb_);
+            const unsigned fb_ = pk_sub(zb_, z1_);
+            const unsigned z2_ = pk_maxu(z1_, bb_);
+            const unsigned z3_ = pk_minu(z2_, capv);
+            const unsigned un_ = pk_sub(z3_, vt1[k]);
+            const unsigned vn_ = pk_sub(z3_, U[k]);
+            const unsigned zq_ = pk_sub(z3_, qv);
+            const unsigned xn_ = pk_maxi(pk_sub(a_, zq_), 0u);
+            const unsigned yn_ = pk_maxi(pk_sub(bb_, zq_), 0u);
+            U[k] = act ? un_ : U[k];
+            V[k] = act ? vn_ : V[k];
+            X[k] = act ? xn_ : X[k];
+            Y[k] = act ? yn_ : Y[k];
+            Fa[k] = shl1_or(Fa[k], pk_nonzero(fa_));
+            Fb[k] = shl1_or(Fb[k], pk_nonzero(fb_));
+            Fx[k] = shl1_or(Fx[k], pk_nonzero(xn_));
+            Fy[k] = shl1_or(Fy[k], pk_nonzero(yn_));
+            // H: the top cell (hi0 > 0 here) from the column to its left before this row, the cells below it from
+            // themselves
+            if (!h_row) continue;  // (wave-uniform; see can_drop)
+            const int32_t vE = (int32_t)((V[k] >> 8) & 0xffu), vO = (int32_t)(V[k] >> 24);
+            const int32_t uE = (int32_t)((U[k] >> 8) & 0xffu), uO = (int32_t)(U[k] >> 24);
+            const unsigned dE = (unsigned)(te - lo0), dO = dE + 1u;
+            // (every candidate computed on all lanes, then two selects: the compiler would otherwise mask EXEC around each)
+            int32_t tE = hleft[k] + uE - sc.qe, tO = He[k] + uO - sc.qe;
+            int32_t mE = He[k] + vE - sc.qe, mO = Ho[k] + vO - sc.qe;
+            SDF_OPQ(tE);
+            SDF_OPQ(tO);
+            SDF_OPQ(mE);
+            SDF_OPQ(mO);
+            int32_t nE = dE == span ? tE : He[k], nO = dO == span ? tO : Ho[k];
+            nE = dE < span ? mE : nE;
+            nO = dO < span ? mO : nO;
+            He[k] = nE;
+            Ho[k] = nO;
+            if (can_drop) {
+              const bool gE = dE <= span && nE > bHe[k], gO = dO <= span && nO > bHo[k];
+              bHe[k] = gE ? nE : bHe[k];
+              bRe[k] = gE ? rl : bRe[k];
+              bHo[k] = gO ? nO : bHo[k];
+              bRo[k] = gO ? rl : bRo[k];
+            }
           }
-          if (r == nrow - 1) {
-            ez_score = hv;
-            have_score = true;
+          if ((m_end >> ri) & 1u) {  // the end of the target: mte, score (:259-262)
+            const int hi0 = tlen - 1, hi = hi0 | 15;
+            const int st = hi0 - T0;
+            int32_t hv = 0;
+#pragma unroll
+            for (int k = 0; k < NREG; ++k)
+              if ((st >> 7) == k) hv = (st & 1) ? __builtin_amdgcn_readlane(Ho[k], (st & 127) >> 1) : __builtin_amdgcn_readlane(He[k], (st & 127) >> 1);
+            if (hv > ez_mte) {
+              ez_mte = hv;
+              ez_mte_q = rl - hi;
+            }
+            if (rl == nrow - 1) {
+              ez_score = hv;
+              have_score = true;
+            }
+          }
+          if (rl >= out_from) {  // my last column after this row, for the right stripe: lane row & 15 of the two words
+            const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
+            const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;
+            const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
+            // (r0 is a multiple of 16: lane rl & 15 is lane ri; the lane select of v_writelane next to an SGPR value is M0)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+                         : "+v"(out_xv), "+v"(out_h) : "s"(ri), "s"(es), "s"(eh) : "m0");
           }
         }
-        if (has_right && r >= next_a - 1) {
-          const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
-          const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;
-          const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
-          out_xv = lane == (r & 15) ? es : out_xv;
-          out_h = lane == (r & 15) ? eh : out_h;
-        }
+        r = r_end;
       }
-      };
-      {
-        // PURE for the rows left in the block?  (all bounds grow with r: the ends of the range decide)
-        const int rl = re - 1;
-        const bool pure = has_left && r >= w && ((r + w) >> 1 | 15) < r && ((rl - w + 1) >> 1) >= rl - qlen + 1 &&
-                          ((rl + w) >> 1) < tlen - 1 && ((r - w) >> 1) >= 0 && ((rl - w) >> 1) >= rl - qlen;
-#ifdef SDF_BS_NO_LEAN
-        (void)pure;
-#elif defined(SDF_BS_NO_PURE)
-        lean_rows(std::false_type{});
-#else
-        if (pure) lean_rows(std::true_type{});
-        else lean_rows(std::false_type{});
 #endif
-      }
       if (r >= re) break;
       Band bd, bp;
       if (!band_of(r, qlen, tlen, w, bd)) {  // the band has run out (every stripe sees it on the same row)

@@ -123,6 +123,26 @@ __device__ __forceinline__ void sel_hi_rng(unsigned &dst, unsigned src, int lo, 
       : "+v"(dst), "=&v"(t) : "v"(src), "s"(lo), "s"(hi > lo ? hi - lo : 0), "v"(lane) : "vcc");
 }
 
+// (the same with the range as start + length: the caller has the length in a register already)
+__device__ __forceinline__ void sel_lo_len(unsigned &dst, unsigned src, int lo, int len, int lane) {
+  unsigned t;
+  asm volatile(
+      "v_subrev_u32 %1, %3, %5\n\t"
+      "v_cmp_gt_u32 vcc, %4, %1\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %2, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\ts_nop 0"
+      : "+v"(dst), "=&v"(t) : "v"(src), "s"(lo), "s"(len), "v"(lane) : "vcc");
+}
+__device__ __forceinline__ void sel_hi_len(unsigned &dst, unsigned src, int lo, int len, int lane) {
+  unsigned t;
+  asm volatile(
+      "v_subrev_u32 %1, %3, %5\n\t"
+      "v_cmp_gt_u32 vcc, %4, %1\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %2, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1\n\ts_nop 0"
+      : "+v"(dst), "=&v"(t) : "v"(src), "s"(lo), "s"(len), "v"(lane) : "vcc");
+}
+
 // both halves of one register: lo half where thr_lo <= lane, hi half where thr_hi <= lane
 __device__ __forceinline__ void sel2_ge(unsigned &dst, unsigned src, int thr_lo, int thr_hi, int lane) {
   asm volatile(
