@@ -32,6 +32,10 @@
 
 namespace sdf {
 
+#ifndef SDF_BS_FIRST_SLEEP
+#define SDF_BS_FIRST_SLEEP 100
+#endif
+
 struct BStripeGeom {
   int nslot, nst, blocks_cap, col_len;
   size_t flag_bytes;  // per stripe
@@ -204,7 +208,8 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
 #ifdef SDF_STRIPE_TIMING
   const unsigned long long tm_start = __builtin_amdgcn_s_memrealtime();
   unsigned long long tm_first = 0, tm_wait = 0;
-  int n_full = 0, n_lean = 0, n_slow = 0;
+  int n_full = 0, n_top_rows = 0, n_lean = 0, n_slow = 0;  // rows by flavour, and the time spent in each
+  unsigned long long tm_full = 0, tm_top = 0, tm_lean = 0, tm_slow = 0, tm_r256 = 0;
 #endif
   int r_stop = r_z + 1;  // (lowered when the band runs out)
   for (int r0 = r_a & ~15; r0 < r_stop; r0 += 16) {
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
       if (__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u))) {
         __builtin_amdgcn_s_setprio(0);  // (a waiting wavefront must not take issue slots from the one it waits for)
         do {
-          if (first_wait) __builtin_amdgcn_s_sleep(100);
+          if (first_wait) __builtin_amdgcn_s_sleep(SDF_BS_FIRST_SLEEP);
           else __builtin_amdgcn_s_sleep(2);
           feed_load(r0, gx, gh);
           if (!__builtin_amdgcn_readfirstlane((int)__any((gx & 1u) == 0u))) break;
@@ -272,6 +277,10 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
       if (has_left && re > rb && ok_first && ok_last && b_last.lo0 < T0 && b_first.hi0 >= T1 && rb >= next_a - 1) {
 #endif
         const bool full_h = can_drop || b_first.hi0 <= T1 + 1;  // (see can_drop)
+#ifdef SDF_STRIPE_TIMING
+        const unsigned long long tf0 = __builtin_amdgcn_s_memrealtime();
+        n_full += re - r;
+#endif
 #pragma unroll 1
         for (; r < re; ++r) {
           unsigned qc[NREG];
@@ -336,6 +345,9 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
             out_h = lane == (r & 15) ? eh : out_h;
           }
         }
+#ifdef SDF_STRIPE_TIMING
+        tm_full += __builtin_amdgcn_s_memrealtime() - tf0;
+#endif
       }
     }
     // ---- ordinary rows, as long as they last (no border cell: hi < r): lane predicates against the row's band; the
@@ -346,7 +358,8 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     // the row number alone: lane i of a few registers computes them for row r0 + i once per 16-row block, and a row reads
     // its own with one v_readlane each.
     int t_lo = 0, t_fix = 0, t_act = 0, t_a1 = 0, t_l1 = 0, t_a0 = 0, t_l0 = 0, t_lo0 = 0, t_span = 0;
-    unsigned m_stop = 0xffffu, m_moved = 0u, m_hrow = 0u, m_end = 0u;
+    int t_actn = 0, t_b1 = 0, t_b0 = 0;  // (the same ranges as bounds from lane 0, for rows whose band starts left of the stripe)
+    unsigned m_stop = 0xffffu, m_moved = 0u, m_hrow = 0u, m_end = 0u, m_top = 0u;
     if (r < re) {  // (a block of rows on which the band covers the whole stripe is done by now)
       const int rr = r0 + (lane & 15);
       int c_lo0 = (rr - w + 1) >> 1, c_hi0 = (rr + w) >> 1, c_plo = (rr - w) >> 1;
@@ -370,6 +383,10 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
       t_l0 = c_b0 > c_a0 ? c_b0 - c_a0 : 0;
       t_act = c_hi - c_lo;
       t_span = c_hi0 - c_lo0;
+      t_actn = (c_hi + 1 - T0) >> 1;
+      t_b1 = c_b1;
+      t_b0 = c_b0;
+      m_top = (unsigned)__ballot(c_lo0 < T0) & 0xffffu;
       m_stop = (unsigned)__ballot(c_stop) & 0xffffu;
       m_moved = (unsigned)__ballot(c_moved) & 0xffffu;
       m_hrow = can_drop ? 0xffffu : (unsigned)__ballot(c_hi0 <= T1 + 1) & 0xffffu;  // (see can_drop)
@@ -385,13 +402,23 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         int r_end = ahead ? r + __builtin_ctz(ahead) : re;
         r_end = r_end < re ? r_end : re;
         const int out_from = has_right ? next_a - 1 : 0x7fffffff;
+        // TOP: the band starts left of the stripe on every row of the run (the stripe holds the band's upper edge: the rows
+        // of a long task's chain that no other stripe can overlap) -- no first computed cell, no moved window, and every
+        // range starts at lane 0: one bound and one compare each
+        const unsigned not_top = (~m_top & 0xffffu) >> (r - r0);
+        const int n_top = not_top ? __builtin_ctz(not_top) : 16;
+        if (n_top > 0 && r + n_top < r_end) r_end = r + n_top;  // (the rest of the rows: the next turn of the outer loop)
+        auto lean_run = [&](auto top_c) {
+        constexpr bool TOP = decltype(top_c)::value;
 #pragma unroll 1
         for (int rl = r; rl < r_end; ++rl) {
           const int ri = rl - r0;
-          const int lo = __builtin_amdgcn_readlane(t_lo, ri), lo_fix = __builtin_amdgcn_readlane(t_fix, ri);
-          const int act_span = __builtin_amdgcn_readlane(t_act, ri);
-          const int a1 = __builtin_amdgcn_readlane(t_a1, ri), l1 = __builtin_amdgcn_readlane(t_l1, ri);
-          const int a0 = __builtin_amdgcn_readlane(t_a0, ri), l0 = __builtin_amdgcn_readlane(t_l0, ri);
+          const int lo = TOP ? 0 : __builtin_amdgcn_readlane(t_lo, ri), lo_fix = TOP ? 0 : __builtin_amdgcn_readlane(t_fix, ri);
+          const int act_span = TOP ? 0 : __builtin_amdgcn_readlane(t_act, ri);
+          const int a1 = TOP ? 0 : __builtin_amdgcn_readlane(t_a1, ri), l1 = TOP ? 0 : __builtin_amdgcn_readlane(t_l1, ri);
+          const int a0 = TOP ? 0 : __builtin_amdgcn_readlane(t_a0, ri), l0 = TOP ? 0 : __builtin_amdgcn_readlane(t_l0, ri);
+          const int actn = TOP ? __builtin_amdgcn_readlane(t_actn, ri) : 0;
+          const int b1 = TOP ? __builtin_amdgcn_readlane(t_b1, ri) : 0, b0 = TOP ? __builtin_amdgcn_readlane(t_b0, ri) : 0;
           const int lo0 = __builtin_amdgcn_readlane(t_lo0, ri);
           const unsigned span = (unsigned)__builtin_amdgcn_readlane(t_span, ri);
           unsigned qc[NREG];
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
             vt1[k] = __builtin_amdgcn_perm(V[k], ps, 0x05040302u);
           }
           // the first computed cell (lo: an even column), its window not moved: its left neighbour reads as 0 (lo_fix)
-          if ((m_moved >> ri) & 1u) {  // moved (one row in 32): the slot to the left as it is, and a negative byte there also
+          if (!TOP && ((m_moved >> ri) & 1u)) {  // moved (one row in 32): the slot to the left as it is, and a negative byte there also
                                        // sets the next three cells (the reference's sign extension, :145-146)
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
@@ -449,19 +476,26 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
 #pragma unroll
           for (int k = 0; k < NREG; ++k) {
             const int te = T0 + 128 * k + 2 * lane;
-            unsigned keep = te == lo_fix ? 0xffff0000u : 0xffffffffu;
-            SDF_OPQ(keep);
-            xt1[k] &= keep;
-            vt1[k] &= keep;
+            if (!TOP) {
+              unsigned keep = te == lo_fix ? 0xffff0000u : 0xffffffffu;
+              SDF_OPQ(keep);
+              xt1[k] &= keep;
+              vt1[k] &= keep;
+            }
             unsigned z = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
             if (has_n) {
               unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
               SDF_OPQ(nn);
               z = (z_wild & nn) | (z & ~nn);
             }
-            sel_lo_len(S[k], z, a1 - 64 * k, l1, lane);
-            sel_hi_len(S[k], z, a0 - 64 * k, l0, lane);
-            const bool act = (unsigned)(te - lo) <= (unsigned)act_span;
+            if (TOP) {
+              sel_lo_below(S[k], z, b1 - 64 * k, lane);
+              sel_hi_below(S[k], z, b0 - 64 * k, lane);
+            } else {
+              sel_lo_len(S[k], z, a1 - 64 * k, l1, lane);
+              sel_hi_len(S[k], z, a0 - 64 * k, l0, lane);
+            }
+            const bool act = TOP ? lane < actn - 64 * k : (unsigned)(te - lo) <= (unsigned)act_span;
             const unsigned a_ = pk_add(xt1[k], vt1[k]);
             const unsigned bb_ = pk_add(Y[k], U[k]);
             const unsigned z0_ = S[k];
@@ -530,15 +564,39 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
             const unsigned ew = __builtin_amdgcn_perm(V[KT], X[KT], 0x07060302u);
             const unsigned es = (unsigned)__builtin_amdgcn_readlane((int)ew, 63) | 1u;
             const unsigned eh = (unsigned)__builtin_amdgcn_readlane(Ho[KT], 63);
-            // (r0 is a multiple of 16: lane rl & 15 is lane ri; the lane select of v_writelane next to an SGPR value is M0)
+            // (r0 is a multiple of 16: lane rl & 15 is lane ri; the lane select of v_writelane next to an SGPR value is M0,
+            // which nothing else in this kernel uses)
+            uint32_t ox = out_xv, oh = out_h;  // (locals: the operands of an asm statement inside a generic lambda)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 1\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
-                         : "+v"(out_xv), "+v"(out_h) : "s"(ri), "s"(es), "s"(eh) : "m0");
+                         : "+v"(ox), "+v"(oh) : "s"(ri), "s"(es), "s"(eh) : "m0");
+#pragma clang diagnostic pop
+            out_xv = ox;
+            out_h = oh;
           }
         }
+        };
+#ifdef SDF_STRIPE_TIMING
+        const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+        if (n_top > 0) n_top_rows += r_end - r;
+        else n_lean += r_end - r;
+#endif
+        if (n_top > 0) lean_run(std::true_type{});
+        else lean_run(std::false_type{});
+#ifdef SDF_STRIPE_TIMING
+        if (n_top > 0) tm_top += __builtin_amdgcn_s_memrealtime() - tl0;
+        else tm_lean += __builtin_amdgcn_s_memrealtime() - tl0;
+        if (r <= r_a + 256 && r_end > r_a + 256) tm_r256 = __builtin_amdgcn_s_memrealtime();
+#endif
         r = r_end;
       }
 #endif
       if (r >= re) break;
+#ifdef SDF_STRIPE_TIMING
+      const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+      ++n_slow;
+#endif
       Band bd, bp;
       if (!band_of(r, qlen, tlen, w, bd)) {  // the band has run out (every stripe sees it on the same row)
         r_stop = r;
@@ -715,6 +773,9 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         out_xv = lane == (r & 15) ? es : out_xv;
         out_h = lane == (r & 15) ? eh : out_h;
       }
+#ifdef SDF_STRIPE_TIMING
+      tm_slow += __builtin_amdgcn_s_memrealtime() - ts0;
+#endif
     }
     // ---- block end: direction flags and edge words of these rows leave for HBM ----
     const int done_hi = r - 1;  // last row done in this block
@@ -736,8 +797,9 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   }
 #ifdef SDF_STRIPE_TIMING
   if (lane == 0 && (sb % 8 == 0 || sb == g.nst - 1))
-    printf("bstripe %d rows %d..%d start %llu first %llu end %llu wait %llu\n", sb, r_a, r_stop - 1, tm_start, tm_first,
-           (unsigned long long)__builtin_amdgcn_s_memrealtime(), tm_wait);
+    printf("bstripe %d rows %d..%d start %llu first %llu r256 %llu end %llu wait %llu | full %d rows %llu, top %d rows %llu, edge %d rows %llu, general %d rows %llu\n",
+           sb, r_a, r_stop - 1, tm_start, tm_first, tm_r256, (unsigned long long)__builtin_amdgcn_s_memrealtime(), tm_wait, n_full, tm_full,
+           n_top_rows, tm_top, n_lean, tm_lean, n_slow, tm_slow);
 #endif
   // the right stripe may read my last column for a few rows after my last one: the final state, repeated
   if (has_right) {

@@ -143,6 +143,22 @@ __device__ __forceinline__ void sel_hi_len(unsigned &dst, unsigned src, int lo, 
       : "+v"(dst), "=&v"(t) : "v"(src), "s"(lo), "s"(len), "v"(lane) : "vcc");
 }
 
+// (the range [0, bound): one signed compare)
+__device__ __forceinline__ void sel_lo_below(unsigned &dst, unsigned src, int bound, int lane) {
+  asm volatile(
+      "v_cmp_gt_i32 vcc, %2, %3\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 "
+      "src1_sel:WORD_0\n\ts_nop 0"
+      : "+v"(dst) : "v"(src), "s"(bound), "v"(lane) : "vcc");
+}
+__device__ __forceinline__ void sel_hi_below(unsigned &dst, unsigned src, int bound, int lane) {
+  asm volatile(
+      "v_cmp_gt_i32 vcc, %2, %3\n\t"
+      "v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 "
+      "src1_sel:WORD_1\n\ts_nop 0"
+      : "+v"(dst) : "v"(src), "s"(bound), "v"(lane) : "vcc");
+}
+
 // both halves of one register: lo half where thr_lo <= lane, hi half where thr_hi <= lane
 __device__ __forceinline__ void sel2_ge(unsigned &dst, unsigned src, int thr_lo, int thr_hi, int lane) {
   asm volatile(
