@@ -63,7 +63,18 @@ int count_matches(const char *a, const char *b, const Cigar &cg) {
 Params g_score_params;  // Align::MATCH etc. are process-wide in the reference (src/globals.cc:25-28)
 }  // namespace
 
-void set_alignment_scoring(const Params &p) { g_score_params = p; }
+void set_alignment_scoring(const Params &p) {
+  // (several buckets of one process run side by side with the same scoring: no write once it is in place)
+  const Params &g = g_score_params;
+  if (g.match == p.match && g.mismatch == p.mismatch && g.gap_open == p.gap_open && g.gap_extend == p.gap_extend &&
+      g.max_ksw_seq_len == p.max_ksw_seq_len && g.kmer == p.kmer && g.min_uppercase_match == p.min_uppercase_match &&
+      g.match_chain_score == p.match_chain_score && g.max_chain_gap == p.max_chain_gap && g.refine_match == p.refine_match &&
+      g.refine_mismatch == p.refine_mismatch && g.refine_gap == p.refine_gap && g.refine_gapopen == p.refine_gapopen &&
+      g.refine_min_read == p.refine_min_read && g.refine_side_align == p.refine_side_align &&
+      g.refine_max_gap == p.refine_max_gap && g.min_read_size == p.min_read_size && g.max_error == p.max_error)
+    return;
+  g_score_params = p;
+}
 char align_dna(char c) { return kDna.align[(unsigned char)c & 127]; }
 char hash_dna(char c) { return kDna.hash[(unsigned char)c & 127]; }
 

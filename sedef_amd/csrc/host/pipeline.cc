@@ -378,6 +378,8 @@ class TestProvider : public DpProvider {
     }
     return out;
   }
+  // (lanes of super-batches and of buckets work with the hook as with the device: the hook is re-entrant)
+  std::unique_ptr<DpProvider> clone(int /*device*/ = -1) override { return std::unique_ptr<DpProvider>(new TestProvider(fn_)); }
 
  private:
   test_dp_fn fn_;
@@ -789,6 +791,7 @@ StageSettings StageSettings::from_env() {
   s.host_threads = (int)num("SDF_HOST_THREADS", 0, 4096, 0);
   if (const char *e = getenv("SDF_STAGE_WS_GIB")) s.stage_ws_gib = atof(e) > 0 ? atof(e) : 0;
   s.debug_timing = getenv("SDF_DEBUG_TIMING") != nullptr;
+  s.bucket_lanes = (int)num("SDF_BUCKET_LANES", 1, 4, 2);
   if (const char *e = getenv("SDF_DEVICES"))
     for (const char *c = e; *c;) {
       char *end = nullptr;
@@ -1316,12 +1319,104 @@ StageHint stage_hint_many(const std::vector<std::string> &beds, int super_batch)
     all.super_batch = std::max(all.super_batch, h.super_batch);
     all.max_batch_bytes = std::max(all.max_batch_bytes, h.max_batch_bytes);
   }
+  // (one-lane buckets run SDF_BUCKET_LANES at a time, generate_many: a provider each)
+  if (all.lanes <= 1 && beds.size() >= 2 && stage_settings().bucket_lanes > 1)
+    all.lanes = (int)std::min<size_t>((size_t)stage_settings().bucket_lanes, beds.size());
   return all;
 }
 
 std::vector<GenerateStats> generate_many(const std::string &ref_path, const std::vector<std::string> &beds, int kmer_size,
                                          const Params &p, DpProvider &dp, const std::string &out_suffix,
                                          const std::string &log_dir, FILE *log, int super_batch) {
+  // One bucket's phases use the host and the device in turn (sequence fetch, anchors, ~65 ms of chaining on all threads, DP
+  // rounds, output): with several one-lane buckets to do, SDF_BUCKET_LANES of them (default 2) are in flight, each on a
+  // provider -- a device context -- of its own, taking buckets as they go.  A bucket's output file and log are its own,
+  // its lines are what a process of its own writes; the order of the "Finished" lines on the shared log is the order of
+  // completion.  (Buckets large enough for several lanes of super-batches run one after the other: their lanes fill the gaps.)
+  size_t conc = 1;
+  if (beds.size() >= 2 && stage_settings().bucket_lanes > 1) {
+    bool one_lane = true;
+    for (const std::string &bed : beds) one_lane = one_lane && stage_hint(bed, super_batch).lanes <= 1;
+    if (one_lane) conc = std::min<size_t>((size_t)stage_settings().bucket_lanes, beds.size());
+  }
+  if (conc > 1) {
+    Params pk = p;
+    pk.kmer = kmer_size;
+    set_alignment_scoring(pk);  // (before the threads: generate_alignments finds it in place)
+    std::vector<GenerateStats> all(beds.size());
+    std::vector<std::unique_ptr<DpProvider>> extra(conc);
+    std::atomic<size_t> next(0);
+    std::mutex mu;
+    std::string failure;
+    bool failed = false;
+    auto run_lane = [&](size_t l) {
+      DpProvider *d = &dp;
+      if (l > 0) {
+        try {
+          extra[l] = dp.clone(-1);
+        } catch (std::string &) {  // (no room for another device context: one bucket lane fewer)
+        }
+        d = extra[l].get();
+        if (!d) return;
+      }
+      for (;;) {
+        const size_t bi = next.fetch_add(1);
+        if (bi >= beds.size()) return;
+        {
+          std::lock_guard<std::mutex> g(mu);
+          if (failed) return;
+        }
+        const std::string &bed = beds[bi];
+        const std::string out_path = bed + out_suffix;
+        FILE *out = fopen(out_path.c_str(), "w");
+        FILE *blog = nullptr;
+        std::string err;
+        if (!out) err = std::string("Cannot open file ") + out_path + " for writing";
+        if (err.empty() && !log_dir.empty()) {
+          const size_t slash = bed.find_last_of('/');
+          const std::string lp = log_dir + "/" + (slash == std::string::npos ? bed : bed.substr(slash + 1)) + ".log";
+          blog = fopen(lp.c_str(), "w");
+          if (!blog) err = std::string("Cannot open file ") + lp + " for writing";
+        }
+        // (without --log-dir the buckets' own progress lines would interleave on the shared log: they go to a buffer that is
+        // written in one piece when the bucket is done)
+        char *membuf = nullptr;
+        size_t memlen = 0;
+        FILE *mlog = (!blog && err.empty()) ? open_memstream(&membuf, &memlen) : nullptr;
+        if (err.empty()) {
+          try {
+            all[bi] = generate_alignments(ref_path, bed, kmer_size, p, *d, out, blog ? blog : mlog ? mlog : log, super_batch);
+          } catch (std::string &e) {
+            err = e.empty() ? std::string("error") : e;
+          } catch (std::exception &e) {
+            err = e.what();
+          }
+        }
+        if (out) fclose(out);
+        if (blog) fclose(blog);
+        if (mlog) fclose(mlog);
+        std::lock_guard<std::mutex> g(mu);
+        if (membuf) {
+          if (memlen) fwrite(membuf, 1, memlen, log);
+          free(membuf);
+        }
+        if (!err.empty()) {
+          if (!failed) failure = err;
+          failed = true;
+          return;
+        }
+        if (blog) fprintf(log, "Finished BED %s (%d lines, generated %d hits)\n", bed.c_str(), all[bi].lines, all[bi].total_written);
+      }
+    };
+    std::vector<std::thread> lanes;
+    for (size_t l = 1; l < conc; l++) lanes.emplace_back(run_lane, l);
+    run_lane(0);
+    for (auto &t : lanes) t.join();
+    for (auto &e : extra)
+      if (e) dp.give_back(std::move(e));
+    if (failed) throw failure;
+    return all;
+  }
   std::vector<GenerateStats> all;
   for (const std::string &bed : beds) {
     const std::string out_path = bed + out_suffix;

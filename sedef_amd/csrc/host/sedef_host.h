@@ -400,6 +400,7 @@ struct StageSettings {
   int host_threads = 0;      // SDF_HOST_THREADS: threads of the per-pair host work (0: the CPUs the process may use, at most 64)
   double stage_ws_gib = 0;   // SDF_STAGE_WS_GIB: direction-flag workspace per lane (0: 8 GiB per process shared out)
   bool debug_timing = false; // SDF_DEBUG_TIMING: one line per phase of every super-batch
+  int bucket_lanes = 2;      // SDF_BUCKET_LANES: buckets of a several-bucket run in flight, each on a device context of its own (1: one after the other)
   static StageSettings from_env();
 };
 const StageSettings &stage_settings();             // the current run's

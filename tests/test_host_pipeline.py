@@ -320,6 +320,24 @@ def test_several_buckets_in_one_run_equal_one_bucket_runs(host, oracle_dp, tmp_p
     assert st2 == st and [open(b + ".aligned.bed").read() for b in buckets] == want
 
 
+@pytest.mark.parametrize("lanes", ["1", "2", "3"])
+def test_buckets_in_flight_write_what_one_after_the_other_writes(host, oracle_dp, tmp_path, monkeypatch, lanes):
+    """SDF_BUCKET_LANES buckets of a several-bucket run are in flight at a time, each on a provider of its own (default 2):
+    every bucket's file and the per-bucket figures are those of buckets done one after the other; without --log-dir each
+    bucket's log lines reach the shared log in one piece."""
+    fa, out, buckets = _buckets(host, tmp_path, seed=21, nsd=16, nb=5)
+    want = []
+    for b in buckets:
+        host.generate(fa, b, 11, b + ".single", test_dp=oracle_dp)
+        want.append(open(b + ".single").read())
+    assert sum(len(w) for w in want) > 0
+    monkeypatch.setenv("SDF_BUCKET_LANES", lanes)
+    st = host.generate_many(fa, buckets, 11, test_dp=oracle_dp)
+    assert [open(b + ".aligned.bed").read() for b in buckets] == want
+    assert [x[0] for x in st] == [sum(1 for _ in open(b)) for b in buckets]
+    assert [x[1] for x in st] == [w.count("\n") for w in want]
+
+
 @pytest.mark.gpu
 def test_cli_several_buckets_one_process_gpu(host, tmp_path):
     """`sedef align generate -k 11 genome.fa bucket_0000 bucket_0001 ...` and `... genome.fa align/`: one process, lanes and
@@ -336,7 +354,8 @@ def test_cli_several_buckets_one_process_gpu(host, tmp_path):
     assert sum(len(w) for w in want) > 0
     logs = tmp_path / "logs"
     logs.mkdir()
-    for args, e in ((buckets, env), ([str(out)], dict(env, SDF_LANES="3", SDF_SUPER_BATCH="2"))):
+    for args, e in ((buckets, env), ([str(out)], dict(env, SDF_LANES="3", SDF_SUPER_BATCH="2")),
+                    (buckets, dict(env, SDF_BUCKET_LANES="1")), ([str(out)], dict(env, SDF_BUCKET_LANES="3"))):
         for b in buckets:
             if os.path.exists(b + ".aligned.bed"):
                 os.remove(b + ".aligned.bed")
