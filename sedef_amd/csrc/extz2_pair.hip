@@ -508,8 +508,8 @@ __device__ __forceinline__ void pair_body(
           unsigned z;
           SDF_PFRESH(z, Tc[k], qcur[k], HASN)
           if (NREG == 1) S[0] = in_mask(lane_mask(ra, b_)) ? z : S[0];
-          else if (k == 0) S[0] = in_mask(lane_mask(ra, 64)) ? z : S[0];
-          else if (k == KT) S[k] = in_mask(lane_mask(0, b_)) ? z : S[k];
+          else if (k == 0) S[0] = in_mask(~0ull << ra) ? z : S[0];  // (steady: 0 <= ra < 32 -- one scalar shift, not lane_mask's six)
+          else if (k == KT) S[k] = in_mask(b_ <= 0 ? 0ull : ~0ull >> (64 - (b_ < 64 ? b_ : 64))) ? z : S[k];
           else S[k] = z;
         } else if (b_ > 0) {
           unsigned z;
