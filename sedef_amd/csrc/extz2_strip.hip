@@ -172,18 +172,22 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
           const unsigned nn = ((TC[k] | qc) >> 2) & 0x00010001u;
           z = pk_mad(nn, pk_sub(ZW2, z), z);
         }
+        // Round 5: the sums and differences are plain 32-bit adds and subtracts.  gfx950 issues v_add_u32 / v_sub_u32 in ~2.3
+        // cycles and every v_pk_* in ~4.2 (profiles/r05_ubench_valu_ops.txt), and on THIS kernel's values they are exact on both
+        // halves: every byte of the state is in 0..127 (tame scoring, full band: the header), so no sum carries out of a half,
+        // and every difference taken here is of a value and something it was maximised over or that the recurrence keeps below
+        // it (z1 - z, z2 - z1; u = z - v >= 0, v = z - u >= 0; z - q >= 0: mismatch + q + 2 e >= 0 is part of strip_ok), so none
+        // borrows.  The two that can go negative, a - (z - q) and b - (z - q), are max(., z - q) - (z - q) instead of max(. - ., 0).
         const unsigned uo = U[k];
-        unsigned a = pk_add(x, v), b = pk_add(Y[k], uo);
+        const unsigned a = x + v, b = Y[k] + uo;
         const unsigned z1 = pk_maxu(z, a);  // ties: diagonal before E before F (:173-178)
         const unsigned z2 = pk_maxu(z1, b);
-        const unsigned fa = pk_minu(pk_sub(z1, z), one2), fb = pk_minu(pk_sub(z2, z1), one2);
+        const unsigned fa = pk_minu(z1 - z, one2), fb = pk_minu(z2 - z1, one2);
         const unsigned z3 = pk_minu(z2, CAP2);
-        const unsigned un = pk_sub(z3, v), vn = pk_sub(z3, uo);
-        const unsigned zq = pk_sub(z3, Q2);
-        a = pk_sub(a, zq);
-        b = pk_sub(b, zq);
-        x = pk_maxi(a, 0u);
-        const unsigned yn = pk_maxi(b, 0u);
+        const unsigned un = z3 - v, vn = z3 - uo;
+        const unsigned zq = z3 - Q2;
+        x = pk_maxu(a, zq) - zq;
+        const unsigned yn = pk_maxu(b, zq) - zq;
         Fa = pk_mad(Fa, two2, fa);
         Fb = pk_mad(Fb, two2, fb);
         Fx = pk_mad(Fx, two2, pk_minu(x, one2));

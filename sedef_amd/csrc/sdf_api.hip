@@ -477,8 +477,9 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     env.strip_always = ctx->strip_always;
     env.strip_cols = ctx->strip_cols;
     env.chain_min = ctx->chain_min;
+    // (zx - q >= 0: the strip kernels take z - q with a 32-bit subtract on packed halves, extz2_strip.hip)
     env.strip_ok = ctx->strip_enabled && !ctx->force_general && !env.degenerate && sc->gapo >= 0 && sc->gape >= 0 && zm >= 0 &&
-                   zm <= 127 && zx >= 0 && zx <= 127;
+                   zm <= 127 && zx >= 0 && zx <= 127 && zx - sc->gapo >= 0 && sc->mat[0] >= 0;
     if (env.lane_ok) {
       SDF_HIP(ctx->host_lane.reserve(n * sizeof(LaneRec)));
       env.lane_recs = (LaneRec *)ctx->host_lane.p;
