@@ -612,6 +612,10 @@ def test_strip_kernel_other_scorings(strip_engine, oracle):
             ma, mi, go, ge = 5, -4, 60, 1  # cap = 127
         if it == 1:
             ma, mi, go, ge = 5, -4, 61, 1  # not tame: the stripe kernels
+        if it == 2:
+            ma, mi, go, ge = 5, -10, 10, 0  # mismatch + q + 2 e = 0: the last scoring whose z - q the strips may take with a 32-bit subtract
+        if it == 3:
+            ma, mi, go, ge = 5, -11, 10, 0  # ... and the first that keeps to the window kernels (tame, but z - q can be -1)
         pairs = _strip_pairs(rng, 36)
         _check_fast(engine, oracle, pairs, [-1] * len(pairs), mat=sedef_mat(ma, mi), gapo=go, gape=ge)
 
