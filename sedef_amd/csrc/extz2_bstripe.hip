@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
             vt1[k] = __builtin_amdgcn_perm(V[k], ps, 0x05040302u);
           }
 #pragma unroll
-          for (int k = 0; k < NREG; ++k) S[k] = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+          for (int k = 0; k < NREG; ++k) S[k] = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
           if (has_n) {
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
               xt1[k] &= keep;
               vt1[k] &= keep;
             }
-            unsigned z = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+            unsigned z = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
             if (has_n) {
               unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
               SDF_OPQ(nn);
@@ -500,14 +500,14 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
             const unsigned bb_ = pk_add(Y[k], U[k]);
             const unsigned z0_ = S[k];
             const unsigned z1_ = pk_maxi(z0_, a_);
-            const unsigned fa_ = pk_sub(z1_, z0_);
+            const unsigned fa_ = z1_ - z0_;  // (32-bit: never borrows, see SDF_CORE)
             const unsigned zb_ = pk_maxi(z1_, bb_);
-            const unsigned fb_ = pk_sub(zb_, z1_);
+            const unsigned fb_ = zb_ - z1_;
             const unsigned z2_ = pk_maxu(z1_, bb_);
             const unsigned z3_ = pk_minu(z2_, capv);
             const unsigned un_ = pk_sub(z3_, vt1[k]);
             const unsigned vn_ = pk_sub(z3_, U[k]);
-            const unsigned zq_ = pk_sub(z3_, qv);
+            const unsigned zq_ = z3_ - qv;
             const unsigned xn_ = pk_maxi(pk_sub(a_, zq_), 0u);
             const unsigned yn_ = pk_maxi(pk_sub(bb_, zq_), 0u);
             U[k] = act ? un_ : U[k];
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         }
         // scores: refreshed in 16-cell strides from lo0 (:124-138)
         {
-          unsigned z = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+          unsigned z = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
           if (has_n) {
             unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
             SDF_OPQ(nn);
@@ -708,14 +708,14 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           const unsigned bb_ = pk_add(Y[k], U[k]);
           const unsigned z0_ = S[k];
           const unsigned z1_ = pk_maxi(z0_, a_);
-          const unsigned fa_ = pk_sub(z1_, z0_);
+          const unsigned fa_ = z1_ - z0_;  // (32-bit: never borrows, see SDF_CORE)
           const unsigned zb_ = pk_maxi(z1_, bb_);
-          const unsigned fb_ = pk_sub(zb_, z1_);
+          const unsigned fb_ = zb_ - z1_;
           const unsigned z2_ = pk_maxu(z1_, bb_);
           const unsigned z3_ = pk_minu(z2_, capv);
           const unsigned un_ = pk_sub(z3_, vt1);
           const unsigned vn_ = pk_sub(z3_, U[k]);
-          const unsigned zq_ = pk_sub(z3_, qv);
+          const unsigned zq_ = z3_ - qv;
           const unsigned xn_ = pk_maxi(pk_sub(a_, zq_), 0u);
           const unsigned yn_ = pk_maxi(pk_sub(bb_, zq_), 0u);
           U[k] = act ? un_ : U[k];

@@ -74,7 +74,7 @@ __host__ __device__ inline int pair_qcap(int qlen, int nreg) {
 #define SDF_PFRESH(z, tc, qword, WITH_N)                                \
   {                                                                     \
     const unsigned qc_ = (qword);                                       \
-    const unsigned d_ = pk_sub(tc, qc_);                                \
+    const unsigned d_ = (tc) ^ qc_; /* != 0 <=> the codes differ */     \
     const unsigned m_ = pk_nonzero(d_);                                 \
     z = pk_mad(m_, z_delta, z_match_v);                                 \
     if (WITH_N) {                                                       \

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
       }
       // scores of the row's cells
 #pragma unroll
-      for (int k = KLO; k <= KHI; ++k) S[k] = pk_mad(pk_nonzero(pk_sub(Tc[k], qc[k])), z_delta, z_match_v);
+      for (int k = KLO; k <= KHI; ++k) S[k] = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
       if (has_n) {
 #pragma unroll
         for (int k = KLO; k <= KHI; ++k) {

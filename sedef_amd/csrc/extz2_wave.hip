@@ -190,20 +190,26 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
 
 // One anti-diagonal step of the recurrence for packed register k (two cells per lane), in the
 // <<8 int16 domain; appends the four direction flags to the accumulators.
+// Round 5: three of its differences are 32-bit subtracts (v_sub_u32: ~2.3 cycles against ~4.2 for v_pk_sub_i16,
+// profiles/r05_ubench_valu_ops.txt).  They are exact on the packed halves for EVERY cell, the artefact cells of a band's
+// edges included, because they never borrow: the score register only ever holds fresh scores z0 = (score + 2 (q + e)) << 8
+// with q <= z0 >> 8 <= 127 (sdf_api.hip: core32_ok -- other scorings run on the general kernel), z1 = max_i(z0, a) is z0 or a
+// larger non-negative value, zb = max_i(z1, b) likewise, and z3 = min_u(max_u(z1, b), cap) >= min(z1, cap) >= q << 8.  The
+// other sums and differences involve u and v, which ARE negative in those cells: they keep the packed forms.
 #define SDF_CORE(k)                                                     \
   {                                                                     \
     const unsigned a_ = pk_add(xt1[k], vt1[k]);                         \
     const unsigned bb_ = pk_add(Y[k], U[k]);                            \
     const unsigned z0_ = S[k];                                          \
     const unsigned z1_ = pk_maxi(z0_, a_);                              \
-    const unsigned fa_ = pk_sub(z1_, z0_); /* != 0 <=> a > z (signed) */ \
+    const unsigned fa_ = z1_ - z0_; /* != 0 <=> a > z (signed); no borrow: z1 >= z0 >= 0 */ \
     const unsigned zb_ = pk_maxi(z1_, bb_);                             \
-    const unsigned fb_ = pk_sub(zb_, z1_); /* != 0 <=> b > max(z,a) */  \
+    const unsigned fb_ = zb_ - z1_; /* != 0 <=> b > max(z,a); no borrow */ \
     const unsigned z2_ = pk_maxu(z1_, bb_);                             \
     const unsigned z3_ = pk_minu(z2_, capv);                            \
     const unsigned un_ = pk_sub(z3_, vt1[k]);                           \
     const unsigned vn_ = pk_sub(z3_, U[k]);                             \
-    const unsigned zq_ = pk_sub(z3_, qv);                               \
+    const unsigned zq_ = z3_ - qv; /* no borrow: z3 >= q << 8 */         \
     const unsigned a2_ = pk_sub(a_, zq_);                               \
     const unsigned b2_ = pk_sub(bb_, zq_);                              \
     const unsigned xn_ = pk_maxi(a2_, 0u);                              \
@@ -222,7 +228,7 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
 #define SDF_FRESH(z, tc, qraw)                                          \
   {                                                                     \
     const unsigned qc_ = __builtin_amdgcn_perm(0u, (qraw), 0x0c010c00u); /* bytes -> halves */ \
-    const unsigned d_ = pk_sub(tc, qc_);                                \
+    const unsigned d_ = (tc) ^ qc_; /* != 0 <=> the codes differ */     \
     const unsigned m_ = pk_nonzero(d_);                                 \
     z = pk_mad(m_, z_delta, z_match_v);                                 \
     if (has_n) {                                                        \

@@ -460,6 +460,15 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   env.gapo = sc->gapo;
   env.max_dyn_lds = ctx->max_dyn_lds;
   env.force_general = ctx->force_general;
+  {
+    // The register-resident window kernels take three differences of the recurrence with 32-bit subtracts (extz2_wave.hip:
+    // SDF_CORE), which needs every fresh score byte z0 = score + 2 (q + e) in q .. 127: SEDEF's scoring and every sane one.
+    // Anything else -- bytes that wrap, a mismatch below -(q + 2 e) -- runs on the general kernel, which emulates the
+    // reference's bytes one by one.
+    const int qe2 = 2 * (sc->gapo + sc->gape), zm = sc->mat[0] + qe2, zx = sc->mat[1] + qe2;
+    const bool core32_ok = sc->gapo >= 0 && sc->gape >= 0 && zm <= 127 && zx <= 127 && zm >= sc->gapo && zx >= sc->gapo;
+    if (!core32_ok) env.force_general = true;
+  }
   env.no_pair = ctx->no_pair;
   env.self_pair_max = ctx->self_pair_max;
   env.no_mixed = ctx->no_mixed;
