@@ -383,6 +383,7 @@ def encoding_split():
     d = json.load(open(p))
     row = d.get("steady_row") or {}
     return {"valu_per_row_of_two_tasks": row.get("valu"), "by_encoding": row.get("by_encoding"),
+            "by_measured_issue_class": row.get("issue_class"),  # (profiles/r05_ubench_valu_ops.txt: ~2.3 and ~4.2 cycles)
             "source": "committed profile: profiles/pair_kernel_isa.json (profiles/isa_split.py on the device assembly)"}
 
 

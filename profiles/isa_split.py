@@ -13,6 +13,8 @@ VOP2 = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xo
         "v_lshrrev_b32", "v_ashrrev_i32", "v_min_u32", "v_max_u32", "v_min_i32", "v_max_i32", "v_add_co_u32", "v_addc_co_u32",
         "v_mul_u32_u24", "v_add_u16", "v_sub_u16", "v_max_u16", "v_min_u16", "v_max_i16", "v_min_i16", "v_lshlrev_b16"}
 VOP1 = {"v_mov_b32", "v_not_b32", "v_bfrev_b32", "v_readfirstlane_b32"}
+FAST = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_mov_b32",
+        "v_add_u16", "v_sub_u16", "v_subrev_u16", "v_max_i16", "v_max_u16", "v_min_i16", "v_min_u16", "v_not_b32"}
 
 
 def klass(ins, ops):
@@ -76,12 +78,23 @@ def main():
         valu = sum(v for k_, v in cnt.items() if k_.startswith("VALU"))
         if valu < 40:
             continue
+        # issue class by the measured cost (profiles/r05_ubench_valu_ops.txt): ~2.3 cycles for 32-bit add / sub / logic / right
+        # shifts / moves and the 16-bit VOP2 forms without a scalar operand, ~4.2 for everything else
+        fast = 0
+        for op, ops in ins[a:b + 1]:
+            base = op.replace("_e32", "").replace("_e64", "")
+            if base in FAST and "dpp" not in op and "sdwa" not in op and "row_" not in ops and "_sel" not in ops and \
+                    not re.search(r"\bs\d+|\bs\[|vcc", ops):
+                fast += 1
         out["innermost_loops"].append({"instructions": b - a + 1, "valu": valu, "by_encoding": cnt,
+                                       "issue_class": {"2.3_cycles": fast, "4.2_cycles": valu - fast,
+                                                       "model_cycles_per_row": round(fast * 2.3 + (valu - fast) * 4.2, 1)},
                                        "v_readlane": sum(1 for x in names if x.startswith("v_readlane")),
                                        "v_pk": sum(1 for x in names if x.startswith("v_pk_"))})
-    # the steady regime (every register of the window active: >= 60 packed instructions), without the N handling
-    # the headline batch does not need: the shortest such loop
-    steady = [l for l in out["innermost_loops"] if l["v_readlane"] == 0 and l["v_pk"] >= 60 and
+    # the steady regime (every register of the window active: >= 50 packed instructions -- 66 until three differences per
+    # register became 32-bit subtracts and the code comparison an xor, round 5), without the N handling the headline batch
+    # does not need: the shortest such loop
+    steady = [l for l in out["innermost_loops"] if l["v_readlane"] == 0 and l["v_pk"] >= 50 and
               l["by_encoding"].get("VALU DPP (8-byte)", 0) >= 10]
     steady.sort(key=lambda l: l["instructions"])
     if steady:

@@ -372,6 +372,17 @@ int make_scorek(sdf_ctx *ctx, const sdf_scoring *sc, ScoreK &k, bool &degenerate
   return SDF_OK;
 }
 
+// The scoring's share of the planning environment (the batch entry points and sdf_debug_plan).
+// The register-resident window kernels take three differences of the recurrence with 32-bit subtracts (extz2_wave.hip:
+// SDF_CORE), which needs every fresh score byte z0 = score + 2 (q + e) in q .. 127: SEDEF's scoring and every sane one.
+// Anything else -- bytes that wrap, a mismatch below -(q + 2 e) -- runs on the general kernel, which emulates the reference's
+// bytes one by one.
+static void scoring_gates(const sdf_scoring *sc, PlanEnv &env) {
+  const int qe2 = 2 * (sc->gapo + sc->gape), zm = sc->mat[0] + qe2, zx = sc->mat[1] + qe2;
+  const bool core32_ok = sc->gapo >= 0 && sc->gape >= 0 && zm <= 127 && zx <= 127 && zm >= sc->gapo && zx >= sc->gapo;
+  if (!core32_ok) env.force_general = true;
+}
+
 // Plans the chunks of a cut, in launch order, on `nthreads` worker threads; wait(ci) blocks until chunk ci is planned.
 // With nthreads == 0 wait(ci) plans the chunk itself (small batches: nothing to overlap with).
 class ChunkPlanner {
@@ -460,15 +471,7 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   env.gapo = sc->gapo;
   env.max_dyn_lds = ctx->max_dyn_lds;
   env.force_general = ctx->force_general;
-  {
-    // The register-resident window kernels take three differences of the recurrence with 32-bit subtracts (extz2_wave.hip:
-    // SDF_CORE), which needs every fresh score byte z0 = score + 2 (q + e) in q .. 127: SEDEF's scoring and every sane one.
-    // Anything else -- bytes that wrap, a mismatch below -(q + 2 e) -- runs on the general kernel, which emulates the
-    // reference's bytes one by one.
-    const int qe2 = 2 * (sc->gapo + sc->gape), zm = sc->mat[0] + qe2, zx = sc->mat[1] + qe2;
-    const bool core32_ok = sc->gapo >= 0 && sc->gape >= 0 && zm <= 127 && zx <= 127 && zm >= sc->gapo && zx >= sc->gapo;
-    if (!core32_ok) env.force_general = true;
-  }
+  scoring_gates(sc, env);
   env.no_pair = ctx->no_pair;
   env.self_pair_max = ctx->self_pair_max;
   env.no_mixed = ctx->no_mixed;
@@ -1540,6 +1543,7 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   ScoreK sk;
   if (int rc = make_scorek(&tmp, sc, sk, env.degenerate)) return rc;
   env.gapo = sc->gapo;
+  scoring_gates(sc, env);
   env.max_dyn_lds = max_dyn_lds;
   BatchCut cut;
   const char *msg = nullptr;

@@ -127,6 +127,15 @@ def test_kernel_choice_by_request():
     assert rc == -3  # SDF_ERR_UNSUPPORTED: not a flag of this kernel
     rc, pt, _ = _plan(_tasks([300, 0], [300, 5]), mat=np.array([1] + [-100] * 24, np.int8), gapo=1, gape=1)
     assert rc == 0 and (pt[:, 0] == -1).all()  # degenerate scoring: the reference returns before any work
+    # the window kernels' 32-bit differences want every fresh score byte in q .. 127 (sdf_api.hip: scoring_gates)
+    from sedef_amd import extz2
+    t2 = _tasks([300, 300, 1000, 1000], [300, 300, 1000, 1000], w=[-1, -1, 128, 128])
+    for (ma, mi, go, ge), fast in (((5, -10, 10, 0), True), ((5, -11, 10, 0), False), ((5, -4, 60, 1), True),
+                                   ((5, -4, 61, 1), False), ((5, -4, 40, 1), True)):
+        rc, pt, _ = _plan(t2, mat=extz2.sedef_mat(ma, mi), gapo=go, gape=ge)
+        assert rc == 0
+        on_general = np.isin(pt[:, 1], (64, 256, 1024))
+        assert on_general.all() != fast and (not fast or not on_general.any()), (ma, mi, go, ge, pt[:, 1])
 
 
 def test_stripe_kernel_routing_and_widths():
