@@ -109,7 +109,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
   const bool more = blk + 1 < nblk;
   const int nstep = qmax + 63;
   unsigned xo = 0u, vo = 0u, qc = 0u, vcap = 0u;
-  unsigned qwa_c = 0u, qna_c = 0u, qwb_c = 0u, qnb_c = 0u;
+  unsigned qrot = 0u;  // the query bases of sixteen rows, rotating (below)
   unsigned e_next = (!CHAIN && blk) ? edge[0] : 0u;
   unsigned e16 = 0u;  // CHAIN: the edge words of rows (s & ~15) + lane, lanes 0..15
   uint2 *drow = dir + (size_t)blk * nstep * 64 + lane;
@@ -137,19 +137,20 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
         else __builtin_amdgcn_s_sleep(64);
       }
     }
-    // lane 0 takes the query bases of row s; the others those their left neighbour had (lanes run a step apart)
-    unsigned ca = 0u, cb = 0u;
-    if (s < qa) {
-      if ((s & 15) == 0) qwa_c = qwa[s >> 4];
-      if ((s & 31) == 0) qna_c = qna[s >> 5];
-      ca = ((qna_c >> (s & 31)) & 1u) ? 4u : ((qwa_c >> ((s & 15) * 2)) & 3u);
+    // lane 0 takes the query bases of row s; the others those their left neighbour had (lanes run a step apart).
+    // Round 5: the bases of the next sixteen rows are unpacked ONCE per sixteen steps, lane i holding row (s & ~15) + i's
+    // (A | B << 16), and the register rotates one lane per step, so that lane 0 always holds the current row's: one DPP
+    // a step where the shifts, masks and selects of the two tasks' words were twelve of a step's ~190 instructions.
+    if ((s & 15) == 0) {
+      const int jr = s + (lane & 15);
+      unsigned ca = 0u, cb = 0u;
+      if (jr < qa) ca = ((qna[jr >> 5] >> (jr & 31)) & 1u) ? 4u : ((qwa[jr >> 4] >> ((jr & 15) * 2)) & 3u);
+      if (jr < qb) cb = ((qnb[jr >> 5] >> (jr & 31)) & 1u) ? 4u : ((qwb[jr >> 4] >> ((jr & 15) * 2)) & 3u);
+      qrot = ca | (cb << 16);
+    } else {
+      qrot = (unsigned)__builtin_amdgcn_mov_dpp((int)qrot, 0x134, 0xf, 0xf, false);  // wave_rol:1
     }
-    if (s < qb) {
-      if ((s & 15) == 0) qwb_c = qwb[s >> 4];
-      if ((s & 31) == 0) qnb_c = qnb[s >> 5];
-      cb = ((qnb_c >> (s & 31)) & 1u) ? 4u : ((qwb_c >> ((s & 15) * 2)) & 3u);
-    }
-    qc = (unsigned)__builtin_amdgcn_update_dpp((int)(ca | (cb << 16)), (int)qc, 0x138, 0xf, 0xf, false);
+    qc = (unsigned)__builtin_amdgcn_update_dpp((int)qrot, (int)qc, 0x138, 0xf, 0xf, false);
     // x, v left of the strip: the left neighbour's last cell of this row; lane 0: the matrix border (:120: x = 0, v = q
     // below the first row) or, from the second block on, the last column of the block before
     unsigned e_cur = e_next;
@@ -208,8 +209,10 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
         else edge[j] = ew;
       }
       {
-        const unsigned wa = (Fa & 0xffu) | ((Fb & 0xffu) << 8) | ((Fx & 0xffu) << 16) | ((Fy & 0xffu) << 24);
-        const unsigned wb = ((Fa >> 16) & 0xffu) | (((Fb >> 16) & 0xffu) << 8) | (((Fx >> 16) & 0xffu) << 16) | ((Fy >> 16) << 24);
+        // byte 0 of the four accumulators' low halves -> task A's word, of their high halves -> task B's (an accumulator holds
+        // at most C <= 8 bits per half): four byte permutes instead of sixteen shifts, masks and ors
+        const unsigned ab = __builtin_amdgcn_perm(Fb, Fa, 0x06020400u), xy = __builtin_amdgcn_perm(Fy, Fx, 0x06020400u);
+        const unsigned wa = __builtin_amdgcn_perm(xy, ab, 0x05040100u), wb = __builtin_amdgcn_perm(xy, ab, 0x07060302u);
         if (solo) {  // (a task without a partner: records of one word)
           if (with_dir_a) reinterpret_cast<uint32_t *>(dir)[((size_t)blk * nstep + s) * 64 + lane] = wa;
         } else if (with_dir_a && with_dir_b) {
