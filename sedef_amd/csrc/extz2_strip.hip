@@ -204,7 +204,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
       xo = x;
       vo = v;
       if (more && lane == 63) {
-        const unsigned ew = (xo & 0xffu) | ((vo & 0xffu) << 8) | (xo & 0xff0000u) | ((vo & 0xff0000u) << 8);
+        const unsigned ew = __builtin_amdgcn_perm(vo, xo, 0x06020400u);  // bytes x_A, v_A, x_B, v_B (one permute)
         if (CHAIN) st_agent(edge_out + j, ew | 0x80u);  // (x <= 127: bit 7 tags the word as written)
         else edge[j] = ew;
       }
@@ -223,26 +223,34 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
           drow[(size_t)s * 64].y = wb;
         }
       }
-      if (j == 0) {  // exact H along the first row: the sum of u (:231, read as bytes) over the lane's columns
+      // (the three blocks below under UNIFORM conditions of their own: as lane predicates alone the compiler runs their
+      // instructions through every step with EXEC empty -- fifteen of a step's ~170 in a block that holds no last column)
+      if (s < 64) {  // (row 0 passes lane l at step l)
+        if (j == 0) {  // exact H along the first row: the sum of u (:231, read as bytes) over the lane's columns
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-          if (k < nva) ha.sum0 += (int)(U[k] & 0xffffu);
-          if (k < nvb) hb.sum0 += (int)(U[k] >> 16);
+          for (int k = 0; k < C; ++k) {
+            if (k < nva) ha.sum0 += (int)(U[k] & 0xffffu);
+            if (k < nvb) hb.sum0 += (int)(U[k] >> 16);
+          }
         }
       }
       // ... and down the last column (v): ascending rows, the first maximum stays (:252)
-      if (last_a && lane == lla && j < qa) {
-        ha.hrel = j ? ha.hrel + (int)(vcap & 0xffffu) - qe : 0;
-        if (j == 0 || ha.hrel > ha.best) {
-          ha.best = ha.hrel;
-          ha.bestj = j;
+      if (last_a) {
+        if (lane == lla && j < qa) {
+          ha.hrel = j ? ha.hrel + (int)(vcap & 0xffffu) - qe : 0;
+          if (j == 0 || ha.hrel > ha.best) {
+            ha.best = ha.hrel;
+            ha.bestj = j;
+          }
         }
       }
-      if (last_b && lane == llb && j < qb) {
-        hb.hrel = j ? hb.hrel + (int)(vcap >> 16) - qe : 0;
-        if (j == 0 || hb.hrel > hb.best) {
-          hb.best = hb.hrel;
-          hb.bestj = j;
+      if (last_b) {
+        if (lane == llb && j < qb) {
+          hb.hrel = j ? hb.hrel + (int)(vcap >> 16) - qe : 0;
+          if (j == 0 || hb.hrel > hb.best) {
+            hb.best = hb.hrel;
+            hb.bestj = j;
+          }
         }
       }
     }
