@@ -270,11 +270,17 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
     // band -- no border cell, no first-cell rule, no masks ----
     {
       Band b_first, b_last;
-      const bool ok_first = band_of(rb, qlen, tlen, w, b_first), ok_last = band_of(re - 1, qlen, tlen, w, b_last);
+      // (what is cheap and necessary first -- hi0(rb) <= (rb + w) >> 1, lo0(re - 1) >= (re - w) >> 1: a stripe at an edge of
+      // the band, whose blocks are the task's chain of rows, fails here and is spared the two band evaluations)
+      bool full = has_left && re > rb && rb >= next_a - 1 && ((rb + w) >> 1) >= T1 && ((re - w) >> 1) < T0;
+      if (full) {
+        const bool ok_first = band_of(rb, qlen, tlen, w, b_first), ok_last = band_of(re - 1, qlen, tlen, w, b_last);
+        full = ok_first && ok_last && b_last.lo0 < T0 && b_first.hi0 >= T1;
+      }
 #ifdef SDF_BS_NO_FULL
       if (false) {
 #else
-      if (has_left && re > rb && ok_first && ok_last && b_last.lo0 < T0 && b_first.hi0 >= T1 && rb >= next_a - 1) {
+      if (full) {
 #endif
         const bool full_h = can_drop || b_first.hi0 <= T1 + 1;  // (see can_drop)
 #ifdef SDF_STRIPE_TIMING
