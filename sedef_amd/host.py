@@ -85,7 +85,9 @@ def generate_many(ref_path, beds, kmer, out_suffix=".aligned.bed", log_dir=None,
     """Several buckets through ONE provider (csrc/host/pipeline.cc: generate_many): bucket b's lines go to b + out_suffix.
     `beds`: bucket files or directories of bucket_???? files.  Returns [(lines, hits)] per bucket."""
     lib = load_host()
-    stats = (C.c_longlong * 4096)()
+    # (two figures per bucket; a directory stands for the bucket_???? files in it)
+    nb = sum(len(os.listdir(b)) if os.path.isdir(b) else 1 for b in beds)
+    stats = (C.c_longlong * (2 * max(nb, 1) + 2))()
     lib.sdfh_generate_many.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p]
     n = lib.sdfh_generate_many(ref_path.encode(), "\n".join(beds).encode(), kmer, out_suffix.encode(),
                                log_dir.encode() if log_dir else None, test_dp, device, stats)

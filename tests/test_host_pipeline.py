@@ -320,6 +320,20 @@ def test_several_buckets_in_one_run_equal_one_bucket_runs(host, oracle_dp, tmp_p
     assert st2 == st and [open(b + ".aligned.bed").read() for b in buckets] == want
 
 
+@pytest.mark.parametrize("lanes", ["1", "2"])
+def test_several_buckets_one_missing_fails_with_its_name(host, oracle_dp, tmp_path, monkeypatch, lanes):
+    """A bucket file that cannot be read ends the run with an error that names it (the CLI: exit code 1), whether the
+    buckets run one after the other or two at a time; the buckets done before it keep their complete outputs."""
+    fa, out, buckets = _buckets(host, tmp_path, seed=23, nsd=8, nb=3)
+    monkeypatch.setenv("SDF_BUCKET_LANES", lanes)
+    missing = str(out / "bucket_9999")
+    with pytest.raises(Exception) as e:
+        host.generate_many(fa, buckets[:1] + [missing] + buckets[1:], 11, test_dp=oracle_dp)
+    assert "bucket_9999" in str(e.value)
+    host.generate(fa, buckets[0], 11, buckets[0] + ".single", test_dp=oracle_dp)
+    assert open(buckets[0] + ".aligned.bed").read() == open(buckets[0] + ".single").read()
+
+
 @pytest.mark.parametrize("lanes", ["1", "2", "3"])
 def test_buckets_in_flight_write_what_one_after_the_other_writes(host, oracle_dp, tmp_path, monkeypatch, lanes):
     """SDF_BUCKET_LANES buckets of a several-bucket run are in flight at a time, each on a provider of its own (default 2):
