@@ -129,7 +129,7 @@ typedef struct sdf_config {
   uint32_t size; /* sizeof(sdf_config), set by sdf_config_default / sdf_config_from_env */
   uint32_t reserved;
   /* which kernel serves a task */
-  int64_t force_general, no_pair, no_quad, no_mixed, mixed_min, self_pair_max;
+  int64_t force_general, no_pair, no_mixed, mixed_min, self_pair_max;
   int64_t no_stripe, stripe_min, stripe_nreg, stripe_claim, stripe_spin_cap;
   int64_t bstripe_min_rows, bstripe_nreg, bstripe_all;
   int64_t no_strip, strip_always, strip_cols, chain_min;
@@ -237,7 +237,6 @@ int sdf_last_launches(const sdf_ctx *ctx);
 /* Number of tasks of the last batch call that ran two per wavefront: tasks with the same (qlen, tlen, w, flag)
  * share the reference's band schedule (extern/ksw2_extz2_sse.cc:101-115) and are packed side by side. */
 long long sdf_last_paired(const sdf_ctx *ctx);
-long long sdf_last_quad_tasks(const sdf_ctx *ctx); /* ... of them four per wavefront (extz2_quad.hip) */
 /* Number of tasks of the last batch call that were run a second time, inside the call, on the one-wavefront / one-workgroup
  * kernels because a stripe kernel's wavefront gave up waiting for its neighbour (SDF_STRIPE_SPIN_CAP polls; the stripe
  * protocol's forward progress rests on the dispatch order).  0 in normal operation. */

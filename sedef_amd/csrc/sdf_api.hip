@@ -344,7 +344,6 @@ extern "C" float sdf_last_ms(const sdf_ctx *ctx, int which) {
 
 extern "C" int sdf_last_launches(const sdf_ctx *ctx) { return ctx ? ctx->launches : 0; }
 extern "C" long long sdf_last_paired(const sdf_ctx *ctx) { return ctx ? ctx->paired : 0; }
-extern "C" long long sdf_last_quad_tasks(const sdf_ctx *ctx) { return ctx ? ctx->quad_tasks : 0; }
 extern "C" long long sdf_last_reran(const sdf_ctx *ctx) { return ctx ? ctx->reran : 0; }
 extern "C" long long sdf_last_lane_tasks(const sdf_ctx *ctx) { return ctx ? ctx->lane_tasks : 0; }
 
@@ -448,7 +447,6 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   for (float &m : ctx->ms) m = 0.f;
   ctx->launches = 0;
   ctx->paired = 0;
-  ctx->quad_tasks = 0;
   // (nothing of this context's earlier calls is in flight: what they outgrew is idle now -- sdf_ctx.h: DevBuf)
   for (DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->gstate_buf, &ctx->h_pool, &ctx->h_out,
                     &ctx->h_brief, &ctx->h_cig, &ctx->ln_recs, &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp})
@@ -597,7 +595,6 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
         return SDF_ERR_INVALID;
       }
       ctx->paired += c.paired;
-      ctx->quad_tasks += c.quad_tasks;
       const float tw = host_ms();
       if (int lrc = launch_chunk(run, ci)) return lrc;
       if (dbg_plan_chunks) fprintf(stderr, "[chunk %zu: %zu tasks (heavy, early) planned by %.2f ms, launched by %.2f ms]\n", ci, c.cnt, tw, host_ms());
@@ -651,7 +648,6 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
         break;
       }
       ctx->paired += c.paired;
-      ctx->quad_tasks += c.quad_tasks;
       const float tw = host_ms();
       rc = launch_chunk(run, ci);
       if (dbg_plan_chunks) fprintf(stderr, "[chunk %zu: %zu tasks%s planned by %.2f ms, launched by %.2f ms]\n", ci, c.cnt, c.heavy ? " (heavy)" : "", tw, host_ms());
@@ -768,7 +764,6 @@ extern "C" int sdf_extz2_batch_device(sdf_ctx *ctx, const sdf_scoring *sc, const
   if (head) {  // the call's statistics cover both parts
     ctx->launches += head->ctx->launches;
     ctx->paired += head->ctx->paired;
-    ctx->quad_tasks += head->ctx->quad_tasks;
     ctx->lane_tasks += head->ctx->lane_tasks;
     ctx->reran += head->ctx->reran;
     ctx->ms[4] = head->ctx->ms[4];  // host time before the call's first launch

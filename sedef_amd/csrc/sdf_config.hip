@@ -25,7 +25,6 @@ static const ConfigField kConfigFields[] = {
     // ---- which kernel serves a task (tests force every kernel through these) ----
     SDF_CF("SDF_FORCE_GENERAL", force_general, 0, 0, 1, "1: every task on the LDS-resident general kernel"),
     SDF_CF("SDF_NO_PAIR", no_pair, 0, 0, 1, "1: never two tasks per wavefront (extz2_pair.hip off)"),
-    SDF_CF("SDF_NO_QUAD", no_quad, 1, 0, 1, "0: four tasks of one geometry per wavefront where their window is 129..144 slots (extz2_quad.hip: exact, measured no faster than the pair kernel -- profiles/r05_quad_kernel.txt -- and off by default)"),
     SDF_CF("SDF_NO_MIXED", no_mixed, 0, 0, 1, "1: no mixed pairs (banded tasks of different lengths in one wavefront)"),
     SDF_CF("SDF_MIXED_MIN", mixed_min, 4096, 0, 1e12, "mixed-pair candidates a chunk must hold"),
     SDF_CF("SDF_SELF_PAIR_MAX", self_pair_max, 512, 0, 1e12, "tasks without a partner above which a chunk uses the one-task wave kernel"),

@@ -310,7 +310,6 @@ struct sdf_ctx {
                                            // first launch, 5 host total, 6 sum of the chunks' DP intervals
   int launches = 0;
   long long paired = 0;  // tasks of the last batch that ran two per wavefront (extz2_pair.hip)
-  long long quad_tasks = 0;  // ... four per wavefront (extz2_quad.hip; they count as paired too)
   std::string err;
   int max_dyn_lds = 64 * 1024;
   bool force_general = false;  // SDF_FORCE_GENERAL=1: route everything to the LDS-resident kernel

@@ -131,9 +131,6 @@ static void launch_dp(const Launch &L, hipStream_t sdp, const PlanTask *lp, cons
     case 116: SDF_PAIR(6, true); break;
     case 108: SDF_PAIR(8, false); break;
     case 118: SDF_PAIR(8, true); break;
-    case 145: /* quads: four tasks per workgroup (extz2_quad.hip) */
-      hipLaunchKernelGGL(extz2_quad_kernel, dim3((unsigned)(L.cnt / 4)), dim3(64), L.lds, sdp, lp, lo, d_pool, sk, dir_reg, d_out);
-      break;
     case 132: SDF_PAIR_MIXED(2); break;
     case 133: SDF_PAIR_MIXED(3); break;
     case 134: SDF_PAIR_MIXED(4); break;

@@ -85,7 +85,6 @@ struct ChunkPlan {
   std::vector<Launch> launches;
   unsigned layouts = 0;  // direction-flag layouts present: bit 0 byte rows, 1 wave blocks, 2 pair blocks, 3 stripes
   long long paired = 0;
-  long long quad_tasks = 0;
   size_t dir_bytes = 0;
   const char *err = nullptr;
 };
@@ -182,10 +181,6 @@ struct PlanScratch {
   std::vector<uint64_t> mix_keys;
   std::vector<int32_t> stripe_lane, stripe_fill;
   std::vector<uint64_t> strip_keys, strip_keys_tmp;
-  std::vector<int32_t> quad_next;    // quads (extz2_quad.hip): see plan_chunk
-  std::vector<char> quadf;
-  std::unordered_map<uint64_t, int32_t> quad_wait;
-  std::unordered_map<uint64_t, bool> quad_ok;  // (qlen, tlen, w) -> quad_window_ok, kept across the chunks of a call
 };
 
 // Returns SDF_OK or an error code with *err set.
@@ -886,7 +881,6 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   c.launches.clear();
   c.layouts = 0;
   c.paired = 0;
-  c.quad_tasks = 0;
   c.dir_bytes = 0;
   if (cnt == 0) return;
   PlanTask *cp = plan + c.pb;  // chunk-relative indexing below
@@ -1105,41 +1099,6 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     }
   }
 
-  // Quads (extz2_quad.hip): two pairs of ONE geometry whose window is the 144 slots that kernel holds per task share a
-  // wavefront in five registers instead of two wavefronts of three.  quad_next[k]: for the first task of a quad's first
-  // pair, the first task of its second pair; quadf: 1 = first pair, 2 = second pair (listed with the first).
-  std::vector<int32_t> &quad_next = sx.quad_next;
-  std::vector<char> &quadf = sx.quadf;
-  quad_next.assign(cnt, -1);
-  quadf.assign(cnt, 0);
-  if (!env.no_pair && !env.force_general && env.cfg->no_quad == 0) {
-    auto &waiting = sx.quad_wait;  // geometry -> a pair of it still waiting for a second one
-    waiting.clear();
-    for (size_t k = 0; k < cnt; ++k) {
-      const PlanTask &x = cp[k];
-      if (x.pad_ != 2 || x.nreg != 3 || mixedf[k] || tracked[k] || partner[k] <= (int32_t)k) continue;  // (first task of a true pair)
-      if (win_need[k] <= 128 || x.w < 113 || x.w > 128 || x.qlen > 1340 || !pair_fits_whole(x.qlen, x.tlen, 3)) continue;
-      const uint64_t key = ((uint64_t)(uint32_t)x.qlen << 40) | ((uint64_t)(uint32_t)x.tlen << 16) | ((uint64_t)(uint32_t)x.w << 1) |
-                           ((x.flag & SDF_FLAG_SCORE_ONLY) ? 1u : 0u);
-      auto ok = sx.quad_ok.find(key >> 1);
-      if (ok == sx.quad_ok.end()) ok = sx.quad_ok.emplace(key >> 1, quad_window_ok_cached(x.qlen, x.tlen, x.w)).first;
-      if (!ok->second) continue;
-      // (the halves of a wavefront share every flag the row code looks at: pairs of one flag word only)
-      const uint64_t fkey = key ^ ((uint64_t)(uint32_t)(x.flag & 0xff) << 56);
-      auto it = waiting.find(fkey);
-      if (it == waiting.end()) {
-        waiting.emplace(fkey, (int32_t)k);
-      } else {
-        const int32_t first = it->second;
-        quad_next[first] = (int32_t)k;
-        quadf[first] = quadf[partner[first]] = 1;
-        quadf[k] = quadf[partner[k]] = 2;
-        c.quad_tasks += 4;
-        waiting.erase(it);
-      }
-    }
-  }
-
   {  // strip kernel: two tasks per wavefront, neighbours in the order of (column blocks, rows, columns) -- the wavefront
      // steps through the larger of its two matrices; a task left over is paired with itself
     std::vector<int32_t> &sl = sx.stripe_lane;  // (scratch)
@@ -1265,12 +1224,6 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       need = strip_lds_bytes(std::max(p.qlen, cp[partner[k]].qlen), std::max(p.tlen, cp[partner[k]].tlen));
       lds = 1024;
       while (lds < need) lds *= 2;
-    } else if (p.pad_ == 2 && quadf[k]) {
-      if (quadf[k] == 2 || partner[k] < (int32_t)k) continue;  // (listed with the quad's first task)
-      bs = 145;  // quad kernel: four tasks of one geometry, 144 window slots each, in five registers (extz2_quad.hip)
-      need = quad_lds_bytes(p.qlen, p.tlen);
-      lds = 8192;
-      while (lds < need) lds *= 2;
     } else if (p.pad_ == 2) {
       if (partner[k] < (int32_t)k) continue;  // placed together with its partner
       // 100 + NREG; + 10 for the streamed-window instantiation (sequences longer than the LDS windows)
@@ -1326,10 +1279,6 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     }
     cl->idx.push_back((int32_t)k);
     if (p.pad_ == 2 || p.pad_ == 9) cl->idx.push_back(partner[k]);
-    if (bs == 145) {  // ... and the quad's second pair
-      cl->idx.push_back(quad_next[k]);
-      cl->idx.push_back(partner[quad_next[k]]);
-    }
   }
   c.dir_bytes = dir_acc;
   if (dir_acc > (c.heavy ? cut.heavy_need : cut.region_need)) {
@@ -1354,7 +1303,7 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
   // starts last is the tail of the launch); pair-kernel entries move as (task, partner) units
   for (auto &x : cls) {
     const bool mixed_cls = x.bs >= 130 && x.bs < 140;  // (long and short tasks in one launch: the long chains start first)
-    if ((x.idx.size() >= 8192 && !mixed_cls) || x.idx.size() < 3 || x.bs == 145) continue;  // (quads: entries of four, tasks of one size)
+    if ((x.idx.size() >= 8192 && !mixed_cls) || x.idx.size() < 3) continue;
     auto work = [&](int32_t k) { return (int64_t)(cp[k].qlen + cp[k].tlen) * cp[k].ncol16; };
     int64_t wmin = work(x.idx[0]), wmax = wmin;
     for (int32_t k : x.idx) {

@@ -377,12 +377,6 @@ class Extz2Engine:
     def last_launches(self):
         return int(self.lib.sdf_last_launches(self.ctx))
 
-    def last_quad_tasks(self):
-        """Tasks of the last batch call that ran four per wavefront (extz2_quad.hip)."""
-        self.lib.sdf_last_quad_tasks.restype = C.c_longlong
-        self.lib.sdf_last_quad_tasks.argtypes = [C.c_void_p]
-        return int(self.lib.sdf_last_quad_tasks(self.ctx))
-
     def last_paired(self):
         """Tasks of the last batch that ran two per wavefront (same-geometry pairs)."""
         return int(self.lib.sdf_last_paired(self.ctx))

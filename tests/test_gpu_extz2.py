@@ -250,43 +250,6 @@ def _fnv(words):
     return int(h)
 
 
-def test_quad_kernel_four_tasks_per_wavefront(oracle):
-    """extz2_quad.hip (SDF_NO_QUAD=0: off by default): four tasks of one geometry in five registers (144 window slots each)
-    against the oracle on every field the fast path returns, and byte for byte against a context that keeps them on the
-    pair kernel: band 113..128, queries of 300..1300 bases, N runs, unrelated sequences, score-only tasks, geometries with
-    one or three pairs left over."""
-    import sedef_amd
-    engine = _engine_with_env(SDF_NO_QUAD=0)
-    rng = np.random.default_rng(14501)
-    pairs, ws, flags = [], [], []
-    for (ql, tl, w, reps) in [(1000, 1000, 128, 24), (1000, 987, 128, 10), (1000, 1013, 128, 6), (700, 720, 128, 8), (320, 330, 128, 4),
-                              (1300, 1250, 120, 8), (900, 940, 113, 8), (1000, 1030, 127, 4), (400, 380, 128, 4), (1000, 1000, 128, 3)]:
-        for it in range(reps):
-            kind = (it + ql) % 7
-            q = random_codes(rng, ql, 0.004 if kind == 3 else 0.0)
-            if kind == 5:
-                t = random_codes(rng, tl)
-            else:
-                t = _fit(rng, mutate(rng, q, 0.06, 0.02, 0.02), tl)
-            if kind == 6:
-                t[tl // 2:tl // 2 + 40] = 4
-            pairs.append((q, t))
-            ws.append(w)
-            flags.append(0)
-    for k in range(8):  # a geometry whose four tasks want no CIGAR
-        q = random_codes(rng, 800)
-        pairs.append((q, _fit(rng, mutate(rng, q, 0.05, 0.02, 0.02), 790)))
-        ws.append(128)
-        flags.append(0x01)
-    _check_fast(engine, oracle, pairs, ws, flags)
-    assert engine.last_quad_tasks() >= 56 and engine.last_reran() == 0
-    off = sedef_amd.Extz2Engine(0)
-    want = sedef_amd.extz2.WANT_CIGAR | sedef_amd.extz2.WANT_SCORE
-    r1, c1 = engine.align_pairs(pairs, w=ws, flag=flags, want=want)
-    r2, c2 = off.align_pairs(pairs, w=ws, flag=flags, want=want)
-    assert np.array_equal(r1, r2) and np.array_equal(c1, c2) and off.last_quad_tasks() == 0
-
-
 def test_config2_batch_checksums(engine, oracle):
     """BASELINE config 2 inputs (seed 42): per-task CIGAR checksums and scores of a 3000-task slice against
     the CPU path (reference kernel when oracle/_ref is present, else the oracle port), and size-independent

@@ -225,24 +225,3 @@ def test_banded_tasks_of_all_lengths_mixed_pairs_and_fewer_chunks():
     _check(small, pt, pc)
 
 
-def test_quads_take_pairs_of_one_geometry_whose_window_fits(monkeypatch):
-    """extz2_quad.hip (SDF_NO_QUAD=0: off by default): two pairs of one (qlen, tlen, w) with a window of 129..144 slots share a
-    wavefront (launch class 145, entries of four); other geometries and wider bands keep the pair kernel."""
-    monkeypatch.setenv("SDF_NO_QUAD", "0")
-    rng = np.random.default_rng(3)
-    n = 6000
-    tl = 1000 + rng.integers(-3, 3, n)
-    t = _tasks(np.full(n, 1000), tl, w=128)
-    rc, pt, pc = _plan(t)
-    assert rc == 0
-    assert (pt[:, 1] == 145).sum() >= n - 6 * 3 - 8  # (per geometry at most three tasks without a full quad, chunk by chunk)
-    quads = pt[:, 1] == 145
-    part = pt[:, 6]
-    assert (part[quads] >= 0).all() and (tl[part[quads]] == tl[quads]).all()
-    _check(t, pt, pc)
-    t2 = _tasks(np.full(n, 1000), tl, w=rng.choice([64, 100, 112, 129, 200], n))
-    rc, pt2, _ = _plan(t2)
-    assert rc == 0 and not (pt2[:, 1] == 145).any()
-    monkeypatch.setenv("SDF_NO_QUAD", "1")
-    rc, pt3, _ = _plan(t)
-    assert rc == 0 and not (pt3[:, 1] == 145).any() and (pt3[:, 1] == 103).sum() >= n - 12
