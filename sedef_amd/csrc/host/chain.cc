@@ -14,6 +14,7 @@
 //             priority search tree -- flat arrays, no recursion -- and its choices are the reference's.
 #include <algorithm>
 #include <climits>
+#include <functional>
 #include <cstdlib>
 
 #include "sedef_host.h"
@@ -90,29 +91,58 @@ const int kInactive = INT_MIN;
 
 inline int64_t key_of(int coord, int idx) { return (int64_t)coord * ((int64_t)1 << 32) + idx; }
 
-// Priority search tree over points sorted by key: node i covers a range of points, `reach[i]` is the largest key of
-// that range, leaves hold one point, and `top[i]` names the leaf of the best active point below i that no ancestor
-// has claimed.  Heap layout, split rule and the three tie rules are those of src/segment.tpp.
+// Sorts keys of the form key_of(coord, idx) whose idx ascend in the input (so a STABLE sort by coord alone is the sort by
+// the whole key): counting passes over 11-bit digits of the coordinate -- two for sequences below 4 Mb -- instead of a
+// comparison sort; the three sorts of a pair's anchors were a third of chain_anchors.  Short inputs and negative
+// coordinates keep std::sort.
+void sort_by_coord(std::vector<int64_t> &v, std::vector<int64_t> &tmp, int64_t max_coord) {
+  const size_t n = v.size();
+  if (n < 96 || max_coord < 0 || max_coord >= ((int64_t)1 << 31)) {
+    std::sort(v.begin(), v.end());
+    return;
+  }
+  tmp.resize(n);
+  int64_t *src = v.data(), *dst = tmp.data();
+  for (int shift = 32; (max_coord >> (shift - 32)) != 0; shift += 11) {
+    uint32_t count[2049] = {0};
+    for (size_t k = 0; k < n; k++) count[((uint64_t)src[k] >> shift & 2047u) + 1]++;
+    for (int d = 0; d < 2048; d++) count[d + 1] += count[d];
+    for (size_t k = 0; k < n; k++) dst[count[(uint64_t)src[k] >> shift & 2047u]++] = src[k];
+    std::swap(src, dst);
+  }
+  if (src != v.data()) v.swap(tmp);
+}
+
+// Priority search tree over points sorted by key: node i covers a range of points, leaves hold one point, and `top` of a
+// node names the leaf (by node index) of the best active point below it that no ancestor has claimed.  Heap layout, split
+// rule and the three tie rules are those of src/segment.tpp.
+//
+// Round 6: the sweep below spends most of a pair's host time in this structure (2.1 million anchors in the chr1-sized stage
+// run), so a node is ONE 24-byte record -- the largest key of its left child's range (what every descent compares with),
+// its `top`, and for a leaf its own key and score -- instead of five parallel arrays, a point finds its leaf through a
+// table instead of a descent from the root, and points are named by their rank.  The operations and their order are
+// unchanged (tests/test_chain_oracle.py replays scripts on this class and on the reference's SegmentTree).
 class RangeMax {
  public:
   std::vector<int64_t> key;  // per point, ascending
-  std::vector<int> score;    // per point; kInactive while not active
-  explicit RangeMax(std::vector<int64_t> sorted_keys) : key(std::move(sorted_keys)), score(key.size(), kInactive) {
+  explicit RangeMax(std::vector<int64_t> sorted_keys) : key(std::move(sorted_keys)), leaf_(key.size(), -1) {
     const int n = (int)key.size();
     int bits = 0;
     for (unsigned v = (unsigned)n - 1u; n > 0 && v; v >>= 1) bits++;
     const int size = 2 << (n > 0 ? bits : 0);  // twice the next power of two (src/segment.tpp:18-19)
-    reach.assign((size_t)size, 0);
-    point.assign((size_t)size, -1);
-    top.assign((size_t)size, -1);
+    node_.assign((size_t)size + 1, Node{0, 0, -1, kInternal});  // (+1: the right child of the last node is tested, never entered)
+    size_ = size;
     // node i covers [lo, hi); children split at (lo + hi + 1) / 2 (src/segment.tpp:184)
     std::vector<int> lo((size_t)size, 0), hi((size_t)size, 0);
+    std::vector<int64_t> reach((size_t)size, 0);
     if (n > 0) hi[0] = n;
     for (int i = 0; i < size; i++) {
       if (hi[i] <= lo[i]) continue;
       reach[i] = key[(size_t)hi[i] - 1];
       if (hi[i] - lo[i] == 1) {
-        point[i] = lo[i];
+        node_[i].key = key[(size_t)lo[i]];
+        node_[i].score = kInactive;
+        leaf_[(size_t)lo[i]] = i;
         continue;
       }
       const int mid = (lo[i] + hi[i] + 1) / 2;
@@ -121,80 +151,94 @@ class RangeMax {
       lo[2 * i + 2] = mid;
       hi[2 * i + 2] = hi[i];
     }
+    for (int i = 0; 2 * i + 1 < size; i++) node_[i].left_reach = reach[2 * i + 1];
+    point_of_leaf_.assign((size_t)size, -1);
+    for (int p = 0; p < n; p++) point_of_leaf_[(size_t)leaf_[(size_t)p]] = p;
   }
+
+  int score_of(int pt) const { return node_[leaf_[(size_t)pt]].score; }
+  int point_of_key(int64_t k) const { return (int)(std::lower_bound(key.begin(), key.end(), k) - key.begin()); }
 
   // point with the largest score among the active points with lo <= key <= hi, or -1.  Among equal scores: a
   // subtree's own top before anything below it, the left subtree before the right one (src/segment.tpp:29-66).
   int best_in(int64_t lo, int64_t hi) const {
-    int best_leaf = -1;
-    stack_.clear();
-    stack_.push_back(0);
-    while (!stack_.empty()) {
-      const int i = stack_.back();
-      stack_.pop_back();
+    int best_leaf = -1, best_score = 0;
+    int stack[96], sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+      const int i = stack[--sp];
+      const Node &nd = node_[i];
       int cand = -1;
-      if (point[i] != -1) {
-        if (lo <= key[point[i]] && key[point[i]] <= hi) cand = i;
-      } else if (top[i] != -1) {
-        const int64_t tk = key[point[top[i]]];
+      if (nd.score != kInternal) {
+        if (lo <= nd.key && nd.key <= hi) cand = i;
+      } else if (nd.top != -1) {
+        const int64_t tk = node_[nd.top].key;
         if (lo <= tk && tk <= hi) {
-          cand = top[i];
-        } else if (hi <= reach[2 * i + 1]) {
-          stack_.push_back(2 * i + 1);
-        } else if (lo > reach[2 * i + 1]) {
-          stack_.push_back(2 * i + 2);
+          cand = nd.top;
+        } else if (hi <= nd.left_reach) {
+          stack[sp++] = 2 * i + 1;
+        } else if (lo > nd.left_reach) {
+          stack[sp++] = 2 * i + 2;
         } else {
-          stack_.push_back(2 * i + 2);  // (popped after the left one: candidates arrive left to right)
-          stack_.push_back(2 * i + 1);
+          stack[sp++] = 2 * i + 2;  // (popped after the left one: candidates arrive left to right)
+          stack[sp++] = 2 * i + 1;
         }
       }
-      if (cand != -1 && (best_leaf == -1 || score[point[cand]] > score[point[best_leaf]])) best_leaf = cand;
+      if (cand != -1 && (best_leaf == -1 || node_[cand].score > best_score)) {
+        best_leaf = cand;
+        best_score = node_[cand].score;
+      }
     }
-    return best_leaf == -1 ? -1 : point[best_leaf];
+    return best_leaf == -1 ? -1 : point_of_leaf_[(size_t)best_leaf];
   }
 
-  void activate(int64_t k, int s) {  // src/segment.tpp:76-103: a newcomer takes the place of an equal score
-    int leaf = leaf_of(k);
-    score[point[leaf]] = s;
-    for (int i = 0; i < (int)top.size() && leaf != -1;) {
-      if (top[i] == -1 || score[point[leaf]] >= score[point[top[i]]]) std::swap(top[i], leaf);
+  void activate(int pt, int s) {  // src/segment.tpp:76-103: a newcomer takes the place of an equal score
+    int leaf = leaf_[(size_t)pt];
+    node_[leaf].score = s;
+    for (int i = 0; i < size_ && leaf != -1;) {
+      Node &nd = node_[i];
+      if (nd.top == -1 || node_[leaf].score >= node_[nd.top].score) std::swap(nd.top, leaf);
       if (leaf == -1) break;
-      i = 2 * i + 1 + (key[point[leaf]] > reach[2 * i + 1]);
+      i = 2 * i + 1 + (node_[leaf].key > nd.left_reach);
     }
   }
 
-  void deactivate(int64_t k) {  // src/segment.tpp:105-146: the hole is filled from below, left child on equal scores
-    int leaf = leaf_of(k);
-    score[point[leaf]] = kInactive;
-    for (int i = 0; i < (int)top.size() && top[i] != -1;) {
-      if (top[i] != leaf) {
-        i = 2 * i + 1 + (k > reach[2 * i + 1]);
-      } else if (point[i] != -1) {
-        top[i] = -1;
+  void deactivate(int pt) {  // src/segment.tpp:105-146: the hole is filled from below, left child on equal scores
+    int leaf = leaf_[(size_t)pt];
+    const int64_t k = node_[leaf].key;
+    node_[leaf].score = kInactive;
+    for (int i = 0; i < size_ && node_[i].top != -1;) {
+      Node &nd = node_[i];
+      if (nd.top != leaf) {
+        i = 2 * i + 1 + (k > nd.left_reach);
+      } else if (nd.score != kInternal) {
+        nd.top = -1;
       } else {
         const int l = 2 * i + 1, r = 2 * i + 2;
-        const bool right = r < (int)top.size() && top[r] != -1 &&
-                           (top[l] == -1 || score[point[top[r]]] > score[point[top[l]]]);
-        top[i] = leaf = top[right ? r : l];
+        const int tl = node_[l].top, tr = r < size_ ? node_[r].top : -1;
+        const bool right = tr != -1 && (tl == -1 || node_[tr].score > node_[tl].score);
+        nd.top = leaf = right ? tr : tl;
         i = right ? r : l;
       }
     }
   }
 
   int dump_tops(int *state, int cap) const {  // (test hook: the node each node's best point sits in)
-    for (int i = 0; i < (int)top.size() && i < cap; i++) state[i] = top[(size_t)i];
-    return (int)top.size();
+    for (int i = 0; i < size_ && i < cap; i++) state[i] = node_[(size_t)i].top;
+    return size_;
   }
 
  private:
-  int leaf_of(int64_t k) const {
-    int i = 0;
-    while (point[i] == -1 || key[point[i]] != k) i = 2 * i + 1 + (k > reach[2 * i + 1]);
-    return i;
-  }
-  std::vector<int64_t> reach;
-  std::vector<int> point, top;
-  mutable std::vector<int> stack_;
+  static const int kInternal = INT_MIN + 1;  // `score` of a node that is not a leaf (no chain scores that low)
+  struct Node {
+    int64_t left_reach;  // largest key below the left child (0: none)
+    int64_t key;         // leaf: its point's key
+    int32_t top;         // leaf node of the best unclaimed active point below, or -1
+    int32_t score;       // leaf: its point's score (kInactive while not active); kInternal otherwise
+  };
+  std::vector<Node> node_;
+  std::vector<int> leaf_, point_of_leaf_;
+  int size_ = 0;
 };
 }  // namespace
 
@@ -210,13 +254,13 @@ int rangemax_script(const int *pts, int n, const int *ops, int nops, int *out, i
     const int *o = ops + 5 * k;
     out[2 * k] = out[2 * k + 1] = -2;
     if (o[0] == 0) {
-      tree.activate(key_of(o[1], o[2]), o[3]);
+      tree.activate(tree.point_of_key(key_of(o[1], o[2])), o[3]);
     } else if (o[0] == 1) {
-      tree.deactivate(key_of(o[1], o[2]));
+      tree.deactivate(tree.point_of_key(key_of(o[1], o[2])));
     } else {
       const int pt = tree.best_in(key_of(o[1], o[2]), key_of(o[3], o[4]));
       out[2 * k] = pt == -1 ? -1 : (int)(uint32_t)tree.key[(size_t)pt];
-      out[2 * k + 1] = pt == -1 ? 0 : tree.score[(size_t)pt];
+      out[2 * k + 1] = pt == -1 ? 0 : tree.score_of(pt);
     }
   }
   return tree.dump_tops(state, state_cap);
@@ -230,46 +274,53 @@ std::pair<std::vector<int>, std::vector<std::pair<int, bool>>> chain_anchors(std
   if (n == 0) return {path, boundaries};
 
   // sweep events in (query coordinate, anchor) order: an anchor's start looks for a predecessor, its end makes it
-  // available as one (src/chain.cc:112-135)
-  std::vector<int64_t> events, ends_r((size_t)n);
-  events.reserve(2 * (size_t)n);
+  // available as one (src/chain.cc:112-135).  The anchors arrive in the order generate_anchors emits them -- ascending query
+  // position --, so the start events (q, i) are already in order: only the end events are sorted, and the sweep merges the two
+  // lists as it goes (an unsorted input sorts its starts too).
+  std::vector<int64_t> starts((size_t)n), ends((size_t)n), sorted_r((size_t)n);
   int far_q = 0, far_r = 0;
+  bool starts_sorted = true;
   for (int i = 0; i < n; i++) {
     const Anchor &a = anchors[i];
-    events.push_back(key_of(a.q, i));
-    events.push_back(key_of(a.q + a.l, i));
-    ends_r[(size_t)i] = key_of(a.r + a.l - 1, i);
+    starts[(size_t)i] = key_of(a.q, i);
+    ends[(size_t)i] = key_of(a.q + a.l, i);
+    sorted_r[(size_t)i] = key_of(a.r + a.l - 1, i);
+    starts_sorted = starts_sorted && (i == 0 || anchors[i - 1].q <= a.q);
     far_q = std::max(far_q, a.q + a.l);
     far_r = std::max(far_r, a.r + a.l);
   }
-  std::sort(events.begin(), events.end());
-  std::vector<int64_t> sorted_r = ends_r;
-  std::sort(sorted_r.begin(), sorted_r.end());
-  RangeMax tree(sorted_r);
+  std::vector<int64_t> scratch;
+  if (!starts_sorted) sort_by_coord(starts, scratch, far_q);
+  sort_by_coord(ends, scratch, far_q);
+  sort_by_coord(sorted_r, scratch, far_r);
+  std::vector<int> point_of((size_t)n);  // anchor -> its point of the tree (the rank of its reference end)
+  for (int p = 0; p < n; p++) point_of[(size_t)(uint32_t)sorted_r[(size_t)p]] = p;
+  RangeMax tree(std::move(sorted_r));
   // (point of the tree -> anchor: the low half of its key)
 
   std::vector<int> best(n, 0), pred(n, -1);
-  size_t expire = 0;  // events before this one have been checked for expiry
-  for (size_t e = 0; e < events.size(); e++) {
-    const int i = (int)(uint32_t)events[e];
-    const int coord = (int)(events[e] >> 32);
-    const Anchor &a = anchors[i];
-    if (coord != a.q) {  // end point; stored score = chain score minus the way to the far corner (:175-176)
-      tree.activate(ends_r[(size_t)i], best[i] - ((far_q + 1 - (a.q + a.l)) + (far_r + 1 - (a.r + a.l))));
+  size_t expire = 0;  // end events before this one have been checked for expiry
+  for (size_t si = 0, ei = 0; si < (size_t)n || ei < (size_t)n;) {
+    if (si == (size_t)n || (ei < (size_t)n && ends[ei] < starts[si])) {
+      // end point; stored score = chain score minus the way to the far corner (:175-176)
+      const int i = (int)(uint32_t)ends[ei++];
+      const Anchor &a = anchors[i];
+      tree.activate(point_of[(size_t)i], best[i] - ((far_q + 1 - (a.q + a.l)) + (far_r + 1 - (a.r + a.l))));
       continue;
     }
-    // anchors that ended more than max_chain_gap before this start are no predecessors any more (:142-152)
-    for (; expire < e; expire++) {
-      const int t = (int)(uint32_t)events[expire];
-      const int tend = anchors[t].q + anchors[t].l;
-      if ((int)(events[expire] >> 32) != tend) continue;  // a start point
-      if (a.q - tend <= P.max_chain_gap) break;
-      tree.deactivate(ends_r[(size_t)t]);
+    const int i = (int)(uint32_t)starts[si++];
+    const Anchor &a = anchors[i];
+    // anchors that ended more than max_chain_gap before this start are no predecessors any more (:142-152); such an end
+    // lies before this start in the event order, so it has been activated
+    for (; expire < ei; expire++) {
+      const int t = (int)(uint32_t)ends[expire];
+      if (a.q - (int)(ends[expire] >> 32) <= P.max_chain_gap) break;
+      tree.deactivate(point_of[(size_t)t]);
     }
     const int w = P.match_chain_score * a.has_u + (P.match_chain_score / 2) * (a.l - a.has_u);
     best[i] = w;
     const int pt = tree.best_in(key_of(a.r - P.max_chain_gap, 0), key_of(a.r - 1, n));
-    if (pt != -1 && tree.score[(size_t)pt] != kInactive) {
+    if (pt != -1 && tree.score_of(pt) != kInactive) {
       const int j = (int)(uint32_t)tree.key[(size_t)pt];
       const Anchor &p = anchors[j];
       const int with = w + best[j] - ((a.q - (p.q + p.l)) + (a.r - (p.r + p.l)));
@@ -281,12 +332,18 @@ std::pair<std::vector<int>, std::vector<std::pair<int, bool>>> chain_anchors(std
   }
   // chains, best first (ties: the later anchor first), each from its last anchor backwards until it meets an anchor
   // an earlier chain took (src/chain.cc:179-197)
-  std::vector<int> order(n);
-  for (int i = 0; i < n; i++) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](int x, int y) { return best[x] != best[y] ? best[x] > best[y] : x > y; });
+  std::vector<int64_t> order((size_t)n);  // (score, anchor) in one word: sorted as numbers
+  int best_max = 0;
+  for (int i = 0; i < n; i++) {
+    order[(size_t)i] = key_of(best[i], i);
+    best_max = std::max(best_max, best[i]);
+  }
+  sort_by_coord(order, scratch, best_max);  // (ascending, ties by ascending anchor: read backwards)
+  std::reverse(order.begin(), order.end());
   path.reserve((size_t)n);
   std::vector<char> taken(n, 0);
-  for (int head : order) {
+  for (const int64_t ord : order) {
+    const int head = (int)(uint32_t)ord;
     if (taken[head]) continue;
     int upper = 0;
     for (int i = head; i != -1 && !taken[i]; i = pred[i]) {
