@@ -211,6 +211,33 @@ int sdf_extz2_batch_brief(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *t
                           uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
 
 
+/* ---- resident sequences: DP tasks that name ranges of characters already in HBM ------------------------------------
+ * The reference's align_helper reads the bases of every DP call in place: the caller hands it two substrings of the pair's
+ * sequences, mapped through align_dna (reference: src/align.cc:39-57,80-84; src/common.h:60-70,91).  The stage driver has
+ * each super-batch's FASTA characters in HBM already -- sdf_anchors_batch uploaded them for the seed anchors -- and its DP
+ * rounds (hundreds of thousands of gap fills of ~25 bases) used to cut the same bases out again on the host, code them,
+ * pack them and upload them, round after round.  Here a task's q_off / t_off are BYTE offsets into that resident pool of raw
+ * FASTA characters; the device does align_dna (ACGT of either case -> 0..3, anything else -> the wildcard 4) and the
+ * packing (seq_pack.hip).  Results as sdf_extz2_batch_brief / sdf_extz2_batch return them.
+ *
+ *   sdf_pool_host(ctx, bytes)       a pinned host buffer of at least `bytes` owned by the context (NULL on failure): filled
+ *                                   there, a pool crosses PCIe as one asynchronous DMA instead of a staged pageable copy
+ *                                   (182 MB: 26 ms pageable).  Valid until the next sdf_pool_host call or sdf_destroy.
+ *   sdf_pool_upload(ctx, p, bytes)  copies `bytes` characters to HBM, enqueued on the context's stream (any host memory;
+ *                                   the buffer must stay unchanged until the next call on this context that returns data).
+ *                                   The pool replaces the one before.
+ *   sdf_anchors_batch(..., seq_pool = NULL, pool_bytes, ...)   the seed anchors of pairs whose offsets point into the
+ *                                   resident pool; with a host seq_pool the call uploads it and leaves it resident.
+ *   sdf_extz2_batch_pairs           the DP batch on ranges of the resident pool, 16-byte results;
+ *   sdf_extz2_batch_pairs_full      the same with sdf_result records and a `want` mask. */
+char *sdf_pool_host(sdf_ctx *ctx, size_t bytes);
+int sdf_pool_upload(sdf_ctx *ctx, const char *chars, size_t bytes);
+size_t sdf_pool_bytes(const sdf_ctx *ctx); /* characters resident at this moment */
+int sdf_extz2_batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, sdf_result_brief *out,
+                          uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+int sdf_extz2_batch_pairs_full(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, uint32_t want,
+                               sdf_result *out, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+
 /* Device-resident form: d_packed_pool, d_out and d_cigar_pool are HBM pointers on ctx's device;
  * tasks (host) carry word offsets into d_packed_pool.  Work is enqueued on `stream`
  * (a hipStream_t, NULL = the context's own stream) and the call returns after the stream has
@@ -251,7 +278,8 @@ long long sdf_last_lane_tasks(const sdf_ctx *ctx);
  * Replaces generate_anchors (reference: src/chain.cc:24-101) for a batch of candidate pairs: maximal exact
  * k-mer matches, in the reference's order (query position, then reference position).  Sequences are the raw
  * FASTA characters (case = soft-masking, N = unknown).  kmer <= 15 and sequences shorter than 2 Gb (SDF_ERR_UNSUPPORTED
- * otherwise); any number of pairs per call (the call runs them in ranges that fit its 64-bit sort key). */
+ * otherwise); any number of pairs per call (the call runs them in ranges that fit its 64-bit sort key).  seq_pool = NULL: the
+ * offsets point into the pool sdf_pool_upload left in HBM (pool_bytes: how much of it the pairs may name). */
 typedef struct {
   int64_t q_off, r_off; /* byte offsets of query / reference characters in seq_pool */
   int32_t qlen, rlen;

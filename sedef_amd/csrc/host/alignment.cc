@@ -97,23 +97,9 @@ Sequence::Sequence(const std::string &n, const std::string &s, bool is_rc_) : na
 }
 
 // ---- DP access ---------------------------------------------------------------------------------------
-Cigar DpSession::align(const std::string &q_codes, const std::string &t_codes) {
-  if (recording) {
-    requests->push_back({q_codes, t_codes});
-    return Cigar();
-  }
-  assert(cursor < results->size());
-  return (*results)[cursor++];
-}
-
 Cigar DpSession::align_ranges(const char *q, int qlen, const char *t, int tlen) {
   if (recording) {
-    DpRequest rq;
-    rq.q.resize((size_t)qlen);
-    rq.t.resize((size_t)tlen);
-    for (int i = 0; i < qlen; i++) rq.q[(size_t)i] = kDna.align[(unsigned char)q[i] & 127];
-    for (int i = 0; i < tlen; i++) rq.t[(size_t)i] = kDna.align[(unsigned char)t[i] & 127];
-    requests->push_back(std::move(rq));
+    requests->push_back(DpRequest{q, t, qlen, tlen});
     return Cigar();
   }
   assert(cursor < results->size());

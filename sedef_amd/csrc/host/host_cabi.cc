@@ -151,15 +151,16 @@ static int alignment_pair_impl(const Params &p, const char *fa, const char *fb, 
   try {
     set_alignment_scoring(p);
     auto dp = provider(test_dp, device);
+    const std::string sa = fa, sb = fb;  // (requests point into the sequences: they live until the DP has run)
     std::vector<DpRequest> reqs;
     DpSession rec;
     rec.requests = &reqs;
-    { Alignment tmp(fa, fb, rec); }
+    { Alignment tmp(sa, sb, rec); }
     std::vector<Cigar> res = dp->run(reqs, p);
     DpSession rep;
     rep.recording = false;
     rep.results = &res;
-    Alignment al(fa, fb, rep);
+    Alignment al(sa, sb, rep);
     counts[0] = al.matches();
     counts[1] = al.mismatches();
     counts[2] = al.gaps();

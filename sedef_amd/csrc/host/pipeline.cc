@@ -46,13 +46,23 @@ struct TaskPool {
   size_t size = 0;
   const uint8_t *data() const { return bytes.get(); }
 };
+struct AlignCodes {  // align_dna (src/common.h:60-70,91): ACGT of either case 0..3, anything else the wildcard 4
+  uint8_t of[256];
+  AlignCodes() {
+    for (int c = 0; c < 256; c++) {  // (the table is indexed with c & 127, like the host's align_dna)
+      const int u = (c & 127) & ~0x20;
+      of[c] = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+    }
+  }
+};
+const AlignCodes kCodes;
 void expand(const std::vector<DpRequest> &reqs, const Params &p, std::vector<TaskRef> &tasks, TaskPool &pool) {
   const size_t n = reqs.size(), step = (size_t)p.max_ksw_seq_len;
   std::vector<size_t> off(n + 1, 0), first(n + 1, 0);
   for (size_t k = 0; k < n; k++) {
     const DpRequest &r = reqs[k];
-    off[k + 1] = off[k] + r.q.size() + r.t.size();
-    const size_t lim = std::min(r.q.size(), r.t.size());
+    off[k + 1] = off[k] + (size_t)r.qlen + (size_t)r.tlen;
+    const size_t lim = (size_t)std::min(r.qlen, r.tlen);
     first[k + 1] = first[k] + (lim + step - 1) / step;
   }
   pool.size = off[n];
@@ -62,18 +72,19 @@ void expand(const std::vector<DpRequest> &reqs, const Params &p, std::vector<Tas
   parallel_for((int)((n + block - 1) / block), [&](int b) {
     for (size_t k = (size_t)b * block; k < std::min(n, ((size_t)b + 1) * block); k++) {
       const DpRequest &r = reqs[k];
-      const size_t qo = off[k], to = qo + r.q.size();
-      memcpy(pool.bytes.get() + qo, r.q.data(), r.q.size());
-      memcpy(pool.bytes.get() + to, r.t.data(), r.t.size());
-      const size_t lim = std::min(r.q.size(), r.t.size());
+      const size_t qo = off[k], to = qo + (size_t)r.qlen;
+      uint8_t *dq = pool.bytes.get() + qo, *dt = pool.bytes.get() + to;
+      for (int i = 0; i < r.qlen; i++) dq[i] = kCodes.of[(unsigned char)r.q[i]];
+      for (int i = 0; i < r.tlen; i++) dt[i] = kCodes.of[(unsigned char)r.t[i]];
+      const size_t lim = (size_t)std::min(r.qlen, r.tlen);
       size_t at = first[k];
       for (size_t sp = 0; sp < lim; sp += step) {
         TaskRef &t = tasks[at++];
         t.req = k;
         t.q_off = qo + sp;
         t.t_off = to + sp;
-        t.qlen = (int)std::min<size_t>(step, r.q.size() - sp);
-        t.tlen = (int)std::min<size_t>(step, r.t.size() - sp);
+        t.qlen = (int)std::min<size_t>(step, (size_t)r.qlen - sp);
+        t.tlen = (int)std::min<size_t>(step, (size_t)r.tlen - sp);
       }
     }
   });
@@ -194,6 +205,8 @@ class GpuProvider : public DpProvider {
     const size_t tasks = max_batch_bytes / 250 + 65536, bases = max_batch_bytes / 6 + (1u << 20);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = sdf_reserve(ctx_, tasks, bases, ws_, SDF_RESERVE_BRIEF | SDF_RESERVE_ANCHORS | (lanes_ > 1 ? SDF_RESERVE_FEW_STREAMS : 0u));
+    // (the super-batch's characters are written straight into pinned memory and cross PCIe as one DMA: sized here, once)
+    if (stage_settings().gpu_anchors) (void)sdf_pool_host(ctx_, max_batch_bytes + 4096);
     if (stage_settings().debug_timing)
       fprintf(stderr, "[sdf_reserve tasks %zu bases %zu: rc %d, %.1f ms]\n", tasks, bases, rc,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -224,32 +237,93 @@ class GpuProvider : public DpProvider {
     for (auto &t : tr) raw.first_task[t.req + 1]++;  // tasks are in request order
     for (size_t r = 0; r < reqs.size(); r++) raw.first_task[r + 1] += raw.first_task[r];
     if (tr.empty()) return true;
-    std::unique_ptr<sdf_task[]> tasks(new sdf_task[tr.size()]);
-    const size_t nt = tr.size(), tblock = 16384, ntb = (nt + tblock - 1) / tblock;
+    const size_t nt = tr.size();
+    std::unique_ptr<sdf_task[]> tasks(new sdf_task[nt]);
+    const size_t tblock = 16384, ntb = (nt + tblock - 1) / tblock;
+    parallel_for((int)ntb, [&](int b) {
+      for (size_t k = (size_t)b * tblock; k < std::min(nt, ((size_t)b + 1) * tblock); k++)
+        tasks[k] = make_task((int64_t)tr[k].q_off, (int64_t)tr[k].t_off, tr[k].qlen, tr[k].tlen);
+    });
+    call_batch(tasks.get(), nt, &pool, p, raw, tp0);
+    return true;
+  }
+
+  // The same round on ranges of the character pool the last anchors() call left on the device: nothing is cut out, coded,
+  // packed or uploaded here (include/sedef_hip.h: sdf_extz2_batch_pairs) -- a request becomes its 60 kb chunks
+  // (src/align.cc:46-47: both sequences advance by the same offset) and that is all the host does per task.
+  bool run_resident(const std::vector<ResidentReq> &reqs, const Params &p, Raw &raw) override {
+    if (!resident_) return false;
+    const size_t n = reqs.size(), step = (size_t)p.max_ksw_seq_len;
+    raw.first_task.assign(n + 1, 0);
+    raw.off.clear();
+    raw.cnt.clear();
+    raw.match.clear();
+    if (reqs.empty()) return true;
+    const auto tp0 = std::chrono::steady_clock::now();
+    const size_t rblock = 16384, nrb = (n + rblock - 1) / rblock;
+    std::vector<size_t> bfirst(nrb + 1, 0);
+    parallel_for((int)nrb, [&](int b) {
+      size_t c = 0;
+      for (size_t k = (size_t)b * rblock; k < std::min(n, ((size_t)b + 1) * rblock); k++)
+        c += ((size_t)std::min(reqs[k].qlen, reqs[k].tlen) + step - 1) / step;
+      bfirst[(size_t)b + 1] = c;
+    });
+    for (size_t b = 0; b < nrb; b++) bfirst[b + 1] += bfirst[b];
+    const size_t nt = bfirst[nrb];
+    raw.first_task[n] = nt;
+    if (nt == 0) {
+      std::fill(raw.first_task.begin(), raw.first_task.end(), 0);
+      return true;
+    }
+    std::unique_ptr<sdf_task[]> tasks(new sdf_task[nt]);
+    parallel_for((int)nrb, [&](int b) {
+      size_t at = bfirst[(size_t)b];
+      for (size_t k = (size_t)b * rblock; k < std::min(n, ((size_t)b + 1) * rblock); k++) {
+        const ResidentReq &r = reqs[k];
+        raw.first_task[k] = at;
+        const size_t lim = (size_t)std::min(r.qlen, r.tlen);
+        for (size_t sp = 0; sp < lim; sp += step)
+          tasks[at++] = make_task(r.q_off + (int64_t)sp, r.t_off + (int64_t)sp, (int)std::min<size_t>(step, (size_t)r.qlen - sp),
+                                  (int)std::min<size_t>(step, (size_t)r.tlen - sp));
+      }
+    });
+    call_batch(tasks.get(), nt, nullptr, p, raw, tp0);
+    return true;
+  }
+
+ private:
+  static sdf_task make_task(int64_t q_off, int64_t t_off, int qlen, int tlen) {
+    sdf_task t;
+    memset(&t, 0, sizeof(t));
+    t.q_off = q_off;
+    t.t_off = t_off;
+    t.qlen = qlen;
+    t.tlen = tlen;
+    t.w = -1;      // src/align.cc:86
+    t.zdrop = -1;  // src/align.cc:54
+    t.flag = 0;
+    return t;
+  }
+  // one device batch call and its results as Raw: `pool` holds the tasks' codes (offsets are bytes of it), or is NULL when the
+  // offsets are ranges of the resident character pool
+  void call_batch(const sdf_task *tasks, size_t nt, const TaskPool *pool, const Params &p, Raw &raw,
+                  std::chrono::steady_clock::time_point tp0) {
+    const size_t tblock = 16384, ntb = (nt + tblock - 1) / tblock;
     std::vector<size_t> cap_part(ntb, 0);
     std::vector<int64_t> cells_part(ntb, 0);
     parallel_for((int)ntb, [&](int b) {
       size_t cap_b = 0;
       int64_t cells_b = 0;
       for (size_t k = (size_t)b * tblock; k < std::min(nt, ((size_t)b + 1) * tblock); k++) {
-        sdf_task &t = tasks[k];
-        memset(&t, 0, sizeof(t));
-        t.q_off = (int64_t)tr[k].q_off;
-        t.t_off = (int64_t)tr[k].t_off;
-        t.qlen = tr[k].qlen;
-        t.tlen = tr[k].tlen;
-        t.w = -1;      // src/align.cc:86
-        t.zdrop = -1;  // src/align.cc:54
-        t.flag = 0;
-        cap_b += (size_t)t.qlen + t.tlen + 2;
-        cells_b += (int64_t)t.qlen * t.tlen;
+        cap_b += (size_t)tasks[k].qlen + tasks[k].tlen + 2;
+        cells_b += (int64_t)tasks[k].qlen * tasks[k].tlen;
       }
       cap_part[(size_t)b] = cap_b;
       cells_part[(size_t)b] = cells_b;
     });
     size_t cap = 0;
     for (size_t b = 0; b < ntb; b++) cap += cap_part[b], cells += cells_part[b];
-    this->tasks += (int64_t)tr.size();
+    this->tasks += (int64_t)nt;
     sdf_scoring sc;
     memset(&sc, 0, sizeof(sc));
     sc.m = 5;
@@ -258,12 +332,13 @@ class GpuProvider : public DpProvider {
     sc.gape = (int8_t)(-p.gap_extend);
     // (plain arrays, not std::vectors: the CIGAR capacity is the worst case, hundreds of megabytes that would be
     // zero-filled and paged in although the call writes only the words it reports in `used`)
-    std::unique_ptr<sdf_result_brief[]> res(new sdf_result_brief[tr.size()]);
+    std::unique_ptr<sdf_result_brief[]> res(new sdf_result_brief[nt]);
     std::unique_ptr<uint32_t[]> cig(new uint32_t[cap]);
     size_t used = 0;
     ready();
     const auto tp1 = std::chrono::steady_clock::now();
-    const int rc = sdf_extz2_batch_brief(ctx_, &sc, tasks.get(), nt, pool.data(), pool.size, res.get(), cig.get(), cap, &used);
+    const int rc = pool ? sdf_extz2_batch_brief(ctx_, &sc, tasks, nt, pool->data(), pool->size, res.get(), cig.get(), cap, &used)
+                        : sdf_extz2_batch_pairs(ctx_, &sc, tasks, nt, res.get(), cig.get(), cap, &used);
     if (rc != SDF_OK) throw std::string("DP batch failed: ") + sdf_last_error(ctx_);
     const auto tp2 = std::chrono::steady_clock::now();
     raw.off.resize(nt);
@@ -279,9 +354,9 @@ class GpuProvider : public DpProvider {
     raw.words = std::move(cig);
     t_pack += std::chrono::duration<double>(tp1 - tp0).count();
     t_call += std::chrono::duration<double>(tp2 - tp1).count();
-    return true;
   }
 
+ public:
   // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
   bool anchors(const std::vector<AnchorJob> &jobs, int kmer, AnchorBatch &out) override {
     if (!stage_settings().gpu_anchors || jobs.empty()) return false;
@@ -307,26 +382,36 @@ class GpuProvider : public DpProvider {
       pairs[k].same_chr = jobs[k].same_chr;
       pairs[k].delta = jobs[k].delta;
     }
-    // (plain arrays, not vectors: nothing here needs the zero fill of a hundred megabytes)
-    std::unique_ptr<char[]> pool(new char[total + 1]);
+    // The characters of all pairs back to back in the context's pinned staging (sized with the lane's other buffers), one
+    // asynchronous DMA, and they STAY on the device: the DP rounds of this super-batch name their tasks as ranges of them
+    // (run_resident).
+    resident_ = false;
+    char *pool = sdf_pool_host(ctx_, total + 1);
+    if (!pool) return host_instead(sdf_last_error(ctx_));
     parallel_for((int)jobs.size(), [&](int k) {
-      memcpy(pool.get() + pairs[k].q_off, jobs[k].query->data(), jobs[k].query->size());
-      memcpy(pool.get() + pairs[k].r_off, jobs[k].ref->data(), jobs[k].ref->size());
+      memcpy(pool + pairs[k].q_off, jobs[k].query->data(), jobs[k].query->size());
+      memcpy(pool + pairs[k].r_off, jobs[k].ref->data(), jobs[k].ref->size());
     });
+    if (sdf_pool_upload(ctx_, pool, total) != SDF_OK) return host_instead(sdf_last_error(ctx_));
     out.off.assign(jobs.size() + 1, 0);
     size_t cap = std::max<size_t>(total / 8, 4096), used = 0;
     static_assert(sizeof(sdf_anchor) == sizeof(Anchor), "layouts must agree");
     out.buf.reset(new Anchor[cap]);
-    int rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.get(), total, kmer, (sdf_anchor *)out.buf.get(), cap,
+    int rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), nullptr, total, kmer, (sdf_anchor *)out.buf.get(), cap,
                                out.off.data(), &used);
     if (rc == SDF_ERR_CIGAR_OVERFLOW) {
       cap = used;
       out.buf.reset(new Anchor[cap]);
-      rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), pool.get(), total, kmer, (sdf_anchor *)out.buf.get(), cap,
+      rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), nullptr, total, kmer, (sdf_anchor *)out.buf.get(), cap,
                              out.off.data(), &used);
     }
     if (rc == SDF_ERR_UNSUPPORTED || rc == SDF_ERR_NOMEM) return host_instead(sdf_last_error(ctx_));
     if (rc != SDF_OK) throw std::string("GPU anchors failed: ") + sdf_last_error(ctx_);
+    resident_ = stage_settings().resident_dp;
+    out.resident = resident_;
+    out.q_base.resize(jobs.size());
+    out.r_base.resize(jobs.size());
+    for (size_t k = 0; k < jobs.size(); k++) out.q_base[k] = pairs[k].q_off, out.r_base[k] = pairs[k].r_off;
     return true;
   }
 
@@ -337,6 +422,7 @@ class GpuProvider : public DpProvider {
   int lanes_;
   int64_t tasks_ = 0;
   bool prepared_ = false;
+  bool resident_ = false;  // the last anchors() call's characters are in HBM (sdf_pool_upload)
   std::thread reserve_thread_;
   std::vector<std::unique_ptr<GpuProvider>> spares_;
   std::vector<int> spare_dev_;
@@ -499,8 +585,10 @@ PairJob::PairJob(const std::string &query, const std::string &ref, const Hit &or
 }
 
 void PairJob::stage_start(std::vector<DpRequest> &out) {  // src/chain.cc:203-258
-  query_ptr_ = std::make_shared<Sequence>("QRY", query_);
-  ref_ptr_ = std::make_shared<Sequence>("REF", ref_);
+  // (the hits' Sequence objects carry names and strands; nothing of the stage reads bases through them -- a copy of both
+  // sequences per pair was 182 MB of memcpy and page faults in the chr1-sized run)
+  query_ptr_ = std::make_shared<Sequence>("QRY", std::string());
+  ref_ptr_ = std::make_shared<Sequence>("REF", std::string());
   if (!have_anchors_) anchors_ = generate_anchors(query_, ref_, orig_, p_.kmer);
   else anchors_.assign(ext_anchors_, ext_anchors_ + ext_count_);
   auto chains = chain_anchors(anchors_, p_);
@@ -647,7 +735,7 @@ std::vector<DpRequest> PairJob::advance(const std::vector<Cigar> &results) {
     cursor += counts[w];
   }
 
-  const std::string &qseq = query_ptr_->seq, &rseq = ref_ptr_->seq;
+  const std::string &qseq = query_, &rseq = ref_;
   for (size_t pk = 0; pk < paths_.size(); pk++) {
     PathState &ps = *paths_[pk];
     if (ps.finished || !ps.est_ok) continue;
@@ -791,6 +879,7 @@ StageSettings StageSettings::from_env() {
   s.host_threads = (int)num("SDF_HOST_THREADS", 0, 4096, 0);
   if (const char *e = getenv("SDF_STAGE_WS_GIB")) s.stage_ws_gib = atof(e) > 0 ? atof(e) : 0;
   s.debug_timing = getenv("SDF_DEBUG_TIMING") != nullptr;
+  s.resident_dp = num("SDF_RESIDENT_DP", 0, 1, 1) != 0;
   s.bucket_lanes = (int)num("SDF_BUCKET_LANES", 1, 4, 2);
   if (const char *e = getenv("SDF_DEVICES"))
     for (const char *c = e; *c;) {
@@ -1053,6 +1142,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     std::vector<size_t> first_req(n, 0), n_req(n, 0);
     for (;;) {
       std::vector<DpRequest> batch;
+      std::vector<DpProvider::ResidentReq> rbatch;
       std::vector<std::pair<int, size_t>> owners;
       bool any = false;
       const auto tadv = now();
@@ -1081,22 +1171,42 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       a.t_longest += longest_us.load() / 1e6;
       a.t_sum += sum_us.load() / 1e6;
       const auto tc = now();
+      std::vector<size_t> first(n + 1, 0);
       for (int k = 0; k < n; k++) {
-        Item &it = items[k];
-        if (!it.pending.empty()) {
-          owners.push_back({k, it.pending.size()});
-          for (auto &r : it.pending) batch.push_back(std::move(r));
-          it.pending.clear();
+        first[k + 1] = first[k] + items[k].pending.size();
+        if (!items[k].pending.empty()) {
+          owners.push_back({k, items[k].pending.size()});
           any = true;
         }
       }
+      // (requests are four words each; with the pairs' characters on the device they become offsets of that pool, on the
+      // host threads: 708,600 of them in the first round of the chr1-sized run)
+      if (seeds.resident) rbatch.resize(first[n]);
+      else batch.resize(first[n]);
+      std::atomic<bool> outside(false);
+      parallel_for(n, [&](int k) {
+        Item &it = items[k];
+        size_t at = first[k];
+        if (seeds.resident) {
+          const char *qa = it.fa.data(), *ra = it.fb.data();
+          for (const DpRequest &r : it.pending) {
+            if (r.q < qa || r.q + r.qlen > qa + it.fa.size() || r.t < ra || r.t + r.tlen > ra + it.fb.size()) outside.store(true);
+            rbatch[at++] = {seeds.q_base[k] + (r.q - qa), seeds.r_base[k] + (r.t - ra), r.qlen, r.tlen};
+          }
+        } else {
+          for (const DpRequest &r : it.pending) batch[at++] = r;
+        }
+        it.pending.clear();
+      });
+      if (outside.load()) throw std::string("internal: a DP request outside its pair's sequences");
       a.t_collect += since(tc);
       if (!any) break;
       a.rounds++;
       mark(base, "jobs advanced, requests collected");
       const auto td = now();
       std::vector<Cigar> got;
-      have_raw = dp.run_raw(batch, p, raw);
+      have_raw = seeds.resident ? dp.run_resident(rbatch, p, raw) : dp.run_raw(batch, p, raw);
+      if (seeds.resident && !have_raw) throw std::string("internal: the provider lost its resident sequences");
       if (!have_raw) got = dp.run(batch, p);
       a.dp_secs += since(td);
       mark(base, "DP round done");

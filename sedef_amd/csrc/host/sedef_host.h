@@ -93,9 +93,13 @@ struct Anchor {  // reference: src/align.h:25-28
 };
 
 // ---- DP requests ---------------------------------------------------------------------------------
-// One align_helper call: the two strings are ALREADY mapped through align_dna (codes 0..4 as chars).
+// One align_helper call (src/align.cc:39-68) before align_dna: two ranges of raw FASTA characters.  The ranges point into
+// the pair's own two sequences -- the reference cuts substrings out of them (src/align.cc:129-175,235-242,583-590); here
+// nothing is copied: a provider that keeps the super-batch's characters in HBM turns the pointers into offsets of that pool
+// (ResidentReq), the others code the bases where they build their task pool.  The sequences must outlive the request.
 struct DpRequest {
-  std::string q, t;
+  const char *q, *t;
+  int qlen, tlen;
 };
 
 // Runs a batch of align_helper-equivalent requests; returns one CIGAR (ops M/D/I) per request.
@@ -115,6 +119,13 @@ class DpProvider {
     Cigar cigar(size_t req) const;
   };
   virtual bool run_raw(const std::vector<DpRequest> &, const Params &, Raw &) { return false; }
+  // Optional: the same for requests named as ranges of the character pool the provider's last anchors() call left on the
+  // device (AnchorBatch::resident; offsets = q_base / r_base of the pair + the range's start in the pair's sequence).
+  struct ResidentReq {
+    int64_t q_off, t_off;
+    int32_t qlen, tlen;
+  };
+  virtual bool run_resident(const std::vector<ResidentReq> &, const Params &, Raw &) { return false; }
   // Optional: another provider of the same kind (own device context) for a second lane of the stage driver.
   // (device < 0: the same device as this one)
   virtual std::unique_ptr<DpProvider> clone(int /*device*/ = -1) { return nullptr; }
@@ -136,6 +147,10 @@ class DpProvider {
   struct AnchorBatch {
     std::unique_ptr<Anchor[]> buf;
     std::vector<int64_t> off;
+    // resident: the pairs' characters stay on the device until the provider's next anchors() call -- pair k's query at
+    // q_base[k], its reference at r_base[k] of that pool -- and run_resident() takes requests in those coordinates
+    bool resident = false;
+    std::vector<int64_t> q_base, r_base;
   };
   virtual bool anchors(const std::vector<AnchorJob> &, int /*kmer*/, AnchorBatch &) { return false; }
   int64_t tasks = 0, cells = 0;  // statistics
@@ -176,8 +191,7 @@ struct DpSession {
   // true: both sequences of the pair hold nothing but ACGTN (either case), so a match on the DP's codes is a match of
   // the reference's character comparison (src/align.cc:29-35) and the device's match counter can be taken as it is
   bool codes_are_exact = false;
-  Cigar align(const std::string &q_codes, const std::string &t_codes);
-  // align_helper on two ranges of raw FASTA characters (mapped through align_dna here)
+  // align_helper on two ranges of raw FASTA characters (align_dna is the provider's business)
   Cigar align_ranges(const char *q, int qlen, const char *t, int tlen);
 };
 
@@ -400,6 +414,7 @@ struct StageSettings {
   int host_threads = 0;      // SDF_HOST_THREADS: threads of the per-pair host work (0: the CPUs the process may use, at most 64)
   double stage_ws_gib = 0;   // SDF_STAGE_WS_GIB: direction-flag workspace per lane (0: 8 GiB per process shared out)
   bool debug_timing = false; // SDF_DEBUG_TIMING: one line per phase of every super-batch
+  bool resident_dp = true;   // SDF_RESIDENT_DP=0: the DP rounds cut their bases out on the host again instead of naming ranges of the characters the anchors call left in HBM
   int bucket_lanes = 2;      // SDF_BUCKET_LANES: buckets of a several-bucket run in flight, each on a device context of its own (1: one after the other)
   static StageSettings from_env();
 };

@@ -254,6 +254,8 @@ extern "C" void sdf_destroy(sdf_ctx *ctx) {
   if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
   ctx->host_lane.release();
   ctx->host_an.release();
+  ctx->host_chars.release();
+  ctx->pk_recs.release();
   if (ctx->rerun_ctx) sdf_destroy(ctx->rerun_ctx);
   if (ctx->part_ctx) sdf_destroy(ctx->part_ctx);
   if (ctx->part_ev) (void)hipEventDestroy(ctx->part_ev);
@@ -783,6 +785,11 @@ __global__ void brief_results_kernel(const sdf_result *__restrict__ res, sdf_res
   out[k] = b;
 }
 
+static int batch_host_tail(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *t2, size_t n, size_t words, uint32_t want,
+                           sdf_result *out, sdf_result_brief *brief, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used,
+                           int nthr, std::chrono::steady_clock::time_point dbg0, std::chrono::steady_clock::time_point dbg1,
+                           const char *what);
+
 // The host-buffer call: sequences packed into pinned memory, one upload, the device-resident call, results and CIGARs back
 // through pinned staging.  `brief`: 16-byte records instead of sdf_result (sdf_extz2_batch_brief).
 static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, const uint8_t *seq_pool,
@@ -798,7 +805,6 @@ static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   }
   SDF_HIP(hipSetDevice(ctx->device));
   // pack every referenced sequence once (2-bit codes + N mask) and rewrite offsets to words
-  const bool dbg_t = ctx->cfg.debug_timing != 0;
   const auto dbg0 = std::chrono::steady_clock::now();
   // (the task array with word offsets: kept by the context -- a fresh vector of 700,000 tasks is 34 MB of page faults per
   // call -- the offsets written here, the other fields copied by the packing threads below)
@@ -855,11 +861,21 @@ static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
   }
   const auto dbg1 = std::chrono::steady_clock::now();
   SDF_HIP(ctx->h_pool.reserve(std::max<size_t>(words, 1) * 4));
+  SDF_HIP(hipMemcpyAsync(ctx->h_pool.p, packed, std::max<size_t>(words, 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  return batch_host_tail(ctx, sc, t2.data(), n, words, want, out, brief, cigar_pool, cigar_cap, cigar_used, nthr, dbg0, dbg1, "sdf_extz2_batch");
+}
+
+// ... the rest of a host-buffer call once the packed sequences are (being) written to ctx->h_pool on ctx->stream: the
+// device-resident call, results and CIGAR words back through pinned staging.
+static int batch_host_tail(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *t2, size_t n, size_t words, uint32_t want,
+                           sdf_result *out, sdf_result_brief *brief, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used,
+                           int nthr, std::chrono::steady_clock::time_point dbg0, std::chrono::steady_clock::time_point dbg1,
+                           const char *what) {
+  const bool dbg_t = ctx->cfg.debug_timing != 0;
   SDF_HIP(ctx->h_out.reserve(n * sizeof(sdf_result)));
   SDF_HIP(ctx->h_cig.reserve(std::max<size_t>(cigar_cap, 1) * 4));
-  SDF_HIP(hipMemcpyAsync(ctx->h_pool.p, packed, std::max<size_t>(words, 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   size_t used = 0;
-  int rc = sdf_extz2_batch_device(ctx, sc, t2.data(), n, (const uint32_t *)ctx->h_pool.p, want,
+  int rc = sdf_extz2_batch_device(ctx, sc, t2, n, (const uint32_t *)ctx->h_pool.p, want,
                                   (sdf_result *)ctx->h_out.p, (uint32_t *)ctx->h_cig.p, cigar_cap, &used,
                                   ctx->stream);
   if (cigar_used) *cigar_used = used;
@@ -897,8 +913,8 @@ static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count();
     };
-    fprintf(stderr, "[sdf_extz2_batch n=%zu words=%zu cap=%zu used=%zu] pack %.1f ms, h2d+device %.1f ms (plan %.1f, dp %.1f, tb %.1f), d2h %.1f ms%s\n",
-            n, words, cigar_cap, used, ms(dbg0, dbg1), ms(dbg1, dbg2), ctx->ms[4], ctx->ms[0], ctx->ms[1], ms(dbg2, dbg3),
+    fprintf(stderr, "[%s n=%zu words=%zu cap=%zu used=%zu] pack %.1f ms, h2d+device %.1f ms (plan %.1f, dp %.1f, tb %.1f), d2h %.1f ms%s\n",
+            what, n, words, cigar_cap, used, ms(dbg0, dbg1), ms(dbg1, dbg2), ctx->ms[4], ctx->ms[0], ctx->ms[1], ms(dbg2, dbg3),
             ctx->reran ? (", " + std::to_string(ctx->reran) + " tasks given up by a stripe wait and run again").c_str() : "");
   }
   return SDF_OK;
@@ -916,6 +932,126 @@ extern "C" int sdf_extz2_batch_brief(sdf_ctx *ctx, const sdf_scoring *sc, const 
                                      uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used) {
   return batch_host(ctx, sc, tasks, n, seq_pool, pool_bytes, SDF_WANT_CIGAR | SDF_WANT_SCORE, nullptr, out, cigar_pool, cigar_cap,
                     cigar_used);
+}
+
+// ---- resident sequences (include/sedef_hip.h; seq_pack.hip) --------------------------------------------------------
+extern "C" char *sdf_pool_host(sdf_ctx *ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  ctx->err.clear();
+  if (hipSetDevice(ctx->device) != hipSuccess || ctx->host_chars.reserve_exact(std::max<size_t>(bytes, 64)) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->err = "cannot pin the character pool's staging";
+    return nullptr;
+  }
+  return (char *)ctx->host_chars.p;
+}
+
+extern "C" int sdf_pool_upload(sdf_ctx *ctx, const char *chars, size_t bytes) {
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  ctx->pool_bytes = 0;
+  if (!chars && bytes) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  SDF_HIP(hipSetDevice(ctx->device));
+  ctx->an_pool.new_call();
+  SDF_HIP(ctx->an_pool.reserve(bytes + 64));
+  if (bytes) SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, chars, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ctx->pool_bytes = bytes;
+  return SDF_OK;
+}
+
+extern "C" size_t sdf_pool_bytes(const sdf_ctx *ctx) { return ctx ? ctx->pool_bytes : 0; }
+
+static int batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, uint32_t want, sdf_result *out,
+                       sdf_result_brief *brief, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used) {
+  using sdf::PackRec;
+  if (!ctx) return SDF_ERR_INVALID;
+  ctx->err.clear();
+  if (cigar_used) *cigar_used = 0;
+  if (n == 0) return SDF_OK;
+  if (!tasks || (!out && !brief) || n > 0x3fffffffu) {
+    ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  SDF_HIP(hipSetDevice(ctx->device));
+  const auto dbg0 = std::chrono::steady_clock::now();
+  // The task array with WORD offsets for the planner and the kernels, and one 32-byte record per task for the packing
+  // kernel: where the task's characters are and where its packed words go.  Two passes over blocks of tasks on a few
+  // threads (700,000 tasks a round in the chr1-sized stage run): the words of each block, then the records.
+  std::vector<sdf_task> &t2 = ctx->host_tasks;
+  if (t2.size() < n) t2.resize(n + n / 2);
+  SDF_HIP(ctx->host_pool.reserve(n * sizeof(PackRec)));
+  PackRec *recs = (PackRec *)ctx->host_pool.p;
+  const size_t block = 32768, nb = (n + block - 1) / block, pool_bytes = ctx->pool_bytes;
+  std::vector<size_t> bwords(nb + 1, 0);
+  std::atomic<bool> bad(false);
+  const unsigned thr_cap = g_live_contexts.load() > 1 ? 4u : (unsigned)std::max(1, std::min(8, usable_cpus() / 2));
+  const int nthr = (int)std::min<size_t>(nb, thr_cap);
+  auto on_blocks = [&](const std::function<void(size_t)> &f) {
+    std::atomic<size_t> next(0);
+    auto work = [&] {
+      for (size_t b = next.fetch_add(1); b < nb; b = next.fetch_add(1)) f(b);
+    };
+    std::vector<std::thread> thr;
+    for (int q = 1; q < nthr; ++q) thr.emplace_back(work);
+    work();
+    for (auto &th : thr) th.join();
+  };
+  on_blocks([&](size_t b) {
+    size_t w = 0;
+    for (size_t k = b * block; k < std::min(n, (b + 1) * block); ++k) {
+      const sdf_task &t = tasks[k];
+      if (t.qlen < 0 || t.tlen < 0 || t.q_off < 0 || t.t_off < 0 || (size_t)t.q_off + (size_t)t.qlen > pool_bytes ||
+          (size_t)t.t_off + (size_t)t.tlen > pool_bytes)
+        bad.store(true);
+      w += sdf_packed_words(t.qlen) + sdf_packed_words(t.tlen);
+    }
+    bwords[b + 1] = w;
+  });
+  if (bad.load()) {
+    ctx->err = "task sequence range outside the resident pool (sdf_pool_upload)";
+    return SDF_ERR_INVALID;
+  }
+  for (size_t b = 0; b < nb; ++b) bwords[b + 1] += bwords[b];
+  const size_t words = bwords[nb];
+  on_blocks([&](size_t b) {
+    size_t w = bwords[b];
+    for (size_t k = b * block; k < std::min(n, (b + 1) * block); ++k) {
+      const sdf_task &t = tasks[k];
+      PackRec &r = recs[k];
+      r.q_byte = t.q_off;
+      r.t_byte = t.t_off;
+      r.q_word = (int64_t)w;
+      r.qlen = t.qlen;
+      r.tlen = t.tlen;
+      t2[k] = t;
+      t2[k].q_off = (int64_t)w;
+      w += sdf_packed_words(t.qlen);
+      t2[k].t_off = (int64_t)w;
+      w += sdf_packed_words(t.tlen);
+    }
+  });
+  const auto dbg1 = std::chrono::steady_clock::now();
+  for (DevBuf *b : {&ctx->pk_recs}) b->new_call();
+  SDF_HIP(ctx->h_pool.reserve(std::max<size_t>(words, 1) * 4));
+  SDF_HIP(ctx->pk_recs.reserve(n * sizeof(PackRec)));
+  SDF_HIP(hipMemcpyAsync(ctx->pk_recs.p, recs, n * sizeof(PackRec), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(sdf::pack_chars_kernel, dim3((unsigned)((2 * n + 15) / 16)), dim3(256), 0, ctx->stream,
+                     (const PackRec *)ctx->pk_recs.p, (long long)(2 * n), (const char *)ctx->an_pool.p, (uint32_t *)ctx->h_pool.p);
+  return batch_host_tail(ctx, sc, t2.data(), n, words, want, out, brief, cigar_pool, cigar_cap, cigar_used, nthr, dbg0, dbg1,
+                         "sdf_extz2_batch_pairs");
+}
+
+extern "C" int sdf_extz2_batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, sdf_result_brief *out,
+                                     uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used) {
+  return batch_pairs(ctx, sc, tasks, n, SDF_WANT_CIGAR | SDF_WANT_SCORE, nullptr, out, cigar_pool, cigar_cap, cigar_used);
+}
+
+extern "C" int sdf_extz2_batch_pairs_full(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, uint32_t want,
+                                          sdf_result *out, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used) {
+  return batch_pairs(ctx, sc, tasks, n, want, out, nullptr, cigar_pool, cigar_cap, cigar_used);
 }
 
 // Buffers sized once (include/sedef_hip.h).  The bounds per task are the planner's: a launch-order entry per task and
@@ -1026,7 +1162,7 @@ extern "C" size_t sdf_device_bytes(const sdf_ctx *ctx) {
   size_t sum = 0;
   for (const DevBuf *b : {&ctx->dir_ws, &ctx->stage_ws, &ctx->plan_buf, &ctx->order_buf, &ctx->misc_buf, &ctx->gstate_buf, &ctx->claim_buf,
                           &ctx->h_pool, &ctx->h_out, &ctx->h_brief, &ctx->h_cig, &ctx->rr_out, &ctx->rr_cig, &ctx->rr_map, &ctx->ln_recs,
-                          &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp,
+                          &ctx->ln_keys, &ctx->ln_vals, &ctx->ln_sizes, &ctx->ln_tmp, &ctx->pk_recs,
                           // the anchors / chaining / stats entry points
                           &ctx->an_pool, &ctx->an_pairs, &ctx->an_keys, &ctx->an_keys2, &ctx->an_q, &ctx->an_off, &ctx->an_flag, &ctx->an_pos,
                           &ctx->an_cand, &ctx->an_out, &ctx->an_tmp, &ctx->an_outoff, &ctx->ch_an, &ctx->ch_off, &ctx->ch_wsoff, &ctx->ch_work,
@@ -1153,8 +1289,13 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
   if (!ctx) return SDF_ERR_INVALID;
   ctx->err.clear();
   if (out_used) *out_used = 0;
-  if (!pairs || !out_off || !out_used || (!seq_pool && pool_bytes)) {
+  if (!pairs || !out_off || !out_used) {
     ctx->err = "invalid arguments";
+    return SDF_ERR_INVALID;
+  }
+  const bool resident = !seq_pool && pool_bytes;  // (the characters sdf_pool_upload left in HBM)
+  if (resident && pool_bytes > ctx->pool_bytes) {
+    ctx->err = "the resident pool (sdf_pool_upload) is shorter than pool_bytes";
     return SDF_ERR_INVALID;
   }
   if (kmer < 1 || kmer > 15) {  // (the reference's hash is the 2-bit code of the k-mer in 32 bits, src/chain.cc:30-35)
@@ -1181,8 +1322,12 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
   }
   const bool dbg_t = ctx->cfg.debug_timing != 0;
   const auto dbg0 = std::chrono::steady_clock::now();
-  SDF_HIP(ctx->an_pool.reserve(pool_bytes + 16));
-  SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!resident) {  // (the pool stays where it is after the call: sdf_extz2_batch_pairs may name ranges of it)
+    ctx->pool_bytes = 0;
+    SDF_HIP(ctx->an_pool.reserve(pool_bytes + 64));
+    SDF_HIP(hipMemcpyAsync(ctx->an_pool.p, seq_pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->pool_bytes = pool_bytes;
+  }
   if (dbg_t) SDF_HIP(hipStreamSynchronize(ctx->stream));
   const auto dbg1 = std::chrono::steady_clock::now();
   // Key = pair | hash (2k bits) | position: the pairs are run in ranges that fit the bits the other two fields leave (k = 11

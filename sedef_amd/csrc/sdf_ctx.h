@@ -72,6 +72,8 @@ __global__ void cigar_compact_kernel(const PlanTask *, int, const sdf_result *, 
                                      uint32_t *, unsigned long long);
 
 __global__ void reset_results_kernel(sdf_result *res, int n);
+struct PackRec;
+__global__ void pack_chars_kernel(const PackRec *, long long, const char *, uint32_t *);
 // (diagnostics of buffers that have no context to ask: set by every sdf_create from its configuration's debug_timing)
 inline std::atomic<bool> g_debug_timing{false};
 
@@ -293,6 +295,9 @@ struct sdf_ctx {
   std::vector<sdf_task> host_tasks;  // ... the task array with word offsets
   // lane kernel (extz2_lane.hip): records as uploaded, sort keys / values (in, out), sizes and their scans, hipCUB scratch
   HostBuf host_lane;
+  HostBuf host_chars;      // pinned staging of a super-batch's FASTA characters (sdf_pool_host)
+  size_t pool_bytes = 0;   // characters resident in an_pool (sdf_pool_upload / sdf_anchors_batch): what sdf_extz2_batch_pairs may name
+  DevBuf pk_recs;          // ... one PackRec per task of such a call (seq_pack.hip)
   HostBuf host_an;  // pinned staging of the anchors call's output (sdf_reserve with SDF_RESERVE_ANCHORS; a pageable copy runs at ~3 GB/s)
   DevBuf ln_recs, ln_keys, ln_vals, ln_sizes, ln_tmp;
   DevBuf ln_bins;  // ... second form of the lane planning: per-key counts, ranks, prefixes (extz2_lane.hip: lane_hist_kernel and on)

@@ -80,6 +80,18 @@ def load_library():
     L.sdf_extz2_batch_brief.restype = C.c_int
     L.sdf_extz2_batch_brief.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdf_pool_host.restype = C.c_void_p
+    L.sdf_pool_host.argtypes = [C.c_void_p, C.c_size_t]
+    L.sdf_pool_upload.restype = C.c_int
+    L.sdf_pool_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.sdf_pool_bytes.restype = C.c_size_t
+    L.sdf_pool_bytes.argtypes = [C.c_void_p]
+    L.sdf_extz2_batch_pairs.restype = C.c_int
+    L.sdf_extz2_batch_pairs.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.POINTER(C.c_size_t)]
+    L.sdf_extz2_batch_pairs_full.restype = C.c_int
+    L.sdf_extz2_batch_pairs_full.argtypes = [C.c_void_p, C.POINTER(_Scoring), C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.sdf_reserve.restype = C.c_int
     L.sdf_reserve.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32]
     L.sdf_device_bytes.restype = C.c_size_t
@@ -277,6 +289,41 @@ class Extz2Engine:
         used = C.c_size_t(0)
         self._check(self.lib.sdf_extz2_batch_brief(self.ctx, C.byref(sc), tasks.ctypes.data, n, pool.ctypes.data, pool.nbytes,
                                                    out.ctypes.data, cig.ctypes.data, cigar_cap, C.byref(used)))
+        return out, cig[:used.value]
+
+    def pool_upload(self, chars, pinned=True):
+        """sdf_pool_host + sdf_pool_upload: raw FASTA characters (bytes) to HBM, where they stay; sdf_extz2_batch_pairs tasks
+        name byte ranges of them.  pinned=False: straight from the caller's (pageable) buffer."""
+        buf = np.frombuffer(chars, np.uint8)
+        if pinned:
+            p = self.lib.sdf_pool_host(self.ctx, len(buf))
+            if not p:
+                raise SdfError(self.lib.sdf_last_error(self.ctx).decode())
+            C.memmove(p, buf.ctypes.data, len(buf))
+            self._check(self.lib.sdf_pool_upload(self.ctx, p, len(buf)))
+        else:
+            self._keep = buf  # (unchanged until the next call that returns data)
+            self._check(self.lib.sdf_pool_upload(self.ctx, buf.ctypes.data, len(buf)))
+        return int(self.lib.sdf_pool_bytes(self.ctx))
+
+    def align_batch_pairs(self, tasks, mat=None, gapo=40, gape=1, want=None, cigar_cap=None):
+        """sdf_extz2_batch_pairs (want=None: 16-byte records) / sdf_extz2_batch_pairs_full: q_off / t_off of the tasks are byte
+        offsets into the resident character pool; align_dna and the packing happen on the device."""
+        tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)
+        n = len(tasks)
+        sc = _scoring(sedef_mat() if mat is None else mat, gapo, gape)
+        if cigar_cap is None:
+            cigar_cap = int((tasks["qlen"].astype(np.int64) + tasks["tlen"] + 2).sum()) + 1
+        cig = np.zeros(cigar_cap, np.uint32)
+        used = C.c_size_t(0)
+        if want is None:
+            out = np.zeros(n, BRIEF_DTYPE)
+            self._check(self.lib.sdf_extz2_batch_pairs(self.ctx, C.byref(sc), tasks.ctypes.data, n, out.ctypes.data,
+                                                       cig.ctypes.data, cigar_cap, C.byref(used)))
+        else:
+            out = np.zeros(n, RESULT_DTYPE)
+            self._check(self.lib.sdf_extz2_batch_pairs_full(self.ctx, C.byref(sc), tasks.ctypes.data, n, want, out.ctypes.data,
+                                                            cig.ctypes.data, cigar_cap, C.byref(used)))
         return out, cig[:used.value]
 
     def reserve(self, max_tasks, max_bases, workspace_bytes=0, flags=0):

@@ -1351,3 +1351,130 @@ def test_brief_results_and_buffers_sized_once(oracle):
         assert cigar_to_str(got) == cigar_to_str(exp["cigar"])
     assert eng.device_bytes() > held
     eng.close()
+
+
+def _fasta_pool(rng, n_seq, lo, hi):
+    """Raw FASTA characters: soft-masked ACGT, N runs and IUPAC letters (align_dna maps all of those to the wildcard)."""
+    letters = np.frombuffer(b"ACGTacgtNnRYKMSWryBDHV-*", np.uint8)
+    prob = np.array([20, 20, 20, 20, 4, 4, 4, 4, 1.0, 0.4] + [0.05] * 14)
+    prob /= prob.sum()
+    seqs = [letters[rng.choice(len(letters), int(rng.integers(lo, hi)), p=prob)] for _ in range(n_seq)]
+    return seqs
+
+
+def _align_codes(chars):
+    """align_dna (reference: src/common.h:60-70,91) as the HOST applies it: table index c & 127."""
+    tab = np.full(128, 4, np.uint8)
+    for k, c in enumerate(b"ACGT"):
+        tab[c] = tab[c | 0x20] = k
+    return tab[chars & 127]
+
+
+def test_resident_pool_tasks_equal_host_coded_tasks(oracle):
+    """sdf_extz2_batch_pairs (round 6): tasks name BYTE RANGES of raw FASTA characters resident in HBM (what the anchors call
+    uploaded); the device applies align_dna and packs them (seq_pack.hip).  Equal -- records and every CIGAR word -- to
+    sdf_extz2_batch_brief / sdf_extz2_batch on the same ranges cut out and coded on the host (reference: src/align.cc:39-57,80-84),
+    for overlapping ranges, every alignment of a range to the 32-base packing groups, soft-masked and IUPAC letters, a 60 kb
+    chunk, pinned and pageable uploads; a sample against the oracle."""
+    import sedef_amd
+    from sedef_amd.extz2 import TASK_DTYPE, WANT_CIGAR, WANT_SCORE
+    eng = sedef_amd.Extz2Engine(0)
+    rng = np.random.default_rng(6001)
+    # pairs of related sequences (a mutated copy, characters kept) so that the DP has something to find
+    pool_parts, spans = [], []
+    off = 0
+    for q in _fasta_pool(rng, 40, 300, 9000) + _fasta_pool(rng, 1, 70000, 70001):
+        keep = rng.random(len(q)) > 0.03
+        t = q[keep].copy()
+        sub = rng.random(len(t)) < 0.05
+        t[sub] = np.frombuffer(b"ACGTacgtN", np.uint8)[rng.integers(0, 9, int(sub.sum()))]
+        spans.append((off, len(q), off + len(q), len(t)))
+        off += len(q) + len(t)
+        pool_parts += [q, t]
+    chars = np.concatenate(pool_parts)
+    tasks = []
+    for (qo, ql, to, tl) in spans[:-1]:
+        for _ in range(60):  # SEDEF's gap fills: short ranges at every offset, plus a few of hundreds of bases
+            a = int(rng.integers(0, min(ql, tl) - 1))
+            n1 = int(rng.integers(1, 70)) if rng.random() < 0.9 else int(rng.integers(70, 1200))
+            n2 = max(1, n1 + int(rng.integers(-6, 7)))
+            tasks.append((qo + a, min(n1, ql - a), to + min(a, tl - 1), min(n2, tl - min(a, tl - 1))))
+    qo, ql, to, tl = spans[-1]
+    tasks.append((qo, 60000, to, 60000))  # one chunk of Align::MAX_KSW_SEQ_LEN
+    tasks.append((qo + 60000, ql - 60000, to + 60000, tl - 60000))
+    t_res = np.zeros(len(tasks), TASK_DTYPE)
+    t_host = np.zeros(len(tasks), TASK_DTYPE)
+    code_parts, coff = [], 0
+    for k, (a, n1, b, n2) in enumerate(tasks):
+        t_res[k] = (a, b, n1, n2, -1, -1, 0, 0)
+        t_host[k] = (coff, coff + n1, n1, n2, -1, -1, 0, 0)
+        code_parts += [_align_codes(chars[a:a + n1]), _align_codes(chars[b:b + n2])]
+        coff += n1 + n2
+    codes_pool = np.concatenate(code_parts)
+    brief_h, cig_h = eng.align_batch_brief(t_host, codes_pool)
+    for pinned in (True, False):
+        assert eng.pool_upload(chars.tobytes(), pinned=pinned) == len(chars)
+        brief_r, cig_r = eng.align_batch_pairs(t_res)
+        assert np.array_equal(cig_r, cig_h)
+        for f in ("cigar_off", "n_cigar", "matches"):
+            assert np.array_equal(brief_r[f], brief_h[f]), f
+    full_r, cig_f = eng.align_batch_pairs(t_res, want=WANT_CIGAR | WANT_SCORE)
+    full_h, cig_fh = eng.align_batch(t_host, codes_pool, want=WANT_CIGAR | WANT_SCORE)
+    assert np.array_equal(cig_f, cig_fh)
+    for f in full_r.dtype.names:
+        assert np.array_equal(full_r[f], full_h[f]), f
+    for k in range(0, len(tasks) - 2, 41):
+        a, n1, b, n2 = tasks[k]
+        exp = oracle.extz2(_align_codes(chars[a:a + n1]), _align_codes(chars[b:b + n2]), w=-1)
+        got = cig_r[int(brief_r["cigar_off"][k]):int(brief_r["cigar_off"][k]) + int(brief_r["n_cigar"][k])]
+        assert cigar_to_str(got) == cigar_to_str(exp["cigar"]) and int(full_r["score"][k]) == exp["score"]
+    # a range outside the resident pool is refused, an empty batch is not an error
+    bad = t_res[:1].copy()
+    bad["q_off"] = len(chars) - 3
+    bad["qlen"] = 8
+    with pytest.raises(sedef_amd.extz2.SdfError):
+        eng.align_batch_pairs(bad)
+    out, cig = eng.align_batch_pairs(t_res[:0])
+    assert len(out) == 0 and len(cig) == 0
+    eng.close()
+
+
+def test_resident_pool_after_anchors_call(oracle):
+    """sdf_anchors_batch leaves the characters it uploaded resident: the stage's order of calls -- anchors of a super-batch,
+    then DP rounds on ranges of the same pool -- and the anchors of a pool that was uploaded first (seq_pool = NULL)."""
+    import ctypes as C
+    import sedef_amd
+    from sedef_amd.extz2 import ANCHOR_DTYPE, ANCHOR_PAIR_DTYPE, TASK_DTYPE
+    eng = sedef_amd.Extz2Engine(0)
+    rng = np.random.default_rng(6002)
+    base = _fasta_pool(rng, 1, 5000, 5001)[0]
+    q = base.copy()
+    r = base[rng.random(len(base)) > 0.02].copy()
+    pool = np.concatenate([q, r])
+    desc = np.zeros(1, ANCHOR_PAIR_DTYPE)
+    desc[0] = (0, len(q), len(q), len(r), 0, 0)
+
+    def anchors(seq_pool):
+        out = np.zeros(len(pool), ANCHOR_DTYPE)
+        offs = np.zeros(2, np.int64)
+        used = C.c_size_t(0)
+        eng._check(eng.lib.sdf_anchors_batch(eng.ctx, desc.ctypes.data, 1, seq_pool, len(pool), 11, out.ctypes.data, len(out),
+                                             offs.ctypes.data, C.byref(used)))
+        return out[:used.value].copy()
+
+    a_host = anchors(pool.tobytes())  # uploads, and leaves the pool resident
+    assert len(a_host) > 5 and int(eng.lib.sdf_pool_bytes(eng.ctx)) == len(pool)
+    t = np.zeros(3, TASK_DTYPE)
+    t[0] = (10, len(q) + 10, 200, 190, -1, -1, 0, 0)
+    t[1] = (0, len(q), len(q), len(r), -1, -1, 0, 0)
+    t[2] = (4000, len(q) + 3900, 33, 35, -1, -1, 0, 0)
+    brief, cig = eng.align_batch_pairs(t)
+    for k in range(3):
+        exp = oracle.extz2(_align_codes(pool[t["q_off"][k]:t["q_off"][k] + t["qlen"][k]]),
+                           _align_codes(pool[t["t_off"][k]:t["t_off"][k] + t["tlen"][k]]), w=-1)
+        got = cig[int(brief["cigar_off"][k]):int(brief["cigar_off"][k]) + int(brief["n_cigar"][k])]
+        assert cigar_to_str(got) == cigar_to_str(exp["cigar"])
+    eng.pool_upload(pool.tobytes())
+    a_res = anchors(None)  # the pairs' offsets point into the resident pool
+    assert np.array_equal(a_res, a_host)
+    eng.close()
