@@ -229,7 +229,12 @@ int sdf_extz2_batch_brief(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *t
  *   sdf_anchors_batch(..., seq_pool = NULL, pool_bytes, ...)   the seed anchors of pairs whose offsets point into the
  *                                   resident pool; with a host seq_pool the call uploads it and leaves it resident.
  *   sdf_extz2_batch_pairs           the DP batch on ranges of the resident pool, 16-byte results;
- *   sdf_extz2_batch_pairs_full      the same with sdf_result records and a `want` mask. */
+ *   sdf_extz2_batch_pairs_full      the same with sdf_result records and a `want` mask.
+ *   sdf_extz2_batch_pairs_view / sdf_anchors_batch_view   the same calls for a caller that reads the results where the device's
+ *                                   copies land -- the context's pinned staging -- instead of receiving a second copy in
+ *                                   arrays of its own (the stage driver: 17 MB of records and CIGAR words per round, 34 MB of
+ *                                   anchors per super-batch).  *out / *cigar_pool are valid until the context's next call of
+ *                                   the same kind. */
 char *sdf_pool_host(sdf_ctx *ctx, size_t bytes);
 int sdf_pool_upload(sdf_ctx *ctx, const char *chars, size_t bytes);
 size_t sdf_pool_bytes(const sdf_ctx *ctx); /* characters resident at this moment */
@@ -237,6 +242,8 @@ int sdf_extz2_batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *t
                           uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
 int sdf_extz2_batch_pairs_full(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, uint32_t want,
                                sdf_result *out, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used);
+int sdf_extz2_batch_pairs_view(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                               const sdf_result_brief **out, const uint32_t **cigar_pool, size_t *cigar_used);
 
 /* Device-resident form: d_packed_pool, d_out and d_cigar_pool are HBM pointers on ctx's device;
  * tasks (host) carry word offsets into d_packed_pool.  Work is enqueued on `stream`
@@ -295,6 +302,9 @@ typedef struct {
  * total; with SDF_ERR_CIGAR_OVERFLOW it holds the capacity needed. */
 int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *seq_pool, size_t pool_bytes,
                       int kmer, sdf_anchor *out, size_t out_cap, int64_t *out_off, size_t *out_used);
+/* ... with the anchors left in the context's pinned staging (*out: valid until the context's next anchors call) */
+int sdf_anchors_batch_view(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *seq_pool, size_t pool_bytes,
+                           int kmer, const sdf_anchor **out, int64_t *out_off, size_t *out_used);
 
 /* ---- anchor chaining on the GPU ---------------------------------------------------------------
  * Replaces chain_anchors (reference: src/chain.cc:103-199) for a batch of pairs whose anchors are laid out as

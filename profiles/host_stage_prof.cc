@@ -50,7 +50,7 @@ struct ProfProvider : sdfh::DpProvider {
             h.ref = std::make_shared<sdfh::Sequence>(jobs[k].same_chr ? "a" : "b", "");
             h.query_start = 0;
             h.ref_start = jobs[k].delta;
-            cache[k] = sdfh::generate_anchors(*jobs[k].query, *jobs[k].ref, h, kmer);
+            cache[k] = sdfh::generate_anchors(jobs[k].query.str(), jobs[k].ref.str(), h, kmer);
           }
         });
       for (auto &t : thr) t.join();

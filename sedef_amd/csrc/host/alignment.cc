@@ -91,6 +91,14 @@ std::string rc(const std::string &s) {  // src/util.cc:43-48
   for (auto &c : r) c = kDna.rev[(unsigned char)c & 127];
   return r;
 }
+void rc_inplace(char *s, size_t n) {  // the same on bases that already lie where they are used
+  for (size_t i = 0, j = n; i < j; i++) {
+    --j;
+    const char a = kDna.rev[(unsigned char)s[i] & 127], b = kDna.rev[(unsigned char)s[j] & 127];
+    s[i] = b;
+    s[j] = a;
+  }
+}
 
 Sequence::Sequence(const std::string &n, const std::string &s, bool is_rc_) : name(n), seq(s), is_rc(is_rc_) {
   if (is_rc) seq = rc(s);
@@ -213,8 +221,8 @@ Alignment::Alignment(const std::string &fa, const std::string &fb, const std::st
   recount(count_matches(seq_a, seq_b, cigar));
 }
 
-Alignment::Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Anchor> &guide,
-                     const std::vector<int> &guide_idx, DpSession &dp)
+Alignment::Alignment(SeqView qstr, SeqView rstr, const std::vector<Anchor> &guide, const std::vector<int> &guide_idx,
+                     DpSession &dp)
     : seq_a(qstr.data()), seq_b(rstr.data()), len_a((int)qstr.size()), len_b((int)rstr.size()) {
   if (guide_idx.empty()) return;
   // anchors are exact matches (case-insensitive, no N): every column of their M runs is a match column
@@ -237,8 +245,7 @@ Alignment::Alignment(const std::string &qstr, const std::string &rstr, const std
   recount(matches_);
 }
 
-Alignment::Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Hit> &guide, int side,
-                     DpSession &dp) {
+Alignment::Alignment(SeqView qstr, SeqView rstr, const std::vector<Hit> &guide, int side, DpSession &dp) {
   *this = guide.front().aln;
   seq_a = qstr.data();
   seq_b = rstr.data();
@@ -504,7 +511,7 @@ void Alignment::normalise() {
   cigar = out;
 }
 
-void Alignment::merge(Alignment &cur, const std::string &qstr, const std::string &rstr, DpSession &dp) {
+void Alignment::merge(Alignment &cur, SeqView qstr, SeqView rstr, DpSession &dp) {
   seq_a = cur.seq_a = qstr.data();
   seq_b = cur.seq_b = rstr.data();
   len_a = cur.len_a = (int)qstr.size();

@@ -117,7 +117,7 @@ FastaReference::~FastaReference() {
   if (fd_ >= 0) close(fd_);
 }
 
-std::string FastaReference::get_sequence(const std::string &seqname, int start, int *end) {  // src/fasta.cc:105-142
+FastaReference::Span FastaReference::locate(const std::string &seqname, int start, int *end) const {  // src/fasta.cc:105-132
   auto it = index_.find(seqname);
   if (it == index_.end()) throw "Chromosome " + seqname + " does not exist";
   const FastaIndexEntry &entry = it->second;
@@ -132,14 +132,36 @@ std::string FastaReference::get_sequence(const std::string &seqname, int start, 
   const int newlines_before = start > 0 ? (start - 1) / entry.line_blen : 0;
   const int newlines_by_end = (start + length - 1) / entry.line_blen;
   const int seqlen = length + (newlines_by_end - newlines_before);
-  if (seqlen <= 0) return std::string();
-  const char *src = (const char *)mm_ + entry.offset + newlines_before + start;
-  std::string s;
-  s.reserve((size_t)seqlen);
-  for (int i = 0; i < seqlen; i++) {
-    const char c = src[i];
-    if (c != '\n' && c != '\0') s += c;  // std::remove of '\n' then '\0' (src/fasta.cc:135-136)
+  Span sp;
+  if (seqlen <= 0) return sp;
+  sp.src = (const char *)mm_ + entry.offset + newlines_before + start;
+  sp.bytes = (size_t)seqlen;
+  return sp;
+}
+
+// std::remove of '\n' then '\0' (src/fasta.cc:135-136), a line at a time
+size_t FastaReference::extract(const Span &sp, char *dst) {
+  const char *src = sp.src, *const stop = sp.src + sp.bytes;
+  char *out = dst;
+  while (src < stop) {
+    const char *nl = (const char *)memchr(src, '\n', (size_t)(stop - src));
+    const size_t seg = (size_t)((nl ? nl : stop) - src);
+    if (memchr(src, '\0', seg)) {
+      for (size_t i = 0; i < seg; i++)
+        if (src[i] != '\0') *out++ = src[i];
+    } else {
+      memcpy(out, src, seg);
+      out += seg;
+    }
+    src += seg + 1;
   }
+  return (size_t)(out - dst);
+}
+
+std::string FastaReference::get_sequence(const std::string &seqname, int start, int *end) {  // src/fasta.cc:105-142
+  const Span sp = locate(seqname, start, end);
+  std::string s(sp.bytes, '\0');
+  s.resize(extract(sp, &s[0]));
   return s;
 }
 

@@ -206,7 +206,9 @@ class GpuProvider : public DpProvider {
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = sdf_reserve(ctx_, tasks, bases, ws_, SDF_RESERVE_BRIEF | SDF_RESERVE_ANCHORS | (lanes_ > 1 ? SDF_RESERVE_FEW_STREAMS : 0u));
     // (the super-batch's characters are written straight into pinned memory and cross PCIe as one DMA: sized here, once)
-    if (stage_settings().gpu_anchors) (void)sdf_pool_host(ctx_, max_batch_bytes + 4096);
+    // (a sequence's slot is as long as its range in the FILE -- a line end per 50-80 bases --, and a pair's end may move to the
+    // chromosome's: a sixteenth more than the bases, so that the stage never pins a second time)
+    if (stage_settings().gpu_anchors) (void)sdf_pool_host(ctx_, max_batch_bytes + max_batch_bytes / 16 + (1u << 20));
     if (stage_settings().debug_timing)
       fprintf(stderr, "[sdf_reserve tasks %zu bases %zu: rc %d, %.1f ms]\n", tasks, bases, rc,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -226,9 +228,8 @@ class GpuProvider : public DpProvider {
 
   bool run_raw(const std::vector<DpRequest> &reqs, const Params &p, Raw &raw) override {
     raw.first_task.assign(reqs.size() + 1, 0);
-    raw.off.clear();
-    raw.cnt.clear();
-    raw.match.clear();
+    raw.recs = nullptr;
+    raw.words = nullptr;
     if (reqs.empty()) return true;
     std::vector<TaskRef> tr;
     TaskPool pool;
@@ -255,9 +256,8 @@ class GpuProvider : public DpProvider {
     if (!resident_) return false;
     const size_t n = reqs.size(), step = (size_t)p.max_ksw_seq_len;
     raw.first_task.assign(n + 1, 0);
-    raw.off.clear();
-    raw.cnt.clear();
-    raw.match.clear();
+    raw.recs = nullptr;
+    raw.words = nullptr;
     if (reqs.empty()) return true;
     const auto tp0 = std::chrono::steady_clock::now();
     const size_t rblock = 16384, nrb = (n + rblock - 1) / rblock;
@@ -330,33 +330,40 @@ class GpuProvider : public DpProvider {
     fill_mat(p, sc.mat);
     sc.gapo = (int8_t)(-p.gap_open);
     sc.gape = (int8_t)(-p.gap_extend);
-    // (plain arrays, not std::vectors: the CIGAR capacity is the worst case, hundreds of megabytes that would be
-    // zero-filled and paged in although the call writes only the words it reports in `used`)
-    std::unique_ptr<sdf_result_brief[]> res(new sdf_result_brief[nt]);
-    std::unique_ptr<uint32_t[]> cig(new uint32_t[cap]);
+    static_assert(sizeof(Raw::Rec) == sizeof(sdf_result_brief), "layouts must agree");
     size_t used = 0;
     ready();
     const auto tp1 = std::chrono::steady_clock::now();
-    const int rc = pool ? sdf_extz2_batch_brief(ctx_, &sc, tasks, nt, pool->data(), pool->size, res.get(), cig.get(), cap, &used)
-                        : sdf_extz2_batch_pairs(ctx_, &sc, tasks, nt, res.get(), cig.get(), cap, &used);
+    int rc;
+    if (pool) {
+      // (plain arrays, not std::vectors: the CIGAR capacity is the worst case, hundreds of megabytes that would be
+      // zero-filled and paged in although the call writes only the words it reports in `used`)
+      raw.own_recs.reset(new Raw::Rec[nt]);
+      raw.own_words.reset(new uint32_t[cap]);
+      rc = sdf_extz2_batch_brief(ctx_, &sc, tasks, nt, pool->data(), pool->size, (sdf_result_brief *)raw.own_recs.get(),
+                                 raw.own_words.get(), cap, &used);
+      raw.recs = raw.own_recs.get();
+      raw.words = raw.own_words.get();
+    } else {  // (read where the device's copies land: nothing is copied out of the pinned staging)
+      const sdf_result_brief *res = nullptr;
+      rc = sdf_extz2_batch_pairs_view(ctx_, &sc, tasks, nt, &res, &raw.words, &used);
+      raw.recs = (const Raw::Rec *)res;
+    }
     if (rc != SDF_OK) throw std::string("DP batch failed: ") + sdf_last_error(ctx_);
     const auto tp2 = std::chrono::steady_clock::now();
-    raw.off.resize(nt);
-    raw.cnt.resize(nt);
-    raw.match.resize(nt);
-    parallel_for((int)ntb, [&](int b) {
-      for (size_t k = (size_t)b * tblock; k < std::min(nt, ((size_t)b + 1) * tblock); k++) {
-        raw.off[k] = res[k].cigar_off;
-        raw.cnt[k] = (int32_t)res[k].n_cigar;
-        raw.match[k] = res[k].matches;
-      }
-    });
-    raw.words = std::move(cig);
     t_pack += std::chrono::duration<double>(tp1 - tp0).count();
     t_call += std::chrono::duration<double>(tp2 - tp1).count();
   }
 
  public:
+  char *pool_host(size_t bytes) override {
+    if (!stage_settings().gpu_anchors) return nullptr;
+    ready();
+    pool_ = sdf_pool_host(ctx_, bytes + 64);
+    pool_cap_ = pool_ ? bytes + 64 : 0;
+    return pool_;
+  }
+
   // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
   bool anchors(const std::vector<AnchorJob> &jobs, int kmer, AnchorBatch &out) override {
     if (!stage_settings().gpu_anchors || jobs.empty()) return false;
@@ -370,43 +377,59 @@ class GpuProvider : public DpProvider {
     if (kmer > 15) return host_instead("GPU anchors implement k-mer sizes up to 15");
     std::vector<sdf_anchor_pair> pairs(jobs.size());
     size_t total = 0;
+    // (sequences the driver fetched into this provider's pinned pool -- pool_host() -- are where they have to be)
+    bool in_pool = pool_ != nullptr;
+    for (size_t k = 0; k < jobs.size() && in_pool; k++)
+      in_pool = jobs[k].query.data() >= pool_ && jobs[k].query.data() + jobs[k].query.size() <= pool_ + pool_cap_ &&
+                jobs[k].ref.data() >= pool_ && jobs[k].ref.data() + jobs[k].ref.size() <= pool_ + pool_cap_;
     for (size_t k = 0; k < jobs.size(); k++) {
-      if (jobs[k].query->size() >= (1u << 31) || jobs[k].ref->size() >= (1u << 31))
+      if (jobs[k].query.size() >= (1u << 31) || jobs[k].ref.size() >= (1u << 31))
         return host_instead("GPU anchors implement sequences shorter than 2 Gb");
-      pairs[k].q_off = (int64_t)total;
-      total += jobs[k].query->size();
-      pairs[k].r_off = (int64_t)total;
-      total += jobs[k].ref->size();
-      pairs[k].qlen = (int32_t)jobs[k].query->size();
-      pairs[k].rlen = (int32_t)jobs[k].ref->size();
+      pairs[k].q_off = in_pool ? (int64_t)(jobs[k].query.data() - pool_) : (int64_t)total;
+      total += jobs[k].query.size();
+      pairs[k].r_off = in_pool ? (int64_t)(jobs[k].ref.data() - pool_) : (int64_t)total;
+      total += jobs[k].ref.size();
+      pairs[k].qlen = (int32_t)jobs[k].query.size();
+      pairs[k].rlen = (int32_t)jobs[k].ref.size();
       pairs[k].same_chr = jobs[k].same_chr;
       pairs[k].delta = jobs[k].delta;
+    }
+    if (in_pool) {  // (the pool's used extent, not the sum: slots are as long as the file's bytes, line ends included)
+      total = 0;
+      for (auto &pr : pairs) total = std::max<size_t>(total, (size_t)std::max(pr.q_off + pr.qlen, pr.r_off + pr.rlen));
     }
     // The characters of all pairs back to back in the context's pinned staging (sized with the lane's other buffers), one
     // asynchronous DMA, and they STAY on the device: the DP rounds of this super-batch name their tasks as ranges of them
     // (run_resident).
     resident_ = false;
-    char *pool = sdf_pool_host(ctx_, total + 1);
-    if (!pool) return host_instead(sdf_last_error(ctx_));
-    parallel_for((int)jobs.size(), [&](int k) {
-      memcpy(pool + pairs[k].q_off, jobs[k].query->data(), jobs[k].query->size());
-      memcpy(pool + pairs[k].r_off, jobs[k].ref->data(), jobs[k].ref->size());
-    });
-    if (sdf_pool_upload(ctx_, pool, total) != SDF_OK) return host_instead(sdf_last_error(ctx_));
-    out.off.assign(jobs.size() + 1, 0);
-    size_t cap = std::max<size_t>(total / 8, 4096), used = 0;
-    static_assert(sizeof(sdf_anchor) == sizeof(Anchor), "layouts must agree");
-    out.buf.reset(new Anchor[cap]);
-    int rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), nullptr, total, kmer, (sdf_anchor *)out.buf.get(), cap,
-                               out.off.data(), &used);
-    if (rc == SDF_ERR_CIGAR_OVERFLOW) {
-      cap = used;
-      out.buf.reset(new Anchor[cap]);
-      rc = sdf_anchors_batch(ctx_, pairs.data(), pairs.size(), nullptr, total, kmer, (sdf_anchor *)out.buf.get(), cap,
-                             out.off.data(), &used);
+    char *pool = pool_;
+    if (!in_pool) {
+      pool = pool_ = sdf_pool_host(ctx_, total + 1);
+      pool_cap_ = pool ? total + 1 : 0;
+      if (!pool) return host_instead(sdf_last_error(ctx_));
+      parallel_for((int)jobs.size(), [&](int k) {
+        memcpy(pool + pairs[k].q_off, jobs[k].query.data(), jobs[k].query.size());
+        memcpy(pool + pairs[k].r_off, jobs[k].ref.data(), jobs[k].ref.size());
+      });
     }
+    const auto tu0 = std::chrono::steady_clock::now();
+    if (sdf_pool_upload(ctx_, pool, total) != SDF_OK) return host_instead(sdf_last_error(ctx_));
+    if (stage_settings().debug_timing)
+      fprintf(stderr, "[anchors: %zu pairs, pool %zu bytes %s, upload enqueued in %.1f ms]\n", jobs.size(), total,
+              in_pool ? "fetched in place" : "copied", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
+    out.off.assign(jobs.size() + 1, 0);
+    size_t used = 0;
+    static_assert(sizeof(sdf_anchor) == sizeof(Anchor), "layouts must agree");
+    // (the anchors stay in the context's pinned staging: the jobs copy theirs out when they start)
+    const sdf_anchor *found = nullptr;
+    out.buf.reset();
+    int rc = sdf_anchors_batch_view(ctx_, pairs.data(), pairs.size(), nullptr, total, kmer, &found, out.off.data(), &used);
+    out.view = (const Anchor *)found;
     if (rc == SDF_ERR_UNSUPPORTED || rc == SDF_ERR_NOMEM) return host_instead(sdf_last_error(ctx_));
     if (rc != SDF_OK) throw std::string("GPU anchors failed: ") + sdf_last_error(ctx_);
+    if (stage_settings().debug_timing)
+      fprintf(stderr, "[anchors: device call returned %.1f ms after the upload was enqueued]\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
     resident_ = stage_settings().resident_dp;
     out.resident = resident_;
     out.q_base.resize(jobs.size());
@@ -423,6 +446,8 @@ class GpuProvider : public DpProvider {
   int64_t tasks_ = 0;
   bool prepared_ = false;
   bool resident_ = false;  // the last anchors() call's characters are in HBM (sdf_pool_upload)
+  char *pool_ = nullptr;   // the context's pinned character staging as last asked for (pool_host / anchors)
+  size_t pool_cap_ = 0;
   std::thread reserve_thread_;
   std::vector<std::unique_ptr<GpuProvider>> spares_;
   std::vector<int> spare_dev_;
@@ -477,8 +502,8 @@ Cigar DpProvider::Raw::cigar(size_t req) const {
   Cigar c;
   c.matches = 0;
   for (size_t k = first_task[req]; k < first_task[req + 1]; k++) {
-    append_ops(c, words.get() + off[k], cnt[k]);
-    c.matches += match[k];
+    append_ops(c, words + recs[k].off, recs[k].cnt);
+    c.matches += recs[k].match;
   }
   return c;
 }
@@ -567,9 +592,9 @@ struct PairJob::PathState {
   Hit result;
 };
 
-PairJob::PairJob(const std::string &query, const std::string &ref, const Hit &orig, const Params &p)
+PairJob::PairJob(SeqView query, SeqView ref, const Hit &orig, const Params &p)
     : query_(query), ref_(ref), orig_(orig), p_(p) {
-  auto plain = [](const std::string &s) {
+  auto plain = [](SeqView s) {
     static const struct Tab {
       bool ok[256];
       Tab() {
@@ -589,7 +614,7 @@ void PairJob::stage_start(std::vector<DpRequest> &out) {  // src/chain.cc:203-25
   // sequences per pair was 182 MB of memcpy and page faults in the chr1-sized run)
   query_ptr_ = std::make_shared<Sequence>("QRY", std::string());
   ref_ptr_ = std::make_shared<Sequence>("REF", std::string());
-  if (!have_anchors_) anchors_ = generate_anchors(query_, ref_, orig_, p_.kmer);
+  if (!have_anchors_) anchors_ = generate_anchors(query_.str(), ref_.str(), orig_, p_.kmer);
   else anchors_.assign(ext_anchors_, ext_anchors_ + ext_count_);
   auto chains = chain_anchors(anchors_, p_);
   const auto &chain = chains.first;
@@ -735,7 +760,7 @@ std::vector<DpRequest> PairJob::advance(const std::vector<Cigar> &results) {
     cursor += counts[w];
   }
 
-  const std::string &qseq = query_, &rseq = ref_;
+  const SeqView qseq = query_, rseq = ref_;
   for (size_t pk = 0; pk < paths_.size(); pk++) {
     PathState &ps = *paths_[pk];
     if (ps.finished || !ps.est_ok) continue;
@@ -1060,7 +1085,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
 
   struct Item {
     Hit h;
-    std::string fa, fb;
+    SeqView fa, fb;  // in the super-batch's pool (the provider's pinned staging, or the lane's own memory)
     std::unique_ptr<PairJob> job;
     std::vector<DpRequest> pending;
   };
@@ -1102,17 +1127,38 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     }
   } join_cleanup{cleanup};
   // One super-batch from the sequences to its formatted output lines (one string per pair, schedule order).
-  auto do_batch = [&](int base, int n, DpProvider &dp, Acc &a, std::vector<std::string> &lines,
-                      std::vector<int> &nhits) {
+  auto do_batch = [&](int base, int n, DpProvider &dp, Acc &a, std::vector<std::string> &lines, std::vector<int> &nhits,
+                      std::unique_ptr<char[]> &own_pool, size_t &own_pool_cap) {
     std::vector<Item> items(n);
     mark(base, "start");
     const auto tf = now();
-    parallel_for(n, [&](int k) {  // src/align_main.cc:299-306
+    // src/align_main.cc:299-306.  The bases of the whole super-batch go into ONE pool -- the provider's pinned staging when it
+    // has one: the anchors call uploads from there without another copy, and the DP rounds name ranges of it -- a slot per
+    // sequence as long as the bytes its range spans in the file (line ends included: the bound known before the copy).
+    std::vector<FastaReference::Span> span(2 * (size_t)n);
+    std::vector<size_t> slot(2 * (size_t)n + 1, 0);
+    for (int k = 0; k < n; k++) {
       Item &it = items[k];
       it.h = schedule[base + k];
-      it.fa = fr.get_sequence(it.h.query->name, it.h.query_start, &it.h.query_end);
-      it.fb = fr.get_sequence(it.h.ref->name, it.h.ref_start, &it.h.ref_end);
-      if (it.h.ref->is_rc) it.fb = rc(it.fb);
+      span[2 * k] = fr.locate(it.h.query->name, it.h.query_start, &it.h.query_end);
+      span[2 * k + 1] = fr.locate(it.h.ref->name, it.h.ref_start, &it.h.ref_end);
+      slot[2 * k + 1] = slot[2 * k] + span[2 * k].bytes;
+      slot[2 * k + 2] = slot[2 * k + 1] + span[2 * k + 1].bytes;
+    }
+    char *pool = dp.pool_host(slot[2 * (size_t)n] + 1);
+    if (!pool) {
+      if (own_pool_cap < slot[2 * (size_t)n] + 1) {
+        own_pool_cap = slot[2 * (size_t)n] + 1 + slot[2 * (size_t)n] / 8;
+        own_pool.reset(new char[own_pool_cap]);
+      }
+      pool = own_pool.get();
+    }
+    parallel_for(n, [&](int k) {
+      Item &it = items[k];
+      char *qa = pool + slot[2 * k], *ra = pool + slot[2 * k + 1];
+      it.fa = SeqView(qa, FastaReference::extract(span[2 * k], qa));
+      it.fb = SeqView(ra, FastaReference::extract(span[2 * k + 1], ra));
+      if (it.h.ref->is_rc) rc_inplace(ra, it.fb.size());
       it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
     });
     a.t_fetch += since(tf);
@@ -1122,13 +1168,13 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       std::vector<DpProvider::AnchorJob> aj(n);
       for (int k = 0; k < n; k++) {
         const Hit &h = items[k].h;
-        aj[k] = {&items[k].fa, &items[k].fb, h.query->name == h.ref->name && h.query->is_rc == h.ref->is_rc,
+        aj[k] = {items[k].fa, items[k].fb, h.query->name == h.ref->name && h.query->is_rc == h.ref->is_rc,
                  h.ref_start - h.query_start};
       }
       const auto ta = now();
       if (dp.anchors(aj, p.kmer, seeds)) {
         for (int k = 0; k < n; k++)
-          items[k].job->set_anchors(seeds.buf.get() + seeds.off[k], (size_t)(seeds.off[k + 1] - seeds.off[k]));
+          items[k].job->set_anchors(seeds.data() + seeds.off[k], (size_t)(seeds.off[k + 1] - seeds.off[k]));
         a.anchor_secs += since(ta);
       }
     }
@@ -1279,8 +1325,10 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
   if (nlanes <= 1) {
     std::vector<std::string> lines;
     std::vector<int> nhits;
+    std::unique_ptr<char[]> own_pool;  // (the lane's sequence pool when its provider has none: kept from batch to batch)
+    size_t own_pool_cap = 0;
     for (auto &b : batches) {
-      do_batch(b.first, b.second, dp0, acc[0], lines, nhits);
+      do_batch(b.first, b.second, dp0, acc[0], lines, nhits, own_pool, own_pool_cap);
       write_batch(b.first, b.second, lines, nhits);
     }
   } else {
@@ -1322,12 +1370,14 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         }
         std::vector<std::string> lines;
         std::vector<int> nhits;
+        std::unique_ptr<char[]> own_pool;
+        size_t own_pool_cap = 0;
         for (;;) {
           const size_t ti = next_batch.fetch_add(1);
           if (ti >= batches.size()) return;
           const size_t bi = turn[ti];
           try {
-            do_batch(batches[bi].first, batches[bi].second, *prov[(size_t)l], acc[(size_t)l], lines, nhits);
+            do_batch(batches[bi].first, batches[bi].second, *prov[(size_t)l], acc[(size_t)l], lines, nhits, own_pool, own_pool_cap);
           } catch (std::string &e) {
             std::lock_guard<std::mutex> g(mu);
             if (!failed) failure = e.empty() ? std::string("error") : e;

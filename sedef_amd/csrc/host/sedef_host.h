@@ -93,6 +93,23 @@ struct Anchor {  // reference: src/align.h:25-28
 };
 
 // ---- DP requests ---------------------------------------------------------------------------------
+// A sequence the stage only points to: a candidate pair's query or reference as the driver fetched it -- since round 6
+// straight into the provider's pinned character pool, where the anchors call uploads it from and the DP rounds' requests
+// point into (the reference holds a std::string per pair and cuts substrings out of it, src/align_main.cc:303-306).
+struct SeqView {
+  const char *p = nullptr;
+  size_t n = 0;
+  SeqView() {}
+  SeqView(const char *p_, size_t n_) : p(p_), n(n_) {}
+  SeqView(const std::string &s) : p(s.data()), n(s.size()) {}  // (the string must outlive the view)
+  const char *data() const { return p; }
+  size_t size() const { return n; }
+  const char *begin() const { return p; }
+  const char *end() const { return p + n; }
+  char operator[](size_t i) const { return p[i]; }
+  std::string str() const { return std::string(p, n); }
+};
+
 // One align_helper call (src/align.cc:39-68) before align_dna: two ranges of raw FASTA characters.  The ranges point into
 // the pair's own two sequences -- the reference cuts substrings out of them (src/align.cc:129-175,235-242,583-590); here
 // nothing is copied: a provider that keeps the super-batch's characters in HBM turns the pointers into offsets of that pool
@@ -111,10 +128,17 @@ class DpProvider {
   // them into Cigars where it consumes them (the stage driver does that on the thread that owns the pair, so that
   // the memory of a pair is allocated and freed by one thread).  Returns false if the provider has no raw form.
   struct Raw {
-    std::unique_ptr<uint32_t[]> words;
-    std::vector<int64_t> off;        // per task: first word
-    std::vector<int32_t> cnt;        // per task: number of words
-    std::vector<int32_t> match;      // per task: match columns (sdf_result.matches)
+    struct Rec {       // per task (the layout of sdf_result_brief)
+      int64_t off;     // first word
+      int32_t cnt;     // number of words
+      int32_t match;   // match columns (sdf_result.matches)
+    };
+    // records and words either in memory of this object or where the provider's device copies landed (its pinned
+    // staging: valid until the provider's next DP call -- the driver has consumed a round's results by then)
+    const Rec *recs = nullptr;
+    const uint32_t *words = nullptr;
+    std::unique_ptr<Rec[]> own_recs;
+    std::unique_ptr<uint32_t[]> own_words;
     std::vector<size_t> first_task;  // per request (+1): its tasks are [first_task[r], first_task[r+1])
     Cigar cigar(size_t req) const;
   };
@@ -139,13 +163,19 @@ class DpProvider {
   // Optional: generate_anchors for a batch of pairs on the device.  Returns false if the provider cannot do it
   // for these inputs (the caller then computes them on the host with generate_anchors()).
   struct AnchorJob {
-    const std::string *query, *ref;
+    SeqView query, ref;
     bool same_chr;
     int delta;
   };
+  // Optional: a host buffer of `bytes` the provider would like the super-batch's sequences fetched INTO (pinned memory it
+  // uploads from: AnchorJob views inside it are not copied again).  Valid until the provider's next pool_host() call.
+  // NULL: the driver keeps the sequences in memory of its own.
+  virtual char *pool_host(size_t /*bytes*/) { return nullptr; }
   // The anchors of pair k are flat.buf[flat.off[k] .. flat.off[k+1]).
   struct AnchorBatch {
     std::unique_ptr<Anchor[]> buf;
+    const Anchor *view = nullptr;  // ... or the provider's pinned staging (valid until its next anchors() call)
+    const Anchor *data() const { return view ? view : buf.get(); }
     std::vector<int64_t> off;
     // resident: the pairs' characters stay on the device until the provider's next anchors() call -- pair k's query at
     // q_base[k], its reference at r_base[k] of that pool -- and run_resident() takes requests in those coordinates
@@ -228,14 +258,12 @@ class Alignment {
   // a given CIGAR string over two whole strings (src/align.cc:90-105)
   Alignment(const std::string &fa, const std::string &fb, const std::string &cigar);
   // guide of refined chains + side extension (src/align.cc:107-197)
-  Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Hit> &guide, int side,
-            DpSession &dp);
+  Alignment(SeqView qstr, SeqView rstr, const std::vector<Hit> &guide, int side, DpSession &dp);
   // chain of seed anchors (src/align.cc:199-270)
-  Alignment(const std::string &qstr, const std::string &rstr, const std::vector<Anchor> &guide,
-            const std::vector<int> &guide_idx, DpSession &dp);
+  Alignment(SeqView qstr, SeqView rstr, const std::vector<Anchor> &guide, const std::vector<int> &guide_idx, DpSession &dp);
 
   // joins `cur`, which starts before this alignment ends, to this one (src/align.cc:505-610)
-  void merge(Alignment &cur, const std::string &qstr, const std::string &rstr, DpSession &dp);
+  void merge(Alignment &cur, SeqView qstr, SeqView rstr, DpSession &dp);
   void trim_front();  // keep the best-scoring suffix of the columns (src/align.cc:343-398)
   void trim_back();   // keep the best-scoring prefix (src/align.cc:400-456)
 
@@ -308,6 +336,15 @@ class FastaReference {
   explicit FastaReference(const std::string &filename);
   ~FastaReference();
   std::string get_sequence(const std::string &seqname, int start = 0, int *end = nullptr);
+  // The same in two steps, for a caller that places the bases itself: locate() clamps `end` like get_sequence and returns the
+  // bytes of the file the range spans (an upper bound of the bases: line ends are still inside; 0: nothing), extract() copies
+  // the bases of such a span to `dst` and returns how many there were.
+  struct Span {
+    const char *src = nullptr;
+    size_t bytes = 0;
+  };
+  Span locate(const std::string &seqname, int start, int *end) const;
+  static size_t extract(const Span &s, char *dst);
 
  private:
   int fd_ = -1;
@@ -334,6 +371,7 @@ std::string format_double(double x);  // fmt 4.0.1 "{}" of a double, as the refe
 void set_alignment_scoring(const Params &p);  // Align::MATCH and co. are process-wide (src/globals.cc:25-28)
 std::vector<std::string> split(const std::string &s, char delim);
 std::string rc(const std::string &s);
+void rc_inplace(char *s, size_t n);  // reverse complement of bases where they lie
 char align_dna(char c);
 char hash_dna(char c);
 
@@ -350,7 +388,7 @@ int rangemax_script(const int *pts, int n, const int *ops, int nops, int *out, i
 // ---- per-pair job: fast_align (src/chain.cc:203-268) + refine_chains (src/refine.cc:23-193), staged ----
 class PairJob {
  public:
-  PairJob(const std::string &query, const std::string &ref, const Hit &orig, const Params &p);
+  PairJob(SeqView query, SeqView ref, const Hit &orig, const Params &p);  // (views: the sequences outlive the job)
   // Advances as far as possible.  Returns the DP requests it is waiting for (empty => finished).
   // Call again with the results of the previous return value, in the same order.
   std::vector<DpRequest> advance(const std::vector<Cigar> &results);
@@ -372,7 +410,7 @@ class PairJob {
   void plan_paths();
   void finish_paths();
 
-  const std::string &query_, &ref_;
+  SeqView query_, ref_;
   Hit orig_;
   Params p_;
   Stage stage_ = START;

@@ -2,6 +2,10 @@
 // src/align_main.cc:341-373): `sedef align generate -k K [--match N --mismatch N --gap-open N --gap-extend N]
 // genome.fa bucket.bed`.  stdout carries only the BEDPE lines; everything else goes to stderr.
 // The DP runs on the GPU; without a HIP device the command fails with exit code 1.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <malloc.h>
@@ -63,7 +67,22 @@ struct Args {
 };
 }  // namespace
 
+// A crash says where: the frames of the faulting thread on stderr (the reference dies silently; sedef.sh:195 only counts the
+// "Finished" lines that are missing afterwards).
+static void crash_handler(int sig) {
+  void *frames[48];
+  const int n = backtrace(frames, 48);
+  const char msg[] = "\nsedef: fatal signal, frames of the faulting thread:\n";
+  if (write(2, msg, sizeof(msg) - 1) < 0) _exit(128 + sig);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
 int main(int argc, char **argv) {
+  signal(SIGSEGV, crash_handler);
+  signal(SIGBUS, crash_handler);
+  signal(SIGABRT, crash_handler);
   // the DP path keeps four streams busy; give the HIP runtime more hardware queues than its default of four so
   // that no two of them share one (has to be in the environment before the runtime initialises)
   setenv("GPU_MAX_HW_QUEUES", "8", 0);

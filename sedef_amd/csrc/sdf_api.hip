@@ -785,10 +785,17 @@ __global__ void brief_results_kernel(const sdf_result *__restrict__ res, sdf_res
   out[k] = b;
 }
 
+// (view: the caller reads records and CIGAR words where the device's copies land -- the context's pinned staging, valid until
+// the context's next call -- instead of receiving copies in arrays of its own)
+struct ResultView {
+  bool brief = true;
+  const void *res = nullptr;
+  const uint32_t *cig = nullptr;
+};
 static int batch_host_tail(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *t2, size_t n, size_t words, uint32_t want,
                            sdf_result *out, sdf_result_brief *brief, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used,
                            int nthr, std::chrono::steady_clock::time_point dbg0, std::chrono::steady_clock::time_point dbg1,
-                           const char *what);
+                           const char *what, ResultView *view = nullptr);
 
 // The host-buffer call: sequences packed into pinned memory, one upload, the device-resident call, results and CIGARs back
 // through pinned staging.  `brief`: 16-byte records instead of sdf_result (sdf_extz2_batch_brief).
@@ -870,7 +877,7 @@ static int batch_host(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
 static int batch_host_tail(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *t2, size_t n, size_t words, uint32_t want,
                            sdf_result *out, sdf_result_brief *brief, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used,
                            int nthr, std::chrono::steady_clock::time_point dbg0, std::chrono::steady_clock::time_point dbg1,
-                           const char *what) {
+                           const char *what, ResultView *view) {
   const bool dbg_t = ctx->cfg.debug_timing != 0;
   SDF_HIP(ctx->h_out.reserve(n * sizeof(sdf_result)));
   SDF_HIP(ctx->h_cig.reserve(std::max<size_t>(cigar_cap, 1) * 4));
@@ -881,11 +888,12 @@ static int batch_host_tail(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *
   if (cigar_used) *cigar_used = used;
   if (rc != SDF_OK) return rc;
   const auto dbg2 = std::chrono::steady_clock::now();
-  const size_t out_bytes = n * (brief ? sizeof(sdf_result_brief) : sizeof(sdf_result)), cig_bytes = (used && cigar_pool) ? used * 4 : 0;
+  const bool as_brief = view ? view->brief : brief != nullptr;
+  const size_t out_bytes = n * (as_brief ? sizeof(sdf_result_brief) : sizeof(sdf_result)), cig_bytes = (used && (cigar_pool || view)) ? used * 4 : 0;
   SDF_HIP(ctx->host_out.reserve(out_bytes + cig_bytes + 64));
   uint8_t *stg = (uint8_t *)ctx->host_out.p;
   const void *d_res = ctx->h_out.p;
-  if (brief) {
+  if (as_brief) {
     SDF_HIP(ctx->h_brief.reserve(out_bytes));
     hipLaunchKernelGGL(brief_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const sdf_result *)ctx->h_out.p, (sdf_result_brief *)ctx->h_brief.p, (int)n);
@@ -895,7 +903,10 @@ static int batch_host_tail(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *
   SDF_HIP(hipMemcpyAsync(stg, d_res, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (cig_bytes) SDF_HIP(hipMemcpyAsync(stg + out_bytes, ctx->h_cig.p, cig_bytes, hipMemcpyDeviceToHost, ctx->stream));
   SDF_HIP(hipStreamSynchronize(ctx->stream));
-  {
+  if (view) {
+    view->res = stg;
+    view->cig = (const uint32_t *)(stg + out_bytes);
+  } else {
     auto copy_range = [&](int q, int of) {
       const size_t a = out_bytes * (size_t)q / (size_t)of, b = out_bytes * (size_t)(q + 1) / (size_t)of;
       memcpy((uint8_t *)out_any + a, stg + a, b - a);
@@ -938,11 +949,19 @@ extern "C" int sdf_extz2_batch_brief(sdf_ctx *ctx, const sdf_scoring *sc, const 
 extern "C" char *sdf_pool_host(sdf_ctx *ctx, size_t bytes) {
   if (!ctx) return nullptr;
   ctx->err.clear();
-  if (hipSetDevice(ctx->device) != hipSuccess || ctx->host_chars.reserve_exact(std::max<size_t>(bytes, 64)) != hipSuccess) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t had = ctx->host_chars.cap;
+  const bool plain = getenv("SDF_POOL_PLAIN") != nullptr;  // (probe: hipHostMalloc instead of registered huge pages)
+  if (hipSetDevice(ctx->device) != hipSuccess ||
+      (plain ? ctx->host_chars.reserve_exact(std::max<size_t>(bytes, 64)) : ctx->host_chars.reserve_huge(std::max<size_t>(bytes, 64))) != hipSuccess) {
     (void)hipGetLastError();
     ctx->err = "cannot pin the character pool's staging";
     return nullptr;
   }
+  (void)ctx->an_pool.reserve(bytes + 64);  // (its place in HBM with it: a first upload of 180 MB waited 8 ms for this)
+  if (ctx->cfg.debug_timing && ctx->host_chars.cap != had)
+    fprintf(stderr, "[sdf_pool_host %zu MiB %s in %.1f ms]\n", ctx->host_chars.cap >> 20, ctx->host_chars.registered ? "registered huge pages" : "hipHostMalloc",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   return (char *)ctx->host_chars.p;
 }
 
@@ -965,13 +984,14 @@ extern "C" int sdf_pool_upload(sdf_ctx *ctx, const char *chars, size_t bytes) {
 extern "C" size_t sdf_pool_bytes(const sdf_ctx *ctx) { return ctx ? ctx->pool_bytes : 0; }
 
 static int batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, uint32_t want, sdf_result *out,
-                       sdf_result_brief *brief, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used) {
+                       sdf_result_brief *brief, uint32_t *cigar_pool, size_t cigar_cap, size_t *cigar_used,
+                       ResultView *view = nullptr) {
   using sdf::PackRec;
   if (!ctx) return SDF_ERR_INVALID;
   ctx->err.clear();
   if (cigar_used) *cigar_used = 0;
   if (n == 0) return SDF_OK;
-  if (!tasks || (!out && !brief) || n > 0x3fffffffu) {
+  if (!tasks || (!out && !brief && !view) || n > 0x3fffffffu) {
     ctx->err = "invalid arguments";
     return SDF_ERR_INVALID;
   }
@@ -985,7 +1005,7 @@ static int batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *task
   SDF_HIP(ctx->host_pool.reserve(n * sizeof(PackRec)));
   PackRec *recs = (PackRec *)ctx->host_pool.p;
   const size_t block = 32768, nb = (n + block - 1) / block, pool_bytes = ctx->pool_bytes;
-  std::vector<size_t> bwords(nb + 1, 0);
+  std::vector<size_t> bwords(nb + 1, 0), bcap(nb, 0);
   std::atomic<bool> bad(false);
   const unsigned thr_cap = g_live_contexts.load() > 1 ? 4u : (unsigned)std::max(1, std::min(8, usable_cpus() / 2));
   const int nthr = (int)std::min<size_t>(nb, thr_cap);
@@ -1000,16 +1020,22 @@ static int batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *task
     for (auto &th : thr) th.join();
   };
   on_blocks([&](size_t b) {
-    size_t w = 0;
+    size_t w = 0, c = 0;
     for (size_t k = b * block; k < std::min(n, (b + 1) * block); ++k) {
       const sdf_task &t = tasks[k];
       if (t.qlen < 0 || t.tlen < 0 || t.q_off < 0 || t.t_off < 0 || (size_t)t.q_off + (size_t)t.qlen > pool_bytes ||
           (size_t)t.t_off + (size_t)t.tlen > pool_bytes)
         bad.store(true);
       w += sdf_packed_words(t.qlen) + sdf_packed_words(t.tlen);
+      c += (size_t)t.qlen + (size_t)t.tlen + 2;
     }
     bwords[b + 1] = w;
+    bcap[b] = c;
   });
+  if (view) {  // (no caller's pool to fit: the staging takes the words there are; the device's bound is the worst case)
+    cigar_cap = 16;
+    for (size_t b = 0; b < nb; ++b) cigar_cap += bcap[b];
+  }
   if (bad.load()) {
     ctx->err = "task sequence range outside the resident pool (sdf_pool_upload)";
     return SDF_ERR_INVALID;
@@ -1041,7 +1067,21 @@ static int batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *task
   hipLaunchKernelGGL(sdf::pack_chars_kernel, dim3((unsigned)((2 * n + 15) / 16)), dim3(256), 0, ctx->stream,
                      (const PackRec *)ctx->pk_recs.p, (long long)(2 * n), (const char *)ctx->an_pool.p, (uint32_t *)ctx->h_pool.p);
   return batch_host_tail(ctx, sc, t2.data(), n, words, want, out, brief, cigar_pool, cigar_cap, cigar_used, nthr, dbg0, dbg1,
-                         "sdf_extz2_batch_pairs");
+                         "sdf_extz2_batch_pairs", view);
+}
+
+extern "C" int sdf_extz2_batch_pairs_view(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n,
+                                          const sdf_result_brief **out, const uint32_t **cigar_pool, size_t *cigar_used) {
+  if (!out || !cigar_pool) return SDF_ERR_INVALID;
+  *out = nullptr;
+  *cigar_pool = nullptr;
+  ResultView v;
+  const int rc = batch_pairs(ctx, sc, tasks, n, SDF_WANT_CIGAR | SDF_WANT_SCORE, nullptr, nullptr, nullptr, 0, cigar_used, &v);
+  if (rc == SDF_OK) {
+    *out = (const sdf_result_brief *)v.res;
+    *cigar_pool = v.cig;
+  }
+  return rc;
 }
 
 extern "C" int sdf_extz2_batch_pairs(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks, size_t n, sdf_result_brief *out,
@@ -1060,19 +1100,28 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   if (!ctx) return SDF_ERR_INVALID;
   ctx->err.clear();
   SDF_HIP(hipSetDevice(ctx->device));
+  const auto rt0 = std::chrono::steady_clock::now();
+  auto lap = [&, last = rt0](const char *what) mutable {  // (SDF_DEBUG_TIMING: the sections that took more than 20 ms)
+    const auto t = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t - last).count();
+    if (ctx->cfg.debug_timing && ms > 20) fprintf(stderr, "[sdf_reserve: %s %.1f ms]\n", what, ms);
+    last = t;
+  };
   const size_t n = std::max<size_t>(max_tasks, 1);
   const size_t words = max_bases / 16 + max_bases / 32 + 4 * n + 16;  // (packed sequences: two roundings per sequence)
   const size_t cig_words = max_bases + 2 * n + 16;
   const size_t nord = 3 * n + max_bases / 16 + 1024;
-  // pinned staging
-  SDF_HIP(ctx->host_pool.reserve_exact(words * 4));
-  SDF_HIP(ctx->host_plan.reserve_exact(n * sizeof(PlanTask)));
-  SDF_HIP(ctx->host_order.reserve_exact(nord * sizeof(int32_t)));
-  SDF_HIP(ctx->host_lane.reserve_exact(n * sizeof(LaneRec)));
+  // pinned staging (registered huge pages: sdf_ctx.h, HostBuf::reserve_huge)
+  SDF_HIP(ctx->host_pool.reserve_huge(std::max(words * 4, n * sizeof(sdf::PackRec))));  // (packed sequences, or a record per task of sdf_extz2_batch_pairs)
+  SDF_HIP(ctx->pk_recs.reserve_exact(n * sizeof(sdf::PackRec)));
+  SDF_HIP(ctx->host_plan.reserve_huge(n * sizeof(PlanTask)));
+  SDF_HIP(ctx->host_order.reserve_huge(nord * sizeof(int32_t)));
+  SDF_HIP(ctx->host_lane.reserve_huge(n * sizeof(LaneRec)));
   // (results + CIGAR words: a quarter of the CIGAR bound -- the stage's rounds fill a tenth of it)
-  SDF_HIP(ctx->host_out.reserve_exact(n * ((flags & SDF_RESERVE_BRIEF) ? sizeof(sdf_result_brief) : sizeof(sdf_result)) +
+  SDF_HIP(ctx->host_out.reserve_huge(n * ((flags & SDF_RESERVE_BRIEF) ? sizeof(sdf_result_brief) : sizeof(sdf_result)) +
                                       cig_words / 4 * 4 + 64));
   if (ctx->host_tasks.size() < n) ctx->host_tasks.resize(n);
+  lap("pinned staging");
   // device
   SDF_HIP(ctx->h_pool.reserve_exact(words * 4));
   SDF_HIP(ctx->h_out.reserve_exact(n * sizeof(sdf_result)));
@@ -1088,6 +1137,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   SDF_HIP(ctx->ln_vals.reserve_exact(n * 8));
   SDF_HIP(ctx->ln_sizes.reserve_exact(n * 32 + 64));
   SDF_HIP(ctx->ln_bins.reserve_exact((size_t)kLaneBins * (4 + 4 + 4 + 8 + 8) + (size_t)(kLaneBins / kLaneScanBlock) * 24 + 256));
+  lap("device buffers");
   {  // (the library sort / scan of the lane tasks' planning: sdf_launch.hip, launch_lane)
     size_t t_sort = 0, t_scan = 0;
     SDF_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, t_sort, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
@@ -1098,6 +1148,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   }
   // the streams the pipeline would create the first time it wants them (a stream is a hardware queue: 7-15 ms each to set
   // up -- the stage's first two rounds spent 35 ms on five of them)
+  lap("sort / scan scratch");
   if (flags & SDF_RESERVE_FEW_STREAMS) ctx->aux_limit = 0;
   if (ctx->pipeline) {
     for (hipStream_t *q : {&ctx->lane_stream, &ctx->aux_stream[0], &ctx->aux_stream[1], &ctx->aux_stream[2], &ctx->aux_stream[3]}) {
@@ -1108,6 +1159,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
       }
     }
   }
+  lap("pipeline streams");
   if (workspace_bytes) {
     const size_t ws = std::min(workspace_bytes, ctx->ws_budget);
     if (ctx->dir_ws.reserve_exact(ws) != hipSuccess) {
@@ -1116,7 +1168,9 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
       return SDF_ERR_NOMEM;
     }
   }
-  if (flags & SDF_RESERVE_ANCHORS) SDF_HIP(ctx->host_an.reserve_exact((size_t)48 << 20));  // (3 million anchors: more go out pageable)
+  lap("direction-flag workspace");
+  if (flags & SDF_RESERVE_ANCHORS) SDF_HIP(ctx->host_an.reserve_huge((size_t)48 << 20));
+  lap("pinned anchors staging");
   if (flags & SDF_RESERVE_ANCHORS) {  // two copies of a short sequence: a handful of anchors through every kernel of the path
     char seq[192];
     uint32_t x = 12345u;
@@ -1135,6 +1189,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
     (void)sdf_anchors_batch(ctx, &pr, 1, seq, sizeof(seq), 11, out, 256, off, &used);
     ctx->err.clear();
   }
+  lap("anchors warm-up call");
   return SDF_OK;
 }
 
@@ -1262,7 +1317,11 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
     hipLaunchKernelGGL(anchors_compact_kernel, dim3(nb), dim3(256), 0, st, d_flag, d_pos, d_cand, (long long)ncand,
                        (CandOut *)ctx->an_out.p, total);
     const size_t bytes = (size_t)total * sizeof(sdf_anchor);
-    if (bytes >= ((size_t)1 << 20) && bytes <= ctx->host_an.cap) {  // through pinned staging, copied out on a few threads
+    const bool out_is_pinned = (const uint8_t *)out >= (const uint8_t *)ctx->host_an.p &&
+                               (const uint8_t *)out + bytes <= (const uint8_t *)ctx->host_an.p + ctx->host_an.cap;
+    if (out_is_pinned) {  // (sdf_anchors_batch_view: the caller reads the staging itself)
+      SDF_HIP(hipMemcpyAsync(out, ctx->an_out.p, bytes, hipMemcpyDeviceToHost, st));
+    } else if (bytes >= ((size_t)1 << 20) && bytes <= ctx->host_an.cap) {  // through pinned staging, copied out on a few threads
       SDF_HIP(hipMemcpyAsync(ctx->host_an.p, ctx->an_out.p, bytes, hipMemcpyDeviceToHost, st));
       SDF_HIP(hipStreamSynchronize(st));
       const int nthr = 4;
@@ -1378,6 +1437,31 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
     fprintf(stderr, "[sdf_anchors_batch n=%zu pool=%zu anchors=%zu] upload %.1f ms, rest %.1f ms\n", n, pool_bytes, *out_used,
             std::chrono::duration<double, std::milli>(dbg1 - dbg0).count(),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg1).count());
+  return rc;
+}
+
+extern "C" int sdf_anchors_batch_view(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *seq_pool, size_t pool_bytes,
+                                      int kmer, const sdf_anchor **out, int64_t *out_off, size_t *out_used) {
+  if (!ctx || !out) return SDF_ERR_INVALID;
+  *out = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess || ctx->host_an.reserve_huge((size_t)48 << 20) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->err = "cannot pin the anchors' staging";
+    return SDF_ERR_NOMEM;
+  }
+  int rc = sdf_anchors_batch(ctx, pairs, n, seq_pool, pool_bytes, kmer, (sdf_anchor *)ctx->host_an.p, ctx->host_an.cap / sizeof(sdf_anchor),
+                             out_off, out_used);
+  if (rc == SDF_ERR_CIGAR_OVERFLOW) {  // more anchors than the staging holds: once more with room for all of them
+    if (ctx->host_an.reserve_huge((*out_used + 1024) * sizeof(sdf_anchor)) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->err = "cannot pin the anchors' staging";
+      return SDF_ERR_NOMEM;
+    }
+    // (the characters are resident since the first attempt)
+    rc = sdf_anchors_batch(ctx, pairs, n, nullptr, pool_bytes, kmer, (sdf_anchor *)ctx->host_an.p, ctx->host_an.cap / sizeof(sdf_anchor),
+                           out_off, out_used);
+  }
+  if (rc == SDF_OK) *out = (const sdf_anchor *)ctx->host_an.p;
   return rc;
 }
 

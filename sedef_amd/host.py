@@ -30,9 +30,9 @@ def build_host(force=False):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     libdir = os.path.join(_HERE, "lib")
-    subprocess.check_call([gxx, "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", LIB] + srcs +
+    subprocess.check_call([gxx, "-O2", "-g", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", LIB] + srcs +
                           ["-L" + libdir, "-lsedef_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
-    subprocess.check_call([gxx, "-O2", "-std=c++17", "-Wall", "-o", CLI, os.path.join(HOST_SRC, "sedef_main.cc"),
+    subprocess.check_call([gxx, "-O2", "-g", "-rdynamic", "-std=c++17", "-Wall", "-o", CLI, os.path.join(HOST_SRC, "sedef_main.cc"),
                            "-L" + libdir, "-lsedef_host", "-lsedef_hip", "-lpthread", "-Wl,-rpath,$ORIGIN/../lib"])
     # sdf_multi: one batch sharded over the GPUs of a node + RCCL all-gatherv of the results, host C++ above the C ABI.  The
     # file holds no kernels: g++ against the HIP runtime headers; a box without them (CPU-only use of the host library and
