@@ -318,6 +318,113 @@ def spot_check(pool, q_off, qlen, t_off, tlen, w, res, cigs, n_sample=64, seed=7
     return {"tasks": int(len(idx)), "checker": kind, "compared": "score + every CIGAR word of the last timed step", "ok": True}
 
 
+
+def stage_block(budget_s=120.0):
+    """The STAGE the north star calls the drop-in (`sedef align generate`, reference: src/align_main.cc:285-337), untimed
+    extra after the headline: the product CLI in processes of its own on BASELINE configs[2]'s workload at size
+    (tests/hostgen.py: make_chr1_genome -- a 249 Mb chromosome, ~1,860 seed pairs of 1-100 kb, fwd + rc).
+      parity     the four buckets of tests/test_stage_scale.py in ONE process; sha256 of their BEDPE in bucket order against
+                 the committed tests/golden/stage_chr1.sha256 (= this repository's host code on the reference kernel)
+      one bucket all seed pairs in one bucket file, one process: the stage's own clock (the reference prints the same
+                 "Finished BED ... in Xs" line, src/align_main.cc:335-336) and the process's wall time
+      8 buckets  the whole seed file under eight names, one process (sedef.sh:187-190 starts one per bucket): the clock
+                 around all eight stages
+      cpu        the same host code with the REFERENCE kernel as the DP on the usable host cores (oracle/_ref behind the
+                 library's test hook): one chr1-sized bucket -- the stage-level CPU figure next to the GPU's
+    Never raises: a failure is reported in the block."""
+    import hashlib
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    t_start = time.time()
+    out = {"what": "`sedef align generate` (product CLI, own processes) on the chr1-sized synthetic genome of BASELINE configs[2]; "
+                   "untimed extra, not part of `value`"}
+    d = tempfile.mkdtemp(prefix="sdf_bench_stage_")
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostgen
+        from sedef_amd import host
+        if not (os.path.exists(host.CLI) and os.path.exists(host.LIB)):
+            raise RuntimeError("host CLI not built (run __graft_entry__.build())")
+        fa = os.path.join(d, "genome.fa")
+        genome, nseeds = hostgen.make_chr1_genome(fa)
+        out["genome_bp"] = sum(len(v) for v in genome.values())
+        del genome
+        for name, nb in (("four", 4), ("one", 1)):
+            os.makedirs(os.path.join(d, name))
+            host.bucket(fa + ".seeds.bed", nb, os.path.join(d, name), fa)
+        os.makedirs(os.path.join(d, "eight"))
+        for k in range(8):
+            shutil.copy(os.path.join(d, "one", "bucket_0000"), os.path.join(d, "eight", "bucket_%04d" % k))
+        out["seed_pairs"] = nseeds
+
+        def cli(args, stdout=None):
+            t0 = time.perf_counter()
+            r = subprocess.run([host.CLI, "align", "generate", "-k", "11", fa] + args, stdout=stdout, stderr=subprocess.PIPE,
+                               timeout=max(20.0, budget_s - (time.time() - t_start)))
+            err = r.stderr.decode(errors="replace").replace("\r", "\n")
+            if r.returncode != 0:
+                raise RuntimeError("sedef align generate failed (%d): %s" % (r.returncode, err[-300:]))
+            return time.perf_counter() - t0, err
+
+        # parity: four buckets, one process, the committed hash
+        cli([os.path.join(d, "four")])
+        text = b"".join(open(os.path.join(d, "four", "bucket_%04d.aligned.bed" % k), "rb").read() for k in range(4))
+        sha = hashlib.sha256(text).hexdigest()
+        committed = open(os.path.join(ROOT, "tests", "golden", "stage_chr1.sha256")).read().split()[0]
+        out["parity"] = {"lines": text.count(b"\n"), "sha256": sha, "committed_sha256": committed, "ok": sha == committed,
+                         "checker": "tests/golden/stage_chr1.sha256: the same host code on the reference's ksw_extz2_sse"}
+        # one chr1-sized bucket, one process (three runs: best and all)
+        clocks, walls = [], []
+        for _ in range(3):
+            with open(os.path.join(d, "one.bed"), "wb") as f:
+                wall, err = cli([os.path.join(d, "one", "bucket_0000")], stdout=f)
+            clocks.append(float(re.search(r"Finished BED \S+ in ([0-9.]+)s", err).group(1)))
+            walls.append(round(wall, 3))
+        tasks = re.search(r"(\d+) tasks, ([0-9.e+]+) cells", err)
+        out["one_bucket"] = {"stage_clock_s": min(clocks), "stage_clock_s_runs": clocks, "process_wall_s_runs": walls,
+                             "lines": open(os.path.join(d, "one.bed"), "rb").read().count(b"\n"),
+                             "dp_tasks": int(tasks.group(1)) if tasks else None,
+                             "dp_cells": float(tasks.group(2)) if tasks else None}
+        # eight chr1-sized buckets, one process
+        runs = []
+        for _ in range(2):
+            for fn in os.listdir(os.path.join(d, "eight")):
+                if fn.endswith(".aligned.bed"):
+                    os.remove(os.path.join(d, "eight", fn))
+            wall, err = cli([os.path.join(d, "eight")], stdout=subprocess.DEVNULL)
+            m = re.search(r"All 8 buckets done in ([0-9.]+)s \((\d+) lines", err)
+            runs.append({"all_stages_s": float(m.group(1)), "process_wall_s": round(wall, 3), "lines": int(m.group(2)),
+                         "stage_clocks_s": [float(x) for x in re.findall(r"Finished BED \S+ in ([0-9.]+)s", err)]})
+        same = all(open(os.path.join(d, "eight", "bucket_%04d.aligned.bed" % k), "rb").read() ==
+                   open(os.path.join(d, "one.bed"), "rb").read() for k in range(8))
+        out["eight_buckets_one_process"] = {"all_stages_s": min(r["all_stages_s"] for r in runs), "runs": runs,
+                                            "every_bucket_equals_the_single_run": same}
+        # the CPU leg: same host code, reference kernel, usable cores
+        try:
+            import ctypes as C
+            from oracle.binding import build_reference
+            so = build_reference()
+            lib = C.CDLL(so)
+            hook = C.cast(lib.ref_extz2_hook, C.c_void_p)
+            t0 = time.perf_counter()
+            st = host.generate(fa, os.path.join(d, "one", "bucket_0000"), 11, os.path.join(d, "cpu.bed"), test_dp=hook)
+            cpu_s = time.perf_counter() - t0
+            out["cpu_stage"] = {"wall_s": round(cpu_s, 3), "cores": effective_cores(), "kind": "reference kernel behind this "
+                                "repository's host pipeline (the reference's own driver needs Boost: unbuildable here)",
+                                "lines": st[0], "equals_gpu_output": open(os.path.join(d, "cpu.bed"), "rb").read() ==
+                                open(os.path.join(d, "one.bed"), "rb").read(),
+                                "gpu_x": round(cpu_s / min(clocks), 2)}
+        except Exception as e:  # noqa: BLE001  (no reference build on this box: the GPU figures stand alone)
+            out["cpu_stage"] = {"error": str(e)[:200]}
+    except Exception as e:  # noqa: BLE001
+        out["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    out["seconds_spent"] = round(time.time() - t_start, 1)
+    return out
+
 def effective_cores():
     """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
     try:
@@ -464,6 +571,8 @@ def main():
     ap.add_argument("--band", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie-pass", action="store_true", help="skip the untimed pass that measures value_incl_pcie")
+    ap.add_argument("--no-stage", action="store_true", help="skip the untimed `stage` block (the product CLI on the chr1-sized "
+                                                            "genome: parity hash, stage clocks)")
     ap.add_argument("--workspace-gib", type=float, default=48.0)
     ap.add_argument("--inflight", type=int, default=2,
                     help="batch calls in flight, each on a device context and host thread of its own (1: one call after the other)")
@@ -780,6 +889,22 @@ def main():
                     estream.synchronize()
                 times.append(time.perf_counter() - tp0)
             incl_pcie = round(cells_rank / min(times[1:]) / 1e9, 3)
+        # One call at a time (what `--inflight 1` measures as `value`): the latency-bound figure next to the throughput one,
+        # untimed extra -- every call returns when its stream has drained, its results go out over pinned D2H like in the
+        # timed steps, all waited for inside the clock
+        one_call = None
+        if world == 1 and len(engs) > 1:
+            k1 = max(3, min(args.steps, 10))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k1):
+                u1 = engs[0].align_batch_device(tasks, d_pool.data_ptr(), d_outs[0].data_ptr(), d_cigs[0].data_ptr(), cig_cap,
+                                                want=want, stream=estreams[0].cuda_stream)
+                with torch.cuda.stream(cstream):
+                    h_outs[0].copy_(d_outs[0], non_blocking=True)
+                    h_cigs[0][:u1].copy_(d_cigs[0][:u1], non_blocking=True)
+            torch.cuda.synchronize()
+            one_call = round(cells_rank * k1 / (time.perf_counter() - t1) / 1e9, 3)
         if hg19:
             wl = ("configs[3]: hg19-shaped task mixture, %d DP tasks %s, all w=-1 (59 %% <=100 cells, 40 %% <=1e4, 1.2 %% "
                   "500x500, 0.06 %% <=1000^2, 0.06 %% up to 6000^2), affine gap 5/-4/40/1, CIGAR+score+counts"
@@ -794,6 +919,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "i8",
             "data": "synthetic",
             "value_incl_pcie": incl_pcie,
+            "value_one_call_in_flight": one_call,
             "timed_region": "planning + DP + traceback + CIGAR compaction + result D2H (pinned, double-buffered under the "
                             "next step)" + (" + all-gatherv of records and CIGARs" if dist_on else "") +
                             ("; two batch calls in flight on two device contexts: a step's planning and tail run under the "
@@ -815,8 +941,22 @@ def main():
                                    "compact": round(cp_ms / args.steps, 3),
                                    "host_planning": round(plan_ms / args.steps, 3),
                                    "host_call_total": round(call_ms / args.steps, 3)},
+            # `bound` / `achieved` / `peak` / `frac` are the HBM roofline SURVEY 8(d) defines for this path (algorithmic bytes
+            # over the launch's duration).  It is NOT what limits the launch: `binding_limit` says what does -- the vector
+            # ALUs' issue slots, from the launch's counted VALU instructions at the measured issue cost of their encodings.
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "binding_limit": ({"bound": "valu_issue", "frac": valu["frac_of_issue_peak_4p2cyc_measured_vop3p"],
+                                            "how": "counted wavefront VALU instructions of the launch x 4.2 cycles (the measured "
+                                                   "issue cost of the packed / VOP3 / DPP encodings that make up 87 % of the row) "
+                                                   "over SIMDs x clock x the launch's live-measured duration; 1.0 = every issue "
+                                                   "slot of every SIMD taken",
+                                            "hbm_frac_is": "0.16 of the HBM peak because the kernel is bound elsewhere: its HBM "
+                                                           "traffic (`traffic`) is 0.93 x the algorithmic bytes, nothing is re-read"}
+                                           if valu else {"bound": "valu_issue", "frac": None,
+                                                         "how": "no committed counters for this workload / kernel source (see "
+                                                                "traffic_source); the DP kernels of this path are VALU-issue "
+                                                                "bound on every profiled shape (DESIGN.md 5)"}),
                          "peak_measured": round(peak_measured, 1), "frac_of_measured": round(achieved / peak_measured, 5),
                          "peak_measured_how": "device-to-device copy of 1 GiB in this run, read + write bytes over the best of 5",
                          "traffic": traffic,
@@ -844,6 +984,8 @@ def main():
                         "kernel scales linearly to host_cores_total logical CPUs and the GPUs to 8 (neither measured here)"}
         if world == 1 and os.environ.get("BENCH_NO_SPOT_CHECK") != "1":
             line["spot_check"] = spot_check(pool, q_off, qlen, t_off, tlen, w, res, h_cigs[lb].numpy().view(np.uint32))
+        if headline and not args.no_stage and os.environ.get("BENCH_NO_STAGE") != "1":
+            line["stage"] = stage_block()
         print(json.dumps(line))
     if dist_on:
         dist.barrier(group=quiet) if quiet is not None else dist.barrier()
