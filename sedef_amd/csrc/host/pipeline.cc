@@ -136,7 +136,9 @@ class GpuProvider : public DpProvider {
     spares_.clear();
     sdf_destroy(ctx_);
   }
-  // Direction-flag workspace of a stage lane: 8 GiB per process, shared out over its lanes (at least 2 GiB each), unless
+  // Direction-flag workspace of a stage lane: 16 GiB per process (round 6: the far-gap round of a chr1-sized bucket -- 10,813
+  // tasks whose flag bound is 15 GB -- then runs as ONE chunk, one 7 ms chain instead of two: its DP 14.6 -> 10.2 ms,
+  // profiles/r06_stage_dp2.txt; 8 GiB until then), shared out over its lanes (at least 2 GiB each), unless
   // SDF_STAGE_WS_GIB gives the figure per lane (the library's default is 64).  A round of the stage that needs more runs in
   // chunks; in exchange a lane allocates its workspace ONCE, where it is set up.  A process that starts right after another
   // one released tens of gigabytes sometimes waits SECONDS for a large hipMalloc (profiles/alloc_probe.py: 24 and 64 GiB
@@ -144,7 +146,7 @@ class GpuProvider : public DpProvider {
   // `sedef align` is one such process per bucket, one after the other.
   static size_t stage_workspace(int lanes) {
     const double asked = stage_settings().stage_ws_gib;
-    const double gib = asked > 0 ? asked : std::max(2.0, 8.0 / std::max(lanes, 1));
+    const double gib = asked > 0 ? asked : std::max(2.0, 16.0 / std::max(lanes, 1));
     return (size_t)(gib * 1073741824.0);
   }
   // Spare providers for the other lanes, each created on a thread of its own (make_gpu_providers)

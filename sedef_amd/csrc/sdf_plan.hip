@@ -311,7 +311,15 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
           bits_only = band_of((int)nrow - 1, t.qlen, t.tlen, w, bl) && wave_lds_bytes(t.qlen, t.tlen, wn) <= (size_t)env.max_dyn_lds;
         }
         hvb = (nrow * (size_t)ncol16 + 16 + 255) & ~(size_t)255;  // (what "heavy" is measured by, whichever layout the task takes)
-        if (!bits_only) bd = hvb;
+        // (round 6) ... nor does a wide FULL-BAND task that plan_chunk always hands to the stripe / strip / chain kernels (their
+        // own bounds follow below: 0.5-0.8 bytes per cell against the byte rows' two per cell of a square matrix).  The
+        // far-gap round of the chr1-sized stage -- 10,813 tasks, 9.5e9 cells -- was cut into two chunks of one 7 ms chain each
+        // by that bound; one chunk: DP 14.4 -> see profiles/r06_stage_dp2.txt.
+        const bool striped_always = !env.force_general && !env.no_stripe && !(env.want & SDF_WANT_EXT) && t.zdrop < 0 && env.gapo >= 0 &&
+                                    !(t.flag & (SDF_FLAG_RIGHT | SDF_FLAG_EXTZ_ONLY | SDF_FLAG_GENERIC_SC | SDF_FLAG_APPROX_MAX | SDF_FLAG_APPROX_DROP)) &&
+                                    w >= std::max(t.qlen, t.tlen) && t.tlen > env.stripe_min && t.tlen <= kStripeMaxT &&
+                                    stripe_lds_bytes(t.qlen, 4) <= (size_t)env.max_dyn_lds;
+        if (!bits_only && !striped_always) bd = hvb;
         // (the wave kernel's blocks: 1 KiB per register of 128 slots -- 1, 2, 3, 4, 6 or 8 of them; the pair kernels' 512 B per
         // register of 64 slots, up to nine, stay below)
         if (need <= 1024)
@@ -343,7 +351,9 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       // the other stripe kernels' inter-stripe words, whatever the task wants)
       if (env.strip_ok && t.tlen > 256 && t.tlen <= kStripChainMaxT && w >= std::max(t.qlen, t.tlen) &&
           (with_dir || t.tlen > kStripMaxT))
-        bd = std::max(bd, ((size_t)strip_blocks(t.tlen, t.tlen > kStripMaxT && env.strip_cols == 4 ? 4 : 8) *
+        // (a chain's blocks are four columns per lane wide when its chunk holds few of them -- plan_chunk decides, unless
+        // SDF_STRIP_COLS=8 does --: twice the blocks, the same records per block)
+        bd = std::max(bd, ((size_t)strip_blocks(t.tlen, t.tlen > kStripMaxT && env.strip_cols != 8 ? 4 : 8) *
                                (size_t)(t.qlen - t.qlen / 5 + 100) * 520 + 512 + 255) & ~(size_t)255);
       mm.qlen = t.qlen, mm.tlen = t.tlen, mm.w = t.w, mm.so = so;
       mm.oc = oc, mm.words = words, mm.bd = bd, mm.hvb = hvb;
@@ -452,6 +462,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
     // Heavy tasks leave the chunk rotation when they are a minority: they are planned and launched FIRST, all together
     // (a launch of few long tasks lasts as long as its longest task: one such launch per kernel, not one per chunk), with
     // a workspace slice of their own, and run next to the chunks of ordinary tasks.
+    bool two_pass_cut = false;
     auto cut_heavy = [&]() {  // (after the pass that finds them)
       for (int q = 0; q < nthr; ++q) {
         cut.n_heavy += parts[q].nh;
@@ -459,6 +470,15 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       }
       cut.split_heavy = cut.pipelined && cut.n_heavy * 4 <= n;
       heavy_budget = cut.split_heavy && cut.n_heavy ? std::min(heavy_bytes + 256, ws_budget / 2) : 0;
+      // (round 6) a batch whose flags fit the workspace as a whole: the heavy tasks take what they need in ONE chunk -- a
+      // launch of few long tasks lasts as long as its longest chain however the rest is cut -- and the others the rest.  Known
+      // only where the scan has seen every task (the single pass of a batch below the two-pass threshold).
+      if (heavy_budget && !two_pass_cut && heavy_bytes + 256 > heavy_budget) {
+        uint64_t all = 0;
+        for (const BatchCut::Block &blk : cut.blocks) all += blk.bd;
+        const double rest = (double)(all - std::min<uint64_t>(all, heavy_bytes)) * 1.05 + 4096.0;
+        if ((double)heavy_bytes + 256 + rest + (double)cut.lane_dir_bytes <= (double)ws_budget) heavy_budget = heavy_bytes + 256;
+      }
       cut.heavy.assign(cut.split_heavy ? n : 0, 0);
       if (!cut.split_heavy) return;
       // heavy chunks: ranges of the (ascending) list of heavy tasks
@@ -517,6 +537,7 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
       return false;
     };
     const bool two_pass = early && *early && nthr > 1 && cut.pipelined;
+    two_pass_cut = two_pass;
     int early_rc = SDF_OK;
     if (two_pass) {
       run_pass(1, nullptr);
