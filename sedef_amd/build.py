@@ -7,6 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsedef_hip.so")
+# code-generation flags of the product build beyond -O3 (SDF_HIPCC_FLAGS in the environment adds to them: experiments)
+EXTRA_FLAGS = []
 
 
 def _sources():
@@ -29,7 +31,8 @@ def build_library(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB_PATH, os.path.join(SRC_DIR, "sdf_unity.hip")]
+           "-Wno-unused-function"] + EXTRA_FLAGS + os.environ.get("SDF_HIPCC_FLAGS", "").split() + \
+          ["-o", LIB_PATH, os.path.join(SRC_DIR, "sdf_unity.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
