@@ -69,3 +69,30 @@ for rep in range(2):
         hip.hipHostFree(p)
     p = t("hipHostMalloc 16 MB", lambda: host_malloc(16 * MB, 0))
     hip.hipHostFree(p)
+
+# ---- round 6, second question: registered BEFORE the pages are written (what sdf_pool_host does at set-up), then filled, then an
+# asynchronous upload on a stream: how long does the ENQUEUE take, how long the copy?
+hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+st = C.c_void_p()
+assert hip.hipStreamCreate(C.byref(st)) == 0
+for order in ("register, then write", "write, then register"):
+    q = libc.aligned_alloc(2 * MB, N)
+    libc.madvise(q, N, 14)
+    if order.startswith("register"):
+        t("[%s] hipHostRegister of untouched huge-page memory" % order, lambda: hip.hipHostRegister(q, N, 0))
+        t("  memset", lambda: libc.memset(q, 1, N))
+    else:
+        t("[%s] memset" % order, lambda: libc.memset(q, 1, N))
+        t("  hipHostRegister", lambda: hip.hipHostRegister(q, N, 0))
+    for rep in range(3):
+        t("  hipMemcpyAsync enqueue", lambda: hip.hipMemcpyAsync(d, q, N, 1, st))
+        t("  ... stream synchronize", lambda: hip.hipStreamSynchronize(st))
+    hip.hipHostUnregister(q)
+    libc.free(q)
+p = host_malloc(N, 0)
+libc.memset(p, 1, N)
+for rep in range(2):
+    t("[hipHostMalloc] hipMemcpyAsync enqueue", lambda: hip.hipMemcpyAsync(d, p, N, 1, st))
+    t("  ... stream synchronize", lambda: hip.hipStreamSynchronize(st))
