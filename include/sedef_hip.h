@@ -137,6 +137,7 @@ typedef struct sdf_config {
   /* how a batch is cut and planned */
   int64_t pipeline, cut_chunks, heavy_bytes, early_heavy, split_min, split_div;
   int64_t plan_threads, plan_pool_from, scan_pool_from, pool_spin_us;
+  int64_t pin_register;
   double workspace_gib;
   /* other entry points */
   int64_t chain_threads_only, stats_items, stats_group_max;

@@ -951,7 +951,7 @@ extern "C" char *sdf_pool_host(sdf_ctx *ctx, size_t bytes) {
   ctx->err.clear();
   const auto t0 = std::chrono::steady_clock::now();
   const size_t had = ctx->host_chars.cap;
-  const bool plain = getenv("SDF_POOL_PLAIN") != nullptr;  // (probe: hipHostMalloc instead of registered huge pages)
+  const bool plain = ctx->cfg.pin_register < 2;  // (sdf_config: the pool crosses PCIe every super-batch -- see pin_register)
   if (hipSetDevice(ctx->device) != hipSuccess ||
       (plain ? ctx->host_chars.reserve_exact(std::max<size_t>(bytes, 64)) : ctx->host_chars.reserve_huge(std::max<size_t>(bytes, 64))) != hipSuccess) {
     (void)hipGetLastError();
@@ -1111,14 +1111,15 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
   const size_t words = max_bases / 16 + max_bases / 32 + 4 * n + 16;  // (packed sequences: two roundings per sequence)
   const size_t cig_words = max_bases + 2 * n + 16;
   const size_t nord = 3 * n + max_bases / 16 + 1024;
-  // pinned staging (registered huge pages: sdf_ctx.h, HostBuf::reserve_huge)
-  SDF_HIP(ctx->host_pool.reserve_huge(std::max(words * 4, n * sizeof(sdf::PackRec))));  // (packed sequences, or a record per task of sdf_extz2_batch_pairs)
+  // pinned staging (registered huge pages unless sdf_config.pin_register says otherwise: sdf_ctx.h, HostBuf::reserve_huge)
+  const bool reg_small = ctx->cfg.pin_register >= 1, reg_big = ctx->cfg.pin_register >= 2;
+  SDF_HIP(ctx->host_pool.reserve_pinned(reg_small, std::max(words * 4, n * sizeof(sdf::PackRec))));  // (packed sequences, or a record per task of sdf_extz2_batch_pairs)
   SDF_HIP(ctx->pk_recs.reserve_exact(n * sizeof(sdf::PackRec)));
-  SDF_HIP(ctx->host_plan.reserve_huge(n * sizeof(PlanTask)));
-  SDF_HIP(ctx->host_order.reserve_huge(nord * sizeof(int32_t)));
-  SDF_HIP(ctx->host_lane.reserve_huge(n * sizeof(LaneRec)));
+  SDF_HIP(ctx->host_plan.reserve_pinned(reg_small, n * sizeof(PlanTask)));
+  SDF_HIP(ctx->host_order.reserve_pinned(reg_small, nord * sizeof(int32_t)));
+  SDF_HIP(ctx->host_lane.reserve_pinned(reg_small, n * sizeof(LaneRec)));
   // (results + CIGAR words: a quarter of the CIGAR bound -- the stage's rounds fill a tenth of it)
-  SDF_HIP(ctx->host_out.reserve_huge(n * ((flags & SDF_RESERVE_BRIEF) ? sizeof(sdf_result_brief) : sizeof(sdf_result)) +
+  SDF_HIP(ctx->host_out.reserve_pinned(reg_small, n * ((flags & SDF_RESERVE_BRIEF) ? sizeof(sdf_result_brief) : sizeof(sdf_result)) +
                                       cig_words / 4 * 4 + 64));
   if (ctx->host_tasks.size() < n) ctx->host_tasks.resize(n);
   lap("pinned staging");
@@ -1169,7 +1170,7 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
     }
   }
   lap("direction-flag workspace");
-  if (flags & SDF_RESERVE_ANCHORS) SDF_HIP(ctx->host_an.reserve_huge((size_t)48 << 20));
+  if (flags & SDF_RESERVE_ANCHORS) SDF_HIP(ctx->host_an.reserve_pinned(reg_big, (size_t)48 << 20));
   lap("pinned anchors staging");
   if (flags & SDF_RESERVE_ANCHORS) {  // two copies of a short sequence: a handful of anchors through every kernel of the path
     char seq[192];
@@ -1232,6 +1233,13 @@ extern "C" size_t sdf_device_bytes(const sdf_ctx *ctx) {
 static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *d_pool, int kmer, int pos_bits,
                          sdf_anchor *out, size_t out_cap, int64_t *out_off, size_t *out_used, hipStream_t st) {
   using namespace sdf;
+  const auto lt0 = std::chrono::steady_clock::now();
+  auto lap = [&, last = lt0](const char *what) mutable {  // (SDF_DEBUG_TIMING: host milliseconds of the call's sections)
+    if (!ctx->cfg.debug_timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[anchors_range: %s %.2f ms]\n", what, std::chrono::duration<double, std::milli>(t - last).count());
+    last = t;
+  };
   int pair_bits = 1;
   while (((size_t)1 << pair_bits) < n) ++pair_bits;
   const int key_bits = std::min(64, pair_bits + 2 * kmer + pos_bits);  // (the sort looks at the bits in use only)
@@ -1263,6 +1271,7 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
   unsigned long long *d_keys = (unsigned long long *)ctx->an_keys.p, *d_keys2 = (unsigned long long *)ctx->an_keys2.p;
   uint32_t *d_qlo = (uint32_t *)ctx->an_q.p, *d_qcnt = d_qlo + nqk, *d_qeff = d_qcnt + nqk, *d_qpair = d_qeff + nqk;
   unsigned long long *d_off = (unsigned long long *)ctx->an_off.p;
+  lap("pair records, buffers");
   SDF_HIP(hipMemcpyAsync(d_pairs, hp.data(), n * sizeof(AnchorPairDev), hipMemcpyHostToDevice, st));
   const dim3 grid(32, (unsigned)std::min<size_t>(n, 65535), (unsigned)((n + 65534) / 65535));
   hipLaunchKernelGGL(ref_keys_kernel, grid, dim3(256), 0, st, d_pairs, (int)n, d_pool, kmer, pos_bits, d_keys);
@@ -1279,7 +1288,9 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
   SDF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->an_tmp.p, scan_bytes, d_qeff, d_off, (int)(nqk + 1), st));
   unsigned long long ncand = 0;
   SDF_HIP(hipMemcpyAsync(&ncand, d_off + nqk, 8, hipMemcpyDeviceToHost, st));
+  lap("keys, sort, lookup, scan enqueued");
   SDF_HIP(hipStreamSynchronize(st));
+  lap("... done on the device");
   if (ncand == 0) return SDF_OK;
   if (ncand > (1ull << 30)) {
     ctx->err = "anchor candidates exceed 2^30 in one batch";
@@ -1302,6 +1313,7 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
   unsigned long long total = 0;
   SDF_HIP(hipMemcpyAsync(&total, d_pos + ncand, 8, hipMemcpyDeviceToHost, st));
   SDF_HIP(hipStreamSynchronize(st));
+  lap("candidates + scan");
   *out_used = (size_t)total;
   long long *d_outoff = (long long *)ctx->an_outoff.p;
   hipLaunchKernelGGL(anchor_offsets_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, d_pairs, (int)n, d_off,
@@ -1338,6 +1350,7 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
     }
   }
   SDF_HIP(hipStreamSynchronize(st));
+  lap("compaction + anchors to the host");
   SDF_HIP(hipGetLastError());
   return SDF_OK;
 }
@@ -1444,7 +1457,7 @@ extern "C" int sdf_anchors_batch_view(sdf_ctx *ctx, const sdf_anchor_pair *pairs
                                       int kmer, const sdf_anchor **out, int64_t *out_off, size_t *out_used) {
   if (!ctx || !out) return SDF_ERR_INVALID;
   *out = nullptr;
-  if (hipSetDevice(ctx->device) != hipSuccess || ctx->host_an.reserve_huge((size_t)48 << 20) != hipSuccess) {
+  if (hipSetDevice(ctx->device) != hipSuccess || ctx->host_an.reserve_pinned(ctx->cfg.pin_register >= 2, (size_t)48 << 20) != hipSuccess) {
     (void)hipGetLastError();
     ctx->err = "cannot pin the anchors' staging";
     return SDF_ERR_NOMEM;
@@ -1452,7 +1465,7 @@ extern "C" int sdf_anchors_batch_view(sdf_ctx *ctx, const sdf_anchor_pair *pairs
   int rc = sdf_anchors_batch(ctx, pairs, n, seq_pool, pool_bytes, kmer, (sdf_anchor *)ctx->host_an.p, ctx->host_an.cap / sizeof(sdf_anchor),
                              out_off, out_used);
   if (rc == SDF_ERR_CIGAR_OVERFLOW) {  // more anchors than the staging holds: once more with room for all of them
-    if (ctx->host_an.reserve_huge((*out_used + 1024) * sizeof(sdf_anchor)) != hipSuccess) {
+    if (ctx->host_an.reserve_pinned(ctx->cfg.pin_register >= 2, (*out_used + 1024) * sizeof(sdf_anchor)) != hipSuccess) {
       (void)hipGetLastError();
       ctx->err = "cannot pin the anchors' staging";
       return SDF_ERR_NOMEM;

@@ -55,6 +55,7 @@ static const ConfigField kConfigFields[] = {
     SDF_CF("SDF_PLAN_POOL_FROM", plan_pool_from, 120000, 0, 1e12, "tasks from which parked threads plan the chunks"),
     SDF_CF("SDF_SCAN_POOL_FROM", scan_pool_from, 120000, 0, 1e12, "tasks from which they scan the cut as well"),
     SDF_CF("SDF_POOL_SPIN_US", pool_spin_us, -1, -1, 1e6, "microseconds a parked planning thread spins before it sleeps; -1: default"),
+    SDF_CF("SDF_PIN_REGISTER", pin_register, 1, 0, 2, "pinned staging sized by sdf_reserve / sdf_pool_host: 0 hipHostMalloc; 1 the small staging buffers as registered huge pages of the process's own, the character pool and the anchors' staging by hipHostMalloc; 2 all of them registered (fast to get; every copy pays for mapping the pages when they are not huge ones)"),
     {"SDF_WORKSPACE_GIB", "workspace_gib", offsetof(sdf_config, workspace_gib), true, 0, 0, 1e6, "direction-flag workspace, overrides the caller's figure; 0: the caller's"},
     // ---- other entry points ----
     SDF_CF("SDF_CHAIN_THREADS", chain_threads_only, 0, 0, 1, "sdf_chain_batch: 1: every pair on the thread-per-pair kernel"),

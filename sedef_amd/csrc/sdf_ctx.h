@@ -193,6 +193,7 @@ struct HostBuf {  // pinned host memory
     }
     return reserve_exact(bytes);
   }
+  hipError_t reserve_pinned(bool registered_huge, size_t bytes) { return registered_huge ? reserve_huge(bytes) : reserve_exact(bytes); }
   void retire() {  // the buffer in use is outgrown: kept until the context goes (each kind on its own list)
     if (p) (registered ? retired_reg : retired).push_back(p);
     p = nullptr;
