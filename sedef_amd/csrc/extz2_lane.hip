@@ -124,11 +124,40 @@ __device__ __forceinline__ uint32_t lane_key_cap(uint32_t key) {  // CIGAR stagi
 __device__ __forceinline__ uint32_t lane_key_dir(uint32_t key) {  // direction-flag bytes
   return (key & (1u << 16)) ? 0u : (uint32_t)lane_dir_bytes((int)((key >> 8) & 0xffu) + 1, (int)(key & 0xffu) + 1);
 }
+// One atomic add per KEY a wavefront holds instead of one per task: SEDEF's gap fills come by the hundred thousand with a
+// handful of sizes (708,600 tasks of ~25 x ~25 bases in the first round of a chr1-sized bucket), and 64 lanes adding to one
+// counter are 64 atomics in a row at the L2 -- the histogram and the placement of that round took 1.9 ms EACH, more than
+// its DP (profiles/r06_stage_kernel_timeline.txt); a batch of many sizes (the hg19 mixture: 0.3 ms each) gives up after
+// eight keys and takes the rest one lane at a time as before.  Returns the lane's rank in its key's bin (the value its own
+// atomic add would have returned) where `rank` is asked for.
+template <bool RANK>
+__device__ __forceinline__ uint32_t lane_bin_add(uint32_t *__restrict__ bins, const uint32_t key, const bool active) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+  uint32_t mine = 0u;
+  for (int round = 0; todo; ++round) {
+    if (round == 8) {  // (many keys in this wavefront: the rest lane by lane)
+      if ((todo >> lane) & 1ull) mine = atomicAdd(&bins[key], 1u);
+      break;
+    }
+    const int leader = __ffsll((long long)todo) - 1;  // wave-uniform
+    const uint32_t k0 = (uint32_t)__shfl((int)key, leader);
+    const unsigned long long same = __ballot(active && key == k0) & todo;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(&bins[k0], (uint32_t)__popcll(same));
+    if (RANK) {
+      base = (uint32_t)__shfl((int)base, leader);
+      if ((same >> lane) & 1ull) mine = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    }
+    todo &= ~same;
+  }
+  return mine;
+}
 __global__ __launch_bounds__(256) void lane_hist_kernel(const LaneRec *__restrict__ recs, int n, uint32_t *__restrict__ count) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  const LaneRec r = recs[k];
-  if (r.flag != 0xffffu) atomicAdd(&count[lane_key(r)], 1u);
+  const bool have = k < n;  // (whole wavefronts take part in the ballots)
+  const LaneRec r = recs[have ? k : n - 1];
+  (void)lane_bin_add<false>(count, lane_key(r), have && r.flag != 0xffffu);
 }
 // per block of 1024 bins: exclusive prefixes inside the block (tasks, staging words, flag bytes) and the block's totals
 __global__ __launch_bounds__(256) void lane_bins_scan_kernel(const uint32_t *__restrict__ count, uint32_t *__restrict__ base,
@@ -194,11 +223,12 @@ __global__ __launch_bounds__(256) void lane_place_kernel(const LaneRec *__restri
                                                          const unsigned long long *__restrict__ tot_dir, int64_t stage0, int64_t dir0,
                                                          PlanTask *__restrict__ plan) {
   const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= n) return;
-  const LaneRec r = recs[k];
-  if (r.flag == 0xffffu) return;
+  const bool have = k < n;
+  const LaneRec r = recs[have ? k : n - 1];
+  const bool live = have && r.flag != 0xffffu;
   const uint32_t key = lane_key(r), blk = key / kLaneScanBlock;
-  const uint32_t rank = atomicAdd(&cursor[key], 1u);
+  const uint32_t rank = lane_bin_add<true>(cursor, key, live);  // (tasks of a bin are interchangeable: any rank will do)
+  if (!live) return;
   const size_t p = (size_t)tot_cnt[blk] + base[key] + rank;
   PlanTask t;
   t.q_word = r.q_word;

@@ -1241,7 +1241,7 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
     last = t;
   };
   int pair_bits = 1;
-  while (((size_t)1 << pair_bits) < n) ++pair_bits;
+  while (((size_t)1 << pair_bits) <= n) ++pair_bits;  // (strictly more than n - 1 needs: the all-ones pair field is the invalid keys' alone)
   const int key_bits = std::min(64, pair_bits + 2 * kmer + pos_bits);  // (the sort looks at the bits in use only)
   std::vector<AnchorPairDev> hp(n);
   long long nrk = 0, nqk = 0;
@@ -1276,12 +1276,13 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
   const dim3 grid(32, (unsigned)std::min<size_t>(n, 65535), (unsigned)((n + 65534) / 65535));
   hipLaunchKernelGGL(ref_keys_kernel, grid, dim3(256), 0, st, d_pairs, (int)n, d_pool, kmer, pos_bits, d_keys);
   size_t tmp_bytes = 0;
-  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, key_bits, st));
+  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int)nrk, pos_bits, key_bits, st));
   size_t scan_bytes = 0;
   SDF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint32_t *)nullptr, (unsigned long long *)nullptr,
                                            (int)(nqk + 1), st));
   SDF_HIP(ctx->an_tmp.reserve(std::max(tmp_bytes, scan_bytes) + 256));
-  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(ctx->an_tmp.p, tmp_bytes, d_keys, d_keys2, (int)nrk, 0, key_bits, st));
+  // (the keys are written in ascending position inside each pair and the sort is stable: the position bits need no pass)
+  SDF_HIP(hipcub::DeviceRadixSort::SortKeys(ctx->an_tmp.p, tmp_bytes, d_keys, d_keys2, (int)nrk, pos_bits, key_bits, st));
   hipLaunchKernelGGL(query_lookup_kernel, grid, dim3(256), 0, st, d_pairs, (int)n, d_pool, kmer, pos_bits, d_keys2, nrk, d_qlo,
                      d_qcnt, d_qeff, d_qpair);
   // exclusive scan over nqk+1 entries (the extra input element is ignored by the exclusive form)
@@ -1407,7 +1408,7 @@ extern "C" int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, siz
   int pos_bits = 1;
   while (pos_bits < 31 && ((int64_t)1 << pos_bits) < (int64_t)rmax) ++pos_bits;
   const int pair_bits = std::min(30, 64 - 2 * kmer - pos_bits);
-  const size_t range_max = (size_t)1 << pair_bits;
+  const size_t range_max = ((size_t)1 << pair_bits) - 1;  // (a range's pair field never reaches all ones: anchors_range)
   int rc = SDF_OK;
   size_t used_total = 0;
   out_off[0] = 0;
