@@ -96,3 +96,23 @@ libc.memset(p, 1, N)
 for rep in range(2):
     t("[hipHostMalloc] hipMemcpyAsync enqueue", lambda: hip.hipMemcpyAsync(d, p, N, 1, st))
     t("  ... stream synchronize", lambda: hip.hipStreamSynchronize(st))
+
+# ---- third question: the ENQUEUE of an asynchronous device-to-host copy into hipHostMalloc memory, by size
+hm = host_malloc(256 * MB, 0)
+libc.memset(hm, 1, 256 * MB)
+for mb in (4, 8, 16, 24, 32, 34, 48, 64, 128):
+    for rep in range(2):
+        t0 = time.perf_counter()
+        hip.hipMemcpyAsync(hm, d, mb * MB, 2, st)
+        t1 = time.perf_counter()
+        hip.hipStreamSynchronize(st)
+        t2 = time.perf_counter()
+        print("D2H %4d MB into hipHostMalloc memory: enqueue %6.2f ms, then synchronize %6.2f ms" % (mb, 1e3 * (t1 - t0), 1e3 * (t2 - t1)), flush=True)
+for mb in (34, 185):
+    for rep in range(2):
+        t0 = time.perf_counter()
+        hip.hipMemcpyAsync(d, hm, mb * MB, 1, st)
+        t1 = time.perf_counter()
+        hip.hipStreamSynchronize(st)
+        t2 = time.perf_counter()
+        print("H2D %4d MB from hipHostMalloc memory: enqueue %6.2f ms, then synchronize %6.2f ms" % (mb, 1e3 * (t1 - t0), 1e3 * (t2 - t1)), flush=True)

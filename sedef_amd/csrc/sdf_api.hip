@@ -1191,6 +1191,16 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
     ctx->err.clear();
   }
   lap("anchors warm-up call");
+  {  // the stream's first asynchronous copy in each direction costs its caller ~8 ms (the runtime sets its copy path up): here,
+     // not in front of a super-batch's upload and its anchors' way back (profiles/r06_stage_timeline.txt)
+    const size_t probe = std::min<size_t>({(size_t)1 << 20, ctx->host_pool.cap, ctx->h_pool.cap, ctx->host_out.cap, ctx->h_out.cap});
+    if (probe) {
+      SDF_HIP(hipMemcpyAsync(ctx->h_pool.p, ctx->host_pool.p, probe, hipMemcpyHostToDevice, ctx->stream));
+      SDF_HIP(hipMemcpyAsync(ctx->host_out.p, ctx->h_out.p, probe, hipMemcpyDeviceToHost, ctx->stream));
+      SDF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  lap("first asynchronous copies");
   return SDF_OK;
 }
 
@@ -1326,14 +1336,17 @@ static int anchors_range(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, c
     return SDF_ERR_CIGAR_OVERFLOW;
   }
   if (total) {
-    SDF_HIP(ctx->an_out.reserve((size_t)total * sizeof(CandOut)));
-    hipLaunchKernelGGL(anchors_compact_kernel, dim3(nb), dim3(256), 0, st, d_flag, d_pos, d_cand, (long long)ncand,
-                       (CandOut *)ctx->an_out.p, total);
     const size_t bytes = (size_t)total * sizeof(sdf_anchor);
+    static_assert(sizeof(CandOut) == sizeof(sdf_anchor), "the compaction writes anchors as they go out");
     const bool out_is_pinned = (const uint8_t *)out >= (const uint8_t *)ctx->host_an.p &&
                                (const uint8_t *)out + bytes <= (const uint8_t *)ctx->host_an.p + ctx->host_an.cap;
-    if (out_is_pinned) {  // (sdf_anchors_batch_view: the caller reads the staging itself)
-      SDF_HIP(hipMemcpyAsync(out, ctx->an_out.p, bytes, hipMemcpyDeviceToHost, st));
+    // (sdf_anchors_batch_view: the caller reads the pinned staging itself, and the compaction kernel WRITES it there -- sixteen
+    // bytes a lane, coalesced, over PCIe; an asynchronous device-to-host copy of the same 34 MB behind the kernel cost its
+    // caller 7-8 ms to enqueue)
+    if (!out_is_pinned) SDF_HIP(ctx->an_out.reserve((size_t)total * sizeof(CandOut)));
+    hipLaunchKernelGGL(anchors_compact_kernel, dim3(nb), dim3(256), 0, st, d_flag, d_pos, d_cand, (long long)ncand,
+                       out_is_pinned ? (CandOut *)out : (CandOut *)ctx->an_out.p, total);
+    if (out_is_pinned) {
     } else if (bytes >= ((size_t)1 << 20) && bytes <= ctx->host_an.cap) {  // through pinned staging, copied out on a few threads
       SDF_HIP(hipMemcpyAsync(ctx->host_an.p, ctx->an_out.p, bytes, hipMemcpyDeviceToHost, st));
       SDF_HIP(hipStreamSynchronize(st));
