@@ -86,6 +86,11 @@ int main(int argc, char **argv) {
   // the DP path keeps four streams busy; give the HIP runtime more hardware queues than its default of four so
   // that no two of them share one (has to be in the environment before the runtime initialises)
   setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // Copies by shader kernels, not by the SDMA engines: the FIRST device-to-host copy of a stage run that goes through SDMA costs
+  // its caller 8-16 ms on this hardware (the anchors' way back or the first round's results, whichever comes first; the engine
+  // has to be woken), a blit kernel 0.4 ms -- chr1-sized bucket 0.10 -> 0.08 s (profiles/r06_sdma_probe.txt).  Before the
+  // runtime starts; a value the user has set stays.
+  setenv("HSA_ENABLE_SDMA", "0", 0);
   // the per-pair host work allocates and frees megabytes on every thread: keep freed memory in the arenas instead
   // of returning it to the kernel each time (munmap / page faults serialise the threads on the address-space lock)
   mallopt(M_MMAP_THRESHOLD, 1 << 30);

@@ -1196,7 +1196,9 @@ extern "C" int sdf_reserve(sdf_ctx *ctx, size_t max_tasks, size_t max_bases, siz
     const size_t probe = std::min<size_t>({(size_t)1 << 20, ctx->host_pool.cap, ctx->h_pool.cap, ctx->host_out.cap, ctx->h_out.cap});
     if (probe) {
       SDF_HIP(hipMemcpyAsync(ctx->h_pool.p, ctx->host_pool.p, probe, hipMemcpyHostToDevice, ctx->stream));
-      SDF_HIP(hipMemcpyAsync(ctx->host_out.p, ctx->h_out.p, probe, hipMemcpyDeviceToHost, ctx->stream));
+      // (device to host: a copy of the size the rounds' results have -- a small one does not take the path a 17 MB one takes)
+      const size_t back = std::min<size_t>({(size_t)32 << 20, ctx->host_out.cap, ctx->h_out.cap});
+      SDF_HIP(hipMemcpyAsync(ctx->host_out.p, ctx->h_out.p, back, hipMemcpyDeviceToHost, ctx->stream));
       SDF_HIP(hipStreamSynchronize(ctx->stream));
     }
   }
