@@ -306,6 +306,11 @@ int sdf_anchors_batch(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, cons
 /* ... with the anchors left in the context's pinned staging (*out: valid until the context's next anchors call) */
 int sdf_anchors_batch_view(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, const char *seq_pool, size_t pool_bytes,
                            int kmer, const sdf_anchor **out, int64_t *out_off, size_t *out_used);
+/* ... of more pairs of the resident pool, written BEHIND the first `keep` anchors of that staging, which stay valid (the stage
+ * driver chains one half of a super-batch while the device finds the anchors of the other).  out_off counts from *out.  The
+ * staging does not grow here: SDF_ERR_CIGAR_OVERFLOW when it has no room (*out_used: the anchors there would be). */
+int sdf_anchors_batch_more(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, size_t pool_bytes, int kmer, size_t keep,
+                           const sdf_anchor **out, int64_t *out_off, size_t *out_used);
 
 /* ---- anchor chaining on the GPU ---------------------------------------------------------------
  * Replaces chain_anchors (reference: src/chain.cc:103-199) for a batch of pairs whose anchors are laid out as

@@ -118,8 +118,8 @@ void sort_by_coord(std::vector<int64_t> &v, std::vector<int64_t> &tmp, int64_t m
 // rule and the three tie rules are those of src/segment.tpp.
 //
 // Round 6: the sweep below spends most of a pair's host time in this structure (2.1 million anchors in the chr1-sized stage
-// run), so a node is ONE 24-byte record -- the largest key of its left child's range (what every descent compares with),
-// its `top`, and for a leaf its own key and score -- instead of five parallel arrays, a point finds its leaf through a
+// run), so a node is ONE 16-byte record -- its `top`, and either the largest key of its left child's range (what every descent
+// compares with) or, for a leaf, its own key and score -- instead of five parallel arrays, a point finds its leaf through a
 // table instead of a descent from the root, and points are named by their rank.  The operations and their order are
 // unchanged (tests/test_chain_oracle.py replays scripts on this class and on the reference's SegmentTree).
 class RangeMax {
@@ -130,7 +130,7 @@ class RangeMax {
     int bits = 0;
     for (unsigned v = (unsigned)n - 1u; n > 0 && v; v >>= 1) bits++;
     const int size = 2 << (n > 0 ? bits : 0);  // twice the next power of two (src/segment.tpp:18-19)
-    node_.assign((size_t)size + 1, Node{0, 0, -1, kInternal});  // (+1: the right child of the last node is tested, never entered)
+    node_.assign((size_t)size + 1, Node{0, -1, kInternal});  // (+1: the right child of the last node is tested, never entered)
     size_ = size;
     // node i covers [lo, hi); children split at (lo + hi + 1) / 2 (src/segment.tpp:184)
     std::vector<int> lo((size_t)size, 0), hi((size_t)size, 0);
@@ -140,7 +140,7 @@ class RangeMax {
       if (hi[i] <= lo[i]) continue;
       reach[i] = key[(size_t)hi[i] - 1];
       if (hi[i] - lo[i] == 1) {
-        node_[i].key = key[(size_t)lo[i]];
+        node_[i].k = key[(size_t)lo[i]];
         node_[i].score = kInactive;
         leaf_[(size_t)lo[i]] = i;
         continue;
@@ -151,7 +151,8 @@ class RangeMax {
       lo[2 * i + 2] = mid;
       hi[2 * i + 2] = hi[i];
     }
-    for (int i = 0; 2 * i + 1 < size; i++) node_[i].left_reach = reach[2 * i + 1];
+    for (int i = 0; 2 * i + 1 < size; i++)
+      if (node_[i].score == kInternal) node_[i].k = reach[2 * i + 1];
     point_of_leaf_.assign((size_t)size, -1);
     for (int p = 0; p < n; p++) point_of_leaf_[(size_t)leaf_[(size_t)p]] = p;
   }
@@ -170,14 +171,14 @@ class RangeMax {
       const Node &nd = node_[i];
       int cand = -1;
       if (nd.score != kInternal) {
-        if (lo <= nd.key && nd.key <= hi) cand = i;
+        if (lo <= nd.k && nd.k <= hi) cand = i;
       } else if (nd.top != -1) {
-        const int64_t tk = node_[nd.top].key;
+        const int64_t tk = node_[nd.top].k;
         if (lo <= tk && tk <= hi) {
           cand = nd.top;
-        } else if (hi <= nd.left_reach) {
+        } else if (hi <= nd.k) {
           stack[sp++] = 2 * i + 1;
-        } else if (lo > nd.left_reach) {
+        } else if (lo > nd.k) {
           stack[sp++] = 2 * i + 2;
         } else {
           stack[sp++] = 2 * i + 2;  // (popped after the left one: candidates arrive left to right)
@@ -199,18 +200,18 @@ class RangeMax {
       Node &nd = node_[i];
       if (nd.top == -1 || node_[leaf].score >= node_[nd.top].score) std::swap(nd.top, leaf);
       if (leaf == -1) break;
-      i = 2 * i + 1 + (node_[leaf].key > nd.left_reach);
+      i = 2 * i + 1 + (node_[leaf].k > split_of(nd));
     }
   }
 
   void deactivate(int pt) {  // src/segment.tpp:105-146: the hole is filled from below, left child on equal scores
     int leaf = leaf_[(size_t)pt];
-    const int64_t k = node_[leaf].key;
+    const int64_t k = node_[leaf].k;
     node_[leaf].score = kInactive;
     for (int i = 0; i < size_ && node_[i].top != -1;) {
       Node &nd = node_[i];
       if (nd.top != leaf) {
-        i = 2 * i + 1 + (k > nd.left_reach);
+        i = 2 * i + 1 + (k > split_of(nd));
       } else if (nd.score != kInternal) {
         nd.top = -1;
       } else {
@@ -230,12 +231,14 @@ class RangeMax {
 
  private:
   static const int kInternal = INT_MIN + 1;  // `score` of a node that is not a leaf (no chain scores that low)
-  struct Node {
-    int64_t left_reach;  // largest key below the left child (0: none)
-    int64_t key;         // leaf: its point's key
+  struct Node {          // 16 bytes: four nodes a cache line
+    int64_t k;           // a leaf: its point's key; an inner node: the largest key below its left child (0: none)
     int32_t top;         // leaf node of the best unclaimed active point below, or -1
     int32_t score;       // leaf: its point's score (kInactive while not active); kInternal otherwise
   };
+  // (what the descent of activate compares with: an inner node's split; a leaf has no children -- 0, as the reference's
+  // `reach` of a childless node)
+  static int64_t split_of(const Node &nd) { return nd.score != kInternal ? 0 : nd.k; }
   std::vector<Node> node_;
   std::vector<int> leaf_, point_of_leaf_;
   int size_ = 0;

@@ -361,26 +361,30 @@ class GpuProvider : public DpProvider {
   char *pool_host(size_t bytes) override {
     if (!stage_settings().gpu_anchors) return nullptr;
     ready();
+    uploaded_ = 0;
     pool_ = sdf_pool_host(ctx_, bytes + 64);
     pool_cap_ = pool_ ? bytes + 64 : 0;
     return pool_;
   }
 
-  // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
-  bool anchors(const std::vector<AnchorJob> &jobs, int kmer, AnchorBatch &out) override {
-    if (!stage_settings().gpu_anchors || jobs.empty()) return false;
-    ready();  // (a reserve still running on its thread uses the context: its warm-up call, its pinning next to this upload)
-    // what the device kernels do not cover goes to the host's generate_anchors -- said once, not silently
-    auto host_instead = [](const char *why) {
-      static std::atomic<bool> said(false);
-      if (!said.exchange(true)) fprintf(stderr, "\n[sedef_amd] seed anchors on the host for this input: %s\n", why);
-      return false;
-    };
-    if (kmer > 15) return host_instead("GPU anchors implement k-mer sizes up to 15");
-    std::vector<sdf_anchor_pair> pairs(jobs.size());
-    size_t total = 0;
-    // (sequences the driver fetched into this provider's pinned pool -- pool_host() -- are where they have to be)
-    bool in_pool = pool_ != nullptr;
+  void pool_ready(size_t bytes) override {
+    uploaded_ = 0;
+    if (!pool_ || !stage_settings().gpu_anchors || bytes > pool_cap_) return;
+    if (sdf_pool_upload(ctx_, pool_, bytes) == SDF_OK) uploaded_ = bytes;
+  }
+
+  // what the device kernels do not cover goes to the host's generate_anchors -- said once, not silently
+  static bool host_instead(const char *why) {
+    static std::atomic<bool> said(false);
+    if (!said.exchange(true)) fprintf(stderr, "\n[sedef_amd] seed anchors on the host for this input: %s\n", why);
+    return false;
+  }
+  // the pairs as the device takes them: offsets of the pool_host() buffer when the driver fetched the sequences into it
+  // (`in_pool`), else back to back (the caller copies them); `total`: the pool's extent
+  bool describe(const std::vector<AnchorJob> &jobs, std::vector<sdf_anchor_pair> &pairs, bool &in_pool, size_t &total) const {
+    pairs.resize(jobs.size());
+    total = 0;
+    in_pool = pool_ != nullptr;
     for (size_t k = 0; k < jobs.size() && in_pool; k++)
       in_pool = jobs[k].query.data() >= pool_ && jobs[k].query.data() + jobs[k].query.size() <= pool_ + pool_cap_ &&
                 jobs[k].ref.data() >= pool_ && jobs[k].ref.data() + jobs[k].ref.size() <= pool_ + pool_cap_;
@@ -400,14 +404,33 @@ class GpuProvider : public DpProvider {
       total = 0;
       for (auto &pr : pairs) total = std::max<size_t>(total, (size_t)std::max(pr.q_off + pr.qlen, pr.r_off + pr.rlen));
     }
-    // The characters of all pairs back to back in the context's pinned staging (sized with the lane's other buffers), one
-    // asynchronous DMA, and they STAY on the device: the DP rounds of this super-batch name their tasks as ranges of them
-    // (run_resident).
+    return true;
+  }
+  void describe_out(const std::vector<sdf_anchor_pair> &pairs, AnchorBatch &out) const {
+    out.resident = resident_;
+    out.q_base.resize(pairs.size());
+    out.r_base.resize(pairs.size());
+    for (size_t k = 0; k < pairs.size(); k++) out.q_base[k] = pairs[k].q_off, out.r_base[k] = pairs[k].r_off;
+  }
+
+  // generate_anchors on the device (include/sedef_hip.h: sdf_anchors_batch)
+  bool anchors(const std::vector<AnchorJob> &jobs, int kmer, AnchorBatch &out) override {
+    if (!stage_settings().gpu_anchors || jobs.empty()) return false;
+    ready();  // (a reserve still running on its thread uses the context: its warm-up call, its pinning next to this upload)
+    if (kmer > 15) return host_instead("GPU anchors implement k-mer sizes up to 15");
+    std::vector<sdf_anchor_pair> pairs;
+    size_t total = 0;
+    bool in_pool = false;
+    if (!describe(jobs, pairs, in_pool, total)) return false;
+    // The characters of all pairs in the context's pinned staging (sized with the lane's other buffers) -- where the driver
+    // fetched them, or copied there now --, one asynchronous DMA, and they STAY on the device: the DP rounds of this
+    // super-batch name their tasks as ranges of them (run_resident).
     resident_ = false;
     char *pool = pool_;
     if (!in_pool) {
       pool = pool_ = sdf_pool_host(ctx_, total + 1);
       pool_cap_ = pool ? total + 1 : 0;
+      uploaded_ = 0;
       if (!pool) return host_instead(sdf_last_error(ctx_));
       parallel_for((int)jobs.size(), [&](int k) {
         memcpy(pool + pairs[k].q_off, jobs[k].query.data(), jobs[k].query.size());
@@ -415,7 +438,11 @@ class GpuProvider : public DpProvider {
       });
     }
     const auto tu0 = std::chrono::steady_clock::now();
-    if (sdf_pool_upload(ctx_, pool, total) != SDF_OK) return host_instead(sdf_last_error(ctx_));
+    const bool sent = in_pool && uploaded_ >= total && sdf_pool_bytes(ctx_) >= total;  // (pool_ready() has sent it)
+    if (!sent) {
+      if (sdf_pool_upload(ctx_, pool, total) != SDF_OK) return host_instead(sdf_last_error(ctx_));
+      uploaded_ = total;
+    }
     if (stage_settings().debug_timing)
       fprintf(stderr, "[anchors: %zu pairs, pool %zu bytes %s, upload enqueued in %.1f ms]\n", jobs.size(), total,
               in_pool ? "fetched in place" : "copied", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
@@ -425,7 +452,8 @@ class GpuProvider : public DpProvider {
     // (the anchors stay in the context's pinned staging: the jobs copy theirs out when they start)
     const sdf_anchor *found = nullptr;
     out.buf.reset();
-    int rc = sdf_anchors_batch_view(ctx_, pairs.data(), pairs.size(), nullptr, total, kmer, &found, out.off.data(), &used);
+    int rc = sdf_anchors_batch_view(ctx_, pairs.data(), pairs.size(), nullptr, std::max<size_t>(total, uploaded_), kmer, &found,
+                                    out.off.data(), &used);
     out.view = (const Anchor *)found;
     if (rc == SDF_ERR_UNSUPPORTED || rc == SDF_ERR_NOMEM) return host_instead(sdf_last_error(ctx_));
     if (rc != SDF_OK) throw std::string("GPU anchors failed: ") + sdf_last_error(ctx_);
@@ -433,10 +461,24 @@ class GpuProvider : public DpProvider {
       fprintf(stderr, "[anchors: device call returned %.1f ms after the upload was enqueued]\n",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
     resident_ = stage_settings().resident_dp;
-    out.resident = resident_;
-    out.q_base.resize(jobs.size());
-    out.r_base.resize(jobs.size());
-    for (size_t k = 0; k < jobs.size(); k++) out.q_base[k] = pairs[k].q_off, out.r_base[k] = pairs[k].r_off;
+    describe_out(pairs, out);
+    return true;
+  }
+
+  bool anchors_more(const std::vector<AnchorJob> &jobs, int kmer, size_t keep, AnchorBatch &out) override {
+    if (!stage_settings().gpu_anchors || jobs.empty() || kmer > 15 || !pool_ || !uploaded_) return false;
+    std::vector<sdf_anchor_pair> pairs;
+    size_t total = 0;
+    bool in_pool = false;
+    if (!describe(jobs, pairs, in_pool, total) || !in_pool || total > uploaded_) return false;
+    out.off.assign(jobs.size() + 1, 0);
+    size_t used = 0;
+    const sdf_anchor *found = nullptr;
+    out.buf.reset();
+    const int rc = sdf_anchors_batch_more(ctx_, pairs.data(), pairs.size(), uploaded_, kmer, keep, &found, out.off.data(), &used);
+    if (rc != SDF_OK) return false;  // (no room behind the kept anchors, or nothing the device covers: the caller's fallback)
+    out.view = (const Anchor *)found;
+    describe_out(pairs, out);
     return true;
   }
 
@@ -449,6 +491,7 @@ class GpuProvider : public DpProvider {
   bool prepared_ = false;
   bool resident_ = false;  // the last anchors() call's characters are in HBM (sdf_pool_upload)
   char *pool_ = nullptr;   // the context's pinned character staging as last asked for (pool_host / anchors)
+  size_t uploaded_ = 0;    // bytes of it on the device (pool_ready / anchors)
   size_t pool_cap_ = 0;
   std::thread reserve_thread_;
   std::vector<std::unique_ptr<GpuProvider>> spares_;
@@ -1148,6 +1191,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       slot[2 * k + 2] = slot[2 * k + 1] + span[2 * k + 1].bytes;
     }
     char *pool = dp.pool_host(slot[2 * (size_t)n] + 1);
+    const bool provider_pool = pool != nullptr;
     if (!pool) {
       if (own_pool_cap < slot[2 * (size_t)n] + 1) {
         own_pool_cap = slot[2 * (size_t)n] + 1 + slot[2 * (size_t)n] / 8;
@@ -1164,23 +1208,87 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       it.job.reset(new PairJob(it.fa, it.fb, it.h, p));
     });
     a.t_fetch += since(tf);
+    dp.pool_ready(slot[2 * (size_t)n]);  // (the whole pool to the device, asynchronously)
     mark(base, "sequences fetched");
-    DpProvider::AnchorBatch seeds;  // lives until the jobs have taken their copies (first round)
-    {  // seed anchors of the whole super-batch in one device pass, when the provider offers it
+    // Seed anchors on the device, when the provider offers it -- in TWO halves of about equal bytes: while the device finds the
+    // anchors of the second half, the host threads chain the first (a pair's first advance(): src/chain.cc:203-258 up to the
+    // requests of its round-A stitch), which is the longest host phase of a super-batch (20 of 85 ms in the chr1-sized run).
+    DpProvider::AnchorBatch seeds, seeds2;  // (live until the jobs have taken their copies: their first advance)
+    std::vector<int64_t> q_base((size_t)n, 0), r_base((size_t)n, 0);
+    bool resident = false;
+    std::vector<char> advanced((size_t)n, 0);  // pairs whose first advance() has run (their requests wait in `pending`)
+    std::atomic<long long> pre_us(0);
+    {
       std::vector<DpProvider::AnchorJob> aj(n);
       for (int k = 0; k < n; k++) {
         const Hit &h = items[k].h;
         aj[k] = {items[k].fa, items[k].fb, h.query->name == h.ref->name && h.query->is_rc == h.ref->is_rc,
                  h.ref_start - h.query_start};
       }
+      int n1 = n;
+      // (only where the sequences lie in the PROVIDER's pool: a provider that copies them replaces its pool with every call)
+      if (provider_pool && n >= 64 && slot[2 * (size_t)n] >= ((size_t)16 << 20)) {  // (small super-batches: one call)
+        n1 = 0;
+        while (n1 < n && slot[2 * (size_t)n1] < slot[2 * (size_t)n] / 2) ++n1;
+        if (n1 < 16 || n - n1 < 16) n1 = n;
+      }
+      auto first_advance = [&](int lo, int hi, const DpProvider::AnchorBatch &sd) {
+        parallel_for(hi - lo, [&](int i) {
+          const int k = lo + i;
+          Item &it = items[k];
+          const auto tj = std::chrono::steady_clock::now();
+          it.job->set_anchors(sd.data() + sd.off[i], (size_t)(sd.off[i + 1] - sd.off[i]));
+          it.pending = it.job->advance(std::vector<Cigar>());
+          advanced[(size_t)k] = 1;
+          pre_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tj).count();
+        });
+      };
       const auto ta = now();
-      if (dp.anchors(aj, p.kmer, seeds)) {
-        for (int k = 0; k < n; k++)
-          items[k].job->set_anchors(seeds.data() + seeds.off[k], (size_t)(seeds.off[k + 1] - seeds.off[k]));
+      const std::vector<DpProvider::AnchorJob> aj1(aj.begin(), aj.begin() + n1), aj2(aj.begin() + n1, aj.end());
+      if (dp.anchors(aj1, p.kmer, seeds)) {
+        resident = seeds.resident;
+        for (int k = 0; k < n1; k++) q_base[k] = resident ? seeds.q_base[k] : 0, r_base[k] = resident ? seeds.r_base[k] : 0;
+        if (n1 == n) {
+          for (int k = 0; k < n; k++)
+            items[k].job->set_anchors(seeds.data() + seeds.off[k], (size_t)(seeds.off[k + 1] - seeds.off[k]));
+        } else {
+          bool ok2 = false;
+          std::string err2;
+          std::thread second([&] {
+            try {
+              ok2 = dp.anchors_more(aj2, p.kmer, (size_t)seeds.off[n1], seeds2);
+            } catch (std::string &e) {
+              err2 = e.empty() ? std::string("error") : e;
+            }
+          });
+          struct Join {
+            std::thread &t;
+            ~Join() {
+              if (t.joinable()) t.join();
+            }
+          } join_second{second};
+          mark(base, "anchors of the first half done");
+          first_advance(0, n1, seeds);
+          second.join();
+          if (!err2.empty()) throw err2;
+          // (no room behind the first half's anchors, or a half the device does not cover: the ordinary call, now that the
+          // first half's jobs have taken their copies)
+          if (!ok2) ok2 = dp.anchors(aj2, p.kmer, seeds2);
+          if (ok2 && seeds2.resident == resident) {
+            for (int k = n1; k < n; k++)
+              q_base[k] = resident ? seeds2.q_base[k - n1] : 0, r_base[k] = resident ? seeds2.r_base[k - n1] : 0;
+            mark(base, "anchors done");
+            first_advance(n1, n, seeds2);
+          } else if (ok2) {  // (the two halves disagree about where the sequences are: the pointer form for everybody)
+            resident = false;
+            first_advance(n1, n, seeds2);
+          }
+          // (else: the second half's jobs find their anchors on the host, in their first advance below)
+        }
         a.anchor_secs += since(ta);
       }
     }
-    mark(base, "anchors done");
+    mark(base, "anchors done, first halves chained");
     // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch.
     // Results of the previous round: Cigars per pair (provider without a raw form), or the raw device words
     // and each pair's first request in them -- then the pair's own thread builds (and later frees) its Cigars
@@ -1197,6 +1305,10 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       std::atomic<long long> longest_us(0), sum_us(0);
       parallel_for(n, [&](int k) {
         Item &it = items[k];
+        if (advanced[(size_t)k]) {  // (its first advance ran next to the second half's anchors: the requests are waiting)
+          advanced[(size_t)k] = 0;
+          return;
+        }
         it.pending.clear();
         if (it.job->done()) return;
         const auto tj = std::chrono::steady_clock::now();
@@ -1217,7 +1329,7 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       });
       a.t_adv += since(tadv);
       a.t_longest += longest_us.load() / 1e6;
-      a.t_sum += sum_us.load() / 1e6;
+      a.t_sum += (sum_us.load() + pre_us.exchange(0)) / 1e6;
       const auto tc = now();
       std::vector<size_t> first(n + 1, 0);
       for (int k = 0; k < n; k++) {
@@ -1229,17 +1341,17 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       }
       // (requests are four words each; with the pairs' characters on the device they become offsets of that pool, on the
       // host threads: 708,600 of them in the first round of the chr1-sized run)
-      if (seeds.resident) rbatch.resize(first[n]);
+      if (resident) rbatch.resize(first[n]);
       else batch.resize(first[n]);
       std::atomic<bool> outside(false);
       parallel_for(n, [&](int k) {
         Item &it = items[k];
         size_t at = first[k];
-        if (seeds.resident) {
+        if (resident) {
           const char *qa = it.fa.data(), *ra = it.fb.data();
           for (const DpRequest &r : it.pending) {
             if (r.q < qa || r.q + r.qlen > qa + it.fa.size() || r.t < ra || r.t + r.tlen > ra + it.fb.size()) outside.store(true);
-            rbatch[at++] = {seeds.q_base[k] + (r.q - qa), seeds.r_base[k] + (r.t - ra), r.qlen, r.tlen};
+            rbatch[at++] = {q_base[k] + (r.q - qa), r_base[k] + (r.t - ra), r.qlen, r.tlen};
           }
         } else {
           for (const DpRequest &r : it.pending) batch[at++] = r;
@@ -1253,8 +1365,8 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
       mark(base, "jobs advanced, requests collected");
       const auto td = now();
       std::vector<Cigar> got;
-      have_raw = seeds.resident ? dp.run_resident(rbatch, p, raw) : dp.run_raw(batch, p, raw);
-      if (seeds.resident && !have_raw) throw std::string("internal: the provider lost its resident sequences");
+      have_raw = resident ? dp.run_resident(rbatch, p, raw) : dp.run_raw(batch, p, raw);
+      if (resident && !have_raw) throw std::string("internal: the provider lost its resident sequences");
       if (!have_raw) got = dp.run(batch, p);
       a.dp_secs += since(td);
       mark(base, "DP round done");

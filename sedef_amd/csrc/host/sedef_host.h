@@ -183,6 +183,11 @@ class DpProvider {
     std::vector<int64_t> q_base, r_base;
   };
   virtual bool anchors(const std::vector<AnchorJob> &, int /*kmer*/, AnchorBatch &) { return false; }
+  // Optional: the anchors of MORE pairs of the same pool while the caller is still reading the `keep` anchors the call
+  // before returned (they stay valid).  false: not possible right now -- the caller calls anchors() when it is done reading.
+  virtual bool anchors_more(const std::vector<AnchorJob> &, int /*kmer*/, size_t /*keep*/, AnchorBatch &) { return false; }
+  // Optional: the first `bytes` of the pool_host() buffer are complete (the provider may send them to the device now).
+  virtual void pool_ready(size_t /*bytes*/) {}
   int64_t tasks = 0, cells = 0;  // statistics
   double t_pack = 0, t_call = 0, t_unpack = 0;  // wall seconds inside run(): request packing, device call, unpacking
 };

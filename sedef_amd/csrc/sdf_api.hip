@@ -1494,6 +1494,24 @@ extern "C" int sdf_anchors_batch_view(sdf_ctx *ctx, const sdf_anchor_pair *pairs
   return rc;
 }
 
+// ... of MORE pairs of the resident pool, written behind the first `keep` anchors of the staging (which stay where they are: a
+// caller that is still reading them -- the stage driver chains the first half of a super-batch while the device finds the
+// anchors of the second -- is not disturbed).  No growth: SDF_ERR_CIGAR_OVERFLOW when the staging has no room for them.
+extern "C" int sdf_anchors_batch_more(sdf_ctx *ctx, const sdf_anchor_pair *pairs, size_t n, size_t pool_bytes, int kmer, size_t keep,
+                                      const sdf_anchor **out, int64_t *out_off, size_t *out_used) {
+  if (!ctx || !out) return SDF_ERR_INVALID;
+  *out = nullptr;
+  const size_t cap = ctx->host_an.cap / sizeof(sdf_anchor);
+  if (!ctx->host_an.p || keep > cap || !pool_bytes) {
+    ctx->err = "sdf_anchors_batch_more follows sdf_anchors_batch_view on a resident pool";
+    return SDF_ERR_INVALID;
+  }
+  sdf_anchor *at = (sdf_anchor *)ctx->host_an.p + keep;
+  const int rc = sdf_anchors_batch(ctx, pairs, n, nullptr, pool_bytes, kmer, at, cap - keep, out_off, out_used);
+  if (rc == SDF_OK) *out = at;
+  return rc;
+}
+
 // ---- anchor chaining (reference: src/chain.cc:103-199) ---------------------------------------------------
 extern "C" int sdf_chain_batch(sdf_ctx *ctx, const sdf_anchor *anchors, const int64_t *off, size_t n, int max_chain_gap,
                                int match_chain_score, int32_t *path, int32_t *bounds, int32_t *nbound) {
