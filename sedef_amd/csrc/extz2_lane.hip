@@ -40,7 +40,7 @@ struct LaneRec {      // what the host uploads per task of the batch (16 bytes; 
 constexpr int kLaneMaxLen = 256;      // longest sequence of a lane task
 constexpr int kLaneMaxCells = 16384;  // most cells of a lane task: a lane alone on its row costs ~100 cycles per cell
 
-// direction flags of a task: per column tile of 16 target positions one 8-byte record per query position (a nibble per
+// direction flags of a task: per column tile of 16 target positions one 8-byte record per query position (four 16-bit flag planes: a bit per
 // cell), the records of a tile back to back -- a lane writes its region front to back, 8 bytes per row of a tile
 __host__ __device__ inline size_t lane_dir_bytes(int qlen, int tlen) { return (size_t)((tlen + 15) >> 4) * (size_t)qlen * 8; }
 // launch classes by query length: the LDS of a wavefront is 128 bytes per query position of its longest task
@@ -257,10 +257,15 @@ __global__ __launch_bounds__(256) void lane_place_kernel(const LaneRec *__restri
 // equal lengths, only the last tile of a row is ragged.
 constexpr int kLaneTile = 16;
 
+// Round 6: the four direction flags of a cell are SIGN BITS of differences the recurrence has anyway -- z - a < 0 (a > z),
+// max(z, a) - b < 0, (z' - q) - a < 0 (x > 0), (z' - q) - b < 0 (y > 0) -- and each is shifted into an accumulator of its own
+// by one v_alignbit (acc << 1 | sign): a subtract and an align per flag where a compare, a select, an or and a shift-or per
+// flag built a nibble (~42 -> ~26 of a cell's ~116 cycles).  Column k of the tile ends at bit 15 - k of every accumulator
+// (a ragged tile's row is shifted up by what it lacks); the record is the pair kernels' (a | b << 16, x | y << 16).
 template <bool RAGGED>
-__device__ __forceinline__ void lane_row(uint32_t (&W)[kLaneTile], int &x, int &v, uint32_t &dw0, uint32_t &dw1, const int ncol,
-                                         const uint32_t qc, const int z_eq, const int z_ne, const int zwild, const int cap,
-                                         const int gq) {
+__device__ __forceinline__ void lane_row(uint32_t (&W)[kLaneTile], int &x, int &v, uint32_t &Fa, uint32_t &Fb, uint32_t &Fx,
+                                         uint32_t &Fy, const int ncol, const uint32_t qc, const int z_eq, const int z_ne,
+                                         const int zwild, const int cap, const int gq) {
 #pragma unroll
   for (int k = 0; k < kLaneTile; ++k) {
     if (!RAGGED || k < ncol) {
@@ -269,24 +274,26 @@ __device__ __forceinline__ void lane_row(uint32_t (&W)[kLaneTile], int &x, int &
       const uint32_t tc = w >> 16;
       int z = tc == qc ? z_eq : z_ne;
       z = tc == 4u ? zwild : z;
-      int a = x + v, b = yo + uo;
-      const uint32_t fa = a > z ? 1u : 0u;  // ties: diagonal before E before F (:173-178)
+      const int a = x + v, b = yo + uo;
+      Fa = __builtin_amdgcn_alignbit(Fa, (uint32_t)(z - a), 31);  // ties: diagonal before E before F (:173-178)
       z = a > z ? a : z;
-      const uint32_t d = b > z ? 2u : fa;
+      Fb = __builtin_amdgcn_alignbit(Fb, (uint32_t)(z - b), 31);
       z = b > z ? b : z;
       z = z < cap ? z : cap;
       const int un = z - v, vn = z - uo;
       z -= gq;
-      a -= z;
-      b -= z;
-      x = a > 0 ? a : 0;
-      const int yn = b > 0 ? b : 0;
-      const uint32_t nib = d | (a > 0 ? 4u : 0u) | (b > 0 ? 8u : 0u);
-      if (k < 8) dw0 |= nib << (4 * (k & 7));
-      else dw1 |= nib << (4 * (k & 7));
+      const int na = z - a, nb = z - b;  // (negative: the gap goes on)
+      Fx = __builtin_amdgcn_alignbit(Fx, (uint32_t)na, 31);
+      Fy = __builtin_amdgcn_alignbit(Fy, (uint32_t)nb, 31);
+      x = na < 0 ? -na : 0;
+      const int yn = nb < 0 ? -nb : 0;
       v = vn;
       W[k] = (uint32_t)un | ((uint32_t)yn << 8) | (w & 0xffff0000u);
     }
+  }
+  if (RAGGED) {
+    const int up = kLaneTile - ncol;
+    Fa <<= up, Fb <<= up, Fx <<= up, Fy <<= up;
   }
 }
 
@@ -345,11 +352,11 @@ __global__ __launch_bounds__(64) void extz2_lane_kernel(const PlanTask *__restri
         const uint32_t qc = (qcw >> ((j & 15) * 2)) & 3u;
         const int z_eq = q_n ? zwild : zm, z_ne = q_n ? zwild : zmis;
         int x = t0 ? (int)(e_cur & 0xffu) : 0, v = t0 ? (int)(e_cur >> 8) : (j ? gq : 0);  // (:120 left of the first column)
-        uint32_t dw0 = 0u, dw1 = 0u;
-        if (full) lane_row<false>(W, x, v, dw0, dw1, ncol, qc, z_eq, z_ne, zwild, cap, gq);
-        else lane_row<true>(W, x, v, dw0, dw1, ncol, qc, z_eq, z_ne, zwild, cap, gq);
+        uint32_t Fa = 0u, Fb = 0u, Fx = 0u, Fy = 0u;
+        if (full) lane_row<false>(W, x, v, Fa, Fb, Fx, Fy, ncol, qc, z_eq, z_ne, zwild, cap, gq);
+        else lane_row<true>(W, x, v, Fa, Fb, Fx, Fy, ncol, qc, z_eq, z_ne, zwild, cap, gq);
         if (more) edge[j * 64] = (uint16_t)((uint32_t)x | ((uint32_t)v << 8));
-        if (with_dir) dirp[(size_t)(t0 >> 4) * qlen + j] = make_uint2(dw0, dw1);
+        if (with_dir) dirp[(size_t)(t0 >> 4) * qlen + j] = make_uint2(Fa | (Fb << 16), Fx | (Fy << 16));
         if (j == 0) {
           // exact H along the first row (:231, u read as a byte): H(0, 0) is the substitution score of the first bases
           // (:249: v - 2 (q + e) with v = z there), every further cell adds its u - (q + e)

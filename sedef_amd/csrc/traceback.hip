@@ -51,9 +51,10 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
     a.idx = (((int64_t)(i >> (6 + sh)) * (rows + 63) + j + ln) * 64 + ln) * ((tk.ncol16 >> 30) ? 1 : 2);
     a.meta = (uint32_t)(tk.nreg - 1 - (il & (tk.nreg - 1)));
   } else if (LAYOUT == 5) {
-    // lane kernel (extz2_lane.hip): per tile of 16 target positions two words per query position, a nibble per cell
-    a.idx = ((int64_t)(i >> 4) * tk.qlen + j) * 2 + ((i >> 3) & 1);
-    a.meta = (uint32_t)((i & 7) * 4);
+    // lane kernel (extz2_lane.hip): per tile of 16 target positions one record per query position -- the pair kernels'
+    // (a | b << 16, x | y << 16) with the tile's column k at bit 15 - k of every half
+    a.idx = (int64_t)(i >> 4) * tk.qlen + j;
+    a.meta = (uint32_t)(15 - (i & 15));
   } else if (LAYOUT == 4) {
     // banded stripes (extz2_bstripe.hip): a flag region per stripe of 128 * nreg target positions, 16-row blocks counted
     // from the block of the stripe's first row, slot t - T0
@@ -100,10 +101,7 @@ __device__ __forceinline__ uint32_t tb_load(const uint8_t *dir, const TbAddr a) 
     const uint32_t w = reinterpret_cast<const uint32_t *>(dir)[a.idx] >> (a.meta & 7u);
     const uint32_t fa = w & 1u, fb = (w >> 8) & 1u, fx = (w >> 16) & 1u, fy = (w >> 24) & 1u;
     return (a.meta & 0x100u) ? a.meta : ((fb ? 2u : fa) | (fx << 3) | (fy << 4));
-  } else if (LAYOUT == 5) {
-    const uint32_t nib = reinterpret_cast<const uint32_t *>(dir)[a.idx] >> (a.meta & 31u);
-    return (a.meta & 0x100u) ? a.meta : ((nib & 3u) | ((nib & 12u) << 1));
-  } else if (LAYOUT == 2) {
+  } else if (LAYOUT == 2 || LAYOUT == 5) {
     const uint2 c = reinterpret_cast<const uint2 *>(dir)[a.idx];
     const uint32_t bit = a.meta & 31u;
     const uint32_t fa = (c.x >> bit) & 1u, fb = (c.x >> (bit + 16)) & 1u;
