@@ -10,9 +10,9 @@ export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8   # (setenv inside the program is too late under rocprofv3: its tool library starts HIP first)
 out=gpurun_out/$tag
 mkdir -p $out
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie-pass"
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie-pass --no-stage"
 BI="$B --inflight 1"   # (the isolated-launch passes: one call at a time, or two whole-batch launches would overlap)
-B1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-pass --inflight 1"
+B1="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-pcie-pass --no-stage --inflight 1"
 SDF_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_iso -o run -- $BI > $out/stats_iso.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_pipe -o run -- $B > $out/stats_pipe.log 2>&1
 SDF_PIPELINE=0 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $out/fetch -o run -- $B1 > $out/fetch.log 2>&1
