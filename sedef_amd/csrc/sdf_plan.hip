@@ -928,44 +928,11 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
       }
       if (force_nreg) nr = force_nreg;
     }
-    // Round 6: a FEW tasks much longer than the rest (the far-gap round of a chr1-sized bucket: a handful of 8 kb x 8 kb tasks
-    // among ten thousand of 1-2 kb) decided the width for everybody -- the model above balances their chain against the
-    // others' throughput and gets neither (two registers: the chain 0.35 us a row, the round's DP 9 ms).  Up to 64 tasks of
-    // 8,192 rows and more take the narrowest stripes in a launch of their own (classes are per width: they run side by side),
-    // the rest the width their own cells and rows ask for.
-    int nr_long = nr;
-    if (!force_nreg && n_stripe_tasks >= 2) {
-      size_t n_long = 0;
-      double cells_rest = 0;
-      int rows_rest = 0;
-      for (size_t k = 0; k < cnt; ++k) {
-        const PlanTask &p = cp[k];
-        if (p.pad_ != 5) continue;
-        if (p.qlen + p.tlen >= 8192) {
-          ++n_long;
-        } else {
-          cells_rest += (double)p.qlen * (double)p.tlen;
-          rows_rest = std::max(rows_rest, p.qlen + p.tlen);
-        }
-      }
-      if (n_long && n_long <= 64 && n_long < n_stripe_tasks) {
-        const double rate[3] = {800e3, 1100e3, 1300e3}, row_us[3] = {0.24, 0.27, 0.50};
-        double best = 1e300;
-        for (int q = 0; q < 3; ++q) {
-          const double t_us = std::max(cells_rest / rate[q], (double)rows_rest * row_us[q]);
-          if (t_us < best) {
-            best = t_us;
-            nr = 1 << q;
-          }
-        }
-        nr_long = 1;
-      }
-    }
     for (size_t k = 0; k < cnt; ++k) {
       PlanTask &p = cp[k];
       if (p.pad_ != 5) continue;
-      p.nreg = p.qlen + p.tlen >= 8192 ? nr_long : nr;
-      if ((p.tlen + 128 * p.nreg - 1) / (128 * p.nreg) > 254) {  // (entry encoding: 8 bits of stripe index, 255 = idle)
+      p.nreg = nr;
+      if ((p.tlen + 128 * nr - 1) / (128 * nr) > 254) {  // (entry encoding: 8 bits of stripe index, 255 = idle)
         p.nreg = 0;
         const bool hbm = general_lds_bytes(p.qlen, p.tlen) > (size_t)env.max_dyn_lds;
         p.pad_ = hbm ? 4 : 3;
