@@ -413,7 +413,8 @@ def stage_block(budget_s=120.0):
             cpu_s = time.perf_counter() - t0
             out["cpu_stage"] = {"wall_s": round(cpu_s, 3), "cores": effective_cores(), "kind": "reference kernel behind this "
                                 "repository's host pipeline (the reference's own driver needs Boost: unbuildable here)",
-                                "lines": st[0], "equals_gpu_output": open(os.path.join(d, "cpu.bed"), "rb").read() ==
+                                "lines": open(os.path.join(d, "cpu.bed"), "rb").read().count(b"\n"), "input_lines": st[0],
+                                "equals_gpu_output": open(os.path.join(d, "cpu.bed"), "rb").read() ==
                                 open(os.path.join(d, "one.bed"), "rb").read(),
                                 "gpu_x": round(cpu_s / min(clocks), 2)}
         except Exception as e:  # noqa: BLE001  (no reference build on this box: the GPU figures stand alone)
