@@ -1478,3 +1478,97 @@ def test_resident_pool_after_anchors_call(oracle):
     a_res = anchors(None)  # the pairs' offsets point into the resident pool
     assert np.array_equal(a_res, a_host)
     eng.close()
+
+
+def test_view_entries_and_anchors_in_two_halves(oracle):
+    """The entry points the stage driver binds since round 6 (host/pipeline.cc: GpuProvider): sdf_anchors_batch_view on the
+    first half of a super-batch's pairs, sdf_anchors_batch_more on the second half BEHIND the first half's anchors (which must
+    stay what they were), sdf_extz2_batch_pairs_view -- against the copying forms of the same calls on the same resident pool."""
+    import ctypes as C
+    import sedef_amd
+    from sedef_amd.extz2 import ANCHOR_DTYPE, ANCHOR_PAIR_DTYPE, BRIEF_DTYPE, TASK_DTYPE, _scoring, sedef_mat
+    eng = sedef_amd.Extz2Engine(0)
+    lib = eng.lib
+    lib.sdf_anchors_batch_view.restype = C.c_int
+    lib.sdf_anchors_batch_view.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int,
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.sdf_anchors_batch_more.restype = C.c_int
+    lib.sdf_anchors_batch_more.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t,
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.sdf_extz2_batch_pairs_view.restype = C.c_int
+    lib.sdf_extz2_batch_pairs_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    rng = np.random.default_rng(6003)
+    n = 300
+    parts, off = [], 0
+    desc = np.zeros(n, ANCHOR_PAIR_DTYPE)
+    for k in range(n):
+        m = int(np.exp(rng.uniform(np.log(40), np.log(9000))))
+        q = _fasta_pool(rng, 1, m, m + 1)[0]
+        r = q[rng.random(len(q)) > 0.03].copy()
+        sub = rng.random(len(r)) < 0.04
+        r[sub] = np.frombuffer(b"ACGTacgtN", np.uint8)[rng.integers(0, 9, int(sub.sum()))]
+        same = int(k % 3 == 0)
+        desc[k] = (off, off + len(q), len(q), len(r), same, int(rng.integers(-50, 50)) if same else 0)
+        off += len(q) + len(r)
+        parts += [q, r]
+    pool = np.concatenate(parts)
+
+    # the copying form, one call over all pairs (uploads the pool and leaves it resident)
+    out_all = np.zeros(len(pool), ANCHOR_DTYPE)
+    off_all = np.zeros(n + 1, np.int64)
+    used = C.c_size_t(0)
+    eng._check(lib.sdf_anchors_batch(eng.ctx, desc.ctypes.data, n, pool.tobytes(), len(pool), 11, out_all.ctypes.data,
+                                     len(out_all), off_all.ctypes.data, C.byref(used)))
+    out_all = out_all[:used.value]
+    assert used.value == off_all[n] and used.value > n
+
+    def view(ptr, count):
+        buf = (C.c_char * (count * ANCHOR_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, ANCHOR_DTYPE, count)
+
+    # the stage's form: pinned pool filled in place, first half as a view, second half behind it
+    eng.pool_upload(pool.tobytes())
+    h = n // 2
+    p1, p2 = C.c_void_p(), C.c_void_p()
+    off1, off2 = np.zeros(h + 1, np.int64), np.zeros(n - h + 1, np.int64)
+    u1, u2 = C.c_size_t(0), C.c_size_t(0)
+    eng._check(lib.sdf_anchors_batch_view(eng.ctx, desc[:h].ctypes.data, h, None, len(pool), 11, C.byref(p1), off1.ctypes.data,
+                                          C.byref(u1)))
+    first = view(p1, u1.value).copy()
+    assert np.array_equal(off1, off_all[:h + 1]) and np.array_equal(first, out_all[:u1.value])
+    eng._check(lib.sdf_anchors_batch_more(eng.ctx, desc[h:].ctypes.data, n - h, len(pool), 11, u1.value, C.byref(p2),
+                                          off2.ctypes.data, C.byref(u2)))
+    assert p2.value == p1.value + u1.value * ANCHOR_DTYPE.itemsize  # the same staging, behind the first half's anchors
+    both = view(p1, u1.value + u2.value)
+    assert np.array_equal(both[:u1.value], first), "the first half's anchors changed under the second call"
+    assert np.array_equal(off2, off_all[h:] - off_all[h])  # (counted from *out)
+    assert np.array_equal(both, out_all)
+
+    # DP on ranges of the same pool: the view form against the copying form
+    t = np.zeros(4000, TASK_DTYPE)
+    pk = rng.integers(0, n, len(t))
+    a = (rng.random(len(t)) * np.maximum(1, np.minimum(desc["qlen"][pk], desc["rlen"][pk]) - 2)).astype(np.int64)
+    n1 = np.minimum(rng.integers(1, 90, len(t)), desc["qlen"][pk] - a)
+    n2 = np.minimum(np.maximum(1, n1 + rng.integers(-5, 6, len(t))), desc["rlen"][pk] - a)
+    t["q_off"], t["t_off"], t["qlen"], t["tlen"] = desc["q_off"][pk] + a, desc["r_off"][pk] + a, n1, n2
+    t["w"], t["zdrop"] = -1, -1
+    brief, cig = eng.align_batch_pairs(t)
+    sc = _scoring(sedef_mat(), 40, 1)
+    pb, pc, cu = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+    eng._check(lib.sdf_extz2_batch_pairs_view(eng.ctx, C.byref(sc), t.ctypes.data, len(t), C.byref(pb), C.byref(pc), C.byref(cu)))
+    vb = np.frombuffer((C.c_char * (len(t) * 16)).from_address(pb.value), BRIEF_DTYPE, len(t))
+    vc = np.frombuffer((C.c_char * (cu.value * 4)).from_address(pc.value), np.uint32, cu.value)
+    assert cu.value == len(cig) and np.array_equal(vc, cig)
+    for f in BRIEF_DTYPE.names:
+        assert np.array_equal(vb[f], brief[f]), f
+    for k in range(0, len(t), 397):
+        exp = oracle.extz2(_align_codes(pool[t["q_off"][k]:t["q_off"][k] + t["qlen"][k]]),
+                           _align_codes(pool[t["t_off"][k]:t["t_off"][k] + t["tlen"][k]]), w=-1)
+        got = vc[int(vb["cigar_off"][k]):int(vb["cigar_off"][k]) + int(vb["n_cigar"][k])]
+        assert cigar_to_str(got) == cigar_to_str(exp["cigar"])
+    # `keep` beyond the staging: refused
+    rc = lib.sdf_anchors_batch_more(eng.ctx, desc[h:].ctypes.data, n - h, len(pool), 11, 1 << 40, C.byref(p2),
+                                    off2.ctypes.data, C.byref(u2))
+    assert rc < 0 and not p2.value
+    eng.close()
