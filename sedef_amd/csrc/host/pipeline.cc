@@ -143,7 +143,8 @@ class GpuProvider : public DpProvider {
   // chunks; in exchange a lane allocates its workspace ONCE, where it is set up.  A process that starts right after another
   // one released tens of gigabytes sometimes waits SECONDS for a large hipMalloc (profiles/alloc_probe.py: 24 and 64 GiB
   // 0.3 ms or 1.8-4.0 s, 8 GiB 0.3 ms in every sample; inside a stage run: a 23 GiB request 0.4 or 580 ms) -- and a run of
-  // `sedef align` is one such process per bucket, one after the other.
+  // `sedef align` is one such process per bucket, one after the other.  (Measured at the end of round 6 for 16 GiB as well:
+  // the CLI asks for 8 when it is given ONE bucket, sedef_main.cc, profiles/r06_proc_probe.txt.)
   static size_t stage_workspace(int lanes) {
     const double asked = stage_settings().stage_ws_gib;
     const double gib = asked > 0 ? asked : std::max(2.0, 16.0 / std::max(lanes, 1));

@@ -80,6 +80,7 @@ static void crash_handler(int sig) {
 }
 
 int main(int argc, char **argv) {
+  const auto t_main = std::chrono::steady_clock::now();
   signal(SIGSEGV, crash_handler);
   signal(SIGBUS, crash_handler);
   signal(SIGABRT, crash_handler);
@@ -152,6 +153,16 @@ int main(int argc, char **argv) {
         }
         if (buckets.empty()) throw std::string("No bucket files in ") + given[0];
         const StageHint hint = many ? stage_hint_many(buckets) : stage_hint(a.pos[2]);
+        if (!many && stage_settings().stage_ws_gib <= 0) {
+          // One bucket per process (sedef.sh:187-190) means one such process right after the other, and a process that follows
+          // one which held 16 GiB of direction flags pays for it: context 0.45 s against 0.33, two runs in eight 0.5 s more on
+          // top (the device buffers' allocation waits), where the larger workspace saves its own stage 8 ms
+          // (profiles/r06_proc_probe.txt: wall 0.73-0.75 s with outliers of 1.2 against 0.61-0.67).  Sixteen stay for a
+          // process that aligns many buckets.
+          StageSettings s = stage_settings();
+          s.stage_ws_gib = 8;
+          set_stage_settings(s);
+        }
         auto dp = make_gpu_providers(dv, hint.lanes, hint.devices, hint.max_batch_bytes);
         const auto t1 = std::chrono::steady_clock::now();
         if (many) {
@@ -166,7 +177,8 @@ int main(int argc, char **argv) {
         const auto t2 = std::chrono::steady_clock::now();
         dp.reset();
         if (stage_settings().debug_timing)
-          fprintf(stderr, "  [process: device context %.2fs, stage %.2fs, context teardown %.2fs]\n",
+          fprintf(stderr, "  [process: main to context %.3fs, device context %.3fs, stage %.3fs, context teardown %.3fs]\n",
+                  std::chrono::duration<double>(t0 - t_main).count(),
                   std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(t2 - t1).count(),
                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count());
       } else if (a.pos[0] == "bucket") {
