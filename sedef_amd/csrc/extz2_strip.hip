@@ -21,7 +21,9 @@
 //
 // Direction flags: per step and lane 8 bytes -- task A's word, task B's word: byte 0 a > z, byte 1 b > z', byte 2 x > 0,
 // byte 3 y > 0, bit 7 - k of a byte = the lane's column k -- 512 contiguous bytes per step of a wavefront
-// (traceback.hip: layout 6).  The exact H runs along the first row (sums of u, :231 read as bytes) and down the last
+// (traceback.hip: layout 6).  With four columns per lane (the chains) a byte is two steps' worth: the even step's four
+// columns in its low, the odd step's in its high bits, one record per PAIR of steps -- four bits a cell like every other
+// register-resident kernel (a byte a cell until the end of round 6: the flag workspace of a chain was twice what it needed).  The exact H runs along the first row (sums of u, :231 read as bytes) and down the last
 // column (v): score, mte (:226-267).
 #include <hip/hip_runtime.h>
 
@@ -36,8 +38,11 @@ constexpr int kStripChainMaxT = 65536;  // ... of a chain of wavefronts, one per
                                        // of a launch entry has eight bits (256 blocks of 256 columns); the stage's tasks end at 60 kb
 
 __host__ __device__ inline int strip_blocks(int tlen, int cols = 8) { return (tlen + 64 * cols - 1) / (64 * cols); }
+__host__ __device__ inline int strip_records(int qlen, int cols) {  // records per block: one per step, or per pair of steps
+  return cols == 4 ? (qlen + 64) >> 1 : qlen + 63;
+}
 __host__ __device__ inline size_t strip_dir_bytes(int qlen, int tlen, int cols = 8, bool solo = false) {
-  return (size_t)strip_blocks(tlen, cols) * (size_t)(qlen + 63) * (solo ? 256 : 512);
+  return (size_t)strip_blocks(tlen, cols) * (size_t)strip_records(qlen, cols) * (solo ? 256 : 512);
 }
 __host__ __device__ inline size_t strip_lds_bytes(int qlen, int tlen) {
   return strip_blocks(tlen) > 1 ? ((size_t)(qlen + 66) * 4 + 15) & ~(size_t)15 : 16;
@@ -108,12 +113,16 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
   const int kca = last_a ? (cla % C) : 0, kcb = last_b ? (clb % C) : 0, lla = cla / C, llb = clb / C;
   const bool more = blk + 1 < nblk;
   const int nstep = qmax + 63;
+  constexpr bool PK = C == 4;  // two steps' flags per record
+  const int nrec = strip_records(qmax, C);
+  const int nloop = PK ? 2 * nrec : nstep;  // (PK: an even number of steps -- the last one may only write the record out)
+  unsigned hold_a = 0u, hold_b = 0u;        // PK: the even step's words
   unsigned xo = 0u, vo = 0u, qc = 0u, vcap = 0u;
   unsigned qrot = 0u;  // the query bases of sixteen rows, rotating (below)
   unsigned e_next = (!CHAIN && blk) ? edge[0] : 0u;
   unsigned e16 = 0u;  // CHAIN: the edge words of rows (s & ~15) + lane, lanes 0..15
-  uint2 *drow = dir + (size_t)blk * nstep * 64 + lane;
-  for (int s = 0; s < nstep; ++s) {
+  uint2 *drow = dir + (size_t)blk * nrec * 64 + lane;
+  for (int s = 0; s < nloop; ++s) {
     if (CHAIN && s == 64) {
       // every lane has passed row 0: this block's share of the first row's sum of u, published before any edge word of
       // a row beyond 0 leaves lane 63 (the blocks holding the tasks' last columns read the totals at their very end)
@@ -161,6 +170,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
     unsigned x = (unsigned)__builtin_amdgcn_update_dpp((int)xb, (int)xo, 0x138, 0xf, 0xf, false);
     unsigned v = (unsigned)__builtin_amdgcn_update_dpp((int)vb, (int)vo, 0x138, 0xf, 0xf, false);
     const int j = s - lane;  // this lane's row
+    unsigned wa = 0u, wb = 0u;  // the step's flag words (0 outside the matrix)
     if (j >= 0 && j < qmax) {
       unsigned Fa = 0u, Fb = 0u, Fx = 0u, Fy = 0u;
       unsigned VN[C];
@@ -212,15 +222,17 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
         // byte 0 of the four accumulators' low halves -> task A's word, of their high halves -> task B's (an accumulator holds
         // at most C <= 8 bits per half): four byte permutes instead of sixteen shifts, masks and ors
         const unsigned ab = __builtin_amdgcn_perm(Fb, Fa, 0x06020400u), xy = __builtin_amdgcn_perm(Fy, Fx, 0x06020400u);
-        const unsigned wa = __builtin_amdgcn_perm(xy, ab, 0x05040100u), wb = __builtin_amdgcn_perm(xy, ab, 0x07060302u);
-        if (solo) {  // (a task without a partner: records of one word)
-          if (with_dir_a) reinterpret_cast<uint32_t *>(dir)[((size_t)blk * nstep + s) * 64 + lane] = wa;
-        } else if (with_dir_a && with_dir_b) {
-          drow[(size_t)s * 64] = make_uint2(wa, wb);
-        } else if (with_dir_a) {
-          drow[(size_t)s * 64].x = wa;
-        } else if (with_dir_b) {
-          drow[(size_t)s * 64].y = wb;
+        wa = __builtin_amdgcn_perm(xy, ab, 0x05040100u), wb = __builtin_amdgcn_perm(xy, ab, 0x07060302u);
+        if (!PK) {
+          if (solo) {  // (a task without a partner: records of one word)
+            if (with_dir_a) reinterpret_cast<uint32_t *>(dir)[((size_t)blk * nrec + s) * 64 + lane] = wa;
+          } else if (with_dir_a && with_dir_b) {
+            drow[(size_t)s * 64] = make_uint2(wa, wb);
+          } else if (with_dir_a) {
+            drow[(size_t)s * 64].x = wa;
+          } else if (with_dir_b) {
+            drow[(size_t)s * 64].y = wb;
+          }
         }
       }
       // (the three blocks below under UNIFORM conditions of their own: as lane predicates alone the compiler runs their
@@ -252,6 +264,26 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
             hb.bestj = j;
           }
         }
+      }
+    }
+    if (PK) {
+      if (s & 1) {
+        if (j >= 0 && j <= qmax) {  // (this step's row or the even step's, j - 1, lies inside the matrix)
+          const unsigned pa = hold_a | (wa << 4), pb = hold_b | (wb << 4);
+          const size_t r = (size_t)(s >> 1) * 64;
+          if (solo) {
+            if (with_dir_a) reinterpret_cast<uint32_t *>(dir)[((size_t)blk * nrec + (s >> 1)) * 64 + lane] = pa;
+          } else if (with_dir_a && with_dir_b) {
+            drow[r] = make_uint2(pa, pb);
+          } else if (with_dir_a) {
+            drow[r].x = pa;
+          } else if (with_dir_b) {
+            drow[r].y = pb;
+          }
+        }
+      } else {
+        hold_a = wa;
+        hold_b = wb;
       }
     }
   }

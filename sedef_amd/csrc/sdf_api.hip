@@ -652,7 +652,10 @@ static int batch_part(sdf_ctx *ctx, const sdf_scoring *sc, const sdf_task *tasks
       ctx->paired += c.paired;
       const float tw = host_ms();
       rc = launch_chunk(run, ci);
-      if (dbg_plan_chunks) fprintf(stderr, "[chunk %zu: %zu tasks%s planned by %.2f ms, launched by %.2f ms]\n", ci, c.cnt, c.heavy ? " (heavy)" : "", tw, host_ms());
+      if (dbg_plan_chunks)
+        fprintf(stderr, "[chunk %zu: %zu tasks%s planned by %.2f ms, launched by %.2f ms; flags %.3f GB placed in a region of %.3f GB (the bound)]\n", ci,
+                c.cnt, c.heavy ? " (heavy)" : "", tw, host_ms(), (double)c.dir_bytes * 1e-9,
+                (double)(c.heavy ? cut.heavy_need : cut.region_need) * 1e-9);
     }
   }
   if (rc != SDF_OK) {  // earlier chunks are in flight and reference the context's buffers: let them finish
@@ -1816,6 +1819,14 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
   env.gapo = sc->gapo;
   scoring_gates(sc, env);
   env.max_dyn_lds = max_dyn_lds;
+  {  // the strip kernels as a context made now would plan them (batch_part; the lane kernel's records need a device)
+    const int qe2 = 2 * (sc->gapo + sc->gape), zm = sc->mat[0] + qe2, zx = sc->mat[1] + qe2;
+    env.strip_always = dcfg.strip_always != 0;
+    env.strip_cols = (int)dcfg.strip_cols;
+    env.chain_min = (size_t)dcfg.chain_min;
+    env.strip_ok = dcfg.no_strip == 0 && dcfg.force_general == 0 && !env.degenerate && sc->gapo >= 0 && sc->gape >= 0 && zm >= 0 &&
+                   zm <= 127 && zx >= 0 && zx <= 127 && zx - sc->gapo >= 0 && sc->mat[0] >= 0;
+  }
   BatchCut cut;
   const char *msg = nullptr;
   const auto tc0 = std::chrono::steady_clock::now();
@@ -1866,24 +1877,29 @@ extern "C" int sdf_debug_plan(const sdf_scoring *sc, const sdf_task *tasks, size
       o[4] = (int64_t)(c.heavy ? cut.heavy_need : cut.region_need);
     }
     for (const Launch &L : c.launches) {
-      const bool pair = L.bs >= 100 && L.bs < 200;
-      const bool stripes = L.bs >= 300 && L.bs < 500;
+      const bool pair = (L.bs >= 100 && L.bs < 200) || L.bs == 500;  // (500: strip kernel, two tasks of any geometry)
+      const bool chained = L.bs == 604 || L.bs == 608;               // (an entry per block of a pair of tasks: the listed one's partner through zdrop)
+      const bool stripes = (L.bs >= 300 && L.bs < 500) || chained;
       for (size_t e = 0; e < L.cnt; ++e) {
         int32_t rel = order[c.ob + L.off + e];
         if (stripes) {  // one entry per stripe: the task is reported at its stripe 0
           if ((uint32_t)rel >> 24) continue;
           rel &= 0xffffff;
         }
-        const PlanTask &p = plan[c.pb + rel];
-        int64_t *o = per_task + 7 * (size_t)p.out_idx;
-        if (o[0] >= 0 && !(pair && o[6] == p.out_idx)) return SDF_ERR_INVALID;  // listed twice (only a self-pair may be)
-        o[0] = (int64_t)ci;
-        o[1] = L.bs;
-        o[2] = p.nreg;
-        o[3] = p.pad_;
-        o[4] = p.dir_off;
-        o[5] = p.cig_slot;
-        o[6] = pair ? plan[c.pb + order[c.ob + L.off + (e ^ 1)]].out_idx : -1;
+        for (int side = 0; side < (chained ? 2 : 1); ++side) {
+          const PlanTask &lead = plan[c.pb + rel];
+          if (side && lead.zdrop == rel) break;  // (a chain without a partner)
+          const PlanTask &p = side ? plan[c.pb + lead.zdrop] : lead;
+          int64_t *o = per_task + 7 * (size_t)p.out_idx;
+          if (o[0] >= 0 && !(pair && o[6] == p.out_idx)) return SDF_ERR_INVALID;  // listed twice (only a self-pair may be)
+          o[0] = (int64_t)ci;
+          o[1] = L.bs;
+          o[2] = p.nreg;
+          o[3] = p.pad_;
+          o[4] = p.dir_off;
+          o[5] = p.cig_slot;
+          o[6] = pair ? plan[c.pb + order[c.ob + L.off + (e ^ 1)]].out_idx : chained ? plan[c.pb + p.zdrop].out_idx : -1;
+        }
       }
     }
   }

@@ -344,17 +344,22 @@ static int cut_batch(const PlanEnv &env, bool pipeline_enabled, size_t ws_budget
         bd = std::max(bd, (bstripe_dir_bytes(t.qlen, t.tlen, w, nr) + bstripe_sync_bytes(t.qlen, t.tlen, w, nr) + 255) & ~(size_t)255);
       }
       // (strip kernel: a region per PAIR of tasks with as many column blocks, sized by the one with more rows -- which
-      // this pass does not know.  A pair of m and M <= 1.5 m + 64 rows needs blocks x (M + 63) records of 8 bytes, a task
-      // without a partner blocks x (rows + 63) records of 4; every task reserves blocks x (0.8 rows + 100) x 520 bytes:
-      // enough for either, the chains' edge columns included)
+      // this pass does not know.  A pair of m and M <= 1.125 m + 64 rows needs blocks x (M + 63) records of 8 bytes, a task
+      // without a partner blocks x (rows + 63) records of 4; every task reserves blocks x (0.54 rows + 60) x 520 bytes:
+      // enough for either, the chains' edge columns included -- 0.54 (1.889 M - 57) + 120 >= M + 64.  Until the end of
+      // round 6 the pairs were allowed M <= 1.5 m + 64 and the factor was 0.8: the far-gap round of the chr1-sized stage
+      // reserved 9.1 GB for flags that take 5.0, and a workspace of 8 GiB cut it in two)
       // (wider targets: a chain of wavefronts, the edge columns between the blocks behind the records -- reserved, like
       // the other stripe kernels' inter-stripe words, whatever the task wants)
       if (env.strip_ok && t.tlen > 256 && t.tlen <= kStripChainMaxT && w >= std::max(t.qlen, t.tlen) &&
           (with_dir || t.tlen > kStripMaxT))
         // (a chain's blocks are four columns per lane wide when its chunk holds few of them -- plan_chunk decides, unless
-        // SDF_STRIP_COLS=8 does --: twice the blocks, the same records per block)
-        bd = std::max(bd, ((size_t)strip_blocks(t.tlen, t.tlen > kStripMaxT && env.strip_cols != 8 ? 4 : 8) *
-                               (size_t)(t.qlen - t.qlen / 5 + 100) * 520 + 512 + 255) & ~(size_t)255);
+        // SDF_STRIP_COLS=8 does --: twice the blocks, a record per PAIR of steps -- the same bytes, one block of rounding
+        // apart, whichever plan_chunk picks)
+        bd = std::max(bd, t.tlen > kStripMaxT && env.strip_cols != 8
+                              ? ((size_t)std::max(strip_blocks(t.tlen, 4), 2 * strip_blocks(t.tlen, 8)) *
+                                     (size_t)(t.qlen * 27 / 50 + 60) * 260 + 512 + 255) & ~(size_t)255
+                              : ((size_t)strip_blocks(t.tlen, 8) * (size_t)(t.qlen * 27 / 50 + 60) * 520 + 512 + 255) & ~(size_t)255);
       mm.qlen = t.qlen, mm.tlen = t.tlen, mm.w = t.w, mm.so = so;
       mm.oc = oc, mm.words = words, mm.bd = bd, mm.hvb = hvb;
       }
@@ -1178,10 +1183,11 @@ static void plan_chunk(const PlanEnv &env, const BatchCut &cut, ChunkPlan &c, Pl
     for (size_t q = 0; q < keys.size(); ++q) sl[q] = (int32_t)(keys[q] & 0xffffffu);
     for (size_t q = 0; q < sl.size();) {
       const int32_t x = sl[q];
-      int32_t y = x;  // the next one, if it has as many column blocks and at most half as many rows again
+      int32_t y = x;  // the next one, if it has as many column blocks and at most an eighth as many rows again (+ 64: the
+                      // flag bound of cut_batch counts on it)
       if (q + 1 < sl.size() && cp[sl[q + 1]].pad_ == cp[x].pad_ &&
           strip_blocks(cp[sl[q + 1]].tlen, cp[x].nreg) == strip_blocks(cp[x].tlen, cp[x].nreg) &&
-          cp[sl[q + 1]].qlen <= cp[x].qlen + cp[x].qlen / 2 + 64)
+          cp[sl[q + 1]].qlen <= cp[x].qlen + cp[x].qlen / 8 + 64)
         y = sl[q + 1];
       q += y == x ? 1 : 2;
       const int32_t lo = std::min(x, y), hi = std::max(x, y);

@@ -47,9 +47,11 @@ __device__ __forceinline__ TbAddr tb_addr(const PlanTask &tk, int i, int j) {
     // (nreg: the columns per lane, 8 or 4; ncol16: the rows of the wavefront's larger task, bit 30: the task has the
     // wavefront to itself -- records of one word)
     const int sh = tk.nreg == 8 ? 3 : 2, il = i & ((64 << sh) - 1), ln = il >> sh;
-    const int rows = tk.ncol16 & 0x3fffffff;
-    a.idx = (((int64_t)(i >> (6 + sh)) * (rows + 63) + j + ln) * 64 + ln) * ((tk.ncol16 >> 30) ? 1 : 2);
-    a.meta = (uint32_t)(tk.nreg - 1 - (il & (tk.nreg - 1)));
+    // (four columns per lane: one record per pair of steps, the odd step's columns in the high bits of every byte)
+    const int rows = tk.ncol16 & 0x3fffffff, st = j + ln;
+    const int nrec = tk.nreg == 8 ? rows + 63 : (rows + 64) >> 1, rec = tk.nreg == 8 ? st : st >> 1;
+    a.idx = (((int64_t)(i >> (6 + sh)) * nrec + rec) * 64 + ln) * ((tk.ncol16 >> 30) ? 1 : 2);
+    a.meta = (uint32_t)(tk.nreg - 1 - (il & (tk.nreg - 1))) + (tk.nreg == 8 ? 0u : (uint32_t)(st & 1) << 2);
   } else if (LAYOUT == 5) {
     // lane kernel (extz2_lane.hip): per tile of 16 target positions one record per query position -- the pair kernels'
     // (a | b << 16, x | y << 16) with the tile's column k at bit 15 - k of every half

@@ -35,8 +35,8 @@ def _dir_need(q, t, bs, nreg, pad):
     nblk = (q + t - 1 + 15) // 16
     if pad == 2:
         return nblk * nreg * 512
-    if pad == 5:
-        return None  # stripe layout: checked by disjointness only
+    if pad in (5, 7, 9, 10):
+        return None  # stripe / strip layouts: checked by disjointness only (strips: test_strip_pairs_fit_...)
     if nreg:
         return nblk * nreg * 1024
     return None
@@ -66,7 +66,12 @@ def _check(tasks, per_task, per_chunk):
     for k in np.flatnonzero(part >= 0):
         p = int(part[k])
         assert part[p] == k and per_task[p, 0] == per_task[k, 0] and per_task[p, 1] == per_task[k, 1]
-        if 130 <= per_task[k, 1] < 140:  # mixed pair (extz2_pair.hip, MIXED): one band and flag set, any lengths
+        if per_task[k, 1] in (500, 604, 608):  # strip kernels: two tasks of any geometry with as many column blocks
+            bw = 64 * (8 if per_task[k, 1] == 500 else int(per_task[k, 2]))
+            assert (tasks["tlen"][p] + bw - 1) // bw == (tasks["tlen"][k] + bw - 1) // bw
+            lo, hi = sorted((int(tasks["qlen"][p]), int(tasks["qlen"][k])))
+            assert hi <= lo + lo // 8 + 64  # (the flag bound of cut_batch counts on it)
+        elif 130 <= per_task[k, 1] < 140:  # mixed pair (extz2_pair.hip, MIXED): one band and flag set, any lengths
             assert tasks["w"][p] == tasks["w"][k] and tasks["flag"][p] == tasks["flag"][k]
             assert per_task[k, 2] == per_task[p, 2]  # ... in the same number of window registers
         else:
@@ -138,13 +143,18 @@ def test_kernel_choice_by_request():
         assert on_general.all() != fast and (not fast or not on_general.any()), (ma, mi, go, ge, pt[:, 1])
 
 
-def test_stripe_kernel_routing_and_widths():
+def test_stripe_kernel_routing_and_widths(monkeypatch):
     """Full-band tasks from 400 target bases up and long banded tasks take the stripe kernels; the stripe width of a chunk
     follows its work (one long task: 128 positions, thousands of tasks: 512), the banded kernel's the target length."""
     rc, pt, _ = _plan(_tasks([6000], [6000]))
     assert rc == 0 and pt[0, 1] == 301                        # one long chain: the narrowest stripes
+    rc, pt, _ = _plan(_tasks([1000] * 6000, [1000] * 6000))
+    assert rc == 0 and (pt[:, 1] == 608).all()                # many tasks: chained strips, eight columns a lane (6,000 wavefronts)
     rc, pt, _ = _plan(_tasks([1000] * 4000, [1000] * 4000))
-    assert rc == 0 and (pt[:, 1] == 304).all()                # many tasks: throughput decides
+    assert rc == 0 and (pt[:, 1] == 604).all()                # fewer: four columns a lane
+    monkeypatch.setenv("SDF_NO_STRIP", "1")
+    rc, pt, _ = _plan(_tasks([1000] * 4000, [1000] * 4000))
+    assert rc == 0 and (pt[:, 1] == 304).all()                # ... without the strip kernels: the widest stripes
     t = _tasks([7000, 7000, 3000, 20000, 33000, 1000, 2500, 12000], [7000, 7100, 3100, 20000, 33000, 1000, 2700, 11000],
                w=[64, 128, 16, 200, 200, 128, 100, 300])
     rc, pt, pc = _plan(t)
@@ -225,3 +235,48 @@ def test_banded_tasks_of_all_lengths_mixed_pairs_and_fewer_chunks():
     _check(small, pt, pc)
 
 
+
+
+@pytest.mark.parametrize("cols", ["0", "4", "8"])
+def test_strip_pairs_fit_the_regions_their_bounds_reserved(monkeypatch, cols):
+    """Strip and chained-strip tasks share a flag region per PAIR whose size the cut does not know when it reserves each task's
+    share (cut_batch: 0.54 rows + 60 records per block and task, pairs of at most 1.125 m + 64 rows): plan_chunk refuses a
+    chunk whose placed flags overrun the region ("direction-flag region overflow").  Full-band tasks of every size the two
+    kernels take, sorted and unsorted, on workspaces that hold the batch in one chunk and in several."""
+    monkeypatch.setenv("SDF_STRIP_COLS", cols)
+    monkeypatch.setenv("SDF_STRIP_ALWAYS", "1")  # (a chunk of few tasks would take the stripe kernels)
+    rng = np.random.default_rng(66 + int(cols))
+    for trial in range(6):
+        n = 6000
+        tl = np.exp(rng.uniform(np.log(257), np.log(7000), n)).astype(np.int64)
+        if trial % 3 == 0:   # rows far from the columns: pairs of very different heights among the neighbours
+            ql = np.exp(rng.uniform(np.log(64), np.log(7000), n)).astype(np.int64)
+        elif trial % 3 == 1:
+            ql = np.maximum(64, tl + rng.integers(-200, 200, n))
+        else:                # few distinct heights, each just beyond the pairing rule of the one before
+            ql = np.array([64, 137, 219, 311, 414, 530, 661, 808, 973, 1159])[rng.integers(0, 10, n)]
+        t = _tasks(ql, tl)
+        for ws in (64 << 30, 2 << 30, 600 << 20):
+            rc, pt, pc = _plan(t, ws=ws)
+            assert rc == 0, (trial, ws)
+            assert ((pt[:, 0] >= 0)).all()
+            assert (pc[:, 3] <= pc[:, 4]).all()     # flags placed <= the region the bounds reserved
+            assert np.isin(pt[:, 1], (500, 604, 608)).sum() > n // 2
+            _check(t, pt, pc)
+            # every strip pair's region ends before the next region of its chunk begins
+            for ci in range(len(pc)):
+                sel = np.flatnonzero((pt[:, 0] == ci))
+                offs = np.sort(pt[sel, 4])
+                for k in sel[np.isin(pt[sel, 1], (500, 604, 608))][:1500]:
+                    p = int(pt[k, 6])
+                    if pt[k, 4] > pt[p, 4]:
+                        continue  # (the pair's region starts at the other one's offset)
+                    c8 = 8 if pt[k, 1] == 500 else int(pt[k, 2])
+                    qm, tm = max(int(ql[k]), int(ql[p])), max(int(tl[k]), int(tl[p]))
+                    blocks = (tm + 64 * c8 - 1) // (64 * c8)
+                    nrec = (qm + 64) >> 1 if c8 == 4 else qm + 63
+                    need = blocks * nrec * (256 if p == k else 512)
+                    if pt[k, 1] != 500:
+                        need = ((need + 255) & ~255) + (((blocks - 1) * (qm + 64) * 4 + 64 + 255) & ~255)
+                    nxt = offs[np.searchsorted(offs, pt[k, 4] + 4, side="right"):]
+                    assert (len(nxt) == 0 or pt[k, 4] + need <= nxt[0]) and pt[k, 4] + need <= pc[ci, 3]
