@@ -99,10 +99,20 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
   const int qmax = qa > qb ? qa : qb;
   constexpr int BW = 64 * C;  // columns of a block
   const int c0 = blk * BW + lane * C;
-  unsigned U[C], Y[C], TC[C];
+  // A cell's score + 2 (q + e) is ONE byte permute: per column a table of four bytes per task -- the score against query
+  // base 0..3 -- and the row's selector: byte 0 = task A's query base (picks a byte of TA), byte 2 = 4 + task B's (a byte of
+  // TB), bytes 1 and 3 = 0x0c (zero).  (Until the end of round 6: xor, min, multiply-add per cell -- a launch of chained
+  // strips issues a vector instruction on 92 % of its SIMD cycles, profiles/r06_chain_pmc.txt: what counts is their number.)
+  // An N on either side (HASN) is patched in afterwards: the table's answer for it is arbitrary.
+  unsigned U[C], Y[C], TA[C], TB[C], NT[HASN ? C : 1];
+  const unsigned zm1 = ZM2 & 0xffu, zx1 = (ZM2 + ZD2) & 0xffu;  // match, mismatch (+ 2 (q + e))
 #pragma unroll
   for (int k = 0; k < C; ++k) {
-    TC[k] = strip_code2(twa, tna, ta, twb, tnb, tb, c0 + k);
+    const unsigned tc = strip_code2(twa, tna, ta, twb, tnb, tb, c0 + k);
+    const unsigned ca = tc & 0xffffu, cb = tc >> 16;
+    TA[k] = (zx1 * 0x01010101u) ^ (ca < 4u ? (zm1 ^ zx1) << (8u * ca) : 0u);
+    TB[k] = (zx1 * 0x01010101u) ^ (cb < 4u ? (zm1 ^ zx1) << (8u * cb) : 0u);
+    if (HASN) NT[k] = (tc >> 2) & 0x00010001u;
     U[k] = (c0 + k) ? Q2 : 0u;  // (:121: u = q beyond the first column, y = 0 above the first row)
     Y[k] = 0u;
   }
@@ -117,7 +127,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
   const int nrec = strip_records(qmax, C);
   const int nloop = PK ? 2 * nrec : nstep;  // (PK: an even number of steps -- the last one may only write the record out)
   unsigned hold_a = 0u, hold_b = 0u;        // PK: the even step's words
-  unsigned xo = 0u, vo = 0u, qc = 0u, vcap = 0u;
+  unsigned xo = 0u, vo = 0u, qc = 0x0c040c00u, vcap = 0u;
   unsigned qrot = 0u;  // the query bases of sixteen rows, rotating (below)
   unsigned e_next = (!CHAIN && blk) ? edge[0] : 0u;
   unsigned e16 = 0u;  // CHAIN: the edge words of rows (s & ~15) + lane, lanes 0..15
@@ -155,7 +165,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
       unsigned ca = 0u, cb = 0u;
       if (jr < qa) ca = ((qna[jr >> 5] >> (jr & 31)) & 1u) ? 4u : ((qwa[jr >> 4] >> ((jr & 15) * 2)) & 3u);
       if (jr < qb) cb = ((qnb[jr >> 5] >> (jr & 31)) & 1u) ? 4u : ((qwb[jr >> 4] >> ((jr & 15) * 2)) & 3u);
-      qrot = ca | (cb << 16);
+      qrot = ca | ((cb + 4u) << 16) | 0x0c000c00u;  // (the selector of the score tables, above)
     } else {
       qrot = (unsigned)__builtin_amdgcn_mov_dpp((int)qrot, 0x134, 0xf, 0xf, false);  // wave_rol:1
     }
@@ -174,13 +184,14 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
     if (j >= 0 && j < qmax) {
       unsigned Fa = 0u, Fb = 0u, Fx = 0u, Fy = 0u;
       unsigned VN[C];
+      // (HASN) the row's base is an N: selector byte 0 = 4, byte 2 = 8
+      const unsigned nq = HASN ? ((qc >> 2) & 1u) | ((qc >> 3) & 0x00010000u) : 0u;
 #pragma unroll
       for (int k = 0; k < C; ++k) {
         // score + 2 (q + e): match / mismatch by the bases, 2 (q + e) with an N on either side (:124-138)
-        const unsigned dd = TC[k] ^ qc;
-        unsigned z = pk_mad(pk_minu(dd, one2), ZD2, ZM2);
+        unsigned z = __builtin_amdgcn_perm(TB[k], TA[k], qc);
         if (HASN) {
-          const unsigned nn = ((TC[k] | qc) >> 2) & 0x00010001u;
+          const unsigned nn = NT[k] | nq;
           z = pk_mad(nn, pk_sub(ZW2, z), z);
         }
         // Round 5: the sums and differences are plain 32-bit adds and subtracts.  gfx950 issues v_add_u32 / v_sub_u32 in ~2.3
@@ -188,7 +199,7 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
         // halves: every byte of the state is in 0..127 (tame scoring, full band: the header), so no sum carries out of a half,
         // and every difference taken here is of a value and something it was maximised over or that the recurrence keeps below
         // it (z1 - z, z2 - z1; u = z - v >= 0, v = z - u >= 0; z - q >= 0: mismatch + q + 2 e >= 0 is part of strip_ok), so none
-        // borrows.  The two that can go negative, a - (z - q) and b - (z - q), are max(., z - q) - (z - q) instead of max(. - ., 0).
+        // borrows.  The two that can go negative, a - (z - q) and b - (z - q), are saturating packed subtracts (max(. - ., 0) in one).
         const unsigned uo = U[k];
         const unsigned a = x + v, b = Y[k] + uo;
         const unsigned z1 = pk_maxu(z, a);  // ties: diagonal before E before F (:173-178)
@@ -197,8 +208,8 @@ __device__ __forceinline__ bool strip_steps(const int blk, const int nblk, const
         const unsigned z3 = pk_minu(z2, CAP2);
         const unsigned un = z3 - v, vn = z3 - uo;
         const unsigned zq = z3 - Q2;
-        x = pk_maxu(a, zq) - zq;
-        const unsigned yn = pk_maxu(b, zq) - zq;
+        x = pk_subsat_u(a, zq);  // max(a - (z - q), 0): one saturating subtract
+        const unsigned yn = pk_subsat_u(b, zq);
         Fa = pk_mad(Fa, two2, fa);
         Fb = pk_mad(Fb, two2, fb);
         Fx = pk_mad(Fx, two2, pk_minu(x, one2));

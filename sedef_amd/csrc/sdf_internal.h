@@ -86,6 +86,10 @@ __device__ __forceinline__ unsigned pk_minu(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a),
                                                                 __builtin_bit_cast(u16x2, b)));
 }
+// max(a - b, 0) per half: one v_pk_sub_u16 with the clamp bit (unsigned saturation)
+__device__ __forceinline__ unsigned pk_subsat_u(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
 // min(x, 1) per half = "x != 0" as 0/1.  Written as the instruction itself: the optimiser would
 // otherwise turn it into per-half compares + selects.
 __device__ __forceinline__ unsigned pk_nonzero_(unsigned a, unsigned one_opaque) {
