@@ -94,7 +94,7 @@ def main():
     # the steady regime (every register of the window active: >= 50 packed instructions -- 66 until three differences per
     # register became 32-bit subtracts and the code comparison an xor, round 5), without the N handling the headline batch
     # does not need: the shortest such loop
-    steady = [l for l in out["innermost_loops"] if l["v_readlane"] == 0 and l["v_pk"] >= 50 and
+    steady = [l for l in out["innermost_loops"] if l["v_readlane"] == 0 and l["v_pk"] >= 45 and
               l["by_encoding"].get("VALU DPP (8-byte)", 0) >= 10]
     steady.sort(key=lambda l: l["instructions"])
     if steady:

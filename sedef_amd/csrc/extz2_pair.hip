@@ -70,19 +70,26 @@ __host__ __device__ inline int pair_qcap(int qlen, int nreg) {
   return whole < win ? whole : win;
 }
 
-// fresh (score + 2(q+e)) << 8 of the lane's cell of both tasks from the target / query byte codes
-#define SDF_PFRESH(z, tc, qword, WITH_N)                                \
+// Fresh (score + 2(q+e)) << 8 of the lane's cell of both tasks: ONE byte permute.  The lane keeps, per window register, a
+// table of four score bytes per task -- its target base against query base 0..3 (an N in the target: the wildcard's score
+// four times) -- and the query window holds the row's bases as the permute's selector: byte 1 = task A's base (a byte of
+// TA), byte 3 = 4 + task B's (a byte of TB), bytes 0 and 2 = 0x0c (zero): the result is 0, zA, 0, zB.  An N in the query
+// selects 0xff -- a negative half, patched to the wildcard's score where the sequences hold any N at all (WITH_N).
+// (Until the end of round 6: xor, min, multiply-add per cell and row.  The kernel issues a vector instruction on 98 % of
+// its SIMD cycles at four cycles each: what counts is their number -- profiles/r06_pair_kernel_pmc.txt.)
+#define SDF_PFRESH(z, k, qword, WITH_N)                                 \
   {                                                                     \
-    const unsigned qc_ = (qword);                                       \
-    const unsigned d_ = (tc) ^ qc_; /* != 0 <=> the codes differ */     \
-    const unsigned m_ = pk_nonzero(d_);                                 \
-    z = pk_mad(m_, z_delta, z_match_v);                                 \
+    z = __builtin_amdgcn_perm(TB[k], TA[k], (qword));                   \
     if (WITH_N) {                                                       \
-      unsigned nn_ = pk_ashr15(pk_shl((tc) | qc_, 8));                  \
+      unsigned nn_ = pk_ashr15(z);                                      \
       SDF_OPQ(nn_);                                                     \
       z = (z_wild & nn_) | (z & ~nn_);                                  \
     }                                                                   \
   }
+// a query window entry from the two tasks' byte codes (0..3, N: bit 7)
+__device__ __forceinline__ uint32_t pair_qsel(uint32_t ca, uint32_t cb) {
+  return 0x000c000cu | (((ca & 0x80u) ? 0xffu : ca) << 8) | (((cb & 0x80u) ? 0xffu : cb + 4u) << 24);
+}
 
 // Mixed pairs (round 4): the band schedule of the reference, lo0 = max(0, r - qlen + 1, (r - w + 1) >> 1), hi0 = min(tlen - 1, r,
 // (r + w) >> 1) (extern/ksw2_extz2_sse.cc:101-115), depends on the lengths only where the r - qlen + 1 / tlen - 1 clips bite:
@@ -175,10 +182,10 @@ __device__ __forceinline__ void pair_body(
         const int ea = e - (qlen - ql_a), eb = e - (qlen - ql_b);
         const uint32_t ca = ea >= 0 && ea < ql_a ? pool_code8(qwa, qna, ql_a - 1 - ea, sc.wild) : 0u;
         const uint32_t cb = eb >= 0 && eb < ql_b ? pool_code8(qwb, qnb, ql_b - 1 - eb, sc.wild) : 0u;
-        W[i] = ca | (cb << 16);
+        W[i] = pair_qsel(ca, cb);
       } else {
         const bool in = e >= 0 && e < qlen;
-        W[i] = in ? (pool_code8(qwa, qna, qlen - 1 - e, sc.wild) | (pool_code8(qwb, qnb, qlen - 1 - e, sc.wild) << 16)) : 0u;
+        W[i] = in ? pair_qsel(pool_code8(qwa, qna, qlen - 1 - e, sc.wild), pool_code8(qwb, qnb, qlen - 1 - e, sc.wild)) : pair_qsel(0u, 0u);
       }
     }
   };
@@ -209,16 +216,19 @@ __device__ __forceinline__ void pair_body(
   const unsigned qb2 = ((unsigned)sc.q_b << 8) * 0x00010001u;
   const unsigned qv = qb2;
   const unsigned capv = ((unsigned)sc.cap_b << 8) * 0x00010001u;
-  const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
-  const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
-  const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
+  const unsigned zb_match = (unsigned)((sc.sc_match + sc.qe2_b) & 0xff), zb_mis = (unsigned)((sc.sc_mis + sc.qe2_b) & 0xff);
+  const unsigned t_mis4 = zb_mis * 0x01010101u, t_delta = zb_match ^ zb_mis, t_wild4 = (unsigned)sc.qe2_b * 0x01010101u;
   const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
   unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16 (in a scalar register)
   asm("" : "+s"(one2));
-  unsigned z_match_v = z_match;  // kept in a VGPR: v_pk_mad_u16 takes one scalar operand only
-  SDF_OPQ(z_match_v);
 
-  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], Tc[NREG];
+  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], TA[NREG], TB[NREG];
+  // the score tables of the lane's slot of register k from its entry of the target window (bytes A | B << 8; N: bit 7)
+  auto load_target = [&](const int k, const unsigned tb16) {
+    const unsigned ca = tb16 & 0xffu, cb = (tb16 >> 8) & 0xffu;
+    TA[k] = (ca & 0x80u) ? t_wild4 : t_mis4 ^ (t_delta << (8u * ca));
+    TB[k] = (cb & 0x80u) ? t_wild4 : t_mis4 ^ (t_delta << (8u * cb));
+  };
   unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
   unsigned xt1[NREG], vt1[NREG];  // x, v of the (r-1, t-1) neighbours; persistent so that the two-step DPP shift
                                   // writes in place (every lane is overwritten each row)
@@ -228,7 +238,7 @@ __device__ __forceinline__ void pair_body(
     U[k] = V[k] = X[k] = Y[k] = 0u;
     S[k] = z_wild;
     Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
-    Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[64 * k + lane], 0x0c010c00u);
+    load_target(k, (unsigned)Tb[64 * k + lane]);
   }
   // TRACK: exact H of the lane's cell of task A per register, and the best (H, row) the lane has seen
   int32_t Hc[TRACK ? NREG : 1], bestH[TRACK ? NREG : 1], bestR[TRACK ? NREG : 1];
@@ -403,7 +413,7 @@ __device__ __forceinline__ void pair_body(
         if (b_ > 0 && a_ < 64) {
           const unsigned qc = W[cq - we0 + 64 * k + lane];
           unsigned z;
-          SDF_PFRESH(z, Tc[k], qc, has_n)
+          SDF_PFRESH(z, k, qc, has_n)
           if (a_ <= 0 && b_ >= 64) S[k] = z;
           else if (lane_in(lane, a_ < 0 ? 0 : a_, b_)) S[k] = z;
         }
@@ -506,14 +516,14 @@ __device__ __forceinline__ void pair_body(
         const int b_ = rbe - 64 * k;
         if (STEADY) {
           unsigned z;
-          SDF_PFRESH(z, Tc[k], qcur[k], HASN)
+          SDF_PFRESH(z, k, qcur[k], HASN)
           if (NREG == 1) S[0] = in_mask(lane_mask(ra, b_)) ? z : S[0];
           else if (k == 0) S[0] = in_mask(~0ull << ra) ? z : S[0];  // (steady: 0 <= ra < 32 -- one scalar shift, not lane_mask's six)
           else if (k == KT) S[k] = in_mask(b_ <= 0 ? 0ull : ~0ull >> (64 - (b_ < 64 ? b_ : 64))) ? z : S[k];
           else S[k] = z;
         } else if (b_ > 0) {
           unsigned z;
-          SDF_PFRESH(z, Tc[k], qcur[k], HASN)
+          SDF_PFRESH(z, k, qcur[k], HASN)
           if (k == 0) {
             if (b_ >= 64) S[0] = lane >= ra ? z : S[0];
             else S[0] = lane_in(lane, ra, b_) ? z : S[0];
@@ -680,7 +690,7 @@ __device__ __forceinline__ void pair_body(
       else fill_query(0);
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[base - tt0 + 64 * k + lane], 0x0c010c00u);
+      for (int k = 0; k < NREG; ++k) load_target(k, (unsigned)Tb[base - tt0 + 64 * k + lane]);
     }
   }
   for (r0 = row_first; r0 < row_last && !ez_zdropped; r0 += 16) {
@@ -725,7 +735,7 @@ __device__ __forceinline__ void pair_body(
         }
 #pragma unroll
         for (int k = 0; k < NREG; ++k)
-          Tc[k] = __builtin_amdgcn_perm(0u, (unsigned)Tb[base - tt0 + 64 * k + lane], 0x0c010c00u);
+          load_target(k, (unsigned)Tb[base - tt0 + 64 * k + lane]);
         zero_low = false;
       }
       {  // reversed-query entries this block reads (rows r0 .. r0+16, the last one as a prefetch): resident?
