@@ -135,7 +135,9 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   const int q0 = qlen - 1 - r_z + T0 - 2;  // first entry any row of the stripe reads (minus the fetch-ahead)
   uint16_t *W = reinterpret_cast<uint16_t *>(lds);
   bool has_n;
-  unsigned Tc[NREG];
+  unsigned TA[NREG], TB[NREG];  // score tables of the lane's two target positions per register
+  const unsigned t_mis4 = (unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) * 0x01010101u, t_wild4 = (unsigned)sc.qe2_b * 0x01010101u;
+  const unsigned t_delta = (unsigned)((sc.sc_match + sc.qe2_b) & 0xff) ^ (unsigned)((sc.sc_mis + sc.qe2_b) & 0xff);
   {
     const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen + 15) / 16;
     const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
@@ -146,9 +148,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
       uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
       uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
       n_seen |= (v0 | v1) >> 8;
-      v0 = (v0 & 0x7fu) | ((v0 >> 8) & 0x80u);
-      v1 = (v1 & 0x7fu) | ((v1 >> 8) & 0x80u);
-      W[i] = (uint16_t)(v0 | (v1 << 8));
+      W[i] = qsel_pair(v0, v1);  // (selector form: extz2_wave.hip, SDF_SCORE2)
     }
 #pragma unroll
     for (int k = 0; k < NREG; ++k) {
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
       const uint32_t c0 = t < tlen ? pool_code16(tw, tn, t, sc.wild) : 0u;
       const uint32_t c1 = t + 1 < tlen ? pool_code16(tw, tn, t + 1, sc.wild) : 0u;
       n_seen |= (c0 | c1) >> 8;
-      Tc[k] = c0 | (c1 << 16);
+      TA[k] = score_table(c0, t_mis4, t_delta, t_wild4);
+      TB[k] = score_table(c1, t_mis4, t_delta, t_wild4);
     }
     has_n = __builtin_amdgcn_readfirstlane((int)__any(n_seen != 0)) != 0;  // wave-uniform
   }
@@ -165,14 +166,9 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
   // ---- constants of the <<8 difference domain ----
   const unsigned qv = ((unsigned)sc.q_b << 8) * 0x00010001u;
   const unsigned capv = ((unsigned)sc.cap_b << 8) * 0x00010001u;
-  const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
-  const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
-  const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
   const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0
   unsigned one2 = 0x00010001u;
   SDF_OPQ(one2);
-  unsigned z_match_v = z_match;
-  SDF_OPQ(z_match_v);
 
   unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG];
   unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
@@ -291,7 +287,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         for (; r < re; ++r) {
           unsigned qc[NREG];
 #pragma unroll
-          for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+          for (int k = 0; k < NREG; ++k) qc[k] = qsel_spread(qnext[k]);
           qaddr -= 2;
           asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
 #pragma unroll
@@ -316,11 +312,11 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
             vt1[k] = __builtin_amdgcn_perm(V[k], ps, 0x05040302u);
           }
 #pragma unroll
-          for (int k = 0; k < NREG; ++k) S[k] = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
-          if (has_n) {
+          for (int k = 0; k < NREG; ++k) SDF_SCORE2(S[k], k, qc[k], false)
+          if (has_n) {  // (an N in the query: the selector picked 0xff)
 #pragma unroll
             for (int k = 0; k < NREG; ++k) {
-              unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
+              unsigned nn = pk_ashr15(S[k]);
               SDF_OPQ(nn);
               S[k] = (z_wild & nn) | (S[k] & ~nn);
             }
@@ -429,7 +425,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
           const unsigned span = (unsigned)__builtin_amdgcn_readlane(t_span, ri);
           unsigned qc[NREG];
 #pragma unroll
-          for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+          for (int k = 0; k < NREG; ++k) qc[k] = qsel_spread(qnext[k]);
           qaddr -= 2;
           asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
 #pragma unroll
@@ -488,12 +484,8 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
               xt1[k] &= keep;
               vt1[k] &= keep;
             }
-            unsigned z = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
-            if (has_n) {
-              unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
-              SDF_OPQ(nn);
-              z = (z_wild & nn) | (z & ~nn);
-            }
+            unsigned z;
+            SDF_SCORE2(z, k, qc[k], has_n)
             if (TOP) {
               sel_lo_below(S[k], z, b1 - 64 * k, lane);
               sel_hi_below(S[k], z, b0 - 64 * k, lane);
@@ -613,7 +605,7 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
       const int prev_lo = r > 0 ? bp.lo : -1;
       unsigned qc[NREG];
 #pragma unroll
-      for (int k = 0; k < NREG; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+      for (int k = 0; k < NREG; ++k) qc[k] = qsel_spread(qnext[k]);
       qaddr -= 2;
       asm volatile("" : "+v"(qaddr) : "v"(qc[0]), "v"(qc[KT]));
 #pragma unroll
@@ -697,12 +689,8 @@ __global__ __launch_bounds__(64, 2) void extz2_bstripe_kernel(const PlanTask *__
         }
         // scores: refreshed in 16-cell strides from lo0 (:124-138)
         {
-          unsigned z = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
-          if (has_n) {
-            unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
-            SDF_OPQ(nn);
-            z = (z_wild & nn) | (z & ~nn);
-          }
+          unsigned z;
+          SDF_SCORE2(z, k, qc[k], has_n)
           const int ra = lo0 - tb, rbe = ra + ((hi0 - lo0) & ~15) + 16;
           sel_lo_rng(S[k], z, (ra + 1) >> 1, (rbe + 1) >> 1, lane);
           sel_hi_rng(S[k], z, ra >> 1, rbe >> 1, lane);

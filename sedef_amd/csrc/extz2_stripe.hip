@@ -170,7 +170,9 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   // (0 outside): lane l of register k reads entry qlen - 1 - r + NSLOT + 128 k + 2 l on row r ----
   uint16_t *W = reinterpret_cast<uint16_t *>(lds);
   bool has_n;
-  unsigned Tc[NREG];
+  unsigned TA[NREG], TB[NREG];  // score tables of the lane's two target positions per register
+  const unsigned t_mis4 = (unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) * 0x01010101u, t_wild4 = (unsigned)sc.qe2_b * 0x01010101u;
+  const unsigned t_delta = (unsigned)((sc.sc_match + sc.qe2_b) & 0xff) ^ (unsigned)((sc.sc_mis + sc.qe2_b) & 0xff);
   {
     const uint32_t *tw = pool + tk.t_word, *tn = tw + (tlen_all + 15) / 16;
     const uint32_t *qw = pool + tk.q_word, *qn = qw + (qlen + 15) / 16;
@@ -183,16 +185,15 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
       const int e0 = i - NSLOT, e1 = e0 + 1;
       uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
       uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
-      v0 = (v0 & 0x7fu) | ((v0 >> 8) & 0x80u);
-      v1 = (v1 & 0x7fu) | ((v1 >> 8) & 0x80u);
-      W[i] = (uint16_t)(v0 | (v1 << 8));
+      W[i] = qsel_pair(v0, v1);  // (selector form: extz2_wave.hip, SDF_SCORE2)
     }
 #pragma unroll
     for (int k = 0; k < NREG; ++k) {
       const int t = 128 * k + 2 * lane;
       const uint32_t c0 = t < tlen ? pool_code16(tw, tn, T0 + t, sc.wild) : 0u;
       const uint32_t c1 = t + 1 < tlen ? pool_code16(tw, tn, T0 + t + 1, sc.wild) : 0u;
-      Tc[k] = c0 | (c1 << 16);
+      TA[k] = score_table(c0, t_mis4, t_delta, t_wild4);
+      TB[k] = score_table(c1, t_mis4, t_delta, t_wild4);
     }
   }
   __syncthreads();
@@ -200,14 +201,9 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
   // ---- constants of the <<8 difference domain ----
   const unsigned qv = ((unsigned)sc.q_b << 8) * 0x00010001u;
   const unsigned capv = ((unsigned)sc.cap_b << 8) * 0x00010001u;
-  const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
-  const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
-  const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
   const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0
   unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16
   SDF_OPQ(one2);
-  unsigned z_match_v = z_match;  // kept in a VGPR: v_pk_mad_u16 takes one scalar operand only
-  SDF_OPQ(z_match_v);
 
   unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG];
   unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
@@ -298,7 +294,7 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
       // covering a fetch issued just before it (the empty asm ties the address to the consumed values)
       unsigned qc[NREG];
 #pragma unroll
-      for (int k = KLO; k <= KHI; ++k) qc[k] = __builtin_amdgcn_perm(0u, qnext[k], 0x0c010c00u);
+      for (int k = KLO; k <= KHI; ++k) qc[k] = qsel_spread(qnext[k]);
       qaddr -= 2;
       asm volatile("" : "+v"(qaddr) : "v"(qc[KLO]), "v"(qc[KHI]));
 #pragma unroll
@@ -342,11 +338,11 @@ __global__ __launch_bounds__(64, 2) void extz2_stripe_kernel(const PlanTask *__r
       }
       // scores of the row's cells
 #pragma unroll
-      for (int k = KLO; k <= KHI; ++k) S[k] = pk_mad(pk_nonzero(Tc[k] ^ qc[k]), z_delta, z_match_v);
-      if (has_n) {
+      for (int k = KLO; k <= KHI; ++k) SDF_SCORE2(S[k], k, qc[k], false)
+      if (has_n) {  // (an N in the query: the selector picked 0xff)
 #pragma unroll
         for (int k = KLO; k <= KHI; ++k) {
-          unsigned nn = pk_ashr15(Tc[k] | pk_shl(qc[k], 8));
+          unsigned nn = pk_ashr15(S[k]);
           SDF_OPQ(nn);
           S[k] = (z_wild & nn) | (S[k] & ~nn);
         }

@@ -188,6 +188,33 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
   return n ? (0xff00u | wild) : c;
 }
 
+// ---- fresh scores as byte permutes (end of round 6; extz2_pair.hip: SDF_PFRESH has the story) ----------------------------
+// The kernels whose lanes hold TWO ADJACENT target positions per register (wave, stripe, banded stripe): a table of four score
+// bytes per position -- against query base 0..3; an N in the target: the wildcard's score four times --, the row's two query
+// bases as a selector (byte 1 = base of the even position: a byte of the first table; byte 3 = 4 + base of the odd one: a byte
+// of the second; bytes 0, 2 = 0x0c: zero; an N: 0xff, patched afterwards where the sequences hold any N).
+// code: what pool_code16 returns (0..3, N: 0xff00 | wild)
+__device__ __forceinline__ unsigned score_table(const unsigned code, const unsigned mis4, const unsigned delta, const unsigned wild4) {
+  return (code & 0xff00u) ? wild4 : mis4 ^ (delta << (8u * code));
+}
+// an entry of a query window of byte pairs (W[i] = bases of window positions i, i + 1) in selector form
+__device__ __forceinline__ uint16_t qsel_pair(const uint32_t v0, const uint32_t v1) {
+  return (uint16_t)(((v0 & 0xff00u) ? 0xffu : v0) | (((v1 & 0xff00u) ? 0xffu : v1 + 4u) << 8));
+}
+// the two selector bytes of a window entry -> the permute's selector 0x0c, s0, 0x0c, s1
+__device__ __forceinline__ unsigned qsel_spread(const unsigned w16) {
+  return __builtin_amdgcn_perm(0x0c0c0c0cu, w16, 0x01040004u);
+}
+#define SDF_SCORE2(z, k, qs, WITH_N)                                    \
+  {                                                                     \
+    z = __builtin_amdgcn_perm(TB[k], TA[k], (qs));                      \
+    if (WITH_N) {                                                       \
+      unsigned nn_ = pk_ashr15(z);                                      \
+      SDF_OPQ(nn_);                                                     \
+      z = (z_wild & nn_) | (z & ~nn_);                                  \
+    }                                                                   \
+  }
+
 // One anti-diagonal step of the recurrence for packed register k (two cells per lane), in the
 // <<8 int16 domain; appends the four direction flags to the accumulators.
 // Round 5: three of its differences are 32-bit subtracts (v_sub_u32: ~2.3 cycles against ~4.2 for v_pk_sub_i16,
@@ -224,19 +251,8 @@ __device__ __forceinline__ uint32_t pool_code16(const uint32_t *codes, const uin
     Fy[k] = shl1_or(Fy[k], pk_nonzero(yn_));                            \
   }
 
-// fresh (score + 2(q+e)) << 8 of the two cells of a lane from their target / query codes
-#define SDF_FRESH(z, tc, qraw)                                          \
-  {                                                                     \
-    const unsigned qc_ = __builtin_amdgcn_perm(0u, (qraw), 0x0c010c00u); /* bytes -> halves */ \
-    const unsigned d_ = (tc) ^ qc_; /* != 0 <=> the codes differ */     \
-    const unsigned m_ = pk_nonzero(d_);                                 \
-    z = pk_mad(m_, z_delta, z_match_v);                                 \
-    if (has_n) {                                                        \
-      unsigned nn_ = pk_ashr15((tc) | pk_shl(qc_, 8));                  \
-      SDF_OPQ(nn_);                                                     \
-      z = (z_wild & nn_) | (z & ~nn_);                                  \
-    }                                                                   \
-  }
+// fresh (score + 2(q+e)) << 8 of the two cells of a lane: two byte permutes (the window entry -> selector, selector -> scores)
+#define SDF_FRESH(z, k, qraw) SDF_SCORE2(z, k, qsel_spread(qraw), has_n)
 
 // entries of the LDS sequence windows: the whole (padded) sequence when it is short, else the window slots plus
 // 1024 entries of slack (see extz2_pair.hip)
@@ -296,9 +312,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 :
       const int e0 = from + i - 32, e1 = e0 + 1;  // QR indices; QR[e] = query[qlen-1-e], 0 outside
       uint32_t v0 = (e0 >= 0 && e0 < qlen) ? pool_code16(qw, qn, qlen - 1 - e0, sc.wild) : 0u;
       uint32_t v1 = (e1 >= 0 && e1 < qlen) ? pool_code16(qw, qn, qlen - 1 - e1, sc.wild) : 0u;
-      v0 = (v0 & 0x7fu) | ((v0 >> 8) & 0x80u);
-      v1 = (v1 & 0x7fu) | ((v1 >> 8) & 0x80u);
-      W[i] = (uint16_t)(v0 | (v1 << 8));
+      W[i] = qsel_pair(v0, v1);  // (selector form: SDF_SCORE2)
     }
   };
 
@@ -319,23 +333,25 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 :
   // ---- constants of the <<8 difference domain ----
   const unsigned qv = ((unsigned)sc.q_b << 8) * 0x00010001u;
   const unsigned capv = ((unsigned)sc.cap_b << 8) * 0x00010001u;
-  const unsigned z_match = ((unsigned)((sc.sc_match + sc.qe2_b) & 0xff) << 8) * 0x00010001u;
-  const unsigned z_mis_h = ((unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) << 8);
-  const unsigned z_delta = ((z_mis_h - (z_match & 0xffffu)) & 0xffffu) * 0x00010001u;
+  const unsigned t_mis4 = (unsigned)((sc.sc_mis + sc.qe2_b) & 0xff) * 0x01010101u, t_wild4 = (unsigned)sc.qe2_b * 0x01010101u;
+  const unsigned t_delta = (unsigned)((sc.sc_match + sc.qe2_b) & 0xff) ^ (unsigned)((sc.sc_mis + sc.qe2_b) & 0xff);
   const unsigned z_wild = ((unsigned)sc.qe2_b << 8) * 0x00010001u;  // score 0, also "never written"
   unsigned one2 = 0x00010001u;  // min(x, 1) per half; opaque so that it stays one v_pk_min_u16
   SDF_OPQ(one2);
-  unsigned z_match_v = z_match;  // kept in a VGPR: v_pk_mad_u16 takes one scalar operand only
-  SDF_OPQ(z_match_v);
 
-  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], Tc[NREG];
+  unsigned U[NREG], V[NREG], X[NREG], Y[NREG], S[NREG], TA[NREG], TB[NREG];
+  // the score tables of the lane's two slots of register k from their entries of the target window (two 16-bit codes)
+  auto load_target = [&](const int k, const uint32_t two) {
+    TA[k] = score_table(two & 0xffffu, t_mis4, t_delta, t_wild4);
+    TB[k] = score_table(two >> 16, t_mis4, t_delta, t_wild4);
+  };
   unsigned Fa[NREG], Fb[NREG], Fx[NREG], Fy[NREG];
 #pragma unroll
   for (int k = 0; k < NREG; ++k) {
     U[k] = V[k] = X[k] = Y[k] = 0u;
     S[k] = z_wild;
     Fa[k] = Fb[k] = Fx[k] = Fy[k] = 0u;
-    Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + 128 * k + 2 * lane);
+    load_target(k, *reinterpret_cast<const uint32_t *>(Tb + 128 * k + 2 * lane));
   }
 
   const bool with_dir = !(tk.flag & SDF_FLAG_SCORE_ONLY);
@@ -459,7 +475,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 :
         if (b_ > 0 && a_ < 128) {
           const unsigned qc = W[cq - we0 + 128 * k + 2 * lane];  // zero-extended byte pair
           unsigned z;
-          SDF_FRESH(z, Tc[k], qc)
+          SDF_FRESH(z, k, qc)
           if (a_ <= 0 && b_ >= 128) {
             S[k] = z;
           } else {
@@ -599,7 +615,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 :
         const int b_ = rbe - 128 * k;
         if (STEADY) {
           unsigned z;
-          SDF_FRESH(z, Tc[k], qcur[k])
+          SDF_FRESH(z, k, qcur[k])
           if (NREG == 1) {
             sel_lo_rng(S[0], z, (ra + 1) >> 1, (b_ + 1) >> 1, lane);
             sel_hi_rng(S[0], z, ra >> 1, b_ >> 1, lane);
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 :
           }
         } else if (b_ > 0) {
           unsigned z;
-          SDF_FRESH(z, Tc[k], qcur[k])
+          SDF_FRESH(z, k, qcur[k])
           if (k == 0) {
             if (b_ >= 128) {
               sel2_ge(S[0], z, (ra + 1) >> 1, ra >> 1, lane);
@@ -745,7 +761,7 @@ __global__ __launch_bounds__(64, NREG <= 2 ? 6 : NREG <= 4 ? 4 : NREG <= 6 ? 3 :
         }
 #pragma unroll
         for (int k = 0; k < NREG; ++k)
-          Tc[k] = *reinterpret_cast<const uint32_t *>(Tb + (base - tt0) + 128 * k + 2 * lane);
+          load_target(k, *reinterpret_cast<const uint32_t *>(Tb + (base - tt0) + 128 * k + 2 * lane));
         zero_low = false;
       }
       if (STREAM) {  // reversed-query entries this block reads (rows r0 .. r0+16, the last as a prefetch): resident?
