@@ -949,11 +949,13 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "binding_limit": ({"bound": "valu_issue", "frac": valu["frac_of_issue_peak_4p2cyc_measured_vop3p"],
                                             "how": "counted wavefront VALU instructions of the launch x 4.2 cycles (the measured "
-                                                   "issue cost of the packed / VOP3 / DPP encodings that make up 87 % of the row) "
+                                                   "issue cost of the packed / VOP3 / DPP encodings that make up 89 % of the row) "
                                                    "over SIMDs x clock x the launch's live-measured duration; 1.0 = every issue "
                                                    "slot of every SIMD taken",
-                                            "hbm_frac_is": "0.16 of the HBM peak because the kernel is bound elsewhere: its HBM "
-                                                           "traffic (`traffic`) is 0.93 x the algorithmic bytes, nothing is re-read"}
+                                            "hbm_frac_is": "%.2f of the HBM peak because the kernel is bound elsewhere: its HBM "
+                                                           "traffic (`traffic`) is %.2f x the algorithmic bytes, nothing is re-read "
+                                                           "(what exceeds 1.0 is register spills at the starts of 16-row blocks)"
+                                                           % (achieved / HBM_PEAK_GBS, (traffic or 0) / max(bytes_per_launch, 1))}
                                            if valu else {"bound": "valu_issue", "frac": None,
                                                          "how": "no committed counters for this workload / kernel source (see "
                                                                 "traffic_source); the DP kernels of this path are VALU-issue "
