@@ -864,6 +864,7 @@ def main():
                 cycles = simds * mhz * 1e6 * avg_launch_s * iso_launches
                 valu = {"insts_per_step": pmc["valu_insts_per_step"], "simds": simds, "clock_mhz": round(mhz, 1),
                         "frac_of_issue_peak_2cyc": round(pmc["valu_insts_per_step"] / (cycles / 2.0), 4),
+                        "frac_of_issue_peak_4cyc": round(pmc["valu_insts_per_step"] / (cycles / 4.0), 4),
                         "frac_of_issue_peak_4p2cyc_measured_vop3p": round(pmc["valu_insts_per_step"] / (cycles / 4.2), 4),
                         "steady_row_by_encoding": encoding_split(),
                         "source": "committed profile: " + str(pmc.get("valu_source"))}
@@ -947,11 +948,14 @@ def main():
             # ALUs' issue slots, from the launch's counted VALU instructions at the measured issue cost of their encodings.
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "binding_limit": ({"bound": "valu_issue", "frac": valu["frac_of_issue_peak_4p2cyc_measured_vop3p"],
-                                            "how": "counted wavefront VALU instructions of the launch x 4.2 cycles (the measured "
-                                                   "issue cost of the packed / VOP3 / DPP encodings that make up 89 % of the row) "
-                                                   "over SIMDs x clock x the launch's live-measured duration; 1.0 = every issue "
-                                                   "slot of every SIMD taken",
+                         "binding_limit": ({"bound": "valu_issue", "frac": valu["frac_of_issue_peak_4cyc"],
+                                            "how": "counted wavefront VALU instructions of the launch x 4 cycles (a wave64 vector "
+                                                   "instruction holds its SIMD's ALU for four cycles: the rate every DP launch "
+                                                   "of this library that fills the device was measured at, profiles/"
+                                                   "r06_chain_pmc.txt; a lone stream of packed / VOP3 / DPP encodings was "
+                                                   "measured at 4.2, valu_issue.frac_of_issue_peak_4p2cyc_measured_vop3p) over "
+                                                   "SIMDs x nominal clock x the launch's live-measured duration; 1.0 = every "
+                                                   "issue slot of every SIMD taken",
                                             "hbm_frac_is": "%.2f of the HBM peak because the kernel is bound elsewhere: its HBM "
                                                            "traffic (`traffic`) is %.2f x the algorithmic bytes, nothing is re-read "
                                                            "(what exceeds 1.0 is register spills at the starts of 16-row blocks)"
