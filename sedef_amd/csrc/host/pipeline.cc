@@ -951,6 +951,7 @@ StageSettings StageSettings::from_env() {
   if (const char *e = getenv("SDF_STAGE_WS_GIB")) s.stage_ws_gib = atof(e) > 0 ? atof(e) : 0;
   s.debug_timing = getenv("SDF_DEBUG_TIMING") != nullptr;
   s.resident_dp = num("SDF_RESIDENT_DP", 0, 1, 1) != 0;
+  s.anchor_parts = (int)num("SDF_ANCHOR_PARTS", 0, 16, 0);
   s.bucket_lanes = (int)num("SDF_BUCKET_LANES", 1, 4, 2);
   if (const char *e = getenv("SDF_DEVICES"))
     for (const char *c = e; *c;) {
@@ -1211,10 +1212,12 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
     a.t_fetch += since(tf);
     dp.pool_ready(slot[2 * (size_t)n]);  // (the whole pool to the device, asynchronously)
     mark(base, "sequences fetched");
-    // Seed anchors on the device, when the provider offers it -- in TWO halves of about equal bytes: while the device finds the
-    // anchors of the second half, the host threads chain the first (a pair's first advance(): src/chain.cc:203-258 up to the
-    // requests of its round-A stitch), which is the longest host phase of a super-batch (20 of 85 ms in the chr1-sized run).
-    DpProvider::AnchorBatch seeds, seeds2;  // (live until the jobs have taken their copies: their first advance)
+    // Seed anchors on the device, when the provider offers it -- in PARTS of about equal bytes (two from 16 MB of sequences,
+    // four from 64 MB): while the device finds the anchors of part i + 1, the host threads chain part i (a pair's first
+    // advance(): src/chain.cc:203-258 up to the requests of its round-A stitch), which is the longest host phase of a
+    // super-batch (20 of 85 ms in the chr1-sized run).  Every part's anchors are appended behind those of the parts before
+    // it in the provider's staging (anchors_more), which stay valid until their jobs have taken their copies.
+    std::vector<DpProvider::AnchorBatch> seeds;  // (live until the jobs have taken their copies: their first advance)
     std::vector<int64_t> q_base((size_t)n, 0), r_base((size_t)n, 0);
     bool resident = false;
     std::vector<char> advanced((size_t)n, 0);  // pairs whose first advance() has run (their requests wait in `pending`)
@@ -1226,13 +1229,26 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
         aj[k] = {items[k].fa, items[k].fb, h.query->name == h.ref->name && h.query->is_rc == h.ref->is_rc,
                  h.ref_start - h.query_start};
       }
-      int n1 = n;
       // (only where the sequences lie in the PROVIDER's pool: a provider that copies them replaces its pool with every call)
-      if (provider_pool && n >= 64 && slot[2 * (size_t)n] >= ((size_t)16 << 20)) {  // (small super-batches: one call)
-        n1 = 0;
-        while (n1 < n && slot[2 * (size_t)n1] < slot[2 * (size_t)n] / 2) ++n1;
-        if (n1 < 16 || n - n1 < 16) n1 = n;
+      const size_t total = slot[2 * (size_t)n];
+      int parts = 1;
+      if (provider_pool && n >= 64 && total >= ((size_t)16 << 20)) parts = 2;  // (small super-batches: one call)
+      if (provider_pool && n >= 256 && total >= ((size_t)64 << 20)) parts = 4;
+      if (stage_settings().anchor_parts > 0 && provider_pool) parts = std::min(stage_settings().anchor_parts, std::max(n / 16, 1));
+      std::vector<int> cut((size_t)parts + 1, n);  // part i: pairs [cut[i], cut[i + 1])
+      cut[0] = 0;
+      for (int i = 1, k = 0; i < parts; i++) {
+        while (k < n && slot[2 * (size_t)k] < total / (size_t)parts * (size_t)i) ++k;
+        cut[(size_t)i] = k;
       }
+      for (int i = 0; i < parts; i++)
+        if (cut[(size_t)i + 1] - cut[(size_t)i] < 16) {  // (a part of a few pairs: one call for everything)
+          parts = 1;
+          cut.assign(2, n);
+          cut[0] = 0;
+          break;
+        }
+      seeds.resize((size_t)parts);
       auto first_advance = [&](int lo, int hi, const DpProvider::AnchorBatch &sd) {
         parallel_for(hi - lo, [&](int i) {
           const int k = lo + i;
@@ -1244,52 +1260,70 @@ GenerateStats generate_alignments(const std::string &ref_path, const std::string
           pre_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tj).count();
         });
       };
+      auto part_jobs = [&](int i) {
+        return std::vector<DpProvider::AnchorJob>(aj.begin() + cut[(size_t)i], aj.begin() + cut[(size_t)i + 1]);
+      };
       const auto ta = now();
-      const std::vector<DpProvider::AnchorJob> aj1(aj.begin(), aj.begin() + n1), aj2(aj.begin() + n1, aj.end());
-      if (dp.anchors(aj1, p.kmer, seeds)) {
-        resident = seeds.resident;
-        for (int k = 0; k < n1; k++) q_base[k] = resident ? seeds.q_base[k] : 0, r_base[k] = resident ? seeds.r_base[k] : 0;
-        if (n1 == n) {
-          for (int k = 0; k < n; k++)
-            items[k].job->set_anchors(seeds.data() + seeds.off[k], (size_t)(seeds.off[k + 1] - seeds.off[k]));
-        } else {
-          bool ok2 = false;
-          std::string err2;
-          std::thread second([&] {
-            try {
-              ok2 = dp.anchors_more(aj2, p.kmer, (size_t)seeds.off[n1], seeds2);
-            } catch (std::string &e) {
-              err2 = e.empty() ? std::string("error") : e;
-            }
-          });
-          struct Join {
-            std::thread &t;
-            ~Join() {
-              if (t.joinable()) t.join();
-            }
-          } join_second{second};
-          mark(base, "anchors of the first half done");
-          first_advance(0, n1, seeds);
-          second.join();
-          if (!err2.empty()) throw err2;
-          // (no room behind the first half's anchors, or a half the device does not cover: the ordinary call, now that the
-          // first half's jobs have taken their copies)
-          if (!ok2) ok2 = dp.anchors(aj2, p.kmer, seeds2);
-          if (ok2 && seeds2.resident == resident) {
-            for (int k = n1; k < n; k++)
-              q_base[k] = resident ? seeds2.q_base[k - n1] : 0, r_base[k] = resident ? seeds2.r_base[k - n1] : 0;
-            mark(base, "anchors done");
-            first_advance(n1, n, seeds2);
-          } else if (ok2) {  // (the two halves disagree about where the sequences are: the pointer form for everybody)
-            resident = false;
-            first_advance(n1, n, seeds2);
+      if (dp.anchors(part_jobs(0), p.kmer, seeds[0])) {
+        resident = seeds[0].resident;
+        auto take_bases = [&](int i) {
+          for (int k = cut[(size_t)i]; k < cut[(size_t)i + 1]; k++) {
+            q_base[k] = resident ? seeds[(size_t)i].q_base[k - cut[(size_t)i]] : 0;
+            r_base[k] = resident ? seeds[(size_t)i].r_base[k - cut[(size_t)i]] : 0;
           }
-          // (else: the second half's jobs find their anchors on the host, in their first advance below)
+        };
+        take_bases(0);
+        if (parts == 1) {
+          for (int k = 0; k < n; k++)
+            items[k].job->set_anchors(seeds[0].data() + seeds[0].off[k], (size_t)(seeds[0].off[k + 1] - seeds[0].off[k]));
+        } else {
+          size_t keep = (size_t)seeds[0].off[cut[1]];  // anchors in the staging so far
+          bool have = true;                            // part i's anchors are there
+          for (int i = 0; i < parts; i++) {
+            const bool more = i + 1 < parts;
+            bool ok_next = false;
+            std::string err_next;
+            std::vector<DpProvider::AnchorJob> next_jobs;
+            std::thread next;
+            if (more) {
+              next_jobs = part_jobs(i + 1);
+              next = std::thread([&] {
+                try {
+                  ok_next = dp.anchors_more(next_jobs, p.kmer, keep, seeds[(size_t)i + 1]);
+                } catch (std::string &e) {
+                  err_next = e.empty() ? std::string("error") : e;
+                }
+              });
+            }
+            struct Join {
+              std::thread &t;
+              ~Join() {
+                if (t.joinable()) t.join();
+              }
+            } join_next{next};
+            if (i == 0) mark(base, "anchors of the first part done");
+            // (a part without anchors from the device: its jobs find theirs on the host, in their first advance below)
+            if (have) first_advance(cut[(size_t)i], cut[(size_t)i + 1], seeds[(size_t)i]);
+            if (!more) break;
+            next.join();
+            if (!err_next.empty()) throw err_next;
+            // (no room behind the anchors of the parts before, or a part the device does not cover: the ordinary call, now
+            // that the earlier parts' jobs have taken their copies -- it starts the staging over)
+            bool fresh = false;
+            if (!ok_next) ok_next = fresh = dp.anchors(next_jobs, p.kmer, seeds[(size_t)i + 1]);
+            have = ok_next;
+            if (!ok_next) resident = false;  // (its pairs have no place in the resident pool the requests could name)
+            if (ok_next && seeds[(size_t)i + 1].resident != resident) resident = false;  // (the parts disagree about where the
+                                                                                        // sequences are: the pointer form for everybody)
+            if (ok_next && resident) take_bases(i + 1);
+            if (ok_next) keep = (fresh ? 0 : keep) + (size_t)seeds[(size_t)i + 1].off[cut[(size_t)i + 2] - cut[(size_t)i + 1]];
+          }
+          mark(base, "anchors done");
         }
         a.anchor_secs += since(ta);
       }
     }
-    mark(base, "anchors done, first halves chained");
+    mark(base, "anchors done, parts chained");
     // rounds: every unfinished job advances; all their DP requests go to the GPU as one batch.
     // Results of the previous round: Cigars per pair (provider without a raw form), or the raw device words
     // and each pair's first request in them -- then the pair's own thread builds (and later frees) its Cigars

@@ -457,6 +457,7 @@ struct StageSettings {
   int host_threads = 0;      // SDF_HOST_THREADS: threads of the per-pair host work (0: the CPUs the process may use, at most 64)
   double stage_ws_gib = 0;   // SDF_STAGE_WS_GIB: direction-flag workspace per lane (0: 8 GiB per process shared out)
   bool debug_timing = false; // SDF_DEBUG_TIMING: one line per phase of every super-batch
+  int anchor_parts = 0;      // SDF_ANCHOR_PARTS: parts a super-batch's seed anchors are found in, each under the chaining of the one before (0: by its size -- 1, 2 or 4)
   bool resident_dp = true;   // SDF_RESIDENT_DP=0: the DP rounds cut their bases out on the host again instead of naming ranges of the characters the anchors call left in HBM
   int bucket_lanes = 2;      // SDF_BUCKET_LANES: buckets of a several-bucket run in flight, each on a device context of its own (1: one after the other)
   static StageSettings from_env();
