@@ -169,6 +169,15 @@ def test_stage_scale_gpu_equals_cpu_and_committed_hash(host, oracle, big_genome,
                        text=True)
     assert r.returncode == 0 and "Finished" in r.stderr
     assert r.stdout == open(tmp_path / "gpu_bucket_0001.bed").read()
+    # ... whatever the driver's settings: the seed anchors in one call or in three parts under the chaining of the part before
+    # (round 6; by default a super-batch of this size takes them in one or two), the DP rounds on the resident characters or on
+    # bases cut out on the host again, three lanes
+    for env in ({"SDF_ANCHOR_PARTS": "1"}, {"SDF_ANCHOR_PARTS": "3"}, {"SDF_RESIDENT_DP": "0"},
+                {"SDF_ANCHOR_PARTS": "5", "SDF_LANES": "3", "SDF_SUPER_BATCH": "256"}):
+        r2 = subprocess.run([CLI, "align", "generate", "-k", "11", fa, str(out / "bucket_0001")], capture_output=True,
+                            text=True, env={**os.environ, **env})
+        assert r2.returncode == 0 and "Finished" in r2.stderr, (env, r2.stderr[-400:])
+        assert r2.stdout == r.stdout, env
 
 
 @pytest.mark.gpu
